@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X:
+   "train interactions/sec + eval users/sec (full-catalog top-K@20), 1/2/4/8 GPU".
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the training hot path (gather + dots + counterfactual
+branches + (B,B) BCE + gradients + TF-style dense Adam) over one batch of B
+synthetic (u, i+, i-) triples that already live in HBM.  Default workload =
+BASELINE.json configs[1]: Gowalla shapes, MACR-MF `rubibceboth`, d=64, B=4096,
+c=40 (the other configs are parity-test cases, selectable with --workload).
+`value` = training interactions/s of the whole job; the evaluator (full
+catalogue, train-masked, top-20, metrics) is timed in the same run and reported
+as `eval_users_per_s` with its own MFMA roofline.
+
+Multi-GPU: the training step of these configs fits one GPU and the
+(B,B) loss couples every pair of a batch, so N GPUs run N independent replicas
+("replicas only", no data-path collective, weak scaling); the evaluator shards
+the item catalogue across the ranks and exchanges per-shard top-K with one RCCL
+all-gather.
+
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant training
+kernel, HIP-event timed), `roofline_eval`, `kernels`, `cpu_baseline` (the CPU
+oracle = "port", timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="gowalla", choices=["addressa", "gowalla", "ml10m", "yelp2018"])
+    ap.add_argument("--train", default="rubibceboth", choices=["normalbce", "rubibceboth"])
+    ap.add_argument("--eval-reps", type=int, default=5)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pos", default="zipf", choices=["zipf", "uniform"], help="positive-item distribution (diagnostic)")
+    ap.add_argument("--no-eval", action="store_true", help="skip the evaluator leg (diagnostic)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(kernel, cfg, B):
+    """per-launch algorithmic HBM bytes of each kernel (fp32, int32)."""
+    d, rows = cfg["d"], cfg["n_users"] + cfg["n_items"]
+    if kernel == "adam_dense":
+        return 24 * d * rows                         # read+write theta,m,v of every row
+    if kernel == "pair_fwd":
+        return B * (12 * d + 12)                     # 3 rows + 3 indices read
+    if kernel in ("pair_bwd", "pair_normal"):
+        return B * (24 * d + 12)                     # 3 rows read + 3 gradient rows written + indices
+    return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from macr_amd import ops, sharding, synth
+    from macr_amd.evaluator import Evaluator
+
+    cfg = synth.WORKLOADS[args.workload]
+    B, d = cfg["batch"], cfg["d"]
+    kind = ops.LOSS_RUBIBCEBOTH if args.train == "rubibceboth" else ops.LOSS_NORMALBCE
+    gen = torch.Generator(device=dev).manual_seed(12345 + rank)
+    P = synth.xavier_table(cfg["n_users"], d, gen, dev)
+    Q = synth.xavier_table(cfg["n_items"], d, gen, dev)
+    w = synth.xavier_table(d, 1, gen, dev).reshape(-1)
+    wu = synth.xavier_table(d, 1, gen, dev).reshape(-1)
+    hyper = ops.make_hyper(cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
+    state = ops.MFState(P, Q, w, wu, hyper, B)
+    n_batches = min(args.steps + args.warmup, 256)
+    batches = synth.train_batches(n_batches, cfg["n_users"], cfg["n_items"], B, gen, dev, zipf=args.pos == "zipf")
+    loss_log = torch.zeros((n_batches, 3), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def run_steps(n, first):
+        for s in range(n):
+            k = (first + s) % n_batches
+            state.step(kind, batches[k, 0], batches[k, 1], batches[k, 2], loss_log[k])
+
+    # ------------------------------------------------------------- training: W warmup + exactly K timed steps
+    run_steps(args.warmup, 0)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps, args.warmup)
+    torch.cuda.synchronize(); barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+    losses = loss_log.cpu().numpy()
+    if not np.isfinite(losses[: min(n_batches, args.steps)]).all():
+        raise SystemExit("ERROR: loss is nan.")
+
+    # ------------------------------------------------------------- per-kernel HIP-event timing (same stream)
+    n_prof = 20
+    ops.timing_begin()
+    run_steps(n_prof, 0)
+    marks = ops.timing_end(max_n=n_prof * 8 + 8)
+    kernels = {}
+    for name, ms in marks:
+        k = kernels.setdefault(name, [0, 0.0])
+        k[0] += 1; k[1] += ms
+    kern_avg = {n: {"launches_per_step": c / n_prof, "avg_us": 1e3 * t / c} for n, (c, t) in kernels.items()}
+    step_kernel_us = sum(v["avg_us"] * v["launches_per_step"] for v in kern_avg.values())
+    pmc = {}
+    pmc_path = os.path.join(REPO, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+        except Exception:
+            pmc = {}
+    for n, v in kern_avg.items():
+        ab = algorithmic_bytes(n, cfg, B)
+        if ab:
+            v["algorithmic_bytes"] = ab
+            v["GBps"] = ab / (v["avg_us"] * 1e-6) / 1e9
+        if n == "bxb":
+            v["gevals_per_s"] = 2.0 * B * B / (v["avg_us"] * 1e-6) / 1e9   # fused-BCE element evaluations
+    hbm_kernels = [n for n in kern_avg if "GBps" in kern_avg[n]]
+    dom = max(hbm_kernels, key=lambda n: kern_avg[n]["avg_us"])
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": kern_avg[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": kern_avg[dom]["GBps"] / HBM_PEAK_GBS,
+                "traffic": pmc.get(args.workload, {}).get(dom), "avg_us": kern_avg[dom]["avg_us"],
+                "algorithmic_bytes": kern_avg[dom]["algorithmic_bytes"]}
+
+    # ------------------------------------------------------------- evaluator: full catalogue, masked, top-20 + metrics
+    users, mask_lists, gt_lists = synth.eval_problem(cfg, seed=777)       # same on every rank
+    ev = Evaluator(mask_lists, gt_lists, cfg["n_items"], dev)
+    uid = torch.from_numpy(users).to(dev)
+    Ks = [20]
+
+    def run_eval():
+        return ev.test_mf(ops.SCORE_RUBI_BOTH, state.P, uid, state.Q, Ks, state.w, state.wu, cfg["c"])
+    ret = run_eval()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.eval_reps):
+        ret = run_eval()
+    torch.cuda.synchronize(); barrier()
+    ev_elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    eval_users_per_s = len(users) * args.eval_reps / ev_elapsed
+    ops.timing_begin()
+    run_eval()
+    emarks = ops.timing_end()
+    ek = {}
+    for name, ms in emarks:
+        ek[name] = ek.get(name, 0.0) + ms
+    lo, hi = sharding.item_shard_range(cfg["n_items"], rank, world)
+    flops = 2.0 * len(users) * (hi - lo) * d
+    st_us = 1e3 * ek.get("score_topk", float("nan"))
+    roofline_eval = {"kernel": "score_topk", "bound": "mfma", "achieved": flops / (st_us * 1e-6) / 1e12,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "avg_us": st_us, "flops": flops,
+                     "traffic": pmc.get(args.workload, {}).get("score_topk"),
+                     "kernels_us": {k: 1e3 * v for k, v in ek.items()}}
+    roofline_eval["frac"] = roofline_eval["achieved"] / MFMA_F32_PEAK_TFLOPS
+
+    # ------------------------------------------------------------- CPU baseline: the oracle ("port") on the host cores
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        threads = os.cpu_count() or 1
+        Pc, Qc = P.cpu().numpy().copy(), Q.cpu().numpy().copy()
+        wc, wuc = w.cpu().numpy().copy(), wu.cpu().numpy().copy()
+        st = oracle.AdamState([Pc.shape, Qc.shape, (d,), (d,)])
+        hb = batches[:8].cpu().numpy()
+        oracle.mf_train_step(kind, hb[0, 0], hb[0, 1], hb[0, 2], Pc, Qc, wc, wuc, st, cfg["lr"], cfg["regs"],
+                             cfg["alpha"], cfg["beta"], B)
+        t0, n_cpu = time.perf_counter(), 0
+        while time.perf_counter() - t0 < args.cpu_seconds * 0.6 and n_cpu < 64:
+            k = (n_cpu + 1) % 8
+            oracle.mf_train_step(kind, hb[k, 0], hb[k, 1], hb[k, 2], Pc, Qc, wc, wuc, st, cfg["lr"], cfg["regs"],
+                                 cfg["alpha"], cfg["beta"], B)
+            n_cpu += 1
+        cpu_train = n_cpu * B / (time.perf_counter() - t0)
+        n_eval_cpu = min(256, len(users))
+        mptr, midx = oracle.csr_from_lists(mask_lists[:n_eval_cpu])
+        gptr, gidx = oracle.csr_from_lists(gt_lists[:n_eval_cpu])
+        t0 = time.perf_counter()
+        sig_i = oracle.branch_sigmoid(Qc, wc)
+        sig_u = oracle.branch_sigmoid(Pc[users[:n_eval_cpu]], wuc)
+        _, oi, oc = oracle.score_topk(oracle.SCORE_RUBI_BOTH, Pc[users[:n_eval_cpu]], Qc, 20, sig_u, sig_i, cfg["c"],
+                                      (mptr, midx))
+        oracle.metrics_mf(oi, oc, (gptr, gidx), Ks)
+        cpu_eval = n_eval_cpu / (time.perf_counter() - t0)
+        cpu = {"value": cpu_train, "unit": "interactions/s", "cores": threads, "kind": "port",
+               "sample": "%d training steps of the same workload (B=%d) on the CPU restatement of the reference "
+                         "path (oracle/macr_oracle.c, OpenMP); eval: %d of the %d query users"
+                         % (n_cpu, B, n_eval_cpu, len(users)),
+               "eval_users_per_s": cpu_eval}
+
+    if rank == 0:
+        out = {
+            "metric": "train interactions/sec + eval users/sec (full-catalog top-K@20)",
+            "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s-shape MACR-MF %s d=%d batch=%d c=%g (n_users=%d, n_items=%d); synthetic "
+                                   "Xavier tables, Zipf positives" % (args.workload, args.train, d, B, cfg["c"],
+                                                                      cfg["n_users"], cfg["n_items"]),
+                       "parallelism": "replicas x%d (train) / item-sharded x%d + RCCL all-gather (eval)" % (world, world),
+                       "global_batch": B * world},
+            "eval_users_per_s": eval_users_per_s, "eval_ms_per_pass": 1e3 * ev_elapsed / args.eval_reps,
+            "eval_users": len(users), "eval_metrics": {k: float(v[0]) for k, v in ret.items()},
+            "step_kernel_us": step_kernel_us, "kernels": kern_avg,
+            "roofline": roofline, "roofline_eval": roofline_eval, "cpu_baseline": cpu,
+            "last_losses": [float(x) for x in losses[(args.warmup + args.steps - 1) % n_batches]],
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

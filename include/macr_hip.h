@@ -1,0 +1,252 @@
+/* ============================================================================
+ * macr_hip.h -- C ABI of the MI355X (gfx950) hot path of MACR.
+ *
+ * libmacr_hip.so (built from macr_amd/csrc/ by hipcc) exports exactly the
+ * symbols declared here.  Conventions, for every entry point:
+ *   - extern "C", plain pointers and sizes, no C++/torch types;
+ *   - every pointer marked (dev) is device memory owned by the CALLER
+ *     (PyTorch tensors on the host side); the library never allocates, frees
+ *     or retains device memory and keeps no global state;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued on it and nothing synchronises the device;
+ *   - return value: MACR_OK (0) or a negative MACR_E_* code; on error nothing
+ *     has been enqueued and macr_last_error() describes the problem;
+ *   - fp32 row-major tensors, int32 indices (the reference's TF placeholders,
+ *     macr_mf/model.py:27-29);
+ *   - thread-compatible: concurrent calls are fine as long as they do not
+ *     share output or workspace buffers.
+ *
+ * Each entry point names the reference code it replaces (file:line relative to
+ * the weitianxin/MACR checkout).  The reference has one real C ABI on this
+ * path -- c_top_k_array_index / evaluate_foldout, declared in
+ * macr_lightgcn/evaluator/cpp/apt_evaluate_foldout.pyx:11-19 -- whose
+ * replacements are macr_topk_scores and macr_metrics_foldout; everything else
+ * replaces a `sess.run` of TF-1.14 stock ops.
+ * ==========================================================================*/
+#ifndef MACR_HIP_H
+#define MACR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MACR_OK              0
+#define MACR_E_INVALID      -1   /* bad argument (null pointer, negative size, ...)            */
+#define MACR_E_UNSUPPORTED  -2   /* valid request this build has no kernel for (dim, K)         */
+#define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
+#define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
+
+#define MACR_ABI_VERSION     1
+
+/* loss kinds */
+#define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
+#define MACR_LOSS_RUBIBCEBOTH 1  /* --train rubibceboth macr_mf/model.py:185-222 ; --loss bceboth LightGCN.py:495-532 */
+
+/* score kinds */
+#define MACR_SCORE_NORMAL    0   /* batch_ratings      macr_mf/model.py:45  ; LightGCN.py:166 */
+#define MACR_SCORE_RUBI_BOTH 1   /* rubi_ratings_both  macr_mf/model.py:199 ; LightGCN.py:509 */
+
+/* largest K the top-K kernels are built for (the reference uses 20; parser default max 30) */
+#define MACR_MAX_TOPK 32
+
+int         macr_abi_version(void);
+const char *macr_last_error(void);          /* thread-local, valid until the next call     */
+const char *macr_build_info(void);          /* "gfx950 hipcc <ver> ..."                    */
+
+/* Optional per-kernel timing for benchmarks (per host thread).  Between
+ * macr_timing_begin(stream) and macr_timing_end(), every kernel the library
+ * launches on that stream is followed by a hipEvent; macr_timing_end waits for
+ * the last one and returns how many (name, milliseconds) pairs it wrote
+ * (names: max_n x 32 chars).  Not capturable into a hipGraph while active. */
+int macr_timing_begin(void *stream);
+int macr_timing_end(int max_n, char *names, float *ms);
+
+/* Hyper-parameters of one training step (all by value, host side). */
+typedef struct macr_hyper {
+    float lr;              /* --lr                                                   */
+    float beta1, beta2;    /* Adam 0.9 / 0.999  (tf.train.AdamOptimizer defaults)    */
+    float adam_eps;        /* 1e-8                                                   */
+    float decay;           /* --regs   (macr_mf/model.py:19 ; LightGCN.py:50)        */
+    float alpha, beta;     /* --alpha --beta (item / user branch weights)            */
+    int32_t batch_size_cfg;/* args.batch_size: divisor of the regulariser (:220)     */
+} macr_hyper;
+
+/* ---------------------------------------------------------------------------
+ * Training step, matrix factorisation.
+ * Replaces  sess.run([opt_X, loss_X, mf_loss_X, reg_loss_X], feed{users,pos,neg})
+ * (macr_mf/train.py:487-496) i.e. gathers (model.py:35-37), loss (:185-222 or
+ * :277-287), gradients, IndexedSlices de-duplication and tf.train.AdamOptimizer
+ * (:74/:95) -- dense Adam semantics, see SURVEY.md A.2.
+ *
+ *   u,i,j      (dev) int32[B]     sampled users / positive / negative items
+ *   P,Q        (dev) fp32[n_users*d], fp32[n_items*d]  updated in place
+ *   w,wu       (dev) fp32[d]      item / user branch vectors (rubibceboth only)
+ *   m*,v*      (dev) Adam slots, same shapes, updated in place
+ *   gP,gQ      (dev) fp32 same shape as P,Q: dense gradient scratch that MUST be
+ *              all-zero on entry and is all-zero again on return (rows touched
+ *              by the batch are consumed and re-zeroed by the Adam kernel)
+ *   touchedP,Q (dev) int32[n_users], int32[n_items]: same zero-in / zero-out rule
+ *   adam_pow   (dev) fp32[2] = {beta1^t, beta2^t} for the step about to run
+ *              (initialise to {beta1, beta2}); advanced on device
+ *   losses     (dev) fp32[3] = {loss, mf_loss, reg_loss} of this step
+ *   workspace  (dev) >= macr_mf_train_workspace_bytes(B, d) bytes, 256-B aligned
+ *
+ * d must be 32, 64, 128 or 256.  B >= 1.  No host synchronisation; safe to
+ * capture into a hipGraph.
+ * -------------------------------------------------------------------------*/
+size_t macr_mf_train_workspace_bytes(int B, int d);
+
+int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items,
+                       const int32_t *u, const int32_t *i, const int32_t *j,
+                       float *P, float *Q, float *w, float *wu,
+                       float *mP, float *vP, float *mQ, float *vQ,
+                       float *mw, float *vw, float *mwu, float *vwu,
+                       float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                       float *adam_pow, const macr_hyper *hp,
+                       float *losses, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * LightGCN propagation  E = mean(E0, A E0, ..., A^L E0)   (L = n_layers)
+ * Replaces _create_lightgcn_embed (macr_lightgcn/LightGCN.py:288-309): the
+ * 100-fold tf.sparse_tensor_dense_matmul loop (:297-305) + stack/reduce_mean
+ * (:306-307).  A is the `pre` adjacency D^-1/2 A D^-1/2 in CSR
+ * (utility/load_data.py:112-121), N = n_users + n_items rows.
+ *   rowptr (dev) int32[N+1], col (dev) int32[nnz], val (dev) fp32[nnz]
+ *   E0 (dev) fp32[N*d] in, E (dev) fp32[N*d] out
+ *   work (dev) fp32[2*N*d] scratch
+ * The same call is the backward pass (A symmetric): feed dE, get dE0.
+ * -------------------------------------------------------------------------*/
+int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col,
+                        const float *val, const float *E0, float *E, float *work, void *stream);
+
+/* One LightGCN training step.  Replaces sess.run([opt_X, loss_X, mf_loss_X,
+ * emb_loss_X, reg_loss_X]) of macr_lightgcn/LightGCN.py:598-607: propagation,
+ * gathers on the propagated table (:145-150), loss (:415-429 or :495-532) with
+ * the regulariser on the ego rows (:525-527), dense gradients through the
+ * propagation, Adam (:186 / :201).
+ *   T (dev) fp32[N*d] = [user_embedding ; item_embedding], updated in place
+ *   mT,vT Adam slots;  work (dev) >= macr_lgcn_train_workspace_bytes(B,N,d) bytes
+ *   losses (dev) fp32[3] = {loss, mf_loss, emb_loss}
+ * -------------------------------------------------------------------------*/
+size_t macr_lgcn_train_workspace_bytes(int B, int N, int d);
+
+int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
+                         const int32_t *rowptr, const int32_t *col, const float *val,
+                         const int32_t *u, const int32_t *i, const int32_t *j,
+                         float *T, float *w, float *wu, float *mT, float *vT,
+                         float *mw, float *vw, float *mwu, float *vwu,
+                         float *adam_pow, const macr_hyper *hp,
+                         float *losses, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * out[r] = sigmoid(rows[r] . w)   -- the test-time branch factors
+ * tf.nn.sigmoid(tf.matmul(e, w)) of macr_mf/model.py:194-196,:199.
+ * idx (dev, may be NULL) selects rows: out[r] = sigmoid(rows[idx[r]] . w).
+ * -------------------------------------------------------------------------*/
+int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, const float *w,
+                        float *out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused full-catalogue scoring + train-item masking + top-K: never
+ * materialises the (U,N) score matrix.
+ * Replaces sess.run(model.batch_ratings | model.rubi_ratings_both,
+ * {users: batch, pos_items: range(N)}) (macr_mf/train.py:224-251,
+ * utility/batch_test.py:50-93) + the candidate filtering and ranking of
+ * macr_mf/train.py:119-138 / batch_test.py:124-134 + tools.h:13-33.
+ *
+ *   users_tab (dev) fp32[*, d], user_ids (dev) int32[U]: row user_ids[q] of
+ *              users_tab is query q (user_ids may be NULL = rows 0..U-1)
+ *   items     (dev) fp32[n_local*d]: the LOCAL item shard; global item id of
+ *              local row t is item_offset + t
+ *   sig_u     (dev) fp32[U]  sigmoid(e_u . w_user)  per query  (RUBI_BOTH only)
+ *   sig_i     (dev) fp32[n_local] sigmoid(e_i . w)  per local item (RUBI_BOTH)
+ *   c         the constant `rubi_c` set by update_c (model.py:313)
+ *   mask_ptr  (dev) int32[U+1], mask_idx (dev) int32[*]: per query, ascending
+ *              GLOBAL item ids to exclude (the user's train items); may be NULL
+ *   n_splits  >= 1: the local shard is cut into n_splits contiguous ranges that
+ *              are ranked by different workgroups (fills the chip when U is
+ *              small); 0 = let the library choose
+ *   out_val (dev) fp32 [n_splits*U*K], out_idx (dev) int32 [n_splits*U*K]:
+ *              per split, per query: K (score,id) pairs, score descending, ties
+ *              by ascending id, unused slots (-inf, -1).  Feed to
+ *              macr_topk_merge.  macr_score_topk_splits() tells n_splits chosen.
+ * Score: NORMAL e_u.e_i ; RUBI_BOTH ((e_u.e_i - c) * sig_i) * sig_u, the dot
+ * product being a k-ascending fp32 fma chain (gfx950 fp32 MFMA arithmetic).
+ * d in {32,64,128,256}; 1 <= K <= MACR_MAX_TOPK.
+ * -------------------------------------------------------------------------*/
+int macr_score_topk_splits(int U, int n_local, int d);
+
+int macr_score_topk(int score_kind, int U, int n_local, int d,
+                    const float *users_tab, const int32_t *user_ids, const float *items,
+                    const float *sig_u, const float *sig_i, float c,
+                    const int32_t *mask_ptr, const int32_t *mask_idx, int item_offset,
+                    int K, int n_splits, float *out_val, int32_t *out_idx, void *stream);
+
+/* Dense scores for callers that want the matrix itself (the literal
+ * sess.run(model.rubi_ratings_both, ...) -> (U,N) fp32 contract). */
+int macr_score_matrix(int score_kind, int U, int n_local, int d,
+                      const float *users_tab, const int32_t *user_ids, const float *items,
+                      const float *sig_u, const float *sig_i, float c,
+                      float *out_scores, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Top-K column indices of every row of a score matrix.
+ * Replaces  void c_top_k_array_index(float *scores_pt, int columns_num,
+ *            int rows_num, int top_k, int thread_num, int *rankings_pt)
+ * (macr_lightgcn/evaluator/cpp/include/tools.h:24; binding in
+ * apt_evaluate_foldout.pyx:11-13).  scores (dev) fp32[rows*cols]; -inf entries
+ * (masked train items, batch_test.py:129) rank last; ties by ascending index
+ * (the reference leaves tie order to std::partial_sort_copy).
+ * out_idx (dev) int32[rows*K], out_val (dev, may be NULL) fp32[rows*K].
+ * -------------------------------------------------------------------------*/
+int macr_topk_scores(const float *scores, int cols, int rows, int K,
+                     int32_t *out_idx, float *out_val, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Merge W lists of K (score,id) pairs per query into one (new; also the merge
+ * step after the RCCL all-gather of per-shard top-K).  vals/idxs (dev)
+ * [W*U*K]; out (dev) [U*K]; out_cnt (dev) int32[U] = number of real candidates.
+ * If fill_mask_ptr != NULL, queries with fewer than K candidates are completed
+ * with their masked ids in ascending order at score -inf (what ranking a
+ * -inf-masked matrix yields, batch_test.py:124-134).
+ * -------------------------------------------------------------------------*/
+int macr_topk_merge(int W, int U, int K, const float *vals, const int32_t *idxs,
+                    const int32_t *fill_mask_ptr, const int32_t *fill_mask_idx,
+                    float *out_val, int32_t *out_idx, int32_t *out_cnt, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Fold-out metrics.  Replaces  void evaluate_foldout(int users_num,
+ *   int *rankings, int rank_len, int **ground_truths, int *ground_truths_num,
+ *   int thread_num, float *results)
+ * (macr_lightgcn/evaluator/cpp/include/evaluate_foldout.h:115-118).
+ * rankings (dev) int32[U*K]; ground truth as CSR (gt_ptr int32[U+1], gt_idx
+ * ascending per query) instead of int**; results (dev) fp32[U*5*K] laid out
+ * [precision | recall | ap | ndcg | mrr] x K prefixes per query.
+ * hr_in_ap_slot != 0 additionally applies the caller-side rewrite of
+ * macr_lightgcn/utility/batch_test.py:143-149: the ap block is replaced by
+ * HR := 1[recall@k != 0].
+ * -------------------------------------------------------------------------*/
+int macr_metrics_foldout(int U, int K, const int32_t *rankings,
+                         const int32_t *gt_ptr, const int32_t *gt_idx, float *results,
+                         int hr_in_ap_slot, void *stream);
+
+/* MF metrics (macr_mf/train.py:32-117, float64 like NumPy): out (dev) f64
+ * [U*4*nK] = per query {precision, recall, ndcg, hit_ratio} x Ks.  cnt (dev,
+ * may be NULL) int32[U] = length of each ranked list. */
+int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const int32_t *cnt,
+                    const int32_t *gt_ptr, const int32_t *gt_idx,
+                    const int32_t *Ks /*host*/, int nK, double *out, void *stream);
+
+/* Column means of a (rows, cols) matrix in float64 (deterministic tree):
+ * the "/ n_test_users" accumulation of macr_mf/train.py:286-290 and the
+ * np.mean(all_result, axis=0) of batch_test.py:151.  in_is_f32 selects input
+ * type; out (dev) f64[cols]. */
+int macr_colmean(const void *in, int in_is_f32, int rows, int cols, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MACR_HIP_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libmacr_hip.so (the C ABI of include/macr_hip.h).
+
+Loading fails LOUDLY when the extension has not been built: there is no
+fallback implementation of the kernels anywhere in this package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# MACR_HIP_LIB lets kernel-development tools load an alternative build of the same ABI (ablations).
+LIB_PATH = os.environ.get("MACR_HIP_LIB") or os.path.join(_HERE, "csrc", "libmacr_hip.so")
+
+OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH = 0, -1, -2, -3, -4
+LOSS_NORMALBCE, LOSS_RUBIBCEBOTH = 0, 1
+SCORE_NORMAL, SCORE_RUBI_BOTH = 0, 1
+MAX_TOPK = 32
+ABI_VERSION = 1
+
+
+class MacrError(RuntimeError):
+    def __init__(self, code, msg):
+        super(MacrError, self).__init__("macr_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Hyper(ctypes.Structure):
+    """struct macr_hyper"""
+    _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
+                ("adam_eps", ctypes.c_float), ("decay", ctypes.c_float), ("alpha", ctypes.c_float),
+                ("beta", ctypes.c_float), ("batch_size_cfg", ctypes.c_int32)]
+
+
+_p, _i, _f, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/macr_hip.h declaration by declaration
+SIGNATURES = {
+    "macr_abi_version": (_i, []),
+    "macr_last_error": (ctypes.c_char_p, []),
+    "macr_build_info": (ctypes.c_char_p, []),
+    "macr_timing_begin": (_i, [_p]),
+    "macr_timing_end": (_i, [_i, _p, _p]),
+    "macr_mf_train_workspace_bytes": (_z, [_i, _i]),
+    "macr_mf_train_step": (_i, [_i] * 5 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [_p, ctypes.POINTER(Hyper), _p, _p, _z, _p]),
+    "macr_lgcn_propagate": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "macr_lgcn_train_workspace_bytes": (_z, [_i, _i, _i]),
+    "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _p, _z, _p]),
+    "macr_branch_sigmoid": (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    "macr_score_topk_splits": (_i, [_i, _i, _i]),
+    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "macr_score_matrix": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
+    "macr_topk_scores": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "macr_topk_merge": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "macr_metrics_foldout": (_i, [_i, _i, _p, _p, _p, _p, _i, _p]),
+    "macr_metrics_mf": (_i, [_i, _i, _p, _p, _p, _p, ctypes.POINTER(ctypes.c_int32), _i, _p, _p]),
+    "macr_colmean": (_i, [_p, _i, _i, _i, _p, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "macr_amd: HIP extension %s is missing.  Build it with "
+                "`python -m macr_amd.build` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        got = L.macr_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError("macr_amd: libmacr_hip.so ABI %d != expected %d; rebuild" % (got, ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise MacrError(rc, lib().macr_last_error().decode("utf-8", "replace"))

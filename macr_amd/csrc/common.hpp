@@ -1,0 +1,141 @@
+// Shared device/host helpers for the gfx950 kernels of the MACR hot path.
+// CDNA4 only: wave = 64 lanes, no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/macr_hip.h"
+
+namespace macr {
+
+constexpr int kWave = 64;
+constexpr int kNumXcd = 8;   // MI355X: block b is dispatched to XCD b % 8 (speed only, never correctness)
+
+// ---- error plumbing (host) -------------------------------------------------
+void set_error(const char *fmt, ...);
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+// Optional per-kernel timing (macr_timing_*): records a hipEvent on `st` after a launch when enabled.
+void timing_mark(const char *name, hipStream_t st);
+
+#define MACR_REQUIRE(cond, code, ...)                 \
+    do {                                              \
+        if (!(cond)) {                                \
+            macr::set_error(__VA_ARGS__);             \
+            return (code);                            \
+        }                                             \
+    } while (0)
+
+#define MACR_CHECK_LAUNCH(what, st)                                                      \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) {                                                          \
+            macr::set_error("%s: %s", (what), hipGetErrorString(e_));                   \
+            return MACR_E_LAUNCH;                                                        \
+        }                                                                                \
+        macr::timing_mark((what), (st));                                                 \
+    } while (0)
+
+inline bool dim_supported(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Dispatch on lanes-per-row (d = 4 * LPR floats, one float4 per lane).
+#define MACR_DISPATCH_LPR(d, ...)                                  \
+    switch (d) {                                                   \
+        case 32:  { constexpr int LPR = 8;  __VA_ARGS__; } break;  \
+        case 64:  { constexpr int LPR = 16; __VA_ARGS__; } break;  \
+        case 128: { constexpr int LPR = 32; __VA_ARGS__; } break;  \
+        case 256: { constexpr int LPR = 64; __VA_ARGS__; } break;  \
+    }
+
+// ---- device helpers ----------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
+    return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
+}
+__device__ __forceinline__ float4 scale4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// Sum over the G consecutive lanes of a group (G power of two <= 64); every lane gets the total.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<kWave>(v); }
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+// Block-wide sum for <=1024 threads; result valid in thread 0.  scratch: >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float *scratch) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < nw; ++k) t += scratch[k];
+    return t;
+}
+
+// sigmoid as the oracle writes it: 1/(1+exp(-x)), fp32.
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// d/dx of -log(sigmoid(x)+eps)   and   d/dy of -log((1-sigmoid(y))+eps)   (see oracle/macr_oracle.c)
+__device__ __forceinline__ float dneglog_sig(float s, float eps) { return -((s * (1.0f - s)) / (s + eps)); }
+__device__ __forceinline__ float dneglog_1msig(float s, float eps) { return (s * (1.0f - s)) / ((1.0f - s) + eps); }
+
+// ---- (score,id) ranking keys --------------------------------------------------
+// Larger key = ranks earlier: score descending, then id ascending.  0 = empty slot.
+__device__ __forceinline__ uint32_t f32_orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;            // -0.0 ties with +0.0 (they compare equal as floats)
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float orderable_f32(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ uint64_t make_key(float score, int32_t id) {
+    return (static_cast<uint64_t>(f32_orderable(score)) << 32) | (0xffffffffu - static_cast<uint32_t>(id));
+}
+__device__ __forceinline__ float key_score(uint64_t k) { return orderable_f32(static_cast<uint32_t>(k >> 32)); }
+__device__ __forceinline__ int32_t key_id(uint64_t k) { return static_cast<int32_t>(0xffffffffu - static_cast<uint32_t>(k)); }
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v >> 32);
+    lo = __shfl_xor(lo, m, kWave);
+    hi = __shfl_xor(hi, m, kWave);
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+// Bitonic sort of one key per lane across the 64 lanes of a wave, DESCENDING by lane index
+// (lane 0 ends up with the largest key).
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const uint64_t other = shfl_xor_u64(key, j);
+            const bool upper = (lane & j) != 0;            // I am the higher lane of the pair
+            const bool desc = (lane & k) == 0;             // this sub-sequence sorts descending
+            // descending: lower lane keeps max.  keep_max = (desc != upper)
+            const bool keep_max = (desc != upper);
+            const uint64_t mx = key > other ? key : other;
+            const uint64_t mn = key > other ? other : key;
+            key = keep_max ? mx : mn;
+        }
+    }
+    return key;
+}
+
+}  // namespace macr

@@ -1,0 +1,653 @@
+// Full-catalogue evaluator kernels for gfx950 (MI355X).
+//
+//   k_score_topk   U.I^T on the fp32 MFMA (v_mfma_f32_32x32x2_f32) with the
+//                  (y - c)*sig_i*sig_u epilogue, train-item masking and a running
+//                  per-user top-K -- the (U,N) score matrix never exists.
+//   k_topk_scores  top-K of a materialised score matrix (drop-in for the reference's
+//                  c_top_k_array_index, tools.h:24).
+//   k_topk_merge   merge of per-split / per-GPU-shard top-K lists.
+//   k_metrics_*    ranking metrics.
+//
+// Ranking rule everywhere: score descending, exact ties by ascending item id
+// (what heapq.nlargest over the ascending candidate list does, macr_mf/train.py:89-104;
+// std::partial_sort_copy, tools.h:13-22, leaves ties unspecified).  Implemented by
+// sorting 64-bit keys (orderable(score) << 32 | ~id).
+#include "common.hpp"
+
+namespace macr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kCap = 64;          // candidate buffer entries per user (= one wave-wide sort)
+constexpr int kTileItems = 32;    // MFMA tile: 32 items x 32 users
+constexpr int kUnitK = 64;        // k-extent staged in LDS at a time
+constexpr int kUnitStride = kUnitK + 1;   // odd stride: conflict-free fragment reads
+constexpr int kWavesPerBlock = 8;
+constexpr int kUsersPerBlock = 32 * kWavesPerBlock;
+
+// Wave-cooperative compaction of one user's candidate buffer: sort the (<= 64) keys,
+// keep the best K, publish the new count and the admission threshold (K-th best score,
+// or -inf while fewer than K candidates exist).  All 64 lanes must call it.
+__device__ __forceinline__ void compact_buffer(uint64_t *keys, uint32_t *cnt, float *thr, int K) {
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t c = *cnt;
+    uint64_t key = (lane < (int)c) ? keys[lane] : 0ull;
+    key = wave_sort_desc(key);
+    if (lane < K) keys[lane] = key;
+    const uint32_t hi_k = __shfl((uint32_t)(key >> 32), K - 1, kWave);
+    const uint32_t lo_k = __shfl((uint32_t)key, K - 1, kWave);
+    if (lane == 0) {
+        *cnt = c < (uint32_t)K ? c : (uint32_t)K;
+        const bool full = (hi_k | lo_k) != 0u;
+        *thr = full ? orderable_f32(hi_k) : -INFINITY;
+    }
+    // other lanes read cnt/thr/keys next: the compiler must not forward values it loaded before
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// ----------------------------------------------------------------------------
+// k_score_topk
+// Replaces sess.run(model.batch_ratings | model.rubi_ratings_both, ...) +
+// candidate filtering + ranking (macr_mf/train.py:224-251,:119-138,:89-104;
+// macr_lightgcn/utility/batch_test.py:50-93,:124-134; tools.h:13-33).
+//
+// Grid: blockIdx.x = user_block * n_splits + split.  A block (8 waves) owns 256 query
+// users and one contiguous item range; consecutive block ids share the user block and
+// differ in split, so with n_splits a multiple of 8 every XCD (block id mod 8) streams
+// only its own slice of the item table through its private L2.
+// Wave w owns users [32w, 32w+32): their embeddings sit in registers as the MFMA B
+// operand (D/2 VGPRs) for the whole kernel.  Items stream through LDS in units of
+// 32 items x 64 k (double buffered, one barrier per unit); each unit costs 32
+// v_mfma_f32_32x32x2_f32 per wave.  MFMA result layout puts user (lane&31) in both lanes
+// l and l+32, each holding 16 of the tile's 32 item scores, so thresholding is 16
+// compares per lane with no cross-lane traffic.  Scores above the user's running
+// threshold are appended to a 64-entry LDS buffer; when it could overflow the wave
+// sorts it (bitonic over 64 lanes) and keeps the best K.
+// ----------------------------------------------------------------------------
+template <int D, int KIND>
+__global__ __launch_bounds__(512, 2) void k_score_topk(
+    int U, int n_local, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
+    const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
+    const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_idx, int item_offset, int K,
+    int n_splits, float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+    constexpr int NKH = D / kUnitK > 0 ? D / kUnitK : 1;     // k-halves per tile (D=32 -> 1 short unit)
+    constexpr int UK = D < kUnitK ? D : kUnitK;              // k extent of one unit
+    constexpr int NT = UK / 2;                               // MFMA steps per unit
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *s_keys = reinterpret_cast<uint64_t *>(smem);                                 // [256][64]
+    float *s_unit = reinterpret_cast<float *>(smem + (size_t)kUsersPerBlock * kCap * 8);   // [2][32][65]
+    float *s_sig = s_unit + 2 * kTileItems * kUnitStride;                                  // [2][32]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_sig + 2 * kTileItems);                // [256]
+    float *s_thr = reinterpret_cast<float *>(s_cnt + kUsersPerBlock);                      // [256]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int ub = blockIdx.x / n_splits, split = blockIdx.x % n_splits;
+    const int uslot = wid * 32 + col;                    // user slot inside the block
+    const int q = ub * kUsersPerBlock + uslot;           // query index
+    const bool q_ok = q < U;
+
+    // item range of this split (multiples of 32 except the last)
+    const int tiles_total = (n_local + kTileItems - 1) / kTileItems;
+    const int tiles_per_split = (tiles_total + n_splits - 1) / n_splits;
+    const int it_lo = min(split * tiles_per_split * kTileItems, n_local);
+    const int it_hi = min(it_lo + tiles_per_split * kTileItems, n_local);
+    const int n_tiles = (it_hi - it_lo + kTileItems - 1) / kTileItems;
+
+    if (tid < kUsersPerBlock) { s_cnt[tid] = 0; s_thr[tid] = -INFINITY; }
+
+    // B operand: lane (col,h) holds user[col][2t+h] for every MFMA step t
+    float bfrag[D / 2];
+    {
+        const float *urow = users_tab + (size_t)(q_ok ? (user_ids ? user_ids[q] : q) : 0) * D;
+#pragma unroll
+        for (int t = 0; t < D / 2; ++t) bfrag[t] = q_ok ? urow[2 * t + h] : 0.f;
+    }
+    const float su = (KIND == MACR_SCORE_RUBI_BOTH && q_ok) ? sig_u[q] : 1.0f;
+
+    // train-item mask cursor: next masked GLOBAL id >= the range start
+    int mpos = 0, mend = 0, mnext = INT_MAX;
+    if (mask_ptr && q_ok) {
+        mpos = mask_ptr[q]; mend = mask_ptr[q + 1];
+        const int lo_gid = it_lo + item_offset;
+        int lo = mpos, hi = mend;                  // first entry >= lo_gid
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (mask_idx[mid] < lo_gid) lo = mid + 1; else hi = mid; }
+        mpos = lo;
+        mnext = mpos < mend ? mask_idx[mpos] : INT_MAX;
+    }
+    float thr = q_ok ? -INFINITY : INFINITY;       // padding users never admit anything
+#ifdef MACR_ABL_NOADMIT
+    thr = INFINITY;
+#endif
+
+    // staging: 512 threads x one float4 = 32 items x 64 k
+    const int st_row = tid >> 4, st_c4 = tid & 15;
+    auto load_unit = [&](int tile, int kh) -> float4 {
+        const int it = it_lo + tile * kTileItems + st_row;
+        if (it < it_hi && st_c4 * 4 < UK) return ld4(items + (size_t)it * D + kh * kUnitK + st_c4 * 4);
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_unit = [&](int buf, float4 v) {
+        float *p = s_unit + (size_t)buf * kTileItems * kUnitStride + st_row * kUnitStride + st_c4 * 4;
+        p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    };
+    auto load_sig = [&](int tile) -> float {
+        const int it = it_lo + tile * kTileItems + tid;
+        return (KIND == MACR_SCORE_RUBI_BOTH && tid < kTileItems && it < it_hi) ? sig_i[it] : 0.f;
+    };
+
+    const int n_units = n_tiles * NKH;
+    if (n_units > 0) {
+        const float4 v0 = load_unit(0, 0);
+        const float sg0 = load_sig(0);
+        store_unit(0, v0);
+        if (tid < kTileItems) s_sig[tid] = sg0;
+    }
+    __syncthreads();
+
+    f32x16 acc;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+#pragma unroll
+        for (int kh = 0; kh < NKH; ++kh) {            // static kh: bfrag[] stays in registers
+            const int unit = tile * NKH + kh, buf = unit & 1;
+            // prefetch the next unit into registers while this one is multiplied
+            const bool has_next = unit + 1 < n_units;
+            const int ntile = (kh + 1 < NKH) ? tile : tile + 1;
+            const int nkh = (kh + 1 < NKH) ? kh + 1 : 0;
+            float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
+            float sgnext = 0.f;
+            if (has_next) { vnext = load_unit(ntile, nkh); if (nkh == 0) sgnext = load_sig(ntile); }
+
+            if (kh == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+            const float *ua = s_unit + (size_t)buf * kTileItems * kUnitStride + col * kUnitStride + h;
+#ifndef MACR_ABL_NOMFMA
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2 * t], bfrag[kh * NT + t], acc, 0, 0, 0);
+#else
+            acc[0] += ua[0] * bfrag[kh * NT];
+#endif
+
+            if (kh == NKH - 1) {
+                // ---------------- epilogue for one 32-item tile ----------------
+                const int it0 = it_lo + tile * kTileItems;             // local id of tile row 0
+                const int gid0 = it0 + item_offset;
+                const int sbuf = tile & 1;
+                float s[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int il = (r & 3) + 8 * (r >> 2) + 4 * h;      // item row inside the tile
+                    float v = acc[r];
+                    if (KIND == MACR_SCORE_RUBI_BOTH) { v = v - c; v = v * s_sig[sbuf * kTileItems + il]; v = v * su; }
+                    s[r] = (it0 + il < it_hi) ? v : -INFINITY;
+                }
+                // masked (train) items of this tile -> -inf
+#ifndef MACR_ABL_NOMASK
+                if (__any(mnext < gid0 + kTileItems)) {
+                    uint32_t tmask = 0;
+                    while (mnext < gid0 + kTileItems) {
+                        tmask |= 1u << (mnext - gid0);
+                        ++mpos;
+                        mnext = mpos < mend ? mask_idx[mpos] : INT_MAX;
+                    }
+                    if (tmask) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if ((tmask >> il) & 1u) s[r] = -INFINITY;
+                        }
+                    }
+                }
+#endif
+                // admission
+                uint32_t cand = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cand |= (s[r] > thr) ? (1u << r) : 0u;
+                if (__any(cand != 0)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if ((cand >> r) & 1u) {
+                            const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const uint32_t pos = atomicAdd(&s_cnt[uslot], 1u);
+                            s_keys[(size_t)uslot * kCap + pos] = make_key(s[r], gid0 + il);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    // compaction for users whose buffer could overflow on the next tile
+                    const bool need = s_cnt[uslot] > (uint32_t)(kCap - kTileItems);
+                    uint64_t todo = __ballot(need && h == 0);
+                    while (todo) {
+                        const int ucol = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const int us = wid * 32 + ucol;
+                        compact_buffer(s_keys + (size_t)us * kCap, &s_cnt[us], &s_thr[us], K);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    thr = q_ok ? s_thr[uslot] : INFINITY;
+                }
+            }
+            if (has_next) {
+                store_unit(buf ^ 1, vnext);
+                if (nkh == 0 && tid < kTileItems) s_sig[(ntile & 1) * kTileItems + tid] = sgnext;
+            }
+            __syncthreads();
+        }
+    }
+
+    // final: sort every user's buffer, write K (score,id) pairs (descending), pad with (-inf,-1)
+    for (int ucol = 0; ucol < 32; ++ucol) {
+        const int us = wid * 32 + ucol;
+        const int qq = ub * kUsersPerBlock + us;
+        if (qq >= U) break;
+        const uint32_t cc = s_cnt[us];
+        uint64_t key = (lane < (int)cc) ? s_keys[(size_t)us * kCap + lane] : 0ull;
+        key = wave_sort_desc(key);
+        if (lane < K) {
+            const size_t o = ((size_t)split * U + qq) * K + lane;
+            out_val[o] = key ? key_score(key) : -INFINITY;
+            out_idx[o] = key ? key_id(key) : -1;
+        }
+    }
+}
+
+inline size_t score_topk_smem_bytes() {
+    return (size_t)kUsersPerBlock * kCap * 8 + 2 * kTileItems * kUnitStride * 4 + 2 * kTileItems * 4 +
+           kUsersPerBlock * 4 + kUsersPerBlock * 4;
+}
+
+// ----------------------------------------------------------------------------
+// k_score_matrix: the literal (U,N) score matrix (model.batch_ratings /
+// model.rubi_ratings_both), same arithmetic as k_score_topk.  One wave = 32 users x 32 items.
+// ----------------------------------------------------------------------------
+template <int D, int KIND>
+__global__ __launch_bounds__(256) void k_score_matrix(int U, int n_local, const float *__restrict__ users_tab,
+                                                      const int32_t *__restrict__ user_ids,
+                                                      const float *__restrict__ items,
+                                                      const float *__restrict__ sig_u,
+                                                      const float *__restrict__ sig_i, float c,
+                                                      float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int q = blockIdx.y * 32 + col;
+    const int it0 = (blockIdx.x * 4 + wid) * 32;
+    if (it0 >= n_local) return;
+    const bool q_ok = q < U;
+    const float *urow = users_tab + (size_t)(q_ok ? (user_ids ? user_ids[q] : q) : 0) * D;
+    const int it = it0 + col;
+    const float *irow = items + (size_t)(it < n_local ? it : 0) * D;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int t = 0; t < D / 2; ++t) {
+        const float a = it < n_local ? irow[2 * t + h] : 0.f;
+        const float b = q_ok ? urow[2 * t + h] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (!q_ok) return;
+    const float su = KIND == MACR_SCORE_RUBI_BOTH ? sig_u[q] : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int id = it0 + il;
+        if (id < n_local) {
+            float v = acc[r];
+            if (KIND == MACR_SCORE_RUBI_BOTH) { v = v - c; v = v * sig_i[id]; v = v * su; }
+            out[(size_t)q * n_local + id] = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_topk_scores: one wave per row of a materialised (rows, cols) score matrix.
+// Replaces c_top_k_array_index (tools.h:24).  HBM-bound: reads rows*cols*4 bytes once.
+// Every column is a candidate (also -inf ones, batch_test.py:129), admission by key.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_topk_scores(const float *__restrict__ scores, int cols, int rows, int K,
+                                                     int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+    __shared__ uint64_t s_keys[4][kCap];
+    __shared__ uint32_t s_cnt[4];
+    __shared__ float s_thr[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= rows) return;
+    const float *src = scores + (size_t)row * cols;
+    uint64_t *keys = s_keys[wid];
+    if (lane == 0) { s_cnt[wid] = 0; s_thr[wid] = -INFINITY; }
+    uint32_t cnt = 0;
+    uint64_t thr_key = 0;                           // admission: key > thr_key
+    for (int base = 0; base < cols; base += kWave) {
+        const int cidx = base + lane;
+        const float v = cidx < cols ? src[cidx] : 0.f;
+        const uint64_t key = cidx < cols ? make_key(v, cidx) : 0ull;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bool mine = (lane >> 5) == half;
+            bool cand = mine && key > thr_key;
+            uint64_t bal = __ballot(cand);
+            if (bal == 0) continue;
+            if (cnt + (uint32_t)__popcll(bal) > (uint32_t)kCap) {
+                if (lane == 0) s_cnt[wid] = cnt;
+                compact_buffer(keys, &s_cnt[wid], &s_thr[wid], K);
+                cnt = s_cnt[wid];
+                thr_key = cnt >= (uint32_t)K ? keys[K - 1] : 0ull;
+                cand = mine && key > thr_key;
+                bal = __ballot(cand);
+            }
+            if (cand) {
+                const uint32_t pos = cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                keys[pos] = key;
+            }
+            cnt += (uint32_t)__popcll(bal);
+        }
+    }
+    uint64_t key = (lane < (int)cnt) ? keys[lane] : 0ull;
+    key = wave_sort_desc(key);
+    if (lane < K) {
+        out_idx[(size_t)row * K + lane] = key ? key_id(key) : -1;
+        if (out_val) out_val[(size_t)row * K + lane] = key ? key_score(key) : -INFINITY;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_topk_merge: one wave per query merges W sorted lists of K into one.
+// Also the merge after the RCCL all-gather of per-shard top-K.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_topk_merge(int W, int U, int K, const float *__restrict__ vals,
+                                                    const int32_t *__restrict__ idxs,
+                                                    const int32_t *__restrict__ fill_ptr,
+                                                    const int32_t *__restrict__ fill_idx,
+                                                    float *__restrict__ out_val, int32_t *__restrict__ out_idx,
+                                                    int32_t *__restrict__ out_cnt) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wid;
+    if (q >= U) return;
+    const int per_round = (kWave - K) / K;          // lists merged per sort (>= 1 since K <= 32)
+    uint64_t best = 0ull;                           // lanes [0,K): current best keys (sorted)
+    for (int s0 = 0; s0 < W; s0 += per_round) {
+        uint64_t key = lane < K ? best : 0ull;
+        const int rel = lane - K;
+        if (rel >= 0 && rel < per_round * K) {
+            const int s = s0 + rel / K, k = rel % K;
+            if (s < W) {
+                const size_t o = ((size_t)s * U + q) * K + k;
+                const int32_t id = idxs[o];
+                if (id >= 0) key = make_key(vals[o], id);
+            }
+        }
+        best = wave_sort_desc(key);
+    }
+    const uint64_t bal = __ballot(lane < K && best != 0ull);
+    int cnt = __popcll(bal);
+    if (lane < K) {
+        out_val[(size_t)q * K + lane] = best ? key_score(best) : -INFINITY;
+        out_idx[(size_t)q * K + lane] = best ? key_id(best) : -1;
+    }
+    if (lane == 0) {
+        if (out_cnt) out_cnt[q] = cnt;
+        if (fill_ptr && cnt < K)       // complete with the masked ids, ascending (score -inf)
+            for (int e = fill_ptr[q]; e < fill_ptr[q + 1] && cnt < K; ++e, ++cnt) {
+                out_idx[(size_t)q * K + cnt] = fill_idx[e];
+                out_val[(size_t)q * K + cnt] = -INFINITY;
+            }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// branch sigmoid: out[r] = sigmoid(rows[idx?idx[r]:r] . w)      macr_mf/model.py:194-196,:199
+// ----------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void k_branch_sigmoid(const float *__restrict__ rows,
+                                                        const int32_t *__restrict__ idx, int n,
+                                                        const float *__restrict__ w, float *__restrict__ out) {
+    constexpr int d = 4 * LPR;
+    const int sub = threadIdx.x % LPR;
+    const int r = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    if (r >= n) return;
+    const size_t src = idx ? (size_t)idx[r] : (size_t)r;
+    const float s = group_sum<LPR>(dot4(ld4(rows + src * d + 4 * sub), ld4(w + 4 * sub)));
+    if (sub == 0) out[r] = sigmoid_acc(s);
+}
+
+// ----------------------------------------------------------------------------
+// metrics
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ bool in_sorted(const int32_t *a, int n, int32_t x) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo < n && a[lo] == x;
+}
+
+// evaluate_foldout.h:16-195 -- [precision|recall|ap|ndcg|mrr] x K prefixes, float accumulators with
+// the double sub-expressions of the C++ (1.0*hits/(i+1), 1.0/log2(i+2)).  Thread per query.
+__global__ void k_metrics_foldout(int U, int K, const int32_t *__restrict__ rankings,
+                                  const int32_t *__restrict__ gt_ptr, const int32_t *__restrict__ gt_idx,
+                                  float *__restrict__ results, int hr_in_ap_slot) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int32_t *rank = rankings + (size_t)u * K;
+    const int32_t *truth = gt_idx + gt_ptr[u];
+    const int truth_len = gt_ptr[u + 1] - gt_ptr[u];
+    float *res = results + (size_t)u * 5 * K;
+    int hits = 0; float sum_pre = 0.f, dcg = 0.f, idcg = 0.f, rr = 0.f; bool found = false;
+    for (int i = 0; i < K; ++i) {
+        const bool hit = rank[i] >= 0 && in_sorted(truth, truth_len, rank[i]);
+        if (hit) {
+            hits += 1;
+            const float pre = (float)(1.0 * hits / (i + 1));
+            sum_pre += pre;
+            dcg = (float)((double)dcg + 1.0 / log2((double)(i + 2)));
+            if (!found) { rr = (float)(1.0 / (i + 1)); found = true; }
+        }
+        if (i < truth_len) idcg = (float)((double)idcg + 1.0 / log2((double)(i + 2)));
+        res[0 * K + i] = (float)(1.0 * hits / (i + 1));
+        res[1 * K + i] = (float)(1.0 * hits / truth_len);
+        res[2 * K + i] = sum_pre / (float)truth_len;
+        // batch_test.py:143-149 overwrites the AP slot with HR := 1[recall@k != 0]
+        if (hr_in_ap_slot) res[2 * K + i] = (res[1 * K + i] != 0.f) ? 1.0f : 0.0f;
+        res[3 * K + i] = dcg / idcg;
+        res[4 * K + i] = rr;
+    }
+}
+
+// macr_mf/train.py:32-117 in float64: per query {precision, recall, ndcg, hit} x Ks.
+struct KsArg { int32_t k[8]; int n; };
+__global__ void k_metrics_mf(int U, int Kmax, const int32_t *__restrict__ rankings,
+                             const int32_t *__restrict__ cnt, const int32_t *__restrict__ gt_ptr,
+                             const int32_t *__restrict__ gt_idx, KsArg Ks, double *__restrict__ out) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const int32_t *rank = rankings + (size_t)u * Kmax;
+    const int32_t *truth = gt_idx + gt_ptr[u];
+    const int truth_len = gt_ptr[u + 1] - gt_ptr[u];
+    const int len = cnt ? cnt[u] : Kmax;
+    for (int qk = 0; qk < Ks.n; ++qk) {
+        const int K = Ks.k[qk];
+        const int m = len < K ? len : K;
+        double hits = 0, dcg = 0, dcg_max = 0;
+        for (int i = 0; i < m; ++i)
+            if (rank[i] >= 0 && in_sorted(truth, truth_len, rank[i])) { hits += 1.0; dcg += 1.0 / log2((double)(i + 2)); }
+        const int lim = truth_len < K ? truth_len : K;
+        for (int i = 0; i < lim; ++i) dcg_max += 1.0 / log2((double)(i + 2));
+        double *o = out + ((size_t)u * 4) * Ks.n;
+        o[0 * Ks.n + qk] = m > 0 ? hits / m : NAN;
+        o[1 * Ks.n + qk] = hits / truth_len;
+        o[2 * Ks.n + qk] = dcg_max != 0 ? dcg / dcg_max : 0.0;
+        o[3 * Ks.n + qk] = hits > 0 ? 1.0 : 0.0;
+    }
+}
+
+// column means in float64, one block per column, fixed-shape tree => deterministic
+template <typename T>
+__global__ __launch_bounds__(256) void k_colmean(const T *__restrict__ in, int rows, int cols, double *__restrict__ out) {
+    __shared__ double red[4];
+    const int cidx = blockIdx.x;
+    double s = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) s += (double)in[(size_t)r * cols + cidx];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[cidx] = (red[0] + red[1] + red[2] + red[3]) / (double)rows;
+}
+
+}  // namespace macr
+
+// ============================================================================
+// C ABI
+// ============================================================================
+using namespace macr;
+
+extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
+    (void)d;
+    if (U <= 0 || n_local <= 0) return 1;
+    const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
+    const int tiles = (n_local + kTileItems - 1) / kTileItems;
+    // aim for >= 2 blocks per CU (512 blocks), splits a multiple of 8 (one item slice per XCD),
+    // but keep at least 16 tiles per split so the per-split warm-up stays amortised
+    int s = (512 + ublocks - 1) / ublocks;
+    s = (s + 7) / 8 * 8;
+    const int max_s = tiles / 16 > 0 ? tiles / 16 : 1;
+    if (s > max_s) s = max_s >= 8 ? max_s / 8 * 8 : max_s;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+#define MACR_DISPATCH_DK(d, kind, ...)                                                              \
+    switch (d) {                                                                                    \
+        case 32:  if (kind == MACR_SCORE_NORMAL) { constexpr int D = 32,  KIND = 0; __VA_ARGS__; }  \
+                  else { constexpr int D = 32,  KIND = 1; __VA_ARGS__; } break;                     \
+        case 64:  if (kind == MACR_SCORE_NORMAL) { constexpr int D = 64,  KIND = 0; __VA_ARGS__; }  \
+                  else { constexpr int D = 64,  KIND = 1; __VA_ARGS__; } break;                     \
+        case 128: if (kind == MACR_SCORE_NORMAL) { constexpr int D = 128, KIND = 0; __VA_ARGS__; }  \
+                  else { constexpr int D = 128, KIND = 1; __VA_ARGS__; } break;                     \
+        case 256: if (kind == MACR_SCORE_NORMAL) { constexpr int D = 256, KIND = 0; __VA_ARGS__; }  \
+                  else { constexpr int D = 256, KIND = 1; __VA_ARGS__; } break;                     \
+    }
+
+extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const float *users_tab,
+                               const int32_t *user_ids, const float *items, const float *sig_u,
+                               const float *sig_i, float c, const int32_t *mask_ptr, const int32_t *mask_idx,
+                               int item_offset, int K, int n_splits, float *out_val, int32_t *out_idx,
+                               void *stream) {
+    MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || score_kind == MACR_SCORE_RUBI_BOTH, MACR_E_INVALID,
+                 "score_topk: score_kind=%d", score_kind);
+    MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk: U=%d n_local=%d", U, n_local);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "score_topk: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
+    MACR_REQUIRE(users_tab && items && out_val && out_idx, MACR_E_INVALID, "score_topk: null pointer");
+    MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || (sig_u && sig_i), MACR_E_INVALID,
+                 "score_topk: RUBI_BOTH needs sig_u and sig_i");
+    MACR_REQUIRE((mask_ptr == nullptr) == (mask_idx == nullptr) || mask_ptr, MACR_E_INVALID, "score_topk: mask_idx without mask_ptr");
+    if (n_splits <= 0) n_splits = macr_score_topk_splits(U, n_local, d);
+    const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
+    const size_t smem = score_topk_smem_bytes();
+    hipStream_t st = as_stream(stream);
+    MACR_DISPATCH_DK(d, score_kind, {
+        auto kern = k_score_topk<D, KIND>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+        kern<<<ublocks * n_splits, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c,
+                                                    mask_ptr, mask_idx, item_offset, K, n_splits, out_val, out_idx);
+    });
+    MACR_CHECK_LAUNCH("score_topk", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_score_matrix(int score_kind, int U, int n_local, int d, const float *users_tab,
+                                 const int32_t *user_ids, const float *items, const float *sig_u,
+                                 const float *sig_i, float c, float *out_scores, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || score_kind == MACR_SCORE_RUBI_BOTH, MACR_E_INVALID,
+                 "score_matrix: score_kind=%d", score_kind);
+    MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_matrix: U=%d n_local=%d", U, n_local);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_matrix: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(users_tab && items && out_scores, MACR_E_INVALID, "score_matrix: null pointer");
+    MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || (sig_u && sig_i), MACR_E_INVALID,
+                 "score_matrix: RUBI_BOTH needs sig_u and sig_i");
+    dim3 grid((n_local + 127) / 128, (U + 31) / 32);
+    MACR_DISPATCH_DK(d, score_kind, (k_score_matrix<D, KIND><<<grid, 256, 0, st>>>(
+                                        U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, out_scores)));
+    MACR_CHECK_LAUNCH("score_matrix", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_topk_scores(const float *scores, int cols, int rows, int K, int32_t *out_idx,
+                                float *out_val, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(scores && out_idx, MACR_E_INVALID, "topk_scores: null pointer");
+    MACR_REQUIRE(cols > 0 && rows > 0, MACR_E_INVALID, "topk_scores: cols=%d rows=%d", cols, rows);
+    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "topk_scores: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
+    k_topk_scores<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val);
+    MACR_CHECK_LAUNCH("topk_scores", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_topk_merge(int W, int U, int K, const float *vals, const int32_t *idxs,
+                               const int32_t *fill_mask_ptr, const int32_t *fill_mask_idx, float *out_val,
+                               int32_t *out_idx, int32_t *out_cnt, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(W >= 1 && U > 0, MACR_E_INVALID, "topk_merge: W=%d U=%d", W, U);
+    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "topk_merge: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
+    MACR_REQUIRE(vals && idxs && out_val && out_idx, MACR_E_INVALID, "topk_merge: null pointer");
+    k_topk_merge<<<(U + 3) / 4, 256, 0, st>>>(W, U, K, vals, idxs, fill_mask_ptr, fill_mask_idx,
+                                                             out_val, out_idx, out_cnt);
+    MACR_CHECK_LAUNCH("topk_merge", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, const float *w,
+                                   float *out, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(rows && w && out, MACR_E_INVALID, "branch_sigmoid: null pointer");
+    MACR_REQUIRE(n > 0, MACR_E_INVALID, "branch_sigmoid: n=%d", n);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "branch_sigmoid: d=%d not in {32,64,128,256}", d);
+    MACR_DISPATCH_LPR(d, (k_branch_sigmoid<LPR><<<(n + (256 / LPR) - 1) / (256 / LPR), 256, 0, st>>>(
+                             rows, idx, n, w, out)));
+    MACR_CHECK_LAUNCH("branch_sigmoid", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_metrics_foldout(int U, int K, const int32_t *rankings, const int32_t *gt_ptr,
+                                    const int32_t *gt_idx, float *results, int hr_in_ap_slot, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(U > 0 && K >= 1, MACR_E_INVALID, "metrics_foldout: U=%d K=%d", U, K);
+    MACR_REQUIRE(rankings && gt_ptr && gt_idx && results, MACR_E_INVALID, "metrics_foldout: null pointer");
+    k_metrics_foldout<<<(U + 127) / 128, 128, 0, st>>>(U, K, rankings, gt_ptr, gt_idx, results, hr_in_ap_slot);
+    MACR_CHECK_LAUNCH("metrics_foldout", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const int32_t *cnt,
+                               const int32_t *gt_ptr, const int32_t *gt_idx, const int32_t *Ks, int nK,
+                               double *out, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(U > 0 && Kmax >= 1, MACR_E_INVALID, "metrics_mf: U=%d Kmax=%d", U, Kmax);
+    MACR_REQUIRE(rankings && gt_ptr && gt_idx && Ks && out, MACR_E_INVALID, "metrics_mf: null pointer");
+    MACR_REQUIRE(nK >= 1 && nK <= 8, MACR_E_UNSUPPORTED, "metrics_mf: nK=%d outside [1,8]", nK);
+    KsArg ka;
+    ka.n = nK;
+    for (int q = 0; q < nK; ++q) {
+        MACR_REQUIRE(Ks[q] >= 1 && Ks[q] <= Kmax, MACR_E_INVALID, "metrics_mf: Ks[%d]=%d outside [1,%d]", q, Ks[q], Kmax);
+        ka.k[q] = Ks[q];
+    }
+    k_metrics_mf<<<(U + 127) / 128, 128, 0, st>>>(U, Kmax, rankings, cnt, gt_ptr, gt_idx, ka, out);
+    MACR_CHECK_LAUNCH("metrics_mf", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_colmean(const void *in, int in_is_f32, int rows, int cols, double *out, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(in && out && rows > 0 && cols > 0, MACR_E_INVALID, "colmean: bad arguments");
+    if (in_is_f32)
+        k_colmean<float><<<cols, 256, 0, st>>>(static_cast<const float *>(in), rows, cols, out);
+    else
+        k_colmean<double><<<cols, 256, 0, st>>>(static_cast<const double *>(in), rows, cols, out);
+    MACR_CHECK_LAUNCH("colmean", st);
+    return MACR_OK;
+}

@@ -1,0 +1,691 @@
+// Training-step kernels of the MACR hot path for gfx950 (MI355X).
+//
+// One step =  pair_fwd  ->  bxb (rubibceboth only)  ->  pair_bwd  ->  adam_dense
+// (normalbce fuses fwd+bwd into pair_normal).  What each kernel replaces in the
+// reference is cited at the kernel; the arithmetic follows SURVEY.md appendix A.
+//
+// Data layout: embedding tables are row-major fp32 [rows][d]; one row is
+// 4*LPR floats and is always touched as LPR lanes x float4 (a 256-B row at
+// d=64 is one coalesced 16-lane access).  A wave therefore works on 64/LPR
+// rows at once and reduces dot products inside each LPR-lane group with
+// cross-lane shuffles.
+#include "common.hpp"
+
+namespace macr {
+
+// Timing probes for tools/ablate.py (never defined in the product build).
+#ifdef MACR_ABL_NOATOMIC
+#define MACR_ATOMIC_ADD(p, v) (*(p) = (v))
+#else
+#define MACR_ATOMIC_ADD(p, v) unsafeAtomicAdd((p), (v))
+#endif
+
+// ----------------------------------------------------------------------------
+// Small per-step scalar block living at the start of the workspace.
+// ----------------------------------------------------------------------------
+struct StepScalars {
+    float lr_t;          // lr * sqrt(1-beta2^t) / (1-beta1^t)   (TF 1.14 Adam)
+    float pad[3];
+};
+
+// Partial-sum slots written by the pair kernels (one set per block), reduced by adam_dense block 0.
+// slot 0: sum of squares (regulariser)   1: L_item terms   2: L_user terms   3: per-pair BCE (normalbce)
+constexpr int kPartStride = 4;
+
+template <int LPR>
+struct RowGroup {
+    static constexpr int kRowsPerWave = kWave / LPR;
+    static constexpr int kRowsPerBlock = 256 / LPR;
+    int sub;    // lane inside the group: owns floats [4*sub, 4*sub+4) of the row
+    int slot;   // row slot inside the block
+    __device__ RowGroup() {
+        sub = threadIdx.x % LPR;
+        slot = threadIdx.x / LPR;
+    }
+};
+
+// ----------------------------------------------------------------------------
+// pair_fwd: gathers + per-pair dots + branch logits.
+//   eu=Usrc[u], ei=Isrc[i], ej=Isrc[j]                    macr_mf/model.py:35-37
+//   p=sum(eu*ei), n=sum(eu*ej)                            :186-187
+//   si=ei.w, sj=ej.w, su=eu.wu                            :194-196
+//   a=sig(si)sig(su), b=sig(sj)sig(su)  (row factors of the (B,B) products :204-205)
+//   partials: l2 regulariser sum (:219), L_item (:213), L_user (:215) terms
+// fwd layout: 7 arrays of Bp floats: p, n, a, b, sig_si, sig_sj, sig_su  (Bp = padded B).
+// ----------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void k_pair_fwd(
+    int B, int Bp, const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
+    const float *__restrict__ Usrc, const float *__restrict__ Isrc,
+    const float *__restrict__ w, const float *__restrict__ wu,
+    float *__restrict__ fwd, float *__restrict__ part, int reg_on_gathered,
+    const float *__restrict__ adam_pow_in, float *adam_pow_out, StepScalars *scal, float lr, float b1, float b2,
+    float *gw_zero /* [2*d]: branch-vector gradient accumulators, cleared here for pair_bwd */) {
+    constexpr int d = 4 * LPR;
+    __shared__ float red[16];
+    RowGroup<LPR> g;
+    const int t = blockIdx.x * RowGroup<LPR>::kRowsPerBlock + g.slot;
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < 2 * d; k += 256) gw_zero[k] = 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // Adam bias correction for this step, then advance TF's fp32 beta powers.
+        const float p1 = adam_pow_in[0], p2 = adam_pow_in[1];
+        scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
+        adam_pow_out[0] = p1 * b1;
+        adam_pow_out[1] = p2 * b2;
+    }
+    float sq = 0.f, litem = 0.f, luser = 0.f;
+    if (t < B) {
+        const float4 eu = ld4(Usrc + (size_t)u[t] * d + 4 * g.sub);
+        const float4 ei = ld4(Isrc + (size_t)i[t] * d + 4 * g.sub);
+        const float4 ej = ld4(Isrc + (size_t)j[t] * d + 4 * g.sub);
+        const float4 w4 = ld4(w + 4 * g.sub), wu4 = ld4(wu + 4 * g.sub);
+        const float p = group_sum<LPR>(dot4(eu, ei));
+        const float n = group_sum<LPR>(dot4(eu, ej));
+        const float si = group_sum<LPR>(dot4(ei, w4));
+        const float sj = group_sum<LPR>(dot4(ej, w4));
+        const float su = group_sum<LPR>(dot4(eu, wu4));
+        if (reg_on_gathered) sq = dot4(eu, eu) + dot4(ei, ei) + dot4(ej, ej);
+        if (g.sub == 0) {
+            const float eps = 1e-10f;
+            const float ssi = sigmoid_acc(si), ssj = sigmoid_acc(sj), ssu = sigmoid_acc(su);
+            fwd[0 * (size_t)Bp + t] = p;
+            fwd[1 * (size_t)Bp + t] = n;
+            fwd[2 * (size_t)Bp + t] = ssi * ssu;
+            fwd[3 * (size_t)Bp + t] = ssj * ssu;
+            fwd[4 * (size_t)Bp + t] = ssi;
+            fwd[5 * (size_t)Bp + t] = ssj;
+            fwd[6 * (size_t)Bp + t] = ssu;
+            litem = -logf(ssi + eps) + -logf((1.0f - ssj) + eps);
+            luser = -logf(ssu + eps) + -logf((1.0f - ssu) + eps);
+        }
+    }
+    const float s0 = block_sum(sq, red);
+    const float s1 = block_sum(litem, red);
+    const float s2 = block_sum(luser, red);
+    if (threadIdx.x == 0) {
+        float *o = part + (size_t)blockIdx.x * kPartStride;
+        o[0] = s0; o[1] = s1; o[2] = s2; o[3] = 0.f;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// bxb: the (B,B) broadcast term of rubibceboth, entirely on chip.
+//   X[r,c]=a[r]*p[c], Y[r,c]=b[r]*n[c]                       macr_mf/model.py:204-205
+//   L_ori = mean(-log(sig(X)+1e-10) - log(1-sig(Y)+1e-10))   :211
+// and its gradient: row sums da,db and column sums dp,dn of f'(X), g'(Y).
+//
+// A wave owns a 64-row x 64-column tile: lane t holds row t for the whole tile and,
+// at iteration k, column (t+k) mod 64.  The column's inputs (p,n) and its running
+// column sums travel with it: after every iteration the four registers are rotated
+// one lane down the wave with DPP (v_mov_b32_dpp wave_rol:1), so after 64 iterations
+// each column sum is back in its home lane holding the total over the wave's 64 rows.
+// Row sums never leave their lane.  No LDS traffic, no atomics in the inner loop; the
+// kernel is bound by the transcendental VALU rate (8 v_exp/v_log/v_rcp per pair).
+// Block = 4 waves = 256 rows x (NCT*64) columns; the waves' column sums meet in LDS once.
+//   rowpart [ncb][2][Bp], colpart [nrb][2][Bp], lpart [nrb*ncb]
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_rol1(float v) {      // lane i <- lane (i+1) mod 64
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x134, 0xf, 0xf, true));
+}
+
+template <int NCT, bool FULL>
+__global__ __launch_bounds__(256) void k_bxb(int B, int Bp, const float *__restrict__ fwd,
+                                             float *__restrict__ rowpart, float *__restrict__ colpart,
+                                             float *__restrict__ lpart) {
+    constexpr int CT = NCT * 64;
+    __shared__ float s_col[4][2][CT];
+    __shared__ float red[16];
+    const int cb = blockIdx.x, rb = blockIdx.y, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int r = rb * 256 + t;
+    const float *p = fwd, *n = fwd + Bp, *a = fwd + 2 * (size_t)Bp, *b = fwd + 3 * (size_t)Bp;
+    const bool rok = FULL || r < B;
+    const float ar = rok ? a[r] : 0.f, br = rok ? b[r] : 0.f;
+    const float eps = 1e-10f;
+    const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+    float da = 0.f, db = 0.f, l2sum = 0.f;     // l2sum accumulates log2 terms; scaled by ln2 at the end
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int c0 = cb * CT + ct * 64;
+        const bool cok = FULL || (c0 + lane < B);
+        float pc = cok ? p[c0 + lane] : 0.f, nc = cok ? n[c0 + lane] : 0.f;
+        float accp = 0.f, accn = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) {
+            const float x = pc * ar, y = nc * br;
+            // sigmoid = 1/(1+exp(-x)) with the hardware exp2 / rcp (1 ulp each)
+            const float sx = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * x));
+            const float sy = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * y));
+            const float tx = sx + eps, omy = 1.0f - sy, ty = omy + eps;
+            float lx = __builtin_amdgcn_logf(tx), ly = __builtin_amdgcn_logf(ty);
+            float gx = -(sx * (1.0f - sx)) * __builtin_amdgcn_rcpf(tx);
+            float gy = (sy * omy) * __builtin_amdgcn_rcpf(ty);
+            if (!FULL) {
+                const bool ok = rok && (c0 + ((lane + k) & 63) < B);
+                lx = ok ? lx : 0.f; ly = ok ? ly : 0.f; gx = ok ? gx : 0.f; gy = ok ? gy : 0.f;
+            }
+            l2sum -= lx + ly;
+            da = fmaf(gx, pc, da);
+            db = fmaf(gy, nc, db);
+            accp = fmaf(gx, ar, accp);
+            accn = fmaf(gy, br, accn);
+            pc = wave_rol1(pc); nc = wave_rol1(nc); accp = wave_rol1(accp); accn = wave_rol1(accn);
+        }
+        s_col[wid][0][ct * 64 + lane] = accp;      // home again: column c0+lane over this wave's rows
+        s_col[wid][1][ct * 64 + lane] = accn;
+    }
+    if (rok) {
+        rowpart[((size_t)cb * 2 + 0) * Bp + r] = da;
+        rowpart[((size_t)cb * 2 + 1) * Bp + r] = db;
+    }
+    const float lsum = block_sum(l2sum * kLn2, red);   // contains the barrier that publishes s_col
+    if (t == 0) lpart[(size_t)rb * gridDim.x + cb] = lsum;
+    for (int c = t; c < CT; c += 256) {
+        const int gc = cb * CT + c;
+        if (FULL || gc < B) {
+            colpart[((size_t)rb * 2 + 0) * Bp + gc] = (s_col[0][0][c] + s_col[1][0][c]) + (s_col[2][0][c] + s_col[3][0][c]);
+            colpart[((size_t)rb * 2 + 1) * Bp + gc] = (s_col[0][1][c] + s_col[1][1][c]) + (s_col[2][1][c] + s_col[3][1][c]);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// pair_bwd (rubibceboth): gradient rows + scatter-add.           SURVEY.md A.1
+//   dp,dn (column sums) and da,db (row sums) come from the bxb partials / B^2
+//   dsi=da*sig'(si)*sig(su)+(alpha/B)f'(si) ...  deu=dp*ei+dn*ej+dsu*wu+coef*eu ...
+//   gU[u]+=deu, gI[i]+=dei, gI[j]+=dej  (duplicates summed = TF IndexedSlices
+//   de-duplication before the sparse apply, macr_mf/model.py:74)
+//   gw+=ei*dsi+ej*dsj, gwu+=eu*dsu
+// Scatter uses hardware fp32 atomics (global_atomic_add_f32): hot items (Addressa
+// item 0 is in half of the batch) pipeline in L2 instead of serialising a CAS loop.
+// ----------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void k_pair_bwd(
+    int B, int Bp, int nrb, int ncb, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+    const int32_t *__restrict__ j, const float *__restrict__ Usrc, const float *__restrict__ Isrc,
+    const float *__restrict__ w, const float *__restrict__ wu, const float *__restrict__ fwd,
+    const float *__restrict__ rowpart, const float *__restrict__ colpart,
+    float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *gw, float *gwu,
+    float alpha, float beta, float coef) {
+    constexpr int d = 4 * LPR;
+    constexpr int RPB = RowGroup<LPR>::kRowsPerBlock;
+    __shared__ float4 s_w[RPB][LPR], s_wu[RPB][LPR];
+    RowGroup<LPR> g;
+    const int t = blockIdx.x * RPB + g.slot;
+    float4 aw = make_float4(0, 0, 0, 0), awu = aw;
+    if (t < B) {
+        // sum the partials cooperatively inside the group
+        float dp = 0.f, dn = 0.f, da = 0.f, db = 0.f;
+#ifndef MACR_ABL_NOPART
+        for (int k = g.sub; k < nrb; k += LPR) {
+            dp += colpart[((size_t)k * 2 + 0) * Bp + t];
+            dn += colpart[((size_t)k * 2 + 1) * Bp + t];
+        }
+        for (int k = g.sub; k < ncb; k += LPR) {
+            da += rowpart[((size_t)k * 2 + 0) * Bp + t];
+            db += rowpart[((size_t)k * 2 + 1) * Bp + t];
+        }
+#endif
+        const float inv_b2 = 1.0f / ((float)B * (float)B);
+        dp = group_sum<LPR>(dp) * inv_b2; dn = group_sum<LPR>(dn) * inv_b2;
+        da = group_sum<LPR>(da) * inv_b2; db = group_sum<LPR>(db) * inv_b2;
+        const float eps = 1e-10f, invB = 1.0f / (float)B;
+        const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
+        const float dsi = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
+        const float dsj = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
+        const float dsu = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
+                          (beta * invB) * (dneglog_sig(ssu, eps) + dneglog_1msig(ssu, eps));
+        const int ru = u[t], ri = i[t], rj = j[t];
+        const float4 eu = ld4(Usrc + (size_t)ru * d + 4 * g.sub);
+        const float4 ei = ld4(Isrc + (size_t)ri * d + 4 * g.sub);
+        const float4 ej = ld4(Isrc + (size_t)rj * d + 4 * g.sub);
+        const float4 w4 = ld4(w + 4 * g.sub), wu4 = ld4(wu + 4 * g.sub);
+        float4 gu = scale4(dp, ei); gu = fma4(dn, ej, gu); gu = fma4(dsu, wu4, gu); gu = fma4(coef, eu, gu);
+        float4 gi = scale4(dp, eu); gi = fma4(dsi, w4, gi); gi = fma4(coef, ei, gi);
+        float4 gj = scale4(dn, eu); gj = fma4(dsj, w4, gj); gj = fma4(coef, ej, gj);
+        float *pu = gU + (size_t)ru * d + 4 * g.sub, *pi = gI + (size_t)ri * d + 4 * g.sub,
+              *pj = gI + (size_t)rj * d + 4 * g.sub;
+        MACR_ATOMIC_ADD(pu + 0, gu.x); MACR_ATOMIC_ADD(pu + 1, gu.y); MACR_ATOMIC_ADD(pu + 2, gu.z); MACR_ATOMIC_ADD(pu + 3, gu.w);
+        MACR_ATOMIC_ADD(pi + 0, gi.x); MACR_ATOMIC_ADD(pi + 1, gi.y); MACR_ATOMIC_ADD(pi + 2, gi.z); MACR_ATOMIC_ADD(pi + 3, gi.w);
+        MACR_ATOMIC_ADD(pj + 0, gj.x); MACR_ATOMIC_ADD(pj + 1, gj.y); MACR_ATOMIC_ADD(pj + 2, gj.z); MACR_ATOMIC_ADD(pj + 3, gj.w);
+        if (g.sub == 0 && touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
+        aw = scale4(dsi, ei); aw = fma4(dsj, ej, aw);
+        awu = scale4(dsu, eu);
+    }
+    // reduce the branch-vector gradients over the block's rows, one atomic per float per block
+    s_w[g.slot][g.sub] = aw;
+    s_wu[g.slot][g.sub] = awu;
+    __syncthreads();
+    if (threadIdx.x < LPR) {
+        float4 sw = make_float4(0, 0, 0, 0), swu = sw;
+        for (int k = 0; k < RPB; ++k) { sw = add4(sw, s_w[k][threadIdx.x]); swu = add4(swu, s_wu[k][threadIdx.x]); }
+        float *pw = gw + 4 * threadIdx.x, *pwu = gwu + 4 * threadIdx.x;
+        MACR_ATOMIC_ADD(pw + 0, sw.x); MACR_ATOMIC_ADD(pw + 1, sw.y); MACR_ATOMIC_ADD(pw + 2, sw.z); MACR_ATOMIC_ADD(pw + 3, sw.w);
+        MACR_ATOMIC_ADD(pwu + 0, swu.x); MACR_ATOMIC_ADD(pwu + 1, swu.y); MACR_ATOMIC_ADD(pwu + 2, swu.z); MACR_ATOMIC_ADD(pwu + 3, swu.w);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// pair_normal: `normalbce` forward + backward in one pass (genuinely per pair).
+//   mf = mean(-log(sig(p)+1e-9) - log(1-sig(n)+1e-9))            macr_mf/model.py:277-287
+//   dp = f'(p)/B, dn = g'(n)/B;  deu=dp*ei+dn*ej, dei=dp*eu, dej=dn*eu (+coef*row)
+// Algorithmic HBM bytes per triple: 3 rows read + 3 gradient rows written + 12 B indices
+// = 24*d+12.
+// ----------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void k_pair_normal(
+    int B, const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
+    const float *__restrict__ Usrc, const float *__restrict__ Isrc,
+    float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *__restrict__ part, float coef,
+    int reg_on_gathered, const float *__restrict__ adam_pow_in, float *adam_pow_out, StepScalars *scal,
+    float lr, float b1, float b2) {
+    constexpr int d = 4 * LPR;
+    __shared__ float red[16];
+    RowGroup<LPR> g;
+    const int t = blockIdx.x * RowGroup<LPR>::kRowsPerBlock + g.slot;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float p1 = adam_pow_in[0], p2 = adam_pow_in[1];
+        scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
+        adam_pow_out[0] = p1 * b1;
+        adam_pow_out[1] = p2 * b2;
+    }
+    float sq = 0.f, bce = 0.f;
+    if (t < B) {
+        const int ru = u[t], ri = i[t], rj = j[t];
+        const float4 eu = ld4(Usrc + (size_t)ru * d + 4 * g.sub);
+        const float4 ei = ld4(Isrc + (size_t)ri * d + 4 * g.sub);
+        const float4 ej = ld4(Isrc + (size_t)rj * d + 4 * g.sub);
+        const float p = group_sum<LPR>(dot4(eu, ei));
+        const float n = group_sum<LPR>(dot4(eu, ej));
+        if (reg_on_gathered) sq = dot4(eu, eu) + dot4(ei, ei) + dot4(ej, ej);
+        const float eps = 1e-9f, invB = 1.0f / (float)B;
+        const float sp = sigmoid_acc(p), sn = sigmoid_acc(n);
+        if (g.sub == 0) bce = -logf(sp + eps) + -logf((1.0f - sn) + eps);
+        const float dp = dneglog_sig(sp, eps) * invB, dn = dneglog_1msig(sn, eps) * invB;
+        float4 gu = scale4(dp, ei); gu = fma4(dn, ej, gu); gu = fma4(coef, eu, gu);
+        float4 gi = scale4(dp, eu); gi = fma4(coef, ei, gi);
+        float4 gj = scale4(dn, eu); gj = fma4(coef, ej, gj);
+        float *pu = gU + (size_t)ru * d + 4 * g.sub, *pi = gI + (size_t)ri * d + 4 * g.sub,
+              *pj = gI + (size_t)rj * d + 4 * g.sub;
+        MACR_ATOMIC_ADD(pu + 0, gu.x); MACR_ATOMIC_ADD(pu + 1, gu.y); MACR_ATOMIC_ADD(pu + 2, gu.z); MACR_ATOMIC_ADD(pu + 3, gu.w);
+        MACR_ATOMIC_ADD(pi + 0, gi.x); MACR_ATOMIC_ADD(pi + 1, gi.y); MACR_ATOMIC_ADD(pi + 2, gi.z); MACR_ATOMIC_ADD(pi + 3, gi.w);
+        MACR_ATOMIC_ADD(pj + 0, gj.x); MACR_ATOMIC_ADD(pj + 1, gj.y); MACR_ATOMIC_ADD(pj + 2, gj.z); MACR_ATOMIC_ADD(pj + 3, gj.w);
+        if (g.sub == 0 && touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
+    }
+    const float s0 = block_sum(sq, red);
+    const float s3 = block_sum(bce, red);
+    if (threadIdx.x == 0) {
+        float *o = part + (size_t)blockIdx.x * kPartStride;
+        o[0] = s0; o[1] = 0.f; o[2] = 0.f; o[3] = s3;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// reg_scatter (LightGCN): the l2 regulariser acts on the EGO rows
+// (macr_lightgcn/LightGCN.py:525-528): G[row] += (decay/batch_size)*T[row] for the
+// batch rows, and the sum of squares for emb_loss.
+// ----------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const int32_t *__restrict__ u,
+                                                     const int32_t *__restrict__ i, const int32_t *__restrict__ j,
+                                                     const float *__restrict__ T, float *G, float coef,
+                                                     float *__restrict__ part) {
+    constexpr int d = 4 * LPR;
+    __shared__ float red[16];
+    RowGroup<LPR> g;
+    const int t = blockIdx.x * RowGroup<LPR>::kRowsPerBlock + g.slot;
+    float sq = 0.f;
+    if (t < B) {
+        const int rows[3] = {u[t], i[t] + item_off, j[t] + item_off};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 e = ld4(T + (size_t)rows[q] * d + 4 * g.sub);
+            sq += dot4(e, e);
+            float *pg = G + (size_t)rows[q] * d + 4 * g.sub;
+            MACR_ATOMIC_ADD(pg + 0, coef * e.x); MACR_ATOMIC_ADD(pg + 1, coef * e.y);
+            MACR_ATOMIC_ADD(pg + 2, coef * e.z); MACR_ATOMIC_ADD(pg + 3, coef * e.w);
+        }
+    }
+    const float s0 = block_sum(sq, red);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * kPartStride] = s0;    // slot 0 only
+}
+
+// ----------------------------------------------------------------------------
+// adam_dense: tf.train.AdamOptimizer as TF 1.14 applies it to embedding tables
+// (macr_mf/model.py:74,:95): EVERY row decays m,v and moves every
+// step; rows touched by the batch additionally consume their summed gradient.
+//   m=b1*m+(1-b1)g; v=b2*v+(1-b2)g^2; theta-=lr_t*m/(sqrt(v)+eps)
+// Streaming kernel, float4 per lane: 24*d bytes per row (read+write theta,m,v) plus a
+// 4-byte touched flag; the gradient row is read (and re-zeroed) only when flagged.
+// Block 0 also reduces the loss partials of the step into losses[3].
+// ----------------------------------------------------------------------------
+struct AdamSeg {
+    float *theta, *m, *v, *g;
+    int32_t *touched;        // NULL: gradient is dense, always read, left untouched
+    long long n_vec;         // number of float4 in the segment
+    long long first_block;   // first block index serving this segment
+};
+struct AdamArgs {
+    AdamSeg seg[4];
+    int n_seg;
+    int lpr;                 // float4 per row
+};
+struct LossArgs {
+    const float *part; int n_part;       // pair-kernel partials  [n_part][4]
+    const float *part2; int n_part2;     // second partial set (LightGCN ego regulariser), slot 0 only
+    const float *lpart; int n_lpart;     // bxb loss partials
+    int kind, B, batch_size_cfg;
+    float alpha, beta, decay;
+    float *losses;
+};
+
+constexpr int kAdamVecPerBlock = 256 * 4;   // each thread handles 4 float4 per segment pass
+
+__global__ __launch_bounds__(256) void k_adam_dense(AdamArgs a, const StepScalars *scal, float b1, float b2,
+                                                    float eps, LossArgs L) {
+    const float lr_t = scal->lr_t;
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < a.n_seg && (long long)blockIdx.x >= a.seg[k].first_block) s = k;
+    const AdamSeg sg = a.seg[s];
+    const long long base = ((long long)blockIdx.x - sg.first_block) * kAdamVecPerBlock + threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const long long vi = base + (long long)it * 256;
+        if (vi < sg.n_vec) {
+            float4 th = ld4(sg.theta + vi * 4), m = ld4(sg.m + vi * 4), v = ld4(sg.v + vi * 4);
+            float4 gr = make_float4(0, 0, 0, 0);
+            if (sg.touched) {
+                const long long row = vi / a.lpr;
+                if (sg.touched[row]) {
+                    gr = ld4(sg.g + vi * 4);
+                    st4(sg.g + vi * 4, make_float4(0, 0, 0, 0));
+                    if (vi % a.lpr == 0) sg.touched[row] = 0;
+                }
+            } else if (sg.g) {
+                gr = ld4(sg.g + vi * 4);
+            }
+            m.x = m.x * b1 + gr.x * omb1; m.y = m.y * b1 + gr.y * omb1; m.z = m.z * b1 + gr.z * omb1; m.w = m.w * b1 + gr.w * omb1;
+            v.x = v.x * b2 + (gr.x * gr.x) * omb2; v.y = v.y * b2 + (gr.y * gr.y) * omb2;
+            v.z = v.z * b2 + (gr.z * gr.z) * omb2; v.w = v.w * b2 + (gr.w * gr.w) * omb2;
+            th.x -= (lr_t * m.x) / (sqrtf(v.x) + eps); th.y -= (lr_t * m.y) / (sqrtf(v.y) + eps);
+            th.z -= (lr_t * m.z) / (sqrtf(v.z) + eps); th.w -= (lr_t * m.w) / (sqrtf(v.w) + eps);
+            st4(sg.theta + vi * 4, th); st4(sg.m + vi * 4, m); st4(sg.v + vi * 4, v);
+        }
+    }
+    if (blockIdx.x == 0 && L.losses) {
+        // deterministic reduction of the step's loss partials (double), one wave
+        if (threadIdx.x < 64) {
+            double sq = 0, li = 0, lu = 0, bce = 0, lo = 0;
+            for (int k = threadIdx.x; k < L.n_part; k += 64) {
+                const float *o = L.part + (size_t)k * kPartStride;
+                sq += o[0]; li += o[1]; lu += o[2]; bce += o[3];
+            }
+            for (int k = threadIdx.x; k < L.n_part2; k += 64) sq += L.part2[(size_t)k * kPartStride];
+            for (int k = threadIdx.x; k < L.n_lpart; k += 64) lo += L.lpart[k];
+            sq = wave_sum_d(sq); li = wave_sum_d(li); lu = wave_sum_d(lu); bce = wave_sum_d(bce); lo = wave_sum_d(lo);
+            if (threadIdx.x == 0) {
+                const double Bd = (double)L.B;
+                float mf;
+                if (L.kind == MACR_LOSS_NORMALBCE) {
+                    mf = (float)(bce / Bd);
+                } else {
+                    const float Lo = (float)(lo / (Bd * Bd)), Li = (float)(li / Bd), Lu = (float)(lu / Bd);
+                    mf = Lo + L.alpha * Li + L.beta * Lu;               // macr_mf/model.py:217
+                }
+                float regularizer = (float)(0.5 * sq);                  // tf.nn.l2_loss x3  (:219)
+                regularizer = regularizer / (float)L.batch_size_cfg;    // (:220)
+                const float reg = L.decay * regularizer;                // (:221)
+                L.losses[0] = mf + reg; L.losses[1] = mf; L.losses[2] = reg;
+            }
+        }
+    }
+}
+
+}  // namespace macr
+
+// ============================================================================
+// Host side: workspace carving + launch sequences (C ABI)
+// ============================================================================
+namespace macr {
+
+int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
+                     const float *E0, float *E, float *work, hipStream_t st);   // spmm_kernels.hip
+
+static inline int bxb_ct(int B) {
+    // columns per block (64 per column tile): more, smaller blocks for small B so the chip stays full
+    if (B >= 8192) return 256;
+    if (B >= 2048) return 128;
+    return 64;
+}
+
+struct PairWs {
+    StepScalars *scal;
+    float *gw;          // [2*d]  (gw, gwu)
+    float *fwd;         // [7*Bp]
+    float *part;        // [nblk_pair*4]
+    float *part2;       // [nblk_pair*4]   (LightGCN ego regulariser)
+    float *lpart;       // [nrb*ncb]
+    float *rowpart;     // [ncb*2*Bp]
+    float *colpart;     // [nrb*2*Bp]
+    int Bp, nrb, ncb, ct, nblk_pair;
+    size_t bytes;
+};
+
+static PairWs carve_pair_ws(void *base, int B, int d) {
+    PairWs w;
+    const int lpr = d / 4, rpb = 256 / lpr;
+    w.Bp = (int)align_up((size_t)B, 256);
+    w.ct = bxb_ct(B);
+    w.nrb = w.Bp / 256;
+    w.ncb = (B + w.ct - 1) / w.ct;
+    w.nblk_pair = (B + rpb - 1) / rpb;
+    char *p = static_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void *r = p ? p + off : nullptr; off += align_up(bytes, 256); return r; };
+    w.scal = static_cast<StepScalars *>(take(sizeof(StepScalars)));
+    w.gw = static_cast<float *>(take((size_t)2 * d * 4));
+    w.fwd = static_cast<float *>(take((size_t)7 * w.Bp * 4));
+    w.part = static_cast<float *>(take((size_t)w.nblk_pair * kPartStride * 4));
+    w.part2 = static_cast<float *>(take((size_t)w.nblk_pair * kPartStride * 4));
+    w.lpart = static_cast<float *>(take((size_t)w.nrb * w.ncb * 4));
+    w.rowpart = static_cast<float *>(take((size_t)w.ncb * 2 * w.Bp * 4));
+    w.colpart = static_cast<float *>(take((size_t)w.nrb * 2 * w.Bp * 4));
+    w.bytes = off;
+    return w;
+}
+
+template <int NCT>
+static void launch_bxb_ct(const PairWs &ws, int B, hipStream_t st) {
+    dim3 grid(ws.ncb, ws.nrb);
+    const bool full = (B % 256 == 0) && (B % (NCT * 64) == 0);
+    if (full) k_bxb<NCT, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.fwd, ws.rowpart, ws.colpart, ws.lpart);
+    else      k_bxb<NCT, false><<<grid, 256, 0, st>>>(B, ws.Bp, ws.fwd, ws.rowpart, ws.colpart, ws.lpart);
+}
+
+// forward + (B,B) + backward of the pair loss; gradients are atomically added into gU/gI.
+static int launch_pair(int kind, int B, int d, const int32_t *u, const int32_t *i, const int32_t *j,
+                       const float *Usrc, const float *Isrc, const float *w, const float *wu,
+                       float *gU, float *gI, int32_t *tU, int32_t *tI, float coef, int reg_on_gathered,
+                       float *adam_pow, const macr_hyper *hp, const PairWs &ws, hipStream_t st) {
+    const int grid = ws.nblk_pair;
+    if (kind == MACR_LOSS_NORMALBCE) {
+        MACR_DISPATCH_LPR(d, (k_pair_normal<LPR><<<grid, 256, 0, st>>>(B, u, i, j, Usrc, Isrc, gU, gI, tU, tI, ws.part,
+                                                                      coef, reg_on_gathered, adam_pow, adam_pow,
+                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2)));
+        MACR_CHECK_LAUNCH("pair_normal", st);
+        return MACR_OK;
+    }
+    MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd, ws.part,
+                                                               reg_on_gathered, adam_pow, adam_pow, ws.scal, hp->lr,
+                                                               hp->beta1, hp->beta2, ws.gw)));
+    MACR_CHECK_LAUNCH("pair_fwd", st);
+    switch (ws.ct) {
+        case 64: launch_bxb_ct<1>(ws, B, st); break;
+        case 128: launch_bxb_ct<2>(ws, B, st); break;
+        default: launch_bxb_ct<4>(ws, B, st); break;
+    }
+    MACR_CHECK_LAUNCH("bxb", st);
+    MACR_DISPATCH_LPR(d, (k_pair_bwd<LPR><<<grid, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu,
+                                                               ws.fwd, ws.rowpart, ws.colpart, gU, gI, tU, tI, ws.gw,
+                                                               ws.gw + d, hp->alpha, hp->beta, coef)));
+    MACR_CHECK_LAUNCH("pair_bwd", st);
+    return MACR_OK;
+}
+
+static void add_seg(AdamArgs &a, float *theta, float *m, float *v, float *g, int32_t *touched, long long rows,
+                    long long &next_block) {
+    AdamSeg &s = a.seg[a.n_seg++];
+    s.theta = theta; s.m = m; s.v = v; s.g = g; s.touched = touched;
+    s.n_vec = rows * a.lpr;
+    s.first_block = next_block;
+    next_block += (s.n_vec + kAdamVecPerBlock - 1) / kAdamVecPerBlock;
+}
+
+static int validate_hyper(const macr_hyper *hp, const char *who) {
+    MACR_REQUIRE(hp, MACR_E_INVALID, "%s: hyper is null", who);
+    MACR_REQUIRE(hp->batch_size_cfg > 0, MACR_E_INVALID, "%s: batch_size_cfg=%d", who, hp->batch_size_cfg);
+    MACR_REQUIRE(hp->beta1 > 0.f && hp->beta1 < 1.f && hp->beta2 > 0.f && hp->beta2 < 1.f, MACR_E_INVALID,
+                 "%s: adam betas (%g,%g) outside (0,1)", who, hp->beta1, hp->beta2);
+    return MACR_OK;
+}
+
+}  // namespace macr
+
+using namespace macr;
+
+extern "C" size_t macr_mf_train_workspace_bytes(int B, int d) {
+    if (B <= 0 || !dim_supported(d)) return 0;
+    return carve_pair_ws(nullptr, B, d).bytes;
+}
+
+extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items, const int32_t *u,
+                                  const int32_t *i, const int32_t *j, float *P, float *Q, float *w, float *wu,
+                                  float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
+                                  float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                                  float *adam_pow, const macr_hyper *hp, float *losses, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || loss_kind == MACR_LOSS_RUBIBCEBOTH, MACR_E_INVALID,
+                 "mf_train_step: loss_kind=%d", loss_kind);
+    MACR_REQUIRE(B > 0 && n_users > 0 && n_items > 0, MACR_E_INVALID, "mf_train_step: B=%d n_users=%d n_items=%d", B,
+                 n_users, n_items);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "mf_train_step: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(u && i && j && P && Q && mP && vP && mQ && vQ && gP && gQ && touchedP && touchedQ && adam_pow &&
+                     losses && workspace, MACR_E_INVALID, "mf_train_step: null pointer");
+    MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || (w && wu && mw && vw && mwu && vwu), MACR_E_INVALID,
+                 "mf_train_step: rubibceboth needs w, wu and their Adam slots");
+    if (int e = validate_hyper(hp, "mf_train_step")) return e;
+    PairWs ws = carve_pair_ws(workspace, B, d);
+    MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "mf_train_step: workspace %zu < %zu bytes",
+                 workspace_bytes, ws.bytes);
+    MACR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
+                 "mf_train_step: workspace must be 256-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const float coef = hp->decay / (float)hp->batch_size_cfg;       // d reg / d row  (model.py:219-221)
+    if (int e = launch_pair(loss_kind, B, d, u, i, j, P, Q, w, wu, gP, gQ, touchedP, touchedQ, coef, 1, adam_pow, hp,
+                            ws, st))
+        return e;
+    AdamArgs a;
+    a.n_seg = 0;
+    a.lpr = d / 4;
+    long long nb = 0;
+    add_seg(a, P, mP, vP, gP, touchedP, n_users, nb);
+    add_seg(a, Q, mQ, vQ, gQ, touchedQ, n_items, nb);
+    if (loss_kind == MACR_LOSS_RUBIBCEBOTH) {       // w, w_user receive gradients only here (model.py:74 vs :95)
+        add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb);
+        add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb);
+    }
+    LossArgs L;
+    L.part = ws.part; L.n_part = ws.nblk_pair; L.part2 = nullptr; L.n_part2 = 0;
+    L.lpart = ws.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.nrb * ws.ncb : 0;
+    L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
+    L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
+    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, hp->beta1, hp->beta2, hp->adam_eps, L);
+    MACR_CHECK_LAUNCH("adam_dense", st);
+    return MACR_OK;
+}
+
+// ---- LightGCN ---------------------------------------------------------------
+namespace macr {
+struct LgcnWs { float *E, *dE, *G, *work; PairWs pair; size_t bytes; };
+static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d) {
+    LgcnWs w;
+    char *p = static_cast<char *>(base);
+    const size_t nd = align_up((size_t)N * d * 4, 256);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void *r = p ? p + off : nullptr; off += bytes; return r; };
+    w.E = static_cast<float *>(take(nd));
+    w.dE = static_cast<float *>(take(nd));
+    w.G = static_cast<float *>(take(nd));
+    w.work = static_cast<float *>(take(2 * nd));
+    w.pair = carve_pair_ws(p ? p + off : nullptr, B, d);
+    off += w.pair.bytes;
+    w.bytes = off;
+    return w;
+}
+}  // namespace macr
+
+extern "C" size_t macr_lgcn_train_workspace_bytes(int B, int N, int d) {
+    if (B <= 0 || N <= 0 || !dim_supported(d)) return 0;
+    return carve_lgcn_ws(nullptr, B, N, d).bytes;
+}
+
+extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
+                                    const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *u,
+                                    const int32_t *i, const int32_t *j, float *T, float *w, float *wu, float *mT,
+                                    float *vT, float *mw, float *vw, float *mwu, float *vwu, float *adam_pow,
+                                    const macr_hyper *hp, float *losses, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+    MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || loss_kind == MACR_LOSS_RUBIBCEBOTH, MACR_E_INVALID,
+                 "lgcn_train_step: loss_kind=%d", loss_kind);
+    MACR_REQUIRE(B > 0 && n_users > 0 && n_items > 0 && n_layers >= 0, MACR_E_INVALID,
+                 "lgcn_train_step: B=%d n_users=%d n_items=%d n_layers=%d", B, n_users, n_items, n_layers);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "lgcn_train_step: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(rowptr && col && val && u && i && j && T && mT && vT && adam_pow && losses && workspace,
+                 MACR_E_INVALID, "lgcn_train_step: null pointer");
+    MACR_REQUIRE(w && wu && mw && vw && mwu && vwu, MACR_E_INVALID, "lgcn_train_step: null branch vectors");
+    if (int e = validate_hyper(hp, "lgcn_train_step")) return e;
+    const int N = n_users + n_items;
+    LgcnWs ws = carve_lgcn_ws(workspace, B, N, d);
+    MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "lgcn_train_step: workspace %zu < %zu bytes",
+                 workspace_bytes, ws.bytes);
+    MACR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
+                 "lgcn_train_step: workspace must be 256-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const size_t nd = (size_t)N * d;
+    // forward propagation (LightGCN.py:288-309)
+    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, T, ws.E, ws.work, st)) return e;
+    hipError_t he = hipMemsetAsync(ws.dE, 0, nd * 4, st);
+    MACR_REQUIRE(he == hipSuccess, MACR_E_LAUNCH, "lgcn_train_step: memset: %s", hipGetErrorString(he));
+    // pair loss on the propagated rows; items live at rows n_users.. of E
+    float *Ei = ws.E + (size_t)n_users * d, *dEi = ws.dE + (size_t)n_users * d;
+    if (int e = launch_pair(loss_kind, B, d, u, i, j, ws.E, Ei, w, wu, ws.dE, dEi, nullptr, nullptr, 0.0f, 0, adam_pow,
+                            hp, ws.pair, st))
+        return e;
+    // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
+    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, ws.dE, ws.G, ws.work, st)) return e;
+    // l2 regulariser on the ego rows (LightGCN.py:525-528)
+    const float coef = hp->decay / (float)hp->batch_size_cfg;
+    MACR_DISPATCH_LPR(d, (k_reg_scatter<LPR><<<ws.pair.nblk_pair, 256, 0, st>>>(B, n_users, u, i, j, T, ws.G, coef,
+                                                                               ws.pair.part2)));
+    MACR_CHECK_LAUNCH("reg_scatter", st);
+    AdamArgs a;
+    a.n_seg = 0;
+    a.lpr = d / 4;
+    long long nb = 0;
+    add_seg(a, T, mT, vT, ws.G, nullptr, N, nb);
+    if (loss_kind == MACR_LOSS_RUBIBCEBOTH) {
+        add_seg(a, w, mw, vw, ws.pair.gw, nullptr, 1, nb);
+        add_seg(a, wu, mwu, vwu, ws.pair.gw + d, nullptr, 1, nb);
+    }
+    LossArgs L;
+    L.part = ws.pair.part; L.n_part = ws.pair.nblk_pair; L.part2 = ws.pair.part2; L.n_part2 = ws.pair.nblk_pair;
+    L.lpart = ws.pair.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.pair.nrb * ws.pair.ncb : 0;
+    L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
+    L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
+    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.pair.scal, hp->beta1, hp->beta2, hp->adam_eps, L);
+    MACR_CHECK_LAUNCH("adam_dense", st);
+    return MACR_OK;
+}

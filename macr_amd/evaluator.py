@@ -1,0 +1,88 @@
+"""Full-catalogue top-K evaluator on the HIP path.
+
+Replaces the per-batch  sess.run(ratings) -> host  -> per-user Python/C++ ranking
+of the reference:
+  * macr_mf/train.py  test() :162-311  (+ test_one_user :119-138, metrics :32-117)
+  * macr_lightgcn/utility/batch_test.py  test() :26-162  (+ evaluator/cpp)
+with: branch sigmoids -> fused scoring/mask/top-K (MFMA) -> merge of splits ->
+[multi-GPU: one RCCL all-gather of the per-shard top-K + merge] -> metrics
+kernel -> column means.  Nothing U x N ever leaves the device (or exists).
+
+Both reference evaluators batch the users by BATCH_SIZE; every per-user result
+is independent of the batching, so all query users are ranked in one pass.
+"""
+import numpy as np
+import torch
+
+from . import ops, sharding
+
+
+class Evaluator(object):
+    def __init__(self, mask_lists, gt_lists, n_items, device):
+        """mask_lists[q]: the train items of query user q (excluded from ranking, train.py:132-133 /
+        batch_test.py:124-129); gt_lists[q]: its test (or valid) items."""
+        assert len(mask_lists) == len(gt_lists)
+        self.n_queries = len(gt_lists)
+        self.n_items = n_items
+        self.device = device
+        self.mask = ops.CSR.from_lists(mask_lists, device)
+        self.gt = ops.CSR.from_lists(gt_lists, device)
+
+    # ------------------------------------------------------------------ ranking
+    def rank(self, kind, users_tab, user_ids, items_tab, K, w=None, wu=None, c=0.0, fill_masked=False):
+        """Top-K item ids for every query user: (val (U,K), idx (U,K), cnt (U,)).
+        users_tab/items_tab: full embedding tables (replicated on every rank); this rank scores
+        only its contiguous item shard and the shards' top-K are all-gathered and merged."""
+        rank, ws = sharding.world()
+        lo, hi = sharding.item_shard_range(items_tab.shape[0], rank, ws)
+        items_local = items_tab[lo:hi]
+        sig_u = sig_i = None
+        if kind == ops.SCORE_RUBI_BOTH:
+            sig_i = ops.branch_sigmoid(items_local, w)              # sigmoid(e_i . w)      model.py:199
+            sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199
+        vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, self.mask, lo)
+        fill = self.mask if fill_masked else None
+        if ws == 1:
+            return ops.topk_merge(vals, idx, fill)
+        lv, li, _ = ops.topk_merge(vals, idx)                        # merge this shard's splits
+        gv, gi = sharding.gather_topk(lv, li)                        # (W,U,K) over RCCL / xGMI
+        return ops.topk_merge(gv, gi, fill)
+
+    # ------------------------------------------------------------------ MF flavour
+    def test_mf(self, kind, users_tab, user_ids, items_tab, Ks, w=None, wu=None, c=0.0):
+        """-> {'precision','recall','ndcg','hit_ratio'}: np.ndarray(len(Ks)) float64, the mean over the
+        query users (train.py:286-290 accumulates re[...]/n_test_users)."""
+        Kmax = max(Ks)
+        _, idx, cnt = self.rank(kind, users_tab, user_ids, items_tab, Kmax, w, wu, c)
+        per_user = ops.metrics_mf(idx, cnt, self.gt, Ks)            # (U,4,nK) float64
+        m = ops.colmean(per_user).cpu().numpy()
+        return {'precision': m[0].copy(), 'recall': m[1].copy(), 'ndcg': m[2].copy(), 'hit_ratio': m[3].copy()}
+
+    # ------------------------------------------------------------------ LightGCN flavour
+    def test_lgcn(self, kind, users_tab, user_ids, items_tab, Ks, w=None, wu=None, c=0.0):
+        """-> {'hr','recall','ndcg'}: np.ndarray(len(Ks)) (batch_test.py:134-161): C++-style fp32 prefix
+        metrics, HR := 1[recall@k != 0], mean over users, columns Ks-1 in ascending-K order."""
+        top_show = np.sort(np.asarray(Ks))
+        max_top = int(top_show.max())
+        _, idx, _ = self.rank(kind, users_tab, user_ids, items_tab, max_top, w, wu, c, fill_masked=True)
+        per_user = ops.metrics_foldout(idx, self.gt, hr_in_ap_slot=True)      # (U,5*max_top) fp32
+        final = ops.colmean(per_user).cpu().numpy().reshape(5, max_top)[:, top_show - 1]
+        return {'hr': final[2].copy(), 'recall': final[1].copy(), 'ndcg': final[3].copy()}
+
+
+def eval_score_matrix_foldout(score_matrix, test_items, top_k=20, thread_num=None):
+    """Drop-in for macr_lightgcn/evaluator/cpp/evaluate_foldout.py:12-18 backed by the HIP kernels
+    (macr_topk_scores + macr_metrics_foldout).  score_matrix: (U,N) array-like with train items already
+    at -inf (batch_test.py:129); test_items: list of per-user ground-truth id lists.
+    Returns np.float32 (U, 5*top_k) laid out [precision|recall|ap|ndcg|mrr].  thread_num is accepted and
+    ignored.  Ties rank by ascending item id (the C++ leaves tie order to std::partial_sort_copy)."""
+    if len(score_matrix) != len(test_items):
+        raise ValueError("The lengths of score_matrix and test_items are not equal.")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if isinstance(score_matrix, torch.Tensor):
+        scores = score_matrix.to(device=dev, dtype=torch.float32).contiguous()
+    else:
+        scores = torch.from_numpy(np.ascontiguousarray(score_matrix, dtype=np.float32)).to(dev)
+    idx, _ = ops.topk_scores(scores, top_k, want_vals=False)
+    gt = ops.CSR.from_lists(test_items, dev)
+    return ops.metrics_foldout(idx, gt).cpu().numpy()

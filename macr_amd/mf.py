@@ -1,0 +1,211 @@
+"""MF family host model: the `BPRMF` object the MF CLI drives, on the HIP path.
+
+Mirrors the part of macr_mf/model.py::BPRMF (:13-326) that the README commands
+exercise:
+    --train normalbce   -> opt_bce / loss_bce / mf_loss_bce / reg_loss_bce           (:92-95, :277-287)
+    --train rubibceboth -> opt_two_bce_both / loss_two_bce_both / ...                (:71-74, :185-222)
+    --test  normal      -> batch_ratings                                             (:45)
+    --test  rubi        -> rubi_ratings_both + update_c                              (:199, :313)
+The reference builds a TF1 graph and the CLI talks to it through
+`sess.run(fetches, feed_dict)`; here the same attribute names are plain fetch
+handles and `Session.run` dispatches them to the C-ABI kernels, so a caller
+written against the reference keeps working.  The fast path (`train_step`,
+`Evaluator`) avoids the per-step host synchronisation `sess.run` implies.
+
+Everything else in model.py (bpr / rubi / rubibce / userc losses, BIASMF,
+IPS_BPRMF, CausalE) is out of scope and raises NotImplementedError.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class Fetch(object):
+    """Symbolic handle standing where the reference has a tf.Tensor / tf.Operation."""
+    __slots__ = ("name", "role", "kind")
+
+    def __init__(self, name, role, kind=None):
+        self.name, self.role, self.kind = name, role, kind
+
+    def __repr__(self):
+        return "<macr fetch %s>" % self.name
+
+
+def xavier_uniform(shape, generator, device):
+    """tf.contrib.layers.xavier_initializer(): U(-L, L), L = sqrt(6/(fan_in+fan_out)) with
+    fan_in=rows, fan_out=cols for a 2-D shape.  TF's Philox stream cannot be
+    replayed; values come from a torch.Generator (parity runs inject weights)."""
+    limit = math.sqrt(6.0 / (shape[0] + shape[1]))
+    t = (torch.rand(shape, generator=generator, dtype=torch.float32) * 2.0 - 1.0) * limit
+    return t.to(device)
+
+
+class BPRMF(object):
+    _TRAIN = {"normalbce": ("bce", ops.LOSS_NORMALBCE), "rubibceboth": ("two_bce_both", ops.LOSS_RUBIBCEBOTH)}
+
+    def __init__(self, args, data_config, device=None, seed=12345, weights=None):
+        self.n_users = data_config['n_users']
+        self.n_items = data_config['n_items']
+        self.decay = args.regs
+        self.emb_dim = args.embed_size
+        self.lr = args.lr
+        self.batch_size = args.batch_size
+        self.verbose = getattr(args, "verbose", 0)
+        self.c = args.c
+        self.alpha = args.alpha
+        self.beta = args.beta
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device
+        # placeholders (model.py:27-29)
+        self.users = Fetch("users", "placeholder")
+        self.pos_items = Fetch("pos_items", "placeholder")
+        self.neg_items = Fetch("neg_items", "placeholder")
+        # parameters (model.py:107-122, :59-60); rubi_c starts at 0 (:117)
+        self.weights = self.init_weights(seed, weights)
+        self.rubi_c = 0.0
+        hyper = ops.make_hyper(self.lr, self.decay, self.alpha, self.beta, self.batch_size)
+        # one optimizer instance (own Adam slots and step count) per `minimize` call of the reference
+        self._opt = {}
+        for train, (suffix, kind) in self._TRAIN.items():
+            self._opt[kind] = ops.MFState(self.weights['user_embedding'], self.weights['item_embedding'],
+                                          self.w, self.w_user, hyper, self.batch_size)
+            setattr(self, "opt_" + suffix, Fetch("opt_" + suffix, "opt", kind))
+            setattr(self, "loss_" + suffix, Fetch("loss_" + suffix, "loss", kind))
+            setattr(self, "mf_loss_" + suffix, Fetch("mf_loss_" + suffix, "mf_loss", kind))
+            setattr(self, "reg_loss_" + suffix, Fetch("reg_loss_" + suffix, "reg_loss", kind))
+        # the MFState objects must all alias the same parameter storage
+        st0 = self._opt[ops.LOSS_NORMALBCE]
+        for st in self._opt.values():
+            st.P, st.Q, st.w, st.wu = st0.P, st0.Q, st0.w, st0.wu
+        self.weights['user_embedding'], self.weights['item_embedding'] = st0.P, st0.Q
+        self.w, self.w_user = st0.w, st0.wu
+        # inference handles
+        self.batch_ratings = Fetch("batch_ratings", "ratings", ops.SCORE_NORMAL)
+        self.rubi_ratings_both = Fetch("rubi_ratings_both", "ratings", ops.SCORE_RUBI_BOTH)
+        for name in ("opt", "opt_two", "opt_two_bce", "opt2", "opt2_bce", "opt3", "opt3_bce", "opt_userc_bce",
+                     "user_const_ratings", "item_const_ratings", "user_rand_ratings", "item_rand_ratings",
+                     "rubi_ratings", "direct_minus_ratings", "rubi_ratings_userc", "rubi_ratings_both_poptest"):
+            setattr(self, name, Fetch(name, "unsupported"))
+        self._statistics_params()
+
+    def init_weights(self, seed, weights=None):
+        gen = torch.Generator().manual_seed(seed)
+        dev, d = self.device, self.emb_dim
+        out = dict()
+        if weights is not None:      # injected (parity runs): numpy/torch arrays
+            as_t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).to(dev).contiguous()
+            out['user_embedding'] = as_t(weights['user_embedding'])
+            out['item_embedding'] = as_t(weights['item_embedding'])
+            self.w = as_t(weights['w']).reshape(-1)
+            self.w_user = as_t(weights['w_user']).reshape(-1)
+        else:
+            out['user_embedding'] = xavier_uniform((self.n_users, d), gen, dev)
+            out['item_embedding'] = xavier_uniform((self.n_items, d), gen, dev)
+            self.w = xavier_uniform((d, 1), gen, dev).reshape(-1)
+            self.w_user = xavier_uniform((d, 1), gen, dev).reshape(-1)
+        return out
+
+    def _statistics_params(self):
+        total = (self.n_users + self.n_items) * self.emb_dim
+        if self.verbose > 0:
+            print("#params: %d" % total)
+
+    # ------------------------------------------------------------------ reference API
+    def update_c(self, sess, c):
+        """model.py:313 -- sess is accepted and ignored."""
+        self.rubi_c = float(c)
+
+    # ------------------------------------------------------------------ fast path
+    def kind_of(self, train):
+        if train not in self._TRAIN:
+            raise NotImplementedError("--train %s is not on the MI355X hot path (normalbce | rubibceboth)" % train)
+        return self._TRAIN[train][1]
+
+    def to_device_batch(self, users, pos_items, neg_items):
+        """Python lists (what Data.sample returns) -> one (3,B) int32 device tensor."""
+        host = torch.tensor([users, pos_items, neg_items], dtype=torch.int32).pin_memory()
+        return host.to(self.device, non_blocking=True)
+
+    def train_step(self, kind, batch, losses=None):
+        """batch: (3,B) int32 device tensor.  Returns the (3,) device tensor {loss, mf_loss, reg_loss};
+        no host synchronisation."""
+        return self._opt[kind].step(kind, batch[0], batch[1], batch[2], losses)
+
+    def opt_state(self, kind):
+        return self._opt[kind]
+
+    @property
+    def user_embedding(self):
+        return self.weights['user_embedding']
+
+    @property
+    def item_embedding(self):
+        return self.weights['item_embedding']
+
+    def ratings(self, kind, user_batch):
+        """Dense (U,N) score matrix: the literal sess.run(model.batch_ratings|rubi_ratings_both)."""
+        uid = torch.as_tensor(list(user_batch), dtype=torch.int32, device=self.device)
+        sig_u = sig_i = None
+        if kind == ops.SCORE_RUBI_BOTH:
+            sig_i = ops.branch_sigmoid(self.item_embedding, self.w)
+            sig_u = ops.branch_sigmoid(self.user_embedding, self.w_user, uid)
+        return ops.score_matrix(kind, self.user_embedding, uid, self.item_embedding, sig_u, sig_i, self.rubi_c)
+
+    def state_dict(self):
+        sd = {"user_embedding": self.user_embedding, "item_embedding": self.item_embedding, "w": self.w,
+              "w_user": self.w_user, "rubi_c": self.rubi_c}
+        for kind, st in self._opt.items():
+            for name in ("mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu", "adam_pow"):
+                sd["opt%d.%s" % (kind, name)] = getattr(st, name)
+        return sd
+
+    def load_state_dict(self, sd):
+        self.user_embedding.copy_(sd["user_embedding"]); self.item_embedding.copy_(sd["item_embedding"])
+        self.w.copy_(sd["w"]); self.w_user.copy_(sd["w_user"]); self.rubi_c = float(sd["rubi_c"])
+        for kind, st in self._opt.items():
+            for name in ("mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu", "adam_pow"):
+                getattr(st, name).copy_(sd["opt%d.%s" % (kind, name)])
+
+
+class Session(object):
+    """Stands where the reference has tf.Session: `run(fetches, feed_dict)` with the fetch handles of
+    BPRMF / LightGCN.  Training fetch lists return [None, loss, mf_loss, reg_loss] as Python floats
+    (one device->host sync per call, like the reference); a ratings fetch returns the (U,N) matrix."""
+
+    def __init__(self, model=None):
+        self.model = model
+
+    def bind(self, model):
+        self.model = model
+        return self
+
+    def run(self, fetches, feed_dict=None):
+        m = self.model
+        single = not isinstance(fetches, (list, tuple))
+        flist = [fetches] if single else list(fetches)
+        feed = feed_dict or {}
+        roles = [f.role for f in flist]
+        if "unsupported" in roles:
+            bad = [f.name for f in flist if f.role == "unsupported"]
+            raise NotImplementedError("fetch %s is outside the MI355X hot path" % bad)
+        out = [None] * len(flist)
+        if "opt" in roles:
+            kind = flist[roles.index("opt")].kind
+            batch = m.to_device_batch(feed[m.users], feed[m.pos_items], feed[m.neg_items])
+            losses = m.train_step(kind, batch).cpu().numpy()
+            names = getattr(m, "_loss_slots", {"loss": 0, "mf_loss": 1, "reg_loss": 2})
+            for k, f in enumerate(flist):
+                if f.role in names:
+                    out[k] = losses[names[f.role]]
+                elif f.role == "zero":
+                    out[k] = np.zeros(1, np.float32)
+        elif "ratings" in roles:
+            for k, f in enumerate(flist):
+                out[k] = m.ratings(f.kind, feed[m.users]).cpu().numpy()
+        else:
+            raise NotImplementedError("nothing to run in %r" % (flist,))
+        return out[0] if single else out

@@ -1,0 +1,292 @@
+"""Torch-tensor face of the C ABI (include/macr_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every operator
+below hands raw device pointers to libmacr_hip.so.  Nothing in this module has
+a CPU or eager-PyTorch fallback -- CPU tensors are rejected.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, SCORE_NORMAL, SCORE_RUBI_BOTH, MAX_TOPK,  # noqa: F401
+                   Hyper, MacrError, check)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=None, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError("tensor required")
+    if not t.is_cuda:
+        raise MacrError(_lib.E_INVALID, "macr_amd.ops needs device (HIP) tensors; got a CPU tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+_f32, _i32, _f64 = torch.float32, torch.int32, torch.float64
+
+
+class CSR(object):
+    """int32 CSR on the device: ptr[rows+1], idx[nnz] (+ optional fp32 val[nnz])."""
+
+    def __init__(self, ptr, idx, val=None):
+        self.ptr, self.idx, self.val = ptr, idx, val
+
+    @staticmethod
+    def from_lists(lists, device, sort=True):
+        ptr = [0]
+        flat = []
+        for row in lists:
+            row = sorted(row) if sort else list(row)
+            flat.extend(row)
+            ptr.append(len(flat))
+        idx = torch.tensor(flat if flat else [0], dtype=_i32, device=device)
+        return CSR(torch.tensor(ptr, dtype=_i32, device=device), idx)
+
+    @staticmethod
+    def from_scipy(m, device):
+        m = m.tocsr()
+        m.sort_indices()
+        return CSR(torch.from_numpy(m.indptr.astype("int32")).to(device),
+                   torch.from_numpy(m.indices.astype("int32")).to(device),
+                   torch.from_numpy(m.data.astype("float32")).to(device))
+
+    def rows(self, sel):
+        """sub-CSR for the given row selection (host-side index list/tensor)."""
+        sel = torch.as_tensor(sel, dtype=torch.long, device=self.ptr.device)
+        starts, ends = self.ptr[sel].long(), self.ptr[sel + 1].long()
+        lens = ends - starts
+        ptr = torch.zeros(len(sel) + 1, dtype=torch.long, device=self.ptr.device)
+        ptr[1:] = torch.cumsum(lens, 0)
+        total = int(ptr[-1])
+        if total == 0:
+            return CSR(ptr.to(_i32), torch.zeros(1, dtype=_i32, device=self.ptr.device))
+        rowid = torch.repeat_interleave(torch.arange(len(sel), device=self.ptr.device), lens)
+        pos = torch.arange(total, device=self.ptr.device) - ptr[rowid] + starts[rowid]
+        return CSR(ptr.to(_i32), self.idx[pos].contiguous())
+
+
+# ------------------------------------------------------------------ per-kernel timing (benchmarks)
+def timing_begin():
+    check(_lib.lib().macr_timing_begin(_stream()))
+
+
+def timing_end(max_n=256):
+    """-> list of (kernel name, milliseconds) for every launch since timing_begin (synchronises)."""
+    names = ctypes.create_string_buffer(32 * max_n)
+    ms = (ctypes.c_float * max_n)()
+    n = _lib.lib().macr_timing_end(max_n, ctypes.cast(names, ctypes.c_void_p), ctypes.cast(ms, ctypes.c_void_p))
+    raw = names.raw
+    return [(raw[k * 32:(k + 1) * 32].split(b"\0", 1)[0].decode(), float(ms[k])) for k in range(n)]
+
+
+# ------------------------------------------------------------------ evaluator ops
+def branch_sigmoid(rows, w, idx=None):
+    """sigmoid(rows[idx] . w)  (macr_mf/model.py:194-196,:199)."""
+    n = rows.shape[0] if idx is None else idx.numel()
+    out = torch.empty(n, dtype=_f32, device=rows.device)
+    check(_lib.lib().macr_branch_sigmoid(_ptr(rows, _f32), _ptr(idx, _i32, True), n, rows.shape[1],
+                                         _ptr(w.reshape(-1), _f32), _ptr(out), _stream()))
+    return out
+
+
+def score_topk_splits(U, n_local, d):
+    return _lib.lib().macr_score_topk_splits(U, n_local, d)
+
+
+def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.0, mask=None,
+               item_offset=0, n_splits=0):
+    """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K)."""
+    U = users_tab.shape[0] if user_ids is None else user_ids.numel()
+    n_local, d = items.shape
+    if n_splits <= 0:
+        n_splits = score_topk_splits(U, n_local, d)
+    vals = torch.empty((n_splits, U, K), dtype=_f32, device=items.device)
+    idx = torch.empty((n_splits, U, K), dtype=_i32, device=items.device)
+    mp = _ptr(mask.ptr, _i32) if mask is not None else None
+    mi = _ptr(mask.idx, _i32) if mask is not None else None
+    check(_lib.lib().macr_score_topk(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
+                                     _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
+                                     float(c), mp, mi, item_offset, K, n_splits, _ptr(vals), _ptr(idx), _stream()))
+    return vals, idx
+
+
+def score_matrix(kind, users_tab, user_ids, items, sig_u=None, sig_i=None, c=0.0):
+    U = users_tab.shape[0] if user_ids is None else user_ids.numel()
+    n_local, d = items.shape
+    out = torch.empty((U, n_local), dtype=_f32, device=items.device)
+    check(_lib.lib().macr_score_matrix(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
+                                       _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
+                                       float(c), _ptr(out), _stream()))
+    return out
+
+
+def topk_scores(scores, K, want_vals=True):
+    """Top-K column ids of every row (replaces c_top_k_array_index, tools.h:24)."""
+    rows, cols = scores.shape
+    idx = torch.empty((rows, K), dtype=_i32, device=scores.device)
+    val = torch.empty((rows, K), dtype=_f32, device=scores.device) if want_vals else None
+    check(_lib.lib().macr_topk_scores(_ptr(scores, _f32), cols, rows, K, _ptr(idx), _ptr(val, None, True), _stream()))
+    return idx, val
+
+
+def topk_merge(vals, idxs, fill_mask=None):
+    """(W,U,K) lists -> (U,K) + count of real candidates."""
+    W, U, K = vals.shape
+    ov = torch.empty((U, K), dtype=_f32, device=vals.device)
+    oi = torch.empty((U, K), dtype=_i32, device=vals.device)
+    oc = torch.empty(U, dtype=_i32, device=vals.device)
+    fp = _ptr(fill_mask.ptr, _i32) if fill_mask is not None else None
+    fi = _ptr(fill_mask.idx, _i32) if fill_mask is not None else None
+    check(_lib.lib().macr_topk_merge(W, U, K, _ptr(vals, _f32), _ptr(idxs, _i32), fp, fi, _ptr(ov), _ptr(oi),
+                                     _ptr(oc), _stream()))
+    return ov, oi, oc
+
+
+def metrics_foldout(rankings, gt, hr_in_ap_slot=False):
+    """(U,K) rankings + ground-truth CSR -> (U,5K) fp32 (replaces evaluate_foldout, evaluate_foldout.h:115).
+    hr_in_ap_slot: also apply batch_test.py:143-149 (ap block := 1[recall@k != 0])."""
+    U, K = rankings.shape
+    out = torch.empty((U, 5 * K), dtype=_f32, device=rankings.device)
+    check(_lib.lib().macr_metrics_foldout(U, K, _ptr(rankings, _i32), _ptr(gt.ptr, _i32), _ptr(gt.idx, _i32),
+                                          _ptr(out), int(hr_in_ap_slot), _stream()))
+    return out
+
+
+def metrics_mf(rankings, cnt, gt, Ks):
+    """(U,Kmax) rankings -> (U,4,len(Ks)) float64 {precision, recall, ndcg, hit} (macr_mf/train.py:32-117)."""
+    U, Kmax = rankings.shape
+    ks = (ctypes.c_int32 * len(Ks))(*[int(k) for k in Ks])
+    out = torch.empty((U, 4, len(Ks)), dtype=_f64, device=rankings.device)
+    check(_lib.lib().macr_metrics_mf(U, Kmax, _ptr(rankings, _i32), _ptr(cnt, _i32, True), _ptr(gt.ptr, _i32),
+                                     _ptr(gt.idx, _i32), ks, len(Ks), _ptr(out), _stream()))
+    return out
+
+
+def colmean(x):
+    rows = x.shape[0]
+    cols = x.numel() // rows
+    out = torch.empty(cols, dtype=_f64, device=x.device)
+    if x.dtype not in (_f32, _f64):
+        raise TypeError("colmean: fp32 or fp64")
+    check(_lib.lib().macr_colmean(_ptr(x), 1 if x.dtype == _f32 else 0, rows, cols, _ptr(out), _stream()))
+    return out.reshape(x.shape[1:])
+
+
+# ------------------------------------------------------------------ LightGCN propagation
+def lgcn_propagate(adj, E0, n_layers, out=None, work=None):
+    """E = mean(E0, A E0, ..., A^L E0)  (LightGCN.py:288-309); also its own backward."""
+    N, d = E0.shape
+    if out is None:
+        out = torch.empty_like(E0)
+    if work is None:
+        work = torch.empty((2, N, d), dtype=_f32, device=E0.device)
+    check(_lib.lib().macr_lgcn_propagate(N, d, n_layers, _ptr(adj.ptr, _i32), _ptr(adj.idx, _i32),
+                                         _ptr(adj.val, _f32), _ptr(E0, _f32), _ptr(out, _f32), _ptr(work, _f32),
+                                         _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ training state
+def make_hyper(lr, decay, alpha, beta, batch_size_cfg, beta1=0.9, beta2=0.999, adam_eps=1e-8):
+    return Hyper(lr, beta1, beta2, adam_eps, decay, alpha, beta, int(batch_size_cfg))
+
+
+class MFState(object):
+    """Device state of the MF model + its optimizer (one tf.train.AdamOptimizer instance).
+
+    P,Q,w,wu mirror weights['user_embedding'], ['item_embedding'], self.w, self.w_user of
+    macr_mf/model.py:107-122,:59-60.  Adam slots start at zero, beta powers at (beta1,beta2)."""
+
+    def __init__(self, P, Q, w, wu, hyper, batch_cap):
+        dev = P.device
+        self.P, self.Q = P.contiguous(), Q.contiguous()
+        self.w, self.wu = w.reshape(-1).contiguous(), wu.reshape(-1).contiguous()
+        self.hyper = hyper
+        self.d = P.shape[1]
+        z = torch.zeros_like
+        self.mP, self.vP, self.mQ, self.vQ = z(self.P), z(self.P), z(self.Q), z(self.Q)
+        self.mw, self.vw, self.mwu, self.vwu = z(self.w), z(self.w), z(self.wu), z(self.wu)
+        self.gP, self.gQ = z(self.P), z(self.Q)
+        self.tP = torch.zeros(P.shape[0], dtype=_i32, device=dev)
+        self.tQ = torch.zeros(Q.shape[0], dtype=_i32, device=dev)
+        self.adam_pow = torch.tensor([hyper.beta1, hyper.beta2], dtype=_f32, device=dev)
+        self.losses = torch.zeros(3, dtype=_f32, device=dev)
+        self.batch_cap = 0
+        self.ws = None
+        self.reserve(batch_cap)
+
+    def reserve(self, B):
+        if B > self.batch_cap:
+            nbytes = _lib.lib().macr_mf_train_workspace_bytes(B, self.d)
+            if nbytes == 0:
+                raise MacrError(_lib.E_UNSUPPORTED, "embed_size %d not in {32,64,128,256}" % self.d)
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.P.device)
+            self.batch_cap = B
+
+    def step(self, kind, u, i, j, losses=None):
+        """One training step; u,i,j int32 device tensors.  Returns the (3,) device loss tensor."""
+        B = u.numel()
+        self.reserve(B)
+        out = self.losses if losses is None else losses
+        check(_lib.lib().macr_mf_train_step(
+            kind, B, self.d, self.P.shape[0], self.Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
+            _ptr(self.P), _ptr(self.Q), _ptr(self.w), _ptr(self.wu), _ptr(self.mP), _ptr(self.vP), _ptr(self.mQ),
+            _ptr(self.vQ), _ptr(self.mw), _ptr(self.vw), _ptr(self.mwu), _ptr(self.vwu), _ptr(self.gP),
+            _ptr(self.gQ), _ptr(self.tP), _ptr(self.tQ), _ptr(self.adam_pow), ctypes.byref(self.hyper),
+            _ptr(out, _f32), _ptr(self.ws), self.ws.numel(), _stream()))
+        return out
+
+
+class LGCNState(object):
+    """Device state of LightGCN: ego table T=[user_embedding; item_embedding] (LightGCN.py:226-232),
+    branch vectors, Adam slots, the `pre` adjacency (utility/load_data.py:112-121)."""
+
+    def __init__(self, T, n_users, n_items, w, wu, adj, n_layers, hyper, batch_cap):
+        self.T = T.contiguous()
+        self.n_users, self.n_items, self.n_layers = n_users, n_items, n_layers
+        self.w, self.wu = w.reshape(-1).contiguous(), wu.reshape(-1).contiguous()
+        self.adj, self.hyper, self.d = adj, hyper, T.shape[1]
+        z = torch.zeros_like
+        self.mT, self.vT = z(self.T), z(self.T)
+        self.mw, self.vw, self.mwu, self.vwu = z(self.w), z(self.w), z(self.wu), z(self.wu)
+        self.adam_pow = torch.tensor([hyper.beta1, hyper.beta2], dtype=_f32, device=T.device)
+        self.losses = torch.zeros(3, dtype=_f32, device=T.device)
+        self.batch_cap, self.ws = 0, None
+        self.reserve(batch_cap)
+        self._E = None
+
+    def reserve(self, B):
+        if B > self.batch_cap:
+            nbytes = _lib.lib().macr_lgcn_train_workspace_bytes(B, self.T.shape[0], self.d)
+            if nbytes == 0:
+                raise MacrError(_lib.E_UNSUPPORTED, "embed_size %d not in {32,64,128,256}" % self.d)
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.T.device)
+            self.batch_cap = B
+
+    def step(self, kind, u, i, j, losses=None):
+        B = u.numel()
+        self.reserve(B)
+        out = self.losses if losses is None else losses
+        self._E = None
+        check(_lib.lib().macr_lgcn_train_step(
+            kind, B, self.d, self.n_users, self.n_items, self.n_layers, _ptr(self.adj.ptr, _i32),
+            _ptr(self.adj.idx, _i32), _ptr(self.adj.val, _f32), _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
+            _ptr(self.T), _ptr(self.w), _ptr(self.wu), _ptr(self.mT), _ptr(self.vT), _ptr(self.mw), _ptr(self.vw),
+            _ptr(self.mwu), _ptr(self.vwu), _ptr(self.adam_pow), ctypes.byref(self.hyper), _ptr(out, _f32),
+            _ptr(self.ws), self.ws.numel(), _stream()))
+        return out
+
+    def propagated(self):
+        """ua_embeddings / ia_embeddings (LightGCN.py:130) -- cached until the next step."""
+        if self._E is None:
+            self._E = lgcn_propagate(self.adj, self.T, self.n_layers)
+        return self._E

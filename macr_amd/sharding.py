@@ -1,0 +1,53 @@
+"""Item-catalogue sharding for multi-GPU evaluation (new functionality).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The
+catalogue is cut into `world` contiguous item ranges; every rank ranks ALL
+query users against its own range (fused scoring + top-K), then the per-shard
+top-K lists -- U*K*(4+4) bytes per rank, a few MB -- are exchanged with ONE
+all-gather and merged.  The merge is exact because the global top-K is a subset
+of the union of the per-shard top-Ks, and the tie rule (score desc, id asc) is
+applied identically everywhere, so 1/2/4/8-GPU results are identical.
+
+This module is host logic only (works with gloo/CPU tensors for tests and with
+nccl/HIP tensors in production); the merge kernel itself is macr_topk_merge.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def item_shard_range(n_items, rank, world_size):
+    """Contiguous, balanced range [lo, hi) of rank's items; shards differ by at most one item."""
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_topk(local_val, local_idx, group=None):
+    """All-gather per-shard (U,K) lists -> (W,U,K) tensors, identical on every rank.
+
+    A direct all-gather (fully connected xGMI, one hop) of a few MB: latency-bound, no
+    bucketing or ring tuning needed at this size."""
+    rank, ws = world()
+    if ws == 1:
+        return local_val.unsqueeze(0), local_idx.unsqueeze(0)
+    vals = torch.empty((ws,) + tuple(local_val.shape), dtype=local_val.dtype, device=local_val.device)
+    idxs = torch.empty((ws,) + tuple(local_idx.shape), dtype=local_idx.dtype, device=local_idx.device)
+    dist.all_gather_into_tensor(vals, local_val.contiguous(), group=group)
+    dist.all_gather_into_tensor(idxs, local_idx.contiguous(), group=group)
+    return vals, idxs
+
+
+def max_over_ranks(x, device):
+    """max of a python float over ranks (bench timing contract)."""
+    rank, ws = world()
+    if ws == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

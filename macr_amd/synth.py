@@ -1,0 +1,92 @@
+"""Synthetic workloads with the shapes of BASELINE.json's configs.
+
+Only Addressa ships a train.txt; Gowalla / ML-10M / Yelp2018 are test-only in the
+reference checkout and there is no network, so the benchmark tables and
+interaction lists are generated here, seeded, directly on the device:
+  users uniform without replacement, positive items Zipf(1.0), negatives uniform,
+  train-list lengths ~ lognormal clipped to [1, n_items/2], embeddings
+  Xavier-uniform U(-sqrt(6/(rows+d)), +sqrt(6/(rows+d))).
+"""
+import math
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # name: n_users, n_items, d, batch, n_train(approx), test users, test items/user, hyper-parameters
+    "addressa": dict(n_users=13485, n_items=744, d=64, batch=1024, n_train=113345, n_test_users=2090,
+                     test_per_user=2, alpha=1e-3, beta=1e-3, lr=1e-3, regs=1e-5, c=40.0),
+    "gowalla": dict(n_users=29858, n_items=40981, d=64, batch=4096, n_train=822358, n_test_users=15424,
+                    test_per_user=13, alpha=1e-2, beta=1e-3, lr=1e-3, regs=1e-5, c=40.0),
+    "ml10m": dict(n_users=69166, n_items=8790, d=64, batch=8192, n_train=4900000, n_test_users=13878,
+                  test_per_user=6, alpha=1e-3, beta=1e-3, lr=1e-3, regs=1e-5, c=40.0),
+    "yelp2018": dict(n_users=31668, n_items=38048, d=64, batch=4096, n_train=1371000, n_test_users=13957,
+                     test_per_user=14, alpha=1e-2, beta=1e-3, lr=1e-3, regs=1e-5, c=40.0),
+}
+
+
+def xavier_table(rows, d, gen, device):
+    limit = math.sqrt(6.0 / (rows + d))
+    return ((torch.rand((rows, d), generator=gen, device=device, dtype=torch.float32) * 2 - 1) * limit).contiguous()
+
+
+def zipf_probs(n, device, s=1.0):
+    p = 1.0 / torch.arange(1, n + 1, device=device, dtype=torch.float64) ** s
+    return (p / p.sum()).to(torch.float32)
+
+
+def train_batches(n_steps, n_users, n_items, batch, gen, device, zipf=True):
+    """(n_steps,3,B) int32: users w/o replacement per step, Zipf positives, uniform negatives."""
+    probs = zipf_probs(n_items, device)
+    out = torch.empty((n_steps, 3, batch), dtype=torch.int32, device=device)
+    for s in range(n_steps):
+        if batch <= n_users:
+            u = torch.randperm(n_users, generator=gen, device=device)[:batch]
+        else:
+            u = torch.randint(0, n_users, (batch,), generator=gen, device=device)
+        out[s, 0] = u.to(torch.int32)
+        if zipf:
+            out[s, 1] = torch.multinomial(probs, batch, replacement=True, generator=gen).to(torch.int32)
+        else:
+            out[s, 1] = torch.randint(0, n_items, (batch,), generator=gen, device=device).to(torch.int32)
+        out[s, 2] = torch.randint(0, n_items, (batch,), generator=gen, device=device).to(torch.int32)
+    return out
+
+
+def interaction_lists(n_rows, n_items, mean_len, seed, zipf=True):
+    """list of sorted unique item lists (host, NumPy): lengths lognormal(mean_len), items Zipf."""
+    rs = np.random.RandomState(seed)
+    sigma = 0.9
+    mu = math.log(max(mean_len, 1.0)) - sigma * sigma / 2
+    lens = np.clip(np.round(rs.lognormal(mu, sigma, n_rows)), 1, max(1, n_items // 2)).astype(np.int64)
+    if zipf:
+        p = 1.0 / np.arange(1, n_items + 1)
+        cdf = np.cumsum(p / p.sum())
+    lists = []
+    for n in lens:
+        if zipf:
+            draw = np.searchsorted(cdf, rs.rand(int(n * 1.5) + 4))
+            items = np.unique(np.minimum(draw, n_items - 1))[:n]
+        else:
+            items = np.unique(rs.randint(0, n_items, int(n)))
+        lists.append(items.tolist())
+    return lists
+
+
+def eval_problem(cfg, seed):
+    """(query user ids, mask lists (train), ground-truth lists (test)) for a workload."""
+    rs = np.random.RandomState(seed)
+    U = cfg["n_test_users"]
+    users = np.sort(rs.choice(cfg["n_users"], U, replace=False)).astype(np.int32)
+    mean_train = cfg["n_train"] / cfg["n_users"]
+    mask = interaction_lists(U, cfg["n_items"], mean_train, seed + 1)
+    gt = []
+    for row in mask:
+        seen = set(row)
+        t = []
+        while len(t) < cfg["test_per_user"]:
+            x = int(rs.randint(0, cfg["n_items"]))
+            if x not in seen:
+                t.append(x); seen.add(x)
+        gt.append(sorted(t))
+    return users, mask, gt

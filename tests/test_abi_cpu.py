@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, and exports every
+symbol include/macr_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from macr_amd import _lib
+from macr_amd.build import build
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build()
+    return _lib.lib()
+
+
+def header_symbols():
+    src = open(os.path.join(REPO, "include", "macr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(macr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = header_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.SIGNATURES) == names          # the ctypes table mirrors the header exactly
+
+
+def test_version_and_error_plumbing(lib):
+    assert lib.macr_abi_version() == _lib.ABI_VERSION
+    assert b"gfx950" in lib.macr_build_info()
+    # argument validation happens before any device work, so it is checkable without a GPU
+    rc = lib.macr_topk_scores(None, 10, 10, 20, None, None, None)
+    assert rc == _lib.E_INVALID and b"null pointer" in lib.macr_last_error()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.macr_topk_scores(p, 10, 10, 64, p, None, None)
+    assert rc == _lib.E_UNSUPPORTED
+    rc = lib.macr_branch_sigmoid(p, None, 1, 48, p, p, None)
+    assert rc == _lib.E_UNSUPPORTED and b"d=48" in lib.macr_last_error()
+    assert lib.macr_mf_train_workspace_bytes(4096, 64) > 0
+    assert lib.macr_mf_train_workspace_bytes(4096, 48) == 0
+    assert lib.macr_score_topk_splits(15424, 40981, 64) >= 8
+
+
+def test_hyper_struct_layout():
+    assert ctypes.sizeof(_lib.Hyper) == 32
+
+
+def test_ops_reject_cpu_tensors():
+    import torch
+    from macr_amd import ops
+    with pytest.raises(ops.MacrError):
+        ops.branch_sigmoid(torch.zeros(4, 64), torch.zeros(64))

@@ -1,0 +1,326 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI (-m gpu).
+
+Index work (top-K ids, merges) must be bit-exact; floating-point model arithmetic
+uses the tolerances of BASELINE.json's north star (per-step loss 1e-5 relative).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+gpu = pytest.mark.gpu
+pytestmark = gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from macr_amd import ops as _ops
+    return _ops
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def make_problem(seed, n_users, n_items, d, B, scale=0.3, dup=True):
+    rs = np.random.RandomState(seed)
+    P = (rs.standard_normal((n_users, d)) * scale).astype(np.float32)
+    Q = (rs.standard_normal((n_items, d)) * scale).astype(np.float32)
+    w = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    wu = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    u = rs.choice(n_users, B, replace=B > n_users).astype(np.int32)
+    i = rs.randint(0, n_items, B).astype(np.int32)
+    j = rs.randint(0, n_items, B).astype(np.int32)
+    if dup:
+        i[: B // 3] = 0                      # hot item (Addressa item 0 sits in half the train lists)
+    return P, Q, w, wu, u, i, j
+
+
+# ----------------------------------------------------------------------------- training step
+@pytest.mark.parametrize("kind", [oracle.LOSS_NORMALBCE, oracle.LOSS_RUBIBCEBOTH])
+@pytest.mark.parametrize("B,d,n_users,n_items", [(96, 64, 300, 50), (257, 64, 300, 50), (1024, 64, 13485, 744),
+                                                 (64, 32, 100, 40), (128, 128, 500, 300), (64, 256, 100, 40),
+                                                 (2048, 64, 3000, 900)])
+def test_mf_train_step_matches_oracle(ops, kind, B, d, n_users, n_items):
+    P, Q, w, wu, u, i, j = make_problem(B + d, n_users, n_items, d, B)
+    alpha, beta, decay, lr, bs = 1e-2, 1e-3, 1e-5, 1e-3, 1024
+    st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
+    Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
+    hyper = ops.make_hyper(lr, decay, alpha, beta, bs)
+    state = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), hyper, B)
+    rs = np.random.RandomState(9)
+    for t in range(3):
+        if t:
+            u = rs.choice(n_users, B, replace=B > n_users).astype(np.int32)
+            i = rs.randint(0, n_items, B).astype(np.int32)
+            j = rs.randint(0, n_items, B).astype(np.int32)
+        want = oracle.mf_train_step(kind, u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, bs)
+        got = state.step(kind, dev(u), dev(i), dev(j)).cpu().numpy()
+        # per-step loss within 1e-5 relative (BASELINE.json north star)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+        if t == 0:
+            # after the first step m = (1-beta1)*g: the dense, de-duplicated gradient itself
+            for name, gm, om in (("P", state.mP, st.m[0]), ("Q", state.mQ, st.m[1])):
+                g_hip, g_orc = gm.cpu().numpy() / 0.1, om / 0.1
+                np.testing.assert_allclose(g_hip, g_orc, rtol=2e-4, atol=1e-6 * np.abs(g_orc).max(), err_msg=name)
+            if kind == oracle.LOSS_RUBIBCEBOTH:
+                np.testing.assert_allclose(state.mw.cpu().numpy(), st.m[2], rtol=2e-4, atol=1e-6 * np.abs(st.m[2]).max())
+                np.testing.assert_allclose(state.mwu.cpu().numpy(), st.m[3], rtol=2e-4, atol=1e-6 * np.abs(st.m[3]).max())
+        # tables: every row moves every step (dense Adam); a step is at most ~lr
+        np.testing.assert_allclose(state.P.cpu().numpy(), Po, rtol=0, atol=0.02 * lr * (t + 1))
+        np.testing.assert_allclose(state.Q.cpu().numpy(), Qo, rtol=0, atol=0.02 * lr * (t + 1))
+        np.testing.assert_allclose(state.w.cpu().numpy(), wo, rtol=0, atol=0.02 * lr * (t + 1))
+        np.testing.assert_allclose(state.wu.cpu().numpy(), wuo, rtol=0, atol=0.02 * lr * (t + 1))
+    # scratch invariants of the ABI: gradient scratch and touched flags are zero again
+    assert float(state.gP.abs().max()) == 0.0 and float(state.gQ.abs().max()) == 0.0
+    assert int(state.tP.sum()) == 0 and int(state.tQ.sum()) == 0
+    np.testing.assert_allclose(state.adam_pow.cpu().numpy(), st.power, rtol=1e-6)
+    if kind == oracle.LOSS_NORMALBCE:        # branch vectors get no gradient -> bitwise untouched
+        assert np.array_equal(state.w.cpu().numpy(), w) and np.array_equal(state.wu.cpu().numpy(), wu)
+
+
+def test_untouched_rows_follow_dense_adam(ops):
+    """TF-1.14 Adam on embedding tables moves EVERY row (SURVEY.md finding 5)."""
+    P, Q, w, wu, u, i, j = make_problem(1, 400, 80, 64, 32, dup=False)
+    hyper = ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, 32)
+    state = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), hyper, 32)
+    state.step(oracle.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j))
+    P1 = state.P.cpu().numpy().copy()
+    untouched = np.setdiff1d(np.arange(400), u)
+    assert np.array_equal(P1[untouched], P[untouched])       # m=v=0, g=0: first step leaves them
+    state.step(oracle.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j))
+    rows_first = u[:4]
+    uu = np.setdiff1d(np.arange(400), rows_first)[:32].astype(np.int32)   # rows_first untouched in step 3
+    state.step(oracle.LOSS_RUBIBCEBOTH, dev(uu), dev(i), dev(j))
+    P3 = state.P.cpu().numpy()
+    P2_rows = None
+    # rows touched earlier keep moving with zero gradient because m != 0
+    assert np.all(np.abs(P3[rows_first] - P1[rows_first]).max(axis=1) > 0)
+
+
+# ----------------------------------------------------------------------------- LightGCN
+def toy_graph(n_users, n_items, seed, density=0.1):
+    import scipy.sparse as sp
+    rs = np.random.RandomState(seed)
+    R = (rs.rand(n_users, n_items) < density).astype(np.float32)
+    R[0, :] = 0
+    R[:, 1] = 1                                   # a hub item: one very long row
+    R[0, 1] = 0
+    A = sp.bmat([[None, sp.csr_matrix(R)], [sp.csr_matrix(R.T), None]]).tocsr()
+    deg = np.asarray(A.sum(1)).ravel()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5).astype(np.float32)
+    dinv[np.isinf(dinv)] = 0
+    A_hat = (sp.diags(dinv) @ A @ sp.diags(dinv)).tocsr().astype(np.float32)
+    A_hat.sort_indices()
+    return A_hat
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("L", [0, 1, 2, 3])
+def test_lgcn_propagate_matches_oracle(ops, d, L):
+    n_users, n_items = 700, 333
+    A = toy_graph(n_users, n_items, 3)
+    rs = np.random.RandomState(d + L)
+    E0 = rs.standard_normal((n_users + n_items, d)).astype(np.float32)
+    want = oracle.lgcn_propagate(A.indptr, A.indices, A.data, E0, L)
+    got = ops.lgcn_propagate(ops.CSR.from_scipy(A, "cuda"), dev(E0), L).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("kind", [oracle.LOSS_NORMALBCE, oracle.LOSS_RUBIBCEBOTH])
+@pytest.mark.parametrize("d,B", [(64, 256), (128, 100)])
+def test_lgcn_train_step_matches_oracle(ops, kind, d, B):
+    n_users, n_items, L = 500, 200, 2
+    A = toy_graph(n_users, n_items, 5)
+    P, Q, w, wu, u, i, j = make_problem(d, n_users, n_items, d, B)
+    T = np.concatenate([P, Q]).astype(np.float32)
+    alpha, beta, decay, lr, bs = 1e-2, 1e-3, 1e-4, 1e-3, B
+    st = oracle.AdamState([T.shape, (d,), (d,)])
+    To, wo, wuo = T.copy(), w.copy(), wu.copy()
+    state = ops.LGCNState(dev(T), n_users, n_items, dev(w), dev(wu), ops.CSR.from_scipy(A, "cuda"), L,
+                          ops.make_hyper(lr, decay, alpha, beta, bs), B)
+    rs = np.random.RandomState(2)
+    for t in range(3):
+        if t:
+            u = rs.choice(n_users, B, replace=False).astype(np.int32)
+            i = rs.randint(0, n_items, B).astype(np.int32)
+            j = rs.randint(0, n_items, B).astype(np.int32)
+        want = oracle.lgcn_train_step(kind, n_users, n_items, L, A.indptr, A.indices, A.data, u, i, j,
+                                      To, wo, wuo, st, lr, decay, alpha, beta, bs)
+        got = state.step(kind, dev(u), dev(i), dev(j)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+        if t == 0:
+            g_hip, g_orc = state.mT.cpu().numpy() / 0.1, st.m[0] / 0.1
+            np.testing.assert_allclose(g_hip, g_orc, rtol=5e-4, atol=2e-6 * np.abs(g_orc).max())
+        np.testing.assert_allclose(state.T.cpu().numpy(), To, rtol=0, atol=0.02 * lr * (t + 1))
+
+
+# ----------------------------------------------------------------------------- evaluator
+def random_mask(rs, U, n_items, mean_len, heavy=()):
+    lists = []
+    for q in range(U):
+        k = int(rs.poisson(mean_len))
+        if q in heavy:
+            k = n_items - 4                      # leaves 4 candidates (< K)
+        k = min(k, n_items)
+        lists.append(sorted(rs.choice(n_items, size=k, replace=False).tolist()))
+    return lists
+
+
+@pytest.mark.parametrize("kind", [oracle.SCORE_NORMAL, oracle.SCORE_RUBI_BOTH])
+@pytest.mark.parametrize("U,N,d,K,splits,off", [
+    (300, 1000, 64, 20, 1, 0), (300, 1000, 64, 20, 3, 0), (257, 2085, 64, 20, 8, 0), (40, 744, 64, 20, 0, 0),
+    (1, 33, 64, 20, 1, 0), (5, 17, 64, 20, 1, 0), (64, 1000, 32, 5, 2, 0), (100, 900, 128, 32, 4, 0),
+    (70, 500, 256, 1, 1, 0), (300, 1000, 64, 20, 2, 5000), (513, 4099, 64, 30, 0, 0)])
+def test_score_topk_bit_exact(ops, kind, U, N, d, K, splits, off):
+    rs = np.random.RandomState(U + N + d + K)
+    n_users = U + 50
+    P = (rs.standard_normal((n_users, d)) * 0.5).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.5).astype(np.float32)
+    Q += (rs.standard_normal(N).astype(np.float32) * 0.5)[:, None] * np.sign(P.mean(0, keepdims=True))   # popularity
+    w = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    wu = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    user_ids = rs.permutation(n_users)[:U].astype(np.int32)
+    mask_lists = random_mask(rs, U, N, 12, heavy=(0, U - 1) if N > 40 else ())
+    mask_lists = [[x + off for x in row] for row in mask_lists]
+    mptr, midx = oracle.csr_from_lists(mask_lists)
+    c = 3.0
+    # branch sigmoids: HIP vs oracle within fp32 rounding, then the SAME arrays feed both rankers
+    sig_i_hip = ops.branch_sigmoid(dev(Q), dev(w))
+    sig_u_hip = ops.branch_sigmoid(dev(P), dev(wu), dev(user_ids))
+    np.testing.assert_allclose(sig_i_hip.cpu().numpy(), oracle.branch_sigmoid(Q, w), rtol=2e-6)
+    np.testing.assert_allclose(sig_u_hip.cpu().numpy(), oracle.branch_sigmoid(P[user_ids], wu), rtol=2e-6)
+    sig_i, sig_u = sig_i_hip.cpu().numpy(), sig_u_hip.cpu().numpy()
+    want_v, want_i, want_c = oracle.score_topk(kind, P[user_ids], Q, K, sig_u, sig_i, c, (mptr, midx), off)
+    mask = ops.CSR(dev(mptr), dev(midx if len(midx) else np.zeros(1, np.int32)))
+    vals, idx = ops.score_topk(kind, dev(P), dev(user_ids), dev(Q), K, sig_u_hip, sig_i_hip, c, mask, off, splits)
+    gv, gi, gc = ops.topk_merge(vals, idx)
+    assert np.array_equal(gi.cpu().numpy(), want_i)
+    assert np.array_equal(gc.cpu().numpy(), want_c)
+    assert np.array_equal(gv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))      # bit for bit
+    # masked fill (what ranking a -inf masked matrix gives, batch_test.py:124-134)
+    fv, fi, fc = ops.topk_merge(vals, idx, fill_mask=mask)
+    ov, oi, oc = oracle.score_topk(kind, P[user_ids], Q, K, sig_u, sig_i, c, (mptr, midx), off, fill_masked=True)
+    assert np.array_equal(fi.cpu().numpy(), oi)
+    # the dense score matrix entry point computes the same numbers
+    if U * N <= 400000:
+        S = ops.score_matrix(kind, dev(P), dev(user_ids), dev(Q), sig_u_hip, sig_i_hip, c).cpu().numpy()
+        rows = np.arange(U)[:, None]
+        valid = want_i >= 0
+        picked = S[rows, np.where(valid, want_i - off, 0)]
+        assert np.array_equal(picked[valid].view(np.uint32), want_v[valid].view(np.uint32))
+
+
+def test_score_topk_item_sharding_equals_unsharded(ops):
+    """Item-sharded scoring + merge == single-shard scoring (the 1/2/4/8-GPU contract)."""
+    rs = np.random.RandomState(0)
+    U, N, d, K = 777, 5003, 64, 20
+    P = (rs.standard_normal((U, d)) * 0.5).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.5).astype(np.float32)
+    Q[100:200] = Q[300:400]                       # exact score ties across shards
+    mask_lists = random_mask(rs, U, N, 20)
+    mptr, midx = oracle.csr_from_lists(mask_lists)
+    mask = ops.CSR(dev(mptr), dev(midx))
+    Pd, Qd = dev(P), dev(Q)
+    v1, i1 = ops.score_topk(oracle.SCORE_NORMAL, Pd, None, Qd, K, mask=mask, n_splits=1)
+    ref_v, ref_i, ref_c = ops.topk_merge(v1, i1)
+    for W in (2, 4, 8):
+        bounds = [N * r // W for r in range(W + 1)]
+        vs, is_ = [], []
+        for r in range(W):
+            lo, hi = bounds[r], bounds[r + 1]
+            v, i = ops.score_topk(oracle.SCORE_NORMAL, Pd, None, Qd[lo:hi].contiguous(), K, mask=mask,
+                                  item_offset=lo, n_splits=2)
+            mv, mi, _ = ops.topk_merge(v, i)
+            vs.append(mv); is_.append(mi)
+        gv, gi, gc = ops.topk_merge(torch.stack(vs), torch.stack(is_))
+        assert torch.equal(gi, ref_i) and torch.equal(gv, ref_v) and torch.equal(gc, ref_c)
+    wv, wi, wc = oracle.score_topk(oracle.SCORE_NORMAL, P, Q, K, mask=(mptr, midx))
+    assert np.array_equal(ref_i.cpu().numpy(), wi)
+
+
+@pytest.mark.parametrize("rows,cols,K", [(7, 50, 20), (33, 744, 20), (5, 12, 10), (64, 40981, 20), (3, 25, 32), (2, 5, 8)])
+def test_topk_scores_bit_exact(ops, rows, cols, K):
+    rs = np.random.RandomState(rows * cols)
+    s = rs.standard_normal((rows, cols)).astype(np.float32)
+    s[0] = np.round(s[0])                          # heavy ties
+    if cols > 8:
+        s[1, 4:] = -np.inf                         # K > #finite
+    want_v, want_i, want_c = oracle.topk_scores(s, K)
+    gi, gv = ops.topk_scores(dev(s), K)
+    assert np.array_equal(gi.cpu().numpy(), want_i)
+    assert np.array_equal(gv.cpu().numpy(), want_v)       # values (−0.0 == +0.0)
+
+
+def test_topk_merge_matches_oracle(ops):
+    rs = np.random.RandomState(4)
+    for W, U, K in ((1, 9, 20), (2, 100, 20), (8, 333, 20), (5, 17, 32), (3, 10, 1), (16, 50, 7)):
+        vals = np.sort(rs.standard_normal((W, U, K)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+        vals = np.round(vals * 4) / 4              # ties across lists
+        idx = np.stack([rs.permutation(10000)[: U * K].reshape(U, K) for _ in range(W)]).astype(np.int32)
+        # ties inside one list must already be id-ascending (as the producers emit them)
+        order = np.lexsort((idx, -vals), axis=2)
+        vals = np.take_along_axis(vals, order, 2); idx = np.take_along_axis(idx, order, 2)
+        short = rs.rand(W, U) < 0.2                # some short lists
+        for s_, u_ in zip(*np.nonzero(short)):
+            n = rs.randint(0, K)
+            vals[s_, u_, n:] = -np.inf; idx[s_, u_, n:] = -1
+        wv, wi, wc = oracle.topk_merge(vals, idx)
+        gv, gi, gc = ops.topk_merge(dev(vals), dev(idx))
+        assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gc.cpu().numpy(), wc)
+        assert np.array_equal(gv.cpu().numpy(), wv)          # values (-0.0 == +0.0 by the tie rule)
+
+
+def test_metrics_match_oracle(ops):
+    rs = np.random.RandomState(8)
+    U, K, N = 500, 20, 300
+    rank = np.stack([rs.permutation(N)[:K] for _ in range(U)]).astype(np.int32)
+    cnt = np.full(U, K, np.int32)
+    cnt[:5] = [0, 1, 3, 19, 20]
+    for q in range(5):
+        rank[q, cnt[q]:] = -1
+    gt_lists = [sorted(rs.choice(N, size=rs.randint(1, 30), replace=False).tolist()) for _ in range(U)]
+    gptr, gidx = oracle.csr_from_lists(gt_lists)
+    gt = ops.CSR(dev(gptr), dev(gidx))
+    want = oracle.metrics_foldout(rank, (gptr, gidx))
+    got = ops.metrics_foldout(dev(rank), gt).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=0)
+    Ks = [1, 5, 20]
+    want = oracle.metrics_mf(rank, cnt, (gptr, gidx), Ks)
+    got = ops.metrics_mf(dev(rank), dev(cnt), gt, Ks).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-14, atol=0, equal_nan=True)
+    np.testing.assert_allclose(ops.colmean(dev(want[5:])).cpu().numpy(), want[5:].mean(0), rtol=1e-13)
+    f = rs.standard_normal((1000, 100)).astype(np.float32)
+    np.testing.assert_allclose(ops.colmean(dev(f)).cpu().numpy(), f.astype(np.float64).mean(0), rtol=1e-12, atol=1e-15)
+
+
+def test_golden_cpp_evaluator_cases(ops, golden_dir):
+    """G7: raw outputs of the reference's C++ evaluator (tools.h + evaluate_foldout.h) on stored inputs."""
+    import os
+    z = np.load(os.path.join(golden_dir, "G7_cpp_eval_cases.npz"))
+    for name in "abcd":
+        s, k = z[name + "_scores"], int(z[name + "_k"])
+        lens = z[name + "_gt_len"]
+        flat = z[name + "_gt_flat"]
+        gptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        gi, _ = ops.topk_scores(dev(s), k)
+        if name != "d":                            # tie-free: rankings must equal the reference's exactly
+            assert np.array_equal(gi.cpu().numpy(), z[name + "_rankings"])
+        res = ops.metrics_foldout(gi, ops.CSR(dev(gptr), dev(flat))).cpu().numpy()
+        np.testing.assert_allclose(res, z[name + "_results"], rtol=2e-7, atol=0)
+
+
+def test_errors_are_loud(ops):
+    with pytest.raises(ops.MacrError):
+        ops.topk_scores(dev(np.zeros((2, 5), np.float32)), 64)              # K > MACR_MAX_TOPK
+    with pytest.raises(ops.MacrError):
+        ops.branch_sigmoid(dev(np.zeros((4, 48), np.float32)), dev(np.zeros(48, np.float32)))   # unsupported d
+    with pytest.raises(ops.MacrError):
+        ops.branch_sigmoid(torch.zeros(4, 64), torch.zeros(64))             # CPU tensors: no fallback
