@@ -203,31 +203,42 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
                     }
                 }
 #endif
-                // admission
-                uint32_t cand = 0;
+                // admission, in two half-tiles of 8 registers so that a user gains at most 16 entries per
+                // round: the buffer may then fill to kCap-16 = 48 before it has to be compacted
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cand |= (s[r] > thr) ? (1u << r) : 0u;
-                if (__any(cand != 0)) {
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t cand = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if ((cand >> r) & 1u) {
-                            const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
-                            const uint32_t pos = atomicAdd(&s_cnt[uslot], 1u);
-                            s_keys[(size_t)uslot * kCap + pos] = make_key(s[r], gid0 + il);
+                    for (int r = 8 * half; r < 8 * half + 8; ++r) cand |= (s[r] > thr) ? (1u << r) : 0u;
+                    const uint32_t n_l = __popc(cand);
+                    if (__any(n_l != 0)) {
+                        uint32_t end = 0;
+                        if (n_l) {
+                            uint32_t pos = atomicAdd(&s_cnt[uslot], n_l);      // ONE LDS atomic per lane and round
+                            uint64_t *dst = s_keys + (size_t)uslot * kCap;
+#pragma unroll
+                            for (int r = 8 * half; r < 8 * half + 8; ++r) {
+                                if ((cand >> r) & 1u) {
+                                    const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
+                                    dst[pos++] = make_key(s[r], gid0 + il);
+                                }
+                            }
+                            end = pos;              // the later of the user's two lanes sees the full count
+                        }
+                        const uint64_t bal = __ballot(end > (uint32_t)(kCap - 16));
+                        uint32_t todo = (uint32_t)bal | (uint32_t)(bal >> 32);      // users (cols) to compact
+                        if (todo) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            const uint32_t mine = (todo >> col) & 1u;
+                            while (todo) {
+                                const int ucol = __ffs((int)todo) - 1;
+                                todo &= todo - 1;
+                                const int us = wid * 32 + ucol;
+                                compact_buffer(s_keys + (size_t)us * kCap, &s_cnt[us], &s_thr[us], K);
+                            }
+                            if (mine && q_ok) thr = s_thr[uslot];
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    // compaction for users whose buffer could overflow on the next tile
-                    const bool need = s_cnt[uslot] > (uint32_t)(kCap - kTileItems);
-                    uint64_t todo = __ballot(need && h == 0);
-                    while (todo) {
-                        const int ucol = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1;
-                        const int us = wid * 32 + ucol;
-                        compact_buffer(s_keys + (size_t)us * kCap, &s_cnt[us], &s_thr[us], K);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    thr = q_ok ? s_thr[uslot] : INFINITY;
                 }
             }
             if (has_next) {
@@ -506,15 +517,18 @@ extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
     if (U <= 0 || n_local <= 0) return 1;
     const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
     const int tiles = (n_local + kTileItems - 1) / kTileItems;
-    // aim for >= 2 blocks per CU (512 blocks), splits a multiple of 8 (one item slice per XCD),
-    // but keep at least 16 tiles per split so the per-split warm-up stays amortised
-    int s = (512 + ublocks - 1) / ublocks;
-    s = (s + 7) / 8 * 8;
-    const int max_s = tiles / 16 > 0 ? tiles / 16 : 1;
-    if (s > max_s) s = max_s >= 8 ? max_s / 8 * 8 : max_s;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return s;
+    // One block (8 waves, 145 KB LDS) per CU, 256 CUs.  Cost model in units of item tiles per block:
+    // rounds * (tiles/s + warm-up), where every split re-pays the running top-K warm-up
+    // (~K ln(n/K) extra admissions, worth about a dozen tiles).  Pick the cheapest s.
+    int best = 1;
+    double best_cost = 1e300;
+    for (int s = 1; s <= 64 && s <= tiles; ++s) {
+        const long long blocks = (long long)ublocks * s;
+        const double rounds = (double)((blocks + 255) / 256);
+        const double cost = rounds * ((double)((tiles + s - 1) / s) + 12.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 
 #define MACR_DISPATCH_DK(d, kind, ...)                                                              \
