@@ -38,8 +38,9 @@ def gather_topk(local_val, local_idx, group=None):
         return local_val.unsqueeze(0), local_idx.unsqueeze(0)
     vals = torch.empty((ws,) + tuple(local_val.shape), dtype=local_val.dtype, device=local_val.device)
     idxs = torch.empty((ws,) + tuple(local_idx.shape), dtype=local_idx.dtype, device=local_idx.device)
-    dist.all_gather_into_tensor(vals, local_val.contiguous(), group=group)
-    dist.all_gather_into_tensor(idxs, local_idx.contiguous(), group=group)
+    # output viewed as the concatenation along dim 0: the form every backend (nccl/RCCL, gloo) accepts
+    dist.all_gather_into_tensor(vals.view((-1,) + tuple(local_val.shape[1:])), local_val.contiguous(), group=group)
+    dist.all_gather_into_tensor(idxs.view((-1,) + tuple(local_idx.shape[1:])), local_idx.contiguous(), group=group)
     return vals, idxs
 
 

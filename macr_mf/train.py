@@ -1,0 +1,182 @@
+"""MF command line of MACR on MI355X -- drop-in for the reference's macr_mf/train.py.
+
+    python ./macr_mf/train.py --dataset addressa --batch_size 1024 --cuda 0 --saveID 1 \
+        --log_interval 10 --lr 0.001 --train normalbce --test normal
+    python ./macr_mf/train.py --dataset gowalla --batch_size 4096 --cuda 0 --saveID 0 --log_interval 10 \
+        --lr 0.001 --check_c 1 --c 40 --train rubibceboth --test rubi --alpha 1e-2 --beta 1e-3
+
+Same flags, stdout/log line formats, early stopping and checkpoint directory naming as the
+reference (macr_mf/train.py:332-611); the training step and the evaluator run on the HIP
+kernels.  `test(sess, model, users, ...)` keeps the reference signature (:162) and returns the
+same dict of np.ndarray(len(Ks)).  Checkpoints are torch files (TF's format is not a goal).
+"""
+import logging
+import os
+import random
+import sys
+from time import time
+
+import numpy as np
+import torch
+
+from batch_test import *          # noqa: F401,F403  (args, data, Ks, BATCH_SIZE, ITEM_NUM, USER_NUM)
+from model import BPRMF, Session
+
+from macr_amd import ops
+from macr_amd.evaluator import Evaluator
+from macr_amd.metrics_host import (precision_at_k, dcg_at_k, ndcg_at_k, recall_at_k, hit_at_k,   # noqa: F401
+                                   get_performance)
+
+logging.getLogger().setLevel(logging.INFO)
+
+_MODEL_TYPES = {'o': ops.SCORE_NORMAL, 'rubi_both': ops.SCORE_RUBI_BOTH}
+_evaluators = {}
+
+
+def test(sess, model, test_users, batch_test_flag=False, model_type='o', valid_set="test",
+         item_pop_test=None, pop_exp=0):
+    """Reference signature (macr_mf/train.py:162).  Ranks every user in `test_users` against the whole
+    catalogue minus its train items and returns the mean precision / recall / ndcg / hit_ratio at Ks.
+    sess, batch_test_flag, item_pop_test, pop_exp are accepted for compatibility."""
+    if model_type not in _MODEL_TYPES:
+        raise NotImplementedError("model_type %r is outside the MI355X hot path ('o' | 'rubi_both')" % model_type)
+    key = (valid_set, len(test_users), test_users[0] if len(test_users) else -1)
+    ev = _evaluators.get(key)
+    if ev is None:
+        mask, gt = data.eval_lists(test_users, valid_set)
+        ev = _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
+                                 torch.tensor(list(test_users), dtype=torch.int32, device=model.device))
+    evaluator, uid = ev
+    return evaluator.test_mf(_MODEL_TYPES[model_type], model.user_embedding, uid, model.item_embedding, Ks,
+                             model.w, model.w_user, model.rubi_c)
+
+
+def early_stop(hr, ndcg, recall, precision, cur_epoch, config, stopping_step, flag_step=10):
+    """Patience-10 early stopping on HR with `>=` (macr_mf/train.py:313-330)."""
+    if hr >= config['best_hr']:
+        stopping_step = 0
+        config.update(best_hr=hr, best_ndcg=ndcg, best_recall=recall, best_pre=precision, best_epoch=cur_epoch)
+    else:
+        stopping_step += 1
+    should_stop = stopping_step >= flag_step
+    if should_stop:
+        print("Early stopping is trigger")
+    return config, stopping_step, should_stop
+
+
+def _ckpt_dir():
+    return '{}_{}_checkpoint/wd_{}_lr_{}_{}/'.format(args.model, args.dataset, args.wd, args.lr, args.saveID)
+
+
+def train_epoch(model, kind, n_batch, loss_log):
+    """n_batch = n_train // batch_size + 1 steps (train.py:467-470).  Sampling follows the reference's
+    python `random` stream; per-step losses stay on the device and come back once per epoch."""
+    for idx in range(n_batch):
+        users, pos_items, neg_items = data.sample()
+        model.train_step(kind, model.to_device_batch(users, pos_items, neg_items), loss_log[idx])
+    per_step = loss_log[:n_batch].cpu().numpy()
+    loss = mf_loss = reg_loss = 0.
+    for row in per_step:                                     # same accumulation order as train.py:497-499
+        loss += row[0] / n_batch
+        mf_loss += row[1] / n_batch
+        reg_loss += row[2] / n_batch
+    return loss, mf_loss, reg_loss
+
+
+def main(sweep=False):
+    """sweep=True is macr_mf/tune.py: evaluate np.linspace(--start, --end, --step) values of c instead of --c."""
+    seed = args.seed
+    random.seed(seed)
+    os.environ['PYTHONHASHSEED'] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    logging.basicConfig(filename="{}_{}_{}_{}".format(args.model, args.dataset, args.train, args.wd))
+    if args.model != 'mf':
+        raise NotImplementedError("--model %s is out of scope (mf only)" % args.model)
+    if not torch.cuda.is_available():
+        raise SystemExit("macr_mf/train.py needs an MI355X: the HIP path has no CPU fallback")
+    dev_index = int(os.environ.get("LOCAL_RANK", args.cuda)) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group("nccl")        # item-sharded evaluation across the node's GPUs
+    config = dict(n_users=data.n_users, n_items=data.n_items)
+    model = BPRMF(args, config, seed=seed)
+    print('MF model.')
+    sess = Session(model)
+    kind = model.kind_of(args.train)
+    if args.pretrain != 0:
+        raise NotImplementedError("--pretrain 1 restores a hard-coded TF checkpoint in the reference; out of scope")
+
+    config["best_hr"], config["best_ndcg"], config['best_recall'], config['best_pre'], config["best_epoch"] = 0, 0, 0, 0, 0
+    config['best_c_hr'], config['best_c_epoch'], config['best_c'] = 0, 0, 0.0
+    stopping_step = 0
+    n_batch = data.n_train // args.batch_size + 1
+    loss_log = torch.zeros((n_batch, 3), dtype=torch.float32, device=model.device)
+    for epoch in range(args.epoch):
+        t1 = time()
+        loss, mf_loss, reg_loss = train_epoch(model, kind, n_batch, loss_log)
+        if np.isnan(loss):
+            print('ERROR: loss is nan.')
+            sys.exit()
+        if (epoch + 1) % args.log_interval != 0:
+            if args.verbose > 0 and epoch % args.verbose == 0:
+                perf_str = 'Epoch %d [%.1fs]: train==[%.5f=%.5f + %.5f]' % (epoch, time() - t1, loss, mf_loss, reg_loss)
+                print(perf_str)
+                logging.info(perf_str)
+            continue
+
+        t2 = time()
+        users_to_test = list((data.test_user_list if args.valid_set == "test" else data.valid_user_list).keys())
+        tail = ('train==[%.8f=%.8f + %.8f], recall=[%.5f, %.5f], precision=[%.5f, %.5f], hit=[%.5f, %.5f], '
+                'ndcg=[%.5f, %.5f]')
+        def report(head, ret):
+            if args.verbose > 0:
+                perf_str = head + tail % (loss, mf_loss, reg_loss, ret['recall'][0], ret['recall'][-1],
+                                          ret['precision'][0], ret['precision'][-1], ret['hit_ratio'][0],
+                                          ret['hit_ratio'][-1], ret['ndcg'][0], ret['ndcg'][-1])
+                print(perf_str)
+                logging.info(perf_str)
+
+        if args.test in ("normal", "rubi_user_wise"):
+            ret = test(sess, model, users_to_test, valid_set=args.valid_set)
+            report('Epoch %d [%.1fs + %.1fs]: ' % (epoch, t2 - t1, time() - t2), ret)
+        elif args.test == "rubi":
+            print('Epoch %d' % epoch)
+            if args.train != 'rubibceboth':
+                raise NotImplementedError("--test rubi needs --train rubibceboth on the hot path")
+            c_values = np.linspace(args.start, args.end, args.step) if sweep else [args.c]
+            best = (0, 0, 0, 0, 0.0)               # train.py:540-544: bests start at 0
+            for c in c_values:                      # tune.py:545-578: the best c of the sweep drives early stopping
+                model.update_c(sess, c)
+                ret = test(sess, model, users_to_test, model_type="rubi_both", valid_set=args.valid_set)
+                report('c:%.2f [%.1fs + %.1fs]: ' % (c, t2 - t1, time() - t2), ret)
+                if ret['hit_ratio'][0] > best[0]:
+                    best = (ret['hit_ratio'][0], ret['recall'][0], ret['precision'][0], ret['ndcg'][0], c)
+            ret['hit_ratio'][0], ret['recall'][0], ret['precision'][0], ret['ndcg'][0] = best[:4]
+            if best[0] > config['best_c_hr']:
+                config['best_c_hr'], config['best_c'], config['best_c_epoch'] = best[0], best[4], epoch
+        else:
+            raise NotImplementedError("--test %s" % args.test)
+
+        config, stopping_step, should_stop = early_stop(ret['hit_ratio'][0], ret['ndcg'][0], ret['recall'][0],
+                                                        ret['precision'][0], epoch, config, stopping_step)
+        if args.save_flag == 1:
+            os.makedirs(_ckpt_dir(), exist_ok=True)
+            torch.save(model.state_dict(), _ckpt_dir() + '{}_ckpt.pt'.format(epoch))
+        if should_stop and args.early_stop == 1:
+            msg = "{} dataset best epoch{}: hr:{} ndcg:{} recall:{} precision:{}".format(
+                args.dataset, config['best_epoch'], config['best_hr'], config['best_ndcg'], config['best_recall'],
+                config['best_pre'])
+            print(msg)
+            logging.info(msg)
+            os.makedirs(_ckpt_dir(), exist_ok=True)
+            with open(_ckpt_dir() + 'best_epoch.txt', 'w') as f:
+                print(config['best_epoch'], file=f)
+            if args.test == 'rubi':
+                with open(_ckpt_dir() + 'best_c.txt', 'w') as f:
+                    print(config['best_c'], file=f)
+            break
+
+
+if __name__ == '__main__':
+    main()

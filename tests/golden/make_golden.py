@@ -220,6 +220,12 @@ def run_mf(dataset, out):
             hit=float(ref_train.hit_at_k(r, k)),
             dcg=float(ref_train.dcg_at_k(r, k))))
     g["G8"] = g8
+
+    # ---- G9 default values of every CLI flag (macr_mf/parse.py:3-92)
+    import parse as ref_parse
+    argv, sys.argv = sys.argv, ["train.py"]
+    g["G9"] = {k: v for k, v in vars(ref_parse.parse_args()).items()}
+    sys.argv = argv
     with open(out, "w") as f:
         json.dump(g, f, indent=1, sort_keys=True)
     shutil.rmtree(work, ignore_errors=True)
@@ -372,6 +378,10 @@ def run_lgcn(dataset, out):
             cases[name + "_results"] = res
             cases[name + "_rankings"] = rank
         np.savez_compressed(os.path.join(HERE, "G7_cpp_eval_cases.npz"), **cases)
+    import utility.parser as ref_parser            # G9: macr_lightgcn/utility/parser.py:10-104
+    argv, sys.argv = sys.argv, ["LightGCN.py"]
+    g["G9"] = {k: v for k, v in vars(ref_parser.parse_args()).items()}
+    sys.argv = argv
     with open(out, "w") as f:
         json.dump(g, f, indent=1, sort_keys=True)
     shutil.rmtree(work, ignore_errors=True)

@@ -1,0 +1,168 @@
+"""The PRODUCT evaluators and CLIs on the GPU (-m gpu): against the reference-generated goldens
+(G5-G7), against the oracle end to end on Addressa, and as command lines."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import GOLD, REPO, dataset_args, golden, masked_scores, score_matrix
+from macr_amd.data import LGCNData, MFData
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from macr_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ----------------------------------------------------------------------------- goldens through the HIP kernels
+@pytest.mark.parametrize("dataset", ["addressa", "tiny"])
+def test_G5_mf_evaluator_on_hip(ops, dataset):
+    """macr_mf/train.py test() outputs (G5) reproduced by macr_topk_scores + macr_metrics_mf + macr_colmean."""
+    g = golden("mf", dataset)["G5"]
+    data = MFData(dataset_args(dataset))
+    users = list(data.test_user_list.keys())
+    mask, gt = data.eval_lists(users)
+    gtc = ops.CSR.from_lists(gt, "cuda")
+    Kmax = max(g["Ks"])
+    cnt = dev(np.asarray([min(Kmax, data.n_items - len(set(m))) for m in mask], np.int32))
+    for kind, seed in g["seeds"].items():
+        full = score_matrix(kind, data.n_users, data.n_items, seed)
+        s = masked_scores(full[np.asarray(users)], mask)         # candidates = all items - train items
+        idx, _ = ops.topk_scores(dev(s), Kmax)
+        m = ops.colmean(ops.metrics_mf(idx, cnt, gtc, g["Ks"])).cpu().numpy()
+        want = g["results"]["%s/o" % kind]
+        for row, k in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
+            np.testing.assert_allclose(m[row], want[k], rtol=1e-12, atol=1e-15, err_msg="%s %s" % (kind, k))
+
+
+@pytest.mark.parametrize("dataset", ["addressa", "tiny"])
+def test_G6_lgcn_evaluator_on_hip(ops, dataset):
+    """utility/batch_test.py test() outputs (G6) via the drop-in eval_score_matrix_foldout path."""
+    from macr_amd.evaluator import eval_score_matrix_foldout
+    g = golden("lgcn", dataset)["G6"]
+    a = dataset_args(dataset)
+    dg = LGCNData(path=a.data_path + a.dataset, batch_size=a.batch_size, args=a)
+    users = list(dg.test_set.keys())
+    mask, gt = dg.eval_lists(users)
+    top_show = np.sort(np.asarray(g["Ks"]))
+    max_top = int(top_show.max())
+    for kind, seed in g["seeds"].items():
+        if kind == "ties":
+            continue
+        full = score_matrix(kind, dg.n_users, dg.n_items, seed)
+        res = eval_score_matrix_foldout(masked_scores(full[np.asarray(users)], mask), gt, max_top)
+        assert res.dtype == np.float32 and res.shape == (len(users), 5 * max_top)
+        res[:, 2 * max_top:3 * max_top] = (res[:, max_top:2 * max_top] != 0)
+        final = res.astype(np.float64).mean(0).reshape(5, max_top)[:, top_show - 1]
+        want = g["results"]["%s/normal" % kind]
+        np.testing.assert_allclose(final[2], want["hr"], rtol=2e-6)
+        np.testing.assert_allclose(final[1], want["recall"], rtol=2e-6)
+        np.testing.assert_allclose(final[3], want["ndcg"], rtol=2e-6)
+
+
+# ----------------------------------------------------------------------------- fused path, end to end on Addressa
+@pytest.mark.parametrize("kind", [0, 1])
+def test_fused_evaluators_match_oracle_on_addressa(ops, kind):
+    from macr_amd.evaluator import Evaluator
+    data = MFData(dataset_args("addressa"))
+    users = list(data.test_user_list.keys())
+    mask, gt = data.eval_lists(users)
+    rs = np.random.RandomState(5)
+    d = 64
+    P = (rs.standard_normal((data.n_users, d)) * 0.4).astype(np.float32)
+    Q = (rs.standard_normal((data.n_items, d)) * 0.4 + rs.standard_normal((data.n_items, 1)) * 0.3).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    c, Ks = 40.0, [5, 20]
+    ev = Evaluator(mask, gt, data.n_items, torch.device("cuda"))
+    uid = dev(np.asarray(users, np.int32))
+    Pd, Qd, wd, wud = dev(P), dev(Q), dev(w), dev(wu)
+    sig_i = ops.branch_sigmoid(Qd, wd).cpu().numpy()
+    sig_u = ops.branch_sigmoid(Pd, wud, uid).cpu().numpy()
+    mcsr, gcsr = oracle.csr_from_lists(mask), oracle.csr_from_lists(gt)
+    _, oi, oc = oracle.score_topk(kind, P[users], Q, max(Ks), sig_u, sig_i, c, mcsr)
+    got = ev.test_mf(kind, Pd, uid, Qd, Ks, wd, wud, c)
+    want = oracle.metrics_mf(oi, oc, gcsr, Ks).mean(0)
+    for row, k in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
+        np.testing.assert_allclose(got[k], want[row], rtol=1e-12, err_msg=k)         # HR/NDCG@20 within 1e-4 (north star)
+    got = ev.test_lgcn(kind, Pd, uid, Qd, Ks, wd, wud, c)
+    _, oi, _ = oracle.score_topk(kind, P[users], Q, max(Ks), sig_u, sig_i, c, mcsr, fill_masked=True)
+    res = oracle.metrics_foldout(oi, gcsr)
+    K = max(Ks)
+    res[:, 2 * K:3 * K] = (res[:, K:2 * K] != 0)
+    fin = res.astype(np.float64).mean(0).reshape(5, K)[:, np.asarray(sorted(Ks)) - 1]
+    np.testing.assert_allclose(got["hr"], fin[2], rtol=1e-6)
+    np.testing.assert_allclose(got["recall"], fin[1], rtol=1e-6)
+    np.testing.assert_allclose(got["ndcg"], fin[3], rtol=1e-6)
+
+
+def test_session_shim_matches_fast_path(ops):
+    """sess.run(fetches, feed_dict) (the reference's call boundary) == the direct train_step / ratings calls."""
+    import types
+    from macr_amd.mf import BPRMF, Session
+    args = types.SimpleNamespace(regs=1e-5, embed_size=64, lr=1e-3, batch_size=256, verbose=0, c=40.0, alpha=1e-2, beta=1e-3)
+    cfg = dict(n_users=900, n_items=300)
+    a, b = BPRMF(args, cfg, seed=7), BPRMF(args, cfg, seed=7)
+    sess = Session(a)
+    rs = np.random.RandomState(0)
+    u = rs.choice(900, 256, replace=False).tolist(); i = rs.randint(0, 300, 256).tolist(); j = rs.randint(0, 300, 256).tolist()
+    for name in ("two_bce_both", "bce"):
+        fetch = [getattr(a, "opt_" + name), getattr(a, "loss_" + name), getattr(a, "mf_loss_" + name),
+                 getattr(a, "reg_loss_" + name)]
+        _, loss, mf, reg = sess.run(fetch, feed_dict={a.users: u, a.pos_items: i, a.neg_items: j})
+        kind = getattr(b, "opt_" + name).kind
+        direct = b.train_step(kind, b.to_device_batch(u, i, j)).cpu().numpy()
+        np.testing.assert_allclose([loss, mf, reg], direct, rtol=1e-6)
+    a.update_c(sess, 40.0); b.update_c(None, 40.0)
+    S = sess.run(a.rubi_ratings_both, {a.users: u[:50], a.pos_items: list(range(300))})
+    assert S.shape == (50, 300) and S.dtype == np.float32
+    np.testing.assert_allclose(S, b.ratings(ops.SCORE_RUBI_BOTH, u[:50]).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        sess.run(a.opt_two, {a.users: u, a.pos_items: i, a.neg_items: j})
+
+
+# ----------------------------------------------------------------------------- command lines
+def _run_cli(cmd, cwd):
+    env = dict(os.environ, PYTHONUNBUFFERED="1")
+    out = subprocess.run([sys.executable] + cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("train,test_", [("normalbce", "normal"), ("rubibceboth", "rubi")])
+def test_mf_cli_addressa(tmp_path, train, test_):
+    os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
+    out = _run_cli([os.path.join(REPO, "macr_mf", "train.py"), "--dataset", "addressa", "--batch_size", "1024",
+                    "--cuda", "0", "--saveID", "t", "--log_interval", "2", "--lr", "0.001", "--epoch", "4",
+                    "--train", train, "--test", test_, "--c", "40", "--alpha", "1e-3", "--beta", "1e-3"], str(tmp_path))
+    lines = [l for l in out.splitlines() if "train==[" in l]
+    assert len(lines) == 4, out
+    evals = [l for l in lines if "hit=[" in l]
+    assert len(evals) == 2 and all(("Epoch" in l) or l.startswith("c:40.00") for l in evals)
+    hit = float(evals[-1].split("hit=[")[1].split(",")[0])
+    assert 0.0 < hit < 1.0
+    assert os.path.exists(tmp_path / ("mf_addressa_checkpoint/wd_1e-05_lr_0.001_t/3_ckpt.pt"))
+
+
+def test_lightgcn_cli_addressa(tmp_path):
+    out = _run_cli([os.path.join(REPO, "macr_lightgcn", "LightGCN.py"), "--data_path", os.path.join(REPO, "data") + "/",
+                    "--dataset", "addressa", "--verbose", "1", "--layer_size", "[64,64]", "--Ks", "[20]", "--loss",
+                    "bceboth", "--test", "rubiboth", "--c", "40", "--epoch", "4", "--early_stop", "1", "--lr", "0.001",
+                    "--batch_size", "1024", "--gpu_id", "0", "--log_interval", "2", "--alpha", "1e-2", "--beta", "1e-3",
+                    "--weights_path", str(tmp_path) + "/"], str(tmp_path))
+    assert out.count("train==[") == 2 and out.count("c:40.00 recall=[") == 2, out
+    hit = float(out.split("hit=[")[-1].split(",")[0])
+    assert 0.0 < hit < 1.0
+    assert not [f for f in os.listdir(os.path.join(REPO, "data", "addressa")) if f.endswith(".npz")]
