@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof (tools/profile.sh) into the small, committed files under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (all kernels of the bench run)
+  profiles/<tag>_pmc.json           per-kernel averages of the PMC passes
+  profiles/pmc_latest.json          {workload: {kernel: HBM bytes per launch}} read by bench.py (`traffic`)
+HBM bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE reports half of a wide coalesced
+read stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated."""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    m = re.search(r"macr::k_([a-z_]+)", name)
+    return m.group(1) if m else None
+
+
+def pmc_avgs(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        if k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+
+
+def main(tag, workload="gowalla"):
+    os.makedirs(DST, exist_ok=True)
+    shutil.copyfile(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, tag + "_kernel_stats.csv"))
+    shutil.copyfile(os.path.join(SRC, "bench_trace.json"), os.path.join(DST, tag + "_bench_under_rocprof.json"))
+    pmc = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        p = os.path.join(SRC, sub, "bench_counter_collection.csv")
+        if os.path.exists(p):
+            for k, d in pmc_avgs(p).items():
+                pmc.setdefault(k, {}).update(d)
+    traffic = {}
+    for k, d in pmc.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+            traffic[k] = d["hbm_bytes_per_launch"]
+    json.dump(pmc, open(os.path.join(DST, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+    latest_path = os.path.join(DST, "pmc_latest.json")
+    latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
+    latest[workload] = traffic
+    json.dump(latest, open(latest_path, "w"), indent=1, sort_keys=True)
+    for k, d in sorted(pmc.items()):
+        print(k, {c: round(v, 1) for c, v in d.items()})
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
