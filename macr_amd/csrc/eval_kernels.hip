@@ -16,6 +16,13 @@
 
 namespace macr {
 
+#ifdef MACR_ABL_COUNT
+__device__ unsigned long long g_dbg[8];      // [0] tiles with any candidate (per wave), [1] appended keys, [2] compactions, [3] tiles
+#define MACR_DBG_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dbg[k], (unsigned long long)(v)); } while (0)
+#else
+#define MACR_DBG_ADD(k, v) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kCap = 64;          // candidate buffer entries per user (= one wave-wide sort)
@@ -25,22 +32,49 @@ constexpr int kUnitStride = kUnitK + 1;   // odd stride: conflict-free fragment 
 constexpr int kWavesPerBlock = 8;
 constexpr int kUsersPerBlock = 32 * kWavesPerBlock;
 
-// Wave-cooperative compaction of one user's candidate buffer: sort the (<= 64) keys,
-// keep the best K, publish the new count and the admission threshold (K-th best score,
-// or -inf while fewer than K candidates exist).  All 64 lanes must call it.
-__device__ __forceinline__ void compact_buffer(uint64_t *keys, uint32_t *cnt, float *thr, int K) {
+// Wave-cooperative compaction of one user's candidate buffer (<= 64 keys, one per lane): keep the
+// best K, publish the new count and the admission threshold (K-th best score, or -inf while fewer
+// than K candidates exist).  All 64 lanes must call it.
+//
+// Selection, not sorting: the K-th largest key is found by a most-significant-bit-first radix
+// select whose state is a 64-bit lane mask in SGPRs (one v_cmp + a few s_* per bit, no cross-lane
+// data movement, early exit as soon as one candidate is left -- usually after 10-20 bits); the
+// survivors are then packed to the front with a prefix popcount.  (A 64-lane bitonic sort through
+// ds_bpermute cost ~5k cycles per call and dominated the kernel.)  The buffer stays unsorted; only
+// the final result is sorted.
+__device__ __forceinline__ void compact_buffer(uint64_t *keys, uint32_t *cnt, float *thr, int K,
+                                               uint64_t *kth_out = nullptr) {
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint32_t c = *cnt;
-    uint64_t key = (lane < (int)c) ? keys[lane] : 0ull;
-    key = wave_sort_desc(key);
-    if (lane < K) keys[lane] = key;
-    const uint32_t hi_k = __shfl((uint32_t)(key >> 32), K - 1, kWave);
-    const uint32_t lo_k = __shfl((uint32_t)key, K - 1, kWave);
+    const bool valid = lane < (int)c;
+    const uint64_t key = valid ? keys[lane] : 0ull;
+    uint64_t kth = 0ull;                                 // 0 = fewer than K candidates: no threshold yet
+    if (c >= (uint32_t)K) {                              // (uniform)
+        uint64_t cand = __ballot(valid);                 // lanes that may still be the K-th largest
+        int remaining = K;
+        for (int bit = 63; bit >= 0; --bit) {
+            if (__popcll(cand) == 1) break;              // keys are distinct (ids differ): one candidate left
+            const uint64_t ones = __ballot((key >> bit) & 1ull) & cand;
+            const int n1 = __popcll(ones);
+            if (n1 >= remaining) cand = ones;            // the K-th largest has this bit set
+            else { remaining -= n1; cand &= ~ones; }
+        }
+        const int kth_lane = __ffsll((long long)cand) - 1;
+        const uint32_t kth_hi = __shfl((uint32_t)(key >> 32), kth_lane, kWave);
+        const uint32_t kth_lo = __shfl((uint32_t)key, kth_lane, kWave);
+        kth = ((uint64_t)kth_hi << 32) | kth_lo;
+        if (c > (uint32_t)K) {
+            const bool keep = valid && key >= kth;
+            const uint64_t kmask = __ballot(keep);
+            // every lane holds its key in a register: overwrite the front of the buffer with the survivors
+            if (keep) keys[__popcll(kmask & ((1ull << lane) - 1ull))] = key;
+        }
+    }
     if (lane == 0) {
         *cnt = c < (uint32_t)K ? c : (uint32_t)K;
-        const bool full = (hi_k | lo_k) != 0u;
-        *thr = full ? orderable_f32(hi_k) : -INFINITY;
+        *thr = kth ? orderable_f32((uint32_t)(kth >> 32)) : -INFINITY;
+        if (kth_out) *kth_out = kth;
     }
     // other lanes read cnt/thr/keys next: the compiler must not forward values it loaded before
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -211,7 +245,12 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
 #pragma unroll
                     for (int r = 8 * half; r < 8 * half + 8; ++r) cand |= (s[r] > thr) ? (1u << r) : 0u;
                     const uint32_t n_l = __popc(cand);
+                    MACR_DBG_ADD(3, 1);
                     if (__any(n_l != 0)) {
+                        MACR_DBG_ADD(0, 1);
+#ifdef MACR_ABL_COUNT
+                        { unsigned tot = n_l; for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, kWave); MACR_DBG_ADD(1, tot); }
+#endif
                         uint32_t end = 0;
                         if (n_l) {
                             uint32_t pos = atomicAdd(&s_cnt[uslot], n_l);      // ONE LDS atomic per lane and round
@@ -234,6 +273,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
                                 const int ucol = __ffs((int)todo) - 1;
                                 todo &= todo - 1;
                                 const int us = wid * 32 + ucol;
+                                MACR_DBG_ADD(2, 1);
                                 compact_buffer(s_keys + (size_t)us * kCap, &s_cnt[us], &s_thr[us], K);
                             }
                             if (mine && q_ok) thr = s_thr[uslot];
@@ -321,6 +361,7 @@ __global__ __launch_bounds__(256) void k_score_matrix(int U, int n_local, const 
 __global__ __launch_bounds__(256) void k_topk_scores(const float *__restrict__ scores, int cols, int rows, int K,
                                                      int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
     __shared__ uint64_t s_keys[4][kCap];
+    __shared__ uint64_t s_kth[4];
     __shared__ uint32_t s_cnt[4];
     __shared__ float s_thr[4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -343,9 +384,9 @@ __global__ __launch_bounds__(256) void k_topk_scores(const float *__restrict__ s
             if (bal == 0) continue;
             if (cnt + (uint32_t)__popcll(bal) > (uint32_t)kCap) {
                 if (lane == 0) s_cnt[wid] = cnt;
-                compact_buffer(keys, &s_cnt[wid], &s_thr[wid], K);
+                compact_buffer(keys, &s_cnt[wid], &s_thr[wid], K, &s_kth[wid]);
                 cnt = s_cnt[wid];
-                thr_key = cnt >= (uint32_t)K ? keys[K - 1] : 0ull;
+                thr_key = s_kth[wid];
                 cand = mine && key > thr_key;
                 bal = __ballot(cand);
             }
@@ -511,6 +552,14 @@ __global__ __launch_bounds__(256) void k_colmean(const T *__restrict__ in, int r
 // C ABI
 // ============================================================================
 using namespace macr;
+
+#ifdef MACR_ABL_COUNT
+extern "C" void macr_dbg_counters(unsigned long long *out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(macr::g_dbg), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(macr::g_dbg), z, sizeof(z));
+}
+#endif
 
 extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
     (void)d;

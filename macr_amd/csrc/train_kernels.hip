@@ -59,14 +59,11 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
     const float *__restrict__ Usrc, const float *__restrict__ Isrc,
     const float *__restrict__ w, const float *__restrict__ wu,
     float *__restrict__ fwd, float *__restrict__ part, int reg_on_gathered,
-    const float *__restrict__ adam_pow_in, float *adam_pow_out, StepScalars *scal, float lr, float b1, float b2,
-    float *gw_zero /* [2*d]: branch-vector gradient accumulators, cleared here for pair_bwd */) {
+    const float *__restrict__ adam_pow_in, float *adam_pow_out, StepScalars *scal, float lr, float b1, float b2) {
     constexpr int d = 4 * LPR;
     __shared__ float red[16];
     RowGroup<LPR> g;
     const int t = blockIdx.x * RowGroup<LPR>::kRowsPerBlock + g.slot;
-    if (blockIdx.x == 0)
-        for (int k = threadIdx.x; k < 2 * d; k += 256) gw_zero[k] = 0.f;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // Adam bias correction for this step, then advance TF's fp32 beta powers.
         const float p1 = adam_pow_in[0], p2 = adam_pow_in[1];
@@ -190,78 +187,94 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, const float *__restr
 }
 
 // ----------------------------------------------------------------------------
+// Row scatter pattern (measured, tools/atomic_bench.hip): a device-scope fp32 atomic INSTRUCTION
+// that hits an L2 line already being updated serialises at ~24 ns.  One wave therefore owns one
+// whole row: lane k adds element k (+64, +128 ...), so a 256-B row at d=64 is ONE atomic
+// instruction covering two full lines instead of four instructions touching both lines four
+// times (16 lanes x float4 layout): 45 -> 12.5 us for a Zipf batch of 12288 row references.
+// Branch-vector gradients are NOT accumulated with atomics at all (every block would hit the same
+// d addresses); each block writes one partial row that adam_dense reduces.
+// ----------------------------------------------------------------------------
+template <int D>
+struct WaveRow {
+    static constexpr int EPL = (D + 63) / 64;          // elements per lane
+    static constexpr int kActive = D < 64 ? D : 64;    // active lanes (d=32 leaves half the wave idle)
+};
+
+// ----------------------------------------------------------------------------
 // pair_bwd (rubibceboth): gradient rows + scatter-add.           SURVEY.md A.1
 //   dp,dn (column sums) and da,db (row sums) come from the bxb partials / B^2
 //   dsi=da*sig'(si)*sig(su)+(alpha/B)f'(si) ...  deu=dp*ei+dn*ej+dsu*wu+coef*eu ...
 //   gU[u]+=deu, gI[i]+=dei, gI[j]+=dej  (duplicates summed = TF IndexedSlices
 //   de-duplication before the sparse apply, macr_mf/model.py:74)
-//   gw+=ei*dsi+ej*dsj, gwu+=eu*dsu
-// Scatter uses hardware fp32 atomics (global_atomic_add_f32): hot items (Addressa
-// item 0 is in half of the batch) pipeline in L2 instead of serialising a CAS loop.
+//   wpart[block] = sum over the block's triples of {ei*dsi+ej*dsj, eu*dsu}
+// One wave per triple (grid-strided); lane k owns element k of every row.
 // ----------------------------------------------------------------------------
-template <int LPR>
+template <int D>
 __global__ __launch_bounds__(256) void k_pair_bwd(
     int B, int Bp, int nrb, int ncb, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
     const int32_t *__restrict__ j, const float *__restrict__ Usrc, const float *__restrict__ Isrc,
     const float *__restrict__ w, const float *__restrict__ wu, const float *__restrict__ fwd,
     const float *__restrict__ rowpart, const float *__restrict__ colpart,
-    float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *gw, float *gwu,
+    float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *__restrict__ wpart,
     float alpha, float beta, float coef) {
-    constexpr int d = 4 * LPR;
-    constexpr int RPB = RowGroup<LPR>::kRowsPerBlock;
-    __shared__ float4 s_w[RPB][LPR], s_wu[RPB][LPR];
-    RowGroup<LPR> g;
-    const int t = blockIdx.x * RPB + g.slot;
-    float4 aw = make_float4(0, 0, 0, 0), awu = aw;
-    if (t < B) {
-        // sum the partials cooperatively inside the group
+    constexpr int EPL = WaveRow<D>::EPL;
+    __shared__ float s_w[4][2][D];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool act = lane < WaveRow<D>::kActive;
+    float wk[EPL], wuk[EPL], aw[EPL], awu[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int k = lane + 64 * e;
+        wk[e] = act ? w[k] : 0.f; wuk[e] = act ? wu[k] : 0.f; aw[e] = 0.f; awu[e] = 0.f;
+    }
+    const float inv_b2 = 1.0f / ((float)B * (float)B), eps = 1e-10f, invB = 1.0f / (float)B;
+    for (int t = blockIdx.x * 4 + wid; t < B; t += gridDim.x * 4) {
+        // per-triple scalars: the wave sums the bxb partials cooperatively
         float dp = 0.f, dn = 0.f, da = 0.f, db = 0.f;
 #ifndef MACR_ABL_NOPART
-        for (int k = g.sub; k < nrb; k += LPR) {
+        for (int k = lane; k < nrb; k += 64) {
             dp += colpart[((size_t)k * 2 + 0) * Bp + t];
             dn += colpart[((size_t)k * 2 + 1) * Bp + t];
         }
-        for (int k = g.sub; k < ncb; k += LPR) {
+        for (int k = lane; k < ncb; k += 64) {
             da += rowpart[((size_t)k * 2 + 0) * Bp + t];
             db += rowpart[((size_t)k * 2 + 1) * Bp + t];
         }
 #endif
-        const float inv_b2 = 1.0f / ((float)B * (float)B);
-        dp = group_sum<LPR>(dp) * inv_b2; dn = group_sum<LPR>(dn) * inv_b2;
-        da = group_sum<LPR>(da) * inv_b2; db = group_sum<LPR>(db) * inv_b2;
-        const float eps = 1e-10f, invB = 1.0f / (float)B;
+        dp = wave_sum(dp) * inv_b2; dn = wave_sum(dn) * inv_b2;
+        da = wave_sum(da) * inv_b2; db = wave_sum(db) * inv_b2;
         const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
         const float dsi = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
         const float dsj = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
         const float dsu = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
                           (beta * invB) * (dneglog_sig(ssu, eps) + dneglog_1msig(ssu, eps));
         const int ru = u[t], ri = i[t], rj = j[t];
-        const float4 eu = ld4(Usrc + (size_t)ru * d + 4 * g.sub);
-        const float4 ei = ld4(Isrc + (size_t)ri * d + 4 * g.sub);
-        const float4 ej = ld4(Isrc + (size_t)rj * d + 4 * g.sub);
-        const float4 w4 = ld4(w + 4 * g.sub), wu4 = ld4(wu + 4 * g.sub);
-        float4 gu = scale4(dp, ei); gu = fma4(dn, ej, gu); gu = fma4(dsu, wu4, gu); gu = fma4(coef, eu, gu);
-        float4 gi = scale4(dp, eu); gi = fma4(dsi, w4, gi); gi = fma4(coef, ei, gi);
-        float4 gj = scale4(dn, eu); gj = fma4(dsj, w4, gj); gj = fma4(coef, ej, gj);
-        float *pu = gU + (size_t)ru * d + 4 * g.sub, *pi = gI + (size_t)ri * d + 4 * g.sub,
-              *pj = gI + (size_t)rj * d + 4 * g.sub;
-        MACR_ATOMIC_ADD(pu + 0, gu.x); MACR_ATOMIC_ADD(pu + 1, gu.y); MACR_ATOMIC_ADD(pu + 2, gu.z); MACR_ATOMIC_ADD(pu + 3, gu.w);
-        MACR_ATOMIC_ADD(pi + 0, gi.x); MACR_ATOMIC_ADD(pi + 1, gi.y); MACR_ATOMIC_ADD(pi + 2, gi.z); MACR_ATOMIC_ADD(pi + 3, gi.w);
-        MACR_ATOMIC_ADD(pj + 0, gj.x); MACR_ATOMIC_ADD(pj + 1, gj.y); MACR_ATOMIC_ADD(pj + 2, gj.z); MACR_ATOMIC_ADD(pj + 3, gj.w);
-        if (g.sub == 0 && touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
-        aw = scale4(dsi, ei); aw = fma4(dsj, ej, aw);
-        awu = scale4(dsu, eu);
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int k = lane + 64 * e;
+                const float eu = Usrc[(size_t)ru * D + k], ei = Isrc[(size_t)ri * D + k], ej = Isrc[(size_t)rj * D + k];
+                const float gu = fmaf(coef, eu, fmaf(dsu, wuk[e], fmaf(dn, ej, dp * ei)));
+                const float gi = fmaf(coef, ei, fmaf(dsi, wk[e], dp * eu));
+                const float gj = fmaf(coef, ej, fmaf(dsj, wk[e], dn * eu));
+                MACR_ATOMIC_ADD(gU + (size_t)ru * D + k, gu);
+                MACR_ATOMIC_ADD(gI + (size_t)ri * D + k, gi);
+                MACR_ATOMIC_ADD(gI + (size_t)rj * D + k, gj);
+                aw[e] = fmaf(dsi, ei, fmaf(dsj, ej, aw[e]));
+                awu[e] = fmaf(dsu, eu, awu[e]);
+            }
+        }
+        if (lane == 0 && touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
     }
-    // reduce the branch-vector gradients over the block's rows, one atomic per float per block
-    s_w[g.slot][g.sub] = aw;
-    s_wu[g.slot][g.sub] = awu;
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { s_w[wid][0][lane + 64 * e] = aw[e]; s_w[wid][1][lane + 64 * e] = awu[e]; }
+    }
     __syncthreads();
-    if (threadIdx.x < LPR) {
-        float4 sw = make_float4(0, 0, 0, 0), swu = sw;
-        for (int k = 0; k < RPB; ++k) { sw = add4(sw, s_w[k][threadIdx.x]); swu = add4(swu, s_wu[k][threadIdx.x]); }
-        float *pw = gw + 4 * threadIdx.x, *pwu = gwu + 4 * threadIdx.x;
-        MACR_ATOMIC_ADD(pw + 0, sw.x); MACR_ATOMIC_ADD(pw + 1, sw.y); MACR_ATOMIC_ADD(pw + 2, sw.z); MACR_ATOMIC_ADD(pw + 3, sw.w);
-        MACR_ATOMIC_ADD(pwu + 0, swu.x); MACR_ATOMIC_ADD(pwu + 1, swu.y); MACR_ATOMIC_ADD(pwu + 2, swu.z); MACR_ATOMIC_ADD(pwu + 3, swu.w);
+    for (int k = threadIdx.x; k < 2 * D; k += 256) {
+        const int q = k / D, kk = k % D;
+        wpart[(size_t)blockIdx.x * 2 * D + k] = (s_w[0][q][kk] + s_w[1][q][kk]) + (s_w[2][q][kk] + s_w[3][q][kk]);
     }
 }
 
@@ -270,19 +283,19 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
 //   mf = mean(-log(sig(p)+1e-9) - log(1-sig(n)+1e-9))            macr_mf/model.py:277-287
 //   dp = f'(p)/B, dn = g'(n)/B;  deu=dp*ei+dn*ej, dei=dp*eu, dej=dn*eu (+coef*row)
 // Algorithmic HBM bytes per triple: 3 rows read + 3 gradient rows written + 12 B indices
-// = 24*d+12.
+// = 24*d+12.  One wave per triple, lane k owns element k.
 // ----------------------------------------------------------------------------
-template <int LPR>
+template <int D>
 __global__ __launch_bounds__(256) void k_pair_normal(
     int B, const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
     const float *__restrict__ Usrc, const float *__restrict__ Isrc,
     float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *__restrict__ part, float coef,
     int reg_on_gathered, const float *__restrict__ adam_pow_in, float *adam_pow_out, StepScalars *scal,
     float lr, float b1, float b2) {
-    constexpr int d = 4 * LPR;
+    constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float red[16];
-    RowGroup<LPR> g;
-    const int t = blockIdx.x * RowGroup<LPR>::kRowsPerBlock + g.slot;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool act = lane < WaveRow<D>::kActive;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const float p1 = adam_pow_in[0], p2 = adam_pow_in[1];
         scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
@@ -290,27 +303,33 @@ __global__ __launch_bounds__(256) void k_pair_normal(
         adam_pow_out[1] = p2 * b2;
     }
     float sq = 0.f, bce = 0.f;
-    if (t < B) {
+    const float eps = 1e-9f, invB = 1.0f / (float)B;
+    for (int t = blockIdx.x * 4 + wid; t < B; t += gridDim.x * 4) {
         const int ru = u[t], ri = i[t], rj = j[t];
-        const float4 eu = ld4(Usrc + (size_t)ru * d + 4 * g.sub);
-        const float4 ei = ld4(Isrc + (size_t)ri * d + 4 * g.sub);
-        const float4 ej = ld4(Isrc + (size_t)rj * d + 4 * g.sub);
-        const float p = group_sum<LPR>(dot4(eu, ei));
-        const float n = group_sum<LPR>(dot4(eu, ej));
-        if (reg_on_gathered) sq = dot4(eu, eu) + dot4(ei, ei) + dot4(ej, ej);
-        const float eps = 1e-9f, invB = 1.0f / (float)B;
+        float eu[EPL], ei[EPL], ej[EPL], pp = 0.f, nn = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int k = lane + 64 * e;
+            eu[e] = act ? Usrc[(size_t)ru * D + k] : 0.f;
+            ei[e] = act ? Isrc[(size_t)ri * D + k] : 0.f;
+            ej[e] = act ? Isrc[(size_t)rj * D + k] : 0.f;
+            pp = fmaf(eu[e], ei[e], pp); nn = fmaf(eu[e], ej[e], nn);
+            if (reg_on_gathered) sq += eu[e] * eu[e] + ei[e] * ei[e] + ej[e] * ej[e];
+        }
+        const float p = wave_sum(pp), n = wave_sum(nn);
         const float sp = sigmoid_acc(p), sn = sigmoid_acc(n);
-        if (g.sub == 0) bce = -logf(sp + eps) + -logf((1.0f - sn) + eps);
+        if (lane == 0) bce += -logf(sp + eps) + -logf((1.0f - sn) + eps);
         const float dp = dneglog_sig(sp, eps) * invB, dn = dneglog_1msig(sn, eps) * invB;
-        float4 gu = scale4(dp, ei); gu = fma4(dn, ej, gu); gu = fma4(coef, eu, gu);
-        float4 gi = scale4(dp, eu); gi = fma4(coef, ei, gi);
-        float4 gj = scale4(dn, eu); gj = fma4(coef, ej, gj);
-        float *pu = gU + (size_t)ru * d + 4 * g.sub, *pi = gI + (size_t)ri * d + 4 * g.sub,
-              *pj = gI + (size_t)rj * d + 4 * g.sub;
-        MACR_ATOMIC_ADD(pu + 0, gu.x); MACR_ATOMIC_ADD(pu + 1, gu.y); MACR_ATOMIC_ADD(pu + 2, gu.z); MACR_ATOMIC_ADD(pu + 3, gu.w);
-        MACR_ATOMIC_ADD(pi + 0, gi.x); MACR_ATOMIC_ADD(pi + 1, gi.y); MACR_ATOMIC_ADD(pi + 2, gi.z); MACR_ATOMIC_ADD(pi + 3, gi.w);
-        MACR_ATOMIC_ADD(pj + 0, gj.x); MACR_ATOMIC_ADD(pj + 1, gj.y); MACR_ATOMIC_ADD(pj + 2, gj.z); MACR_ATOMIC_ADD(pj + 3, gj.w);
-        if (g.sub == 0 && touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int k = lane + 64 * e;
+                MACR_ATOMIC_ADD(gU + (size_t)ru * D + k, fmaf(coef, eu[e], fmaf(dn, ej[e], dp * ei[e])));
+                MACR_ATOMIC_ADD(gI + (size_t)ri * D + k, fmaf(coef, ei[e], dp * eu[e]));
+                MACR_ATOMIC_ADD(gI + (size_t)rj * D + k, fmaf(coef, ej[e], dn * eu[e]));
+            }
+        }
+        if (lane == 0 && touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
     }
     const float s0 = block_sum(sq, red);
     const float s3 = block_sum(bce, red);
@@ -323,27 +342,31 @@ __global__ __launch_bounds__(256) void k_pair_normal(
 // ----------------------------------------------------------------------------
 // reg_scatter (LightGCN): the l2 regulariser acts on the EGO rows
 // (macr_lightgcn/LightGCN.py:525-528): G[row] += (decay/batch_size)*T[row] for the
-// batch rows, and the sum of squares for emb_loss.
+// batch rows, and the sum of squares for emb_loss.  One wave per triple.
 // ----------------------------------------------------------------------------
-template <int LPR>
+template <int D>
 __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const int32_t *__restrict__ u,
                                                      const int32_t *__restrict__ i, const int32_t *__restrict__ j,
                                                      const float *__restrict__ T, float *G, float coef,
                                                      float *__restrict__ part) {
-    constexpr int d = 4 * LPR;
+    constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float red[16];
-    RowGroup<LPR> g;
-    const int t = blockIdx.x * RowGroup<LPR>::kRowsPerBlock + g.slot;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool act = lane < WaveRow<D>::kActive;
     float sq = 0.f;
-    if (t < B) {
+    for (int t = blockIdx.x * 4 + wid; t < B; t += gridDim.x * 4) {
         const int rows[3] = {u[t], i[t] + item_off, j[t] + item_off};
+        if (act) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const float4 e = ld4(T + (size_t)rows[q] * d + 4 * g.sub);
-            sq += dot4(e, e);
-            float *pg = G + (size_t)rows[q] * d + 4 * g.sub;
-            MACR_ATOMIC_ADD(pg + 0, coef * e.x); MACR_ATOMIC_ADD(pg + 1, coef * e.y);
-            MACR_ATOMIC_ADD(pg + 2, coef * e.z); MACR_ATOMIC_ADD(pg + 3, coef * e.w);
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int k = lane + 64 * e;
+                    const float x = T[(size_t)rows[q] * D + k];
+                    sq = fmaf(x, x, sq);
+                    MACR_ATOMIC_ADD(G + (size_t)rows[q] * D + k, coef * x);
+                }
+            }
         }
     }
     const float s0 = block_sum(sq, red);
@@ -361,6 +384,8 @@ __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const 
 // ----------------------------------------------------------------------------
 struct AdamSeg {
     float *theta, *m, *v, *g;
+    int n_parts;             // > 0: g holds n_parts partial rows (stride part_stride floats) to be summed
+    int part_stride;
     int32_t *touched;        // NULL: gradient is dense, always read, left untouched
     long long n_vec;         // number of float4 in the segment
     long long first_block;   // first block index serving this segment
@@ -391,13 +416,27 @@ __global__ __launch_bounds__(256) void k_adam_dense(AdamArgs a, const StepScalar
         if (k < a.n_seg && (long long)blockIdx.x >= a.seg[k].first_block) s = k;
     const AdamSeg sg = a.seg[s];
     const long long base = ((long long)blockIdx.x - sg.first_block) * kAdamVecPerBlock + threadIdx.x;
+    __shared__ float4 s_red[256];
+    float4 gsum = make_float4(0, 0, 0, 0);
+    if (sg.n_parts > 0) {
+        // branch-vector segment (one row): the whole block sums the per-block partial rows of pair_bwd
+        const int sub = threadIdx.x % a.lpr, grp = threadIdx.x / a.lpr, ngrp = 256 / a.lpr;
+        for (int k = grp; k < sg.n_parts; k += ngrp) gsum = add4(gsum, ld4(sg.g + (size_t)k * sg.part_stride + 4 * sub));
+        s_red[threadIdx.x] = gsum;
+        __syncthreads();
+        gsum = make_float4(0, 0, 0, 0);
+        if (threadIdx.x < a.lpr)
+            for (int k = 0; k < ngrp; ++k) gsum = add4(gsum, s_red[k * a.lpr + threadIdx.x]);
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const long long vi = base + (long long)it * 256;
         if (vi < sg.n_vec) {
             float4 th = ld4(sg.theta + vi * 4), m = ld4(sg.m + vi * 4), v = ld4(sg.v + vi * 4);
             float4 gr = make_float4(0, 0, 0, 0);
-            if (sg.touched) {
+            if (sg.n_parts > 0) {
+                gr = gsum;
+            } else if (sg.touched) {
                 const long long row = vi / a.lpr;
                 if (sg.touched[row]) {
                     gr = ld4(sg.g + vi * 4);
@@ -454,6 +493,14 @@ namespace macr {
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
                      const float *E0, float *E, float *work, hipStream_t st);   // spmm_kernels.hip
 
+#define MACR_DISPATCH_D(d, ...)                                  \
+    switch (d) {                                                 \
+        case 32:  { constexpr int D = 32;  __VA_ARGS__; } break; \
+        case 64:  { constexpr int D = 64;  __VA_ARGS__; } break; \
+        case 128: { constexpr int D = 128; __VA_ARGS__; } break; \
+        case 256: { constexpr int D = 256; __VA_ARGS__; } break; \
+    }
+
 static inline int bxb_ct(int B) {
     // columns per block (64 per column tile): more, smaller blocks for small B so the chip stays full
     if (B >= 8192) return 256;
@@ -463,7 +510,8 @@ static inline int bxb_ct(int B) {
 
 struct PairWs {
     StepScalars *scal;
-    float *gw;          // [2*d]  (gw, gwu)
+    float *gw;          // [nblk_bwd][2*d] per-block partial rows of the branch-vector gradients
+    int nblk_bwd;
     float *fwd;         // [7*Bp]
     float *part;        // [nblk_pair*4]
     float *part2;       // [nblk_pair*4]   (LightGCN ego regulariser)
@@ -482,14 +530,16 @@ static PairWs carve_pair_ws(void *base, int B, int d) {
     w.nrb = w.Bp / 256;
     w.ncb = (B + w.ct - 1) / w.ct;
     w.nblk_pair = (B + rpb - 1) / rpb;
+    w.nblk_bwd = (B + 3) / 4 < 256 ? (B + 3) / 4 : 256;     // one wave per triple, grid-strided
     char *p = static_cast<char *>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) { void *r = p ? p + off : nullptr; off += align_up(bytes, 256); return r; };
     w.scal = static_cast<StepScalars *>(take(sizeof(StepScalars)));
-    w.gw = static_cast<float *>(take((size_t)2 * d * 4));
+    w.gw = static_cast<float *>(take((size_t)w.nblk_bwd * 2 * d * 4));
     w.fwd = static_cast<float *>(take((size_t)7 * w.Bp * 4));
-    w.part = static_cast<float *>(take((size_t)w.nblk_pair * kPartStride * 4));
-    w.part2 = static_cast<float *>(take((size_t)w.nblk_pair * kPartStride * 4));
+    const int npart = w.nblk_pair > w.nblk_bwd ? w.nblk_pair : w.nblk_bwd;
+    w.part = static_cast<float *>(take((size_t)npart * kPartStride * 4));
+    w.part2 = static_cast<float *>(take((size_t)npart * kPartStride * 4));
     w.lpart = static_cast<float *>(take((size_t)w.nrb * w.ncb * 4));
     w.rowpart = static_cast<float *>(take((size_t)w.ncb * 2 * w.Bp * 4));
     w.colpart = static_cast<float *>(take((size_t)w.nrb * 2 * w.Bp * 4));
@@ -512,7 +562,7 @@ static int launch_pair(int kind, int B, int d, const int32_t *u, const int32_t *
                        float *adam_pow, const macr_hyper *hp, const PairWs &ws, hipStream_t st) {
     const int grid = ws.nblk_pair;
     if (kind == MACR_LOSS_NORMALBCE) {
-        MACR_DISPATCH_LPR(d, (k_pair_normal<LPR><<<grid, 256, 0, st>>>(B, u, i, j, Usrc, Isrc, gU, gI, tU, tI, ws.part,
+        MACR_DISPATCH_D(d, (k_pair_normal<D><<<ws.nblk_bwd, 256, 0, st>>>(B, u, i, j, Usrc, Isrc, gU, gI, tU, tI, ws.part,
                                                                       coef, reg_on_gathered, adam_pow, adam_pow,
                                                                       ws.scal, hp->lr, hp->beta1, hp->beta2)));
         MACR_CHECK_LAUNCH("pair_normal", st);
@@ -520,7 +570,7 @@ static int launch_pair(int kind, int B, int d, const int32_t *u, const int32_t *
     }
     MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd, ws.part,
                                                                reg_on_gathered, adam_pow, adam_pow, ws.scal, hp->lr,
-                                                               hp->beta1, hp->beta2, ws.gw)));
+                                                               hp->beta1, hp->beta2)));
     MACR_CHECK_LAUNCH("pair_fwd", st);
     switch (ws.ct) {
         case 64: launch_bxb_ct<1>(ws, B, st); break;
@@ -528,17 +578,18 @@ static int launch_pair(int kind, int B, int d, const int32_t *u, const int32_t *
         default: launch_bxb_ct<4>(ws, B, st); break;
     }
     MACR_CHECK_LAUNCH("bxb", st);
-    MACR_DISPATCH_LPR(d, (k_pair_bwd<LPR><<<grid, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu,
-                                                               ws.fwd, ws.rowpart, ws.colpart, gU, gI, tU, tI, ws.gw,
-                                                               ws.gw + d, hp->alpha, hp->beta, coef)));
+    MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu,
+                                                                  ws.fwd, ws.rowpart, ws.colpart, gU, gI, tU, tI, ws.gw,
+                                                                  hp->alpha, hp->beta, coef)));
     MACR_CHECK_LAUNCH("pair_bwd", st);
     return MACR_OK;
 }
 
 static void add_seg(AdamArgs &a, float *theta, float *m, float *v, float *g, int32_t *touched, long long rows,
-                    long long &next_block) {
+                    long long &next_block, int n_parts = 0, int part_stride = 0) {
     AdamSeg &s = a.seg[a.n_seg++];
     s.theta = theta; s.m = m; s.v = v; s.g = g; s.touched = touched;
+    s.n_parts = n_parts; s.part_stride = part_stride;
     s.n_vec = rows * a.lpr;
     s.first_block = next_block;
     next_block += (s.n_vec + kAdamVecPerBlock - 1) / kAdamVecPerBlock;
@@ -594,11 +645,12 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
     add_seg(a, P, mP, vP, gP, touchedP, n_users, nb);
     add_seg(a, Q, mQ, vQ, gQ, touchedQ, n_items, nb);
     if (loss_kind == MACR_LOSS_RUBIBCEBOTH) {       // w, w_user receive gradients only here (model.py:74 vs :95)
-        add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb);
-        add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb);
+        add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, ws.nblk_bwd, 2 * d);
+        add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb, ws.nblk_bwd, 2 * d);
     }
     LossArgs L;
-    L.part = ws.part; L.n_part = ws.nblk_pair; L.part2 = nullptr; L.n_part2 = 0;
+    L.part = ws.part; L.n_part = loss_kind == MACR_LOSS_NORMALBCE ? ws.nblk_bwd : ws.nblk_pair;
+    L.part2 = nullptr; L.n_part2 = 0;
     L.lpart = ws.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.nrb * ws.ncb : 0;
     L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
     L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
@@ -668,7 +720,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, ws.dE, ws.G, ws.work, st)) return e;
     // l2 regulariser on the ego rows (LightGCN.py:525-528)
     const float coef = hp->decay / (float)hp->batch_size_cfg;
-    MACR_DISPATCH_LPR(d, (k_reg_scatter<LPR><<<ws.pair.nblk_pair, 256, 0, st>>>(B, n_users, u, i, j, T, ws.G, coef,
+    MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, u, i, j, T, ws.G, coef,
                                                                                ws.pair.part2)));
     MACR_CHECK_LAUNCH("reg_scatter", st);
     AdamArgs a;
@@ -677,11 +729,12 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     long long nb = 0;
     add_seg(a, T, mT, vT, ws.G, nullptr, N, nb);
     if (loss_kind == MACR_LOSS_RUBIBCEBOTH) {
-        add_seg(a, w, mw, vw, ws.pair.gw, nullptr, 1, nb);
-        add_seg(a, wu, mwu, vwu, ws.pair.gw + d, nullptr, 1, nb);
+        add_seg(a, w, mw, vw, ws.pair.gw, nullptr, 1, nb, ws.pair.nblk_bwd, 2 * d);
+        add_seg(a, wu, mwu, vwu, ws.pair.gw + d, nullptr, 1, nb, ws.pair.nblk_bwd, 2 * d);
     }
     LossArgs L;
-    L.part = ws.pair.part; L.n_part = ws.pair.nblk_pair; L.part2 = ws.pair.part2; L.n_part2 = ws.pair.nblk_pair;
+    L.part = ws.pair.part; L.n_part = loss_kind == MACR_LOSS_NORMALBCE ? ws.pair.nblk_bwd : ws.pair.nblk_pair;
+    L.part2 = ws.pair.part2; L.n_part2 = ws.pair.nblk_bwd;
     L.lpart = ws.pair.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.pair.nrb * ws.pair.ncb : 0;
     L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
     L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;

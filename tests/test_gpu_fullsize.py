@@ -1,0 +1,121 @@
+"""BASELINE.json-sized cases on the GPU (-m gpu): the oracle checks a slice it can finish in seconds,
+the rest is covered by size-independent properties (split/shard invariance, idempotence, linearity)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from macr_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_gowalla_size_eval(ops):
+    """configs[1]: 15 424 query users x 40 981 items, d=64, c=40, K=20."""
+    from macr_amd import synth
+    from macr_amd.evaluator import Evaluator
+    cfg = synth.WORKLOADS["gowalla"]
+    rs = np.random.RandomState(1)
+    P = (rs.standard_normal((cfg["n_users"], 64)) * 0.3).astype(np.float32)
+    pop = np.sort(rs.standard_normal(cfg["n_items"]))[::-1].astype(np.float32)       # popular items have low ids
+    Q = (rs.standard_normal((cfg["n_items"], 64)) * 0.3).astype(np.float32)
+    Q[:, 0] += pop
+    P[:, 0] = np.abs(P[:, 0])                        # scores rise and fall with popularity: adversarial stream order
+    w = (rs.standard_normal(64) * 0.3).astype(np.float32)
+    wu = (rs.standard_normal(64) * 0.3).astype(np.float32)
+    users, mask, gt = synth.eval_problem(cfg, seed=3)
+    ev = Evaluator(mask, gt, cfg["n_items"], torch.device("cuda"))
+    uid, Pd, Qd, wd, wud = dev(users), dev(P), dev(Q), dev(w), dev(wu)
+    mcsr = oracle.csr_from_lists(mask)
+    for kind in (0, 1):
+        val, idx, cnt = ev.rank(kind, Pd, uid, Qd, 20, wd, wud, 40.0)
+        sel = np.arange(0, len(users), 97)                                   # oracle on every 97th user
+        sig_i = ops.branch_sigmoid(Qd, wd).cpu().numpy()
+        sig_u = ops.branch_sigmoid(Pd, wud, uid).cpu().numpy()
+        sub = oracle.csr_from_lists([mask[q] for q in sel])
+        wv, wi, wc = oracle.score_topk(kind, P[users[sel]], Q, 20, sig_u[sel], sig_i, 40.0, sub)
+        assert np.array_equal(idx.cpu().numpy()[sel], wi)
+        assert np.array_equal(val.cpu().numpy()[sel].view(np.uint32), wv.view(np.uint32))
+        # properties on ALL users: split-count invariance, sortedness, no masked item, idempotence
+        sig_ud = dev(sig_u); sig_id = dev(sig_i)
+        v1, i1 = ops.score_topk(kind, Pd, uid, Qd, 20, sig_ud, sig_id, 40.0, ev.mask, 0, n_splits=7)
+        m1 = ops.topk_merge(v1, i1)
+        assert torch.equal(m1[1], idx) and torch.equal(m1[0], val)
+        v = val.cpu().numpy(); ix = idx.cpu().numpy()
+        assert np.all(v[:, :-1] >= v[:, 1:])
+        ties = v[:, :-1] == v[:, 1:]
+        assert np.all(ix[:, :-1][ties] < ix[:, 1:][ties])
+        for q in range(0, len(users), 501):
+            assert not set(ix[q]) & set(mask[q])
+        again = ops.topk_merge(val.unsqueeze(0).contiguous(), idx.unsqueeze(0).contiguous())
+        assert torch.equal(again[1], idx)
+
+
+@pytest.mark.parametrize("workload,kind", [("ml10m", 1), ("gowalla", 1), ("gowalla", 0)])
+def test_fullsize_train_step(ops, workload, kind):
+    """configs[1]/[2]: B=4096 / 8192 on the real table shapes, one step against the oracle."""
+    from macr_amd import synth
+    cfg = synth.WORKLOADS[workload]
+    B, d = cfg["batch"], 64
+    rs = np.random.RandomState(2)
+    P = (rs.standard_normal((cfg["n_users"], d)) * 0.1).astype(np.float32)
+    Q = (rs.standard_normal((cfg["n_items"], d)) * 0.1).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    u = rs.choice(cfg["n_users"], B, replace=False).astype(np.int32)
+    i = (rs.zipf(1.3, B) - 1).clip(0, cfg["n_items"] - 1).astype(np.int32)
+    j = rs.randint(0, cfg["n_items"], B).astype(np.int32)
+    st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
+    Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
+    state = ops.MFState(dev(P), dev(Q), dev(w), dev(wu),
+                        ops.make_hyper(cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B), B)
+    want = oracle.mf_train_step(kind, u, i, j, Po, Qo, wo, wuo, st, cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
+    got = state.step(kind, dev(u), dev(i), dev(j)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    g_hip, g_orc = state.mQ.cpu().numpy() / 0.1, st.m[1] / 0.1
+    np.testing.assert_allclose(g_hip, g_orc, rtol=5e-4, atol=2e-6 * np.abs(g_orc).max())
+    np.testing.assert_allclose(state.P.cpu().numpy(), Po, rtol=0, atol=0.02 * cfg["lr"])
+    np.testing.assert_allclose(state.Q.cpu().numpy(), Qo, rtol=0, atol=0.02 * cfg["lr"])
+
+
+def test_yelp_size_propagation(ops):
+    """configs[3]: N=69 716 nodes, nnz ~2.7 M, 2 layers, d=64.  Oracle on the full graph + linearity."""
+    import scipy.sparse as sp
+    from macr_amd import synth
+    cfg = synth.WORKLOADS["yelp2018"]
+    n_u, n_i = cfg["n_users"], cfg["n_items"]
+    lists = synth.interaction_lists(n_u, n_i, cfg["n_train"] / n_u, seed=9)
+    rows = np.repeat(np.arange(n_u), [len(l) for l in lists])
+    cols = np.concatenate(lists)
+    R = sp.csr_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n_u, n_i))
+    A = sp.bmat([[None, R], [R.T, None]], format="csr", dtype=np.float32)
+    deg = np.asarray(A.sum(1)).ravel()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5).astype(np.float32)
+    dinv[np.isinf(dinv)] = 0
+    A = (sp.diags(dinv) @ A @ sp.diags(dinv)).tocsr().astype(np.float32)
+    A.sort_indices()
+    rs = np.random.RandomState(0)
+    E0 = rs.standard_normal((n_u + n_i, 64)).astype(np.float32)
+    adj = ops.CSR.from_scipy(A, "cuda")
+    got = ops.lgcn_propagate(adj, dev(E0), 2)
+    want = oracle.lgcn_propagate(A.indptr, A.indices, A.data, E0, 2)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=3e-5, atol=3e-6)
+    E1 = rs.standard_normal(E0.shape).astype(np.float32)
+    lin = ops.lgcn_propagate(adj, dev(2.0 * E0 + E1), 2) - (2.0 * got + ops.lgcn_propagate(adj, dev(E1), 2))
+    assert float(lin.abs().max()) < 2e-5
+    # symmetric operator: <x, A y> == <A x, y>  (the backward pass reuses the forward kernel)
+    x, y = dev(E0), dev(E1)
+    lhs = float((x.double() * ops.lgcn_propagate(adj, y, 2).double()).sum())
+    rhs = float((ops.lgcn_propagate(adj, x, 2).double() * y.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * abs(lhs) + 1e-3
