@@ -14,7 +14,7 @@ OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH = 0, -1, -2, -3, -4
 LOSS_NORMALBCE, LOSS_RUBIBCEBOTH = 0, 1
 SCORE_NORMAL, SCORE_RUBI_BOTH = 0, 1
 MAX_TOPK = 32
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MacrError(RuntimeError):
@@ -46,7 +46,8 @@ SIGNATURES = {
     "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _p, _z, _p]),
     "macr_branch_sigmoid": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "macr_score_topk_splits": (_i, [_i, _i, _i]),
-    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "macr_score_topk_workspace_bytes": (_z, [_i]),
+    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _p, _p, _p, _z, _p]),
     "macr_score_matrix": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "macr_topk_scores": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "macr_topk_merge": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -43,7 +43,7 @@ constexpr int kUsersPerBlock = 32 * kWavesPerBlock;
 // ds_bpermute cost ~5k cycles per call and dominated the kernel.)  The buffer stays unsorted; only
 // the final result is sorted.
 __device__ __forceinline__ void compact_buffer(uint64_t *keys, uint32_t *cnt, float *thr, int K,
-                                               uint64_t *kth_out = nullptr) {
+                                               uint64_t *kth_out = nullptr, uint32_t *shared_thr = nullptr) {
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint32_t c = *cnt;
@@ -75,6 +75,8 @@ __device__ __forceinline__ void compact_buffer(uint64_t *keys, uint32_t *cnt, fl
         *cnt = c < (uint32_t)K ? c : (uint32_t)K;
         *thr = kth ? orderable_f32((uint32_t)(kth >> 32)) : -INFINITY;
         if (kth_out) *kth_out = kth;
+        // publish a lower bound of the GLOBAL K-th best score to the other item splits of this user
+        if (shared_thr && kth) atomicMax(shared_thr, (uint32_t)(kth >> 32));
     }
     // other lanes read cnt/thr/keys next: the compiler must not forward values it loaded before
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     int U, int n_local, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
     const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_idx, int item_offset, int K,
-    int n_splits, float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+    int n_splits, float *__restrict__ out_val, int32_t *__restrict__ out_idx, uint32_t *shared_thr) {
     constexpr int NKH = D / kUnitK > 0 ? D / kUnitK : 1;     // k-halves per tile (D=32 -> 1 short unit)
     constexpr int UK = D < kUnitK ? D : kUnitK;              // k extent of one unit
     constexpr int NT = UK / 2;                               // MFMA steps per unit
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     float *s_sig = s_unit + 2 * kTileItems * kUnitStride;                                  // [2][32]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_sig + 2 * kTileItems);                // [256]
     float *s_thr = reinterpret_cast<float *>(s_cnt + kUsersPerBlock);                      // [256]
+    uint64_t *s_kth = reinterpret_cast<uint64_t *>(s_thr + kUsersPerBlock);                // [256]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     const int it_hi = min(it_lo + tiles_per_split * kTileItems, n_local);
     const int n_tiles = (it_hi - it_lo + kTileItems - 1) / kTileItems;
 
-    if (tid < kUsersPerBlock) { s_cnt[tid] = 0; s_thr[tid] = -INFINITY; }
+    if (tid < kUsersPerBlock) { s_cnt[tid] = 0; s_thr[tid] = -INFINITY; s_kth[tid] = 0ull; }
 
     // B operand: lane (col,h) holds user[col][2t+h] for every MFMA step t
     float bfrag[D / 2];
@@ -140,17 +143,32 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     }
     const float su = (KIND == MACR_SCORE_RUBI_BOTH && q_ok) ? sig_u[q] : 1.0f;
 
-    // train-item mask cursor: next masked GLOBAL id >= the range start
-    int mpos = 0, mend = 0, mnext = INT_MAX;
+    // Stream order.  Item ids often correlate with popularity (ids are handed out by first appearance), and
+    // a monotone score trend along the stream is the worst case of a running top-K (every item beats the
+    // threshold).  So the tiles are visited in two ascending passes: every 8th tile first (a sample that
+    // spans the whole range and sets a good threshold), then the rest.
+    constexpr int kStride = 8;
+    const int n_pass_a = (n_tiles + kStride - 1) / kStride;
+    auto tile_at = [&](int step) -> int {
+        if (step < n_pass_a) return step * kStride;
+        const int r = step - n_pass_a;
+        return r + r / (kStride - 1) + 1;
+    };
+
+    // train-item mask cursor: next masked GLOBAL id >= the current position; reset at the start of pass B
+    int mbeg = 0, mpos = 0, mend = 0, mnext = INT_MAX;
     if (mask_ptr && q_ok) {
         mpos = mask_ptr[q]; mend = mask_ptr[q + 1];
         const int lo_gid = it_lo + item_offset;
         int lo = mpos, hi = mend;                  // first entry >= lo_gid
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (mask_idx[mid] < lo_gid) lo = mid + 1; else hi = mid; }
-        mpos = lo;
+        mbeg = mpos = lo;
         mnext = mpos < mend ? mask_idx[mpos] : INT_MAX;
     }
-    float thr = q_ok ? -INFINITY : INFINITY;       // padding users never admit anything
+    // admission threshold = the user's current K-th best KEY (score, id); 0 = none yet.  Padding users never admit.
+    float thr = q_ok ? -INFINITY : INFINITY;
+    int thr_id = -1;                               // with score == thr, only ids below thr_id rank higher
+    float gthr = -INFINITY;                        // lower bound of the global K-th best score, from the other splits
 #ifdef MACR_ABL_NOADMIT
     thr = INFINITY;
 #endif
@@ -173,21 +191,31 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
 
     const int n_units = n_tiles * NKH;
     if (n_units > 0) {
-        const float4 v0 = load_unit(0, 0);
-        const float sg0 = load_sig(0);
+        const float4 v0 = load_unit(tile_at(0), 0);
+        const float sg0 = load_sig(tile_at(0));
         store_unit(0, v0);
         if (tid < kTileItems) s_sig[tid] = sg0;
     }
     __syncthreads();
 
     f32x16 acc;
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    for (int step = 0; step < n_tiles; ++step) {
+        const int tile = tile_at(step);
+        const int tile_next = step + 1 < n_tiles ? tile_at(step + 1) : 0;
+        if (step == n_pass_a) {                     // pass B starts again from the front of the range
+            mpos = mbeg;
+            mnext = mpos < mend ? mask_idx[mpos] : INT_MAX;
+        }
+        // other splits' thresholds (relaxed agent-scope load: served by L2, stale values only prune less)
+        uint32_t g_bits = 0;
+        if (shared_thr && q_ok && (step & 3) == 0)
+            g_bits = __hip_atomic_load(&shared_thr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int kh = 0; kh < NKH; ++kh) {            // static kh: bfrag[] stays in registers
-            const int unit = tile * NKH + kh, buf = unit & 1;
+            const int unit = step * NKH + kh, buf = unit & 1;
             // prefetch the next unit into registers while this one is multiplied
             const bool has_next = unit + 1 < n_units;
-            const int ntile = (kh + 1 < NKH) ? tile : tile + 1;
+            const int ntile = (kh + 1 < NKH) ? tile : tile_next;
             const int nkh = (kh + 1 < NKH) ? kh + 1 : 0;
             float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
             float sgnext = 0.f;
@@ -210,21 +238,23 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
                 // ---------------- epilogue for one 32-item tile ----------------
                 const int it0 = it_lo + tile * kTileItems;             // local id of tile row 0
                 const int gid0 = it0 + item_offset;
-                const int sbuf = tile & 1;
+                const int sbuf = step & 1;
+                if (g_bits) gthr = fmaxf(gthr, orderable_f32(g_bits));
+                const float kNone = __builtin_nanf("");                // masked / out of range: every compare is false
                 float s[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int il = (r & 3) + 8 * (r >> 2) + 4 * h;      // item row inside the tile
                     float v = acc[r];
                     if (KIND == MACR_SCORE_RUBI_BOTH) { v = v - c; v = v * s_sig[sbuf * kTileItems + il]; v = v * su; }
-                    s[r] = (it0 + il < it_hi) ? v : -INFINITY;
+                    s[r] = (it0 + il < it_hi) ? v : kNone;
                 }
-                // masked (train) items of this tile -> -inf
 #ifndef MACR_ABL_NOMASK
+                // masked (train) items of this tile; the cursor skips the entries of tiles this pass jumps over
                 if (__any(mnext < gid0 + kTileItems)) {
                     uint32_t tmask = 0;
                     while (mnext < gid0 + kTileItems) {
-                        tmask |= 1u << (mnext - gid0);
+                        if (mnext >= gid0) tmask |= 1u << (mnext - gid0);
                         ++mpos;
                         mnext = mpos < mend ? mask_idx[mpos] : INT_MAX;
                     }
@@ -232,18 +262,23 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
-                            if ((tmask >> il) & 1u) s[r] = -INFINITY;
+                            if ((tmask >> il) & 1u) s[r] = kNone;
                         }
                     }
                 }
 #endif
                 // admission, in two half-tiles of 8 registers so that a user gains at most 16 entries per
-                // round: the buffer may then fill to kCap-16 = 48 before it has to be compacted
+                // round: the buffer may then fill to kCap-16 = 48 before it has to be compacted.
+                // Exact rule: key(s,id) > key(thr,thr_id); and s >= the other splits' bound (ties pass).
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     uint32_t cand = 0;
 #pragma unroll
-                    for (int r = 8 * half; r < 8 * half + 8; ++r) cand |= (s[r] > thr) ? (1u << r) : 0u;
+                    for (int r = 8 * half; r < 8 * half + 8; ++r) {
+                        const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool in = (s[r] > thr || (s[r] == thr && gid0 + il < thr_id)) && s[r] >= gthr;
+                        cand |= in ? (1u << r) : 0u;
+                    }
                     const uint32_t n_l = __popc(cand);
                     MACR_DBG_ADD(3, 1);
                     if (__any(n_l != 0)) {
@@ -273,17 +308,22 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
                                 const int ucol = __ffs((int)todo) - 1;
                                 todo &= todo - 1;
                                 const int us = wid * 32 + ucol;
+                                const int uq = ub * kUsersPerBlock + us;
                                 MACR_DBG_ADD(2, 1);
-                                compact_buffer(s_keys + (size_t)us * kCap, &s_cnt[us], &s_thr[us], K);
+                                compact_buffer(s_keys + (size_t)us * kCap, &s_cnt[us], &s_thr[us], K, &s_kth[us],
+                                               (shared_thr && uq < U) ? shared_thr + uq : nullptr);
                             }
-                            if (mine && q_ok) thr = s_thr[uslot];
+                            if (mine && q_ok) {
+                                const uint64_t kk = s_kth[uslot];
+                                if (kk) { thr = key_score(kk); thr_id = key_id(kk); }
+                            }
                         }
                     }
                 }
             }
             if (has_next) {
                 store_unit(buf ^ 1, vnext);
-                if (nkh == 0 && tid < kTileItems) s_sig[(ntile & 1) * kTileItems + tid] = sgnext;
+                if (nkh == 0 && tid < kTileItems) s_sig[((step + 1) & 1) * kTileItems + tid] = sgnext;
             }
             __syncthreads();
         }
@@ -307,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
 
 inline size_t score_topk_smem_bytes() {
     return (size_t)kUsersPerBlock * kCap * 8 + 2 * kTileItems * kUnitStride * 4 + 2 * kTileItems * 4 +
-           kUsersPerBlock * 4 + kUsersPerBlock * 4;
+           kUsersPerBlock * 4 + kUsersPerBlock * 4 + kUsersPerBlock * 8;
 }
 
 // ----------------------------------------------------------------------------
@@ -561,6 +601,8 @@ extern "C" void macr_dbg_counters(unsigned long long *out) {
 }
 #endif
 
+extern "C" size_t macr_score_topk_workspace_bytes(int U) { return U > 0 ? (size_t)U * 4 : 0; }
+
 extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
     (void)d;
     if (U <= 0 || n_local <= 0) return 1;
@@ -596,7 +638,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
                                const int32_t *user_ids, const float *items, const float *sig_u,
                                const float *sig_i, float c, const int32_t *mask_ptr, const int32_t *mask_idx,
                                int item_offset, int K, int n_splits, float *out_val, int32_t *out_idx,
-                               void *stream) {
+                               void *workspace, size_t workspace_bytes, void *stream) {
     MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || score_kind == MACR_SCORE_RUBI_BOTH, MACR_E_INVALID,
                  "score_topk: score_kind=%d", score_kind);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk: U=%d n_local=%d", U, n_local);
@@ -610,13 +652,22 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
     const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
     const size_t smem = score_topk_smem_bytes();
     hipStream_t st = as_stream(stream);
+    uint32_t *shared_thr = nullptr;             // per-query admission bounds shared by the item splits
+    if (workspace && n_splits > 1) {
+        MACR_REQUIRE(workspace_bytes >= (size_t)U * 4, MACR_E_WORKSPACE, "score_topk: workspace %zu < %zu bytes",
+                     workspace_bytes, (size_t)U * 4);
+        shared_thr = static_cast<uint32_t *>(workspace);
+        hipError_t me = hipMemsetAsync(shared_thr, 0, (size_t)U * 4, st);
+        MACR_REQUIRE(me == hipSuccess, MACR_E_LAUNCH, "score_topk: memset: %s", hipGetErrorString(me));
+    }
     MACR_DISPATCH_DK(d, score_kind, {
         auto kern = k_score_topk<D, KIND>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
         kern<<<ublocks * n_splits, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c,
-                                                    mask_ptr, mask_idx, item_offset, K, n_splits, out_val, out_idx);
+                                                    mask_ptr, mask_idx, item_offset, K, n_splits, out_val, out_idx,
+                                                    shared_thr);
     });
     MACR_CHECK_LAUNCH("score_topk", st);
     return MACR_OK;

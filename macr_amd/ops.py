@@ -113,9 +113,11 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     idx = torch.empty((n_splits, U, K), dtype=_i32, device=items.device)
     mp = _ptr(mask.ptr, _i32) if mask is not None else None
     mi = _ptr(mask.idx, _i32) if mask is not None else None
+    ws = torch.empty(U, dtype=_i32, device=items.device) if n_splits > 1 else None     # shared thresholds
     check(_lib.lib().macr_score_topk(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
                                      _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
-                                     float(c), mp, mi, item_offset, K, n_splits, _ptr(vals), _ptr(idx), _stream()))
+                                     float(c), mp, mi, item_offset, K, n_splits, _ptr(vals), _ptr(idx),
+                                     _ptr(ws, None, True), 0 if ws is None else ws.numel() * 4, _stream()))
     return vals, idx
 
 
