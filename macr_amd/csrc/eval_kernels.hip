@@ -14,6 +14,8 @@
 // sorting 64-bit keys (orderable(score) << 32 | ~id).
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace macr {
 
 #ifdef MACR_ABL_COUNT
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *s_keys = reinterpret_cast<uint64_t *>(smem);                                 // [256][64]
     float *s_unit = reinterpret_cast<float *>(smem + (size_t)kUsersPerBlock * kCap * 8);   // [2][32][65]
-    float *s_sig = s_unit + 2 * kTileItems * kUnitStride;                                  // [2][32]
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_sig + 2 * kTileItems);                // [256]
+    float *s_sig = s_unit + 2 * kTileItems * kUnitStride;                                  // [3][32]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_sig + 3 * kTileItems);                // [256]
     float *s_thr = reinterpret_cast<float *>(s_cnt + kUsersPerBlock);                      // [256]
     uint64_t *s_kth = reinterpret_cast<uint64_t *>(s_thr + kUsersPerBlock);                // [256]
 
@@ -198,18 +200,55 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     }
     __syncthreads();
 
-    f32x16 acc;
-    for (int step = 0; step < n_tiles; ++step) {
-        const int tile = tile_at(step);
+    // Software pipeline: while the matrix pipe multiplies tile `step`, the VALU scores, masks and
+    // thresholds tile `step-1` from the other accumulator -- the epilogue instructions sit between the
+    // MFMAs of the same wave (an fp32 32x32x2 MFMA occupies the pipe for 64 cycles; ~8 VALU fit per gap).
+    // Only the rare admission path (LDS atomics, compaction) runs outside the MFMA stream.
+    struct Prev { int tile; int step; };
+    const float kNone = __builtin_nanf("");                // masked / out of range: every compare is false
+
+    auto stage = [&](auto have_cur_t, auto have_prev_t, f32x16 &acc_cur, const f32x16 &acc_prev, int step, Prev prev) {
+        constexpr bool have_cur = decltype(have_cur_t)::value;     // compile-time: keeps the MFMA stream branch-free
+        constexpr bool have_prev = decltype(have_prev_t)::value;
+        const int tile = have_cur ? tile_at(step) : 0;
         const int tile_next = step + 1 < n_tiles ? tile_at(step + 1) : 0;
-        if (step == n_pass_a) {                     // pass B starts again from the front of the range
-            mpos = mbeg;
-            mnext = mpos < mend ? mask_idx[mpos] : INT_MAX;
+        // ---- previous tile: mask bits and thresholds first (they feed the interleaved scoring)
+        const int it0 = it_lo + prev.tile * kTileItems;            // local id of the previous tile's row 0
+        const int gid0 = it0 + item_offset;
+        uint32_t tmask = 0;
+        if (have_prev) {
+            if (prev.step == n_pass_a) {                        // pass B starts again from the front of the range
+                mpos = mbeg;
+                mnext = mpos < mend ? mask_idx[mpos] : INT_MAX;
+            }
+#ifndef MACR_ABL_NOMASK
+            if (__any(mnext < gid0 + kTileItems)) {             // the cursor also skips tiles this pass jumps over
+                while (mnext < gid0 + kTileItems) {
+                    if (mnext >= gid0) tmask |= 1u << (mnext - gid0);
+                    ++mpos;
+                    mnext = mpos < mend ? mask_idx[mpos] : INT_MAX;
+                }
+            }
+#endif
+            // other splits' thresholds (relaxed agent-scope load: served by L2, stale values only prune less)
+            if (shared_thr && q_ok && (prev.step & 3) == 0) {
+                const uint32_t g_bits = __hip_atomic_load(&shared_thr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g_bits) gthr = fmaxf(gthr, orderable_f32(g_bits));
+            }
         }
-        // other splits' thresholds (relaxed agent-scope load: served by L2, stale values only prune less)
-        uint32_t g_bits = 0;
-        if (shared_thr && q_ok && (step & 3) == 0)
-            g_bits = __hip_atomic_load(&shared_thr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int sbuf = (prev.step >= 0 ? prev.step : 0) % 3;
+        float s[16];
+        uint32_t cand = 0;
+        auto score_one = [&](int r) {                            // branch-free: interleaves with the MFMAs
+            const int il = (r & 3) + 8 * (r >> 2) + 4 * h;       // item row inside the tile
+            float v = acc_prev[r];
+            if (KIND == MACR_SCORE_RUBI_BOTH) { v = v - c; v = v * s_sig[sbuf * kTileItems + il]; v = v * su; }
+            const bool live = (it0 + il < it_hi) & (((tmask >> il) & 1u) == 0u);
+            v = live ? v : kNone;
+            s[r] = v;
+            const bool in = ((v > thr) | ((v == thr) & (gid0 + il < thr_id))) & (v >= gthr);   // no short-circuit: no branches
+            cand |= in ? (1u << r) : 0u;
+        };
 #pragma unroll
         for (int kh = 0; kh < NKH; ++kh) {            // static kh: bfrag[] stays in registers
             const int unit = step * NKH + kh, buf = unit & 1;
@@ -219,67 +258,36 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
             const int nkh = (kh + 1 < NKH) ? kh + 1 : 0;
             float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
             float sgnext = 0.f;
+#ifndef MACR_ABL_NOSTAGE
             if (has_next) { vnext = load_unit(ntile, nkh); if (nkh == 0) sgnext = load_sig(ntile); }
+#endif
 
             if (kh == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc_cur[r] = 0.f;
             }
             const float *ua = s_unit + (size_t)buf * kTileItems * kUnitStride + col * kUnitStride + h;
 #ifndef MACR_ABL_NOMFMA
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2 * t], bfrag[kh * NT + t], acc, 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+                if (have_cur) acc_cur = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2 * t], bfrag[kh * NT + t], acc_cur, 0, 0, 0);
+                if (kh == 0 && (t * 16) % NT == 0 && have_prev) score_one(t * 16 / NT);
+            }
 #else
-            acc[0] += ua[0] * bfrag[kh * NT];
-#endif
-
-            if (kh == NKH - 1) {
-                // ---------------- epilogue for one 32-item tile ----------------
-                const int it0 = it_lo + tile * kTileItems;             // local id of tile row 0
-                const int gid0 = it0 + item_offset;
-                const int sbuf = step & 1;
-                if (g_bits) gthr = fmaxf(gthr, orderable_f32(g_bits));
-                const float kNone = __builtin_nanf("");                // masked / out of range: every compare is false
-                float s[16];
+            if (have_cur) acc_cur[0] += ua[0] * bfrag[kh * NT];
+            if (kh == 0 && have_prev) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int il = (r & 3) + 8 * (r >> 2) + 4 * h;      // item row inside the tile
-                    float v = acc[r];
-                    if (KIND == MACR_SCORE_RUBI_BOTH) { v = v - c; v = v * s_sig[sbuf * kTileItems + il]; v = v * su; }
-                    s[r] = (it0 + il < it_hi) ? v : kNone;
-                }
-#ifndef MACR_ABL_NOMASK
-                // masked (train) items of this tile; the cursor skips the entries of tiles this pass jumps over
-                if (__any(mnext < gid0 + kTileItems)) {
-                    uint32_t tmask = 0;
-                    while (mnext < gid0 + kTileItems) {
-                        if (mnext >= gid0) tmask |= 1u << (mnext - gid0);
-                        ++mpos;
-                        mnext = mpos < mend ? mask_idx[mpos] : INT_MAX;
-                    }
-                    if (tmask) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
-                            if ((tmask >> il) & 1u) s[r] = kNone;
-                        }
-                    }
-                }
+                for (int r = 0; r < 16; ++r) score_one(r);
+            }
 #endif
+            if (kh == 0 && have_prev) {
                 // admission, in two half-tiles of 8 registers so that a user gains at most 16 entries per
                 // round: the buffer may then fill to kCap-16 = 48 before it has to be compacted.
                 // Exact rule: key(s,id) > key(thr,thr_id); and s >= the other splits' bound (ties pass).
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    uint32_t cand = 0;
-#pragma unroll
-                    for (int r = 8 * half; r < 8 * half + 8; ++r) {
-                        const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool in = (s[r] > thr || (s[r] == thr && gid0 + il < thr_id)) && s[r] >= gthr;
-                        cand |= in ? (1u << r) : 0u;
-                    }
-                    const uint32_t n_l = __popc(cand);
+                    const uint32_t cand_h = cand & (0xffu << (8 * half));
+                    const uint32_t n_l = __popc(cand_h);
                     MACR_DBG_ADD(3, 1);
                     if (__any(n_l != 0)) {
                         MACR_DBG_ADD(0, 1);
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
                             uint64_t *dst = s_keys + (size_t)uslot * kCap;
 #pragma unroll
                             for (int r = 8 * half; r < 8 * half + 8; ++r) {
-                                if ((cand >> r) & 1u) {
+                                if ((cand_h >> r) & 1u) {
                                     const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
                                     dst[pos++] = make_key(s[r], gid0 + il);
                                 }
@@ -321,11 +329,38 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
                     }
                 }
             }
+#ifndef MACR_ABL_NOSTAGE
             if (has_next) {
                 store_unit(buf ^ 1, vnext);
-                if (nkh == 0 && tid < kTileItems) s_sig[((step + 1) & 1) * kTileItems + tid] = sgnext;
+                if (nkh == 0 && tid < kTileItems) s_sig[((step + 1) % 3) * kTileItems + tid] = sgnext;
             }
+#endif
+#ifndef MACR_ABL_NOBARRIER
             __syncthreads();
+#endif
+        }
+        return Prev{tile, have_cur ? step : -1};
+    };
+
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+    Prev prev{0, -1};
+    using T = std::true_type;
+    using F = std::false_type;
+    // n_tiles + 1 stages: fill, steady state (two per trip so the accumulators swap statically), drain
+    if (n_tiles > 0) {
+        prev = stage(T{}, F{}, accA, accB, 0, prev);
+        int step = 1;
+        for (; step + 1 < n_tiles; step += 2) {
+            prev = stage(T{}, T{}, accB, accA, step, prev);
+            prev = stage(T{}, T{}, accA, accB, step + 1, prev);
+        }
+        if (step < n_tiles) {                 // one steady stage left, then drain from B
+            prev = stage(T{}, T{}, accB, accA, step, prev);
+            prev = stage(F{}, T{}, accA, accB, step + 1, prev);
+        } else {                              // drain from A
+            prev = stage(F{}, T{}, accB, accA, step, prev);
         }
     }
 
@@ -346,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
 }
 
 inline size_t score_topk_smem_bytes() {
-    return (size_t)kUsersPerBlock * kCap * 8 + 2 * kTileItems * kUnitStride * 4 + 2 * kTileItems * 4 +
+    return (size_t)kUsersPerBlock * kCap * 8 + 2 * kTileItems * kUnitStride * 4 + 3 * kTileItems * 4 +
            kUsersPerBlock * 4 + kUsersPerBlock * 4 + kUsersPerBlock * 8;
 }
 
