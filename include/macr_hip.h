@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     2
+#define MACR_ABI_VERSION     3
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -109,18 +109,37 @@ int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items,
                        float *losses, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * SpMM plan (host side, built once per graph -- the adjacency never changes).
+ * Interaction graphs have hub rows (items with 10^4..10^5 neighbours); the plan
+ * cuts rows longer than 512 non-zeros into work items of 512 so that no single
+ * wavefront serialises a hub, and lists the rows whose partial sums a fix-up
+ * kernel combines (in fixed order: deterministic, no atomics).
+ *   rowptr_host (HOST) int32[N+1]
+ *   plan_host   (HOST) >= macr_spmm_plan_bytes(N, rowptr_host) bytes, written by
+ *               macr_spmm_plan_build; the caller uploads a copy to the device and
+ *               passes BOTH pointers (device copy for the kernels, host copy for the
+ *               launch geometry) to the LightGCN entry points.  Passing NULL for both
+ *               selects the plain one-wavefront-per-row kernel.
+ * -------------------------------------------------------------------------*/
+size_t macr_spmm_plan_bytes(int N, const int32_t *rowptr_host);
+int    macr_spmm_plan_build(int N, const int32_t *rowptr_host, void *plan_host, size_t plan_bytes);
+size_t macr_lgcn_work_floats(int N, int d, const void *plan_host);   /* size of `work` below, in floats */
+
+/* ---------------------------------------------------------------------------
  * LightGCN propagation  E = mean(E0, A E0, ..., A^L E0)   (L = n_layers)
  * Replaces _create_lightgcn_embed (macr_lightgcn/LightGCN.py:288-309): the
  * 100-fold tf.sparse_tensor_dense_matmul loop (:297-305) + stack/reduce_mean
  * (:306-307).  A is the `pre` adjacency D^-1/2 A D^-1/2 in CSR
  * (utility/load_data.py:112-121), N = n_users + n_items rows.
  *   rowptr (dev) int32[N+1], col (dev) int32[nnz], val (dev) fp32[nnz]
+ *   plan_dev (dev) / plan_host (HOST): the SpMM plan, or both NULL
  *   E0 (dev) fp32[N*d] in, E (dev) fp32[N*d] out
- *   work (dev) fp32[2*N*d] scratch
+ *   work (dev) fp32[macr_lgcn_work_floats(N, d, plan_host)] scratch
  * The same call is the backward pass (A symmetric): feed dE, get dE0.
  * -------------------------------------------------------------------------*/
 int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col,
-                        const float *val, const float *E0, float *E, float *work, void *stream);
+                        const float *val, const void *plan_dev, const void *plan_host,
+                        const float *E0, float *E, float *work, void *stream);
 
 /* One LightGCN training step.  Replaces sess.run([opt_X, loss_X, mf_loss_X,
  * emb_loss_X, reg_loss_X]) of macr_lightgcn/LightGCN.py:598-607: propagation,
@@ -128,13 +147,14 @@ int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *rowptr, const
  * the regulariser on the ego rows (:525-527), dense gradients through the
  * propagation, Adam (:186 / :201).
  *   T (dev) fp32[N*d] = [user_embedding ; item_embedding], updated in place
- *   mT,vT Adam slots;  work (dev) >= macr_lgcn_train_workspace_bytes(B,N,d) bytes
+ *   mT,vT Adam slots;  workspace (dev) >= macr_lgcn_train_workspace_bytes(B,N,d,plan_host) bytes
  *   losses (dev) fp32[3] = {loss, mf_loss, emb_loss}
  * -------------------------------------------------------------------------*/
-size_t macr_lgcn_train_workspace_bytes(int B, int N, int d);
+size_t macr_lgcn_train_workspace_bytes(int B, int N, int d, const void *plan_host);
 
 int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
                          const int32_t *rowptr, const int32_t *col, const float *val,
+                         const void *plan_dev, const void *plan_host,
                          const int32_t *u, const int32_t *i, const int32_t *j,
                          float *T, float *w, float *wu, float *mT, float *vT,
                          float *mw, float *vw, float *mwu, float *vwu,

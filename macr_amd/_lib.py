@@ -14,7 +14,7 @@ OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH = 0, -1, -2, -3, -4
 LOSS_NORMALBCE, LOSS_RUBIBCEBOTH = 0, 1
 SCORE_NORMAL, SCORE_RUBI_BOTH = 0, 1
 MAX_TOPK = 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MacrError(RuntimeError):
@@ -41,9 +41,12 @@ SIGNATURES = {
     "macr_timing_end": (_i, [_i, _p, _p]),
     "macr_mf_train_workspace_bytes": (_z, [_i, _i]),
     "macr_mf_train_step": (_i, [_i] * 5 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [_p, ctypes.POINTER(Hyper), _p, _p, _z, _p]),
-    "macr_lgcn_propagate": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
-    "macr_lgcn_train_workspace_bytes": (_z, [_i, _i, _i]),
-    "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _p, _z, _p]),
+    "macr_spmm_plan_bytes": (_z, [_i, _p]),
+    "macr_spmm_plan_build": (_i, [_i, _p, _p, _z]),
+    "macr_lgcn_work_floats": (_z, [_i, _i, _p]),
+    "macr_lgcn_propagate": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "macr_lgcn_train_workspace_bytes": (_z, [_i, _i, _i, _p]),
+    "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 2 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _p, _z, _p]),
     "macr_branch_sigmoid": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "macr_score_topk_splits": (_i, [_i, _i, _i]),
     "macr_score_topk_workspace_bytes": (_z, [_i]),

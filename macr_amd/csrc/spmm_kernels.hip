@@ -5,34 +5,61 @@
 // stack/reduce_mean of :306-307.  A_hat = D^-1/2 A D^-1/2 in CSR
 // (macr_lightgcn/utility/load_data.py:112-121), X is the (N,d) embedding table.
 //
-// One wave per output row; the wave is split into 64/LPR neighbour groups, each
+// One wave per WORK ITEM; the wave is split into 64/LPR neighbour groups, each
 // group streams one neighbour row as LPR lanes x float4 (a coalesced 256-B read at
-// d=64), so 4 neighbours are in flight per wave instruction at d=64.  The groups'
-// partial rows are combined with cross-lane shuffles; group 0 writes the row.
+// d=64), two neighbours in flight per group.  The groups' partial rows are combined
+// with cross-lane shuffles; group 0 writes the row.
+// Work items come from a static plan (the graph never changes): a row with at most
+// kChunk non-zeros is one item and is written with the fused epilogue; a longer row
+// (interaction graphs have hub items with 10^4..10^5 neighbours -- Addressa item 0 has
+// 7077, the Zipf synthetic Yelp-size graph 1.2e5) is cut into kChunk-sized items whose
+// partial rows go to a scratch slab and are summed, in slot order (deterministic, no
+// atomics), by a small fix-up kernel that also applies the epilogue.  Without the split
+// one wave serialises the whole hub row: 1.65 ms per layer instead of ~0.1 ms.
 // HBM-bound: compulsory bytes per layer nnz*8 + (N+1)*4 + 2*N*d*4;
-// X itself is L2/Infinity-Cache resident for every real dataset.
+// X itself is Infinity-Cache resident for every real dataset.
 #include "common.hpp"
+
+#include <string.h>
+#include <vector>
 
 namespace macr {
 
-// Y = A X (if Y), S_out = (S_in + A X) * scale (if S_out).
+constexpr int kChunk = 512;       // non-zeros per work item
+
+struct PlanHeader {               // all int32, followed by the arrays below
+    int32_t magic, n_items, n_split, n_slots, N, reserved[3];
+};
+constexpr int32_t kPlanMagic = 0x4d414352;   // "MACR"
+// layout after the header:  item_row[n_items] item_beg[n_items] item_end[n_items] item_slot[n_items]
+//                           split_row[n_split] split_slot0[n_split+1]
+
+struct PlanView {
+    const int32_t *item_row, *item_beg, *item_end, *item_slot, *split_row, *split_slot0;
+    int n_items, n_split, n_slots;
+};
+
+__device__ __host__ inline PlanView view_plan(const void *plan, const PlanHeader &h) {
+    const int32_t *p = reinterpret_cast<const int32_t *>(plan) + sizeof(PlanHeader) / 4;
+    PlanView v;
+    v.n_items = h.n_items; v.n_split = h.n_split; v.n_slots = h.n_slots;
+    v.item_row = p; p += h.n_items;
+    v.item_beg = p; p += h.n_items;
+    v.item_end = p; p += h.n_items;
+    v.item_slot = p; p += h.n_items;
+    v.split_row = p; p += h.n_split;
+    v.split_slot0 = p;
+    return v;
+}
+
 template <int LPR>
-__global__ __launch_bounds__(256) void k_spmm_csr(int N, const int32_t *__restrict__ rowptr,
-                                                  const int32_t *__restrict__ col, const float *__restrict__ val,
-                                                  const float *__restrict__ X, float *__restrict__ Y,
-                                                  const float *S_in, float *S_out /* may alias (running sum updated in place) */,
-                                                  float scale) {
+__device__ __forceinline__ float4 gather_range(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                               const float *__restrict__ X, int beg, int end, int sub, int grp) {
     constexpr int d = 4 * LPR;
     constexpr int NG = kWave / LPR;                 // neighbour groups per wave
-    const int lane = threadIdx.x & 63;
-    const int sub = lane % LPR, grp = lane / LPR;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= N) return;
-    const int beg = rowptr[r], end = rowptr[r + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int e = beg + grp;
-    // two neighbours per group in flight to cover L2 latency
-    for (; e + NG < end; e += 2 * NG) {
+    for (; e + NG < end; e += 2 * NG) {             // two neighbours per group in flight
         const int c0 = col[e], c1 = col[e + NG];
         const float a0 = val[e], a1 = val[e + NG];
         const float4 x0 = ld4(X + (size_t)c0 * d + 4 * sub);
@@ -40,24 +67,82 @@ __global__ __launch_bounds__(256) void k_spmm_csr(int N, const int32_t *__restri
         acc = fma4(a0, x0, acc);
         acc = fma4(a1, x1, acc);
     }
-    if (e < end) {
-        const float4 x0 = ld4(X + (size_t)col[e] * d + 4 * sub);
-        acc = fma4(val[e], x0, acc);
-    }
+    if (e < end) acc = fma4(val[e], ld4(X + (size_t)col[e] * d + 4 * sub), acc);
 #pragma unroll
     for (int m = LPR; m < kWave; m <<= 1) {
         acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
         acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
     }
-    if (grp == 0) {
-        const size_t o = (size_t)r * d + 4 * sub;
-        if (Y) st4(Y + o, acc);
-        if (S_out) {
-            const float4 s = ld4(S_in + o);
-            st4(S_out + o, make_float4((s.x + acc.x) * scale, (s.y + acc.y) * scale,
-                                       (s.z + acc.z) * scale, (s.w + acc.w) * scale));
-        }
+    return acc;
+}
+
+template <int LPR>
+__device__ __forceinline__ void write_row(int r, int sub, float4 acc, float *Y, const float *S_in, float *S_out, float scale) {
+    constexpr int d = 4 * LPR;
+    const size_t o = (size_t)r * d + 4 * sub;
+    if (Y) st4(Y + o, acc);
+    if (S_out) {
+        const float4 s = ld4(S_in + o);
+        st4(S_out + o, make_float4((s.x + acc.x) * scale, (s.y + acc.y) * scale, (s.z + acc.z) * scale, (s.w + acc.w) * scale));
     }
+}
+
+// Y = A X (if Y), S_out = (S_in + A X) * scale (if S_out; may alias S_in: updated in place row by row).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_spmm_csr(int N, const int32_t *__restrict__ rowptr,
+                                                  const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                  const void *__restrict__ plan, PlanHeader ph,
+                                                  const float *__restrict__ X, float *Y, const float *S_in,
+                                                  float *S_out, float scale, float *__restrict__ slab) {
+    constexpr int d = 4 * LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int r, beg, end, slot = -1;
+    if (plan) {
+        const PlanView pv = view_plan(plan, ph);
+        if (w >= pv.n_items) return;
+        r = pv.item_row[w]; beg = pv.item_beg[w]; end = pv.item_end[w]; slot = pv.item_slot[w];
+    } else {
+        if (w >= N) return;
+        r = w; beg = rowptr[r]; end = rowptr[r + 1];
+    }
+    const float4 acc = gather_range<LPR>(col, val, X, beg, end, sub, grp);
+    if (grp == 0) {
+        if (slot < 0) write_row<LPR>(r, sub, acc, Y, S_in, S_out, scale);
+        else st4(slab + (size_t)slot * d + 4 * sub, acc);
+    }
+}
+
+// Sums the chunk partials of every split (hub) row and applies the epilogue.  One wave per hub row:
+// the 64/LPR groups take interleaved slots (two loads in flight each), then combine by shuffles --
+// a fixed summation tree, so the result is deterministic.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_spmm_fixup(const void *__restrict__ plan, PlanHeader ph,
+                                                    const float *__restrict__ slab, float *Y, const float *S_in,
+                                                    float *S_out, float scale) {
+    constexpr int d = 4 * LPR;
+    constexpr int NG = kWave / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const PlanView pv = view_plan(plan, ph);
+    if (k >= pv.n_split) return;
+    const int s0 = pv.split_slot0[k], s1 = pv.split_slot0[k + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
+    int s = s0 + grp;
+    for (; s + NG < s1; s += 2 * NG) {
+        acc = add4(acc, ld4(slab + (size_t)s * d + 4 * sub));
+        acc2 = add4(acc2, ld4(slab + (size_t)(s + NG) * d + 4 * sub));
+    }
+    if (s < s1) acc = add4(acc, ld4(slab + (size_t)s * d + 4 * sub));
+    acc = add4(acc, acc2);
+#pragma unroll
+    for (int m = LPR; m < kWave; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
+        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
+    }
+    if (grp == 0) write_row<LPR>(pv.split_row[k], sub, acc, Y, S_in, S_out, scale);
 }
 
 // out = in * scale   (n_layers == 0 degenerate case) -- float4 per lane
@@ -68,40 +153,119 @@ __global__ void k_scale_copy(size_t n_vec, const float *__restrict__ in, float *
     }
 }
 
+// work: [2*N*d] layer buffers followed by [n_slots*d] slab when a plan is given.
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
-                     const float *E0, float *E, float *work, hipStream_t st) {
+                     const void *plan_dev, const void *plan_host_header, const float *E0, float *E, float *work,
+                     hipStream_t st) {
     const size_t nd = (size_t)N * d;
     float *bufA = work, *bufB = work + nd;            // alternating layer outputs
+    float *slab = work + 2 * nd;
     const float inv = 1.0f / (float)(n_layers + 1);
     if (n_layers == 0) {
         k_scale_copy<<<1024, 256, 0, st>>>(nd / 4, E0, E, 1.0f);
         MACR_CHECK_LAUNCH("scale_copy", st);
         return MACR_OK;
     }
-    const int grid = (N + 3) / 4;
+    PlanHeader ph = {};
+    if (plan_dev) ph = *static_cast<const PlanHeader *>(plan_host_header);
+    const int n_waves = plan_dev ? ph.n_items : N;
+    const int grid = (n_waves + 3) / 4;
     const float *X = E0;
     const float *S_in = E0;
     for (int l = 0; l < n_layers; ++l) {
         const bool last = (l == n_layers - 1);
         float *Y = last ? nullptr : ((l & 1) ? bufB : bufA);
-        // running sum lives in E (S_out); first layer reads E0 as S_in
-        MACR_DISPATCH_LPR(d, (k_spmm_csr<LPR><<<grid, 256, 0, st>>>(N, rowptr, col, val, X, Y, S_in, E,
-                                                                   last ? inv : 1.0f)));
+        const float scale = last ? inv : 1.0f;        // running sum lives in E; first layer reads E0 as S_in
+        MACR_DISPATCH_LPR(d, (k_spmm_csr<LPR><<<grid, 256, 0, st>>>(N, rowptr, col, val, plan_dev, ph, X, Y, S_in, E,
+                                                                   scale, slab)));
         MACR_CHECK_LAUNCH("spmm_csr", st);
+        if (plan_dev && ph.n_split > 0) {
+            MACR_DISPATCH_LPR(d, (k_spmm_fixup<LPR><<<(ph.n_split + 3) / 4, 256, 0, st>>>(
+                                     plan_dev, ph, slab, Y, S_in, E, scale)));
+            MACR_CHECK_LAUNCH("spmm_fixup", st);
+        }
         X = Y;
         S_in = E;
     }
     return MACR_OK;
 }
 
+static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) {
+    std::vector<int32_t> irow, ibeg, iend, islot, srow, sslot0;
+    int n_slots = 0;
+    for (int r = 0; r < N; ++r) {
+        const int beg = rowptr[r], end = rowptr[r + 1];
+        if (end - beg <= kChunk) {
+            irow.push_back(r); ibeg.push_back(beg); iend.push_back(end); islot.push_back(-1);
+        } else {
+            srow.push_back(r); sslot0.push_back(n_slots);
+            for (int b = beg; b < end; b += kChunk) {
+                irow.push_back(r); ibeg.push_back(b); iend.push_back(b + kChunk < end ? b + kChunk : end);
+                islot.push_back(n_slots++);
+            }
+        }
+    }
+    sslot0.push_back(n_slots);
+    PlanHeader h = {};
+    h.magic = kPlanMagic; h.n_items = (int32_t)irow.size(); h.n_split = (int32_t)srow.size(); h.n_slots = n_slots; h.N = N;
+    out.assign(reinterpret_cast<int32_t *>(&h), reinterpret_cast<int32_t *>(&h) + sizeof(h) / 4);
+    out.insert(out.end(), irow.begin(), irow.end());
+    out.insert(out.end(), ibeg.begin(), ibeg.end());
+    out.insert(out.end(), iend.begin(), iend.end());
+    out.insert(out.end(), islot.begin(), islot.end());
+    out.insert(out.end(), srow.begin(), srow.end());
+    out.insert(out.end(), sslot0.begin(), sslot0.end());
+}
+
 }  // namespace macr
 
+using namespace macr;
+
+// ---- plan (host) ----------------------------------------------------------------
+extern "C" size_t macr_spmm_plan_bytes(int N, const int32_t *rowptr_host) {
+    if (N <= 0 || !rowptr_host) return 0;
+    size_t items = 0, split = 0;
+    for (int r = 0; r < N; ++r) {
+        const int len = rowptr_host[r + 1] - rowptr_host[r];
+        if (len <= kChunk) items += 1; else { items += (len + kChunk - 1) / kChunk; split += 1; }
+    }
+    return sizeof(PlanHeader) + 4 * (4 * items + split + split + 1);
+}
+
+extern "C" int macr_spmm_plan_build(int N, const int32_t *rowptr_host, void *plan_host, size_t plan_bytes) {
+    MACR_REQUIRE(N > 0 && rowptr_host && plan_host, MACR_E_INVALID, "spmm_plan_build: bad arguments");
+    std::vector<int32_t> v;
+    build_plan(N, rowptr_host, v);
+    MACR_REQUIRE(plan_bytes >= v.size() * 4, MACR_E_WORKSPACE, "spmm_plan_build: buffer %zu < %zu bytes", plan_bytes, v.size() * 4);
+    memcpy(plan_host, v.data(), v.size() * 4);
+    return MACR_OK;
+}
+
+extern "C" size_t macr_lgcn_work_floats(int N, int d, const void *plan_host) {
+    size_t n = (size_t)2 * N * d;
+    if (plan_host) n += (size_t)static_cast<const PlanHeader *>(plan_host)->n_slots * d;
+    return n;
+}
+
+static int check_plan(const void *plan_dev, const void *plan_host, int N, const char *who) {
+    MACR_REQUIRE((plan_dev == nullptr) == (plan_host == nullptr), MACR_E_INVALID,
+                 "%s: plan needs both its device copy and its host copy (or neither)", who);
+    if (plan_host) {
+        const PlanHeader *h = static_cast<const PlanHeader *>(plan_host);
+        MACR_REQUIRE(h->magic == kPlanMagic && h->N == N, MACR_E_INVALID, "%s: plan does not belong to this graph", who);
+    }
+    return MACR_OK;
+}
+
 extern "C" int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col,
-                                   const float *val, const float *E0, float *E, float *work, void *stream) {
+                                   const float *val, const void *plan_dev, const void *plan_host, const float *E0,
+                                   float *E, float *work, void *stream) {
     MACR_REQUIRE(N > 0 && n_layers >= 0, MACR_E_INVALID, "lgcn_propagate: N=%d n_layers=%d", N, n_layers);
     MACR_REQUIRE(macr::dim_supported(d), MACR_E_UNSUPPORTED, "lgcn_propagate: d=%d not in {32,64,128,256}", d);
-    MACR_REQUIRE(rowptr && col && val && E0 && E && (work || n_layers < 2), MACR_E_INVALID,
+    MACR_REQUIRE(rowptr && col && val && E0 && E && (work || (n_layers < 2 && !plan_dev)), MACR_E_INVALID,
                  "lgcn_propagate: null pointer");
     MACR_REQUIRE(E != E0, MACR_E_INVALID, "lgcn_propagate: E must not alias E0");
-    return macr::launch_propagate(N, d, n_layers, rowptr, col, val, E0, E, work, macr::as_stream(stream));
+    if (int e = check_plan(plan_dev, plan_host, N, "lgcn_propagate")) return e;
+    return macr::launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, E0, E, work,
+                                  macr::as_stream(stream));
 }

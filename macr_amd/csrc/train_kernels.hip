@@ -491,7 +491,8 @@ __global__ __launch_bounds__(256) void k_adam_dense(AdamArgs a, const StepScalar
 namespace macr {
 
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
-                     const float *E0, float *E, float *work, hipStream_t st);   // spmm_kernels.hip
+                     const void *plan_dev, const void *plan_host_header, const float *E0, float *E, float *work,
+                     hipStream_t st);   // spmm_kernels.hip
 
 #define MACR_DISPATCH_D(d, ...)                                  \
     switch (d) {                                                 \
@@ -662,7 +663,7 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
 // ---- LightGCN ---------------------------------------------------------------
 namespace macr {
 struct LgcnWs { float *E, *dE, *G, *work; PairWs pair; size_t bytes; };
-static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d) {
+static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, int n_slots) {
     LgcnWs w;
     char *p = static_cast<char *>(base);
     const size_t nd = align_up((size_t)N * d * 4, 256);
@@ -671,7 +672,7 @@ static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d) {
     w.E = static_cast<float *>(take(nd));
     w.dE = static_cast<float *>(take(nd));
     w.G = static_cast<float *>(take(nd));
-    w.work = static_cast<float *>(take(2 * nd));
+    w.work = static_cast<float *>(take(2 * nd + align_up((size_t)n_slots * d * 4, 256)));
     w.pair = carve_pair_ws(p ? p + off : nullptr, B, d);
     off += w.pair.bytes;
     w.bytes = off;
@@ -679,13 +680,17 @@ static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d) {
 }
 }  // namespace macr
 
-extern "C" size_t macr_lgcn_train_workspace_bytes(int B, int N, int d) {
+struct PlanHeaderLite { int32_t magic, n_items, n_split, n_slots, N, reserved[3]; };   // = spmm_kernels.hip PlanHeader
+
+extern "C" size_t macr_lgcn_train_workspace_bytes(int B, int N, int d, const void *plan_host) {
     if (B <= 0 || N <= 0 || !dim_supported(d)) return 0;
-    return carve_lgcn_ws(nullptr, B, N, d).bytes;
+    const int n_slots = plan_host ? static_cast<const PlanHeaderLite *>(plan_host)->n_slots : 0;
+    return carve_lgcn_ws(nullptr, B, N, d, n_slots).bytes;
 }
 
 extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
-                                    const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *u,
+                                    const int32_t *rowptr, const int32_t *col, const float *val,
+                                    const void *plan_dev, const void *plan_host, const int32_t *u,
                                     const int32_t *i, const int32_t *j, float *T, float *w, float *wu, float *mT,
                                     float *vT, float *mw, float *vw, float *mwu, float *vwu, float *adam_pow,
                                     const macr_hyper *hp, float *losses, void *workspace, size_t workspace_bytes,
@@ -700,7 +705,12 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     MACR_REQUIRE(w && wu && mw && vw && mwu && vwu, MACR_E_INVALID, "lgcn_train_step: null branch vectors");
     if (int e = validate_hyper(hp, "lgcn_train_step")) return e;
     const int N = n_users + n_items;
-    LgcnWs ws = carve_lgcn_ws(workspace, B, N, d);
+    MACR_REQUIRE((plan_dev == nullptr) == (plan_host == nullptr), MACR_E_INVALID,
+                 "lgcn_train_step: plan needs both its device copy and its host copy (or neither)");
+    const int n_slots = plan_host ? static_cast<const PlanHeaderLite *>(plan_host)->n_slots : 0;
+    MACR_REQUIRE(!plan_host || static_cast<const PlanHeaderLite *>(plan_host)->N == N, MACR_E_INVALID,
+                 "lgcn_train_step: plan does not belong to this graph");
+    LgcnWs ws = carve_lgcn_ws(workspace, B, N, d, n_slots);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "lgcn_train_step: workspace %zu < %zu bytes",
                  workspace_bytes, ws.bytes);
     MACR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
@@ -708,7 +718,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     hipStream_t st = as_stream(stream);
     const size_t nd = (size_t)N * d;
     // forward propagation (LightGCN.py:288-309)
-    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, T, ws.E, ws.work, st)) return e;
+    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, T, ws.E, ws.work, st)) return e;
     hipError_t he = hipMemsetAsync(ws.dE, 0, nd * 4, st);
     MACR_REQUIRE(he == hipSuccess, MACR_E_LAUNCH, "lgcn_train_step: memset: %s", hipGetErrorString(he));
     // pair loss on the propagated rows; items live at rows n_users.. of E
@@ -717,7 +727,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
                             hp, ws.pair, st))
         return e;
     // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
-    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, ws.dE, ws.G, ws.work, st)) return e;
+    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st)) return e;
     // l2 regulariser on the ego rows (LightGCN.py:525-528)
     const float coef = hp->decay / (float)hp->batch_size_cfg;
     MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, u, i, j, T, ws.G, coef,

@@ -39,6 +39,26 @@ class CSR(object):
 
     def __init__(self, ptr, idx, val=None):
         self.ptr, self.idx, self.val = ptr, idx, val
+        self.plan_host = self.plan_dev = None          # SpMM plan (adjacency matrices only)
+
+    def build_spmm_plan(self):
+        """Static row-split schedule for the SpMM kernels (macr_spmm_plan_build); built once per graph."""
+        import numpy as np
+        rowptr = np.ascontiguousarray(self.ptr.cpu().numpy(), dtype=np.int32)
+        N = len(rowptr) - 1
+        L = _lib.lib()
+        nbytes = L.macr_spmm_plan_bytes(N, rowptr.ctypes.data_as(ctypes.c_void_p))
+        host = np.zeros((nbytes + 3) // 4, np.int32)
+        check(L.macr_spmm_plan_build(N, rowptr.ctypes.data_as(ctypes.c_void_p), host.ctypes.data_as(ctypes.c_void_p),
+                                     host.nbytes))
+        self.plan_host = host                            # keep alive: the launcher reads its header
+        self.plan_dev = torch.from_numpy(host).to(self.ptr.device)
+        return self
+
+    def _plan_ptrs(self):
+        if self.plan_host is None:
+            return None, None
+        return ctypes.c_void_p(self.plan_dev.data_ptr()), self.plan_host.ctypes.data_as(ctypes.c_void_p)
 
     @staticmethod
     def from_lists(lists, device, sort=True):
@@ -57,7 +77,7 @@ class CSR(object):
         m.sort_indices()
         return CSR(torch.from_numpy(m.indptr.astype("int32")).to(device),
                    torch.from_numpy(m.indices.astype("int32")).to(device),
-                   torch.from_numpy(m.data.astype("float32")).to(device))
+                   torch.from_numpy(m.data.astype("float32")).to(device)).build_spmm_plan()
 
     def rows(self, sel):
         """sub-CSR for the given row selection (host-side index list/tensor)."""
@@ -189,11 +209,13 @@ def lgcn_propagate(adj, E0, n_layers, out=None, work=None):
     N, d = E0.shape
     if out is None:
         out = torch.empty_like(E0)
-    if work is None:
-        work = torch.empty((2, N, d), dtype=_f32, device=E0.device)
+    pd, ph = adj._plan_ptrs()
+    need = _lib.lib().macr_lgcn_work_floats(N, d, ph)
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=_f32, device=E0.device)
     check(_lib.lib().macr_lgcn_propagate(N, d, n_layers, _ptr(adj.ptr, _i32), _ptr(adj.idx, _i32),
-                                         _ptr(adj.val, _f32), _ptr(E0, _f32), _ptr(out, _f32), _ptr(work, _f32),
-                                         _stream()))
+                                         _ptr(adj.val, _f32), pd, ph, _ptr(E0, _f32), _ptr(out, _f32),
+                                         _ptr(work, _f32), _stream()))
     return out
 
 
@@ -268,7 +290,7 @@ class LGCNState(object):
 
     def reserve(self, B):
         if B > self.batch_cap:
-            nbytes = _lib.lib().macr_lgcn_train_workspace_bytes(B, self.T.shape[0], self.d)
+            nbytes = _lib.lib().macr_lgcn_train_workspace_bytes(B, self.T.shape[0], self.d, self.adj._plan_ptrs()[1])
             if nbytes == 0:
                 raise MacrError(_lib.E_UNSUPPORTED, "embed_size %d not in {32,64,128,256}" % self.d)
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.T.device)
@@ -279,9 +301,10 @@ class LGCNState(object):
         self.reserve(B)
         out = self.losses if losses is None else losses
         self._E = None
+        pd, ph = self.adj._plan_ptrs()
         check(_lib.lib().macr_lgcn_train_step(
             kind, B, self.d, self.n_users, self.n_items, self.n_layers, _ptr(self.adj.ptr, _i32),
-            _ptr(self.adj.idx, _i32), _ptr(self.adj.val, _f32), _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
+            _ptr(self.adj.idx, _i32), _ptr(self.adj.val, _f32), pd, ph, _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
             _ptr(self.T), _ptr(self.w), _ptr(self.wu), _ptr(self.mT), _ptr(self.vT), _ptr(self.mw), _ptr(self.vw),
             _ptr(self.mwu), _ptr(self.vwu), _ptr(self.adam_pow), ctypes.byref(self.hyper), _ptr(out, _f32),
             _ptr(self.ws), self.ws.numel(), _stream()))

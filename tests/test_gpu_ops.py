@@ -130,8 +130,13 @@ def test_lgcn_propagate_matches_oracle(ops, d, L):
     rs = np.random.RandomState(d + L)
     E0 = rs.standard_normal((n_users + n_items, d)).astype(np.float32)
     want = oracle.lgcn_propagate(A.indptr, A.indices, A.data, E0, L)
-    got = ops.lgcn_propagate(ops.CSR.from_scipy(A, "cuda"), dev(E0), L).cpu().numpy()
+    adj = ops.CSR.from_scipy(A, "cuda")                    # with the row-split plan (hub item > 512 neighbours)
+    assert adj.plan_host is not None and adj.plan_host[2] >= 1          # header: n_split >= 1
+    got = ops.lgcn_propagate(adj, dev(E0), L).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    plain = ops.CSR(adj.ptr, adj.idx, adj.val)             # no plan: one wavefront per row
+    got2 = ops.lgcn_propagate(plain, dev(E0), L).cpu().numpy()
+    np.testing.assert_allclose(got2, want, rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("kind", [oracle.LOSS_NORMALBCE, oracle.LOSS_RUBIBCEBOTH])
