@@ -156,34 +156,37 @@ def main():
 
     # ------------------------------------------------------------- evaluator: full catalogue, masked, top-20 + metrics
     users, mask_lists, gt_lists = synth.eval_problem(cfg, seed=777)       # same on every rank
-    ev = Evaluator(mask_lists, gt_lists, cfg["n_items"], dev)
-    uid = torch.from_numpy(users).to(dev)
     Ks = [20]
+    eval_users_per_s = ev_elapsed = None
+    ret, roofline_eval = {}, None
+    if not args.no_eval:
+        ev = Evaluator(mask_lists, gt_lists, cfg["n_items"], dev)
+        uid = torch.from_numpy(users).to(dev)
 
-    def run_eval():
-        return ev.test_mf(ops.SCORE_RUBI_BOTH, state.P, uid, state.Q, Ks, state.w, state.wu, cfg["c"])
-    ret = run_eval()
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.eval_reps):
+        def run_eval():
+            return ev.test_mf(ops.SCORE_RUBI_BOTH, state.P, uid, state.Q, Ks, state.w, state.wu, cfg["c"])
         ret = run_eval()
-    torch.cuda.synchronize(); barrier()
-    ev_elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
-    eval_users_per_s = len(users) * args.eval_reps / ev_elapsed
-    ops.timing_begin()
-    run_eval()
-    emarks = ops.timing_end()
-    ek = {}
-    for name, ms in emarks:
-        ek[name] = ek.get(name, 0.0) + ms
-    lo, hi = sharding.item_shard_range(cfg["n_items"], rank, world)
-    flops = 2.0 * len(users) * (hi - lo) * d
-    st_us = 1e3 * ek.get("score_topk", float("nan"))
-    roofline_eval = {"kernel": "score_topk", "bound": "mfma", "achieved": flops / (st_us * 1e-6) / 1e12,
-                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "avg_us": st_us, "flops": flops,
-                     "traffic": pmc.get(args.workload, {}).get("score_topk"),
-                     "kernels_us": {k: 1e3 * v for k, v in ek.items()}}
-    roofline_eval["frac"] = roofline_eval["achieved"] / MFMA_F32_PEAK_TFLOPS
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.eval_reps):
+            ret = run_eval()
+        torch.cuda.synchronize(); barrier()
+        ev_elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+        eval_users_per_s = len(users) * args.eval_reps / ev_elapsed
+        ops.timing_begin()
+        run_eval()
+        emarks = ops.timing_end()
+        ek = {}
+        for name, ms in emarks:
+            ek[name] = ek.get(name, 0.0) + ms
+        lo, hi = sharding.item_shard_range(cfg["n_items"], rank, world)
+        flops = 2.0 * len(users) * (hi - lo) * d
+        st_us = 1e3 * ek.get("score_topk", float("nan"))
+        roofline_eval = {"kernel": "score_topk", "bound": "mfma", "achieved": flops / (st_us * 1e-6) / 1e12,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "avg_us": st_us, "flops": flops,
+                         "traffic": pmc.get(args.workload, {}).get("score_topk"),
+                         "kernels_us": {k: 1e3 * v for k, v in ek.items()}}
+        roofline_eval["frac"] = roofline_eval["achieved"] / MFMA_F32_PEAK_TFLOPS
 
     # ------------------------------------------------------------- CPU baseline: the oracle ("port") on the host cores
     cpu = None
@@ -230,7 +233,8 @@ def main():
                                                                       cfg["n_users"], cfg["n_items"]),
                        "parallelism": "replicas x%d (train) / item-sharded x%d + RCCL all-gather (eval)" % (world, world),
                        "global_batch": B * world},
-            "eval_users_per_s": eval_users_per_s, "eval_ms_per_pass": 1e3 * ev_elapsed / args.eval_reps,
+            "eval_users_per_s": eval_users_per_s,
+            "eval_ms_per_pass": None if ev_elapsed is None else 1e3 * ev_elapsed / args.eval_reps,
             "eval_users": len(users), "eval_metrics": {k: float(v[0]) for k, v in ret.items()},
             "step_kernel_us": step_kernel_us, "kernels": kern_avg,
             "roofline": roofline, "roofline_eval": roofline_eval, "cpu_baseline": cpu,

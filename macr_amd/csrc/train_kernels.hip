@@ -504,6 +504,10 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
 
 static inline int bxb_ct(int B) {
     // columns per block (64 per column tile): more, smaller blocks for small B so the chip stays full
+#ifdef MACR_ABL_BXB_SMALL
+    if (B >= 8192) return 128;
+    return 64;
+#endif
     if (B >= 8192) return 256;
     if (B >= 2048) return 128;
     return 64;

@@ -47,6 +47,23 @@ def main(tag, workload="gowalla"):
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
             traffic[k] = d["hbm_bytes_per_launch"]
+    # GRBM_GUI_ACTIVE per nanosecond of kernel time: proportional to the clock the kernel ran at (DVFS).  This
+    # rocprofv3 sums the counter over an unknown number of instances, so only RATIOS between kernels are used.
+    trace = os.path.join(SRC, "pmc_sq", "bench_kernel_trace.csv")
+    if os.path.exists(trace):
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(trace)):
+            k = short(r["Kernel_Name"])
+            if k:
+                dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        for k, d in pmc.items():
+            if k in dur and "GRBM_GUI_ACTIVE" in d:
+                d["avg_ns_under_pmc"] = sum(dur[k]) / len(dur[k])
+                d["gui_active_per_ns"] = d["GRBM_GUI_ACTIVE"] / d["avg_ns_under_pmc"]
+        top = max((d.get("gui_active_per_ns", 0) for d in pmc.values()), default=0)
+        for d in pmc.values():
+            if top and "gui_active_per_ns" in d:
+                d["clock_rel_to_fastest_kernel"] = d["gui_active_per_ns"] / top
     json.dump(pmc, open(os.path.join(DST, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     latest_path = os.path.join(DST, "pmc_latest.json")
     latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
