@@ -109,6 +109,20 @@ int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items,
                        float *losses, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Device-side sampler of (user, positive, negative) triples (new).
+ * Same distribution as Data.sample of the reference (macr_mf/load_data.py:543-566,
+ * macr_lightgcn/utility/load_data.py:174-212): B distinct users from the pool (with
+ * replacement when B > n_pool), a uniform positive from the user's train list (item 0
+ * when empty), a uniform negative outside it.  NOT the reference's random stream: a
+ * batch is a pure function of (seed, step).
+ *   pool (dev, may be NULL = users 0..n_pool-1) int32[n_pool]: candidate user ids
+ *   train_ptr (dev) int32[max_user+2], train_idx (dev): train items per user id, ascending
+ *   out (dev) int32[3*B] = users | pos_items | neg_items
+ * -------------------------------------------------------------------------*/
+int macr_sample_triples(uint64_t seed, uint64_t step, int B, int n_items, const int32_t *pool, int n_pool,
+                        const int32_t *train_ptr, const int32_t *train_idx, int32_t *out, void *stream);
+
+/* ---------------------------------------------------------------------------
  * SpMM plan (host side, built once per graph -- the adjacency never changes).
  * Interaction graphs have hub rows (items with 10^4..10^5 neighbours); the plan
  * cuts rows longer than 512 non-zeros into work items of 512 so that no single

@@ -44,6 +44,7 @@ _FLAGS = [
     ("step", int, 20, "LightGCN_tune.py: number of c values"),
     ("out", int, 0, "(compat)"),
     ("seed", int, 12345, "[new] seed of python/numpy/torch RNGs (the reference hard-codes 12345)"),
+    ("sampler", str, "reference", "[new] reference: the reference's random/numpy streams (host); device: GPU sampler"),
 ]
 
 

@@ -68,12 +68,17 @@ def _ckpt_dir():
     return '{}_{}_checkpoint/wd_{}_lr_{}_{}/'.format(args.model, args.dataset, args.wd, args.lr, args.saveID)
 
 
-def train_epoch(model, kind, n_batch, loss_log):
-    """n_batch = n_train // batch_size + 1 steps (train.py:467-470).  Sampling follows the reference's
-    python `random` stream; per-step losses stay on the device and come back once per epoch."""
+def train_epoch(model, kind, n_batch, loss_log, device_sampler=None):
+    """n_batch = n_train // batch_size + 1 steps (train.py:467-470).  --sampler reference follows the
+    reference's python `random` stream (host-bound); --sampler device draws the batches on the GPU.
+    Per-step losses stay on the device and come back once per epoch."""
     for idx in range(n_batch):
-        users, pos_items, neg_items = data.sample()
-        model.train_step(kind, model.to_device_batch(users, pos_items, neg_items), loss_log[idx])
+        if device_sampler is not None:
+            batch = device_sampler.sample()
+        else:
+            users, pos_items, neg_items = data.sample()
+            batch = model.to_device_batch(users, pos_items, neg_items)
+        model.train_step(kind, batch, loss_log[idx])
     per_step = loss_log[:n_batch].cpu().numpy()
     loss = mf_loss = reg_loss = 0.
     for row in per_step:                                     # same accumulation order as train.py:497-499
@@ -112,9 +117,16 @@ def main(sweep=False):
     stopping_step = 0
     n_batch = data.n_train // args.batch_size + 1
     loss_log = torch.zeros((n_batch, 3), dtype=torch.float32, device=model.device)
+    device_sampler = None
+    if args.sampler == "device":
+        from macr_amd.sampler import DeviceSampler
+        device_sampler = DeviceSampler(data.train_user_list, data.n_users, data.n_items, args.batch_size,
+                                       model.device, seed=seed)
+    elif args.sampler != "reference":
+        raise SystemExit("--sampler must be reference or device")
     for epoch in range(args.epoch):
         t1 = time()
-        loss, mf_loss, reg_loss = train_epoch(model, kind, n_batch, loss_log)
+        loss, mf_loss, reg_loss = train_epoch(model, kind, n_batch, loss_log, device_sampler)
         if np.isnan(loss):
             print('ERROR: loss is nan.')
             sys.exit()

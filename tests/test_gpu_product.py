@@ -133,6 +133,38 @@ def test_session_shim_matches_fast_path(ops):
         sess.run(a.opt_two, {a.users: u, a.pos_items: i, a.neg_items: j})
 
 
+# ----------------------------------------------------------------------------- device sampler
+def test_device_sampler_distribution(ops):
+    from macr_amd.sampler import DeviceSampler
+    rs = np.random.RandomState(0)
+    n_users, n_items, B = 500, 200, 256
+    train = {u: sorted(rs.choice(n_items, size=rs.randint(1, 40), replace=False).tolist()) for u in range(n_users)}
+    train[7] = []                                   # empty list -> positive 0 (load_data.py:551-552)
+    train[9] = list(range(n_items - 1))             # one admissible negative only
+    smp = DeviceSampler(train, n_users, n_items, B, torch.device("cuda"), seed=3)
+    seen_users = np.zeros(n_users)
+    neg_hist = np.zeros(n_items)
+    for step in range(200):
+        u, i, j = smp.sample().cpu().numpy()
+        assert len(set(u.tolist())) == B            # rd.sample: without replacement inside a batch
+        for uu, ii, jj in zip(u, i, j):
+            assert jj not in train[uu]
+            assert (ii in train[uu]) or (train[uu] == [] and ii == 0)
+        seen_users[u] += 1
+        neg_hist[j] += 1
+    # every user is drawn with probability B/n_users per batch
+    exp = 200 * B / n_users
+    assert abs(seen_users.mean() - exp) < 1e-9 and seen_users.std() < 4 * np.sqrt(exp)
+    assert neg_hist.min() > 0
+    a = DeviceSampler(train, n_users, n_items, B, torch.device("cuda"), seed=3).sample().cpu().numpy()
+    b = DeviceSampler(train, n_users, n_items, B, torch.device("cuda"), seed=3).sample().cpu().numpy()
+    c = DeviceSampler(train, n_users, n_items, B, torch.device("cuda"), seed=4).sample().cpu().numpy()
+    assert np.array_equal(a, b) and not np.array_equal(a, c)       # pure function of (seed, step)
+    big = DeviceSampler(train, n_users, n_items, 2048, torch.device("cuda"), seed=1, pool=list(range(0, 500, 2)))
+    u, i, j = big.sample().cpu().numpy()           # B > pool: with replacement, only pool users
+    assert set(u.tolist()) <= set(range(0, 500, 2)) and len(u) == 2048
+
+
 # ----------------------------------------------------------------------------- command lines
 def _run_cli(cmd, cwd):
     env = dict(os.environ, PYTHONUNBUFFERED="1")
@@ -141,12 +173,14 @@ def _run_cli(cmd, cwd):
     return out.stdout
 
 
-@pytest.mark.parametrize("train,test_", [("normalbce", "normal"), ("rubibceboth", "rubi")])
-def test_mf_cli_addressa(tmp_path, train, test_):
+@pytest.mark.parametrize("train,test_,sampler", [("normalbce", "normal", "reference"), ("rubibceboth", "rubi", "reference"),
+                                                  ("rubibceboth", "rubi", "device")])
+def test_mf_cli_addressa(tmp_path, train, test_, sampler):
     os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
     out = _run_cli([os.path.join(REPO, "macr_mf", "train.py"), "--dataset", "addressa", "--batch_size", "1024",
                     "--cuda", "0", "--saveID", "t", "--log_interval", "2", "--lr", "0.001", "--epoch", "4",
-                    "--train", train, "--test", test_, "--c", "40", "--alpha", "1e-3", "--beta", "1e-3"], str(tmp_path))
+                    "--train", train, "--test", test_, "--c", "40", "--alpha", "1e-3", "--beta", "1e-3",
+                    "--sampler", sampler], str(tmp_path))
     lines = [l for l in out.splitlines() if "train==[" in l]
     assert len(lines) == 4, out
     evals = [l for l in lines if "hit=[" in l]

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "macr_amd", "csrc")
-SRCS = ["capi_common.hip", "train_kernels.hip", "spmm_kernels.hip", "eval_kernels.hip"]
+SRCS = ["capi_common.hip", "train_kernels.hip", "spmm_kernels.hip", "eval_kernels.hip", "sample_kernels.hip"]
 
 
 def build(name, defs):
