@@ -160,6 +160,9 @@ def main():
     eval_users_per_s = ev_elapsed = None
     ret, roofline_eval = {}, None
     if not args.no_eval:
+        if world > 1:      # replicas trained on different batches: evaluate ONE model (rank 0's), item-sharded
+            for t in (state.P, state.Q, state.w, state.wu):
+                torch.distributed.broadcast(t, 0)
         ev = Evaluator(mask_lists, gt_lists, cfg["n_items"], dev)
         uid = torch.from_numpy(users).to(dev)
 
