@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pos", default="zipf", choices=["zipf", "uniform"], help="positive-item distribution (diagnostic)")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluator leg (diagnostic)")
+    ap.add_argument("--unsorted", action="store_true", help="do not order the triples of a batch by positive item (diagnostic)")
     return ap.parse_args()
 
 
@@ -97,7 +98,8 @@ def main():
     hyper = ops.make_hyper(cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
     state = ops.MFState(P, Q, w, wu, hyper, B)
     n_batches = min(args.steps + args.warmup, 256)
-    batches = synth.train_batches(n_batches, cfg["n_users"], cfg["n_items"], B, gen, dev, zipf=args.pos == "zipf")
+    batches = synth.train_batches(n_batches, cfg["n_users"], cfg["n_items"], B, gen, dev, zipf=args.pos == "zipf",
+                                  sort_by_pos=not args.unsorted)
     loss_log = torch.zeros((n_batches, 3), dtype=torch.float32, device=dev)
 
     def barrier():
@@ -241,7 +243,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s-shape MACR-MF %s d=%d batch=%d c=%g (n_users=%d, n_items=%d); synthetic "
-                                   "Xavier tables, Zipf positives" % (args.workload, args.train, d, B, cfg["c"],
+                                   "Xavier tables, Zipf positives, batches ordered by positive item" % (args.workload, args.train, d, B, cfg["c"],
                                                                       cfg["n_users"], cfg["n_items"]),
                        "parallelism": "replicas x%d (train) / item-sharded x%d + RCCL all-gather (eval)" % (world, world),
                        "global_batch": B * world},

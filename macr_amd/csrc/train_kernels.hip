@@ -195,6 +195,8 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, const float *__restr
 // Branch-vector gradients are NOT accumulated with atomics at all (every block would hit the same
 // d addresses); each block writes one partial row that adam_dense reduces.
 // ----------------------------------------------------------------------------
+constexpr int kChunkT = 16;       // consecutive triples per block pass in the backward kernels
+
 template <int D>
 struct WaveRow {
     static constexpr int EPL = (D + 63) / 64;          // elements per lane
@@ -220,6 +222,8 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     float alpha, float beta, float coef) {
     constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float s_w[4][2][D];
+    __shared__ float s_gi[kChunkT][D];
+    __shared__ int s_pos[kChunkT];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bool act = lane < WaveRow<D>::kActive;
     float wk[EPL], wuk[EPL], aw[EPL], awu[EPL];
@@ -229,43 +233,70 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
         wk[e] = act ? w[k] : 0.f; wuk[e] = act ? wu[k] : 0.f; aw[e] = 0.f; awu[e] = 0.f;
     }
     const float inv_b2 = 1.0f / ((float)B * (float)B), eps = 1e-10f, invB = 1.0f / (float)B;
-    for (int t = blockIdx.x * 4 + wid; t < B; t += gridDim.x * 4) {
-        // per-triple scalars: the wave sums the bxb partials cooperatively
-        float dp = 0.f, dn = 0.f, da = 0.f, db = 0.f;
+    // A block owns kChunkT CONSECUTIVE triples per pass.  The order of the triples of a batch is free (every
+    // loss term is a sum over the batch), so the input pipeline may sort a batch by positive item: equal positive
+    // items are then adjacent, and the block adds each RUN of equal rows once (LDS segmented sum) instead of once
+    // per triple -- the hottest item of a Zipf batch costs (#blocks it spans) serialised atomics, not (#references).
+    // Unsorted batches stay correct (runs of length one).
+    for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += gridDim.x) {
+#pragma unroll 1
+        for (int q = 0; q < kChunkT / 4; ++q) {
+            const int slot = wid * (kChunkT / 4) + q;
+            const int t = chunk * kChunkT + slot;
+            if (t >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
+            // per-triple scalars: the wave sums the bxb partials cooperatively
+            float dp = 0.f, dn = 0.f, da = 0.f, db = 0.f;
 #ifndef MACR_ABL_NOPART
-        for (int k = lane; k < nrb; k += 64) {
-            dp += colpart[((size_t)k * 2 + 0) * Bp + t];
-            dn += colpart[((size_t)k * 2 + 1) * Bp + t];
-        }
-        for (int k = lane; k < ncb; k += 64) {
-            da += rowpart[((size_t)k * 2 + 0) * Bp + t];
-            db += rowpart[((size_t)k * 2 + 1) * Bp + t];
-        }
+            for (int k = lane; k < nrb; k += 64) {
+                dp += colpart[((size_t)k * 2 + 0) * Bp + t];
+                dn += colpart[((size_t)k * 2 + 1) * Bp + t];
+            }
+            for (int k = lane; k < ncb; k += 64) {
+                da += rowpart[((size_t)k * 2 + 0) * Bp + t];
+                db += rowpart[((size_t)k * 2 + 1) * Bp + t];
+            }
 #endif
-        dp = wave_sum(dp) * inv_b2; dn = wave_sum(dn) * inv_b2;
-        da = wave_sum(da) * inv_b2; db = wave_sum(db) * inv_b2;
-        const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
-        const float dsi = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
-        const float dsj = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
-        const float dsu = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
-                          (beta * invB) * (dneglog_sig(ssu, eps) + dneglog_1msig(ssu, eps));
-        const int ru = u[t], ri = i[t], rj = j[t];
-        if (act) {
+            dp = wave_sum(dp) * inv_b2; dn = wave_sum(dn) * inv_b2;
+            da = wave_sum(da) * inv_b2; db = wave_sum(db) * inv_b2;
+            const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
+            const float dsi = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
+            const float dsj = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
+            const float dsu = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
+                              (beta * invB) * (dneglog_sig(ssu, eps) + dneglog_1msig(ssu, eps));
+            const int ru = u[t], ri = i[t], rj = j[t];
+            if (act) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int k = lane + 64 * e;
-                const float eu = Usrc[(size_t)ru * D + k], ei = Isrc[(size_t)ri * D + k], ej = Isrc[(size_t)rj * D + k];
-                const float gu = fmaf(coef, eu, fmaf(dsu, wuk[e], fmaf(dn, ej, dp * ei)));
-                const float gi = fmaf(coef, ei, fmaf(dsi, wk[e], dp * eu));
-                const float gj = fmaf(coef, ej, fmaf(dsj, wk[e], dn * eu));
-                MACR_ATOMIC_ADD(gU + (size_t)ru * D + k, gu);
-                MACR_ATOMIC_ADD(gI + (size_t)ri * D + k, gi);
-                MACR_ATOMIC_ADD(gI + (size_t)rj * D + k, gj);
-                aw[e] = fmaf(dsi, ei, fmaf(dsj, ej, aw[e]));
-                awu[e] = fmaf(dsu, eu, awu[e]);
+                for (int e = 0; e < EPL; ++e) {
+                    const int k = lane + 64 * e;
+                    const float eu = Usrc[(size_t)ru * D + k], ei = Isrc[(size_t)ri * D + k], ej = Isrc[(size_t)rj * D + k];
+                    const float gu = fmaf(coef, eu, fmaf(dsu, wuk[e], fmaf(dn, ej, dp * ei)));
+                    const float gi = fmaf(coef, ei, fmaf(dsi, wk[e], dp * eu));
+                    const float gj = fmaf(coef, ej, fmaf(dsj, wk[e], dn * eu));
+                    MACR_ATOMIC_ADD(gU + (size_t)ru * D + k, gu);
+                    MACR_ATOMIC_ADD(gI + (size_t)rj * D + k, gj);
+                    s_gi[slot][k] = gi;                         // positive row: combined per run below
+                    aw[e] = fmaf(dsi, ei, fmaf(dsj, ej, aw[e]));
+                    awu[e] = fmaf(dsu, eu, awu[e]);
+                }
+            }
+            if (lane == 0) {
+                s_pos[slot] = ri;
+                if (touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
             }
         }
-        if (lane == 0 && touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
+        __syncthreads();
+        for (int k = threadIdx.x; k < D; k += 256) {            // thread k owns element k of every positive row
+            float acc = 0.f;
+#pragma unroll 4
+            for (int slot = 0; slot < kChunkT; ++slot) {
+                const int row = s_pos[slot];
+                if (row < 0) break;
+                acc += s_gi[slot][k];
+                const int nxt = slot + 1 < kChunkT ? s_pos[slot + 1] : -1;
+                if (nxt != row) { MACR_ATOMIC_ADD(gI + (size_t)row * D + k, acc); acc = 0.f; }
+            }
+        }
+        __syncthreads();
     }
     if (act) {
 #pragma unroll
@@ -294,6 +325,8 @@ __global__ __launch_bounds__(256) void k_pair_normal(
     float lr, float b1, float b2) {
     constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float red[16];
+    __shared__ float s_gi[kChunkT][D];
+    __shared__ int s_pos[kChunkT];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bool act = lane < WaveRow<D>::kActive;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -304,32 +337,54 @@ __global__ __launch_bounds__(256) void k_pair_normal(
     }
     float sq = 0.f, bce = 0.f;
     const float eps = 1e-9f, invB = 1.0f / (float)B;
-    for (int t = blockIdx.x * 4 + wid; t < B; t += gridDim.x * 4) {
-        const int ru = u[t], ri = i[t], rj = j[t];
-        float eu[EPL], ei[EPL], ej[EPL], pp = 0.f, nn = 0.f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int k = lane + 64 * e;
-            eu[e] = act ? Usrc[(size_t)ru * D + k] : 0.f;
-            ei[e] = act ? Isrc[(size_t)ri * D + k] : 0.f;
-            ej[e] = act ? Isrc[(size_t)rj * D + k] : 0.f;
-            pp = fmaf(eu[e], ei[e], pp); nn = fmaf(eu[e], ej[e], nn);
-            if (reg_on_gathered) sq += eu[e] * eu[e] + ei[e] * ei[e] + ej[e] * ej[e];
-        }
-        const float p = wave_sum(pp), n = wave_sum(nn);
-        const float sp = sigmoid_acc(p), sn = sigmoid_acc(n);
-        if (lane == 0) bce += -logf(sp + eps) + -logf((1.0f - sn) + eps);
-        const float dp = dneglog_sig(sp, eps) * invB, dn = dneglog_1msig(sn, eps) * invB;
-        if (act) {
+    for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += gridDim.x) {      // see pair_bwd: runs of equal positives
+#pragma unroll 1
+        for (int q = 0; q < kChunkT / 4; ++q) {
+            const int slot = wid * (kChunkT / 4) + q;
+            const int t = chunk * kChunkT + slot;
+            if (t >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
+            const int ru = u[t], ri = i[t], rj = j[t];
+            float eu[EPL], ei[EPL], ej[EPL], pp = 0.f, nn = 0.f;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const int k = lane + 64 * e;
-                MACR_ATOMIC_ADD(gU + (size_t)ru * D + k, fmaf(coef, eu[e], fmaf(dn, ej[e], dp * ei[e])));
-                MACR_ATOMIC_ADD(gI + (size_t)ri * D + k, fmaf(coef, ei[e], dp * eu[e]));
-                MACR_ATOMIC_ADD(gI + (size_t)rj * D + k, fmaf(coef, ej[e], dn * eu[e]));
+                eu[e] = act ? Usrc[(size_t)ru * D + k] : 0.f;
+                ei[e] = act ? Isrc[(size_t)ri * D + k] : 0.f;
+                ej[e] = act ? Isrc[(size_t)rj * D + k] : 0.f;
+                pp = fmaf(eu[e], ei[e], pp); nn = fmaf(eu[e], ej[e], nn);
+                if (reg_on_gathered) sq += eu[e] * eu[e] + ei[e] * ei[e] + ej[e] * ej[e];
+            }
+            const float p = wave_sum(pp), n = wave_sum(nn);
+            const float sp = sigmoid_acc(p), sn = sigmoid_acc(n);
+            if (lane == 0) bce += -logf(sp + eps) + -logf((1.0f - sn) + eps);
+            const float dp = dneglog_sig(sp, eps) * invB, dn = dneglog_1msig(sn, eps) * invB;
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int k = lane + 64 * e;
+                    MACR_ATOMIC_ADD(gU + (size_t)ru * D + k, fmaf(coef, eu[e], fmaf(dn, ej[e], dp * ei[e])));
+                    MACR_ATOMIC_ADD(gI + (size_t)rj * D + k, fmaf(coef, ej[e], dn * eu[e]));
+                    s_gi[slot][k] = fmaf(coef, ei[e], dp * eu[e]);
+                }
+            }
+            if (lane == 0) {
+                s_pos[slot] = ri;
+                if (touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
             }
         }
-        if (lane == 0 && touchedU) { touchedU[ru] = 1; touchedI[ri] = 1; touchedI[rj] = 1; }
+        __syncthreads();
+        for (int k = threadIdx.x; k < D; k += 256) {
+            float acc = 0.f;
+#pragma unroll 4
+            for (int slot = 0; slot < kChunkT; ++slot) {
+                const int row = s_pos[slot];
+                if (row < 0) break;
+                acc += s_gi[slot][k];
+                const int nxt = slot + 1 < kChunkT ? s_pos[slot + 1] : -1;
+                if (nxt != row) { MACR_ATOMIC_ADD(gI + (size_t)row * D + k, acc); acc = 0.f; }
+            }
+        }
+        __syncthreads();
     }
     const float s0 = block_sum(sq, red);
     const float s3 = block_sum(bce, red);
@@ -535,7 +590,7 @@ static PairWs carve_pair_ws(void *base, int B, int d) {
     w.nrb = w.Bp / 256;
     w.ncb = (B + w.ct - 1) / w.ct;
     w.nblk_pair = (B + rpb - 1) / rpb;
-    w.nblk_bwd = (B + 3) / 4 < 256 ? (B + 3) / 4 : 256;     // one wave per triple, grid-strided
+    w.nblk_bwd = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;   // 16 consecutive triples per block pass
     char *p = static_cast<char *>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) { void *r = p ? p + off : nullptr; off += align_up(bytes, 256); return r; };

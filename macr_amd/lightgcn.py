@@ -11,6 +11,7 @@ dropout, pretrained restore are out of scope (NotImplementedError).
 """
 import ast
 
+import numpy as np
 import torch
 
 from . import ops
@@ -103,7 +104,11 @@ class LightGCN(object):
         return self._LOSS[loss][1]
 
     def to_device_batch(self, users, pos_items, neg_items):
-        host = torch.tensor([users, pos_items, neg_items], dtype=torch.int32).pin_memory()
+        arr = np.asarray([users, pos_items, neg_items], dtype=np.int32)
+        # the order of the triples inside a batch is free: sorting by positive item makes equal rows adjacent so
+        # the backward kernel adds each run once (hot items are 5-10 % of all positives)
+        arr = arr[:, np.argsort(arr[1], kind="stable")]
+        host = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
         return host.to(self.device, non_blocking=True)
 
     def train_step(self, kind, batch, losses=None):

@@ -35,8 +35,10 @@ def zipf_probs(n, device, s=1.0):
     return (p / p.sum()).to(torch.float32)
 
 
-def train_batches(n_steps, n_users, n_items, batch, gen, device, zipf=True):
-    """(n_steps,3,B) int32: users w/o replacement per step, Zipf positives, uniform negatives."""
+def train_batches(n_steps, n_users, n_items, batch, gen, device, zipf=True, sort_by_pos=True):
+    """(n_steps,3,B) int32: users w/o replacement per step, Zipf positives, uniform negatives.
+    sort_by_pos: order the triples of every batch by positive item id, as the input pipeline does (the order
+    inside a batch is mathematically irrelevant; adjacent equal rows let the backward kernel add each run once)."""
     probs = zipf_probs(n_items, device)
     out = torch.empty((n_steps, 3, batch), dtype=torch.int32, device=device)
     for s in range(n_steps):
@@ -50,6 +52,9 @@ def train_batches(n_steps, n_users, n_items, batch, gen, device, zipf=True):
         else:
             out[s, 1] = torch.randint(0, n_items, (batch,), generator=gen, device=device).to(torch.int32)
         out[s, 2] = torch.randint(0, n_items, (batch,), generator=gen, device=device).to(torch.int32)
+        if sort_by_pos:
+            order = torch.argsort(out[s, 1], stable=True)
+            out[s] = out[s][:, order]
     return out
 
 
