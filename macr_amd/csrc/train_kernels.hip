@@ -112,77 +112,92 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
 //   L_ori = mean(-log(sig(X)+1e-10) - log(1-sig(Y)+1e-10))   :211
 // and its gradient: row sums da,db and column sums dp,dn of f'(X), g'(Y).
 //
-// A wave owns a 64-row x 64-column tile: lane t holds row t for the whole tile and,
-// at iteration k, column (t+k) mod 64.  The column's inputs (p,n) and its running
-// column sums travel with it: after every iteration the four registers are rotated
-// one lane down the wave with DPP (v_mov_b32_dpp wave_rol:1), so after 64 iterations
-// each column sum is back in its home lane holding the total over the wave's 64 rows.
-// Row sums never leave their lane.  No LDS traffic, no atomics in the inner loop; the
-// kernel is bound by the transcendental VALU rate (8 v_exp/v_log/v_rcp per pair).
-// Block = 4 waves = 256 rows x (NCT*64) columns; the waves' column sums meet in LDS once.
-//   rowpart [ncb][2][Bp], colpart [nrb][2][Bp], lpart [nrb*ncb]
+// A wave owns a (64*R)-row x 64-column tile: lane t holds rows t, t+64, ... (R of them) for
+// the whole tile and, at iteration k, column (t+k) mod 64.  The column's inputs (p,n) and
+// its running column sums travel with it: after every iteration the four registers are
+// rotated one lane down the wave with DPP (v_mov_b32_dpp wave_rol:1), so after 64
+// iterations each column sum is back in its home lane holding the total over the wave's
+// rows; R rows per lane amortise the four rotations over R pairs.  Row sums never leave
+// their lane.  No LDS traffic, no atomics in the inner loop.
+// The X and Y halves of a pair are the two lanes of packed fp32 math (v_pk_mul/add/fma_f32:
+// two results per lane per issue), which leaves the kernel bound by its eight
+// transcendentals per pair (2 v_exp, 4 v_rcp, 2 v_log at a fraction of the VALU rate).
+// Block = 4 waves = (64*R) rows x 256 columns (one 64-column tile per wave); the waves' row
+// sums meet in LDS once.   rowpart [ncb][2][Bp], colpart [nrb][2][Bp], lpart [nrb*ncb]
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ float wave_rol1(float v) {      // lane i <- lane (i+1) mod 64
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x134, 0xf, 0xf, true));
 }
 
-template <int NCT, bool FULL>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int R, bool FULL>
 __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, const float *__restrict__ fwd,
                                              float *__restrict__ rowpart, float *__restrict__ colpart,
                                              float *__restrict__ lpart) {
-    constexpr int CT = NCT * 64;
-    __shared__ float s_col[4][2][CT];
+    constexpr int RB = 64 * R;                 // rows per block
+    __shared__ float s_row[4][2][RB];
     __shared__ float red[16];
     const int cb = blockIdx.x, rb = blockIdx.y, t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int r = rb * 256 + t;
     const float *p = fwd, *n = fwd + Bp, *a = fwd + 2 * (size_t)Bp, *b = fwd + 3 * (size_t)Bp;
-    const bool rok = FULL || r < B;
-    const float ar = rok ? a[r] : 0.f, br = rok ? b[r] : 0.f;
-    const float eps = 1e-10f;
     const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-    float da = 0.f, db = 0.f, l2sum = 0.f;     // l2sum accumulates log2 terms; scaled by ln2 at the end
+    const v2f one = {1.0f, 1.0f}, eps = {1e-10f, 1e-10f};
+    v2f ab[R], abs_[R], dab[R];                // {a,b} of the lane's rows; the same scaled by -log2(e); row sums
+    bool rok[R];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        const int c0 = cb * CT + ct * 64;
-        const bool cok = FULL || (c0 + lane < B);
-        float pc = cok ? p[c0 + lane] : 0.f, nc = cok ? n[c0 + lane] : 0.f;
-        float accp = 0.f, accn = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k) {
-            const float x = pc * ar, y = nc * br;
-            // sigmoid = 1/(1+exp(-x)) with the hardware exp2 / rcp (1 ulp each)
-            const float sx = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * x));
-            const float sy = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * y));
-            const float tx = sx + eps, omy = 1.0f - sy, ty = omy + eps;
-            float lx = __builtin_amdgcn_logf(tx), ly = __builtin_amdgcn_logf(ty);
-            float gx = -(sx * (1.0f - sx)) * __builtin_amdgcn_rcpf(tx);
-            float gy = (sy * omy) * __builtin_amdgcn_rcpf(ty);
+    for (int q = 0; q < R; ++q) {
+        const int r = rb * RB + q * 64 + lane;
+        rok[q] = FULL || r < B;
+        ab[q] = v2f{rok[q] ? a[r] : 0.f, rok[q] ? b[r] : 0.f};
+        abs_[q] = ab[q] * (-kLog2e);
+        dab[q] = v2f{0.f, 0.f};
+    }
+    const int c = cb * 256 + wid * 64 + lane;  // the column this lane is home to
+    const bool cok = FULL || c < B;
+    v2f cn = {cok ? p[c] : 0.f, cok ? n[c] : 0.f};
+    v2f acc = {0.f, 0.f}, l2 = {0.f, 0.f};     // column sums travelling with cn; log2 terms (scaled by ln2 at the end)
+#pragma unroll 2
+    for (int k = 0; k < 64; ++k) {
+        bool colok = true;
+        if (!FULL) colok = cb * 256 + wid * 64 + ((lane + k) & 63) < B;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const v2f z = cn * abs_[q];                                        // -log2(e) * {x, y}
+            const v2f dd = v2f{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + one;
+            const v2f s = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};   // sigmoid(x), sigmoid(y)
+            const v2f om = one - s;
+            const v2f tt = v2f{s.x, om.y} + eps;                              // sig(x)+eps, (1-sig(y))+eps
+            v2f lg = {__builtin_amdgcn_logf(tt.x), __builtin_amdgcn_logf(tt.y)};
+            const v2f rt = {__builtin_amdgcn_rcpf(tt.x), __builtin_amdgcn_rcpf(tt.y)};
+            // g = {-f'(x), g'(y)}: f'(x) = -s(1-s)/(s+eps), g'(y) = s(1-s)/((1-s)+eps); the sign of the x half is
+            // applied once, after the loops
+            v2f g = (s * om) * rt;
             if (!FULL) {
-                const bool ok = rok && (c0 + ((lane + k) & 63) < B);
-                lx = ok ? lx : 0.f; ly = ok ? ly : 0.f; gx = ok ? gx : 0.f; gy = ok ? gy : 0.f;
+                const bool ok = rok[q] && colok;
+                lg = ok ? lg : v2f{0.f, 0.f};
+                g = ok ? g : v2f{0.f, 0.f};
             }
-            l2sum -= lx + ly;
-            da = fmaf(gx, pc, da);
-            db = fmaf(gy, nc, db);
-            accp = fmaf(gx, ar, accp);
-            accn = fmaf(gy, br, accn);
-            pc = wave_rol1(pc); nc = wave_rol1(nc); accp = wave_rol1(accp); accn = wave_rol1(accn);
+            l2 += lg;
+            dab[q] = __builtin_elementwise_fma(g, cn, dab[q]);
+            acc = __builtin_elementwise_fma(g, ab[q], acc);
         }
-        s_col[wid][0][ct * 64 + lane] = accp;      // home again: column c0+lane over this wave's rows
-        s_col[wid][1][ct * 64 + lane] = accn;
+        cn.x = wave_rol1(cn.x); cn.y = wave_rol1(cn.y); acc.x = wave_rol1(acc.x); acc.y = wave_rol1(acc.y);
     }
-    if (rok) {
-        rowpart[((size_t)cb * 2 + 0) * Bp + r] = da;
-        rowpart[((size_t)cb * 2 + 1) * Bp + r] = db;
+    if (cok) {                                  // home again: column c over this wave's 64*R rows
+        colpart[((size_t)rb * 2 + 0) * Bp + c] = -acc.x;
+        colpart[((size_t)rb * 2 + 1) * Bp + c] = acc.y;
     }
-    const float lsum = block_sum(l2sum * kLn2, red);   // contains the barrier that publishes s_col
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        s_row[wid][0][q * 64 + lane] = -dab[q].x;
+        s_row[wid][1][q * 64 + lane] = dab[q].y;
+    }
+    const float lsum = block_sum(-(l2.x + l2.y) * kLn2, red);   // contains the barrier that publishes s_row
     if (t == 0) lpart[(size_t)rb * gridDim.x + cb] = lsum;
-    for (int c = t; c < CT; c += 256) {
-        const int gc = cb * CT + c;
-        if (FULL || gc < B) {
-            colpart[((size_t)rb * 2 + 0) * Bp + gc] = (s_col[0][0][c] + s_col[1][0][c]) + (s_col[2][0][c] + s_col[3][0][c]);
-            colpart[((size_t)rb * 2 + 1) * Bp + gc] = (s_col[0][1][c] + s_col[1][1][c]) + (s_col[2][1][c] + s_col[3][1][c]);
-        }
+    for (int e = t; e < 2 * RB; e += 256) {
+        const int q = e / RB, rr = e % RB, r = rb * RB + rr;
+        if (FULL || r < B)
+            rowpart[((size_t)cb * 2 + q) * Bp + r] = (s_row[0][q][rr] + s_row[1][q][rr]) + (s_row[2][q][rr] + s_row[3][q][rr]);
     }
 }
 
@@ -557,15 +572,14 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
         case 256: { constexpr int D = 256; __VA_ARGS__; } break; \
     }
 
-static inline int bxb_ct(int B) {
-    // columns per block (64 per column tile): more, smaller blocks for small B so the chip stays full
-#ifdef MACR_ABL_BXB_SMALL
-    if (B >= 8192) return 128;
-    return 64;
+static inline int bxb_rows(int B) {
+    // rows per lane of the bxb kernel: fewer for small B so the chip stays full
+#ifdef MACR_BXB_ROWS
+    return MACR_BXB_ROWS;
 #endif
-    if (B >= 8192) return 256;
-    if (B >= 2048) return 128;
-    return 64;
+    if (B >= 8192) return 4;
+    if (B >= 4096) return 2;
+    return 1;
 }
 
 struct PairWs {
@@ -578,7 +592,7 @@ struct PairWs {
     float *lpart;       // [nrb*ncb]
     float *rowpart;     // [ncb*2*Bp]
     float *colpart;     // [nrb*2*Bp]
-    int Bp, nrb, ncb, ct, nblk_pair;
+    int Bp, nrb, ncb, rows, nblk_pair;
     size_t bytes;
 };
 
@@ -586,9 +600,9 @@ static PairWs carve_pair_ws(void *base, int B, int d) {
     PairWs w;
     const int lpr = d / 4, rpb = 256 / lpr;
     w.Bp = (int)align_up((size_t)B, 256);
-    w.ct = bxb_ct(B);
-    w.nrb = w.Bp / 256;
-    w.ncb = (B + w.ct - 1) / w.ct;
+    w.rows = bxb_rows(B);
+    w.nrb = w.Bp / (64 * w.rows);
+    w.ncb = w.Bp / 256;
     w.nblk_pair = (B + rpb - 1) / rpb;
     w.nblk_bwd = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;   // 16 consecutive triples per block pass
     char *p = static_cast<char *>(base);
@@ -607,12 +621,11 @@ static PairWs carve_pair_ws(void *base, int B, int d) {
     return w;
 }
 
-template <int NCT>
-static void launch_bxb_ct(const PairWs &ws, int B, hipStream_t st) {
+template <int R>
+static void launch_bxb_rows(const PairWs &ws, int B, hipStream_t st) {
     dim3 grid(ws.ncb, ws.nrb);
-    const bool full = (B % 256 == 0) && (B % (NCT * 64) == 0);
-    if (full) k_bxb<NCT, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.fwd, ws.rowpart, ws.colpart, ws.lpart);
-    else      k_bxb<NCT, false><<<grid, 256, 0, st>>>(B, ws.Bp, ws.fwd, ws.rowpart, ws.colpart, ws.lpart);
+    if (B % 256 == 0) k_bxb<R, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.fwd, ws.rowpart, ws.colpart, ws.lpart);
+    else              k_bxb<R, false><<<grid, 256, 0, st>>>(B, ws.Bp, ws.fwd, ws.rowpart, ws.colpart, ws.lpart);
 }
 
 // forward + (B,B) + backward of the pair loss; gradients are atomically added into gU/gI.
@@ -632,10 +645,10 @@ static int launch_pair(int kind, int B, int d, const int32_t *u, const int32_t *
                                                                reg_on_gathered, adam_pow, adam_pow, ws.scal, hp->lr,
                                                                hp->beta1, hp->beta2)));
     MACR_CHECK_LAUNCH("pair_fwd", st);
-    switch (ws.ct) {
-        case 64: launch_bxb_ct<1>(ws, B, st); break;
-        case 128: launch_bxb_ct<2>(ws, B, st); break;
-        default: launch_bxb_ct<4>(ws, B, st); break;
+    switch (ws.rows) {
+        case 1: launch_bxb_rows<1>(ws, B, st); break;
+        case 2: launch_bxb_rows<2>(ws, B, st); break;
+        default: launch_bxb_rows<4>(ws, B, st); break;
     }
     MACR_CHECK_LAUNCH("bxb", st);
     MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu,
