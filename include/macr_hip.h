@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     3
+#define MACR_ABI_VERSION     4
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -96,7 +96,31 @@ typedef struct macr_hyper {
  *
  * d must be 32, 64, 128 or 256.  B >= 1.  No host synchronisation; safe to
  * capture into a hipGraph.
+ *
+ * flags = 0: the call is one complete step (P, Q, w, wu and the slots are up to
+ * date in stream order when it returns).
+ * Deferred mode (rubibceboth only): the step's pass over ALL rows of P and Q
+ * (tf.train.AdamOptimizer moves every row every step) is bound by HBM, the
+ * (B,B) loss kernel by the VALU; neither depends on the other across a step
+ * boundary, so consecutive steps can overlap them:
+ *   MACR_STEP_DEFER    leave this step's dense Adam pass pending.  On return the
+ *                      losses are final, the gradient sums are in gP/gQ (flags
+ *                      in touchedP/Q) and lr_t / the branch-vector partials are
+ *                      in the workspace; P, Q, w, wu and the slots still hold
+ *                      the previous values.
+ *   MACR_STEP_PENDING  the previous call on these buffers used MACR_STEP_DEFER:
+ *                      this call first completes that update for the rows its
+ *                      own batch reads (and for w, wu), then runs the rest of the
+ *                      pending pass as extra blocks of its (B,B) launch.  Needs
+ *                      the same B, d, gP/gQ/touched buffers and the same,
+ *                      unmodified workspace as the deferring call.
+ * macr_mf_train_flush completes a pending pass on its own (before evaluation,
+ * checkpointing, a change of B, or the end of training).  The arithmetic of every
+ * row is identical in both modes; only the order of independent rows changes.
  * -------------------------------------------------------------------------*/
+#define MACR_STEP_DEFER   1
+#define MACR_STEP_PENDING 2
+
 size_t macr_mf_train_workspace_bytes(int B, int d);
 
 int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items,
@@ -106,7 +130,14 @@ int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items,
                        float *mw, float *vw, float *mwu, float *vwu,
                        float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
                        float *adam_pow, const macr_hyper *hp,
-                       float *losses, void *workspace, size_t workspace_bytes, void *stream);
+                       float *losses, int flags, void *workspace, size_t workspace_bytes, void *stream);
+
+int macr_mf_train_flush(int B, int d, int n_users, int n_items,
+                        float *P, float *Q, float *w, float *wu,
+                        float *mP, float *vP, float *mQ, float *vQ,
+                        float *mw, float *vw, float *mwu, float *vwu,
+                        float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                        const macr_hyper *hp, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Device-side sampler of (user, positive, negative) triples (new).

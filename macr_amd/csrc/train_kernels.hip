@@ -45,6 +45,153 @@ struct RowGroup {
 };
 
 // ----------------------------------------------------------------------------
+// adam_dense: tf.train.AdamOptimizer as TF 1.14 applies it to embedding tables
+// (macr_mf/model.py:74,:95; SURVEY.md A.2): EVERY row decays m,v and moves every
+// step; rows touched by the batch additionally consume their summed gradient.
+//   m=b1*m+(1-b1)g; v=b2*v+(1-b2)g^2; theta-=lr_t*m/(sqrt(v)+eps)
+// Streaming pass, float4 per lane: 24*d bytes per row (read+write theta,m,v) plus a
+// 4-byte row flag; the gradient row is read (and re-zeroed) only when flagged.
+// The same block routine serves the stand-alone kernel and the Adam blocks that ride in
+// the bxb launch (deferred mode).  Branch vectors (one row each) take their gradient from
+// the kBranchSlots partial rows pair_bwd adds into, and leave them zero.
+// ----------------------------------------------------------------------------
+struct AdamSeg {
+    float *theta, *m, *v, *g;
+    int n_parts;             // > 0: g holds n_parts partial rows (stride part_stride floats) to be summed
+    int part_stride;
+    int32_t *touched;        // NULL: gradient is dense, always read, left untouched
+    long long n_vec;         // number of float4 in the segment
+    long long first_block;   // first block index serving this segment
+};
+struct AdamArgs {
+    AdamSeg seg[4];
+    int n_seg;
+    int lpr;                 // float4 per row
+    float b1, b2, eps;
+};
+struct LossArgs {
+    const float *part; int n_part;       // pair-kernel partials  [n_part][4]
+    const float *part2; int n_part2;     // second partial set (LightGCN ego regulariser), slot 0 only
+    const float *lpart; int n_lpart;     // bxb loss partials
+    int kind, B, batch_size_cfg;
+    float alpha, beta, decay;
+    float *losses;
+};
+
+constexpr int kAdamVecPerBlock = 256 * 4;   // each thread handles 4 float4 per segment pass
+constexpr int kBranchSlots = 8;             // partial rows of the branch-vector gradients (pair_bwd adds, Adam consumes)
+
+__device__ __forceinline__ void adam4(float4 &th, float4 &m, float4 &v, const float4 gr, float lr_t, float b1,
+                                      float b2, float eps) {
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    m.x = m.x * b1 + gr.x * omb1; m.y = m.y * b1 + gr.y * omb1; m.z = m.z * b1 + gr.z * omb1; m.w = m.w * b1 + gr.w * omb1;
+    v.x = v.x * b2 + (gr.x * gr.x) * omb2; v.y = v.y * b2 + (gr.y * gr.y) * omb2;
+    v.z = v.z * b2 + (gr.z * gr.z) * omb2; v.w = v.w * b2 + (gr.w * gr.w) * omb2;
+    th.x -= (lr_t * m.x) / (sqrtf(v.x) + eps); th.y -= (lr_t * m.y) / (sqrtf(v.y) + eps);
+    th.z -= (lr_t * m.z) / (sqrtf(v.z) + eps); th.w -= (lr_t * m.w) / (sqrtf(v.w) + eps);
+}
+
+// One block's share of the pass: block `blk` of the segment list.  s_red (256 float4) is only used by
+// partial-row segments (PARTS).
+template <bool PARTS>
+__device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, float lr_t, float4 *s_red) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < a.n_seg && blk >= a.seg[k].first_block) s = k;
+    const AdamSeg sg = a.seg[s];
+    const long long base = (blk - sg.first_block) * kAdamVecPerBlock + threadIdx.x;
+    float4 gsum = make_float4(0, 0, 0, 0);
+    if (PARTS && sg.n_parts > 0) {
+        // branch-vector segment (one row): the whole block sums the per-block partial rows of pair_bwd
+        const int sub = threadIdx.x % a.lpr, grp = threadIdx.x / a.lpr, ngrp = 256 / a.lpr;
+        for (int k = grp; k < sg.n_parts; k += ngrp) {
+            gsum = add4(gsum, ld4(sg.g + (size_t)k * sg.part_stride + 4 * sub));
+            st4(sg.g + (size_t)k * sg.part_stride + 4 * sub, make_float4(0, 0, 0, 0));
+        }
+        s_red[threadIdx.x] = gsum;
+        __syncthreads();
+        gsum = make_float4(0, 0, 0, 0);
+        if (threadIdx.x < a.lpr)
+            for (int k = 0; k < ngrp; ++k) gsum = add4(gsum, s_red[k * a.lpr + threadIdx.x]);
+    }
+    if (PARTS && sg.n_parts > 0) {
+        if (base < sg.n_vec) {
+            float4 th = ld4(sg.theta + base * 4), m = ld4(sg.m + base * 4), v = ld4(sg.v + base * 4);
+            adam4(th, m, v, gsum, lr_t, a.b1, a.b2, a.eps);
+            st4(sg.theta + base * 4, th); st4(sg.m + base * 4, m); st4(sg.v + base * 4, v);
+        }
+        return;
+    }
+    // Table segment.  All of a thread's loads are issued before anything is consumed (12 float4 + 4 flags in
+    // flight per lane): the pass is bound by memory-level parallelism, not by its arithmetic.
+    float4 th[4], m[4], v[4];
+    int flag[4];
+    long long vi[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        vi[it] = base + (long long)it * 256;
+        flag[it] = 0;
+        if (vi[it] < sg.n_vec) {
+            flag[it] = sg.touched ? sg.touched[vi[it] / a.lpr] : (sg.g != nullptr);
+            th[it] = ld4(sg.theta + vi[it] * 4); m[it] = ld4(sg.m + vi[it] * 4); v[it] = ld4(sg.v + vi[it] * 4);
+        }
+    }
+    float4 gr[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        gr[it] = make_float4(0, 0, 0, 0);
+        if (flag[it]) {                      // implies vi < n_vec
+            gr[it] = ld4(sg.g + vi[it] * 4);
+            if (sg.touched) {                // consume: gradient row and flag back to zero
+                st4(sg.g + vi[it] * 4, make_float4(0, 0, 0, 0));
+                if (vi[it] % a.lpr == 0) sg.touched[vi[it] / a.lpr] = 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (vi[it] < sg.n_vec) {
+            adam4(th[it], m[it], v[it], gr[it], lr_t, a.b1, a.b2, a.eps);
+            st4(sg.theta + vi[it] * 4, th[it]); st4(sg.m + vi[it] * 4, m[it]); st4(sg.v + vi[it] * 4, v[it]);
+        }
+    }
+}
+
+// deterministic reduction of the step's loss partials (double) by the calling wave -> losses[3]
+__device__ __forceinline__ void finalize_losses(const LossArgs &L, int lane) {
+    double sq = 0, li = 0, lu = 0, bce = 0, lo = 0;
+    for (int k = lane; k < L.n_part; k += 64) {
+        const float *o = L.part + (size_t)k * kPartStride;
+        sq += o[0]; li += o[1]; lu += o[2]; bce += o[3];
+    }
+    for (int k = lane; k < L.n_part2; k += 64) sq += L.part2[(size_t)k * kPartStride];
+    for (int k = lane; k < L.n_lpart; k += 64) lo += L.lpart[k];
+    sq = wave_sum_d(sq); li = wave_sum_d(li); lu = wave_sum_d(lu); bce = wave_sum_d(bce); lo = wave_sum_d(lo);
+    if (lane == 0) {
+        const double Bd = (double)L.B;
+        float mf;
+        if (L.kind == MACR_LOSS_NORMALBCE) {
+            mf = (float)(bce / Bd);
+        } else {
+            const float Lo = (float)(lo / (Bd * Bd)), Li = (float)(li / Bd), Lu = (float)(lu / Bd);
+            mf = Lo + L.alpha * Li + L.beta * Lu;               // macr_mf/model.py:217
+        }
+        float regularizer = (float)(0.5 * sq);                  // tf.nn.l2_loss x3  (:219)
+        regularizer = regularizer / (float)L.batch_size_cfg;    // (:220)
+        const float reg = L.decay * regularizer;                // (:221)
+        L.losses[0] = mf + reg; L.losses[1] = mf; L.losses[2] = reg;
+    }
+}
+
+// Block 0 also reduces the loss partials of the step into losses[3] (when L.losses is set).
+__global__ __launch_bounds__(256) void k_adam_dense(AdamArgs a, const StepScalars *scal, LossArgs L) {
+    __shared__ float4 s_red[256];
+    adam_block<true>(a, blockIdx.x, scal->lr_t, s_red);
+    if (blockIdx.x == 0 && L.losses && threadIdx.x < 64) finalize_losses(L, threadIdx.x);
+}
+
+// ----------------------------------------------------------------------------
 // pair_fwd: gathers + per-pair dots + branch logits.
 //   eu=Usrc[u], ei=Isrc[i], ej=Isrc[j]                    macr_mf/model.py:35-37
 //   p=sum(eu*ei), n=sum(eu*ej)                            :186-187
@@ -53,30 +200,64 @@ struct RowGroup {
 //   partials: l2 regulariser sum (:219), L_item (:213), L_user (:215) terms
 // fwd layout: 7 arrays of Bp floats: p, n, a, b, sig_si, sig_sj, sig_su  (Bp = padded B).
 // ----------------------------------------------------------------------------
-template <int LPR>
+// Tables the deferred-mode forward needs to see one update ahead (below).
+struct PendingAdam {
+    const float *mU, *vU, *gU, *mI, *vI, *gI;      // slots and gradient sums of the user / item table
+    const int32_t *tU, *tI;                          // row flags: gradient present
+    const float *mw, *vw, *mwu, *vwu;                // slots of the branch vectors
+    const StepScalars *scal;
+    float b1, b2, eps;
+};
+
+// PENDING (deferred mode): the previous step's Adam update has not been applied yet -- it is applied to ALL rows
+// by the Adam blocks riding in this step's bxb launch.  The forward needs the updated rows now, so every lane
+// computes theta' = adam(theta, m, v, g) for the float4 it gathers (and for w, w_user) in registers, with exactly
+// the arithmetic the pass will use, and writes nothing back: 3x more bytes gathered per row, no atomics, no
+// ordering between references to the same row, no extra launch.
+template <int LPR, bool PENDING>
 __global__ __launch_bounds__(256) void k_pair_fwd(
     int B, int Bp, const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
     const float *__restrict__ Usrc, const float *__restrict__ Isrc,
     const float *__restrict__ w, const float *__restrict__ wu,
-    float *__restrict__ fwd, float *__restrict__ part, int reg_on_gathered,
-    const float *__restrict__ adam_pow_in, float *adam_pow_out, StepScalars *scal, float lr, float b1, float b2) {
+    float *__restrict__ fwd, float *__restrict__ part, int reg_on_gathered, float *__restrict__ gw, PendingAdam pa) {
     constexpr int d = 4 * LPR;
     __shared__ float red[16];
     RowGroup<LPR> g;
     const int t = blockIdx.x * RowGroup<LPR>::kRowsPerBlock + g.slot;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // Adam bias correction for this step, then advance TF's fp32 beta powers.
-        const float p1 = adam_pow_in[0], p2 = adam_pow_in[1];
-        scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
-        adam_pow_out[0] = p1 * b1;
-        adam_pow_out[1] = p2 * b2;
-    }
     float sq = 0.f, litem = 0.f, luser = 0.f;
+    if (!PENDING && blockIdx.x == 0) {
+        // nothing reads the branch-vector partial rows before this step's pair_bwd adds into them
+        for (int k = threadIdx.x; k < kBranchSlots * 2 * d; k += 256) gw[k] = 0.f;
+    }
     if (t < B) {
-        const float4 eu = ld4(Usrc + (size_t)u[t] * d + 4 * g.sub);
-        const float4 ei = ld4(Isrc + (size_t)i[t] * d + 4 * g.sub);
-        const float4 ej = ld4(Isrc + (size_t)j[t] * d + 4 * g.sub);
-        const float4 w4 = ld4(w + 4 * g.sub), wu4 = ld4(wu + 4 * g.sub);
+        const int ru = u[t], ri = i[t], rj = j[t];
+        float4 eu = ld4(Usrc + (size_t)ru * d + 4 * g.sub);
+        float4 ei = ld4(Isrc + (size_t)ri * d + 4 * g.sub);
+        float4 ej = ld4(Isrc + (size_t)rj * d + 4 * g.sub);
+        float4 w4 = ld4(w + 4 * g.sub), wu4 = ld4(wu + 4 * g.sub);
+        if (PENDING) {
+            const float lr_t = pa.scal->lr_t;
+            const float4 zero = make_float4(0, 0, 0, 0);
+            const size_t au = (size_t)ru * d + 4 * g.sub, ai = (size_t)ri * d + 4 * g.sub, aj = (size_t)rj * d + 4 * g.sub;
+            float4 mu = ld4(pa.mU + au), vu = ld4(pa.vU + au), mi = ld4(pa.mI + ai), vi = ld4(pa.vI + ai);
+            float4 mj = ld4(pa.mI + aj), vj = ld4(pa.vI + aj);
+            const float4 gu = pa.tU[ru] ? ld4(pa.gU + au) : zero;
+            const float4 gi = pa.tI[ri] ? ld4(pa.gI + ai) : zero;
+            const float4 gj = pa.tI[rj] ? ld4(pa.gI + aj) : zero;
+            float4 gw4 = zero, gwu4 = zero;
+#pragma unroll
+            for (int k = 0; k < kBranchSlots; ++k) {
+                gw4 = add4(gw4, ld4(gw + (size_t)k * 2 * d + 4 * g.sub));
+                gwu4 = add4(gwu4, ld4(gw + (size_t)k * 2 * d + d + 4 * g.sub));
+            }
+            float4 mw4 = ld4(pa.mw + 4 * g.sub), vw4 = ld4(pa.vw + 4 * g.sub);
+            float4 mwu4 = ld4(pa.mwu + 4 * g.sub), vwu4 = ld4(pa.vwu + 4 * g.sub);
+            adam4(eu, mu, vu, gu, lr_t, pa.b1, pa.b2, pa.eps);
+            adam4(ei, mi, vi, gi, lr_t, pa.b1, pa.b2, pa.eps);
+            adam4(ej, mj, vj, gj, lr_t, pa.b1, pa.b2, pa.eps);
+            adam4(w4, mw4, vw4, gw4, lr_t, pa.b1, pa.b2, pa.eps);
+            adam4(wu4, mwu4, vwu4, gwu4, lr_t, pa.b1, pa.b2, pa.eps);
+        }
         const float p = group_sum<LPR>(dot4(eu, ei));
         const float n = group_sum<LPR>(dot4(eu, ej));
         const float si = group_sum<LPR>(dot4(ei, w4));
@@ -131,14 +312,28 @@ __device__ __forceinline__ float wave_rol1(float v) {      // lane i <- lane (i+
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int R, bool FULL>
-__global__ __launch_bounds__(256) void k_bxb(int B, int Bp, const float *__restrict__ fwd,
+// ADAM (deferred mode): blocks [nbxb, gridDim.x) of the launch are Adam blocks completing the PREVIOUS step's
+// dense pass (they touch only theta/m/v/g, never the bxb inputs): the bxb blocks are resident for the whole
+// launch and bound by the transcendental rate, the Adam blocks stream through the remaining wave slots and are
+// bound by HBM, so the two costs overlap instead of adding.
+template <int R, bool FULL, bool ADAM>
+__global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, const float *__restrict__ fwd,
                                              float *__restrict__ rowpart, float *__restrict__ colpart,
-                                             float *__restrict__ lpart) {
+                                             float *__restrict__ lpart, AdamArgs adam, const StepScalars *scal) {
     constexpr int RB = 64 * R;                 // rows per block
     __shared__ float s_row[4][2][RB];
     __shared__ float red[16];
-    const int cb = blockIdx.x, rb = blockIdx.y, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    __shared__ float4 s_red[ADAM ? 256 : 1];
+    const bool is_adam = ADAM && (int)blockIdx.x >= nbxb;
+    const int ablk = blockIdx.x - nbxb, bblk = blockIdx.x;
+    if (is_adam) {
+        // the bxb waves are older and would win every issue slot: the Adam waves (a handful of VALU instructions
+        // between long memory waits) go first whenever they are ready
+        __builtin_amdgcn_s_setprio(3);
+        adam_block<true>(adam, (long long)ablk, scal->lr_t, s_red);
+        return;
+    }
+    const int cb = bblk % ncb, rb = bblk / ncb, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const float *p = fwd, *n = fwd + Bp, *a = fwd + 2 * (size_t)Bp, *b = fwd + 3 * (size_t)Bp;
     const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
     const v2f one = {1.0f, 1.0f}, eps = {1e-10f, 1e-10f};
@@ -166,12 +361,24 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, const float *__restr
             const v2f dd = v2f{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + one;
             const v2f s = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};   // sigmoid(x), sigmoid(y)
             const v2f om = one - s;
+#ifdef MACR_ABL_BXB_8TRANS
             const v2f tt = v2f{s.x, om.y} + eps;                              // sig(x)+eps, (1-sig(y))+eps
             v2f lg = {__builtin_amdgcn_logf(tt.x), __builtin_amdgcn_logf(tt.y)};
             const v2f rt = {__builtin_amdgcn_rcpf(tt.x), __builtin_amdgcn_rcpf(tt.y)};
+            v2f g = (s * om) * rt;
+#else
+            // tx = sig(x)+eps, ty = (1-sig(y))+eps.  Only log(tx)+log(ty) and the two reciprocals are needed: ONE
+            // logarithm and ONE reciprocal of the product tx*ty (>= 1e-20, no underflow) serve both halves:
+            // 1/tx = ty/(tx*ty).  Six transcendentals per pair instead of eight.
+            const v2f ts = s + eps, tom = om + eps;                           // .x of ts and .y of tom are used
+            const float txy = ts.x * tom.y;
+            v2f lg = {__builtin_amdgcn_logf(txy), 0.f};
+            const float r2 = __builtin_amdgcn_rcpf(txy);
+            const v2f h = (s * om) * r2;
+            v2f g = {h.x * tom.y, h.y * ts.x};
+#endif
             // g = {-f'(x), g'(y)}: f'(x) = -s(1-s)/(s+eps), g'(y) = s(1-s)/((1-s)+eps); the sign of the x half is
             // applied once, after the loops
-            v2f g = (s * om) * rt;
             if (!FULL) {
                 const bool ok = rok[q] && colok;
                 lg = ok ? lg : v2f{0.f, 0.f};
@@ -193,7 +400,7 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, const float *__restr
         s_row[wid][1][q * 64 + lane] = dab[q].y;
     }
     const float lsum = block_sum(-(l2.x + l2.y) * kLn2, red);   // contains the barrier that publishes s_row
-    if (t == 0) lpart[(size_t)rb * gridDim.x + cb] = lsum;
+    if (t == 0) lpart[(size_t)rb * ncb + cb] = lsum;
     for (int e = t; e < 2 * RB; e += 256) {
         const int q = e / RB, rr = e % RB, r = rb * RB + rr;
         if (FULL || r < B)
@@ -224,7 +431,8 @@ struct WaveRow {
 //   dsi=da*sig'(si)*sig(su)+(alpha/B)f'(si) ...  deu=dp*ei+dn*ej+dsu*wu+coef*eu ...
 //   gU[u]+=deu, gI[i]+=dei, gI[j]+=dej  (duplicates summed = TF IndexedSlices
 //   de-duplication before the sparse apply, macr_mf/model.py:74)
-//   wpart[block] = sum over the block's triples of {ei*dsi+ej*dsj, eu*dsu}
+//   wpart[block % kBranchSlots] += sum over the block's triples of {ei*dsi+ej*dsj, eu*dsu}
+//   (a few partial rows instead of one: 32 blocks per slot add without queueing on one line)
 // One wave per triple (grid-strided); lane k owns element k of every row.
 // ----------------------------------------------------------------------------
 template <int D>
@@ -234,11 +442,26 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     const float *__restrict__ w, const float *__restrict__ wu, const float *__restrict__ fwd,
     const float *__restrict__ rowpart, const float *__restrict__ colpart,
     float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *__restrict__ wpart,
-    float alpha, float beta, float coef) {
+    float alpha, float beta, float coef, float *adam_pow, StepScalars *scal, float lr, float b1, float b2,
+    LossArgs L) {
     constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float s_w[4][2][D];
     __shared__ float s_gi[kChunkT][D];
     __shared__ int s_pos[kChunkT];
+    const int nblk = gridDim.x - 1;
+    if ((int)blockIdx.x == nblk) {
+        // Step bookkeeping, by one wave of an extra block.  Every Adam pass of the PREVIOUS update has completed
+        // before this kernel starts and every pass of THIS update starts after it ends, so this is where lr_t may
+        // change: Adam bias correction for this step, then advance TF's fp32 beta powers.
+        if (threadIdx.x == 0) {
+            const float p1 = adam_pow[0], p2 = adam_pow[1];
+            scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
+            adam_pow[0] = p1 * b1;
+            adam_pow[1] = p2 * b2;
+        }
+        if (L.losses && threadIdx.x < 64) finalize_losses(L, threadIdx.x);   // deferred mode: no adam_dense launch to do it
+        return;
+    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bool act = lane < WaveRow<D>::kActive;
     float wk[EPL], wuk[EPL], aw[EPL], awu[EPL];
@@ -253,7 +476,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     // items are then adjacent, and the block adds each RUN of equal rows once (LDS segmented sum) instead of once
     // per triple -- the hottest item of a Zipf batch costs (#blocks it spans) serialised atomics, not (#references).
     // Unsorted batches stay correct (runs of length one).
-    for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += gridDim.x) {
+    for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += nblk) {
 #pragma unroll 1
         for (int q = 0; q < kChunkT / 4; ++q) {
             const int slot = wid * (kChunkT / 4) + q;
@@ -320,7 +543,8 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * D; k += 256) {
         const int q = k / D, kk = k % D;
-        wpart[(size_t)blockIdx.x * 2 * D + k] = (s_w[0][q][kk] + s_w[1][q][kk]) + (s_w[2][q][kk] + s_w[3][q][kk]);
+        MACR_ATOMIC_ADD(wpart + (size_t)(blockIdx.x % kBranchSlots) * 2 * D + k,
+                        (s_w[0][q][kk] + s_w[1][q][kk]) + (s_w[2][q][kk] + s_w[3][q][kk]));
     }
 }
 
@@ -443,116 +667,6 @@ __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const 
     if (threadIdx.x == 0) part[(size_t)blockIdx.x * kPartStride] = s0;    // slot 0 only
 }
 
-// ----------------------------------------------------------------------------
-// adam_dense: tf.train.AdamOptimizer as TF 1.14 applies it to embedding tables
-// (macr_mf/model.py:74,:95; SURVEY.md A.2): EVERY row decays m,v and moves every
-// step; rows touched by the batch additionally consume their summed gradient.
-//   m=b1*m+(1-b1)g; v=b2*v+(1-b2)g^2; theta-=lr_t*m/(sqrt(v)+eps)
-// Streaming kernel, float4 per lane: 24*d bytes per row (read+write theta,m,v) plus a
-// 4-byte touched flag; the gradient row is read (and re-zeroed) only when flagged.
-// Block 0 also reduces the loss partials of the step into losses[3].
-// ----------------------------------------------------------------------------
-struct AdamSeg {
-    float *theta, *m, *v, *g;
-    int n_parts;             // > 0: g holds n_parts partial rows (stride part_stride floats) to be summed
-    int part_stride;
-    int32_t *touched;        // NULL: gradient is dense, always read, left untouched
-    long long n_vec;         // number of float4 in the segment
-    long long first_block;   // first block index serving this segment
-};
-struct AdamArgs {
-    AdamSeg seg[4];
-    int n_seg;
-    int lpr;                 // float4 per row
-};
-struct LossArgs {
-    const float *part; int n_part;       // pair-kernel partials  [n_part][4]
-    const float *part2; int n_part2;     // second partial set (LightGCN ego regulariser), slot 0 only
-    const float *lpart; int n_lpart;     // bxb loss partials
-    int kind, B, batch_size_cfg;
-    float alpha, beta, decay;
-    float *losses;
-};
-
-constexpr int kAdamVecPerBlock = 256 * 4;   // each thread handles 4 float4 per segment pass
-
-__global__ __launch_bounds__(256) void k_adam_dense(AdamArgs a, const StepScalars *scal, float b1, float b2,
-                                                    float eps, LossArgs L) {
-    const float lr_t = scal->lr_t;
-    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-    int s = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-        if (k < a.n_seg && (long long)blockIdx.x >= a.seg[k].first_block) s = k;
-    const AdamSeg sg = a.seg[s];
-    const long long base = ((long long)blockIdx.x - sg.first_block) * kAdamVecPerBlock + threadIdx.x;
-    __shared__ float4 s_red[256];
-    float4 gsum = make_float4(0, 0, 0, 0);
-    if (sg.n_parts > 0) {
-        // branch-vector segment (one row): the whole block sums the per-block partial rows of pair_bwd
-        const int sub = threadIdx.x % a.lpr, grp = threadIdx.x / a.lpr, ngrp = 256 / a.lpr;
-        for (int k = grp; k < sg.n_parts; k += ngrp) gsum = add4(gsum, ld4(sg.g + (size_t)k * sg.part_stride + 4 * sub));
-        s_red[threadIdx.x] = gsum;
-        __syncthreads();
-        gsum = make_float4(0, 0, 0, 0);
-        if (threadIdx.x < a.lpr)
-            for (int k = 0; k < ngrp; ++k) gsum = add4(gsum, s_red[k * a.lpr + threadIdx.x]);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const long long vi = base + (long long)it * 256;
-        if (vi < sg.n_vec) {
-            float4 th = ld4(sg.theta + vi * 4), m = ld4(sg.m + vi * 4), v = ld4(sg.v + vi * 4);
-            float4 gr = make_float4(0, 0, 0, 0);
-            if (sg.n_parts > 0) {
-                gr = gsum;
-            } else if (sg.touched) {
-                const long long row = vi / a.lpr;
-                if (sg.touched[row]) {
-                    gr = ld4(sg.g + vi * 4);
-                    st4(sg.g + vi * 4, make_float4(0, 0, 0, 0));
-                    if (vi % a.lpr == 0) sg.touched[row] = 0;
-                }
-            } else if (sg.g) {
-                gr = ld4(sg.g + vi * 4);
-            }
-            m.x = m.x * b1 + gr.x * omb1; m.y = m.y * b1 + gr.y * omb1; m.z = m.z * b1 + gr.z * omb1; m.w = m.w * b1 + gr.w * omb1;
-            v.x = v.x * b2 + (gr.x * gr.x) * omb2; v.y = v.y * b2 + (gr.y * gr.y) * omb2;
-            v.z = v.z * b2 + (gr.z * gr.z) * omb2; v.w = v.w * b2 + (gr.w * gr.w) * omb2;
-            th.x -= (lr_t * m.x) / (sqrtf(v.x) + eps); th.y -= (lr_t * m.y) / (sqrtf(v.y) + eps);
-            th.z -= (lr_t * m.z) / (sqrtf(v.z) + eps); th.w -= (lr_t * m.w) / (sqrtf(v.w) + eps);
-            st4(sg.theta + vi * 4, th); st4(sg.m + vi * 4, m); st4(sg.v + vi * 4, v);
-        }
-    }
-    if (blockIdx.x == 0 && L.losses) {
-        // deterministic reduction of the step's loss partials (double), one wave
-        if (threadIdx.x < 64) {
-            double sq = 0, li = 0, lu = 0, bce = 0, lo = 0;
-            for (int k = threadIdx.x; k < L.n_part; k += 64) {
-                const float *o = L.part + (size_t)k * kPartStride;
-                sq += o[0]; li += o[1]; lu += o[2]; bce += o[3];
-            }
-            for (int k = threadIdx.x; k < L.n_part2; k += 64) sq += L.part2[(size_t)k * kPartStride];
-            for (int k = threadIdx.x; k < L.n_lpart; k += 64) lo += L.lpart[k];
-            sq = wave_sum_d(sq); li = wave_sum_d(li); lu = wave_sum_d(lu); bce = wave_sum_d(bce); lo = wave_sum_d(lo);
-            if (threadIdx.x == 0) {
-                const double Bd = (double)L.B;
-                float mf;
-                if (L.kind == MACR_LOSS_NORMALBCE) {
-                    mf = (float)(bce / Bd);
-                } else {
-                    const float Lo = (float)(lo / (Bd * Bd)), Li = (float)(li / Bd), Lu = (float)(lu / Bd);
-                    mf = Lo + L.alpha * Li + L.beta * Lu;               // macr_mf/model.py:217
-                }
-                float regularizer = (float)(0.5 * sq);                  // tf.nn.l2_loss x3  (:219)
-                regularizer = regularizer / (float)L.batch_size_cfg;    // (:220)
-                const float reg = L.decay * regularizer;                // (:221)
-                L.losses[0] = mf + reg; L.losses[1] = mf; L.losses[2] = reg;
-            }
-        }
-    }
-}
-
 }  // namespace macr
 
 // ============================================================================
@@ -584,7 +698,7 @@ static inline int bxb_rows(int B) {
 
 struct PairWs {
     StepScalars *scal;
-    float *gw;          // [nblk_bwd][2*d] per-block partial rows of the branch-vector gradients
+    float *gw;          // [kBranchSlots][2*d] partial rows of the branch-vector gradients
     int nblk_bwd;
     float *fwd;         // [7*Bp]
     float *part;        // [nblk_pair*4]
@@ -609,7 +723,7 @@ static PairWs carve_pair_ws(void *base, int B, int d) {
     size_t off = 0;
     auto take = [&](size_t bytes) { void *r = p ? p + off : nullptr; off += align_up(bytes, 256); return r; };
     w.scal = static_cast<StepScalars *>(take(sizeof(StepScalars)));
-    w.gw = static_cast<float *>(take((size_t)w.nblk_bwd * 2 * d * 4));
+    w.gw = static_cast<float *>(take((size_t)kBranchSlots * 2 * d * 4));
     w.fwd = static_cast<float *>(take((size_t)7 * w.Bp * 4));
     const int npart = w.nblk_pair > w.nblk_bwd ? w.nblk_pair : w.nblk_bwd;
     w.part = static_cast<float *>(take((size_t)npart * kPartStride * 4));
@@ -622,17 +736,28 @@ static PairWs carve_pair_ws(void *base, int B, int d) {
 }
 
 template <int R>
-static void launch_bxb_rows(const PairWs &ws, int B, hipStream_t st) {
-    dim3 grid(ws.ncb, ws.nrb);
-    if (B % 256 == 0) k_bxb<R, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.fwd, ws.rowpart, ws.colpart, ws.lpart);
-    else              k_bxb<R, false><<<grid, 256, 0, st>>>(B, ws.Bp, ws.fwd, ws.rowpart, ws.colpart, ws.lpart);
+static void launch_bxb_rows(const PairWs &ws, int B, const AdamArgs *pending, long long n_adam_blocks, hipStream_t st) {
+    const int nbxb = ws.ncb * ws.nrb;
+    const bool full = B % 256 == 0;
+    if (pending) {
+        const unsigned grid = (unsigned)(nbxb + n_adam_blocks);
+        if (full) k_bxb<R, true, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal);
+        else      k_bxb<R, false, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal);
+    } else {
+        AdamArgs none;
+        none.n_seg = 0;
+        if (full) k_bxb<R, true, false><<<nbxb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal);
+        else      k_bxb<R, false, false><<<nbxb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal);
+    }
 }
 
 // forward + (B,B) + backward of the pair loss; gradients are atomically added into gU/gI.
 static int launch_pair(int kind, int B, int d, const int32_t *u, const int32_t *i, const int32_t *j,
                        const float *Usrc, const float *Isrc, const float *w, const float *wu,
                        float *gU, float *gI, int32_t *tU, int32_t *tI, float coef, int reg_on_gathered,
-                       float *adam_pow, const macr_hyper *hp, const PairWs &ws, hipStream_t st) {
+                       float *adam_pow, const macr_hyper *hp, const PairWs &ws, hipStream_t st,
+                       const PendingAdam *pa = nullptr, const AdamArgs *pending = nullptr,
+                       long long n_pending_blocks = 0, const LossArgs *finalize = nullptr) {
     const int grid = ws.nblk_pair;
     if (kind == MACR_LOSS_NORMALBCE) {
         MACR_DISPATCH_D(d, (k_pair_normal<D><<<ws.nblk_bwd, 256, 0, st>>>(B, u, i, j, Usrc, Isrc, gU, gI, tU, tI, ws.part,
@@ -641,19 +766,27 @@ static int launch_pair(int kind, int B, int d, const int32_t *u, const int32_t *
         MACR_CHECK_LAUNCH("pair_normal", st);
         return MACR_OK;
     }
-    MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd, ws.part,
-                                                               reg_on_gathered, adam_pow, adam_pow, ws.scal, hp->lr,
-                                                               hp->beta1, hp->beta2)));
+    if (pa) {
+        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, true><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
+                                                                         ws.part, reg_on_gathered, ws.gw, *pa)));
+    } else {
+        PendingAdam none = {};
+        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, false><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
+                                                                          ws.part, reg_on_gathered, ws.gw, none)));
+    }
     MACR_CHECK_LAUNCH("pair_fwd", st);
     switch (ws.rows) {
-        case 1: launch_bxb_rows<1>(ws, B, st); break;
-        case 2: launch_bxb_rows<2>(ws, B, st); break;
-        default: launch_bxb_rows<4>(ws, B, st); break;
+        case 1: launch_bxb_rows<1>(ws, B, pending, n_pending_blocks, st); break;
+        case 2: launch_bxb_rows<2>(ws, B, pending, n_pending_blocks, st); break;
+        default: launch_bxb_rows<4>(ws, B, pending, n_pending_blocks, st); break;
     }
-    MACR_CHECK_LAUNCH("bxb", st);
-    MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu,
-                                                                  ws.fwd, ws.rowpart, ws.colpart, gU, gI, tU, tI, ws.gw,
-                                                                  hp->alpha, hp->beta, coef)));
+    MACR_CHECK_LAUNCH(pending ? "bxb+adam" : "bxb", st);
+    LossArgs L;
+    if (finalize) L = *finalize; else L.losses = nullptr;
+    MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd + 1, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w,
+                                                                      wu, ws.fwd, ws.rowpart, ws.colpart, gU, gI, tU, tI,
+                                                                      ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal,
+                                                                      hp->lr, hp->beta1, hp->beta2, L)));
     MACR_CHECK_LAUNCH("pair_bwd", st);
     return MACR_OK;
 }
@@ -685,11 +818,33 @@ extern "C" size_t macr_mf_train_workspace_bytes(int B, int d) {
     return carve_pair_ws(nullptr, B, d).bytes;
 }
 
+namespace macr {
+// Adam segment lists of the MF model.  tables: P and Q (row-flag protocol); branch: w, w_user (partial rows of
+// pair_bwd), only for rubibceboth (model.py:74 vs :95).
+static void mf_adam_args(AdamArgs &a, long long &nb, bool tables, bool branch, int d, int n_users, int n_items,
+                         float *P, float *Q, float *w, float *wu, float *mP, float *vP, float *mQ, float *vQ,
+                         float *mw, float *vw, float *mwu, float *vwu, float *gP, float *gQ, int32_t *tP,
+                         int32_t *tQ, const macr_hyper *hp, const PairWs &ws) {
+    a.n_seg = 0;
+    a.lpr = d / 4;
+    a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
+    nb = 0;
+    if (tables) {
+        add_seg(a, P, mP, vP, gP, tP, n_users, nb);
+        add_seg(a, Q, mQ, vQ, gQ, tQ, n_items, nb);
+    }
+    if (branch) {
+        add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
+        add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
+    }
+}
+}  // namespace macr
+
 extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items, const int32_t *u,
                                   const int32_t *i, const int32_t *j, float *P, float *Q, float *w, float *wu,
                                   float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
                                   float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
-                                  float *adam_pow, const macr_hyper *hp, float *losses, void *workspace,
+                                  float *adam_pow, const macr_hyper *hp, float *losses, int flags, void *workspace,
                                   size_t workspace_bytes, void *stream) {
     MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || loss_kind == MACR_LOSS_RUBIBCEBOTH, MACR_E_INVALID,
                  "mf_train_step: loss_kind=%d", loss_kind);
@@ -700,6 +855,9 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
                      losses && workspace, MACR_E_INVALID, "mf_train_step: null pointer");
     MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || (w && wu && mw && vw && mwu && vwu), MACR_E_INVALID,
                  "mf_train_step: rubibceboth needs w, wu and their Adam slots");
+    MACR_REQUIRE((flags & ~(MACR_STEP_DEFER | MACR_STEP_PENDING)) == 0, MACR_E_INVALID, "mf_train_step: flags=%d", flags);
+    MACR_REQUIRE(!flags || loss_kind == MACR_LOSS_RUBIBCEBOTH, MACR_E_INVALID,
+                 "mf_train_step: deferred mode exists for rubibceboth only (flags=%d)", flags);
     if (int e = validate_hyper(hp, "mf_train_step")) return e;
     PairWs ws = carve_pair_ws(workspace, B, d);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "mf_train_step: workspace %zu < %zu bytes",
@@ -708,26 +866,58 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
                  "mf_train_step: workspace must be 256-byte aligned");
     hipStream_t st = as_stream(stream);
     const float coef = hp->decay / (float)hp->batch_size_cfg;       // d reg / d row  (model.py:219-221)
-    if (int e = launch_pair(loss_kind, B, d, u, i, j, P, Q, w, wu, gP, gQ, touchedP, touchedQ, coef, 1, adam_pow, hp,
-                            ws, st))
-        return e;
-    AdamArgs a;
-    a.n_seg = 0;
-    a.lpr = d / 4;
-    long long nb = 0;
-    add_seg(a, P, mP, vP, gP, touchedP, n_users, nb);
-    add_seg(a, Q, mQ, vQ, gQ, touchedQ, n_items, nb);
-    if (loss_kind == MACR_LOSS_RUBIBCEBOTH) {       // w, w_user receive gradients only here (model.py:74 vs :95)
-        add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, ws.nblk_bwd, 2 * d);
-        add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb, ws.nblk_bwd, 2 * d);
-    }
+    const bool rubi = loss_kind == MACR_LOSS_RUBIBCEBOTH;
     LossArgs L;
-    L.part = ws.part; L.n_part = loss_kind == MACR_LOSS_NORMALBCE ? ws.nblk_bwd : ws.nblk_pair;
+    L.part = ws.part; L.n_part = rubi ? ws.nblk_pair : ws.nblk_bwd;
     L.part2 = nullptr; L.n_part2 = 0;
-    L.lpart = ws.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.nrb * ws.ncb : 0;
+    L.lpart = ws.lpart; L.n_lpart = rubi ? ws.nrb * ws.ncb : 0;
     L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
     L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
-    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, hp->beta1, hp->beta2, hp->adam_eps, L);
+    AdamArgs a;
+    long long nb = 0;
+    const bool pending = flags & MACR_STEP_PENDING, defer = flags & MACR_STEP_DEFER;
+    PendingAdam pa = {};
+    if (pending) {
+        // the previous call left its dense pass pending: pair_fwd looks one update ahead, the pass itself (tables
+        // and branch vectors) rides in the bxb launch
+        pa.mU = mP; pa.vU = vP; pa.gU = gP; pa.mI = mQ; pa.vI = vQ; pa.gI = gQ; pa.tU = touchedP; pa.tI = touchedQ;
+        pa.mw = mw; pa.vw = vw; pa.mwu = mwu; pa.vwu = vwu; pa.scal = ws.scal;
+        pa.b1 = hp->beta1; pa.b2 = hp->beta2; pa.eps = hp->adam_eps;
+        mf_adam_args(a, nb, true, true, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
+                     touchedP, touchedQ, hp, ws);
+    }
+    if (int e = launch_pair(loss_kind, B, d, u, i, j, P, Q, w, wu, gP, gQ, touchedP, touchedQ, coef, 1, adam_pow, hp,
+                            ws, st, pending ? &pa : nullptr, pending ? &a : nullptr, nb, defer ? &L : nullptr))
+        return e;
+    if (defer) return MACR_OK;
+    mf_adam_args(a, nb, true, rubi, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
+                 touchedP, touchedQ, hp, ws);
+    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
+    MACR_CHECK_LAUNCH("adam_dense", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_mf_train_flush(int B, int d, int n_users, int n_items, float *P, float *Q, float *w, float *wu,
+                                   float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
+                                   float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                                   const macr_hyper *hp, void *workspace, size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(B > 0 && n_users > 0 && n_items > 0, MACR_E_INVALID, "mf_train_flush: B=%d n_users=%d n_items=%d", B,
+                 n_users, n_items);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "mf_train_flush: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(P && Q && w && wu && mP && vP && mQ && vQ && mw && vw && mwu && vwu && gP && gQ && touchedP &&
+                     touchedQ && workspace, MACR_E_INVALID, "mf_train_flush: null pointer");
+    if (int e = validate_hyper(hp, "mf_train_flush")) return e;
+    PairWs ws = carve_pair_ws(workspace, B, d);
+    MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "mf_train_flush: workspace %zu < %zu bytes",
+                 workspace_bytes, ws.bytes);
+    AdamArgs a;
+    long long nb = 0;
+    mf_adam_args(a, nb, true, true, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
+                 touchedP, touchedQ, hp, ws);
+    LossArgs L;
+    L.losses = nullptr;
+    hipStream_t st = as_stream(stream);
+    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;
 }
@@ -808,11 +998,12 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     AdamArgs a;
     a.n_seg = 0;
     a.lpr = d / 4;
+    a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
     long long nb = 0;
     add_seg(a, T, mT, vT, ws.G, nullptr, N, nb);
     if (loss_kind == MACR_LOSS_RUBIBCEBOTH) {
-        add_seg(a, w, mw, vw, ws.pair.gw, nullptr, 1, nb, ws.pair.nblk_bwd, 2 * d);
-        add_seg(a, wu, mwu, vwu, ws.pair.gw + d, nullptr, 1, nb, ws.pair.nblk_bwd, 2 * d);
+        add_seg(a, w, mw, vw, ws.pair.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
+        add_seg(a, wu, mwu, vwu, ws.pair.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
     }
     LossArgs L;
     L.part = ws.pair.part; L.n_part = loss_kind == MACR_LOSS_NORMALBCE ? ws.pair.nblk_bwd : ws.pair.nblk_pair;
@@ -820,7 +1011,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     L.lpart = ws.pair.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.pair.nrb * ws.pair.ncb : 0;
     L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
     L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
-    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.pair.scal, hp->beta1, hp->beta2, hp->adam_eps, L);
+    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.pair.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;
 }

@@ -134,10 +134,20 @@ class BPRMF(object):
         host = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
         return host.to(self.device, non_blocking=True)
 
-    def train_step(self, kind, batch, losses=None):
+    def train_step(self, kind, batch, losses=None, defer=False):
         """batch: (3,B) int32 device tensor.  Returns the (3,) device tensor {loss, mf_loss, reg_loss};
-        no host synchronisation."""
-        return self._opt[kind].step(kind, batch[0], batch[1], batch[2], losses)
+        no host synchronisation.  defer=True lets consecutive rubibceboth steps overlap the dense Adam pass of
+        one step with the (B,B) kernel of the next (MACR_STEP_DEFER); the parameters are then only up to date
+        after sync(), which every reader below calls."""
+        for k, st in self._opt.items():
+            if k != kind:
+                st.flush()
+        return self._opt[kind].step(kind, batch[0], batch[1], batch[2], losses, defer=defer)
+
+    def sync(self):
+        """Complete any pending parameter update (stream-ordered; no host synchronisation)."""
+        for st in self._opt.values():
+            st.flush()
 
     def opt_state(self, kind):
         return self._opt[kind]
@@ -152,6 +162,7 @@ class BPRMF(object):
 
     def ratings(self, kind, user_batch):
         """Dense (U,N) score matrix: the literal sess.run(model.batch_ratings|rubi_ratings_both)."""
+        self.sync()
         uid = torch.as_tensor(list(user_batch), dtype=torch.int32, device=self.device)
         sig_u = sig_i = None
         if kind == ops.SCORE_RUBI_BOTH:
@@ -160,6 +171,7 @@ class BPRMF(object):
         return ops.score_matrix(kind, self.user_embedding, uid, self.item_embedding, sig_u, sig_i, self.rubi_c)
 
     def state_dict(self):
+        self.sync()
         sd = {"user_embedding": self.user_embedding, "item_embedding": self.item_embedding, "w": self.w,
               "w_user": self.w_user, "rubi_c": self.rubi_c}
         for kind, st in self._opt.items():
@@ -168,6 +180,7 @@ class BPRMF(object):
         return sd
 
     def load_state_dict(self, sd):
+        self.sync()
         self.user_embedding.copy_(sd["user_embedding"]); self.item_embedding.copy_(sd["item_embedding"])
         self.w.copy_(sd["w"]); self.w_user.copy_(sd["w_user"]); self.rubi_c = float(sd["rubi_c"])
         for kind, st in self._opt.items():

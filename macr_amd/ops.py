@@ -246,28 +246,50 @@ class MFState(object):
         self.losses = torch.zeros(3, dtype=_f32, device=dev)
         self.batch_cap = 0
         self.ws = None
+        self.pending_B = 0
         self.reserve(batch_cap)
 
     def reserve(self, B):
         if B > self.batch_cap:
+            self.flush()                 # a pending pass keeps lr_t and partial rows in the old workspace
             nbytes = _lib.lib().macr_mf_train_workspace_bytes(B, self.d)
             if nbytes == 0:
                 raise MacrError(_lib.E_UNSUPPORTED, "embed_size %d not in {32,64,128,256}" % self.d)
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.P.device)
             self.batch_cap = B
 
-    def step(self, kind, u, i, j, losses=None):
-        """One training step; u,i,j int32 device tensors.  Returns the (3,) device loss tensor."""
+    def _tables(self):
+        return (_ptr(self.P), _ptr(self.Q), _ptr(self.w), _ptr(self.wu), _ptr(self.mP), _ptr(self.vP), _ptr(self.mQ),
+                _ptr(self.vQ), _ptr(self.mw), _ptr(self.vw), _ptr(self.mwu), _ptr(self.vwu), _ptr(self.gP),
+                _ptr(self.gQ), _ptr(self.tP), _ptr(self.tQ))
+
+    def step(self, kind, u, i, j, losses=None, defer=False):
+        """One training step; u,i,j int32 device tensors.  Returns the (3,) device loss tensor.
+        defer=True (rubibceboth): leave the dense Adam pass pending so that the next step runs it under its
+        (B,B) kernel (include/macr_hip.h, MACR_STEP_DEFER); call flush() before reading the parameters."""
         B = u.numel()
+        if self.pending_B and self.pending_B != B:
+            self.flush()
         self.reserve(B)
         out = self.losses if losses is None else losses
+        defer = bool(defer) and kind == LOSS_RUBIBCEBOTH
+        if self.pending_B and kind != LOSS_RUBIBCEBOTH:
+            self.flush()
+        flags = (_lib.STEP_DEFER if defer else 0) | (_lib.STEP_PENDING if self.pending_B else 0)
         check(_lib.lib().macr_mf_train_step(
             kind, B, self.d, self.P.shape[0], self.Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
-            _ptr(self.P), _ptr(self.Q), _ptr(self.w), _ptr(self.wu), _ptr(self.mP), _ptr(self.vP), _ptr(self.mQ),
-            _ptr(self.vQ), _ptr(self.mw), _ptr(self.vw), _ptr(self.mwu), _ptr(self.vwu), _ptr(self.gP),
-            _ptr(self.gQ), _ptr(self.tP), _ptr(self.tQ), _ptr(self.adam_pow), ctypes.byref(self.hyper),
-            _ptr(out, _f32), _ptr(self.ws), self.ws.numel(), _stream()))
+            *self._tables(), _ptr(self.adam_pow), ctypes.byref(self.hyper),
+            _ptr(out, _f32), flags, _ptr(self.ws), self.ws.numel(), _stream()))
+        self.pending_B = B if defer else 0
         return out
+
+    def flush(self):
+        """Complete a pending dense Adam pass (no-op when nothing is pending)."""
+        if self.pending_B:
+            check(_lib.lib().macr_mf_train_flush(
+                self.pending_B, self.d, self.P.shape[0], self.Q.shape[0], *self._tables(),
+                ctypes.byref(self.hyper), _ptr(self.ws), self.ws.numel(), _stream()))
+            self.pending_B = 0
 
 
 class LGCNState(object):

@@ -47,6 +47,7 @@ def test(sess, model, test_users, batch_test_flag=False, model_type='o', valid_s
         ev = _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
                                  torch.tensor(list(test_users), dtype=torch.int32, device=model.device))
     evaluator, uid = ev
+    model.sync()
     return evaluator.test_mf(_MODEL_TYPES[model_type], model.user_embedding, uid, model.item_embedding, Ks,
                              model.w, model.w_user, model.rubi_c)
 
@@ -78,7 +79,8 @@ def train_epoch(model, kind, n_batch, loss_log, device_sampler=None):
         else:
             users, pos_items, neg_items = data.sample()
             batch = model.to_device_batch(users, pos_items, neg_items)
-        model.train_step(kind, batch, loss_log[idx])
+        model.train_step(kind, batch, loss_log[idx], defer=True)    # the Adam pass rides under the next step
+    model.sync()
     per_step = loss_log[:n_batch].cpu().numpy()
     loss = mf_loss = reg_loss = 0.
     for row in per_step:                                     # same accumulation order as train.py:497-499

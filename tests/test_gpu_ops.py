@@ -85,6 +85,70 @@ def test_mf_train_step_matches_oracle(ops, kind, B, d, n_users, n_items):
         assert np.array_equal(state.w.cpu().numpy(), w) and np.array_equal(state.wu.cpu().numpy(), wu)
 
 
+@pytest.mark.parametrize("B,d,n_users,n_items,sort", [(96, 64, 300, 50, False), (257, 64, 300, 50, True),
+                                                      (1024, 64, 13485, 744, True), (64, 32, 100, 40, True),
+                                                      (128, 128, 500, 300, False), (64, 256, 100, 40, True),
+                                                      (4096, 64, 3000, 900, True)])
+def test_mf_deferred_adam_equals_complete_steps(ops, B, d, n_users, n_items, sort):
+    """MACR_STEP_DEFER / MACR_STEP_PENDING: the dense Adam pass of step t runs under the (B,B) kernel of step
+    t+1 (rows of batch t+1 first).  Losses per step follow the oracle to 1e-5; after flush the whole state equals
+    the state of complete (flags=0) steps -- same arithmetic per row, only float-atomic order differs."""
+    P, Q, w, wu, u, i, j = make_problem(B + d + 1, n_users, n_items, d, B)
+    alpha, beta, decay, lr, bs = 1e-2, 1e-3, 1e-5, 1e-3, 1024
+    kind = oracle.LOSS_RUBIBCEBOTH
+    st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
+    Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
+    hyper = ops.make_hyper(lr, decay, alpha, beta, bs)
+    lazy = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), hyper, B)
+    eager = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), hyper, B)
+    rs = np.random.RandomState(19)
+    for t in range(5):
+        if t:
+            u = rs.choice(n_users, B, replace=B > n_users).astype(np.int32)
+            i = rs.randint(0, n_items, B).astype(np.int32)
+            j = rs.randint(0, n_items, B).astype(np.int32)
+            if t == 2:
+                i[: B // 2] = 3                         # a different hot item
+        if sort:
+            o = np.argsort(i, kind="stable")
+            u, i, j = u[o], i[o], j[o]
+        want = oracle.mf_train_step(kind, u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, bs)
+        got = lazy.step(kind, dev(u), dev(i), dev(j), defer=True).cpu().numpy()
+        ref = eager.step(kind, dev(u), dev(i), dev(j)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+        np.testing.assert_allclose(got, ref, rtol=2e-6, atol=0)
+        assert lazy.pending_B == B
+    lazy.flush()
+    assert lazy.pending_B == 0
+    for name in ("P", "Q", "w", "wu", "mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu"):
+        a, b = getattr(lazy, name).cpu().numpy(), getattr(eager, name).cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-7 + 1e-5 * np.abs(b).max(), err_msg=name)
+    np.testing.assert_allclose(lazy.P.cpu().numpy(), Po, rtol=0, atol=0.02 * lr * 5)
+    np.testing.assert_allclose(lazy.Q.cpu().numpy(), Qo, rtol=0, atol=0.02 * lr * 5)
+    assert float(lazy.gP.abs().max()) == 0.0 and float(lazy.gQ.abs().max()) == 0.0
+    assert int(lazy.tP.sum()) == 0 and int(lazy.tQ.sum()) == 0
+    np.testing.assert_allclose(lazy.adam_pow.cpu().numpy(), st.power, rtol=1e-6)
+    np.testing.assert_array_equal(lazy.adam_pow.cpu().numpy(), eager.adam_pow.cpu().numpy())
+
+
+def test_mf_deferred_mode_flushes_on_batch_size_change(ops):
+    P, Q, w, wu, u, i, j = make_problem(5, 300, 50, 64, 200)
+    hyper = ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, 1024)
+    kind = oracle.LOSS_RUBIBCEBOTH
+    lazy = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), hyper, 64)
+    eager = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), hyper, 64)
+    for B in (64, 64, 200, 200, 96, 200):             # growth re-allocates the workspace; shrink changes its carving
+        a, b = lazy.step(kind, dev(u[:B]), dev(i[:B]), dev(j[:B]), defer=True), eager.step(kind, dev(u[:B]), dev(i[:B]), dev(j[:B]))
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6)
+    # normalbce has no (B,B) kernel to hide the pass under: a pending pass is completed first, nothing is left pending
+    lazy.step(oracle.LOSS_NORMALBCE, dev(u[:64]), dev(i[:64]), dev(j[:64]), defer=True)
+    eager.step(oracle.LOSS_NORMALBCE, dev(u[:64]), dev(i[:64]), dev(j[:64]))
+    assert lazy.pending_B == 0
+    for name in ("P", "Q", "w", "wu", "mP", "vP", "mQ", "vQ"):
+        a, b = getattr(lazy, name).cpu().numpy(), getattr(eager, name).cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-7 + 1e-5 * np.abs(b).max(), err_msg=name)
+
+
 def test_untouched_rows_follow_dense_adam(ops):
     """TF-1.14 Adam on embedding tables moves EVERY row (SURVEY.md finding 5)."""
     P, Q, w, wu, u, i, j = make_problem(1, 400, 80, 64, 32, dup=False)
