@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     4
+#define MACR_ABI_VERSION     5
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -238,23 +238,35 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  *              per split, per query: K (score,id) pairs, score descending, ties
  *              by ascending id, unused slots (-inf, -1).  Feed to
  *              macr_topk_merge.  macr_score_topk_splits() tells n_splits chosen.
- *   workspace (dev, optional) >= macr_score_topk_workspace_bytes(U) bytes: lets the
- *              item splits of a query exchange their running K-th best score (a lower
- *              bound of the final one) so that every split admits fewer candidates;
- *              NULL disables the exchange (same results, slower).
+ *              Since ABI 5 the merged result of all splits is in split 0 and the other
+ *              splits hold only padding (macr_topk_merge accepts both forms).
+ *   workspace (dev) >= macr_score_topk_workspace_bytes(U, n_local, n_splits) bytes, 256-B
+ *              aligned: per-query thresholds, the (item tile, query) mask bitmap and the
+ *              per-(split,query) candidate lists of the fixed-threshold stream (512 or
+ *              1024 keys of 8 bytes each).  Contents need not be initialised or preserved.
  * Score: NORMAL e_u.e_i ; RUBI_BOTH ((e_u.e_i - c) * sig_i) * sig_u, the dot
  * product being a k-ascending fp32 fma chain (gfx950 fp32 MFMA arithmetic).
  * d in {32,64,128,256}; 1 <= K <= MACR_MAX_TOPK.
  * -------------------------------------------------------------------------*/
 int    macr_score_topk_splits(int U, int n_local, int d);
-size_t macr_score_topk_workspace_bytes(int U);
+size_t macr_score_topk_workspace_bytes(int U, int n_local, int n_splits);
 
 int macr_score_topk(int score_kind, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
                     const float *sig_u, const float *sig_i, float c,
-                    const int32_t *mask_ptr, const int32_t *mask_idx, int item_offset,
-                    int K, int n_splits, float *out_val, int32_t *out_idx,
+                    const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
+                    int item_offset, int K, int n_splits, float *out_val, int32_t *out_idx,
                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* The train-item mask as the ranking kernels read it: mask_bits[tile][query] has bit (i % 32)
+ * set when the query masks item 32*tile + i of the shard.  The mask of an evaluator never
+ * changes during training (macr_mf/train.py:119-138 filters the same train lists every
+ * epoch), so it is built once and passed to every macr_score_topk call of the same
+ * (queries, shard); with mask_bits == NULL macr_score_topk builds it per call into its
+ * workspace. */
+size_t macr_mask_bits_bytes(int U, int n_local);
+int    macr_mask_bits_build(int U, int n_local, const int32_t *mask_ptr, const int32_t *mask_idx,
+                            int item_offset, uint32_t *mask_bits, void *stream);
 
 /* Dense scores for callers that want the matrix itself (the literal
  * sess.run(model.rubi_ratings_both, ...) -> (U,N) fp32 contract). */

@@ -15,7 +15,7 @@ LOSS_NORMALBCE, LOSS_RUBIBCEBOTH = 0, 1
 STEP_DEFER, STEP_PENDING = 1, 2
 SCORE_NORMAL, SCORE_RUBI_BOTH = 0, 1
 MAX_TOPK = 32
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MacrError(RuntimeError):
@@ -52,8 +52,10 @@ SIGNATURES = {
     "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 2 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _p, _z, _p]),
     "macr_branch_sigmoid": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "macr_score_topk_splits": (_i, [_i, _i, _i]),
-    "macr_score_topk_workspace_bytes": (_z, [_i]),
-    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "macr_score_topk_workspace_bytes": (_z, [_i, _i, _i]),
+    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "macr_mask_bits_bytes": (_z, [_i, _i]),
+    "macr_mask_bits_build": (_i, [_i, _i, _p, _p, _i, _p, _p]),
     "macr_score_matrix": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "macr_topk_scores": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "macr_topk_merge": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),

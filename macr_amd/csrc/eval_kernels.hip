@@ -108,7 +108,9 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     int U, int n_local, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
     const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_idx, int item_offset, int K,
-    int n_splits, float *__restrict__ out_val, int32_t *__restrict__ out_idx, uint32_t *shared_thr) {
+    int n_splits, float *__restrict__ out_val, int32_t *__restrict__ out_idx, uint32_t *shared_thr,
+    const int32_t *run_flag) {
+    if (run_flag && *run_flag == 0) return;             // fallback launch: only when a candidate list overflowed
     constexpr int NKH = D / kUnitK > 0 ? D / kUnitK : 1;     // k-halves per tile (D=32 -> 1 short unit)
     constexpr int UK = D < kUnitK ? D : kUnitK;              // k extent of one unit
     constexpr int NT = UK / 2;                               // MFMA steps per unit
@@ -386,6 +388,406 @@ inline size_t score_topk_smem_bytes() {
 }
 
 // ----------------------------------------------------------------------------
+// k_score_stream + k_tau + k_select: the full-catalogue ranking as a FIXED-threshold stream.
+//
+// On gfx950 the fp32-input MFMA and the fp32 VALU do not overlap (tools/mfma_valu_bench.hip: every
+// VALU instruction beside v_mfma_f32_32x32x2_f32 costs ~3 cycles on top of the MFMA's 64), so the
+// cost of a ranking kernel is MFMA time + everything else, and a running top-K per user (buffers,
+// compaction, thresholds that move) was 2/3 of k_score_topk.  Here the threshold of a user is
+// CONSTANT during a launch and candidates are only appended:
+//   pass 0 (MODE_MAX)   every 8th item tile.  Nothing is listed: each lane keeps the running maximum of each of
+//                       its 16 accumulator slots (one v_max per score).  A (split, lane half, slot) class holds
+//                       distinct items, so the K-th largest of a user's S*32 class maxima is the score of at
+//                       least K distinct items: a valid lower bound tau of the user's K-th best score, at about
+//                       rank K in the 1/8 sample, i.e. rank ~8K overall -- whatever the catalogue size.
+//   k_tau               one wave per user: tau = K-th largest class maximum.
+//   pass 1 (MODE_LIST)  all tiles: an item is listed iff score >= tau (~8K per user); per element that is the
+//                       score epilogue and one compare, per listed item an LDS counter bump and an 8-byte store.
+//   k_select            one wave per user: exact top K of the list by (score desc, id asc), sorted.
+// No key buffers in LDS: 18 KB per block instead of 152 KB, so two blocks (4 waves per SIMD) share a CU
+// and hide each other's barriers and LDS waits.  Pass 0 re-multiplies 1/8 of the tiles; that is cheaper
+// than any way of listing the sample.
+// Exactness: the list of a user always contains her true top K (tau is a lower bound of the K-th best
+// score, ties are listed); scores are the same MFMA accumulation and epilogue as k_score_topk / the
+// oracle.  A list that overflows (adversarial score order) raises *overflow and the launch sequence falls
+// back to k_score_topk, which is exact for any input.
+//
+// Masked (train) items and the tail of the last tile are poisoned at accumulator INIT (NaN + x = NaN,
+// NaN >= tau is false, max(m, NaN) = m): nothing per element.  Which items of a tile a user masks is one
+// 32-bit word of a (tile, user) bitmap that k_mask_bits scatters from the CSR lists once per call; the
+// word is prefetched with the tile (a CSR cursor costs a dependent load whenever it advances).
+// A operand in LDS as [item][h][t] (k = 2t+h), row stride D+4: a lane's whole k-row is contiguous
+// (ds_read_b128) and 16 lanes x 16 B cover all 64 banks once.
+// ----------------------------------------------------------------------------
+constexpr int kModeMax = 0, kModeList = 1;
+constexpr int kSampleLog2 = 3;                       // pass 0 visits tiles t with t % 8 == 0
+
+template <int D>
+struct StreamCfg {
+    static constexpr int RS = D + 4;                 // LDS row stride (floats)
+    static constexpr int NT = D / 2;                 // MFMA steps per tile
+    static constexpr int LD4 = (kTileItems * D / 4 + 511) / 512;   // float4 per thread per tile
+    static constexpr size_t smem = (size_t)2 * kTileItems * RS * 4 + 2 * kTileItems * 4 + kUsersPerBlock * 4;
+};
+
+// mask_bits[tile][user] |= 1 << (item % 32) for every masked item of the shard; one wave per user.
+__global__ __launch_bounds__(256) void k_mask_bits(int U, int n_local, const int32_t *__restrict__ mask_ptr,
+                                                   const int32_t *__restrict__ mask_idx, int item_offset,
+                                                   uint32_t *__restrict__ mask_bits) {
+    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= U) return;
+    const int e0 = mask_ptr[q], e1 = mask_ptr[q + 1];
+    for (int e = e0 + lane; e < e1; e += 64) {
+        const int it = mask_idx[e] - item_offset;
+        if (it >= 0 && it < n_local) atomicOr(&mask_bits[(size_t)(it >> 5) * U + q], 1u << (it & 31));
+    }
+}
+
+template <int D, int KIND, int MODE>
+__global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
+    int U, int n_local, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
+    const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
+    const uint32_t *__restrict__ mask_bits, int item_offset,
+    int n_splits, const float *__restrict__ tau, float *__restrict__ maxima, uint64_t *__restrict__ lists,
+    int32_t *__restrict__ counts, int cap, int32_t *overflow) {
+    using C = StreamCfg<D>;
+    constexpr int RS = C::RS, NT = C::NT;
+    constexpr int kStep = MODE == kModeMax ? (1 << kSampleLog2) : 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_a = reinterpret_cast<float *>(smem);                       // [2][32][RS]
+    float *s_sig = s_a + 2 * kTileItems * RS;                           // [2][32]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_sig + 2 * kTileItems);   // [256]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int ub = blockIdx.x / n_splits, split = blockIdx.x % n_splits;
+    const int uslot = wid * 32 + col;
+    const int q = ub * kUsersPerBlock + uslot;
+    const bool q_ok = q < U;
+
+    const int tiles_total = (n_local + kTileItems - 1) / kTileItems;
+    const int tiles_per_split = (tiles_total + n_splits - 1) / n_splits;
+    const int t_lo = min(split * tiles_per_split, tiles_total), t_hi = min(t_lo + tiles_per_split, tiles_total);
+
+    if (MODE == kModeList && tid < kUsersPerBlock) s_cnt[tid] = 0u;
+    float bfrag[NT];
+    {
+        const float *urow = users_tab + (size_t)(q_ok ? (user_ids ? user_ids[q] : q) : 0) * D;
+#pragma unroll
+        for (int t4 = 0; t4 < D / 4; ++t4) {           // k = 4*t4 .. 4*t4+3  ->  steps 2*t4 (k=+0,+1) and 2*t4+1 (k=+2,+3)
+            const float4 v = q_ok ? ld4(urow + 4 * t4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bfrag[2 * t4] = h ? v.y : v.x;
+            bfrag[2 * t4 + 1] = h ? v.w : v.z;
+        }
+    }
+    const float su = (KIND == MACR_SCORE_RUBI_BOTH && q_ok) ? sig_u[q] : 1.0f;
+    // listing test: score >= tau_s (NaN = never: padding users, poisoned scores)
+    const float tau_s = (MODE == kModeList && q_ok) ? tau[q] : __builtin_nanf("");
+    uint64_t *my_list = lists + ((size_t)split * U + (q_ok ? q : 0)) * cap;
+
+    int t = (t_lo + kStep - 1) & ~(kStep - 1);
+    // staging: thread -> (item row, float4 column); k=4c..4c+3 lands as (h=0: t=2c,2c+1 <- x,z) (h=1: <- y,w)
+    float4 stg[C::LD4];
+    float sg = 0.f;
+    uint32_t tm_next = 0u;
+    // Rows past the end of the shard are clamped, not zeroed: their scores are poisoned through tmask anyway, and
+    // an unconditional load lets the compiler keep the prefetch in flight across the whole MFMA phase.
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int k = 0; k < C::LD4; ++k) {
+            const int e = tid + 512 * k, row = (e / (D / 4)) & (kTileItems - 1), c4 = e % (D / 4);
+            const int it = min(tile * kTileItems + row, n_local - 1);
+            stg[k] = ld4(items + (size_t)it * D + 4 * c4);
+        }
+        if (KIND == MACR_SCORE_RUBI_BOTH) sg = sig_i[min(tile * kTileItems + (tid & (kTileItems - 1)), n_local - 1)];
+        tm_next = (mask_bits && q_ok) ? mask_bits[(size_t)tile * U + q] : 0u;      // masked items of (tile, user)
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < C::LD4; ++k) {
+            // opaque to the optimiser: otherwise the (x,z)/(y,w) register shuffle -- and with it the wait for the
+            // prefetch -- is hoisted to right after the load, in front of the MFMA phase
+            asm volatile("" : "+v"(stg[k].x), "+v"(stg[k].y), "+v"(stg[k].z), "+v"(stg[k].w));
+            const int e = tid + 512 * k, row = e / (D / 4), c4 = e % (D / 4);
+            if (row < kTileItems) {
+                float *p = s_a + ((size_t)buf * kTileItems + row) * RS + 2 * c4;
+                *reinterpret_cast<float2 *>(p) = make_float2(stg[k].x, stg[k].z);
+                *reinterpret_cast<float2 *>(p + NT) = make_float2(stg[k].y, stg[k].w);
+            }
+        }
+        if (KIND == MACR_SCORE_RUBI_BOTH) {
+            asm volatile("" : "+v"(sg));
+            if (tid < kTileItems) s_sig[buf * kTileItems + tid] = sg;
+        }
+    };
+
+    float cmax[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cmax[r] = -INFINITY;
+    int buf = 0;
+    if (t < t_hi) { load_tile(t); store_tile(0); }
+    uint32_t tm_cur = tm_next;
+    __syncthreads();
+    const float kNone = __builtin_nanf("");
+#ifdef MACR_ABL_S_NOLOOP
+    t = t_hi;
+#endif
+    while (t < t_hi) {
+        const int tn = t + kStep;
+        const bool has_next = tn < t_hi;
+        const uint32_t tm_this = tm_cur;
+        (void)tm_this;
+#ifndef MACR_ABL_S_NOSTAGE
+        if (has_next) load_tile(tn);
+#endif
+
+        const int gid0 = t * kTileItems + item_offset;
+        uint32_t tmask = tm_cur;
+#ifdef MACR_ABL_S_NOMASK
+        tmask = 0;
+#endif
+        const int valid = n_local - t * kTileItems;                 // < 32 only in the last tile of the shard
+        if (valid < kTileItems) tmask |= ~0u << valid;
+
+        const float *ua = s_a + ((size_t)buf * kTileItems + col) * RS + h * NT;
+        f32x16 acc;
+        float a4[4];
+        *reinterpret_cast<float4 *>(a4) = *reinterpret_cast<const float4 *>(ua);
+        if (__any(tmask != 0)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = ((tmask >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1u) ? kNone : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], bfrag[0], acc, 0, 0, 0);
+        } else {
+            f32x16 zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], bfrag[0], zero, 0, 0, 0);
+        }
+#ifndef MACR_ABL_S_NOMFMA
+#pragma unroll
+        for (int tt = 1; tt < NT; ++tt) {
+            if ((tt & 3) == 0) *reinterpret_cast<float4 *>(a4) = *reinterpret_cast<const float4 *>(ua + tt);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tt & 3], bfrag[tt], acc, 0, 0, 0);
+        }
+#endif
+
+        // epilogue: 16 scores per lane
+        float sgi[16];
+        if (KIND == MACR_SCORE_RUBI_BOTH) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(sgi + 4 * g) = *reinterpret_cast<const float4 *>(s_sig + buf * kTileItems + 8 * g + 4 * h);
+        }
+#ifdef MACR_ABL_S_NOEPI
+        if (acc[0] == 12345.f) *overflow = 1;
+#else
+        float v[16];
+        bool hit = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[r] = acc[r];
+            if (KIND == MACR_SCORE_RUBI_BOTH) { v[r] = v[r] - c; v[r] = v[r] * sgi[r]; v[r] = v[r] * su; }
+            if (MODE == kModeMax) cmax[r] = fmaxf(cmax[r], v[r]);
+            else hit |= v[r] >= tau_s;
+        }
+#ifdef MACR_ABL_S_NOAPPEND
+        if (v[3] == 12345.f) *overflow = 1;
+        hit = false;
+#endif
+        if (MODE == kModeList && __any(hit)) {              // one wave-uniform branch per tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (v[r] >= tau_s) {
+                    const uint32_t pos = atomicAdd(&s_cnt[uslot], 1u);
+                    if (pos < (uint32_t)cap) my_list[pos] = make_key(v[r], gid0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    else *overflow = 1;
+                }
+            }
+        }
+#endif
+#ifndef MACR_ABL_S_NOSTAGE
+        if (has_next) store_tile(buf ^ 1);
+        __syncthreads();
+#endif
+        tm_cur = tm_next;
+        buf ^= 1;
+        t = tn;
+    }
+    if (MODE == kModeMax) {
+        if (q_ok) {
+            float *o = maxima + ((size_t)split * U + q) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)       // slots (r&3)+8(r>>2)+4h: four runs of four consecutive floats
+                *reinterpret_cast<float4 *>(o + 8 * g + 4 * h) = make_float4(cmax[4 * g], cmax[4 * g + 1], cmax[4 * g + 2], cmax[4 * g + 3]);
+        }
+    } else if (tid < kUsersPerBlock) {
+        const int qq = ub * kUsersPerBlock + tid;
+        if (qq < U) counts[(size_t)split * U + qq] = (int32_t)min(s_cnt[tid], (uint32_t)cap);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_tau: one wave per user.  tau = the K-th largest of the user's n_splits*32 class maxima of pass 0
+// (-inf while fewer than K classes saw an unmasked item: everything is listed then).
+// MSB-first radix select on the order-preserving integer image of the floats; the state is one 64-bit
+// lane mask per register (wave-uniform, SGPRs): per bit and register one v_and + v_cmp and a few scalar
+// instructions, no cross-lane data movement.
+// ----------------------------------------------------------------------------
+constexpr int kSelWaves = 4;
+
+// The one-wave-per-user kernels are bound by the CU's single scalar unit: their loops are unrolled over a
+// COMPILE-TIME register count (no per-register guards) and the count is dispatched outside.
+template <int NREG>
+__global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int K, const float *__restrict__ maxima,
+                                                        float *__restrict__ tau) {
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * kSelWaves + wid;
+    if (q >= U) return;
+    const int n = n_splits * 32;
+    uint32_t key[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+        const int e = j * 64 + lane;                              // split e/32, class e%32
+        float m = -INFINITY;
+        if (e < n) m = maxima[((size_t)(e >> 5) * U + q) * 32 + (e & 31)];
+        key[j] = m > -INFINITY ? f32_orderable(m) : 0u;           // 0 = the class saw no unmasked item
+    }
+    int n_valid = 0;
+    uint64_t cand[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) { cand[j] = __ballot(key[j] != 0u); n_valid += __popcll(cand[j]); }
+    float t_out = -INFINITY;
+    if (n_valid >= K) {
+        int remaining = K;
+        uint32_t prefix = 0u;                                     // bits decided so far of the K-th largest key
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t m = 1u << bit;
+            uint64_t ones[NREG];
+            int n1 = 0;
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) { ones[j] = __ballot((key[j] & m) != 0u) & cand[j]; n1 += __popcll(ones[j]); }
+            if (n1 >= remaining) {
+                prefix |= m;
+#pragma unroll
+                for (int j = 0; j < NREG; ++j) cand[j] = ones[j];
+            } else {
+                remaining -= n1;
+#pragma unroll
+                for (int j = 0; j < NREG; ++j) cand[j] &= ~ones[j];
+            }
+        }
+        t_out = orderable_f32(prefix);                            // all 32 bits decided: the K-th largest key itself
+    }
+    if (lane == 0) tau[q] = t_out;
+}
+
+// ----------------------------------------------------------------------------
+// k_select: one wave per user.  Gathers the user's candidate lists of all splits, finds the K-th best
+// key by the same radix select over 64-bit keys held in registers (kSelRegs per lane), sorts the K
+// survivors and writes them as (score, id) rows to out_val/out_idx[0][u][:]; the other splits' rows are
+// padded with (-inf, -1).
+// ----------------------------------------------------------------------------
+constexpr int kSelRegs = 16;                       // up to 1024 candidates per user (more: fallback)
+
+// K-th largest of the n gathered keys (distinct: ids differ) held NREG per lane; lanes/registers past n hold 0.
+template <int NREG>
+__device__ __forceinline__ uint64_t select_kth(const uint64_t (&key)[kSelRegs], int n, int K, int lane) {
+    uint64_t cand[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) cand[j] = __ballot(j * 64 + lane < n);
+    int remaining = K, alive = n;
+    for (int bit = 63; bit >= 0 && alive > 1; --bit) {          // ends as soon as one candidate is left
+        const uint32_t m = 1u << (bit & 31);
+        uint64_t ones[NREG];
+        int n1 = 0;
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) {
+            const uint32_t word = bit >= 32 ? (uint32_t)(key[j] >> 32) : (uint32_t)key[j];
+            ones[j] = __ballot((word & m) != 0u) & cand[j];
+            n1 += __popcll(ones[j]);
+        }
+        if (n1 >= remaining) {
+            alive = n1;
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) cand[j] = ones[j];
+        } else {
+            remaining -= n1; alive -= n1;
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) cand[j] &= ~ones[j];
+        }
+    }
+    uint32_t hi = 0, lo = 0;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+        if (cand[j]) {
+            const int src_lane = __ffsll((long long)cand[j]) - 1;
+            hi = __shfl((uint32_t)(key[j] >> 32), src_lane, kWave);
+            lo = __shfl((uint32_t)key[j], src_lane, kWave);
+        }
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, int K, int cap, const uint64_t *__restrict__ lists,
+                                                           const int32_t *__restrict__ counts, int32_t *overflow,
+                                                           float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+    __shared__ uint64_t s_top[kSelWaves][64];
+    // wave-uniform values are made so explicitly (readfirstlane): the selection state then lives in SGPRs
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * kSelWaves + wid;
+    if (q >= U) return;
+    // list lengths of all splits at once (lane s <-> split s), exclusive prefix = offsets in the gathered order
+    const int my_c = lane < n_splits ? counts[(size_t)lane * U + q] : 0;
+    int incl = my_c;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, kWave); if (lane >= m) incl += o; }
+    const int n_all = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, kWave));
+    const int n = n_all < kSelRegs * 64 ? n_all : kSelRegs * 64;
+    if (n_all > kSelRegs * 64 && lane == 0) *overflow = 1;
+    // element e of the gathered order lives in split s(e) at position e - offset(s); the addresses are resolved
+    // first (uniform loop over the splits), then all loads are issued back to back
+    size_t rel[kSelRegs];
+#pragma unroll
+    for (int j = 0; j < kSelRegs; ++j) rel[j] = (size_t)q * cap + (j * 64 + lane);
+    for (int s = 1; s < n_splits; ++s) {
+        const int off = __builtin_amdgcn_readlane(incl, s - 1);                // exclusive prefix of split s
+        if (off >= n) break;
+        const size_t base = ((size_t)s * U + q) * cap - off;
+#pragma unroll
+        for (int j = 0; j < kSelRegs; ++j)
+            if (j * 64 + lane >= off) rel[j] = base + (j * 64 + lane);
+    }
+    uint64_t key[kSelRegs];
+#pragma unroll
+    for (int j = 0; j < kSelRegs; ++j) key[j] = j * 64 + lane < n ? lists[rel[j]] : 0ull;
+    uint64_t kth = 0ull;
+    if (n >= K) kth = n <= 256 ? select_kth<4>(key, n, K, lane) : select_kth<kSelRegs>(key, n, K, lane);
+    // survivors (exactly min(n, K)) -> LDS by prefix popcount, then one wave-wide sort
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < kSelRegs; ++j) {
+        const bool keep = key[j] != 0ull && key[j] >= kth;
+        const uint64_t km = __ballot(keep);
+        if (km) {
+            if (keep) s_top[wid][base + __popcll(km & ((1ull << lane) - 1ull))] = key[j];
+            base += __popcll(km);
+        }
+    }
+    const int kept = base;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint64_t k1 = lane < kept ? s_top[wid][lane] : 0ull;
+    k1 = wave_sort_desc(k1);
+    if (lane < K) {
+        out_val[(size_t)q * K + lane] = k1 ? key_score(k1) : -INFINITY;
+        out_idx[(size_t)q * K + lane] = k1 ? key_id(k1) : -1;
+        for (int s = 1; s < n_splits; ++s) {
+            out_val[((size_t)s * U + q) * K + lane] = -INFINITY;
+            out_idx[((size_t)s * U + q) * K + lane] = -1;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
 // k_score_matrix: the literal (U,N) score matrix (model.batch_ratings /
 // model.rubi_ratings_both), same arithmetic as k_score_topk.  One wave = 32 users x 32 items.
 // ----------------------------------------------------------------------------
@@ -636,22 +1038,71 @@ extern "C" void macr_dbg_counters(unsigned long long *out) {
 }
 #endif
 
-extern "C" size_t macr_score_topk_workspace_bytes(int U) { return U > 0 ? (size_t)U * 4 : 0; }
+namespace macr {
+// Workspace of macr_score_topk: counts[S][U] | flags | shared_thr[U] (fallback kernel) | tau[U] | maxima[S][U][32] |
+// mask_bits[tiles][U] | lists[S][U][cap]
+struct TopkWs {
+    float *tau, *maxima; int32_t *counts; int32_t *overflow; uint32_t *shared_thr, *mask_bits; uint64_t *lists;
+    int cap; size_t header_bytes, mask_bytes, bytes;
+};
+static TopkWs carve_topk_ws(void *base, int U, int n_local, int n_splits) {
+    TopkWs w;
+    char *p = static_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void *r = p ? p + off : nullptr; off += align_up(bytes, 256); return r; };
+    // One list per (split, user).  ~8K listed items per user in total, but item ids often follow popularity, so one
+    // split may receive nearly all of them: capacity is per split, not divided by S.
+    w.cap = n_splits == 1 ? 1024 : 512;
+    w.counts = static_cast<int32_t *>(take((size_t)n_splits * U * 4));
+    w.overflow = static_cast<int32_t *>(take(256));
+    w.shared_thr = static_cast<uint32_t *>(take((size_t)U * 4));
+    w.header_bytes = off;                                   // zeroed at the start of every call
+    w.tau = static_cast<float *>(take((size_t)U * 4));
+    w.maxima = static_cast<float *>(take((size_t)n_splits * U * 32 * 4));
+    w.mask_bytes = (size_t)((n_local + kTileItems - 1) / kTileItems) * U * 4;
+    w.mask_bits = static_cast<uint32_t *>(take(w.mask_bytes));
+    w.lists = static_cast<uint64_t *>(take((size_t)n_splits * U * w.cap * 8));
+    w.bytes = off;
+    return w;
+}
+}  // namespace macr
+
+extern "C" size_t macr_score_topk_workspace_bytes(int U, int n_local, int n_splits) {
+    if (U <= 0 || n_local <= 0 || n_splits <= 0) return 0;
+    return carve_topk_ws(nullptr, U, n_local, n_splits).bytes;
+}
+
+extern "C" size_t macr_mask_bits_bytes(int U, int n_local) {
+    if (U <= 0 || n_local <= 0) return 0;
+    return (size_t)((n_local + kTileItems - 1) / kTileItems) * U * 4;
+}
+
+extern "C" int macr_mask_bits_build(int U, int n_local, const int32_t *mask_ptr, const int32_t *mask_idx, int item_offset,
+                                    uint32_t *mask_bits, void *stream) {
+    MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "mask_bits_build: U=%d n_local=%d", U, n_local);
+    MACR_REQUIRE(mask_ptr && mask_idx && mask_bits, MACR_E_INVALID, "mask_bits_build: null pointer");
+    hipStream_t st = as_stream(stream);
+    hipError_t me = hipMemsetAsync(mask_bits, 0, macr_mask_bits_bytes(U, n_local), st);
+    MACR_REQUIRE(me == hipSuccess, MACR_E_LAUNCH, "mask_bits_build: memset: %s", hipGetErrorString(me));
+    k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, mask_bits);
+    MACR_CHECK_LAUNCH("mask_bits", st);
+    return MACR_OK;
+}
 
 extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
-    (void)d;
     if (U <= 0 || n_local <= 0) return 1;
     const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
     const int tiles = (n_local + kTileItems - 1) / kTileItems;
-    // One block (8 waves, 145 KB LDS) per CU, 256 CUs.  Cost model in units of item tiles per block:
-    // rounds * (tiles/s + warm-up), where every split re-pays the running top-K warm-up
-    // (~K ln(n/K) extra admissions, worth about a dozen tiles).  Pick the cheapest s.
+    // Blocks of 8 waves; `slots` of them are resident on the 256 CUs (two per CU up to d=64: 18 KB of LDS, <=128
+    // VGPRs).  Cost model in units of item tiles per block: rounds * (tiles/s + per-block overhead); pick the
+    // cheapest s.  Every split pays its own prologue (user rows, thresholds) and list traffic: ~4 tiles.
+    const int slots = d <= 64 ? 512 : 256;
     int best = 1;
     double best_cost = 1e300;
     for (int s = 1; s <= 64 && s <= tiles; ++s) {
         const long long blocks = (long long)ublocks * s;
-        const double rounds = (double)((blocks + 255) / 256);
-        const double cost = rounds * ((double)((tiles + s - 1) / s) + 12.0);
+        const double rounds = (double)((blocks + slots - 1) / slots);
+        const double cost = rounds * ((double)((tiles + s - 1) / s) + 4.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
     return best;
@@ -672,8 +1123,10 @@ extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
 extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const float *users_tab,
                                const int32_t *user_ids, const float *items, const float *sig_u,
                                const float *sig_i, float c, const int32_t *mask_ptr, const int32_t *mask_idx,
-                               int item_offset, int K, int n_splits, float *out_val, int32_t *out_idx,
-                               void *workspace, size_t workspace_bytes, void *stream) {
+                               const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, float *out_val,
+                               int32_t *out_idx, void *workspace, size_t workspace_bytes, void *stream) {
+    // MACR_TOPK_FALLBACK=1 in the environment runs the fallback kernel unconditionally (tests of that path)
+    static const bool force_fallback = getenv("MACR_TOPK_FALLBACK") && getenv("MACR_TOPK_FALLBACK")[0] == '1';
     MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || score_kind == MACR_SCORE_RUBI_BOTH, MACR_E_INVALID,
                  "score_topk: score_kind=%d", score_kind);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk: U=%d n_local=%d", U, n_local);
@@ -685,24 +1138,65 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
     MACR_REQUIRE((mask_ptr == nullptr) == (mask_idx == nullptr) || mask_ptr, MACR_E_INVALID, "score_topk: mask_idx without mask_ptr");
     if (n_splits <= 0) n_splits = macr_score_topk_splits(U, n_local, d);
     const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
-    const size_t smem = score_topk_smem_bytes();
     hipStream_t st = as_stream(stream);
-    uint32_t *shared_thr = nullptr;             // per-query admission bounds shared by the item splits
-    if (workspace && n_splits > 1) {
-        MACR_REQUIRE(workspace_bytes >= (size_t)U * 4, MACR_E_WORKSPACE, "score_topk: workspace %zu < %zu bytes",
-                     workspace_bytes, (size_t)U * 4);
-        shared_thr = static_cast<uint32_t *>(workspace);
-        hipError_t me = hipMemsetAsync(shared_thr, 0, (size_t)U * 4, st);
+    MACR_REQUIRE(n_splits <= 64, MACR_E_INVALID, "score_topk: n_splits=%d > 64", n_splits);
+    MACR_REQUIRE(workspace, MACR_E_INVALID, "score_topk: workspace is null (macr_score_topk_workspace_bytes)");
+    MACR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
+                 "score_topk: workspace must be 256-byte aligned");
+    TopkWs ws = carve_topk_ws(workspace, U, n_local, n_splits);
+    MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "score_topk: workspace %zu < %zu bytes", workspace_bytes,
+                 ws.bytes);
+    hipError_t me = hipMemsetAsync(workspace, 0, ws.header_bytes, st);          // counts, flag, shared_thr
+    MACR_REQUIRE(me == hipSuccess, MACR_E_LAUNCH, "score_topk: memset: %s", hipGetErrorString(me));
+    const int sel_blocks = (U + kSelWaves - 1) / kSelWaves;
+    const uint32_t *mask_bits = mask_bits_in;
+    MACR_REQUIRE(!mask_bits_in || mask_ptr, MACR_E_INVALID, "score_topk: mask_bits without the CSR mask it was built from");
+    if (mask_ptr && !mask_bits_in) {
+        me = hipMemsetAsync(ws.mask_bits, 0, ws.mask_bytes, st);
         MACR_REQUIRE(me == hipSuccess, MACR_E_LAUNCH, "score_topk: memset: %s", hipGetErrorString(me));
+        k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, ws.mask_bits);
+        MACR_CHECK_LAUNCH("mask_bits", st);
+        mask_bits = ws.mask_bits;
     }
+    MACR_DISPATCH_DK(d, score_kind, {
+        auto pass0 = k_score_stream<D, KIND, kModeMax>;
+        auto pass1 = k_score_stream<D, KIND, kModeList>;
+        const size_t smem = StreamCfg<D>::smem;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass0),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+        pass0<<<ublocks * n_splits, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits,
+                                                     item_offset, n_splits, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
+                                                     ws.overflow);
+        MACR_CHECK_LAUNCH("score_sample", st);
+        const int tau_regs = (n_splits * 32 + 63) / 64;
+        if (tau_regs <= 1) k_tau<1><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
+        else if (tau_regs <= 2) k_tau<2><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
+        else if (tau_regs <= 4) k_tau<4><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
+        else if (tau_regs <= 8) k_tau<8><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
+        else if (tau_regs <= 16) k_tau<16><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
+        else k_tau<32><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
+        MACR_CHECK_LAUNCH("tau", st);
+        pass1<<<ublocks * n_splits, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits,
+                                                     item_offset, n_splits, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
+                                                     ws.overflow);
+        MACR_CHECK_LAUNCH("score_stream", st);
+        k_select<<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow, out_val, out_idx);
+        MACR_CHECK_LAUNCH("select", st);
+    });
+    // Fallback, armed by the overflow flag on the device (its blocks return at once otherwise): the running
+    // top-K kernel is exact for any score order.
+    const size_t smem_old = score_topk_smem_bytes();
     MACR_DISPATCH_DK(d, score_kind, {
         auto kern = k_score_topk<D, KIND>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
-        kern<<<ublocks * n_splits, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c,
-                                                    mask_ptr, mask_idx, item_offset, K, n_splits, out_val, out_idx,
-                                                    shared_thr);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_old);
+        MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem_old, hipGetErrorString(e));
+        kern<<<ublocks * n_splits, 512, smem_old, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c,
+                                                        mask_ptr, mask_idx, item_offset, K, n_splits, out_val, out_idx,
+                                                        n_splits > 1 ? ws.shared_thr : nullptr, force_fallback ? nullptr : ws.overflow);
     });
     MACR_CHECK_LAUNCH("score_topk", st);
     return MACR_OK;

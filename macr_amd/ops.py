@@ -55,6 +55,21 @@ class CSR(object):
         self.plan_dev = torch.from_numpy(host).to(self.ptr.device)
         return self
 
+    def mask_bits(self, U, n_local, item_offset):
+        """(item tile, row) bitmap of this CSR used as a ranking mask (macr_mask_bits_build); cached: the train
+        lists an evaluator masks never change."""
+        key = (U, n_local, item_offset)
+        cache = self.__dict__.setdefault("_mask_bits", {})
+        bits = cache.get(key)
+        if bits is None:
+            if len(cache) >= 4:
+                cache.clear()
+            nbytes = _lib.lib().macr_mask_bits_bytes(U, n_local)
+            bits = cache[key] = torch.empty(nbytes // 4, dtype=_i32, device=self.ptr.device)
+            check(_lib.lib().macr_mask_bits_build(U, n_local, _ptr(self.ptr, _i32), _ptr(self.idx, _i32), item_offset,
+                                                  _ptr(bits), _stream()))
+        return bits
+
     def _plan_ptrs(self):
         if self.plan_host is None:
             return None, None
@@ -122,6 +137,18 @@ def score_topk_splits(U, n_local, d):
     return _lib.lib().macr_score_topk_splits(U, n_local, d)
 
 
+_topk_ws_cache = {}
+
+
+def _topk_workspace(U, n_local, n_splits, device):
+    """Scratch of macr_score_topk (candidate lists); one buffer per device, grown on demand."""
+    need = _lib.lib().macr_score_topk_workspace_bytes(U, n_local, n_splits)
+    ws = _topk_ws_cache.get(device)
+    if ws is None or ws.numel() < need:
+        ws = _topk_ws_cache[device] = torch.empty(need, dtype=torch.uint8, device=device)
+    return ws
+
+
 def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.0, mask=None,
                item_offset=0, n_splits=0):
     """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K)."""
@@ -133,11 +160,12 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     idx = torch.empty((n_splits, U, K), dtype=_i32, device=items.device)
     mp = _ptr(mask.ptr, _i32) if mask is not None else None
     mi = _ptr(mask.idx, _i32) if mask is not None else None
-    ws = torch.empty(U, dtype=_i32, device=items.device) if n_splits > 1 else None     # shared thresholds
+    mb = _ptr(mask.mask_bits(U, n_local, item_offset)) if mask is not None else None
+    ws = _topk_workspace(U, n_local, n_splits, items.device)
     check(_lib.lib().macr_score_topk(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
                                      _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
-                                     float(c), mp, mi, item_offset, K, n_splits, _ptr(vals), _ptr(idx),
-                                     _ptr(ws, None, True), 0 if ws is None else ws.numel() * 4, _stream()))
+                                     float(c), mp, mi, mb, item_offset, K, n_splits, _ptr(vals), _ptr(idx),
+                                     _ptr(ws), ws.numel(), _stream()))
     return vals, idx
 
 

@@ -315,6 +315,38 @@ def test_score_topk_item_sharding_equals_unsharded(ops):
     assert np.array_equal(ref_i.cpu().numpy(), wi)
 
 
+@pytest.mark.parametrize("splits", [1, 3])
+def test_score_topk_overflowing_lists_fall_back_to_running_topk(ops, splits):
+    """Adversarial score order for the fixed-threshold stream: every sampled tile (multiples of 8) scores far
+    below the rest, so the thresholds learnt from the samples admit ~everything and the candidate lists overflow;
+    the device-armed fallback (running top-K kernel) must still return the exact ranking."""
+    rs = np.random.RandomState(5)
+    U, N, d, K = 300, 4096 * 3, 64, 20
+    P = np.abs(rs.standard_normal((U, d)) * 0.5).astype(np.float32)
+    Q = np.abs(rs.standard_normal((N, d)) * 0.5).astype(np.float32)
+    tile = np.arange(N) // 32
+    Q[tile % 8 == 0] *= -1.0                          # all-positive factors: these items score negative
+    mask_lists = random_mask(rs, U, N, 10)
+    mptr, midx = oracle.csr_from_lists(mask_lists)
+    mask = ops.CSR(dev(mptr), dev(midx))
+    want_v, want_i, want_c = oracle.score_topk(oracle.SCORE_NORMAL, P, Q, K, mask=(mptr, midx))
+    vals, idx = ops.score_topk(oracle.SCORE_NORMAL, dev(P), None, dev(Q), K, mask=mask, n_splits=splits)
+    gv, gi, gc = ops.topk_merge(vals, idx)
+    assert np.array_equal(gi.cpu().numpy(), want_i)
+    assert np.array_equal(gv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+
+
+def test_score_topk_forced_fallback_kernel(ops):
+    """MACR_TOPK_FALLBACK=1 runs the running top-K kernel unconditionally: it stays covered by the parity suite."""
+    import os, subprocess, sys
+    env = dict(os.environ, MACR_TOPK_FALLBACK="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_ops.py", "-k",
+                        "test_score_topk_bit_exact or test_score_topk_item_sharding"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("rows,cols,K", [(7, 50, 20), (33, 744, 20), (5, 12, 10), (64, 40981, 20), (3, 25, 32), (2, 5, 8)])
 def test_topk_scores_bit_exact(ops, rows, cols, K):
     rs = np.random.RandomState(rows * cols)
