@@ -240,7 +240,7 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  *              macr_topk_merge.  macr_score_topk_splits() tells n_splits chosen.
  *              Since ABI 5 the merged result of all splits is in split 0 and the other
  *              splits hold only padding (macr_topk_merge accepts both forms).
- *   workspace (dev) >= macr_score_topk_workspace_bytes(U, n_local, n_splits) bytes, 256-B
+ *   workspace (dev) >= macr_score_topk_workspace_bytes(U, n_local, d) bytes, 256-B
  *              aligned: per-query thresholds, the (item tile, query) mask bitmap and the
  *              per-(split,query) candidate lists of the fixed-threshold stream (512 or
  *              1024 keys of 8 bytes each).  Contents need not be initialised or preserved.
@@ -249,7 +249,7 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  * d in {32,64,128,256}; 1 <= K <= MACR_MAX_TOPK.
  * -------------------------------------------------------------------------*/
 int    macr_score_topk_splits(int U, int n_local, int d);
-size_t macr_score_topk_workspace_bytes(int U, int n_local, int n_splits);
+size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
 
 int macr_score_topk(int score_kind, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     int U, int n_local, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
     const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
     const uint32_t *__restrict__ mask_bits, int item_offset,
-    int n_splits, const float *__restrict__ tau, float *__restrict__ maxima, uint64_t *__restrict__ lists,
+    int ublocks, const float *__restrict__ tau, float *__restrict__ maxima, uint64_t *__restrict__ lists,
     int32_t *__restrict__ counts, int cap, int32_t *overflow) {
     using C = StreamCfg<D>;
     constexpr int RS = C::RS, NT = C::NT;
@@ -460,14 +460,27 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int ub = blockIdx.x / n_splits, split = blockIdx.x % n_splits;
     const int uslot = wid * 32 + col;
+    const int tiles_total = (n_local + kTileItems - 1) / kTileItems;
+
+    // Work = (user block, visited tile) pairs in user-block-major order, cut into gridDim.x equal ranges: every
+    // resident block slot gets the same number of tiles whatever ublocks is.  A block's range may end one user
+    // block and begin the next ("segments"); the k-th block overlapping a user block writes that block's
+    // result slot k (lists / counts / maxima are [slot][user]).
+    const int T = (tiles_total + kStep - 1) / kStep;                    // visited tiles per user block
+    const long long W = (long long)ublocks * T, G = gridDim.x, b = blockIdx.x;
+    const long long w_end = W * (b + 1) / G;
+    for (long long w = W * b / G; w < w_end;) {
+    const int ub = (int)(w / T), i0 = (int)(w - (long long)ub * T);
+    const int i1 = (int)min((long long)T, i0 + (w_end - w));
+    w += i1 - i0;
+    long long first = (long long)ub * T * G / W;                        // the block holding this user block's first tile
+    while (W * (first + 1) / G <= (long long)ub * T) ++first;
+    while (W * first / G > (long long)ub * T) --first;
+    const int split = (int)(b - first);
+    const int t_hi = min(i1 * kStep, tiles_total);
     const int q = ub * kUsersPerBlock + uslot;
     const bool q_ok = q < U;
-
-    const int tiles_total = (n_local + kTileItems - 1) / kTileItems;
-    const int tiles_per_split = (tiles_total + n_splits - 1) / n_splits;
-    const int t_lo = min(split * tiles_per_split, tiles_total), t_hi = min(t_lo + tiles_per_split, tiles_total);
 
     if (MODE == kModeList && tid < kUsersPerBlock) s_cnt[tid] = 0u;
     float bfrag[NT];
@@ -485,7 +498,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     const float tau_s = (MODE == kModeList && q_ok) ? tau[q] : __builtin_nanf("");
     uint64_t *my_list = lists + ((size_t)split * U + (q_ok ? q : 0)) * cap;
 
-    int t = (t_lo + kStep - 1) & ~(kStep - 1);
+    int t = i0 * kStep;
     // staging: thread -> (item row, float4 column); k=4c..4c+3 lands as (h=0: t=2c,2c+1 <- x,z) (h=1: <- y,w)
     float4 stg[C::LD4];
     float sg = 0.f;
@@ -624,6 +637,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
         const int qq = ub * kUsersPerBlock + tid;
         if (qq < U) counts[(size_t)split * U + qq] = (int32_t)min(s_cnt[tid], (uint32_t)cap);
     }
+    }   // segments
 }
 
 // ----------------------------------------------------------------------------
@@ -728,7 +742,8 @@ __device__ __forceinline__ uint64_t select_kth(const uint64_t (&key)[kSelRegs], 
     return ((uint64_t)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, int K, int cap, const uint64_t *__restrict__ lists,
+__global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, int n_out, int K, int cap,
+                                                           const uint64_t *__restrict__ lists,
                                                            const int32_t *__restrict__ counts, int32_t *overflow,
                                                            float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
     __shared__ uint64_t s_top[kSelWaves][64];
@@ -780,7 +795,7 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
     if (lane < K) {
         out_val[(size_t)q * K + lane] = k1 ? key_score(k1) : -INFINITY;
         out_idx[(size_t)q * K + lane] = k1 ? key_id(k1) : -1;
-        for (int s = 1; s < n_splits; ++s) {
+        for (int s = 1; s < n_out; ++s) {
             out_val[((size_t)s * U + q) * K + lane] = -INFINITY;
             out_idx[((size_t)s * U + q) * K + lane] = -1;
         }
@@ -1039,37 +1054,61 @@ extern "C" void macr_dbg_counters(unsigned long long *out) {
 #endif
 
 namespace macr {
-// Workspace of macr_score_topk: counts[S][U] | flags | shared_thr[U] (fallback kernel) | tau[U] | maxima[S][U][32] |
-// mask_bits[tiles][U] | lists[S][U][cap]
+// Launch geometry of the two streaming passes (see k_score_stream): grid sizes and the number of result slots a
+// user block can have (= blocks overlapping its tile range).
+struct StreamGeo { int ublocks, grid0, slots0, grid1, slots1; };
+static StreamGeo stream_geo(int U, int n_local, int d) {
+    StreamGeo g;
+    g.ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
+    const int resident = d <= 64 ? 512 : 256;                 // 8-wave blocks resident on 256 CUs
+    const int T1 = (n_local + kTileItems - 1) / kTileItems, T0 = (T1 + (1 << kSampleLog2) - 1) >> kSampleLog2;
+    auto plan = [&](int T, int &grid, int &slots) {
+        const long long W = (long long)g.ublocks * T;
+        long long G = resident;
+        if (G > W / 2) G = W / 2;                             // at least two tiles per block
+        if (G > (long long)g.ublocks * 60) G = (long long)g.ublocks * 60;   // at most ~62 blocks per user block
+        if (G < 1) G = 1;
+        const long long chunk = W / G;                        // shortest range
+        grid = (int)G;
+        slots = (int)((T + chunk - 1) / chunk + 1);
+    };
+    plan(T0, g.grid0, g.slots0);
+    plan(T1, g.grid1, g.slots1);
+    return g;
+}
+
+// Workspace of macr_score_topk: counts[S1][U] | flags | shared_thr[U] (fallback kernel) | tau[U] | maxima[S0][U][32] |
+// mask_bits[tiles][U] | lists[S1][U][cap]
 struct TopkWs {
     float *tau, *maxima; int32_t *counts; int32_t *overflow; uint32_t *shared_thr, *mask_bits; uint64_t *lists;
-    int cap; size_t header_bytes, mask_bytes, bytes;
+    int cap; size_t header_bytes, maxima_bytes, mask_bytes, bytes;
 };
-static TopkWs carve_topk_ws(void *base, int U, int n_local, int n_splits) {
+static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g) {
     TopkWs w;
     char *p = static_cast<char *>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) { void *r = p ? p + off : nullptr; off += align_up(bytes, 256); return r; };
-    // One list per (split, user).  ~8K listed items per user in total, but item ids often follow popularity, so one
-    // split may receive nearly all of them: capacity is per split, not divided by S.
-    w.cap = n_splits == 1 ? 1024 : 512;
-    w.counts = static_cast<int32_t *>(take((size_t)n_splits * U * 4));
+    // One list per (slot, user).  ~8K listed items per user in total, but item ids often follow popularity, so one
+    // slot may receive nearly all of them: capacity is per slot, not divided by their number.
+    w.cap = g.slots1 <= 2 ? 1024 : 512;
+    w.counts = static_cast<int32_t *>(take((size_t)g.slots1 * U * 4));
     w.overflow = static_cast<int32_t *>(take(256));
     w.shared_thr = static_cast<uint32_t *>(take((size_t)U * 4));
     w.header_bytes = off;                                   // zeroed at the start of every call
     w.tau = static_cast<float *>(take((size_t)U * 4));
-    w.maxima = static_cast<float *>(take((size_t)n_splits * U * 32 * 4));
+    w.maxima_bytes = (size_t)g.slots0 * U * 32 * 4;         // set to NaN (0xff bytes) at the start of every call
+    w.maxima = static_cast<float *>(take(w.maxima_bytes));
     w.mask_bytes = (size_t)((n_local + kTileItems - 1) / kTileItems) * U * 4;
     w.mask_bits = static_cast<uint32_t *>(take(w.mask_bytes));
-    w.lists = static_cast<uint64_t *>(take((size_t)n_splits * U * w.cap * 8));
+    w.lists = static_cast<uint64_t *>(take((size_t)g.slots1 * U * w.cap * 8));
     w.bytes = off;
     return w;
 }
 }  // namespace macr
 
-extern "C" size_t macr_score_topk_workspace_bytes(int U, int n_local, int n_splits) {
-    if (U <= 0 || n_local <= 0 || n_splits <= 0) return 0;
-    return carve_topk_ws(nullptr, U, n_local, n_splits).bytes;
+extern "C" size_t macr_score_topk_workspace_bytes(int U, int n_local, int d) {
+    if (U <= 0 || n_local <= 0 || !dim_supported(d)) return 0;
+    return carve_topk_ws(nullptr, U, n_local, stream_geo(U, n_local, d)).bytes;
 }
 
 extern "C" size_t macr_mask_bits_bytes(int U, int n_local) {
@@ -1090,22 +1129,10 @@ extern "C" int macr_mask_bits_build(int U, int n_local, const int32_t *mask_ptr,
 }
 
 extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
-    if (U <= 0 || n_local <= 0) return 1;
-    const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
-    const int tiles = (n_local + kTileItems - 1) / kTileItems;
-    // Blocks of 8 waves; `slots` of them are resident on the 256 CUs (two per CU up to d=64: 18 KB of LDS, <=128
-    // VGPRs).  Cost model in units of item tiles per block: rounds * (tiles/s + per-block overhead); pick the
-    // cheapest s.  Every split pays its own prologue (user rows, thresholds) and list traffic: ~4 tiles.
-    const int slots = d <= 64 ? 512 : 256;
-    int best = 1;
-    double best_cost = 1e300;
-    for (int s = 1; s <= 64 && s <= tiles; ++s) {
-        const long long blocks = (long long)ublocks * s;
-        const double rounds = (double)((blocks + slots - 1) / slots);
-        const double cost = rounds * ((double)((tiles + s - 1) / s) + 4.0);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
-    }
-    return best;
+    // The streaming passes balance their own grid (stream_geo) and leave the merged result in list 0; more output
+    // lists would only add padding for macr_topk_merge to read.  (n_splits > 1 still shapes the fallback kernel.)
+    (void)U; (void)n_local; (void)d;
+    return 1;
 }
 
 #define MACR_DISPATCH_DK(d, kind, ...)                                                              \
@@ -1143,10 +1170,12 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
     MACR_REQUIRE(workspace, MACR_E_INVALID, "score_topk: workspace is null (macr_score_topk_workspace_bytes)");
     MACR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
                  "score_topk: workspace must be 256-byte aligned");
-    TopkWs ws = carve_topk_ws(workspace, U, n_local, n_splits);
+    const StreamGeo geo = stream_geo(U, n_local, d);
+    TopkWs ws = carve_topk_ws(workspace, U, n_local, geo);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "score_topk: workspace %zu < %zu bytes", workspace_bytes,
                  ws.bytes);
     hipError_t me = hipMemsetAsync(workspace, 0, ws.header_bytes, st);          // counts, flag, shared_thr
+    if (me == hipSuccess) me = hipMemsetAsync(ws.maxima, 0xff, ws.maxima_bytes, st);     // NaN: slot saw nothing
     MACR_REQUIRE(me == hipSuccess, MACR_E_LAUNCH, "score_topk: memset: %s", hipGetErrorString(me));
     const int sel_blocks = (U + kSelWaves - 1) / kSelWaves;
     const uint32_t *mask_bits = mask_bits_in;
@@ -1167,23 +1196,22 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
-        pass0<<<ublocks * n_splits, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits,
-                                                     item_offset, n_splits, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
-                                                     ws.overflow);
+        pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits, item_offset,
+                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow);
         MACR_CHECK_LAUNCH("score_sample", st);
-        const int tau_regs = (n_splits * 32 + 63) / 64;
-        if (tau_regs <= 1) k_tau<1><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
-        else if (tau_regs <= 2) k_tau<2><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
-        else if (tau_regs <= 4) k_tau<4><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
-        else if (tau_regs <= 8) k_tau<8><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
-        else if (tau_regs <= 16) k_tau<16><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
-        else k_tau<32><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.maxima, ws.tau);
+        const int tau_regs = (geo.slots0 * 32 + 63) / 64;
+        if (tau_regs <= 1) k_tau<1><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
+        else if (tau_regs <= 2) k_tau<2><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
+        else if (tau_regs <= 4) k_tau<4><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
+        else if (tau_regs <= 8) k_tau<8><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
+        else if (tau_regs <= 16) k_tau<16><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
+        else k_tau<32><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
         MACR_CHECK_LAUNCH("tau", st);
-        pass1<<<ublocks * n_splits, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits,
-                                                     item_offset, n_splits, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
-                                                     ws.overflow);
+        pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits, item_offset,
+                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow);
         MACR_CHECK_LAUNCH("score_stream", st);
-        k_select<<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow, out_val, out_idx);
+        k_select<<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow,
+                                                       out_val, out_idx);
         MACR_CHECK_LAUNCH("select", st);
     });
     // Fallback, armed by the overflow flag on the device (its blocks return at once otherwise): the running

@@ -140,9 +140,9 @@ def score_topk_splits(U, n_local, d):
 _topk_ws_cache = {}
 
 
-def _topk_workspace(U, n_local, n_splits, device):
+def _topk_workspace(U, n_local, d, device):
     """Scratch of macr_score_topk (candidate lists); one buffer per device, grown on demand."""
-    need = _lib.lib().macr_score_topk_workspace_bytes(U, n_local, n_splits)
+    need = _lib.lib().macr_score_topk_workspace_bytes(U, n_local, d)
     ws = _topk_ws_cache.get(device)
     if ws is None or ws.numel() < need:
         ws = _topk_ws_cache[device] = torch.empty(need, dtype=torch.uint8, device=device)
@@ -161,7 +161,7 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     mp = _ptr(mask.ptr, _i32) if mask is not None else None
     mi = _ptr(mask.idx, _i32) if mask is not None else None
     mb = _ptr(mask.mask_bits(U, n_local, item_offset)) if mask is not None else None
-    ws = _topk_workspace(U, n_local, n_splits, items.device)
+    ws = _topk_workspace(U, n_local, d, items.device)
     check(_lib.lib().macr_score_topk(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
                                      _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
                                      float(c), mp, mi, mb, item_offset, K, n_splits, _ptr(vals), _ptr(idx),

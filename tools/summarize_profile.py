@@ -20,7 +20,18 @@ DST = os.path.join(ROOT, "profiles")
 
 def short(name):
     m = re.search(r"macr::k_([a-z_]+)", name)
-    return m.group(1) if m else None
+    if not m:
+        return None
+    k = m.group(1)
+    if k == "score_stream":          # k_score_stream<D, KIND, MODE>: MODE 0 is the sampling pass
+        t = re.search(r"k_score_stream<\s*\d+\s*,\s*\d+\s*,\s*(\d+)", name)
+        if t and t.group(1) == "0":
+            k = "score_sample"
+    if k == "bxb":                   # k_bxb<R, FULL, ADAM>: ADAM=true carries the deferred Adam blocks
+        t = re.search(r"k_bxb<\s*\d+\s*,\s*(?:true|false|\d+)\s*,\s*(true|1)", name)
+        if t:
+            k = "bxb+adam"
+    return k
 
 
 def pmc_avgs(path):
