@@ -26,6 +26,7 @@ class Evaluator(object):
         self.n_items = n_items
         self.device = device
         self.mask = ops.CSR.from_lists(mask_lists, device)
+        self.max_queries_per_pass = 131072       # bounds the ranking workspace (~1.5 GB of candidate lists)
         self.gt = ops.CSR.from_lists(gt_lists, device)
 
     # ------------------------------------------------------------------ ranking
@@ -40,7 +41,20 @@ class Evaluator(object):
         if kind == ops.SCORE_RUBI_BOTH:
             sig_i = ops.branch_sigmoid(items_local, w)              # sigmoid(e_i . w)      model.py:199
             sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199
-        vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, self.mask, lo)
+        U = self.n_queries
+        if U <= self.max_queries_per_pass:
+            vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, self.mask, lo)
+        else:
+            # the ranking workspace (candidate lists, mask bitmap) grows with the number of queries: rank them in
+            # chunks; every query is independent of the chunking
+            parts = []
+            for a in range(0, U, self.max_queries_per_pass):
+                b = min(U, a + self.max_queries_per_pass)
+                uid = user_ids[a:b] if user_ids is not None else torch.arange(a, b, dtype=torch.int32, device=self.device)
+                parts.append(ops.score_topk(kind, users_tab, uid, items_local, K, None if sig_u is None else sig_u[a:b],
+                                            sig_i, c, self.mask.row_range(a, b), lo))
+            vals = torch.cat([p[0] for p in parts], dim=1)
+            idx = torch.cat([p[1] for p in parts], dim=1)
         fill = self.mask if fill_masked else None
         if ws == 1:
             return ops.topk_merge(vals, idx, fill)

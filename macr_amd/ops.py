@@ -94,6 +94,16 @@ class CSR(object):
                    torch.from_numpy(m.indices.astype("int32")).to(device),
                    torch.from_numpy(m.data.astype("float32")).to(device)).build_spmm_plan()
 
+    def row_range(self, a, b):
+        """CSR of the contiguous rows [a, b) (cached: evaluators rank the same query chunks every epoch)."""
+        cache = self.__dict__.setdefault("_row_ranges", {})
+        sub = cache.get((a, b))
+        if sub is None:
+            lo, hi = int(self.ptr[a]), int(self.ptr[b])
+            idx = self.idx[lo:hi] if hi > lo else self.idx[:1]
+            sub = cache[(a, b)] = CSR((self.ptr[a:b + 1] - lo).contiguous(), idx.contiguous())
+        return sub
+
     def rows(self, sel):
         """sub-CSR for the given row selection (host-side index list/tensor)."""
         sel = torch.as_tensor(sel, dtype=torch.long, device=self.ptr.device)

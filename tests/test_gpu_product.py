@@ -106,6 +106,12 @@ def test_fused_evaluators_match_oracle_on_addressa(ops, kind):
     np.testing.assert_allclose(got["hr"], fin[2], rtol=1e-6)
     np.testing.assert_allclose(got["recall"], fin[1], rtol=1e-6)
     np.testing.assert_allclose(got["ndcg"], fin[3], rtol=1e-6)
+    # queries ranked in chunks (bounded workspace) give the same rankings
+    whole = ev.rank(kind, Pd, uid, Qd, max(Ks), wd, wud, c)
+    ev.max_queries_per_pass = 1000
+    parts = ev.rank(kind, Pd, uid, Qd, max(Ks), wd, wud, c)
+    for a, b in zip(whole, parts):
+        assert torch.equal(a, b)
 
 
 def test_session_shim_matches_fast_path(ops):
