@@ -237,14 +237,13 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
         float4 w4 = ld4(w + 4 * g.sub), wu4 = ld4(wu + 4 * g.sub);
         if (PENDING) {
             const float lr_t = pa.scal->lr_t;
-            const float4 zero = make_float4(0, 0, 0, 0);
             const size_t au = (size_t)ru * d + 4 * g.sub, ai = (size_t)ri * d + 4 * g.sub, aj = (size_t)rj * d + 4 * g.sub;
             float4 mu = ld4(pa.mU + au), vu = ld4(pa.vU + au), mi = ld4(pa.mI + ai), vi = ld4(pa.vI + ai);
             float4 mj = ld4(pa.mI + aj), vj = ld4(pa.vI + aj);
-            const float4 gu = pa.tU[ru] ? ld4(pa.gU + au) : zero;
-            const float4 gi = pa.tI[ri] ? ld4(pa.gI + ai) : zero;
-            const float4 gj = pa.tI[rj] ? ld4(pa.gI + aj) : zero;
-            float4 gw4 = zero, gwu4 = zero;
+            // gradient rows are read unconditionally: rows without a gradient are all-zero (the scratch invariant),
+            // and a flag test would put a second memory latency in front of the row load
+            const float4 gu = ld4(pa.gU + au), gi = ld4(pa.gI + ai), gj = ld4(pa.gI + aj);
+            float4 gw4 = make_float4(0, 0, 0, 0), gwu4 = make_float4(0, 0, 0, 0);
 #pragma unroll
             for (int k = 0; k < kBranchSlots; ++k) {
                 gw4 = add4(gw4, ld4(gw + (size_t)k * 2 * d + 4 * g.sub));

@@ -36,6 +36,10 @@ def gather_topk(local_val, local_idx, group=None):
     rank, ws = world()
     if ws == 1:
         return local_val.unsqueeze(0), local_idx.unsqueeze(0)
+    if local_val.is_cuda and dist.get_backend(group) == "gloo":
+        # test rig only (several ranks sharing one GPU cannot use RCCL): gloo gathers host tensors
+        v, i = gather_topk(local_val.cpu(), local_idx.cpu(), group)
+        return v.to(local_val.device), i.to(local_idx.device)
     vals = torch.empty((ws,) + tuple(local_val.shape), dtype=local_val.dtype, device=local_val.device)
     idxs = torch.empty((ws,) + tuple(local_idx.shape), dtype=local_idx.dtype, device=local_idx.device)
     # output viewed as the concatenation along dim 0: the form every backend (nccl/RCCL, gloo) accepts
@@ -49,6 +53,6 @@ def max_over_ranks(x, device):
     rank, ws = world()
     if ws == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

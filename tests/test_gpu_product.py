@@ -206,3 +206,24 @@ def test_lightgcn_cli_addressa(tmp_path):
     hit = float(out.split("hit=[")[-1].split(",")[0])
     assert 0.0 < hit < 1.0
     assert not [f for f in os.listdir(os.path.join(REPO, "data", "addressa")) if f.endswith(".npz")]
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """bench.py's N>1 path (replica training, rank-0 broadcast, item-sharded evaluation, all-gather, merge) with
+    two ranks on ONE GPU through the gloo test rig; the single-rank run is the reference for the eval metrics."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "addressa", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--eval-reps", "1"]
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = dict(os.environ, MACR_DIST_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "2"] + common,
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-1000:] + two.stderr[-3000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and b["value"] > 0 and b["config"]["global_batch"] == 2 * a["config"]["global_batch"]
+    for k, v in a["eval_metrics"].items():            # same model (rank 0's), item-sharded: same ranking metrics
+        assert abs(b["eval_metrics"][k] - v) <= 2e-3 * max(abs(v), 1e-3), (k, v, b["eval_metrics"][k])
