@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     __shared__ float s_w[4][2][D];
     __shared__ float s_gi[kChunkT][D];
     __shared__ int s_pos[kChunkT];
+    __shared__ float s_d[4][kChunkT];
     const int nblk = gridDim.x - 1;
     if ((int)blockIdx.x == nblk) {
         // Step bookkeeping, by one wave of an extra block.  Every Adam pass of the PREVIOUS update has completed
@@ -476,31 +477,41 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     // per triple -- the hottest item of a Zipf batch costs (#blocks it spans) serialised atomics, not (#references).
     // Unsorted batches stay correct (runs of length one).
     for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += nblk) {
-#pragma unroll 1
+        // The chunk's column sums dp,dn and row sums da,db of the (B,B) term: wave w reduces quantity w over the bxb
+        // partials for all 16 triples at once -- lane (k%4, t%16) reads 64-byte runs -- instead of every triple's wave
+        // gathering 96 words from 96 different lines.
+        // (the wave's own 4x3 row indices are fetched alongside, so the row gathers can start right after the barrier)
+        int my_idx = 0;
+        {
+            const int tq = chunk * kChunkT + wid * (kChunkT / 4) + (lane & 3);
+            if (lane < 12 && tq < B) my_idx = (lane < 4 ? u : lane < 8 ? i : j)[tq];
+        }
+        {
+            const int tt = lane & 15, kq = lane >> 4, t = chunk * kChunkT + tt;
+            const float *src = wid < 2 ? colpart + (size_t)wid * Bp : rowpart + (size_t)(wid - 2) * Bp;
+            const int np = wid < 2 ? nrb : ncb;
+            float acc = 0.f;
+#ifndef MACR_ABL_NOPART
+            if (t < B)
+                for (int k = kq; k < np; k += 4) acc += src[(size_t)k * 2 * Bp + t];
+#endif
+            acc += __shfl_xor(acc, 16, kWave);
+            acc += __shfl_xor(acc, 32, kWave);
+            if (kq == 0) s_d[wid][tt] = acc * inv_b2;
+        }
+        __syncthreads();
+#pragma unroll                                   // the four triples' row gathers are issued together
         for (int q = 0; q < kChunkT / 4; ++q) {
             const int slot = wid * (kChunkT / 4) + q;
             const int t = chunk * kChunkT + slot;
             if (t >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
-            // per-triple scalars: the wave sums the bxb partials cooperatively
-            float dp = 0.f, dn = 0.f, da = 0.f, db = 0.f;
-#ifndef MACR_ABL_NOPART
-            for (int k = lane; k < nrb; k += 64) {
-                dp += colpart[((size_t)k * 2 + 0) * Bp + t];
-                dn += colpart[((size_t)k * 2 + 1) * Bp + t];
-            }
-            for (int k = lane; k < ncb; k += 64) {
-                da += rowpart[((size_t)k * 2 + 0) * Bp + t];
-                db += rowpart[((size_t)k * 2 + 1) * Bp + t];
-            }
-#endif
-            dp = wave_sum(dp) * inv_b2; dn = wave_sum(dn) * inv_b2;
-            da = wave_sum(da) * inv_b2; db = wave_sum(db) * inv_b2;
+            const float dp = s_d[0][slot], dn = s_d[1][slot], da = s_d[2][slot], db = s_d[3][slot];
             const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
             const float dsi = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
             const float dsj = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
             const float dsu = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
                               (beta * invB) * (dneglog_sig(ssu, eps) + dneglog_1msig(ssu, eps));
-            const int ru = u[t], ri = i[t], rj = j[t];
+            const int ru = __shfl(my_idx, q, kWave), ri = __shfl(my_idx, 4 + q, kWave), rj = __shfl(my_idx, 8 + q, kWave);
             if (act) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
