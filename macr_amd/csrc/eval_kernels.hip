@@ -672,25 +672,31 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int
     for (int j = 0; j < NREG; ++j) { cand[j] = __ballot(key[j] != 0u); n_valid += __popcll(cand[j]); }
     float t_out = -INFINITY;
     if (n_valid >= K) {
-        int remaining = K;
+        int remaining = K, alive = n_valid;
         uint32_t prefix = 0u;                                     // bits decided so far of the K-th largest key
-        for (int bit = 31; bit >= 0; --bit) {
+        int bit = 31;
+        for (; bit >= 0 && alive > 1; --bit) {
             const uint32_t m = 1u << bit;
             uint64_t ones[NREG];
             int n1 = 0;
 #pragma unroll
             for (int j = 0; j < NREG; ++j) { ones[j] = __ballot((key[j] & m) != 0u) & cand[j]; n1 += __popcll(ones[j]); }
             if (n1 >= remaining) {
-                prefix |= m;
+                prefix |= m; alive = n1;
 #pragma unroll
                 for (int j = 0; j < NREG; ++j) cand[j] = ones[j];
             } else {
-                remaining -= n1;
+                remaining -= n1; alive -= n1;
 #pragma unroll
                 for (int j = 0; j < NREG; ++j) cand[j] &= ~ones[j];
             }
         }
-        t_out = orderable_f32(prefix);                            // all 32 bits decided: the K-th largest key itself
+        if (bit >= 0) {                                           // one candidate left: it is the K-th largest
+#pragma unroll
+            for (int j = 0; j < NREG; ++j)
+                if (cand[j]) prefix = __shfl(key[j], __ffsll((long long)cand[j]) - 1, kWave);
+        }
+        t_out = orderable_f32(prefix);                            // (all 32 bits decided when equal maxima remain)
     }
     if (lane == 0) tau[q] = t_out;
 }
@@ -703,43 +709,88 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int
 // ----------------------------------------------------------------------------
 constexpr int kSelRegs = 16;                       // up to 1024 candidates per user (more: fallback)
 
-// K-th largest of the n gathered keys (distinct: ids differ) held NREG per lane; lanes/registers past n hold 0.
+// Gather, select and sort for one user with NREG keys per lane (n <= 64*NREG); see k_select.
 template <int NREG>
-__device__ __forceinline__ uint64_t select_kth(const uint64_t (&key)[kSelRegs], int n, int K, int lane) {
-    uint64_t cand[NREG];
+__device__ __forceinline__ void select_user(int q, int lane, int U, int n_splits, int n_out, int K, int cap, int n, int incl,
+                                            const uint64_t *__restrict__ lists, uint64_t *s_top,
+                                            float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+    // element e of the gathered order lives in split s(e) at position e - offset(s); the addresses are resolved
+    // first (uniform loop over the splits), then all loads are issued back to back
+    size_t rel[NREG];
 #pragma unroll
-    for (int j = 0; j < NREG; ++j) cand[j] = __ballot(j * 64 + lane < n);
-    int remaining = K, alive = n;
-    for (int bit = 63; bit >= 0 && alive > 1; --bit) {          // ends as soon as one candidate is left
-        const uint32_t m = 1u << (bit & 31);
-        uint64_t ones[NREG];
-        int n1 = 0;
+    for (int j = 0; j < NREG; ++j) rel[j] = (size_t)q * cap + (j * 64 + lane);
+    for (int s = 1; s < n_splits; ++s) {
+        const int off = __builtin_amdgcn_readlane(incl, s - 1);                // exclusive prefix of split s
+        if (off >= n) break;
+        const size_t base = ((size_t)s * U + q) * cap - off;
+#pragma unroll
+        for (int j = 0; j < NREG; ++j)
+            if (j * 64 + lane >= off) rel[j] = base + (j * 64 + lane);
+    }
+    uint64_t key[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) key[j] = j * 64 + lane < n ? lists[rel[j]] : 0ull;
+    // K-th largest of the n keys (distinct: ids differ): MSB-first radix select on lane masks
+    uint64_t kth = 0ull;
+    if (n >= K) {
+        uint64_t cand[NREG];
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) cand[j] = __ballot(j * 64 + lane < n);
+        int remaining = K, alive = n;
+        for (int bit = 63; bit >= 0 && alive > 1; --bit) {          // ends as soon as one candidate is left
+            const uint32_t m = 1u << (bit & 31);
+            uint64_t ones[NREG];
+            int n1 = 0;
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) {
+                const uint32_t word = bit >= 32 ? (uint32_t)(key[j] >> 32) : (uint32_t)key[j];
+                ones[j] = __ballot((word & m) != 0u) & cand[j];
+                n1 += __popcll(ones[j]);
+            }
+            if (n1 >= remaining) {
+                alive = n1;
+#pragma unroll
+                for (int j = 0; j < NREG; ++j) cand[j] = ones[j];
+            } else {
+                remaining -= n1; alive -= n1;
+#pragma unroll
+                for (int j = 0; j < NREG; ++j) cand[j] &= ~ones[j];
+            }
+        }
+        uint32_t hi = 0, lo = 0;
 #pragma unroll
         for (int j = 0; j < NREG; ++j) {
-            const uint32_t word = bit >= 32 ? (uint32_t)(key[j] >> 32) : (uint32_t)key[j];
-            ones[j] = __ballot((word & m) != 0u) & cand[j];
-            n1 += __popcll(ones[j]);
+            if (cand[j]) {
+                const int src_lane = __ffsll((long long)cand[j]) - 1;
+                hi = __shfl((uint32_t)(key[j] >> 32), src_lane, kWave);
+                lo = __shfl((uint32_t)key[j], src_lane, kWave);
+            }
         }
-        if (n1 >= remaining) {
-            alive = n1;
-#pragma unroll
-            for (int j = 0; j < NREG; ++j) cand[j] = ones[j];
-        } else {
-            remaining -= n1; alive -= n1;
-#pragma unroll
-            for (int j = 0; j < NREG; ++j) cand[j] &= ~ones[j];
-        }
+        kth = ((uint64_t)hi << 32) | lo;
     }
-    uint32_t hi = 0, lo = 0;
+    // survivors (exactly min(n, K)) -> LDS by prefix popcount, then one wave-wide sort
+    int base = 0;
 #pragma unroll
     for (int j = 0; j < NREG; ++j) {
-        if (cand[j]) {
-            const int src_lane = __ffsll((long long)cand[j]) - 1;
-            hi = __shfl((uint32_t)(key[j] >> 32), src_lane, kWave);
-            lo = __shfl((uint32_t)key[j], src_lane, kWave);
+        const bool keep = key[j] != 0ull && key[j] >= kth;
+        const uint64_t km = __ballot(keep);
+        if (km) {
+            if (keep) s_top[base + __popcll(km & ((1ull << lane) - 1ull))] = key[j];
+            base += __popcll(km);
         }
     }
-    return ((uint64_t)hi << 32) | lo;
+    const int kept = base;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint64_t k1 = lane < kept ? s_top[lane] : 0ull;
+    k1 = wave_sort_desc(k1);
+    if (lane < K) {
+        out_val[(size_t)q * K + lane] = k1 ? key_score(k1) : -INFINITY;
+        out_idx[(size_t)q * K + lane] = k1 ? key_id(k1) : -1;
+        for (int s = 1; s < n_out; ++s) {
+            out_val[((size_t)s * U + q) * K + lane] = -INFINITY;
+            out_idx[((size_t)s * U + q) * K + lane] = -1;
+        }
+    }
 }
 
 __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, int n_out, int K, int cap,
@@ -759,47 +810,10 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
     const int n_all = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, kWave));
     const int n = n_all < kSelRegs * 64 ? n_all : kSelRegs * 64;
     if (n_all > kSelRegs * 64 && lane == 0) *overflow = 1;
-    // element e of the gathered order lives in split s(e) at position e - offset(s); the addresses are resolved
-    // first (uniform loop over the splits), then all loads are issued back to back
-    size_t rel[kSelRegs];
-#pragma unroll
-    for (int j = 0; j < kSelRegs; ++j) rel[j] = (size_t)q * cap + (j * 64 + lane);
-    for (int s = 1; s < n_splits; ++s) {
-        const int off = __builtin_amdgcn_readlane(incl, s - 1);                // exclusive prefix of split s
-        if (off >= n) break;
-        const size_t base = ((size_t)s * U + q) * cap - off;
-#pragma unroll
-        for (int j = 0; j < kSelRegs; ++j)
-            if (j * 64 + lane >= off) rel[j] = base + (j * 64 + lane);
-    }
-    uint64_t key[kSelRegs];
-#pragma unroll
-    for (int j = 0; j < kSelRegs; ++j) key[j] = j * 64 + lane < n ? lists[rel[j]] : 0ull;
-    uint64_t kth = 0ull;
-    if (n >= K) kth = n <= 256 ? select_kth<4>(key, n, K, lane) : select_kth<kSelRegs>(key, n, K, lane);
-    // survivors (exactly min(n, K)) -> LDS by prefix popcount, then one wave-wide sort
-    int base = 0;
-#pragma unroll
-    for (int j = 0; j < kSelRegs; ++j) {
-        const bool keep = key[j] != 0ull && key[j] >= kth;
-        const uint64_t km = __ballot(keep);
-        if (km) {
-            if (keep) s_top[wid][base + __popcll(km & ((1ull << lane) - 1ull))] = key[j];
-            base += __popcll(km);
-        }
-    }
-    const int kept = base;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    uint64_t k1 = lane < kept ? s_top[wid][lane] : 0ull;
-    k1 = wave_sort_desc(k1);
-    if (lane < K) {
-        out_val[(size_t)q * K + lane] = k1 ? key_score(k1) : -INFINITY;
-        out_idx[(size_t)q * K + lane] = k1 ? key_id(k1) : -1;
-        for (int s = 1; s < n_out; ++s) {
-            out_val[((size_t)s * U + q) * K + lane] = -INFINITY;
-            out_idx[((size_t)s * U + q) * K + lane] = -1;
-        }
-    }
+    // the common case (a few hundred candidates) runs the 4-keys-per-lane instance: these kernels are bound by the
+    // CU's scalar unit and by registers, both proportional to the register count
+    if (n <= 256) select_user<4>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx);
+    else select_user<kSelRegs>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx);
 }
 
 // ----------------------------------------------------------------------------
@@ -1065,7 +1079,7 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
     auto plan = [&](int T, int &grid, int &slots) {
         const long long W = (long long)g.ublocks * T;
         long long G = resident;
-        if (G > W / 2) G = W / 2;                             // at least two tiles per block
+        if (G > W / 8) G = W / 8;                             // at least eight tiles per block (prologue, result slots)
         if (G > (long long)g.ublocks * 60) G = (long long)g.ublocks * 60;   // at most ~62 blocks per user block
         if (G < 1) G = 1;
         const long long chunk = W / G;                        // shortest range
