@@ -231,15 +231,15 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  *   c         the constant `rubi_c` set by update_c (model.py:313)
  *   mask_ptr  (dev) int32[U+1], mask_idx (dev) int32[*]: per query, ascending
  *              GLOBAL item ids to exclude (the user's train items); may be NULL
- *   n_splits  >= 1: the local shard is cut into n_splits contiguous ranges that
- *              are ranked by different workgroups (fills the chip when U is
- *              small); 0 = let the library choose
+ *   n_splits  >= 1: number of (U,K) result lists in out_val/out_idx; 0 = let the
+ *              library choose (macr_score_topk_splits(), 1 since ABI 5).  The ranking
+ *              balances its own grid over (query block, item tile) ranges; the merged
+ *              result of the whole shard is list 0, further lists hold only padding.
+ *              (n_splits > 1 still shapes the grid of the fallback kernel, below.)
  *   out_val (dev) fp32 [n_splits*U*K], out_idx (dev) int32 [n_splits*U*K]:
- *              per split, per query: K (score,id) pairs, score descending, ties
- *              by ascending id, unused slots (-inf, -1).  Feed to
- *              macr_topk_merge.  macr_score_topk_splits() tells n_splits chosen.
- *              Since ABI 5 the merged result of all splits is in split 0 and the other
- *              splits hold only padding (macr_topk_merge accepts both forms).
+ *              per list, per query: K (score,id) pairs, score descending, ties
+ *              by ascending id, unused slots (-inf, -1).  Feed to macr_topk_merge
+ *              (with the other shards' lists on several GPUs).
  *   workspace (dev) >= macr_score_topk_workspace_bytes(U, n_local, d) bytes, 256-B
  *              aligned: per-query thresholds, the (item tile, query) mask bitmap and the
  *              per-(split,query) candidate lists of the fixed-threshold stream (512 or
@@ -247,6 +247,11 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  * Score: NORMAL e_u.e_i ; RUBI_BOTH ((e_u.e_i - c) * sig_i) * sig_u, the dot
  * product being a k-ascending fp32 fma chain (gfx950 fp32 MFMA arithmetic).
  * d in {32,64,128,256}; 1 <= K <= MACR_MAX_TOPK.
+ * Launches: a sampling pass over every 8th item tile (per-query lower bound tau of
+ * the K-th best score), the listing pass over all tiles (items scoring >= tau go to
+ * per-query candidate lists), a selection kernel (exact top K of each list), and a
+ * fallback launch of the running-top-K kernel whose blocks return at once unless a
+ * candidate list overflowed (exact for any input).  No host synchronisation.
  * -------------------------------------------------------------------------*/
 int    macr_score_topk_splits(int U, int n_local, int d);
 size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
