@@ -595,19 +595,19 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
         if (acc[0] == 12345.f) *overflow = 1;
 #else
         float v[16];
-        bool hit = false;
+        uint64_t hit = 0ull;                                // OR of the compare masks: scalar unit, not VALU
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             v[r] = acc[r];
             if (KIND == MACR_SCORE_RUBI_BOTH) { v[r] = v[r] - c; v[r] = v[r] * sgi[r]; v[r] = v[r] * su; }
             if (MODE == kModeMax) cmax[r] = fmaxf(cmax[r], v[r]);
-            else hit |= v[r] >= tau_s;
+            else hit |= __ballot(v[r] >= tau_s);
         }
 #ifdef MACR_ABL_S_NOAPPEND
         if (v[3] == 12345.f) *overflow = 1;
-        hit = false;
+        hit = 0ull;
 #endif
-        if (MODE == kModeList && __any(hit)) {              // one wave-uniform branch per tile
+        if (MODE == kModeList && hit) {                     // one wave-uniform branch per tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (v[r] >= tau_s) {
