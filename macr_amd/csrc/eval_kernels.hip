@@ -1070,7 +1070,7 @@ extern "C" void macr_dbg_counters(unsigned long long *out) {
 namespace macr {
 // Launch geometry of the two streaming passes (see k_score_stream): grid sizes and the number of result slots a
 // user block can have (= blocks overlapping its tile range).
-struct StreamGeo { int ublocks, grid0, slots0, grid1, slots1; };
+struct StreamGeo { int ublocks, grid0, slots0, grid1, slots1, range1; };   // range1: longest tile range of pass 1
 static StreamGeo stream_geo(int U, int n_local, int d) {
     StreamGeo g;
     g.ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
@@ -1088,6 +1088,7 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
     };
     plan(T0, g.grid0, g.slots0);
     plan(T1, g.grid1, g.slots1);
+    g.range1 = (int)(((long long)g.ublocks * T1 + g.grid1 - 1) / g.grid1);
     return g;
 }
 
@@ -1210,6 +1211,13 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+        // A catalogue (shard) whose every tile range fits a candidate list needs no threshold: tau = -inf lists every unmasked item
+        // and the selection kernel ranks them -- no sampling pass, no k_tau.
+        const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
+        if (list_all) {
+            e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.tau), (int)0xff800000u, (size_t)U, st);   // -inf
+            MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: memset: %s", hipGetErrorString(e));
+        } else {
         pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits, item_offset,
                                             geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow);
         MACR_CHECK_LAUNCH("score_sample", st);
@@ -1221,6 +1229,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         else if (tau_regs <= 16) k_tau<16><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
         else k_tau<32><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
         MACR_CHECK_LAUNCH("tau", st);
+        }
         pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits, item_offset,
                                             geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow);
         MACR_CHECK_LAUNCH("score_stream", st);
