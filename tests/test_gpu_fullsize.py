@@ -21,19 +21,26 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def test_gowalla_size_eval(ops):
-    """configs[1]: 15 424 query users x 40 981 items, d=64, c=40, K=20."""
+SYNTH128 = dict(n_users=40000, n_items=30011, d=128, batch=8192, n_train=1600000, n_test_users=5000, test_per_user=8,
+                alpha=1e-3, beta=1e-3, lr=1e-3, regs=1e-5, c=40.0)
+
+
+@pytest.mark.parametrize("workload", ["gowalla", "ml10m", "synthetic-d128"])
+def test_fullsize_eval(ops, workload):
+    """configs[1] (15 424 query users x 40 981 items), configs[2] shapes (13 878 x 8 790) and a d=128 catalogue as in
+    configs[4]; c=40, K=20.  The oracle ranks every 97th user, properties cover all of them."""
     from macr_amd import synth
     from macr_amd.evaluator import Evaluator
-    cfg = synth.WORKLOADS["gowalla"]
+    cfg = SYNTH128 if workload == "synthetic-d128" else synth.WORKLOADS[workload]
+    d = cfg["d"]
     rs = np.random.RandomState(1)
-    P = (rs.standard_normal((cfg["n_users"], 64)) * 0.3).astype(np.float32)
+    P = (rs.standard_normal((cfg["n_users"], d)) * 0.3).astype(np.float32)
     pop = np.sort(rs.standard_normal(cfg["n_items"]))[::-1].astype(np.float32)       # popular items have low ids
-    Q = (rs.standard_normal((cfg["n_items"], 64)) * 0.3).astype(np.float32)
+    Q = (rs.standard_normal((cfg["n_items"], d)) * 0.3).astype(np.float32)
     Q[:, 0] += pop
     P[:, 0] = np.abs(P[:, 0])                        # scores rise and fall with popularity: adversarial stream order
-    w = (rs.standard_normal(64) * 0.3).astype(np.float32)
-    wu = (rs.standard_normal(64) * 0.3).astype(np.float32)
+    w = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    wu = (rs.standard_normal(d) * 0.3).astype(np.float32)
     users, mask, gt = synth.eval_problem(cfg, seed=3)
     ev = Evaluator(mask, gt, cfg["n_items"], torch.device("cuda"))
     uid, Pd, Qd, wd, wud = dev(users), dev(P), dev(Q), dev(w), dev(wu)

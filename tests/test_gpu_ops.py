@@ -336,6 +336,25 @@ def test_score_topk_overflowing_lists_fall_back_to_running_topk(ops, splits):
     assert np.array_equal(gv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
 
 
+def test_score_topk_all_scores_tie(ops):
+    """Zero user vectors: every item scores 0 (and -0), the threshold equals every score, the candidate lists
+    overflow and the fallback ranks by ascending id among the unmasked items."""
+    rs = np.random.RandomState(2)
+    U, N, d, K = 70, 6000, 64, 20
+    P = np.zeros((U, d), np.float32)
+    Q = rs.standard_normal((N, d)).astype(np.float32)
+    mask_lists = random_mask(rs, U, N, 6)
+    mask_lists[0] = list(range(0, 40, 2))                       # user 0 masks every other low id
+    mptr, midx = oracle.csr_from_lists(mask_lists)
+    mask = ops.CSR(dev(mptr), dev(midx))
+    want_v, want_i, _ = oracle.score_topk(oracle.SCORE_NORMAL, P, Q, K, mask=(mptr, midx))
+    vals, idx = ops.score_topk(oracle.SCORE_NORMAL, dev(P), None, dev(Q), K, mask=mask)
+    gv, gi, _ = ops.topk_merge(vals, idx)
+    assert np.array_equal(gi.cpu().numpy(), want_i)
+    assert np.array_equal(gi.cpu().numpy()[0], np.arange(1, 40, 2)[:K])
+    assert np.all(gv.cpu().numpy() == 0.0)
+
+
 def test_score_topk_forced_fallback_kernel(ops):
     """MACR_TOPK_FALLBACK=1 runs the running top-K kernel unconditionally: it stays covered by the parity suite."""
     import os, subprocess, sys
