@@ -1,8 +1,11 @@
 // Full-catalogue evaluator kernels for gfx950 (MI355X).
 //
-//   k_score_topk   U.I^T on the fp32 MFMA (v_mfma_f32_32x32x2_f32) with the
-//                  (y - c)*sig_i*sig_u epilogue, train-item masking and a running
-//                  per-user top-K -- the (U,N) score matrix never exists.
+//   k_score_stream U.I^T on the fp32 MFMA (v_mfma_f32_32x32x2_f32) with the
+//   k_tau          (y - c)*sig_i*sig_u epilogue and train-item masking, as a sampling pass
+//   k_select       (per-user threshold) and a listing pass (candidates above it), plus the
+//                  exact top-K selection -- the (U,N) score matrix never exists.
+//   k_score_topk   the same ranking with a running per-user top-K in LDS: the first design,
+//                  kept as the fallback that is exact for any score order.
 //   k_topk_scores  top-K of a materialised score matrix (drop-in for the reference's
 //                  c_top_k_array_index, tools.h:24).
 //   k_topk_merge   merge of per-split / per-GPU-shard top-K lists.
@@ -101,7 +104,9 @@ __device__ __forceinline__ void compact_buffer(uint64_t *keys, uint32_t *cnt, fl
 // l and l+32, each holding 16 of the tile's 32 item scores, so thresholding is 16
 // compares per lane with no cross-lane traffic.  Scores above the user's running
 // threshold are appended to a 64-entry LDS buffer; when it could overflow the wave
-// sorts it (bitonic over 64 lanes) and keeps the best K.
+// keeps the best K by a radix select on lane masks (compact_buffer).
+// Since ABI 5 this kernel is the FALLBACK of macr_score_topk: launched after the streaming
+// passes, it returns at once unless *run_flag says a candidate list overflowed.
 // ----------------------------------------------------------------------------
 template <int D, int KIND>
 __global__ __launch_bounds__(512, 2) void k_score_topk(
