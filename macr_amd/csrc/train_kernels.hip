@@ -1,8 +1,12 @@
 // Training-step kernels of the MACR hot path for gfx950 (MI355X).
 //
 // One step =  pair_fwd  ->  bxb (rubibceboth only)  ->  pair_bwd  ->  adam_dense
-// (normalbce fuses fwd+bwd into pair_normal).  What each kernel replaces in the
-// reference is cited at the kernel; the arithmetic follows SURVEY.md appendix A.
+// (normalbce fuses fwd+bwd into pair_normal).  In deferred mode (MACR_STEP_DEFER /
+// MACR_STEP_PENDING) the dense Adam pass of step t runs as extra blocks of the bxb
+// launch of step t+1 and pair_fwd looks one update ahead in registers:
+//   pair_fwd<PENDING>  ->  bxb+adam  ->  pair_bwd          (macr_mf_train_flush ends it)
+// What each kernel replaces in the reference is cited at the kernel; the arithmetic
+// follows SURVEY.md appendix A.
 //
 // Data layout: embedding tables are row-major fp32 [rows][d]; one row is
 // 4*LPR floats and is always touched as LPR lanes x float4 (a 256-B row at
