@@ -1044,17 +1044,28 @@ __global__ void k_metrics_mf(int U, int Kmax, const int32_t *__restrict__ rankin
     }
 }
 
-// column means in float64, one block per column, fixed-shape tree => deterministic
+// column means in float64, one 1024-thread block per column, fixed-shape tree => deterministic
 template <typename T>
-__global__ __launch_bounds__(256) void k_colmean(const T *__restrict__ in, int rows, int cols, double *__restrict__ out) {
-    __shared__ double red[4];
+__global__ __launch_bounds__(1024) void k_colmean(const T *__restrict__ in, int rows, int cols, double *__restrict__ out) {
+    __shared__ double red[16];
     const int cidx = blockIdx.x;
-    double s = 0;
-    for (int r = threadIdx.x; r < rows; r += 256) s += (double)in[(size_t)r * cols + cidx];
-    s = wave_sum_d(s);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;                  // four independent chains: loads stay in flight
+    int r = threadIdx.x;
+    for (; r + 3 * 1024 < rows; r += 4 * 1024) {
+        s0 += (double)in[(size_t)r * cols + cidx];
+        s1 += (double)in[(size_t)(r + 1024) * cols + cidx];
+        s2 += (double)in[(size_t)(r + 2048) * cols + cidx];
+        s3 += (double)in[(size_t)(r + 3072) * cols + cidx];
+    }
+    for (; r < rows; r += 1024) s0 += (double)in[(size_t)r * cols + cidx];
+    double s = wave_sum_d((s0 + s1) + (s2 + s3));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[cidx] = (red[0] + red[1] + red[2] + red[3]) / (double)rows;
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        out[cidx] = t / (double)rows;
+    }
 }
 
 }  // namespace macr
@@ -1344,9 +1355,9 @@ extern "C" int macr_colmean(const void *in, int in_is_f32, int rows, int cols, d
     hipStream_t st = as_stream(stream);
     MACR_REQUIRE(in && out && rows > 0 && cols > 0, MACR_E_INVALID, "colmean: bad arguments");
     if (in_is_f32)
-        k_colmean<float><<<cols, 256, 0, st>>>(static_cast<const float *>(in), rows, cols, out);
+        k_colmean<float><<<cols, 1024, 0, st>>>(static_cast<const float *>(in), rows, cols, out);
     else
-        k_colmean<double><<<cols, 256, 0, st>>>(static_cast<const double *>(in), rows, cols, out);
+        k_colmean<double><<<cols, 1024, 0, st>>>(static_cast<const double *>(in), rows, cols, out);
     MACR_CHECK_LAUNCH("colmean", st);
     return MACR_OK;
 }
