@@ -1019,28 +1019,35 @@ __global__ void k_metrics_foldout(int U, int K, const int32_t *__restrict__ rank
 
 // macr_mf/train.py:32-117 in float64: per query {precision, recall, ndcg, hit} x Ks.
 struct KsArg { int32_t k[8]; int n; };
-__global__ void k_metrics_mf(int U, int Kmax, const int32_t *__restrict__ rankings,
-                             const int32_t *__restrict__ cnt, const int32_t *__restrict__ gt_ptr,
-                             const int32_t *__restrict__ gt_idx, KsArg Ks, double *__restrict__ out) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per query: lane i owns rank position i (Kmax <= 32), so the membership searches and the log2 terms of a
+// query run side by side; sums are fixed-shape shuffle trees (deterministic).
+__global__ __launch_bounds__(256) void k_metrics_mf(int U, int Kmax, const int32_t *__restrict__ rankings,
+                                                    const int32_t *__restrict__ cnt, const int32_t *__restrict__ gt_ptr,
+                                                    const int32_t *__restrict__ gt_idx, KsArg Ks, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (u >= U) return;
-    const int32_t *rank = rankings + (size_t)u * Kmax;
     const int32_t *truth = gt_idx + gt_ptr[u];
     const int truth_len = gt_ptr[u + 1] - gt_ptr[u];
     const int len = cnt ? cnt[u] : Kmax;
+    const int item = lane < Kmax ? rankings[(size_t)u * Kmax + lane] : -1;
+    const bool hit = item >= 0 && in_sorted(truth, truth_len, item);
+    const double term = 1.0 / log2((double)(lane + 2));          // DCG discount of position `lane`
     for (int qk = 0; qk < Ks.n; ++qk) {
         const int K = Ks.k[qk];
         const int m = len < K ? len : K;
-        double hits = 0, dcg = 0, dcg_max = 0;
-        for (int i = 0; i < m; ++i)
-            if (rank[i] >= 0 && in_sorted(truth, truth_len, rank[i])) { hits += 1.0; dcg += 1.0 / log2((double)(i + 2)); }
         const int lim = truth_len < K ? truth_len : K;
-        for (int i = 0; i < lim; ++i) dcg_max += 1.0 / log2((double)(i + 2));
-        double *o = out + ((size_t)u * 4) * Ks.n;
-        o[0 * Ks.n + qk] = m > 0 ? hits / m : NAN;
-        o[1 * Ks.n + qk] = hits / truth_len;
-        o[2 * Ks.n + qk] = dcg_max != 0 ? dcg / dcg_max : 0.0;
-        o[3 * Ks.n + qk] = hits > 0 ? 1.0 : 0.0;
+        const bool mine = hit && lane < m;
+        const double hits = (double)__popcll(__ballot(mine));
+        const double dcg = wave_sum_d(mine ? term : 0.0);
+        const double dcg_max = wave_sum_d(lane < lim ? term : 0.0);
+        if (lane == 0) {
+            double *o = out + ((size_t)u * 4) * Ks.n;
+            o[0 * Ks.n + qk] = m > 0 ? hits / m : NAN;
+            o[1 * Ks.n + qk] = hits / truth_len;
+            o[2 * Ks.n + qk] = dcg_max != 0 ? dcg / dcg_max : 0.0;
+            o[3 * Ks.n + qk] = hits > 0 ? 1.0 : 0.0;
+        }
     }
 }
 
@@ -1338,6 +1345,7 @@ extern "C" int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const i
                                double *out, void *stream) {
     hipStream_t st = as_stream(stream);
     MACR_REQUIRE(U > 0 && Kmax >= 1, MACR_E_INVALID, "metrics_mf: U=%d Kmax=%d", U, Kmax);
+    MACR_REQUIRE(Kmax <= 64, MACR_E_UNSUPPORTED, "metrics_mf: Kmax=%d > 64", Kmax);
     MACR_REQUIRE(rankings && gt_ptr && gt_idx && Ks && out, MACR_E_INVALID, "metrics_mf: null pointer");
     MACR_REQUIRE(nK >= 1 && nK <= 8, MACR_E_UNSUPPORTED, "metrics_mf: nK=%d outside [1,8]", nK);
     KsArg ka;
@@ -1346,7 +1354,7 @@ extern "C" int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const i
         MACR_REQUIRE(Ks[q] >= 1 && Ks[q] <= Kmax, MACR_E_INVALID, "metrics_mf: Ks[%d]=%d outside [1,%d]", q, Ks[q], Kmax);
         ka.k[q] = Ks[q];
     }
-    k_metrics_mf<<<(U + 127) / 128, 128, 0, st>>>(U, Kmax, rankings, cnt, gt_ptr, gt_idx, ka, out);
+    k_metrics_mf<<<(U + 3) / 4, 256, 0, st>>>(U, Kmax, rankings, cnt, gt_ptr, gt_idx, ka, out);
     MACR_CHECK_LAUNCH("metrics_mf", st);
     return MACR_OK;
 }
