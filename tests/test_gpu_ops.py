@@ -336,6 +336,43 @@ def test_score_topk_overflowing_lists_fall_back_to_running_topk(ops, splits):
     assert np.array_equal(gv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_score_topk_random_shapes(ops, seed):
+    """Randomised shapes through the streaming ranking: query counts around the 256-user block, catalogues around
+    the 32-item tile / the 8-tile sampling stride / the list-everything limit, every d, K up to 32, shards with
+    an offset, heavy and empty masks, duplicated item rows (exact ties)."""
+    rs = np.random.RandomState(1000 + seed)
+    U = int(rs.choice([1, 3, 31, 33, 255, 257, 300, 700, 1500]))
+    N = int(rs.choice([5, 31, 33, 255, 257, 1024, 1025, 1100, 2047, 2500, 4100, 9000]))
+    d = int(rs.choice([32, 64, 64, 64, 128, 256]))
+    K = int(rs.choice([1, 5, 20, 20, 32]))
+    off = int(rs.choice([0, 0, 1000]))
+    kind = int(rs.choice([oracle.SCORE_NORMAL, oracle.SCORE_RUBI_BOTH]))
+    n_users = U + 17
+    P = (rs.standard_normal((n_users, d)) * 0.5).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.5).astype(np.float32)
+    if N > 40:
+        Q[N // 2:N // 2 + 10] = Q[:10]                              # exact ties far apart
+    w = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    wu = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    user_ids = rs.permutation(n_users)[:U].astype(np.int32)
+    per_user = int(rs.choice([0, 3, 40]))
+    mask_lists = random_mask(rs, U, N, per_user, heavy=(0,) if (N > 40 and per_user) else ()) if per_user else [[] for _ in range(U)]
+    mask_lists = [[x + off for x in row] for row in mask_lists]
+    mptr, midx = oracle.csr_from_lists(mask_lists)
+    sig_i_hip = ops.branch_sigmoid(dev(Q), dev(w))
+    sig_u_hip = ops.branch_sigmoid(dev(P), dev(wu), dev(user_ids))
+    sig_i, sig_u = sig_i_hip.cpu().numpy(), sig_u_hip.cpu().numpy()
+    c = float(rs.choice([0.0, 3.0, 40.0]))
+    want_v, want_i, want_c = oracle.score_topk(kind, P[user_ids], Q, K, sig_u, sig_i, c, (mptr, midx), off)
+    mask = ops.CSR(dev(mptr), dev(midx if len(midx) else np.zeros(1, np.int32)))
+    vals, idx = ops.score_topk(kind, dev(P), dev(user_ids), dev(Q), K, sig_u_hip, sig_i_hip, c, mask, off)
+    gv, gi, gc = ops.topk_merge(vals, idx)
+    assert np.array_equal(gi.cpu().numpy(), want_i), (U, N, d, K, off, kind, per_user)
+    assert np.array_equal(gc.cpu().numpy(), want_c)
+    assert np.array_equal(gv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+
+
 def test_score_topk_all_scores_tie(ops):
     """Zero user vectors: every item scores 0 (and -0), the threshold equals every score, the candidate lists
     overflow and the fallback ranks by ascending id among the unmasked items."""
