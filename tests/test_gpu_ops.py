@@ -131,6 +131,41 @@ def test_mf_deferred_adam_equals_complete_steps(ops, B, d, n_users, n_items, sor
     np.testing.assert_array_equal(lazy.adam_pow.cpu().numpy(), eager.adam_pow.cpu().numpy())
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_mf_deferred_random_shapes(ops, seed):
+    """Random batch sizes (around the 256-row (B,B) tile and the 16-triple backward chunk), tables, widths and
+    duplicate patterns: deferred steps and complete steps agree step by step and after the flush."""
+    rs = np.random.RandomState(500 + seed)
+    B = int(rs.choice([1, 15, 17, 255, 256, 257, 1000, 1024, 3000, 4096, 5000]))
+    d = int(rs.choice([32, 64, 64, 128, 256]))
+    n_users = int(rs.choice([B + 1, 2 * B + 7, 5000])) if B > 1 else 9
+    n_items = int(rs.choice([3, 50, 700, 4000]))
+    P = (rs.standard_normal((n_users, d)) * 0.3).astype(np.float32)
+    Q = (rs.standard_normal((n_items, d)) * 0.3).astype(np.float32)
+    w = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    wu = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    hyper = ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, 1024)
+    kind = oracle.LOSS_RUBIBCEBOTH
+    lazy = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), hyper, B)
+    eager = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), hyper, B)
+    for t in range(4):
+        u = rs.choice(n_users, B, replace=False).astype(np.int32)
+        i = (rs.zipf(1.3, B) % n_items).astype(np.int32)            # heavy duplicates among the positives
+        j = rs.randint(0, n_items, B).astype(np.int32)
+        if rs.rand() < 0.5:
+            o = np.argsort(i, kind="stable"); u, i, j = u[o], i[o], j[o]
+        a = lazy.step(kind, dev(u), dev(i), dev(j), defer=True).cpu().numpy()
+        b = eager.step(kind, dev(u), dev(i), dev(j)).cpu().numpy()
+        assert np.isfinite(a).all()
+        np.testing.assert_allclose(a, b, rtol=5e-6, atol=0, err_msg=str((B, d, n_users, n_items, t)))
+    lazy.flush()
+    for name in ("P", "Q", "w", "wu", "mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu"):
+        x, y = getattr(lazy, name).cpu().numpy(), getattr(eager, name).cpu().numpy()
+        np.testing.assert_allclose(x, y, rtol=3e-4, atol=1e-7 + 2e-5 * np.abs(y).max(), err_msg=name)
+    assert float(lazy.gP.abs().max()) == 0.0 and float(lazy.gQ.abs().max()) == 0.0
+    assert int(lazy.tP.sum()) == 0 and int(lazy.tQ.sum()) == 0
+
+
 def test_mf_deferred_mode_flushes_on_batch_size_change(ops):
     P, Q, w, wu, u, i, j = make_problem(5, 300, 50, 64, 200)
     hyper = ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, 1024)
