@@ -15,6 +15,8 @@
 // cross-lane shuffles.
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace macr {
 
 // Timing probes for tools/ablate.py (never defined in the product build).
@@ -304,8 +306,9 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
 // rows; R rows per lane amortise the four rotations over R pairs.  Row sums never leave
 // their lane.  No LDS traffic, no atomics in the inner loop.
 // The X and Y halves of a pair are the two lanes of packed fp32 math (v_pk_mul/add/fma_f32:
-// two results per lane per issue), which leaves the kernel bound by its eight
-// transcendentals per pair (2 v_exp, 4 v_rcp, 2 v_log at a fraction of the VALU rate).
+// two results per lane per issue), which leaves the kernel bound by its transcendentals
+// (~8.5 cycles per wave64 each): 4 per pair on the FAST path, 6 on the EXACT path (see
+// run_tile below; the reference writes 8: 2 exp, 2+2 rcp, 2 log).
 // Block = 4 waves = (64*R) rows x 256 columns (one 64-column tile per wave); the waves' row
 // sums meet in LDS once.   rowpart [ncb][2][Bp], colpart [nrb][2][Bp], lpart [nrb*ncb]
 // ----------------------------------------------------------------------------
@@ -354,45 +357,76 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
     const bool cok = FULL || c < B;
     v2f cn = {cok ? p[c] : 0.f, cok ? n[c] : 0.f};
     v2f acc = {0.f, 0.f}, l2 = {0.f, 0.f};     // column sums travelling with cn; log2 terms (scaled by ln2 at the end)
+    // Two forms of the pair arithmetic.  EXACT follows the reference operation by operation: s = 1/(1+e^-z), then
+    // s+eps and (1-s)+eps with 1-s by subtraction (6 transcendentals with the shared log/rcp of tx*ty).  FAST works
+    // on numerators and denominators, with ex = e^-x, dx = 1+ex, nx = 1+eps*dx (so s+eps = nx/dx) and ey, dy,
+    // ny = ey+eps*dy (so (1-s)+eps = ny/dy):
+    //     log(tx*ty) = log(N^2 * r),  f'(x) = -ex*r*(dy*ny),  g'(y) = ey*r*(dx*nx),   N = nx*ny,  r = 1/(dx*nx*dy*ny)
+    // -- 4 transcendentals (2 exp, 1 rcp, 1 log).  It is the same real function; in fp32 it differs from EXACT where
+    // the reference's subtraction 1-s loses bits, i.e. by ~6e-8*e^y relative on (1-s): a wave takes FAST only when
+    // every column of its tile has -20 <= p, -20 <= n <= 3 (a, b are in (0,1), so |x| <= |p|, |y| <= |n|): no
+    // overflow of the products, and EXACT/FAST agree to ~1e-6 relative per term, below the 1e-5 loss tolerance.
+    auto run_tile = [&](auto fast_t) {
+        constexpr bool FAST = decltype(fast_t)::value;
 #pragma unroll 2
-    for (int k = 0; k < 64; ++k) {
-        bool colok = true;
-        if (!FULL) colok = cb * 256 + wid * 64 + ((lane + k) & 63) < B;
+        for (int k = 0; k < 64; ++k) {
+            bool colok = true;
+            if (!FULL) colok = cb * 256 + wid * 64 + ((lane + k) & 63) < B;
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const v2f z = cn * abs_[q];                                        // -log2(e) * {x, y}
-            const v2f dd = v2f{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + one;
-            const v2f s = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};   // sigmoid(x), sigmoid(y)
-            const v2f om = one - s;
+            for (int q = 0; q < R; ++q) {
+                const v2f z = cn * abs_[q];                                    // -log2(e) * {x, y}
+                v2f lg, g;
+                if (FAST) {
+                    const v2f e2 = {__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};   // e^-x, e^-y
+                    const v2f dd = e2 + one;
+                    const v2f nn = __builtin_elementwise_fma(eps, dd, v2f{1.0f, e2.y});
+                    const v2f A = dd * nn;
+                    const float r = __builtin_amdgcn_rcpf(A.x * A.y);
+                    const float N = nn.x * nn.y;
+                    lg = v2f{__builtin_amdgcn_logf((N * N) * r), 0.f};
+                    const v2f er = e2 * r;
+                    g = v2f{er.x * A.y, er.y * A.x};
+                } else {
+                    const v2f dd = v2f{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + one;
+                    const v2f s = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};   // sigmoid(x), sigmoid(y)
+                    const v2f om = one - s;
 #ifdef MACR_ABL_BXB_8TRANS
-            const v2f tt = v2f{s.x, om.y} + eps;                              // sig(x)+eps, (1-sig(y))+eps
-            v2f lg = {__builtin_amdgcn_logf(tt.x), __builtin_amdgcn_logf(tt.y)};
-            const v2f rt = {__builtin_amdgcn_rcpf(tt.x), __builtin_amdgcn_rcpf(tt.y)};
-            v2f g = (s * om) * rt;
+                    const v2f tt = v2f{s.x, om.y} + eps;                      // sig(x)+eps, (1-sig(y))+eps
+                    lg = v2f{__builtin_amdgcn_logf(tt.x), __builtin_amdgcn_logf(tt.y)};
+                    const v2f rt = {__builtin_amdgcn_rcpf(tt.x), __builtin_amdgcn_rcpf(tt.y)};
+                    g = (s * om) * rt;
 #else
-            // tx = sig(x)+eps, ty = (1-sig(y))+eps.  Only log(tx)+log(ty) and the two reciprocals are needed: ONE
-            // logarithm and ONE reciprocal of the product tx*ty (>= 1e-20, no underflow) serve both halves:
-            // 1/tx = ty/(tx*ty).  Six transcendentals per pair instead of eight.
-            const v2f ts = s + eps, tom = om + eps;                           // .x of ts and .y of tom are used
-            const float txy = ts.x * tom.y;
-            v2f lg = {__builtin_amdgcn_logf(txy), 0.f};
-            const float r2 = __builtin_amdgcn_rcpf(txy);
-            const v2f h = (s * om) * r2;
-            v2f g = {h.x * tom.y, h.y * ts.x};
+                    // tx = sig(x)+eps, ty = (1-sig(y))+eps.  Only log(tx)+log(ty) and the two reciprocals are needed:
+                    // ONE logarithm and ONE reciprocal of the product tx*ty (>= 1e-20, no underflow) serve both
+                    // halves: 1/tx = ty/(tx*ty).
+                    const v2f ts = s + eps, tom = om + eps;                   // .x of ts and .y of tom are used
+                    const float txy = ts.x * tom.y;
+                    lg = v2f{__builtin_amdgcn_logf(txy), 0.f};
+                    const float r2 = __builtin_amdgcn_rcpf(txy);
+                    const v2f h = (s * om) * r2;
+                    g = v2f{h.x * tom.y, h.y * ts.x};
 #endif
-            // g = {-f'(x), g'(y)}: f'(x) = -s(1-s)/(s+eps), g'(y) = s(1-s)/((1-s)+eps); the sign of the x half is
-            // applied once, after the loops
-            if (!FULL) {
-                const bool ok = rok[q] && colok;
-                lg = ok ? lg : v2f{0.f, 0.f};
-                g = ok ? g : v2f{0.f, 0.f};
+                }
+                // g = {-f'(x), g'(y)}: f'(x) = -s(1-s)/(s+eps), g'(y) = s(1-s)/((1-s)+eps); the sign of the x half
+                // is applied once, after the loops
+                if (!FULL) {
+                    const bool ok = rok[q] && colok;
+                    lg = ok ? lg : v2f{0.f, 0.f};
+                    g = ok ? g : v2f{0.f, 0.f};
+                }
+                l2 += lg;
+                dab[q] = __builtin_elementwise_fma(g, cn, dab[q]);
+                acc = __builtin_elementwise_fma(g, ab[q], acc);
             }
-            l2 += lg;
-            dab[q] = __builtin_elementwise_fma(g, cn, dab[q]);
-            acc = __builtin_elementwise_fma(g, ab[q], acc);
+            cn.x = wave_rol1(cn.x); cn.y = wave_rol1(cn.y); acc.x = wave_rol1(acc.x); acc.y = wave_rol1(acc.y);
         }
-        cn.x = wave_rol1(cn.x); cn.y = wave_rol1(cn.y); acc.x = wave_rol1(acc.x); acc.y = wave_rol1(acc.y);
-    }
+    };
+#ifdef MACR_ABL_BXB_EXACT
+    const bool fast = false;
+#else
+    const bool fast = !__any(!(cn.x >= -20.0f) || !(cn.y >= -20.0f) || !(cn.y <= 3.0f));   // (NaN -> exact path)
+#endif
+    if (fast) run_tile(std::true_type{}); else run_tile(std::false_type{});
     if (cok) {                                  // home again: column c over this wave's 64*R rows
         colpart[((size_t)rb * 2 + 0) * Bp + c] = -acc.x;
         colpart[((size_t)rb * 2 + 1) * Bp + c] = acc.y;

@@ -85,6 +85,31 @@ def test_mf_train_step_matches_oracle(ops, kind, B, d, n_users, n_items):
         assert np.array_equal(state.w.cpu().numpy(), w) and np.array_equal(state.wu.cpu().numpy(), wu)
 
 
+@pytest.mark.parametrize("scale", [0.45, 0.6, 1.2])
+@pytest.mark.parametrize("B", [300, 4096])
+def test_mf_rubibceboth_large_logits(ops, scale, B):
+    """The (B,B) kernel takes its 4-transcendental form only for column tiles with -20 <= p, -20 <= n <= 3 and the
+    operation-by-operation form otherwise.  Larger embeddings put tiles on both sides of that test (scale 0.6: dot
+    products of std ~3) or almost all on the exact side (1.2: std ~12, saturated sigmoids); loss and gradients must
+    follow the oracle (which mirrors the reference's 1-sigmoid subtraction) everywhere."""
+    d, n_users, n_items = 64, 5000, 900
+    P, Q, w, wu, u, i, j = make_problem(int(scale * 100) + B, n_users, n_items, d, B, scale=scale)
+    alpha, beta, decay, lr, bs = 1e-2, 1e-3, 1e-5, 1e-3, 1024
+    st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
+    Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
+    n = np.einsum("bd,bd->b", P[u], Q[j])
+    assert (scale < 1.0) or (np.abs(n) > 3).mean() > 0.5             # the exact side is really exercised
+    state = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), ops.make_hyper(lr, decay, alpha, beta, bs), B)
+    want = oracle.mf_train_step(oracle.LOSS_RUBIBCEBOTH, u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, bs)
+    got = state.step(oracle.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+    for name, gm, om in (("P", state.mP, st.m[0]), ("Q", state.mQ, st.m[1])):
+        g_hip, g_orc = gm.cpu().numpy() / 0.1, om / 0.1
+        np.testing.assert_allclose(g_hip, g_orc, rtol=5e-4, atol=2e-6 * np.abs(g_orc).max(), err_msg=name)
+    np.testing.assert_allclose(state.mw.cpu().numpy(), st.m[2], rtol=5e-4, atol=2e-6 * np.abs(st.m[2]).max())
+    np.testing.assert_allclose(state.mwu.cpu().numpy(), st.m[3], rtol=5e-4, atol=2e-6 * np.abs(st.m[3]).max())
+
+
 @pytest.mark.parametrize("B,d,n_users,n_items,sort", [(96, 64, 300, 50, False), (257, 64, 300, 50, True),
                                                       (1024, 64, 13485, 744, True), (64, 32, 100, 40, True),
                                                       (128, 128, 500, 300, False), (64, 256, 100, 40, True),
