@@ -220,9 +220,11 @@ def main():
         torch.cuda.synchronize(); barrier()
         ev_elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
         eval_users_per_s = len(users) * args.eval_reps / ev_elapsed
+        ev.use_graph = False            # per-kernel events need the launches themselves, not the graph replay
         ops.timing_begin()
         run_eval()
         emarks = ops.timing_end()
+        ev.use_graph = True
         ek = {}
         for name, ms in emarks:
             ek[name] = ek.get(name, 0.0) + max(ms - 1e-3 * event_overhead_us, 0.0)

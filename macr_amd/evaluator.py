@@ -27,6 +27,9 @@ class Evaluator(object):
         self.device = device
         self.mask = ops.CSR.from_lists(mask_lists, device)
         self.max_queries_per_pass = 131072       # bounds the ranking workspace (~1.5 GB of candidate lists)
+        self.use_graph = True                    # replay the evaluation as one HIP graph (see _means)
+        self._graphs = {}
+        self._graph_misses = 0
         self.gt = ops.CSR.from_lists(gt_lists, device)
 
     # ------------------------------------------------------------------ ranking
@@ -66,11 +69,43 @@ class Evaluator(object):
     def test_mf(self, kind, users_tab, user_ids, items_tab, Ks, w=None, wu=None, c=0.0):
         """-> {'precision','recall','ndcg','hit_ratio'}: np.ndarray(len(Ks)) float64, the mean over the
         query users (train.py:286-290 accumulates re[...]/n_test_users)."""
-        Kmax = max(Ks)
-        _, idx, cnt = self.rank(kind, users_tab, user_ids, items_tab, Kmax, w, wu, c)
-        per_user = ops.metrics_mf(idx, cnt, self.gt, Ks)            # (U,4,nK) float64
-        m = ops.colmean(per_user).cpu().numpy()
+        m = self._means("mf", kind, users_tab, user_ids, items_tab, tuple(Ks), w, wu, c).cpu().numpy()
         return {'precision': m[0].copy(), 'recall': m[1].copy(), 'ndcg': m[2].copy(), 'hit_ratio': m[3].copy()}
+
+    def _mf_means(self, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
+        _, idx, cnt = self.rank(kind, users_tab, user_ids, items_tab, max(Ks), w, wu, c)
+        per_user = ops.metrics_mf(idx, cnt, self.gt, list(Ks))      # (U,4,nK) float64
+        return ops.colmean(per_user)
+
+    def _means(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
+        """The device part of an evaluation.  An evaluator ranks the same queries against the same (in-place updated)
+        tables every epoch, and the ~14 launches of one evaluation are issued from Python between two host
+        synchronisations: on one GPU the sequence is captured once into a HIP graph and replayed (one launch instead
+        of ~90 us of launch gaps per evaluation).  Anything that changes the sequence -- other tensors, K, c -- is
+        another graph; `use_graph = False` (or several ranks) runs the launches directly."""
+        fn = self._mf_means if flavour == "mf" else self._lgcn_means
+        if not self.use_graph or sharding.world()[1] > 1:
+            return fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
+        key = (flavour, kind, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
+               Ks, None if w is None else w.data_ptr(), None if wu is None else wu.data_ptr(), float(c),
+               torch.cuda.current_stream().cuda_stream)
+        entry = self._graphs.get(key)
+        if entry is None:
+            # capturing costs about two evaluations: callers that keep changing the sequence (a c sweep evaluates
+            # dozens of c values per epoch) are better off launching directly
+            self._graph_misses += 1
+            if self._graph_misses > 6:
+                self.use_graph = False
+                self._graphs.clear()
+                return fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
+            fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)          # warm-up: allocations, caches, attributes
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
+            entry = self._graphs[key] = (g, out, (users_tab, user_ids, items_tab, w, wu))     # keep the inputs alive
+        entry[0].replay()
+        return entry[1]
 
     # ------------------------------------------------------------------ LightGCN flavour
     def test_lgcn(self, kind, users_tab, user_ids, items_tab, Ks, w=None, wu=None, c=0.0):
@@ -78,10 +113,14 @@ class Evaluator(object):
         metrics, HR := 1[recall@k != 0], mean over users, columns Ks-1 in ascending-K order."""
         top_show = np.sort(np.asarray(Ks))
         max_top = int(top_show.max())
-        _, idx, _ = self.rank(kind, users_tab, user_ids, items_tab, max_top, w, wu, c, fill_masked=True)
-        per_user = ops.metrics_foldout(idx, self.gt, hr_in_ap_slot=True)      # (U,5*max_top) fp32
-        final = ops.colmean(per_user).cpu().numpy().reshape(5, max_top)[:, top_show - 1]
+        final = self._means("lgcn", kind, users_tab, user_ids, items_tab, tuple(Ks), w, wu, c).cpu().numpy()
+        final = final.reshape(5, max_top)[:, top_show - 1]
         return {'hr': final[2].copy(), 'recall': final[1].copy(), 'ndcg': final[3].copy()}
+
+    def _lgcn_means(self, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
+        _, idx, _ = self.rank(kind, users_tab, user_ids, items_tab, max(Ks), w, wu, c, fill_masked=True)
+        per_user = ops.metrics_foldout(idx, self.gt, hr_in_ap_slot=True)      # (U,5*max_top) fp32
+        return ops.colmean(per_user)
 
 
 def eval_score_matrix_foldout(score_matrix, test_items, top_k=20, thread_num=None):

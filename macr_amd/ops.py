@@ -373,5 +373,10 @@ class LGCNState(object):
     def propagated(self):
         """ua_embeddings / ia_embeddings (LightGCN.py:130) -- cached until the next step."""
         if self._E is None:
-            self._E = lgcn_propagate(self.adj, self.T, self.n_layers)
+            # persistent buffers: the evaluator replays its launches as a graph keyed on tensor addresses
+            if getattr(self, "_E_buf", None) is None:
+                self._E_buf = torch.empty_like(self.T)
+                self._E_work = torch.empty(_lib.lib().macr_lgcn_work_floats(self.T.shape[0], self.d, self.adj._plan_ptrs()[1]),
+                                           dtype=_f32, device=self.T.device)
+            self._E = lgcn_propagate(self.adj, self.T, self.n_layers, out=self._E_buf, work=self._E_work)
         return self._E
