@@ -103,7 +103,12 @@ class Evaluator(object):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
-            entry = self._graphs[key] = (g, out, (users_tab, user_ids, items_tab, w, wu))     # keep the inputs alive
+            # the graph bakes in the addresses of everything it touched: keep the inputs and the cached scratch
+            # (ranking workspace, mask bitmaps) alive for as long as the graph exists, whatever the caches do later
+            keep = [users_tab, user_ids, items_tab, w, wu, ops._topk_ws_cache.get(items_tab.device)]
+            for csr in [self.mask] + list(self.mask.__dict__.get("_row_ranges", {}).values()):
+                keep.extend(csr.__dict__.get("_mask_bits", {}).values())
+            entry = self._graphs[key] = (g, out, keep)
         entry[0].replay()
         return entry[1]
 

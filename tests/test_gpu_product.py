@@ -227,3 +227,44 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert b["n_gpus"] == 2 and b["value"] > 0 and b["config"]["global_batch"] == 2 * a["config"]["global_batch"]
     for k, v in a["eval_metrics"].items():            # same model (rank 0's), item-sharded: same ranking metrics
         assert abs(b["eval_metrics"][k] - v) <= 2e-3 * max(abs(v), 1e-3), (k, v, b["eval_metrics"][k])
+
+
+def test_evaluator_graphs_survive_scratch_reallocation(ops):
+    """Evaluations are replayed as HIP graphs that bake in the addresses of the shared ranking workspace and of the
+    cached mask bitmaps; a later, larger evaluator makes the caches allocate new buffers.  The first evaluator's
+    graph must keep working on its own (kept-alive) scratch, and in-place table updates must show in the replays."""
+    from macr_amd.evaluator import Evaluator
+    rs = np.random.RandomState(3)
+    d, n_items = 64, 3000
+    P = dev((rs.standard_normal((6000, d)) * 0.4).astype(np.float32))
+    Q = dev((rs.standard_normal((n_items, d)) * 0.4).astype(np.float32))
+    w, wu = dev((rs.standard_normal(d) * 0.3).astype(np.float32)), dev((rs.standard_normal(d) * 0.3).astype(np.float32))
+
+    def mk(U, seed):
+        r = np.random.RandomState(seed)
+        users = np.sort(r.choice(6000, U, replace=False)).astype(np.int32)
+        mask = [sorted(r.choice(n_items, 20, replace=False).tolist()) for _ in range(U)]
+        gt = [sorted(r.choice(n_items, 5, replace=False).tolist()) for _ in range(U)]
+        return Evaluator(mask, gt, n_items, torch.device("cuda", torch.cuda.current_device())), dev(users)
+
+    def direct(ev, uid):
+        ev2 = Evaluator.__new__(Evaluator); ev2.__dict__.update(ev.__dict__); ev2.use_graph = False
+        return ev2.test_mf(1, P, uid, Q, [20], w, wu, 40.0)
+
+    small, uid_s = mk(300, 1)
+    a1 = small.test_mf(1, P, uid_s, Q, [20], w, wu, 40.0)            # captured
+    big, uid_b = mk(5000, 2)
+    b1 = big.test_mf(1, P, uid_b, Q, [20], w, wu, 40.0)              # larger workspace replaces the cached one
+    junk = [torch.full((1 << 20,), 7.0, device="cuda") for _ in range(8)]   # reuse whatever was freed
+    a2 = small.test_mf(1, P, uid_s, Q, [20], w, wu, 40.0)            # replay of the first graph
+    for k in a1:
+        assert np.array_equal(a1[k], a2[k]), k
+        assert np.array_equal(a1[k], direct(small, uid_s)[k]), k
+        assert np.array_equal(b1[k], direct(big, uid_b)[k]), k
+    Q.mul_(-1.0)                                                     # tables change in place between evaluations
+    a3 = small.test_mf(1, P, uid_s, Q, [20], w, wu, 40.0)
+    want = direct(small, uid_s)
+    for k in a3:
+        assert np.array_equal(a3[k], want[k]), k
+    assert any(not np.array_equal(a3[k], a1[k]) for k in a3)
+    del junk
