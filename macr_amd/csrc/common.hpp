@@ -118,6 +118,17 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
     return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
+// Fill n 32-bit words.  Used instead of hipMemsetAsync everywhere a call sequence may be captured into a HIP graph:
+// memset nodes lose their effect from the second replay on (ROCm 7.2, tools/graph_memset_check.py).
+static __global__ __launch_bounds__(256) void k_fill_words(uint32_t *__restrict__ p, size_t n, uint32_t value) {
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < n; w += (size_t)gridDim.x * blockDim.x) p[w] = value;
+}
+static inline void fill_words(void *p, size_t n_words, uint32_t value, hipStream_t st) {
+    if (!n_words) return;
+    size_t g = (n_words + 256 * 16 - 1) / (256 * 16);
+    k_fill_words<<<(unsigned)(g < 4096 ? g : 4096), 256, 0, st>>>(static_cast<uint32_t *>(p), n_words, value);
+}
+
 // Bitonic sort of one key per lane across the 64 lanes of a wave, DESCENDING by lane index
 // (lane 0 ends up with the largest key).
 __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key) {

@@ -435,6 +435,20 @@ struct StreamCfg {
     static constexpr size_t smem = (size_t)2 * kTileItems * RS * 4 + 2 * kTileItems * 4 + kUsersPerBlock * 4;
 };
 
+// Initialises the head of the ranking workspace in ONE launch: [0, n_zero) words <- 0 (counts, flags), the next n_tau
+// words <- tau_bits when set_tau (the -inf thresholds of the list-everything path), the next n_max words <- all-ones
+// (NaN: "this class saw nothing").  A kernel, not hipMemsetAsync: memset nodes of a captured HIP graph lose their
+// effect from the second replay on (ROCm 7.2, tools/graph_memset_check.py), and the evaluator replays this sequence.
+__global__ __launch_bounds__(256) void k_topk_ws_init(uint32_t *__restrict__ base, size_t n_zero, size_t n_tau,
+                                                      uint32_t tau_bits, int set_tau, size_t n_max) {
+    const size_t total = n_zero + n_tau + n_max;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
+        if (w < n_zero) base[w] = 0u;
+        else if (w < n_zero + n_tau) { if (set_tau) base[w] = tau_bits; }
+        else base[w] = 0xffffffffu;
+    }
+}
+
 // mask_bits[tile][user] |= 1 << (item % 32) for every masked item of the shard; one wave per user.
 __global__ __launch_bounds__(256) void k_mask_bits(int U, int n_local, const int32_t *__restrict__ mask_ptr,
                                                    const int32_t *__restrict__ mask_idx, int item_offset,
@@ -1159,8 +1173,7 @@ extern "C" int macr_mask_bits_build(int U, int n_local, const int32_t *mask_ptr,
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "mask_bits_build: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(mask_ptr && mask_idx && mask_bits, MACR_E_INVALID, "mask_bits_build: null pointer");
     hipStream_t st = as_stream(stream);
-    hipError_t me = hipMemsetAsync(mask_bits, 0, macr_mask_bits_bytes(U, n_local), st);
-    MACR_REQUIRE(me == hipSuccess, MACR_E_LAUNCH, "mask_bits_build: memset: %s", hipGetErrorString(me));
+    fill_words(mask_bits, macr_mask_bits_bytes(U, n_local) / 4, 0u, st);
     k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, mask_bits);
     MACR_CHECK_LAUNCH("mask_bits", st);
     return MACR_OK;
@@ -1212,15 +1225,23 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
     TopkWs ws = carve_topk_ws(workspace, U, n_local, geo);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "score_topk: workspace %zu < %zu bytes", workspace_bytes,
                  ws.bytes);
-    hipError_t me = hipMemsetAsync(workspace, 0, ws.header_bytes, st);          // counts, flag, shared_thr
-    if (me == hipSuccess) me = hipMemsetAsync(ws.maxima, 0xff, ws.maxima_bytes, st);     // NaN: slot saw nothing
-    MACR_REQUIRE(me == hipSuccess, MACR_E_LAUNCH, "score_topk: memset: %s", hipGetErrorString(me));
+    // workspace head: counts, flag, shared_thr <- 0; tau <- -inf on the list-everything path; maxima <- NaN
+    const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
+    {
+        const size_t n_zero = ws.header_bytes / 4;
+        const size_t n_tau = (reinterpret_cast<char *>(ws.maxima) - reinterpret_cast<char *>(ws.tau)) / 4;
+        const size_t n_max = list_all ? 0 : ws.maxima_bytes / 4;
+        const size_t total = n_zero + n_tau + n_max;
+        const unsigned grid = (unsigned)((total + 256 * 8 - 1) / (256 * 8) < 2048 ? (total + 256 * 8 - 1) / (256 * 8) : 2048);
+        k_topk_ws_init<<<grid ? grid : 1, 256, 0, st>>>(static_cast<uint32_t *>(workspace), n_zero, n_tau, 0xff800000u,
+                                                     list_all ? 1 : 0, n_max);
+        MACR_CHECK_LAUNCH("ws_init", st);
+    }
     const int sel_blocks = (U + kSelWaves - 1) / kSelWaves;
     const uint32_t *mask_bits = mask_bits_in;
     MACR_REQUIRE(!mask_bits_in || mask_ptr, MACR_E_INVALID, "score_topk: mask_bits without the CSR mask it was built from");
     if (mask_ptr && !mask_bits_in) {
-        me = hipMemsetAsync(ws.mask_bits, 0, ws.mask_bytes, st);
-        MACR_REQUIRE(me == hipSuccess, MACR_E_LAUNCH, "score_topk: memset: %s", hipGetErrorString(me));
+        fill_words(ws.mask_bits, ws.mask_bytes / 4, 0u, st);
         k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, ws.mask_bits);
         MACR_CHECK_LAUNCH("mask_bits", st);
         mask_bits = ws.mask_bits;
@@ -1236,11 +1257,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
         // A catalogue (shard) whose every tile range fits a candidate list needs no threshold: tau = -inf lists every unmasked item
         // and the selection kernel ranks them -- no sampling pass, no k_tau.
-        const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
-        if (list_all) {
-            e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.tau), (int)0xff800000u, (size_t)U, st);   // -inf
-            MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: memset: %s", hipGetErrorString(e));
-        } else {
+        if (!list_all) {
         pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits, item_offset,
                                             geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow);
         MACR_CHECK_LAUNCH("score_sample", st);

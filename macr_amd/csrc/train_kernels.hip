@@ -1029,8 +1029,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     const size_t nd = (size_t)N * d;
     // forward propagation (LightGCN.py:288-309)
     if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, T, ws.E, ws.work, st)) return e;
-    hipError_t he = hipMemsetAsync(ws.dE, 0, nd * 4, st);
-    MACR_REQUIRE(he == hipSuccess, MACR_E_LAUNCH, "lgcn_train_step: memset: %s", hipGetErrorString(he));
+    fill_words(ws.dE, nd, 0u, st);
     // pair loss on the propagated rows; items live at rows n_users.. of E
     float *Ei = ws.E + (size_t)n_users * d, *dEi = ws.dE + (size_t)n_users * d;
     if (int e = launch_pair(loss_kind, B, d, u, i, j, ws.E, Ei, w, wu, ws.dE, dEi, nullptr, nullptr, 0.0f, 0, adam_pow,

@@ -11,6 +11,8 @@ kernel -> column means.  Nothing U x N ever leaves the device (or exists).
 Both reference evaluators batch the users by BATCH_SIZE; every per-user result
 is independent of the batching, so all query users are ranked in one pass.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -27,7 +29,7 @@ class Evaluator(object):
         self.device = device
         self.mask = ops.CSR.from_lists(mask_lists, device)
         self.max_queries_per_pass = 131072       # bounds the ranking workspace (~1.5 GB of candidate lists)
-        self.use_graph = True                    # replay the evaluation as one HIP graph (see _means)
+        self.use_graph = os.environ.get("MACR_EVAL_GRAPH", "1") != "0"    # replay the evaluation as one HIP graph (_means)
         self._graphs = {}
         self._graph_misses = 0
         self.gt = ops.CSR.from_lists(gt_lists, device)
