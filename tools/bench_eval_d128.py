@@ -20,6 +20,7 @@ for rep in range(3):
     r = ev.test_mf(ops.SCORE_RUBI_BOTH, P, uid, Q, [20], w, wu, 40.0)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
 fl = 2.0 * len(users) * cfg["n_items"] * d
+ev.use_graph = False          # per-kernel events need the launches themselves
 ops.timing_begin(); ev.test_mf(ops.SCORE_RUBI_BOTH, P, uid, Q, [20], w, wu, 40.0)
 marks = {}
 for n, ms in ops.timing_end():
