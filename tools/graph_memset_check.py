@@ -1,4 +1,5 @@
-"""hipMemsetAsync nodes inside a captured HIP graph: on ROCm 7.2 / gfx950 the first memset of this three-memset sequence\nstops taking effect from the second replay on (prints `hdr zero: False`).  libmacr_hip therefore fills with kernels."""
+"""hipMemsetAsync nodes inside a captured HIP graph: on ROCm 7.2 / gfx950 the first memset of this three-memset sequence
+stops taking effect from the second replay on (prints `hdr zero: False`).  libmacr_hip therefore fills with kernels."""
 import ctypes, torch
 hip = ctypes.CDLL("libamdhip64.so")
 dev = torch.device("cuda", 0)
