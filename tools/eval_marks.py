@@ -17,6 +17,7 @@ w = synth.xavier_table(d, 1, gen, dev).reshape(-1); wu = synth.xavier_table(d, 1
 users, mask_lists, gt_lists = synth.eval_problem(cfg, seed=777)
 ev = Evaluator(mask_lists, gt_lists, cfg["n_items"], dev)
 uid = torch.from_numpy(users).to(dev)
+ev.use_graph = False          # per-launch events need the launches themselves, not the graph replay
 for rep in range(3):
     ev.test_mf(ops.SCORE_RUBI_BOTH, P, uid, Q, [20], w, wu, cfg["c"])
 torch.cuda.synchronize()
