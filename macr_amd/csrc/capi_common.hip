@@ -22,6 +22,8 @@ static thread_local int g_nmarks = 0;
 
 void timing_mark(const char *name, hipStream_t st) {
     if (!g_timing || g_nmarks >= 256) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;       // events cannot be timed inside a graph capture
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
     Mark &m = g_marks[g_nmarks];
     if (hipEventCreate(&m.ev) != hipSuccess) return;
     strncpy(m.name, name, sizeof(m.name) - 1);
