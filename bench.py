@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--pos", default="zipf", choices=["zipf", "uniform"], help="positive-item distribution (diagnostic)")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluator leg (diagnostic)")
     ap.add_argument("--no-defer", action="store_true", help="complete every step's Adam pass inside the step instead of under the next step's (B,B) kernel (diagnostic)")
-    ap.add_argument("--unsorted", action="store_true", help="do not order the triples of a batch by positive item (diagnostic)")
+    ap.add_argument("--presorted", action="store_true", help="feed batches already ordered by positive item (diagnostic; the step orders its batch on the device either way)")
     return ap.parse_args()
 
 
@@ -110,7 +110,7 @@ def main():
     state = ops.MFState(P, Q, w, wu, hyper, B)
     n_batches = min(args.steps + args.warmup, 256)
     batches = synth.train_batches(n_batches, cfg["n_users"], cfg["n_items"], B, gen, dev, zipf=args.pos == "zipf",
-                                  sort_by_pos=not args.unsorted)
+                                  sort_by_pos=args.presorted)
     loss_log = torch.zeros((n_batches, 3), dtype=torch.float32, device=dev)
 
     def barrier():

@@ -1,0 +1,178 @@
+// Stable LSD radix sort of (key, value) pairs of 32-bit words, for the row references of a training batch.
+//
+// Why a sort at all: the gradient of a batch is a sum over its 3B row references (macr_mf/model.py:35-37 gathers,
+// :74 IndexedSlices de-duplication before the sparse Adam apply), and the reference's sampler draws positives by
+// popularity (macr_mf/load_data.py:543-566), so a batch references a handful of rows hundreds of times.  Ordering
+// the references by row turns "hundreds of atomics on one L2 line" into segments:
+//   * small batches (B <= kSmallBatchMax): ONE workgroup buckets the triples of the batch by the low byte of the
+//     positive item while the (B,B) kernel runs (batch_bucket_block in train_kernels.hip, one pass built from the
+//     pieces below); pair_bwd then adds equal positive rows of a 16-slot chunk once;
+//   * large batches: all 3B references are sorted by row with the multi-block kernels below and a segment-reduce
+//     pass sums each row's contributions from a staging buffer written with plain stores -- no atomics on the path.
+// 8-bit digits; a wave ranks 64 keys at a time with ballots (no LDS atomics in the ranking step); every pass is
+// stable, so equal rows keep their batch order and the summation order of a row is the same in every run.
+#pragma once
+#include "common.hpp"
+
+namespace macr {
+
+constexpr int kRadix = 256;
+constexpr int kSortTile = 8192;          // keys per workgroup in the multi-block passes (256 threads x 32)
+
+// Lanes of the wave that hold the same 8-bit digit as this lane (valid lanes only).
+__device__ __forceinline__ uint64_t match_digit(uint32_t dgt, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (dgt >> b) & 1u;
+        const uint64_t m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+constexpr int kSortBatch = 8;            // keys per lane fetched before any is ranked (the loops are latency bound)
+
+// hist[digit] += number of keys of [lo,hi) with that digit (hist: 256 LDS words owned by this wave, zeroed).
+// Loads use clamped addresses instead of predicates: a predicated load compiles to a branch with its own wait, which
+// serialises the batch (measured: 8 us for 8 loads).
+__device__ __forceinline__ void wave_count(const uint32_t *__restrict__ kin, int lo, int hi, int shift, uint32_t *hist) {
+    const int lane = threadIdx.x & 63;
+    for (int base = lo; base < hi; base += 64 * kSortBatch) {
+        uint32_t k[kSortBatch];
+#pragma unroll
+        for (int q = 0; q < kSortBatch; ++q) { const int p = base + q * 64 + lane; k[q] = kin[p < hi ? p : hi - 1]; }
+#pragma unroll
+        for (int q = 0; q < kSortBatch; ++q)
+            if (base + q * 64 + lane < hi) atomicAdd(&hist[(k[q] >> shift) & 255u], 1u);
+    }
+}
+
+// The wave moves keys [lo,hi) to kout/vout in order, 64 at a time: offs[digit] is the next free output position of
+// that digit for THIS wave (LDS, owned by the wave; advanced here: LDS operations of a wave execute in order).
+__device__ __forceinline__ void wave_rank_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                  int lo, int hi, int shift, uint32_t *offs,
+                                                  uint32_t *__restrict__ kout, uint32_t *__restrict__ vout) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int base = lo; base < hi; base += 64 * kSortBatch) {
+        uint32_t kk[kSortBatch], vv[kSortBatch];
+#pragma unroll
+        for (int q = 0; q < kSortBatch; ++q) {
+            const int p = base + q * 64 + lane, pc = p < hi ? p : hi - 1;
+            kk[q] = kin[pc];
+            vv[q] = vin[pc];
+        }
+#pragma unroll
+        for (int q = 0; q < kSortBatch; ++q) {
+            if (base + q * 64 >= hi) break;                               // wave-uniform
+            const bool valid = base + q * 64 + lane < hi;
+            const uint32_t dgt = (kk[q] >> shift) & 255u;
+            const uint64_t peers = match_digit(dgt, valid);
+            const uint32_t rank = (uint32_t)__popcll(peers & below);
+            const uint32_t dst = offs[dgt] + rank;
+            if (valid && rank == 0) offs[dgt] = dst + (uint32_t)__popcll(peers);     // lowest peer advances the digit
+            if (valid) { kout[dst] = kk[q]; vout[dst] = vv[q]; }
+        }
+    }
+}
+
+// Turns per-wave digit counts s_hist[w][digit] into output positions: position of (digit, wave) in digit-major,
+// wave-minor order, plus gbase[digit] (the digit's start outside this workgroup; NULL = exclusive scan over digits).
+// All threads of the block must call it (contains barriers).  s_wtot: 4 LDS words.
+template <int NW>
+__device__ __forceinline__ void block_digit_offsets(uint32_t *s_hist, uint32_t *s_wtot, const uint32_t *gbase, int gstride) {
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    uint32_t tot = 0, excl = 0;
+    if (t < kRadix) {
+#pragma unroll 4
+        for (int w = 0; w < NW; ++w) { const uint32_t c = s_hist[w * kRadix + t]; s_hist[w * kRadix + t] = tot; tot += c; }
+        if (gbase) {
+            excl = gbase[(size_t)t * gstride];
+        } else {
+            uint32_t inc = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(inc, o, kWave); if (lane >= o) inc += x; }
+            excl = inc - tot;
+            if (lane == 63) s_wtot[wid] = inc;
+        }
+    }
+    __syncthreads();
+    if (t < kRadix) {
+        if (!gbase)
+            for (int w = 0; w < wid; ++w) excl += s_wtot[w];
+#pragma unroll 4
+        for (int w = 0; w < NW; ++w) s_hist[w * kRadix + t] += excl;
+    }
+    __syncthreads();
+}
+
+// ---- multi-block passes (large batches) -------------------------------------------------------------------------
+// ghist[digit][block]: per-workgroup digit counts, then (after k_rs_scan) the global start of (digit, block).
+static __global__ __launch_bounds__(256) void k_rs_count(const uint32_t *__restrict__ kin, int n, int shift,
+                                                         uint32_t *__restrict__ ghist, int nblk) {
+    __shared__ uint32_t s_hist[kRadix];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int lo = blockIdx.x * kSortTile, hi = lo + kSortTile < n ? lo + kSortTile : n;
+    for (int p = lo + threadIdx.x; p < hi; p += 256) atomicAdd(&s_hist[(kin[p] >> shift) & 255u], 1u);
+    __syncthreads();
+    ghist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// exclusive scan of `total` words in place, one workgroup of 1024 threads
+static __global__ __launch_bounds__(1024) void k_rs_scan(uint32_t *__restrict__ x, int total) {
+    __shared__ uint32_t s_w[16];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int per = (total + 1023) / 1024, lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
+    uint32_t sum = 0;
+    for (int k = lo; k < hi; ++k) sum += x[k];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, kWave); if (lane >= o) inc += y; }
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wid; ++w) run += s_w[w];
+    for (int k = lo; k < hi; ++k) { const uint32_t c = x[k]; x[k] = run; run += c; }
+}
+
+static __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                           uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int n,
+                                                           int shift, const uint32_t *__restrict__ ghist, int nblk) {
+    __shared__ uint32_t s_hist[4 * kRadix + 4];
+    const int t = threadIdx.x, wid = t >> 6;
+    const int blo = blockIdx.x * kSortTile, bhi = blo + kSortTile < n ? blo + kSortTile : n;
+    const int lo = blo + wid * (kSortTile / 4) < bhi ? blo + wid * (kSortTile / 4) : bhi;
+    const int hi = lo + kSortTile / 4 < bhi ? lo + kSortTile / 4 : bhi;
+    for (int k = t; k < 4 * kRadix; k += 256) s_hist[k] = 0;
+    __syncthreads();
+    wave_count(kin, lo, hi, shift, s_hist + wid * kRadix);
+    __syncthreads();
+    block_digit_offsets<4>(s_hist, s_hist + 4 * kRadix, ghist + blockIdx.x, nblk);
+    wave_rank_scatter(kin, vin, lo, hi, shift, s_hist + wid * kRadix, kout, vout);
+}
+
+static inline int key_bits_for(uint32_t max_key) {
+    int b = 1;
+    while (b < 32 && (max_key >> b)) ++b;
+    return b;
+}
+
+// Sorts n pairs held in (ka,va) with (kb,vb) as the second buffer; returns 0 if the result is in (ka,va), 1 if in
+// (kb,vb).  ghist: 256 * ceil(n / kSortTile) words.
+static inline int launch_radix_sort(uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb, int n, uint32_t max_key,
+                                    uint32_t *ghist, hipStream_t st) {
+    const int nblk = (n + kSortTile - 1) / kSortTile, bits = key_bits_for(max_key);
+    int flip = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        uint32_t *kin = flip ? kb : ka, *vin = flip ? vb : va, *kout = flip ? ka : kb, *vout = flip ? va : vb;
+        k_rs_count<<<nblk, 256, 0, st>>>(kin, n, shift, ghist, nblk);
+        k_rs_scan<<<1, 1024, 0, st>>>(ghist, kRadix * nblk);
+        k_rs_scatter<<<nblk, 256, 0, st>>>(kin, vin, kout, vout, n, shift, ghist, nblk);
+        flip ^= 1;
+    }
+    return flip;
+}
+
+}  // namespace macr

@@ -14,6 +14,7 @@
 // rows at once and reduces dot products inside each LPR-lane group with
 // cross-lane shuffles.
 #include "common.hpp"
+#include "refsort.hpp"
 
 #include <type_traits>
 
@@ -312,6 +313,73 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
 // Block = 4 waves = (64*R) rows x 256 columns (one 64-column tile per wave); the waves' row
 // sums meet in LDS once.   rowpart [ncb][2][Bp], colpart [nrb][2][Bp], lpart [nrb*ncb]
 // ----------------------------------------------------------------------------
+// ----------------------------------------------------------------------------
+// Batch grouping (small batches).  The order of the triples of a batch is free -- every loss term is a sum over the
+// batch -- and the reference's sampler draws positives by popularity (macr_mf/load_data.py:543-566): a batch
+// references a few item rows hundreds of times, and hundreds of atomics on one L2 line serialise (~24 ns each).
+// The batch is therefore bucketed by the low byte of the positive item -- a single stable counting pass: one trip to
+// global memory, 4 KB of LDS per workgroup -- so that equal positive items land in the same 16-slot chunks of
+// pair_bwd, which adds equal rows of a chunk once (combine_positive_rows).  The workgroups are extra blocks of the
+// (B,B) launch (rubibceboth: 14+ us of cover) or a tiny launch of their own (normalbce).
+// Output: the batch in bucket order (us, is, js) and perm[s] = position in the caller's batch of the triple at slot s
+// (its index in fwd and in the bxb partials).  Measured before settling on this: a full 16-bit sort by one workgroup
+// through global ping-pong buffers took 40 us (two trips per pass and phase), and its LDS version would have taken
+// the LDS of the (B,B) blocks it rides with.
+// ----------------------------------------------------------------------------
+struct BatchSort {
+    const int32_t *u, *i, *j;
+    int B;
+    int32_t *perm, *us, *is, *js;       // [B] each
+};
+
+constexpr int kBucketSpan = 512;        // triples bucketed by one workgroup (independently of the other spans)
+
+// Workgroup `part` buckets slots [part*kBucketSpan, (part+1)*kBucketSpan) of the batch among themselves: a hot item
+// is spread evenly over the batch, so grouping inside spans of 512 combines as well as grouping the whole batch,
+// and B/512 workgroups finish in a quarter of the time one needs for B = 4096 (the pass is a chain of LDS and
+// global-memory latencies, not throughput).
+template <int NW>
+__device__ __forceinline__ void batch_bucket_block(const BatchSort &s, int part, uint32_t *s_hist /* NW*256 + 4 words */) {
+    const int t = threadIdx.x, wid = t >> 6, lane = t & 63;
+    const int plo = part * kBucketSpan, phi = plo + kBucketSpan < s.B ? plo + kBucketSpan : s.B;
+    constexpr int per = kBucketSpan / NW;
+    const int lo = plo + wid * per < phi ? plo + wid * per : phi, hi = lo + per < phi ? lo + per : phi;
+    const uint32_t *keys = reinterpret_cast<const uint32_t *>(s.i);
+    for (int k = t; k < NW * kRadix; k += NW * 64) s_hist[k] = 0;
+    __syncthreads();
+    wave_count(keys, lo, hi, 0, s_hist + wid * kRadix);
+    __syncthreads();
+    block_digit_offsets<NW>(s_hist, s_hist + NW * kRadix, nullptr, 0);
+    uint32_t *offs = s_hist + wid * kRadix;
+    const uint64_t below = (1ull << lane) - 1ull;
+    constexpr int NQ = per / 64;
+    int32_t ri[NQ], ru[NQ], rj[NQ];
+    if (lo < hi) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {                                        // clamped, unpredicated: all in flight at once
+            const int p = lo + q * 64 + lane, pc = p < hi ? p : hi - 1;
+            ri[q] = s.i[pc]; ru[q] = s.u[pc]; rj[q] = s.j[pc];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (lo + q * 64 >= hi) break;                                     // wave-uniform
+        const int p = lo + q * 64 + lane;
+        const bool valid = p < hi;
+        const uint32_t dgt = (uint32_t)ri[q] & 255u;
+        const uint64_t peers = match_digit(dgt, valid);
+        const uint32_t rank = (uint32_t)__popcll(peers & below);
+        const uint32_t dst = plo + offs[dgt] + rank;
+        if (valid && rank == 0) offs[dgt] = dst - plo + (uint32_t)__popcll(peers);
+        if (valid) { s.perm[dst] = p; s.us[dst] = ru[q]; s.is[dst] = ri[q]; s.js[dst] = rj[q]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_batch_sort(BatchSort s) {
+    __shared__ uint32_t s_hist[4 * kRadix + 4];
+    batch_bucket_block<4>(s, blockIdx.x, s_hist);
+}
+
 __device__ __forceinline__ float wave_rol1(float v) {      // lane i <- lane (i+1) mod 64
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x134, 0xf, 0xf, true));
 }
@@ -325,13 +393,21 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 template <int R, bool FULL, bool ADAM>
 __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, const float *__restrict__ fwd,
                                              float *__restrict__ rowpart, float *__restrict__ colpart,
-                                             float *__restrict__ lpart, AdamArgs adam, const StepScalars *scal) {
+                                             float *__restrict__ lpart, AdamArgs adam, const StepScalars *scal,
+                                             BatchSort sort) {
     constexpr int RB = 64 * R;                 // rows per block
     __shared__ float s_row[4][2][RB];
     __shared__ float red[16];
     __shared__ float4 s_red[ADAM ? 256 : 1];
-    const bool is_adam = ADAM && (int)blockIdx.x >= nbxb;
-    const int ablk = blockIdx.x - nbxb, bblk = blockIdx.x;
+    __shared__ uint32_t s_hist[4 * kRadix + 4];
+    const int nsort = (sort.B + kBucketSpan - 1) / kBucketSpan;
+    if ((int)blockIdx.x >= nbxb && (int)blockIdx.x < nbxb + nsort) {     // these blocks group the batch for pair_bwd
+        __builtin_amdgcn_s_setprio(3);         // a chain of latencies beside VALU-bound waves: go first when ready
+        batch_bucket_block<4>(sort, blockIdx.x - nbxb, s_hist);
+        return;
+    }
+    const bool is_adam = ADAM && (int)blockIdx.x >= nbxb + nsort;
+    const int ablk = blockIdx.x - nbxb - nsort, bblk = blockIdx.x;
     if (is_adam) {
         // the bxb waves are older and would win every issue slot: the Adam waves (a handful of VALU instructions
         // between long memory waits) go first whenever they are ready
@@ -462,6 +538,30 @@ struct WaveRow {
     static constexpr int kActive = D < 64 ? D : 64;    // active lanes (d=32 leaves half the wave idle)
 };
 
+// The positive rows of a chunk (s_pos[slot] = row, -1 past the end of the batch; s_gi[slot] = its gradient row):
+// thread k owns element k and adds every DISTINCT row once -- equal rows of the chunk are summed first, adjacent or
+// not (the batch arrives bucketed by the low byte of the positive item, batch_bucket_block, so the hottest item of a
+// batch costs (#chunks it spans) serialised atomics instead of (#references)).
+template <int D>
+__device__ __forceinline__ void combine_positive_rows(const int *s_pos, const float (*s_gi)[D], float *gI) {
+    if (threadIdx.x >= D) return;
+    int rows[kChunkT];
+#pragma unroll
+    for (int s = 0; s < kChunkT; ++s) rows[s] = s_pos[s];
+    for (int k = threadIdx.x; k < D; k += 256) {
+        uint32_t done = 0;
+#pragma unroll
+        for (int L = 0; L < kChunkT; ++L) {
+            if (rows[L] < 0 || ((done >> L) & 1u)) continue;
+            float acc = s_gi[L][k];
+#pragma unroll
+            for (int s2 = L + 1; s2 < kChunkT; ++s2)
+                if (rows[s2] == rows[L]) { acc += s_gi[s2][k]; done |= 1u << s2; }
+            MACR_ATOMIC_ADD(gI + (size_t)rows[L] * D + k, acc);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------
 // pair_bwd (rubibceboth): gradient rows + scatter-add.           SURVEY.md A.1
 //   dp,dn (column sums) and da,db (row sums) come from the bxb partials / B^2
@@ -474,8 +574,9 @@ struct WaveRow {
 // ----------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void k_pair_bwd(
-    int B, int Bp, int nrb, int ncb, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
-    const int32_t *__restrict__ j, const float *__restrict__ Usrc, const float *__restrict__ Isrc,
+    int B, int Bp, int nrb, int ncb, const int32_t *__restrict__ perm, const int32_t *__restrict__ u,
+    const int32_t *__restrict__ i, const int32_t *__restrict__ j, const float *__restrict__ Usrc,
+    const float *__restrict__ Isrc,
     const float *__restrict__ w, const float *__restrict__ wu, const float *__restrict__ fwd,
     const float *__restrict__ rowpart, const float *__restrict__ colpart,
     float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *__restrict__ wpart,
@@ -485,6 +586,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     __shared__ float s_w[4][2][D];
     __shared__ float s_gi[kChunkT][D];
     __shared__ int s_pos[kChunkT];
+    __shared__ int s_tp[kChunkT];
     __shared__ float s_d[4][kChunkT];
     const int nblk = gridDim.x - 1;
     if ((int)blockIdx.x == nblk) {
@@ -509,11 +611,9 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
         wk[e] = act ? w[k] : 0.f; wuk[e] = act ? wu[k] : 0.f; aw[e] = 0.f; awu[e] = 0.f;
     }
     const float inv_b2 = 1.0f / ((float)B * (float)B), eps = 1e-10f, invB = 1.0f / (float)B;
-    // A block owns kChunkT CONSECUTIVE triples per pass.  The order of the triples of a batch is free (every
-    // loss term is a sum over the batch), so the input pipeline may sort a batch by positive item: equal positive
-    // items are then adjacent, and the block adds each RUN of equal rows once (LDS segmented sum) instead of once
-    // per triple -- the hottest item of a Zipf batch costs (#blocks it spans) serialised atomics, not (#references).
-    // Unsorted batches stay correct (runs of length one).
+    // A block owns kChunkT CONSECUTIVE slots of the batch BUCKETED BY POSITIVE ITEM (u, i, j are the bucketed copies,
+    // perm[s] the triple's position in the caller's batch = its index in fwd and in the bxb partials; see
+    // batch_bucket_block) and adds equal positive rows of a chunk once (combine_positive_rows).
     for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += nblk) {
         // The chunk's column sums dp,dn and row sums da,db of the (B,B) term: wave w reduces quantity w over the bxb
         // partials for all 16 triples at once -- lane (k%4, t%16) reads 64-byte runs -- instead of every triple's wave
@@ -525,24 +625,25 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
             if (lane < 12 && tq < B) my_idx = (lane < 4 ? u : lane < 8 ? i : j)[tq];
         }
         {
-            const int tt = lane & 15, kq = lane >> 4, t = chunk * kChunkT + tt;
+            const int tt = lane & 15, kq = lane >> 4, slot_t = chunk * kChunkT + tt;
             const float *src = wid < 2 ? colpart + (size_t)wid * Bp : rowpart + (size_t)(wid - 2) * Bp;
             const int np = wid < 2 ? nrb : ncb;
             float acc = 0.f;
+            const int t = slot_t < B ? perm[slot_t] : 0;
 #ifndef MACR_ABL_NOPART
-            if (t < B)
+            if (slot_t < B)
                 for (int k = kq; k < np; k += 4) acc += src[(size_t)k * 2 * Bp + t];
 #endif
             acc += __shfl_xor(acc, 16, kWave);
             acc += __shfl_xor(acc, 32, kWave);
-            if (kq == 0) s_d[wid][tt] = acc * inv_b2;
+            if (kq == 0) { s_d[wid][tt] = acc * inv_b2; if (wid == 0) s_tp[tt] = t; }
         }
         __syncthreads();
 #pragma unroll                                   // the four triples' row gathers are issued together
         for (int q = 0; q < kChunkT / 4; ++q) {
             const int slot = wid * (kChunkT / 4) + q;
-            const int t = chunk * kChunkT + slot;
-            if (t >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
+            if (chunk * kChunkT + slot >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
+            const int t = s_tp[slot];
             const float dp = s_d[0][slot], dn = s_d[1][slot], da = s_d[2][slot], db = s_d[3][slot];
             const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
             const float dsi = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
@@ -571,17 +672,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
             }
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < D; k += 256) {            // thread k owns element k of every positive row
-            float acc = 0.f;
-#pragma unroll 4
-            for (int slot = 0; slot < kChunkT; ++slot) {
-                const int row = s_pos[slot];
-                if (row < 0) break;
-                acc += s_gi[slot][k];
-                const int nxt = slot + 1 < kChunkT ? s_pos[slot + 1] : -1;
-                if (nxt != row) { MACR_ATOMIC_ADD(gI + (size_t)row * D + k, acc); acc = 0.f; }
-            }
-        }
+        combine_positive_rows<D>(s_pos, s_gi, gI);
         __syncthreads();
     }
     if (act) {
@@ -624,7 +715,7 @@ __global__ __launch_bounds__(256) void k_pair_normal(
     }
     float sq = 0.f, bce = 0.f;
     const float eps = 1e-9f, invB = 1.0f / (float)B;
-    for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += gridDim.x) {      // see pair_bwd: runs of equal positives
+    for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += gridDim.x) {      // see pair_bwd: equal positives of a chunk are added once
 #pragma unroll 1
         for (int q = 0; q < kChunkT / 4; ++q) {
             const int slot = wid * (kChunkT / 4) + q;
@@ -660,17 +751,7 @@ __global__ __launch_bounds__(256) void k_pair_normal(
             }
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < D; k += 256) {
-            float acc = 0.f;
-#pragma unroll 4
-            for (int slot = 0; slot < kChunkT; ++slot) {
-                const int row = s_pos[slot];
-                if (row < 0) break;
-                acc += s_gi[slot][k];
-                const int nxt = slot + 1 < kChunkT ? s_pos[slot + 1] : -1;
-                if (nxt != row) { MACR_ATOMIC_ADD(gI + (size_t)row * D + k, acc); acc = 0.f; }
-            }
-        }
+        combine_positive_rows<D>(s_pos, s_gi, gI);
         __syncthreads();
     }
     const float s0 = block_sum(sq, red);
@@ -678,6 +759,185 @@ __global__ __launch_bounds__(256) void k_pair_normal(
     if (threadIdx.x == 0) {
         float *o = part + (size_t)blockIdx.x * kPartStride;
         o[0] = s0; o[1] = 0.f; o[2] = 0.f; o[3] = s3;
+    }
+}
+
+// ============================================================================
+// Large batches: staging + sorted references + segment reduce (no atomics on the path).
+// Above kSmallBatchMax triples the pair kernels stop being latency bound and become HBM bound, and a row atomic is a
+// read-modify-write at L2/HBM (measured: 1.44x the algorithmic traffic, 0.85 TB/s at B = 2^20).  Here the pair
+// kernel reads its 3 rows once and writes its 3 gradient rows ONCE, with plain coalesced stores, to a staging buffer
+// in batch order -- exactly the algorithmic 24*d+12 bytes per triple -- while the 3B references (key = table row,
+// value = staging row) are radix-sorted by row (refsort.hpp).  k_seg_reduce then gives every row ONE owner that
+// sums its contributions in sorted (= batch) order and stores the row into gP/gQ: the IndexedSlices de-duplication
+// of tf.train.AdamOptimizer (macr_mf/model.py:74), deterministic.  Rows referenced more than kSegChunk times are cut
+// into chunks that add atomically (a handful of atomics for the hottest rows only).
+// ============================================================================
+constexpr int kSmallBatchMax = 8192;
+
+__global__ __launch_bounds__(256) void k_refs_init(int B, int n_users, const int32_t *__restrict__ u,
+                                                   const int32_t *__restrict__ i, const int32_t *__restrict__ j,
+                                                   uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < B; t += gridDim.x * 256) {
+        key[t] = (uint32_t)u[t];                       val[t] = (uint32_t)t;
+        key[B + t] = (uint32_t)(n_users + i[t]);       val[B + t] = (uint32_t)(B + t);
+        key[2 * (size_t)B + t] = (uint32_t)(n_users + j[t]);   val[2 * (size_t)B + t] = (uint32_t)(2 * (size_t)B + t);
+    }
+}
+
+// normalbce forward+backward, one LPR-lane group per triple, float4 per lane; see k_pair_normal for the arithmetic.
+// stage: [3][B][d] gradient rows of (user, positive, negative) in batch order.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_pair_normal_stage(
+    int B, const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
+    const float *__restrict__ Usrc, const float *__restrict__ Isrc, float *__restrict__ stage,
+    float *__restrict__ part, float coef, int reg_on_gathered, const float *__restrict__ adam_pow_in,
+    float *adam_pow_out, StepScalars *scal, float lr, float b1, float b2) {
+    constexpr int d = 4 * LPR, RPB = RowGroup<LPR>::kRowsPerBlock;
+    __shared__ float red[16];
+    RowGroup<LPR> g;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float p1 = adam_pow_in[0], p2 = adam_pow_in[1];
+        scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
+        adam_pow_out[0] = p1 * b1;
+        adam_pow_out[1] = p2 * b2;
+    }
+    float sq = 0.f, bce = 0.f;
+    const float eps = 1e-9f, invB = 1.0f / (float)B;
+    for (long long base = (long long)blockIdx.x * RPB; base < B; base += (long long)gridDim.x * RPB) {
+        const long long t = base + g.slot;
+        if (t >= B) continue;
+        const int ru = u[t], ri = i[t], rj = j[t];
+        const float4 eu = ld4(Usrc + (size_t)ru * d + 4 * g.sub);
+        const float4 ei = ld4(Isrc + (size_t)ri * d + 4 * g.sub);
+        const float4 ej = ld4(Isrc + (size_t)rj * d + 4 * g.sub);
+        const float p = group_sum<LPR>(dot4(eu, ei)), n = group_sum<LPR>(dot4(eu, ej));
+        if (reg_on_gathered) sq += dot4(eu, eu) + dot4(ei, ei) + dot4(ej, ej);
+        const float sp = sigmoid_acc(p), sn = sigmoid_acc(n);
+        if (g.sub == 0) bce += -logf(sp + eps) + -logf((1.0f - sn) + eps);
+        const float dp = dneglog_sig(sp, eps) * invB, dn = dneglog_1msig(sn, eps) * invB;
+        st4(stage + ((size_t)t) * d + 4 * g.sub, fma4(coef, eu, fma4(dn, ej, scale4(dp, ei))));
+        st4(stage + ((size_t)B + t) * d + 4 * g.sub, fma4(coef, ei, scale4(dp, eu)));
+        st4(stage + (2 * (size_t)B + t) * d + 4 * g.sub, fma4(coef, ej, scale4(dn, eu)));
+    }
+    const float s0 = block_sum(sq, red);
+    const float s3 = block_sum(bce, red);
+    if (threadIdx.x == 0) {
+        float *o = part + (size_t)blockIdx.x * kPartStride;
+        o[0] = s0; o[1] = 0.f; o[2] = 0.f; o[3] = s3;
+    }
+}
+
+// rubibceboth backward; see k_pair_bwd for the arithmetic.  The last block does the step bookkeeping.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_pair_bwd_stage(
+    int B, int Bp, int nrb, int ncb, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+    const int32_t *__restrict__ j, const float *__restrict__ Usrc, const float *__restrict__ Isrc,
+    const float *__restrict__ w, const float *__restrict__ wu, const float *__restrict__ fwd,
+    const float *__restrict__ rowpart, const float *__restrict__ colpart, float *__restrict__ stage,
+    float *__restrict__ wpart, float alpha, float beta, float coef, float *adam_pow, StepScalars *scal, float lr,
+    float b1, float b2, LossArgs L) {
+    constexpr int d = 4 * LPR, RPB = RowGroup<LPR>::kRowsPerBlock;
+    __shared__ float4 s_w[2][256];
+    const int nblk = gridDim.x - 1;
+    if ((int)blockIdx.x == nblk) {
+        if (threadIdx.x == 0) {
+            const float p1 = adam_pow[0], p2 = adam_pow[1];
+            scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
+            adam_pow[0] = p1 * b1;
+            adam_pow[1] = p2 * b2;
+        }
+        if (L.losses && threadIdx.x < 64) finalize_losses(L, threadIdx.x);
+        return;
+    }
+    RowGroup<LPR> g;
+    const float4 w4 = ld4(w + 4 * g.sub), wu4 = ld4(wu + 4 * g.sub);
+    float4 aw = make_float4(0, 0, 0, 0), awu = make_float4(0, 0, 0, 0);
+    const float inv_b2 = 1.0f / ((float)B * (float)B), eps = 1e-10f, invB = 1.0f / (float)B;
+    for (long long base = (long long)blockIdx.x * RPB; base < B; base += (long long)nblk * RPB) {
+        const long long t = base + g.slot;
+        if (t >= B) continue;
+        float dp = 0.f, dn = 0.f, da = 0.f, db = 0.f;
+        for (int k = g.sub; k < nrb; k += LPR) { dp += colpart[((size_t)k * 2) * Bp + t]; dn += colpart[((size_t)k * 2 + 1) * Bp + t]; }
+        for (int k = g.sub; k < ncb; k += LPR) { da += rowpart[((size_t)k * 2) * Bp + t]; db += rowpart[((size_t)k * 2 + 1) * Bp + t]; }
+        dp = group_sum<LPR>(dp) * inv_b2; dn = group_sum<LPR>(dn) * inv_b2;
+        da = group_sum<LPR>(da) * inv_b2; db = group_sum<LPR>(db) * inv_b2;
+        const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
+        const float dsi = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
+        const float dsj = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
+        const float dsu = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
+                          (beta * invB) * (dneglog_sig(ssu, eps) + dneglog_1msig(ssu, eps));
+        const int ru = u[t], ri = i[t], rj = j[t];
+        const float4 eu = ld4(Usrc + (size_t)ru * d + 4 * g.sub);
+        const float4 ei = ld4(Isrc + (size_t)ri * d + 4 * g.sub);
+        const float4 ej = ld4(Isrc + (size_t)rj * d + 4 * g.sub);
+        st4(stage + ((size_t)t) * d + 4 * g.sub, fma4(coef, eu, fma4(dsu, wu4, fma4(dn, ej, scale4(dp, ei)))));
+        st4(stage + ((size_t)B + t) * d + 4 * g.sub, fma4(coef, ei, fma4(dsi, w4, scale4(dp, eu))));
+        st4(stage + (2 * (size_t)B + t) * d + 4 * g.sub, fma4(coef, ej, fma4(dsj, w4, scale4(dn, eu))));
+        aw = fma4(dsi, ei, fma4(dsj, ej, aw));
+        awu = fma4(dsu, eu, awu);
+    }
+    s_w[0][threadIdx.x] = aw; s_w[1][threadIdx.x] = awu;
+    __syncthreads();
+    if (threadIdx.x < 2 * LPR) {                       // thread (q, sub): sums its float4 over the block's row groups
+        const int q = threadIdx.x / LPR, sub = threadIdx.x % LPR;
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int k = 0; k < RPB; ++k) acc = add4(acc, s_w[q][k * LPR + sub]);
+        float *dst = wpart + (size_t)(blockIdx.x % kBranchSlots) * 2 * d + (size_t)q * d + 4 * sub;
+        MACR_ATOMIC_ADD(dst + 0, acc.x); MACR_ATOMIC_ADD(dst + 1, acc.y);
+        MACR_ATOMIC_ADD(dst + 2, acc.z); MACR_ATOMIC_ADD(dst + 3, acc.w);
+    }
+}
+
+// One LPR-lane group per position p of the sorted reference list.  The group at the head of a chunk -- first
+// reference of a row, or a multiple of CH -- sums the (at most CH) staging rows of its chunk in list order and
+// stores the row (whole run in one chunk: plain store; gP/gQ rows are zero between steps) or adds it atomically
+// (runs cut into several chunks).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_seg_reduce(int n, int n_users, const uint32_t *__restrict__ sk,
+                                                    const uint32_t *__restrict__ sv, const float *__restrict__ stage,
+                                                    float *gU, float *gI, int32_t *tU, int32_t *tI) {
+    constexpr int d = 4 * LPR, RPB = RowGroup<LPR>::kRowsPerBlock, CH = LPR < 16 ? LPR : 16;
+    RowGroup<LPR> g;
+    const long long p = (long long)blockIdx.x * RPB + g.slot;
+    const bool in = p < n;
+    const int lane = threadIdx.x & 63, gbase = lane - g.sub;
+    uint32_t ks = 0xffffffffu, vs = 0u;
+    if (in && g.sub < CH && p + g.sub < n) { ks = sk[p + g.sub]; vs = sv[p + g.sub]; }
+    const uint32_t key0 = __shfl(ks, gbase, kWave);
+    const uint32_t prev = (in && p > 0) ? sk[p - 1] : 0xffffffffu;
+    const uint64_t eq = __ballot(in && g.sub < CH && ks == key0);
+    const uint64_t gmask = LPR == 64 ? ~0ull : (((1ull << LPR) - 1ull) << gbase);
+    const int cnt_eq = __popcll(eq & gmask);                        // equal keys are contiguous from the head (sorted)
+    const int lim = (int)(p % CH) == 0 ? CH : CH - (int)(p % CH);
+    const int len = cnt_eq < lim ? cnt_eq : lim;
+    const bool head = in && (key0 != prev || (p % CH) == 0);
+    if (head) {
+        const uint32_t next = (p + len < n) ? sk[p + len] : 0xffffffffu;
+        const bool multi = key0 == prev || next == key0;
+        float4 acc = make_float4(0, 0, 0, 0);
+        int k = 0;
+        for (; k + 4 <= len; k += 4) {
+            const uint32_t r0 = __shfl(vs, gbase + k, kWave), r1 = __shfl(vs, gbase + k + 1, kWave);
+            const uint32_t r2 = __shfl(vs, gbase + k + 2, kWave), r3 = __shfl(vs, gbase + k + 3, kWave);
+            const float4 x0 = ld4(stage + (size_t)r0 * d + 4 * g.sub), x1 = ld4(stage + (size_t)r1 * d + 4 * g.sub);
+            const float4 x2 = ld4(stage + (size_t)r2 * d + 4 * g.sub), x3 = ld4(stage + (size_t)r3 * d + 4 * g.sub);
+            acc = add4(add4(add4(add4(acc, x0), x1), x2), x3);
+        }
+        for (; k < len; ++k) {
+            const uint32_t r = __shfl(vs, gbase + k, kWave);
+            acc = add4(acc, ld4(stage + (size_t)r * d + 4 * g.sub));
+        }
+        const bool is_user = key0 < (uint32_t)n_users;
+        const size_t row = is_user ? key0 : key0 - (uint32_t)n_users;
+        float *dst = (is_user ? gU : gI) + row * d + 4 * g.sub;
+        if (multi) {
+            MACR_ATOMIC_ADD(dst + 0, acc.x); MACR_ATOMIC_ADD(dst + 1, acc.y);
+            MACR_ATOMIC_ADD(dst + 2, acc.z); MACR_ATOMIC_ADD(dst + 3, acc.w);
+        } else {
+            st4(dst, acc);
+        }
+        if (g.sub == 0 && key0 != prev && tU) (is_user ? tU : tI)[row] = 1;
     }
 }
 
@@ -744,9 +1004,21 @@ static inline int bxb_rows(int B) {
     return 1;
 }
 
+static inline bool use_staging(int B) {
+    // MACR_STAGING=1/0 forces the large-batch / small-batch gradient path (measurements); default: by batch size
+    static const char *env = getenv("MACR_STAGING");
+    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
+    return B > kSmallBatchMax;
+}
+
 struct PairWs {
     StepScalars *scal;
     float *gw;          // [kBranchSlots][2*d] partial rows of the branch-vector gradients
+    bool staged;        // large-batch path: staging + sorted references + segment reduce
+    int32_t *perm, *us, *is, *js;            // small path: the batch grouped by positive item  [B] each
+    uint32_t *ska, *sva, *skb, *svb;         // staged: sort buffers [3B] each
+    uint32_t *ghist;                         // staged: [256 * ceil(3B / kSortTile)]
+    float *stage;                            // staged: [3][B][d] gradient rows in batch order
     int nblk_bwd;
     float *fwd;         // [7*Bp]
     float *part;        // [nblk_pair*4]
@@ -766,7 +1038,9 @@ static PairWs carve_pair_ws(void *base, int B, int d) {
     w.nrb = w.Bp / (64 * w.rows);
     w.ncb = w.Bp / 256;
     w.nblk_pair = (B + rpb - 1) / rpb;
-    w.nblk_bwd = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;   // 16 consecutive triples per block pass
+    w.staged = use_staging(B);
+    if (w.staged) w.nblk_bwd = w.nblk_pair < 4096 ? w.nblk_pair : 4096;                      // grid-strided row groups
+    else w.nblk_bwd = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;   // 16 consecutive slots per block pass
     char *p = static_cast<char *>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) { void *r = p ? p + off : nullptr; off += align_up(bytes, 256); return r; };
@@ -779,37 +1053,85 @@ static PairWs carve_pair_ws(void *base, int B, int d) {
     w.lpart = static_cast<float *>(take((size_t)w.nrb * w.ncb * 4));
     w.rowpart = static_cast<float *>(take((size_t)w.ncb * 2 * w.Bp * 4));
     w.colpart = static_cast<float *>(take((size_t)w.nrb * 2 * w.Bp * 4));
+    const size_t nsort = 3 * (size_t)B;
+    w.ska = w.sva = w.skb = w.svb = nullptr;
+    w.perm = w.us = w.is = w.js = nullptr; w.ghist = nullptr; w.stage = nullptr;
+    if (w.staged) {
+        w.ska = static_cast<uint32_t *>(take(nsort * 4)); w.sva = static_cast<uint32_t *>(take(nsort * 4));
+        w.skb = static_cast<uint32_t *>(take(nsort * 4)); w.svb = static_cast<uint32_t *>(take(nsort * 4));
+        w.ghist = static_cast<uint32_t *>(take((size_t)kRadix * ((nsort + kSortTile - 1) / kSortTile) * 4));
+        w.stage = static_cast<float *>(take(nsort * d * 4));
+    } else {
+        w.perm = static_cast<int32_t *>(take((size_t)B * 4)); w.us = static_cast<int32_t *>(take((size_t)B * 4));
+        w.is = static_cast<int32_t *>(take((size_t)B * 4));   w.js = static_cast<int32_t *>(take((size_t)B * 4));
+    }
     w.bytes = off;
     return w;
 }
 
+// grid: nbxb (B,B) blocks, then the blocks that group the batch (small path), then the pending Adam blocks
 template <int R>
-static void launch_bxb_rows(const PairWs &ws, int B, const AdamArgs *pending, long long n_adam_blocks, hipStream_t st) {
-    const int nbxb = ws.ncb * ws.nrb;
+static void launch_bxb_rows(const PairWs &ws, int B, const AdamArgs *pending, long long n_adam_blocks,
+                            const BatchSort &sort, hipStream_t st) {
+    const int nbxb = ws.ncb * ws.nrb, nsort = (sort.B + kBucketSpan - 1) / kBucketSpan;
     const bool full = B % 256 == 0;
     if (pending) {
-        const unsigned grid = (unsigned)(nbxb + n_adam_blocks);
-        if (full) k_bxb<R, true, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal);
-        else      k_bxb<R, false, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal);
+        const unsigned grid = (unsigned)(nbxb + nsort + n_adam_blocks);
+        if (full) k_bxb<R, true, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal, sort);
+        else      k_bxb<R, false, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal, sort);
     } else {
         AdamArgs none;
         none.n_seg = 0;
-        if (full) k_bxb<R, true, false><<<nbxb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal);
-        else      k_bxb<R, false, false><<<nbxb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal);
+        if (full) k_bxb<R, true, false><<<nbxb + nsort, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort);
+        else      k_bxb<R, false, false><<<nbxb + nsort, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort);
     }
 }
 
-// forward + (B,B) + backward of the pair loss; gradients are atomically added into gU/gI.
-static int launch_pair(int kind, int B, int d, const int32_t *u, const int32_t *i, const int32_t *j,
-                       const float *Usrc, const float *Isrc, const float *w, const float *wu,
+static BatchSort batch_sort_args(const PairWs &ws, int B, const int32_t *u, const int32_t *i, const int32_t *j) {
+    BatchSort s;
+    s.u = u; s.i = i; s.j = j; s.B = B;
+    s.perm = ws.perm; s.us = ws.us; s.is = ws.is; s.js = ws.js;
+    return s;
+}
+
+// staged path: sort the 3B references by row, then one owner per row sums its staging rows into gU/gI
+static int launch_ref_sort_reduce(int B, int d, int n_urows, int n_irows, const int32_t *u, const int32_t *i,
+                                  const int32_t *j, float *gU, float *gI, int32_t *tU, int32_t *tI, const PairWs &ws,
+                                  hipStream_t st) {
+    const int n = 3 * B;
+    k_refs_init<<<(B + 255) / 256 < 2048 ? (B + 255) / 256 : 2048, 256, 0, st>>>(B, n_urows, u, i, j, ws.ska, ws.sva);
+    const int flip = launch_radix_sort(ws.ska, ws.sva, ws.skb, ws.svb, n, (uint32_t)(n_urows + n_irows - 1), ws.ghist, st);
+    MACR_CHECK_LAUNCH("ref_sort", st);
+    const uint32_t *sk = flip ? ws.skb : ws.ska, *sv = flip ? ws.svb : ws.sva;
+    MACR_DISPATCH_LPR(d, (k_seg_reduce<LPR><<<(n + 256 / LPR - 1) / (256 / LPR), 256, 0, st>>>(n, n_urows, sk, sv, ws.stage,
+                                                                                              gU, gI, tU, tI)));
+    MACR_CHECK_LAUNCH("seg_reduce", st);
+    return MACR_OK;
+}
+
+// forward + (B,B) + backward of the pair loss; on return (stream order) gU/gI hold the de-duplicated gradient rows.
+// n_urows / n_irows: rows of the tables Usrc / Isrc (sort key range).
+static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const int32_t *u, const int32_t *i,
+                       const int32_t *j, const float *Usrc, const float *Isrc, const float *w, const float *wu,
                        float *gU, float *gI, int32_t *tU, int32_t *tI, float coef, int reg_on_gathered,
                        float *adam_pow, const macr_hyper *hp, const PairWs &ws, hipStream_t st,
                        const PendingAdam *pa = nullptr, const AdamArgs *pending = nullptr,
                        long long n_pending_blocks = 0, const LossArgs *finalize = nullptr) {
     const int grid = ws.nblk_pair;
+    BatchSort sort = batch_sort_args(ws, B, u, i, j);
+    if (ws.staged) sort.B = 0;
     if (kind == MACR_LOSS_NORMALBCE) {
-        MACR_DISPATCH_D(d, (k_pair_normal<D><<<ws.nblk_bwd, 256, 0, st>>>(B, u, i, j, Usrc, Isrc, gU, gI, tU, tI, ws.part,
-                                                                      coef, reg_on_gathered, adam_pow, adam_pow,
+        if (ws.staged) {
+            MACR_DISPATCH_LPR(d, (k_pair_normal_stage<LPR><<<ws.nblk_bwd, 256, 0, st>>>(
+                                     B, u, i, j, Usrc, Isrc, ws.stage, ws.part, coef, reg_on_gathered, adam_pow, adam_pow,
+                                     ws.scal, hp->lr, hp->beta1, hp->beta2)));
+            MACR_CHECK_LAUNCH("pair_normal", st);
+            return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st);
+        }
+        k_batch_sort<<<(B + kBucketSpan - 1) / kBucketSpan, 256, 0, st>>>(sort);
+        MACR_CHECK_LAUNCH("batch_sort", st);
+        MACR_DISPATCH_D(d, (k_pair_normal<D><<<ws.nblk_bwd, 256, 0, st>>>(B, ws.us, ws.is, ws.js, Usrc, Isrc, gU, gI, tU, tI,
+                                                                      ws.part, coef, reg_on_gathered, adam_pow, adam_pow,
                                                                       ws.scal, hp->lr, hp->beta1, hp->beta2)));
         MACR_CHECK_LAUNCH("pair_normal", st);
         return MACR_OK;
@@ -824,17 +1146,24 @@ static int launch_pair(int kind, int B, int d, const int32_t *u, const int32_t *
     }
     MACR_CHECK_LAUNCH("pair_fwd", st);
     switch (ws.rows) {
-        case 1: launch_bxb_rows<1>(ws, B, pending, n_pending_blocks, st); break;
-        case 2: launch_bxb_rows<2>(ws, B, pending, n_pending_blocks, st); break;
-        default: launch_bxb_rows<4>(ws, B, pending, n_pending_blocks, st); break;
+        case 1: launch_bxb_rows<1>(ws, B, pending, n_pending_blocks, sort, st); break;
+        case 2: launch_bxb_rows<2>(ws, B, pending, n_pending_blocks, sort, st); break;
+        default: launch_bxb_rows<4>(ws, B, pending, n_pending_blocks, sort, st); break;
     }
     MACR_CHECK_LAUNCH(pending ? "bxb+adam" : "bxb", st);
     LossArgs L;
     if (finalize) L = *finalize; else L.losses = nullptr;
-    MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd + 1, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w,
-                                                                      wu, ws.fwd, ws.rowpart, ws.colpart, gU, gI, tU, tI,
-                                                                      ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal,
-                                                                      hp->lr, hp->beta1, hp->beta2, L)));
+    if (ws.staged) {
+        MACR_DISPATCH_LPR(d, (k_pair_bwd_stage<LPR><<<ws.nblk_bwd + 1, 256, 0, st>>>(
+                                 B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, ws.stage,
+                                 ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal, hp->lr, hp->beta1, hp->beta2, L)));
+        MACR_CHECK_LAUNCH("pair_bwd", st);
+        return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st);
+    }
+    MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd + 1, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, ws.perm, ws.us, ws.is, ws.js,
+                                                                      Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, gU,
+                                                                      gI, tU, tI, ws.gw, hp->alpha, hp->beta, coef, adam_pow,
+                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2, L)));
     MACR_CHECK_LAUNCH("pair_bwd", st);
     return MACR_OK;
 }
@@ -934,8 +1263,8 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
         mf_adam_args(a, nb, true, true, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
                      touchedP, touchedQ, hp, ws);
     }
-    if (int e = launch_pair(loss_kind, B, d, u, i, j, P, Q, w, wu, gP, gQ, touchedP, touchedQ, coef, 1, adam_pow, hp,
-                            ws, st, pending ? &pa : nullptr, pending ? &a : nullptr, nb, defer ? &L : nullptr))
+    if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, P, Q, w, wu, gP, gQ, touchedP, touchedQ, coef, 1,
+                            adam_pow, hp, ws, st, pending ? &pa : nullptr, pending ? &a : nullptr, nb, defer ? &L : nullptr))
         return e;
     if (defer) return MACR_OK;
     mf_adam_args(a, nb, true, rubi, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
@@ -1032,8 +1361,8 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     fill_words(ws.dE, nd, 0u, st);
     // pair loss on the propagated rows; items live at rows n_users.. of E
     float *Ei = ws.E + (size_t)n_users * d, *dEi = ws.dE + (size_t)n_users * d;
-    if (int e = launch_pair(loss_kind, B, d, u, i, j, ws.E, Ei, w, wu, ws.dE, dEi, nullptr, nullptr, 0.0f, 0, adam_pow,
-                            hp, ws.pair, st))
+    if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, ws.E, Ei, w, wu, ws.dE, dEi, nullptr, nullptr,
+                            0.0f, 0, adam_pow, hp, ws.pair, st))
         return e;
     // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
     if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st)) return e;

@@ -128,9 +128,7 @@ class BPRMF(object):
     def to_device_batch(self, users, pos_items, neg_items):
         """Python lists (what Data.sample returns) -> one (3,B) int32 device tensor."""
         arr = np.asarray([users, pos_items, neg_items], dtype=np.int32)
-        # the order of the triples inside a batch is free: sorting by positive item makes equal rows adjacent so
-        # the backward kernel adds each run once (hot items are 5-10 % of all positives)
-        arr = arr[:, np.argsort(arr[1], kind="stable")]
+        # (the library orders the batch by positive item itself, on the device: batch_sort_block in train_kernels.hip)
         host = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
         return host.to(self.device, non_blocking=True)
 

@@ -35,10 +35,10 @@ def zipf_probs(n, device, s=1.0):
     return (p / p.sum()).to(torch.float32)
 
 
-def train_batches(n_steps, n_users, n_items, batch, gen, device, zipf=True, sort_by_pos=True):
+def train_batches(n_steps, n_users, n_items, batch, gen, device, zipf=True, sort_by_pos=False):
     """(n_steps,3,B) int32: users w/o replacement per step, Zipf positives, uniform negatives.
-    sort_by_pos: order the triples of every batch by positive item id, as the input pipeline does (the order
-    inside a batch is mathematically irrelevant; adjacent equal rows let the backward kernel add each run once)."""
+    sort_by_pos: pre-order the triples of every batch by positive item id (diagnostic only: the training step orders
+    its batch itself, on the device, so benchmarks feed batches exactly as a sampler emits them)."""
     probs = zipf_probs(n_items, device)
     out = torch.empty((n_steps, 3, batch), dtype=torch.int32, device=device)
     for s in range(n_steps):

@@ -191,6 +191,53 @@ def test_mf_deferred_random_shapes(ops, seed):
     assert int(lazy.tP.sum()) == 0 and int(lazy.tQ.sum()) == 0
 
 
+@pytest.mark.parametrize("kind,B,d,n_users,n_items", [
+    (oracle.LOSS_NORMALBCE, 20000, 64, 30000, 5000), (oracle.LOSS_NORMALBCE, 9001, 32, 500, 60),
+    (oracle.LOSS_NORMALBCE, 8200, 128, 9000, 700), (oracle.LOSS_RUBIBCEBOTH, 9000, 64, 12000, 3000),
+    (oracle.LOSS_RUBIBCEBOTH, 8448, 256, 400, 90)])
+def test_mf_large_batch_staged_path_matches_oracle(ops, kind, B, d, n_users, n_items):
+    """B > 8192 takes the staging + sorted-references + segment-reduce path (train_kernels.hip, k_seg_reduce): hot
+    rows (a third of the positives on one item: runs far longer than a 16-reference chunk), users drawn with
+    replacement when B > n_users, three steps so that the gradient scratch invariant is exercised."""
+    P, Q, w, wu, u, i, j = make_problem(B + d, n_users, n_items, d, B)
+    alpha, beta, decay, lr, bs = 1e-2, 1e-3, 1e-5, 1e-3, 1024
+    st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
+    Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
+    state = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), ops.make_hyper(lr, decay, alpha, beta, bs), B)
+    rs = np.random.RandomState(3)
+    for t in range(3):
+        if t:
+            u = rs.choice(n_users, B, replace=B > n_users).astype(np.int32)
+            i = (rs.zipf(1.2, B) % n_items).astype(np.int32)
+            j = rs.randint(0, n_items, B).astype(np.int32)
+        want = oracle.mf_train_step(kind, u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, bs)
+        got = state.step(kind, dev(u), dev(i), dev(j)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+        if t == 0:
+            for name, gm, om in (("P", state.mP, st.m[0]), ("Q", state.mQ, st.m[1])):
+                np.testing.assert_allclose(gm.cpu().numpy() / 0.1, om / 0.1, rtol=2e-4, atol=2e-6 * np.abs(om / 0.1).max(),
+                                           err_msg=name)
+    for name, mine, theirs in (("P", state.P, Po), ("Q", state.Q, Qo), ("mP", state.mP, st.m[0]), ("mQ", state.mQ, st.m[1]),
+                               ("vP", state.vP, st.v[0]), ("vQ", state.vQ, st.v[1])):
+        np.testing.assert_allclose(mine.cpu().numpy(), theirs, rtol=1e-3, atol=1e-6 + 1e-4 * np.abs(theirs).max(), err_msg=name)
+    assert float(state.gP.abs().max()) == 0.0 and float(state.gQ.abs().max()) == 0.0
+    assert int(state.tP.sum()) == 0 and int(state.tQ.sum()) == 0
+
+
+def test_mf_large_batch_staged_path_is_deterministic(ops):
+    """Every row has one owner that sums in sorted (= batch) order; only rows cut into several chunks add atomically.
+    With no row referenced more than a chunk's worth of times two runs give the same bits."""
+    B, d, n_users, n_items = 16384, 64, 40000, 30000
+    P, Q, w, wu, u, i, j = make_problem(77, n_users, n_items, d, B, dup=False)
+    outs = []
+    for _ in range(2):
+        state = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, 1024), B)
+        for _t in range(2):
+            state.step(oracle.LOSS_NORMALBCE, dev(u), dev(i), dev(j))
+        outs.append((state.P.cpu().numpy(), state.Q.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_mf_deferred_mode_flushes_on_batch_size_change(ops):
     P, Q, w, wu, u, i, j = make_problem(5, 300, 50, 64, 200)
     hyper = ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, 1024)
