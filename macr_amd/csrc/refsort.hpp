@@ -17,7 +17,7 @@
 namespace macr {
 
 constexpr int kRadix = 256;
-constexpr int kSortTile = 8192;          // keys per workgroup in the multi-block passes (256 threads x 32)
+constexpr int kSortTile = 16384;         // keys per workgroup in the multi-block passes (16 waves x 1024)
 
 // Lanes of the wave that hold the same 8-bit digit as this lane (valid lanes only).
 __device__ __forceinline__ uint64_t match_digit(uint32_t dgt, bool valid) {
@@ -108,48 +108,68 @@ __device__ __forceinline__ void block_digit_offsets(uint32_t *s_hist, uint32_t *
 }
 
 // ---- multi-block passes (large batches) -------------------------------------------------------------------------
+// A workgroup of 16 waves owns a tile of kSortTile keys (1024 per wave: every phase is a chain of memory and LDS
+// latencies, so a wave's share is kept short and the number of tiles -- the length of the histogram scan -- small).
 // ghist[digit][block]: per-workgroup digit counts, then (after k_rs_scan) the global start of (digit, block).
-static __global__ __launch_bounds__(256) void k_rs_count(const uint32_t *__restrict__ kin, int n, int shift,
-                                                         uint32_t *__restrict__ ghist, int nblk) {
+static __global__ __launch_bounds__(1024) void k_rs_count(const uint32_t *__restrict__ kin, int n, int shift,
+                                                          uint32_t *__restrict__ ghist, int nblk) {
     __shared__ uint32_t s_hist[kRadix];
-    s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < kRadix) s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int lo = blockIdx.x * kSortTile, hi = lo + kSortTile < n ? lo + kSortTile : n;
-    for (int p = lo + threadIdx.x; p < hi; p += 256) atomicAdd(&s_hist[(kin[p] >> shift) & 255u], 1u);
+    constexpr int NQ = kSortTile / 1024;
+    uint32_t k[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int p = lo + q * 1024 + threadIdx.x; k[q] = kin[p < hi ? p : hi - 1]; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (lo + q * 1024 + (int)threadIdx.x < hi) atomicAdd(&s_hist[(k[q] >> shift) & 255u], 1u);
     __syncthreads();
-    ghist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+    if (threadIdx.x < kRadix) ghist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
 }
 
-// exclusive scan of `total` words in place, one workgroup of 1024 threads
+// exclusive scan of `total` words in place, one workgroup of 1024 threads: rounds of 4096 words, four per thread
+// (coalesced 16-byte accesses; total is a multiple of 256), the next round's load issued before this round's scan.
 static __global__ __launch_bounds__(1024) void k_rs_scan(uint32_t *__restrict__ x, int total) {
     __shared__ uint32_t s_w[16];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int per = (total + 1023) / 1024, lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
-    uint32_t sum = 0;
-    for (int k = lo; k < hi; ++k) sum += x[k];
-    uint32_t inc = sum;
+    uint4 *x4 = reinterpret_cast<uint4 *>(x);
+    const int n4 = total / 4;
+    uint32_t carry = 0;
+    uint4 nxt = t < n4 ? x4[t] : make_uint4(0, 0, 0, 0);
+    for (int base = 0; base < n4; base += 1024) {
+        const uint4 v = nxt;
+        const int q = base + t;
+        if (q + 1024 < n4) nxt = x4[q + 1024];
+        const uint32_t sum = q < n4 ? v.x + v.y + v.z + v.w : 0u;
+        uint32_t inc = sum;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, kWave); if (lane >= o) inc += y; }
-    if (lane == 63) s_w[wid] = inc;
-    __syncthreads();
-    uint32_t run = inc - sum;
-    for (int w = 0; w < wid; ++w) run += s_w[w];
-    for (int k = lo; k < hi; ++k) { const uint32_t c = x[k]; x[k] = run; run += c; }
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, kWave); if (lane >= o) inc += y; }
+        __syncthreads();                                  // s_w of the previous round has been read
+        if (lane == 63) s_w[wid] = inc;
+        __syncthreads();
+        uint32_t run = carry + inc - sum, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const uint32_t c = s_w[w]; if (w < wid) run += c; tot += c; }
+        if (q < n4) x4[q] = make_uint4(run, run + v.x, run + v.x + v.y, run + v.x + v.y + v.z);
+        carry += tot;
+    }
 }
 
-static __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
-                                                           uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int n,
-                                                           int shift, const uint32_t *__restrict__ ghist, int nblk) {
-    __shared__ uint32_t s_hist[4 * kRadix + 4];
+static __global__ __launch_bounds__(1024) void k_rs_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                            uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int n,
+                                                            int shift, const uint32_t *__restrict__ ghist, int nblk) {
+    __shared__ uint32_t s_hist[16 * kRadix + 4];
     const int t = threadIdx.x, wid = t >> 6;
+    constexpr int per = kSortTile / 16;
     const int blo = blockIdx.x * kSortTile, bhi = blo + kSortTile < n ? blo + kSortTile : n;
-    const int lo = blo + wid * (kSortTile / 4) < bhi ? blo + wid * (kSortTile / 4) : bhi;
-    const int hi = lo + kSortTile / 4 < bhi ? lo + kSortTile / 4 : bhi;
-    for (int k = t; k < 4 * kRadix; k += 256) s_hist[k] = 0;
+    const int lo = blo + wid * per < bhi ? blo + wid * per : bhi;
+    const int hi = lo + per < bhi ? lo + per : bhi;
+    for (int k = t; k < 16 * kRadix; k += 1024) s_hist[k] = 0;
     __syncthreads();
     wave_count(kin, lo, hi, shift, s_hist + wid * kRadix);
     __syncthreads();
-    block_digit_offsets<4>(s_hist, s_hist + 4 * kRadix, ghist + blockIdx.x, nblk);
+    block_digit_offsets<16>(s_hist, s_hist + 16 * kRadix, ghist + blockIdx.x, nblk);
     wave_rank_scatter(kin, vin, lo, hi, shift, s_hist + wid * kRadix, kout, vout);
 }
 
@@ -167,9 +187,9 @@ static inline int launch_radix_sort(uint32_t *ka, uint32_t *va, uint32_t *kb, ui
     int flip = 0;
     for (int shift = 0; shift < bits; shift += 8) {
         uint32_t *kin = flip ? kb : ka, *vin = flip ? vb : va, *kout = flip ? ka : kb, *vout = flip ? va : vb;
-        k_rs_count<<<nblk, 256, 0, st>>>(kin, n, shift, ghist, nblk);
+        k_rs_count<<<nblk, 1024, 0, st>>>(kin, n, shift, ghist, nblk);
         k_rs_scan<<<1, 1024, 0, st>>>(ghist, kRadix * nblk);
-        k_rs_scatter<<<nblk, 256, 0, st>>>(kin, vin, kout, vout, n, shift, ghist, nblk);
+        k_rs_scatter<<<nblk, 1024, 0, st>>>(kin, vin, kout, vout, n, shift, ghist, nblk);
         flip ^= 1;
     }
     return flip;

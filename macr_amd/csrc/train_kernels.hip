@@ -73,7 +73,8 @@ struct AdamSeg {
 struct AdamArgs {
     AdamSeg seg[4];
     int n_seg;
-    int lpr;                 // float4 per row
+    int lpr;                 // float4 per row (8, 16, 32 or 64)
+    int lpr_shift;           // log2(lpr): row of a float4 = index >> lpr_shift (a 64-bit division per access otherwise)
     float b1, b2, eps;
 };
 struct LossArgs {
@@ -111,7 +112,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, flo
     float4 gsum = make_float4(0, 0, 0, 0);
     if (PARTS && sg.n_parts > 0) {
         // branch-vector segment (one row): the whole block sums the per-block partial rows of pair_bwd
-        const int sub = threadIdx.x % a.lpr, grp = threadIdx.x / a.lpr, ngrp = 256 / a.lpr;
+        const int sub = threadIdx.x & (a.lpr - 1), grp = threadIdx.x >> a.lpr_shift, ngrp = 256 >> a.lpr_shift;
         for (int k = grp; k < sg.n_parts; k += ngrp) {
             gsum = add4(gsum, ld4(sg.g + (size_t)k * sg.part_stride + 4 * sub));
             st4(sg.g + (size_t)k * sg.part_stride + 4 * sub, make_float4(0, 0, 0, 0));
@@ -140,7 +141,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, flo
         vi[it] = base + (long long)it * 256;
         flag[it] = 0;
         if (vi[it] < sg.n_vec) {
-            flag[it] = sg.touched ? sg.touched[vi[it] / a.lpr] : (sg.g != nullptr);
+            flag[it] = sg.touched ? sg.touched[vi[it] >> a.lpr_shift] : (sg.g != nullptr);
             th[it] = ld4(sg.theta + vi[it] * 4); m[it] = ld4(sg.m + vi[it] * 4); v[it] = ld4(sg.v + vi[it] * 4);
         }
     }
@@ -152,7 +153,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, flo
             gr[it] = ld4(sg.g + vi[it] * 4);
             if (sg.touched) {                // consume: gradient row and flag back to zero
                 st4(sg.g + vi[it] * 4, make_float4(0, 0, 0, 0));
-                if (vi[it] % a.lpr == 0) sg.touched[vi[it] / a.lpr] = 0;
+                if ((vi[it] & (a.lpr - 1)) == 0) sg.touched[vi[it] >> a.lpr_shift] = 0;
             }
         }
     }
@@ -544,21 +545,24 @@ struct WaveRow {
 // batch costs (#chunks it spans) serialised atomics instead of (#references)).
 template <int D>
 __device__ __forceinline__ void combine_positive_rows(const int *s_pos, const float (*s_gi)[D], float *gI) {
-    if (threadIdx.x >= D) return;
+    // thread = (element k, part): part p of NP handles the distinct rows whose FIRST slot L has L % NP == p
+    constexpr int NP = D >= 256 ? 1 : 256 / D;
+    const int k = threadIdx.x % D, part = threadIdx.x / D;
     int rows[kChunkT];
 #pragma unroll
     for (int s = 0; s < kChunkT; ++s) rows[s] = s_pos[s];
-    for (int k = threadIdx.x; k < D; k += 256) {
-        uint32_t done = 0;
 #pragma unroll
-        for (int L = 0; L < kChunkT; ++L) {
-            if (rows[L] < 0 || ((done >> L) & 1u)) continue;
-            float acc = s_gi[L][k];
+    for (int L = 0; L < kChunkT; ++L) {
+        if (rows[L] < 0 || (L % NP) != part) continue;
+        bool first = true;
 #pragma unroll
-            for (int s2 = L + 1; s2 < kChunkT; ++s2)
-                if (rows[s2] == rows[L]) { acc += s_gi[s2][k]; done |= 1u << s2; }
-            MACR_ATOMIC_ADD(gI + (size_t)rows[L] * D + k, acc);
-        }
+        for (int s0 = 0; s0 < L; ++s0) first = first && rows[s0] != rows[L];
+        if (!first) continue;
+        float acc = s_gi[L][k];
+#pragma unroll
+        for (int s2 = L + 1; s2 < kChunkT; ++s2)
+            if (rows[s2] == rows[L]) acc += s_gi[s2][k];
+        MACR_ATOMIC_ADD(gI + (size_t)rows[L] * D + k, acc);
     }
 }
 
@@ -586,8 +590,6 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     __shared__ float s_w[4][2][D];
     __shared__ float s_gi[kChunkT][D];
     __shared__ int s_pos[kChunkT];
-    __shared__ int s_tp[kChunkT];
-    __shared__ float s_d[4][kChunkT];
     const int nblk = gridDim.x - 1;
     if ((int)blockIdx.x == nblk) {
         // Step bookkeeping, by one wave of an extra block.  Every Adam pass of the PREVIOUS update has completed
@@ -611,57 +613,61 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
         wk[e] = act ? w[k] : 0.f; wuk[e] = act ? wu[k] : 0.f; aw[e] = 0.f; awu[e] = 0.f;
     }
     const float inv_b2 = 1.0f / ((float)B * (float)B), eps = 1e-10f, invB = 1.0f / (float)B;
+    constexpr int SPW = kChunkT / 4;               // slots per wave
     // A block owns kChunkT CONSECUTIVE slots of the batch BUCKETED BY POSITIVE ITEM (u, i, j are the bucketed copies,
     // perm[s] the triple's position in the caller's batch = its index in fwd and in the bxb partials; see
-    // batch_bucket_block) and adds equal positive rows of a chunk once (combine_positive_rows).
+    // batch_bucket_block) and adds equal positive rows of a chunk once (combine_positive_rows).  A wave owns SPW of
+    // the slots from the index loads to the atomics: one trip for the indices, one for everything that depends on
+    // them (bxb partials, forward scalars, rows), no barrier in between.
     for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += nblk) {
-        // The chunk's column sums dp,dn and row sums da,db of the (B,B) term: wave w reduces quantity w over the bxb
-        // partials for all 16 triples at once -- lane (k%4, t%16) reads 64-byte runs -- instead of every triple's wave
-        // gathering 96 words from 96 different lines.
-        // (the wave's own 4x3 row indices are fetched alongside, so the row gathers can start right after the barrier)
-        int my_idx = 0;
+        const int slot0 = chunk * kChunkT + wid * SPW;
+        int my_idx = 0;                             // lanes 0..4*SPW-1: u | i | j | perm of the wave's slots
         {
-            const int tq = chunk * kChunkT + wid * (kChunkT / 4) + (lane & 3);
-            if (lane < 12 && tq < B) my_idx = (lane < 4 ? u : lane < 8 ? i : j)[tq];
+            const int tq = slot0 + (lane % SPW);
+            if (lane < 4 * SPW && tq < B) my_idx = (lane < SPW ? u : lane < 2 * SPW ? i : lane < 3 * SPW ? j : perm)[tq];
         }
-        {
-            const int tt = lane & 15, kq = lane >> 4, slot_t = chunk * kChunkT + tt;
-            const float *src = wid < 2 ? colpart + (size_t)wid * Bp : rowpart + (size_t)(wid - 2) * Bp;
-            const int np = wid < 2 ? nrb : ncb;
-            float acc = 0.f;
-            const int t = slot_t < B ? perm[slot_t] : 0;
+        // column sums dp,dn and row sums da,db of the (B,B) term: lane (q = lane/16, kk = lane%16) adds partials
+        // kk, kk+16, ... of slot q, then the 16 lanes of a slot meet by shuffles
+        const int q_own = lane >> 4, kk = lane & 15;
+        float dp = 0.f, dn = 0.f, da = 0.f, db = 0.f, ssi = 0.f, ssj = 0.f, ssu = 0.f;
+        const int t_own = __shfl(my_idx, 3 * SPW + q_own, kWave);
+        const bool own_ok = slot0 + q_own < B;
 #ifndef MACR_ABL_NOPART
-            if (slot_t < B)
-                for (int k = kq; k < np; k += 4) acc += src[(size_t)k * 2 * Bp + t];
-#endif
-            acc += __shfl_xor(acc, 16, kWave);
-            acc += __shfl_xor(acc, 32, kWave);
-            if (kq == 0) { s_d[wid][tt] = acc * inv_b2; if (wid == 0) s_tp[tt] = t; }
+        if (own_ok) {
+            for (int k = kk; k < nrb; k += 16) { dp += colpart[((size_t)k * 2) * Bp + t_own]; dn += colpart[((size_t)k * 2 + 1) * Bp + t_own]; }
+            for (int k = kk; k < ncb; k += 16) { da += rowpart[((size_t)k * 2) * Bp + t_own]; db += rowpart[((size_t)k * 2 + 1) * Bp + t_own]; }
+            if (kk < 3) ssi = fwd[(4 + kk) * (size_t)Bp + t_own];      // lane kk = 0,1,2: sig(si), sig(sj), sig(su)
         }
-        __syncthreads();
-#pragma unroll                                   // the four triples' row gathers are issued together
-        for (int q = 0; q < kChunkT / 4; ++q) {
-            const int slot = wid * (kChunkT / 4) + q;
-            if (chunk * kChunkT + slot >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
-            const int t = s_tp[slot];
-            const float dp = s_d[0][slot], dn = s_d[1][slot], da = s_d[2][slot], db = s_d[3][slot];
-            const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
-            const float dsi = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
-            const float dsj = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
-            const float dsu = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
+#endif
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            dp += __shfl_xor(dp, m, kWave); dn += __shfl_xor(dn, m, kWave);
+            da += __shfl_xor(da, m, kWave); db += __shfl_xor(db, m, kWave);
+        }
+        ssj = __shfl(ssi, (lane & 48) + 1, kWave); ssu = __shfl(ssi, (lane & 48) + 2, kWave); ssi = __shfl(ssi, lane & 48, kWave);
+        dp *= inv_b2; dn *= inv_b2; da *= inv_b2; db *= inv_b2;
+        const float dsi_own = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
+        const float dsj_own = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
+        const float dsu_own = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
                               (beta * invB) * (dneglog_sig(ssu, eps) + dneglog_1msig(ssu, eps));
-            const int ru = __shfl(my_idx, q, kWave), ri = __shfl(my_idx, 4 + q, kWave), rj = __shfl(my_idx, 8 + q, kWave);
+#pragma unroll                                   // the SPW triples' row gathers are issued together
+        for (int q = 0; q < SPW; ++q) {
+            const int slot = wid * SPW + q;
+            if (slot0 + q >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
+            const float dpq = __shfl(dp, q * 16, kWave), dnq = __shfl(dn, q * 16, kWave);
+            const float dsi = __shfl(dsi_own, q * 16, kWave), dsj = __shfl(dsj_own, q * 16, kWave), dsu = __shfl(dsu_own, q * 16, kWave);
+            const int ru = __shfl(my_idx, q, kWave), ri = __shfl(my_idx, SPW + q, kWave), rj = __shfl(my_idx, 2 * SPW + q, kWave);
             if (act) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     const int k = lane + 64 * e;
                     const float eu = Usrc[(size_t)ru * D + k], ei = Isrc[(size_t)ri * D + k], ej = Isrc[(size_t)rj * D + k];
-                    const float gu = fmaf(coef, eu, fmaf(dsu, wuk[e], fmaf(dn, ej, dp * ei)));
-                    const float gi = fmaf(coef, ei, fmaf(dsi, wk[e], dp * eu));
-                    const float gj = fmaf(coef, ej, fmaf(dsj, wk[e], dn * eu));
+                    const float gu = fmaf(coef, eu, fmaf(dsu, wuk[e], fmaf(dnq, ej, dpq * ei)));
+                    const float gi = fmaf(coef, ei, fmaf(dsi, wk[e], dpq * eu));
+                    const float gj = fmaf(coef, ej, fmaf(dsj, wk[e], dnq * eu));
                     MACR_ATOMIC_ADD(gU + (size_t)ru * D + k, gu);
                     MACR_ATOMIC_ADD(gI + (size_t)rj * D + k, gj);
-                    s_gi[slot][k] = gi;                         // positive row: combined per run below
+                    s_gi[slot][k] = gi;                         // positive row: combined per chunk below
                     aw[e] = fmaf(dsi, ei, fmaf(dsj, ej, aw[e]));
                     awu[e] = fmaf(dsu, eu, awu[e]);
                 }
@@ -681,9 +687,9 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * D; k += 256) {
-        const int q = k / D, kk = k % D;
+        const int q = k / D, kk2 = k % D;
         MACR_ATOMIC_ADD(wpart + (size_t)(blockIdx.x % kBranchSlots) * 2 * D + k,
-                        (s_w[0][q][kk] + s_w[1][q][kk]) + (s_w[2][q][kk] + s_w[3][q][kk]));
+                        (s_w[0][q][kk2] + s_w[1][q][kk2]) + (s_w[2][q][kk2] + s_w[3][q][kk2]));
     }
 }
 
@@ -1203,7 +1209,7 @@ static void mf_adam_args(AdamArgs &a, long long &nb, bool tables, bool branch, i
                          float *mw, float *vw, float *mwu, float *vwu, float *gP, float *gQ, int32_t *tP,
                          int32_t *tQ, const macr_hyper *hp, const PairWs &ws) {
     a.n_seg = 0;
-    a.lpr = d / 4;
+    a.lpr = d / 4; a.lpr_shift = d == 32 ? 3 : d == 64 ? 4 : d == 128 ? 5 : 6;
     a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
     nb = 0;
     if (tables) {
@@ -1373,7 +1379,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     MACR_CHECK_LAUNCH("reg_scatter", st);
     AdamArgs a;
     a.n_seg = 0;
-    a.lpr = d / 4;
+    a.lpr = d / 4; a.lpr_shift = d == 32 ? 3 : d == 64 ? 4 : d == 128 ? 5 : 6;
     a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
     long long nb = 0;
     add_seg(a, T, mT, vT, ws.G, nullptr, N, nb);

@@ -13,7 +13,7 @@ gen = torch.Generator(device=dev).manual_seed(1)
 P = synth.xavier_table(n_users, d, gen, dev); Q = synth.xavier_table(n_items, d, gen, dev)
 w = synth.xavier_table(d, 1, gen, dev).reshape(-1); wu = synth.xavier_table(d, 1, gen, dev).reshape(-1)
 out = []
-for logB in (12, 16, 18, 20):
+for logB in (12, 14, 16, 18, 20):
     B = 1 << logB
     for kind, name in ((ops.LOSS_NORMALBCE, "normalbce"),):
         state = ops.MFState(P, Q, w, wu, ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, B), B)
@@ -32,8 +32,11 @@ for logB in (12, 16, 18, 20):
         pair_us = us.get("pair_normal", 0.0)
         bytes_pair = B * (24 * d + 12)
         bytes_adam = 24 * d * (n_users + n_items)
+        grad_us = pair_us + us.get("ref_sort", 0.0) + us.get("seg_reduce", 0.0) + us.get("batch_sort", 0.0)
         out.append({"B": B, "loss": name, "kernels_us": {k: round(v, 1) for k, v in us.items()},
                     "pair_GBps": bytes_pair / (pair_us * 1e-6) / 1e9, "pair_frac_of_8TBps": bytes_pair / (pair_us * 1e-6) / 8e12,
+                    "gradient_path_us": round(grad_us, 1),          # pair kernel + reference sort + segment reduce
+                    "gradient_path_frac_of_8TBps": bytes_pair / (grad_us * 1e-6) / 8e12,
                     "adam_GBps": bytes_adam / (us["adam_dense"] * 1e-6) / 1e9})
         del state
 print(json.dumps(out))
