@@ -72,11 +72,15 @@ def test_mf_train_step_matches_oracle(ops, kind, B, d, n_users, n_items):
             if kind == oracle.LOSS_RUBIBCEBOTH:
                 np.testing.assert_allclose(state.mw.cpu().numpy(), st.m[2], rtol=2e-4, atol=1e-6 * np.abs(st.m[2]).max())
                 np.testing.assert_allclose(state.mwu.cpu().numpy(), st.m[3], rtol=2e-4, atol=1e-6 * np.abs(st.m[3]).max())
-        # tables: every row moves every step (dense Adam); a step is at most ~lr
-        np.testing.assert_allclose(state.P.cpu().numpy(), Po, rtol=0, atol=0.02 * lr * (t + 1))
-        np.testing.assert_allclose(state.Q.cpu().numpy(), Qo, rtol=0, atol=0.02 * lr * (t + 1))
-        np.testing.assert_allclose(state.w.cpu().numpy(), wo, rtol=0, atol=0.02 * lr * (t + 1))
-        np.testing.assert_allclose(state.wu.cpu().numpy(), wuo, rtol=0, atol=0.02 * lr * (t + 1))
+        # tables: every row moves every step (dense Adam); a step is at most ~lr.  The Adam update lr_t*m/(sqrt(v)+eps)
+        # amplifies a relative gradient difference only where |g| ~ eps, by at most lr/4 per unit of relative error:
+        # 0.2 % of a step bounds it with room for summation-order noise in cancelling gradient sums.
+        for name, mine, theirs in (("P", state.P, Po), ("Q", state.Q, Qo), ("w", state.w, wo), ("wu", state.wu, wuo)):
+            np.testing.assert_allclose(mine.cpu().numpy(), theirs, rtol=0, atol=2e-3 * lr * (t + 1), err_msg=name)
+    # Adam slots after three steps: m and v of every table against the oracle
+    for name, mine, theirs in (("mP", state.mP, st.m[0]), ("mQ", state.mQ, st.m[1]), ("vP", state.vP, st.v[0]),
+                               ("vQ", state.vQ, st.v[1])):
+        np.testing.assert_allclose(mine.cpu().numpy(), theirs, rtol=1e-4, atol=2e-6 * np.abs(theirs).max(), err_msg=name)
     # scratch invariants of the ABI: gradient scratch and touched flags are zero again
     assert float(state.gP.abs().max()) == 0.0 and float(state.gQ.abs().max()) == 0.0
     assert int(state.tP.sum()) == 0 and int(state.tQ.sum()) == 0
