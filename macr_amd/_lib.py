@@ -89,3 +89,29 @@ def lib():
 def check(rc):
     if rc != OK:
         raise MacrError(rc, lib().macr_last_error().decode("utf-8", "replace"))
+
+
+# ---- the reference's own evaluator ABI (include/macr_eval_compat.h): same names and signatures as
+# macr_lightgcn/evaluator/cpp/include/tools.h:24 and evaluate_foldout.h:115-118
+COMPAT_LIB_PATH = os.path.join(_HERE, "csrc", "libmacr_eval_compat.so")
+COMPAT_SIGNATURES = {
+    "c_top_k_array_index": (None, [_p, _i, _i, _i, _i, _p]),
+    "evaluate_foldout": (None, [_i, _p, _i, _p, _p, _i, _p]),
+    "macr_eval_compat_status": (_i, []),
+    "macr_eval_compat_error": (ctypes.c_char_p, []),
+}
+_compat = None
+
+
+def compat_lib():
+    global _compat
+    if _compat is None:
+        if not os.path.exists(COMPAT_LIB_PATH):
+            raise RuntimeError("macr_amd: %s is missing; build it with `python -m macr_amd.build`" % COMPAT_LIB_PATH)
+        L = ctypes.CDLL(COMPAT_LIB_PATH)
+        for name, (res, args) in COMPAT_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _compat = L
+    return _compat

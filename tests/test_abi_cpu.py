@@ -58,3 +58,18 @@ def test_ops_reject_cpu_tensors():
     from macr_amd import ops
     with pytest.raises(ops.MacrError):
         ops.branch_sigmoid(torch.zeros(4, 64), torch.zeros(64))
+
+
+def test_reference_evaluator_abi_is_exported_with_its_own_names():
+    """include/macr_eval_compat.h: the two functions the reference's .pyx binds (apt_evaluate_foldout.pyx:11-19)."""
+    build()
+    L = _lib.compat_lib()
+    src = open(os.path.join(REPO, "include", "macr_eval_compat.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b([a-z_][a-z0-9_]+)\s*\(", src)) - {"defined"})
+    assert declared == sorted(_lib.COMPAT_SIGNATURES)
+    for name in declared:
+        assert hasattr(L, name), name
+    # argument validation is checkable without a GPU: a failed call reports through the status channel
+    L.c_top_k_array_index(None, 5, 2, 3, 1, None)
+    assert L.macr_eval_compat_status() == _lib.E_INVALID and b"bad argument" in L.macr_eval_compat_error()

@@ -585,6 +585,38 @@ def test_golden_cpp_evaluator_cases(ops, golden_dir):
         np.testing.assert_allclose(res, z[name + "_results"], rtol=2e-7, atol=0)
 
 
+def test_golden_cpp_evaluator_cases_through_the_reference_abi(golden_dir):
+    """G7 through libmacr_eval_compat.so: c_top_k_array_index / evaluate_foldout with the reference's own signatures
+    (host pointers, int** ground truths in any order, void return) -- what the reference's .pyx links against."""
+    import ctypes
+    import os
+    from macr_amd import _lib
+    L = _lib.compat_lib()
+    z = np.load(os.path.join(golden_dir, "G7_cpp_eval_cases.npz"))
+    for name in "abcd":
+        s, k = np.ascontiguousarray(z[name + "_scores"], dtype=np.float32), int(z[name + "_k"])
+        lens, flat = z[name + "_gt_len"].astype(np.int32), z[name + "_gt_flat"].astype(np.int32)
+        rows, cols = s.shape
+        rank = np.full((rows, k), -7, np.int32)
+        L.c_top_k_array_index(s.ctypes.data, cols, rows, k, 4, rank.ctypes.data)
+        assert L.macr_eval_compat_status() == 0, L.macr_eval_compat_error()
+        if name != "d":
+            assert np.array_equal(rank, z[name + "_rankings"])
+        # int **ground_truths: borrowed row pointers, rows given in DESCENDING order to show any order is accepted
+        starts = np.concatenate([[0], np.cumsum(lens)])
+        rows_gt = [np.ascontiguousarray(flat[starts[u]:starts[u + 1]][::-1]) for u in range(rows)]
+        ptrs = (ctypes.c_void_p * rows)(*[r.ctypes.data if len(r) else None for r in rows_gt])
+        res = np.zeros((rows, 5 * k), np.float32)
+        L.evaluate_foldout(rows, rank.ctypes.data, k, ctypes.cast(ptrs, ctypes.c_void_p), lens.ctypes.data, 4, res.ctypes.data)
+        assert L.macr_eval_compat_status() == 0, L.macr_eval_compat_error()
+        np.testing.assert_allclose(res, z[name + "_results"], rtol=2e-7, atol=0)
+    # no error channel in the reference: a failed call poisons its output and sets the status
+    bad = np.zeros((2, 40), np.float32)
+    out = np.zeros((2, 40), np.int32)
+    L.c_top_k_array_index(bad.ctypes.data, 40, 2, 40, 1, out.ctypes.data)           # top_k > MACR_MAX_TOPK
+    assert L.macr_eval_compat_status() != 0 and (out == -1).all()
+
+
 def test_errors_are_loud(ops):
     with pytest.raises(ops.MacrError):
         ops.topk_scores(dev(np.zeros((2, 5), np.float32)), 64)              # K > MACR_MAX_TOPK
