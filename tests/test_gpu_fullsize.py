@@ -126,3 +126,100 @@ def test_yelp_size_propagation(ops):
     lhs = float((x.double() * ops.lgcn_propagate(adj, y, 2).double()).sum())
     rhs = float((ops.lgcn_propagate(adj, x, 2).double() * y.double()).sum())
     assert abs(lhs - rhs) < 1e-6 * abs(lhs) + 1e-3
+
+
+def yelp_graph(cfg, seed=9):
+    import scipy.sparse as sp
+    from macr_amd import synth
+    n_u, n_i = cfg["n_users"], cfg["n_items"]
+    lists = synth.interaction_lists(n_u, n_i, cfg["n_train"] / n_u, seed=seed)
+    rows = np.repeat(np.arange(n_u), [len(l) for l in lists])
+    cols = np.concatenate(lists)
+    R = sp.csr_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n_u, n_i))
+    A = sp.bmat([[None, R], [R.T, None]], format="csr", dtype=np.float32)
+    deg = np.asarray(A.sum(1)).ravel()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5).astype(np.float32)
+    dinv[np.isinf(dinv)] = 0
+    A = (sp.diags(dinv) @ A @ sp.diags(dinv)).tocsr().astype(np.float32)
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("kind", [1, 0])
+def test_yelp_size_lightgcn_train_step(ops, kind):
+    """configs[3], the WHOLE step: Yelp2018 shapes (N = 69 716 nodes, nnz ~2.7 M), 2 layers, d = 64, B = 4096:
+    propagation, pair loss on propagated rows, backward through the propagation, ego-row regulariser, dense Adam --
+    two consecutive steps against the oracle (LightGCN.py:288-309, :495-532 / :415-429, :525-528, :201 / :186)."""
+    from macr_amd import synth
+    cfg = synth.WORKLOADS["yelp2018"]
+    n_u, n_i, d, B = cfg["n_users"], cfg["n_items"], 64, cfg["batch"]
+    A = yelp_graph(cfg)
+    rs = np.random.RandomState(4)
+    T = (rs.standard_normal((n_u + n_i, d)) * 0.1).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    adj = ops.CSR.from_scipy(A, "cuda")
+    state = ops.LGCNState(dev(T), n_u, n_i, dev(w), dev(wu), adj, 2,
+                          ops.make_hyper(cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B), B)
+    st = oracle.AdamState([T.shape, (d,), (d,)])
+    To, wo, wuo = T.copy(), w.copy(), wu.copy()
+    for t in range(2):
+        u = rs.choice(n_u, B, replace=False).astype(np.int32)
+        i = (rs.zipf(1.3, B) - 1).clip(0, n_i - 1).astype(np.int32)          # popular positives: hot rows in the scatter
+        j = rs.randint(0, n_i, B).astype(np.int32)
+        want = oracle.lgcn_train_step(kind, n_u, n_i, 2, A.indptr, A.indices, A.data, u, i, j, To, wo, wuo, st,
+                                      cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
+        got = state.step(kind, dev(u), dev(i), dev(j)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, err_msg="step %d" % t)
+        if t == 0:           # m = 0.1 * dense gradient of the ego table (every row: the propagation spreads it)
+            g_hip, g_orc = state.mT.cpu().numpy() / 0.1, st.m[0] / 0.1
+            np.testing.assert_allclose(g_hip, g_orc, rtol=5e-4, atol=2e-6 * np.abs(g_orc).max())
+    np.testing.assert_allclose(state.mT.cpu().numpy(), st.m[0], rtol=5e-4, atol=2e-6 * np.abs(st.m[0]).max())
+    np.testing.assert_allclose(state.vT.cpu().numpy(), st.v[0], rtol=1e-3, atol=2e-6 * np.abs(st.v[0]).max())
+    np.testing.assert_allclose(state.T.cpu().numpy(), To, rtol=0, atol=4e-3 * cfg["lr"])
+    if kind == 1:
+        np.testing.assert_allclose(state.w.cpu().numpy(), wo, rtol=0, atol=4e-3 * cfg["lr"])
+        np.testing.assert_allclose(state.wu.cpu().numpy(), wuo, rtol=0, atol=4e-3 * cfg["lr"])
+
+
+def test_config4_shard_eval(ops):
+    """configs[4] (10 M x 1 M, d = 128, item-sharded over 8 GPUs), ONE rank's share at full size: 20 000 query users
+    against a 125 000-item shard whose global ids start at item_offset.  The oracle ranks every 97th user bit for
+    bit; all users: the shard's result is independent of how the listing is split, sub-shards merge to the same
+    lists (what the all-gather + merge does across ranks), no masked item is returned, ids carry the offset."""
+    from macr_amd import synth
+    from macr_amd.evaluator import Evaluator
+    cfg = dict(n_users=200000, n_items=125000, d=128, n_train=200000 * 20, n_test_users=20000, test_per_user=10)
+    d, off = 128, 3 * 125000                                   # rank 3 of 8
+    rs = np.random.RandomState(5)
+    P = (rs.standard_normal((cfg["n_users"], d)) * 0.2).astype(np.float32)
+    Q = (rs.standard_normal((cfg["n_items"], d)) * 0.2).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    users, mask_local, _ = synth.eval_problem(cfg, seed=11)
+    mask = [[off + x for x in row] for row in mask_local]      # masks hold GLOBAL ids
+    Pd, Qd, wd, wud, uid = dev(P), dev(Q), dev(w), dev(wu), dev(users)
+    sig_i = ops.branch_sigmoid(Qd, wd)
+    sig_u = ops.branch_sigmoid(Pd, wud, uid)
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    v, ix = ops.score_topk(ops.SCORE_RUBI_BOTH, Pd, uid, Qd, 20, sig_u, sig_i, 40.0, mcsr, off)
+    val, idx, cnt = ops.topk_merge(v, ix)
+    sel = np.arange(0, len(users), 97)
+    wv, wi, wc = oracle.score_topk(oracle.SCORE_RUBI_BOTH, P[users[sel]], Q, 20, sig_u.cpu().numpy()[sel],
+                                   sig_i.cpu().numpy(), 40.0, oracle.csr_from_lists([mask[q] for q in sel]), item_offset=off)
+    assert np.array_equal(idx.cpu().numpy()[sel], wi)
+    assert np.array_equal(val.cpu().numpy()[sel].view(np.uint32), wv.view(np.uint32))
+    ixn = idx.cpu().numpy()
+    assert ixn.min() >= off and ixn.max() < off + cfg["n_items"]
+    for q in range(0, len(users), 211):
+        assert not set(ixn[q]) & set(mask[q])
+    # two sub-shards of this shard, merged: the 1/2/4/8-rank invariance at shard scale
+    half = cfg["n_items"] // 2 + 7
+    parts = []
+    for lo, hi in ((0, half), (half, cfg["n_items"])):
+        pv, pi = ops.score_topk(ops.SCORE_RUBI_BOTH, Pd, uid, Qd[lo:hi].contiguous(), 20, sig_u, sig_i[lo:hi].contiguous(),
+                                40.0, mcsr, off + lo)
+        mv, mi, _ = ops.topk_merge(pv, pi)
+        parts.append((mv, mi))
+    gv = torch.stack([p[0] for p in parts]); gi = torch.stack([p[1] for p in parts])
+    m2 = ops.topk_merge(gv, gi)
+    assert torch.equal(m2[1], idx) and torch.equal(m2[0], val)
