@@ -39,15 +39,20 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     5
+#define MACR_ABI_VERSION     6
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
 #define MACR_LOSS_RUBIBCEBOTH 1  /* --train rubibceboth macr_mf/model.py:185-222 ; --loss bceboth LightGCN.py:495-532 */
+#define MACR_LOSS_RUBIBCE     2  /* --train rubibce     macr_mf/model.py:158-183 : item branch only (MF only);
+                                    the rubibceboth graph with sigmoid(e_u.w_user) := 1, w_user untouched        */
 
 /* score kinds */
 #define MACR_SCORE_NORMAL    0   /* batch_ratings      macr_mf/model.py:45  ; LightGCN.py:166 */
-#define MACR_SCORE_RUBI_BOTH 1   /* rubi_ratings_both  macr_mf/model.py:199 ; LightGCN.py:509 */
+#define MACR_SCORE_RUBI_BOTH 1   /* rubi_ratings_both  macr_mf/model.py:199 ; LightGCN.py:509   ((y - c) * sig_i) * sig_u */
+#define MACR_SCORE_RUBI      2   /* rubi_ratings       macr_mf/model.py:141                      (y - c) * sig_i          */
+#define MACR_SCORE_DIRECT_MINUS      3  /* direct_minus_ratings      model.py:142               y - (c * sig_i)           */
+#define MACR_SCORE_DIRECT_MINUS_BOTH 4  /* direct_minus_ratings_both model.py:201 ; LightGCN.py:510  y - ((c * sig_i) * sig_u) */
 
 /* largest K the top-K kernels are built for (the reference uses 20; parser default max 30) */
 #define MACR_MAX_TOPK 32
@@ -132,7 +137,7 @@ int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items,
                        float *adam_pow, const macr_hyper *hp,
                        float *losses, int flags, void *workspace, size_t workspace_bytes, void *stream);
 
-int macr_mf_train_flush(int B, int d, int n_users, int n_items,
+int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int n_items,
                         float *P, float *Q, float *w, float *wu,
                         float *mP, float *vP, float *mQ, float *vQ,
                         float *mw, float *vw, float *mwu, float *vwu,
@@ -244,8 +249,11 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  *              aligned: per-query thresholds, the (item tile, query) mask bitmap and the
  *              per-(split,query) candidate lists of the fixed-threshold stream (512 or
  *              1024 keys of 8 bytes each).  Contents need not be initialised or preserved.
- * Score: NORMAL e_u.e_i ; RUBI_BOTH ((e_u.e_i - c) * sig_i) * sig_u, the dot
+ * Score: NORMAL e_u.e_i ; RUBI_BOTH ((e_u.e_i - c) * sig_i) * sig_u ; RUBI,
+ * DIRECT_MINUS, DIRECT_MINUS_BOTH as listed at the MACR_SCORE_* constants (every
+ * operation rounds on its own, in the order of the reference's expression), the dot
  * product being a k-ascending fp32 fma chain (gfx950 fp32 MFMA arithmetic).
+ * sig_i is needed by every kind but NORMAL, sig_u by RUBI_BOTH and DIRECT_MINUS_BOTH.
  * d in {32,64,128,256}; 1 <= K <= MACR_MAX_TOPK.
  * Launches: a sampling pass over every 8th item tile (per-query lower bound tau of
  * the K-th best score), the listing pass over all tiles (items scoring >= tau go to

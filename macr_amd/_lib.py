@@ -11,11 +11,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MACR_HIP_LIB") or os.path.join(_HERE, "csrc", "libmacr_hip.so")
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH = 0, -1, -2, -3, -4
-LOSS_NORMALBCE, LOSS_RUBIBCEBOTH = 0, 1
+LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, LOSS_RUBIBCE = 0, 1, 2
 STEP_DEFER, STEP_PENDING = 1, 2
-SCORE_NORMAL, SCORE_RUBI_BOTH = 0, 1
+SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINUS_BOTH = 0, 1, 2, 3, 4
 MAX_TOPK = 32
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MacrError(RuntimeError):
@@ -42,7 +42,7 @@ SIGNATURES = {
     "macr_timing_end": (_i, [_i, _p, _p]),
     "macr_mf_train_workspace_bytes": (_z, [_i, _i]),
     "macr_mf_train_step": (_i, [_i] * 5 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [_p, ctypes.POINTER(Hyper), _p, _i, _p, _z, _p]),
-    "macr_mf_train_flush": (_i, [_i] * 4 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), _p, _z, _p]),
+    "macr_mf_train_flush": (_i, [_i] * 5 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), _p, _z, _p]),
     "macr_sample_triples": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _i, _p, _i, _p, _p, _p, _p]),
     "macr_spmm_plan_bytes": (_z, [_i, _p]),
     "macr_spmm_plan_build": (_i, [_i, _p, _p, _z]),

@@ -95,6 +95,23 @@ __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + ex
 __device__ __forceinline__ float dneglog_sig(float s, float eps) { return -((s * (1.0f - s)) / (s + eps)); }
 __device__ __forceinline__ float dneglog_1msig(float s, float eps) { return (s * (1.0f - s)) / ((1.0f - s) + eps); }
 
+// ---- test-time score epilogue (macr_mf/model.py:45, :141-142, :199-201) ---------------------------------
+// Every operation rounds on its own, in the order the reference's expression evaluates (the empty asm pins the
+// product in a register: hipcc would otherwise contract `v - c*s` into one fma -- __fmul_rn does not prevent that
+// here, measured as 1-ulp differences against the oracle); oracle/macr_oracle.c::orc_score_epilogue is the same sequence.
+__host__ __device__ constexpr bool score_uses_sig_i(int kind) { return kind != MACR_SCORE_NORMAL; }
+__host__ __device__ constexpr bool score_uses_sig_u(int kind) {
+    return kind == MACR_SCORE_RUBI_BOTH || kind == MACR_SCORE_DIRECT_MINUS_BOTH;
+}
+template <int KIND>
+__device__ __forceinline__ float score_epilogue(float v, float c, float sgi, float su) {
+    if (KIND == MACR_SCORE_RUBI_BOTH) { v = v - c; v = v * sgi; v = v * su; }
+    else if (KIND == MACR_SCORE_RUBI) { v = v - c; v = v * sgi; }
+    else if (KIND == MACR_SCORE_DIRECT_MINUS) { float t = c * sgi; asm volatile("" : "+v"(t)); v = v - t; }
+    else if (KIND == MACR_SCORE_DIRECT_MINUS_BOTH) { float t = c * sgi; t = t * su; asm volatile("" : "+v"(t)); v = v - t; }
+    return v;
+}
+
 // ---- (score,id) ranking keys --------------------------------------------------
 // Larger key = ranks earlier: score descending, then id ascending.  0 = empty slot.
 __device__ __forceinline__ uint32_t f32_orderable(float f) {

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
 #pragma unroll
         for (int t = 0; t < D / 2; ++t) bfrag[t] = q_ok ? urow[2 * t + h] : 0.f;
     }
-    const float su = (KIND == MACR_SCORE_RUBI_BOTH && q_ok) ? sig_u[q] : 1.0f;
+    const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
 
     // Stream order.  Item ids often correlate with popularity (ids are handed out by first appearance), and
     // a monotone score trend along the stream is the worst case of a running top-K (every item beats the
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     };
     auto load_sig = [&](int tile) -> float {
         const int it = it_lo + tile * kTileItems + tid;
-        return (KIND == MACR_SCORE_RUBI_BOTH && tid < kTileItems && it < it_hi) ? sig_i[it] : 0.f;
+        return (score_uses_sig_i(KIND) && tid < kTileItems && it < it_hi) ? sig_i[it] : 0.f;
     };
 
     const int n_units = n_tiles * NKH;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
         auto score_one = [&](int r) {                            // branch-free: interleaves with the MFMAs
             const int il = (r & 3) + 8 * (r >> 2) + 4 * h;       // item row inside the tile
             float v = acc_prev[r];
-            if (KIND == MACR_SCORE_RUBI_BOTH) { v = v - c; v = v * s_sig[sbuf * kTileItems + il]; v = v * su; }
+            if (score_uses_sig_i(KIND)) v = score_epilogue<KIND>(v, c, s_sig[sbuf * kTileItems + il], su);
             const bool live = (it0 + il < it_hi) & (((tmask >> il) & 1u) == 0u);
             v = live ? v : kNone;
             s[r] = v;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
             bfrag[2 * t4 + 1] = h ? v.w : v.z;
         }
     }
-    const float su = (KIND == MACR_SCORE_RUBI_BOTH && q_ok) ? sig_u[q] : 1.0f;
+    const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
     // listing test: score >= tau_s (NaN = never: padding users, poisoned scores)
     const float tau_s = (MODE == kModeList && q_ok) ? tau[q] : __builtin_nanf("");
     uint64_t *my_list = lists + ((size_t)split * U + (q_ok ? q : 0)) * cap;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
             const int it = min(tile * kTileItems + row, n_local - 1);
             stg[k] = ld4(items + (size_t)it * D + 4 * c4);
         }
-        if (KIND == MACR_SCORE_RUBI_BOTH) sg = sig_i[min(tile * kTileItems + (tid & (kTileItems - 1)), n_local - 1)];
+        if (score_uses_sig_i(KIND)) sg = sig_i[min(tile * kTileItems + (tid & (kTileItems - 1)), n_local - 1)];
         tm_next = (mask_bits && q_ok) ? mask_bits[(size_t)tile * U + q] : 0u;      // masked items of (tile, user)
     };
     auto store_tile = [&](int buf) {
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
                 *reinterpret_cast<float2 *>(p + NT) = make_float2(stg[k].y, stg[k].w);
             }
         }
-        if (KIND == MACR_SCORE_RUBI_BOTH) {
+        if (score_uses_sig_i(KIND)) {
             asm volatile("" : "+v"(sg));
             if (tid < kTileItems) s_sig[buf * kTileItems + tid] = sg;
         }
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 
         // epilogue: 16 scores per lane
         float sgi[16];
-        if (KIND == MACR_SCORE_RUBI_BOTH) {
+        if (score_uses_sig_i(KIND)) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4 *>(sgi + 4 * g) = *reinterpret_cast<const float4 *>(s_sig + buf * kTileItems + 8 * g + 4 * h);
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             v[r] = acc[r];
-            if (KIND == MACR_SCORE_RUBI_BOTH) { v[r] = v[r] - c; v[r] = v[r] * sgi[r]; v[r] = v[r] * su; }
+            if (score_uses_sig_i(KIND)) v[r] = score_epilogue<KIND>(v[r], c, sgi[r], su);
             if (MODE == kModeMax) cmax[r] = fmaxf(cmax[r], v[r]);
             else hit |= __ballot(v[r] >= tau_s);
         }
@@ -865,14 +865,14 @@ __global__ __launch_bounds__(256) void k_score_matrix(int U, int n_local, const 
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     if (!q_ok) return;
-    const float su = KIND == MACR_SCORE_RUBI_BOTH ? sig_u[q] : 1.f;
+    const float su = score_uses_sig_u(KIND) ? sig_u[q] : 1.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int il = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int id = it0 + il;
         if (id < n_local) {
             float v = acc[r];
-            if (KIND == MACR_SCORE_RUBI_BOTH) { v = v - c; v = v * sig_i[id]; v = v * su; }
+            if (score_uses_sig_i(KIND)) v = score_epilogue<KIND>(v, c, sig_i[id], su);
             out[(size_t)q * n_local + id] = v;
         }
     }
@@ -1186,17 +1186,23 @@ extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
     return 1;
 }
 
-#define MACR_DISPATCH_DK(d, kind, ...)                                                              \
-    switch (d) {                                                                                    \
-        case 32:  if (kind == MACR_SCORE_NORMAL) { constexpr int D = 32,  KIND = 0; __VA_ARGS__; }  \
-                  else { constexpr int D = 32,  KIND = 1; __VA_ARGS__; } break;                     \
-        case 64:  if (kind == MACR_SCORE_NORMAL) { constexpr int D = 64,  KIND = 0; __VA_ARGS__; }  \
-                  else { constexpr int D = 64,  KIND = 1; __VA_ARGS__; } break;                     \
-        case 128: if (kind == MACR_SCORE_NORMAL) { constexpr int D = 128, KIND = 0; __VA_ARGS__; }  \
-                  else { constexpr int D = 128, KIND = 1; __VA_ARGS__; } break;                     \
-        case 256: if (kind == MACR_SCORE_NORMAL) { constexpr int D = 256, KIND = 0; __VA_ARGS__; }  \
-                  else { constexpr int D = 256, KIND = 1; __VA_ARGS__; } break;                     \
+#define MACR_DISPATCH_K(Dv, kind, ...)                                                                    \
+    switch (kind) {                                                                                       \
+        case MACR_SCORE_NORMAL:            { constexpr int D = Dv, KIND = MACR_SCORE_NORMAL; __VA_ARGS__; } break;            \
+        case MACR_SCORE_RUBI_BOTH:         { constexpr int D = Dv, KIND = MACR_SCORE_RUBI_BOTH; __VA_ARGS__; } break;         \
+        case MACR_SCORE_RUBI:              { constexpr int D = Dv, KIND = MACR_SCORE_RUBI; __VA_ARGS__; } break;              \
+        case MACR_SCORE_DIRECT_MINUS:      { constexpr int D = Dv, KIND = MACR_SCORE_DIRECT_MINUS; __VA_ARGS__; } break;      \
+        case MACR_SCORE_DIRECT_MINUS_BOTH: { constexpr int D = Dv, KIND = MACR_SCORE_DIRECT_MINUS_BOTH; __VA_ARGS__; } break; \
     }
+#define MACR_DISPATCH_DK(d, kind, ...)                              \
+    switch (d) {                                                    \
+        case 32:  MACR_DISPATCH_K(32, kind, __VA_ARGS__); break;    \
+        case 64:  MACR_DISPATCH_K(64, kind, __VA_ARGS__); break;    \
+        case 128: MACR_DISPATCH_K(128, kind, __VA_ARGS__); break;   \
+        case 256: MACR_DISPATCH_K(256, kind, __VA_ARGS__); break;   \
+    }
+
+static inline bool score_kind_valid(int k) { return k >= MACR_SCORE_NORMAL && k <= MACR_SCORE_DIRECT_MINUS_BOTH; }
 
 extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const float *users_tab,
                                const int32_t *user_ids, const float *items, const float *sig_u,
@@ -1205,14 +1211,13 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
                                int32_t *out_idx, void *workspace, size_t workspace_bytes, void *stream) {
     // MACR_TOPK_FALLBACK=1 in the environment runs the fallback kernel unconditionally (tests of that path)
     static const bool force_fallback = getenv("MACR_TOPK_FALLBACK") && getenv("MACR_TOPK_FALLBACK")[0] == '1';
-    MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || score_kind == MACR_SCORE_RUBI_BOTH, MACR_E_INVALID,
-                 "score_topk: score_kind=%d", score_kind);
+    MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "score_topk: score_kind=%d", score_kind);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk: d=%d not in {32,64,128,256}", d);
     MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "score_topk: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
     MACR_REQUIRE(users_tab && items && out_val && out_idx, MACR_E_INVALID, "score_topk: null pointer");
-    MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || (sig_u && sig_i), MACR_E_INVALID,
-                 "score_topk: RUBI_BOTH needs sig_u and sig_i");
+    MACR_REQUIRE((!score_uses_sig_i(score_kind) || sig_i) && (!score_uses_sig_u(score_kind) || sig_u), MACR_E_INVALID,
+                 "score_topk: score_kind %d needs sig_i%s", score_kind, score_uses_sig_u(score_kind) ? " and sig_u" : "");
     MACR_REQUIRE((mask_ptr == nullptr) == (mask_idx == nullptr) || mask_ptr, MACR_E_INVALID, "score_topk: mask_idx without mask_ptr");
     if (n_splits <= 0) n_splits = macr_score_topk_splits(U, n_local, d);
     const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
@@ -1297,13 +1302,12 @@ extern "C" int macr_score_matrix(int score_kind, int U, int n_local, int d, cons
                                  const int32_t *user_ids, const float *items, const float *sig_u,
                                  const float *sig_i, float c, float *out_scores, void *stream) {
     hipStream_t st = as_stream(stream);
-    MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || score_kind == MACR_SCORE_RUBI_BOTH, MACR_E_INVALID,
-                 "score_matrix: score_kind=%d", score_kind);
+    MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "score_matrix: score_kind=%d", score_kind);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_matrix: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_matrix: d=%d not in {32,64,128,256}", d);
     MACR_REQUIRE(users_tab && items && out_scores, MACR_E_INVALID, "score_matrix: null pointer");
-    MACR_REQUIRE(score_kind == MACR_SCORE_NORMAL || (sig_u && sig_i), MACR_E_INVALID,
-                 "score_matrix: RUBI_BOTH needs sig_u and sig_i");
+    MACR_REQUIRE((!score_uses_sig_i(score_kind) || sig_i) && (!score_uses_sig_u(score_kind) || sig_u), MACR_E_INVALID,
+                 "score_matrix: score_kind %d needs sig_i%s", score_kind, score_uses_sig_u(score_kind) ? " and sig_u" : "");
     dim3 grid((n_local + 127) / 128, (U + 31) / 32);
     MACR_DISPATCH_DK(d, score_kind, (k_score_matrix<D, KIND><<<grid, 256, 0, st>>>(
                                         U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, out_scores)));

@@ -183,7 +183,8 @@ __device__ __forceinline__ void finalize_losses(const LossArgs &L, int lane) {
             mf = (float)(bce / Bd);
         } else {
             const float Lo = (float)(lo / (Bd * Bd)), Li = (float)(li / Bd), Lu = (float)(lu / Bd);
-            mf = Lo + L.alpha * Li + L.beta * Lu;               // macr_mf/model.py:217
+            mf = L.kind == MACR_LOSS_RUBIBCE ? Lo + L.alpha * Li            // macr_mf/model.py:178
+                                             : Lo + L.alpha * Li + L.beta * Lu;               // :217
         }
         float regularizer = (float)(0.5 * sq);                  // tf.nn.l2_loss x3  (:219)
         regularizer = regularizer / (float)L.batch_size_cfg;    // (:220)
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
     int B, int Bp, const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
     const float *__restrict__ Usrc, const float *__restrict__ Isrc,
     const float *__restrict__ w, const float *__restrict__ wu,
-    float *__restrict__ fwd, float *__restrict__ part, int reg_on_gathered, float *__restrict__ gw, PendingAdam pa) {
+    float *__restrict__ fwd, float *__restrict__ part, int reg_on_gathered, float *__restrict__ gw, PendingAdam pa,
+    int user_branch) {
     constexpr int d = 4 * LPR;
     __shared__ float red[16];
     RowGroup<LPR> g;
@@ -273,7 +275,9 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
         if (reg_on_gathered) sq = dot4(eu, eu) + dot4(ei, ei) + dot4(ej, ej);
         if (g.sub == 0) {
             const float eps = 1e-10f;
-            const float ssi = sigmoid_acc(si), ssj = sigmoid_acc(sj), ssu = sigmoid_acc(su);
+            // MACR_LOSS_RUBIBCE (model.py:158-183) is this graph without the user factor: sig(su) := 1, which also
+            // zeroes d/dsu in pair_bwd (ssu*(1-ssu) = 0 and both L_user derivatives vanish at 1); L_user is not in the loss
+            const float ssi = sigmoid_acc(si), ssj = sigmoid_acc(sj), ssu = user_branch ? sigmoid_acc(su) : 1.0f;
             fwd[0 * (size_t)Bp + t] = p;
             fwd[1 * (size_t)Bp + t] = n;
             fwd[2 * (size_t)Bp + t] = ssi * ssu;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
             fwd[5 * (size_t)Bp + t] = ssj;
             fwd[6 * (size_t)Bp + t] = ssu;
             litem = -logf(ssi + eps) + -logf((1.0f - ssj) + eps);
-            luser = -logf(ssu + eps) + -logf((1.0f - ssu) + eps);
+            luser = user_branch ? -logf(ssu + eps) + -logf((1.0f - ssu) + eps) : 0.0f;
         }
     }
     const float s0 = block_sum(sq, red);
@@ -1124,6 +1128,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
                        const PendingAdam *pa = nullptr, const AdamArgs *pending = nullptr,
                        long long n_pending_blocks = 0, const LossArgs *finalize = nullptr) {
     const int grid = ws.nblk_pair;
+    const int user_branch = kind == MACR_LOSS_RUBIBCEBOTH;
     BatchSort sort = batch_sort_args(ws, B, u, i, j);
     if (ws.staged) sort.B = 0;
     if (kind == MACR_LOSS_NORMALBCE) {
@@ -1144,11 +1149,11 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
     }
     if (pa) {
         MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, true><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                         ws.part, reg_on_gathered, ws.gw, *pa)));
+                                                                         ws.part, reg_on_gathered, ws.gw, *pa, user_branch)));
     } else {
         PendingAdam none = {};
         MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, false><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                          ws.part, reg_on_gathered, ws.gw, none)));
+                                                                          ws.part, reg_on_gathered, ws.gw, none, user_branch)));
     }
     MACR_CHECK_LAUNCH("pair_fwd", st);
     switch (ws.rows) {
@@ -1202,9 +1207,9 @@ extern "C" size_t macr_mf_train_workspace_bytes(int B, int d) {
 }
 
 namespace macr {
-// Adam segment lists of the MF model.  tables: P and Q (row-flag protocol); branch: w, w_user (partial rows of
-// pair_bwd), only for rubibceboth (model.py:74 vs :95).
-static void mf_adam_args(AdamArgs &a, long long &nb, bool tables, bool branch, int d, int n_users, int n_items,
+// Adam segment lists of the MF model.  tables: P and Q (row-flag protocol); branch vectors w, w_user (partial rows
+// of pair_bwd) as the loss kind trains them (model.py:74 / :69 / :95).
+static void mf_adam_args(AdamArgs &a, long long &nb, bool tables, int loss_kind, int d, int n_users, int n_items,
                          float *P, float *Q, float *w, float *wu, float *mP, float *vP, float *mQ, float *vQ,
                          float *mw, float *vw, float *mwu, float *vwu, float *gP, float *gQ, int32_t *tP,
                          int32_t *tQ, const macr_hyper *hp, const PairWs &ws) {
@@ -1216,10 +1221,9 @@ static void mf_adam_args(AdamArgs &a, long long &nb, bool tables, bool branch, i
         add_seg(a, P, mP, vP, gP, tP, n_users, nb);
         add_seg(a, Q, mQ, vQ, gQ, tQ, n_items, nb);
     }
-    if (branch) {
-        add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
-        add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
-    }
+    // w: both branch losses; w_user: rubibceboth only (its gradient is None elsewhere -> TF leaves it alone)
+    if (loss_kind != MACR_LOSS_NORMALBCE) add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
+    if (loss_kind == MACR_LOSS_RUBIBCEBOTH) add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
 }
 }  // namespace macr
 
@@ -1229,8 +1233,8 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
                                   float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
                                   float *adam_pow, const macr_hyper *hp, float *losses, int flags, void *workspace,
                                   size_t workspace_bytes, void *stream) {
-    MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || loss_kind == MACR_LOSS_RUBIBCEBOTH, MACR_E_INVALID,
-                 "mf_train_step: loss_kind=%d", loss_kind);
+    MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE,
+                 MACR_E_INVALID, "mf_train_step: loss_kind=%d", loss_kind);
     MACR_REQUIRE(B > 0 && n_users > 0 && n_items > 0, MACR_E_INVALID, "mf_train_step: B=%d n_users=%d n_items=%d", B,
                  n_users, n_items);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "mf_train_step: d=%d not in {32,64,128,256}", d);
@@ -1239,8 +1243,8 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
     MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || (w && wu && mw && vw && mwu && vwu), MACR_E_INVALID,
                  "mf_train_step: rubibceboth needs w, wu and their Adam slots");
     MACR_REQUIRE((flags & ~(MACR_STEP_DEFER | MACR_STEP_PENDING)) == 0, MACR_E_INVALID, "mf_train_step: flags=%d", flags);
-    MACR_REQUIRE(!flags || loss_kind == MACR_LOSS_RUBIBCEBOTH, MACR_E_INVALID,
-                 "mf_train_step: deferred mode exists for rubibceboth only (flags=%d)", flags);
+    MACR_REQUIRE(!flags || loss_kind != MACR_LOSS_NORMALBCE, MACR_E_INVALID,
+                 "mf_train_step: deferred mode exists for the (B,B) losses only (flags=%d)", flags);
     if (int e = validate_hyper(hp, "mf_train_step")) return e;
     PairWs ws = carve_pair_ws(workspace, B, d);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "mf_train_step: workspace %zu < %zu bytes",
@@ -1249,7 +1253,7 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
                  "mf_train_step: workspace must be 256-byte aligned");
     hipStream_t st = as_stream(stream);
     const float coef = hp->decay / (float)hp->batch_size_cfg;       // d reg / d row  (model.py:219-221)
-    const bool rubi = loss_kind == MACR_LOSS_RUBIBCEBOTH;
+    const bool rubi = loss_kind != MACR_LOSS_NORMALBCE;          // the (B,B) losses: rubibceboth, rubibce
     LossArgs L;
     L.part = ws.part; L.n_part = rubi ? ws.nblk_pair : ws.nblk_bwd;
     L.part2 = nullptr; L.n_part2 = 0;
@@ -1266,24 +1270,26 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
         pa.mU = mP; pa.vU = vP; pa.gU = gP; pa.mI = mQ; pa.vI = vQ; pa.gI = gQ; pa.tU = touchedP; pa.tI = touchedQ;
         pa.mw = mw; pa.vw = vw; pa.mwu = mwu; pa.vwu = vwu; pa.scal = ws.scal;
         pa.b1 = hp->beta1; pa.b2 = hp->beta2; pa.eps = hp->adam_eps;
-        mf_adam_args(a, nb, true, true, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
+        mf_adam_args(a, nb, true, loss_kind, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
                      touchedP, touchedQ, hp, ws);
     }
     if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, P, Q, w, wu, gP, gQ, touchedP, touchedQ, coef, 1,
                             adam_pow, hp, ws, st, pending ? &pa : nullptr, pending ? &a : nullptr, nb, defer ? &L : nullptr))
         return e;
     if (defer) return MACR_OK;
-    mf_adam_args(a, nb, true, rubi, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
+    mf_adam_args(a, nb, true, loss_kind, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
                  touchedP, touchedQ, hp, ws);
     k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;
 }
 
-extern "C" int macr_mf_train_flush(int B, int d, int n_users, int n_items, float *P, float *Q, float *w, float *wu,
+extern "C" int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int n_items, float *P, float *Q, float *w, float *wu,
                                    float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
                                    float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
                                    const macr_hyper *hp, void *workspace, size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE, MACR_E_INVALID,
+                 "mf_train_flush: loss_kind=%d has no deferred mode", loss_kind);
     MACR_REQUIRE(B > 0 && n_users > 0 && n_items > 0, MACR_E_INVALID, "mf_train_flush: B=%d n_users=%d n_items=%d", B,
                  n_users, n_items);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "mf_train_flush: d=%d not in {32,64,128,256}", d);
@@ -1295,7 +1301,7 @@ extern "C" int macr_mf_train_flush(int B, int d, int n_users, int n_items, float
                  workspace_bytes, ws.bytes);
     AdamArgs a;
     long long nb = 0;
-    mf_adam_args(a, nb, true, true, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
+    mf_adam_args(a, nb, true, loss_kind, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
                  touchedP, touchedQ, hp, ws);
     LossArgs L;
     L.losses = nullptr;

@@ -43,9 +43,10 @@ class Evaluator(object):
         lo, hi = sharding.item_shard_range(items_tab.shape[0], rank, ws)
         items_local = items_tab[lo:hi]
         sig_u = sig_i = None
-        if kind == ops.SCORE_RUBI_BOTH:
-            sig_i = ops.branch_sigmoid(items_local, w)              # sigmoid(e_i . w)      model.py:199
-            sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199
+        if kind != ops.SCORE_NORMAL:
+            sig_i = ops.branch_sigmoid(items_local, w)              # sigmoid(e_i . w)      model.py:141-142,:199-201
+        if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH):
+            sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199,:201
         U = self.n_queries
         if U <= self.max_queries_per_pass:
             vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, self.mask, lo)

@@ -4,15 +4,17 @@ Mirrors the part of macr_mf/model.py::BPRMF (:13-326) that the README commands
 exercise:
     --train normalbce   -> opt_bce / loss_bce / mf_loss_bce / reg_loss_bce           (:92-95, :277-287)
     --train rubibceboth -> opt_two_bce_both / loss_two_bce_both / ...                (:71-74, :185-222)
+    --train rubibce     -> opt_two_bce / loss_two_bce / ...  (item branch only)      (:67-69, :158-183)
     --test  normal      -> batch_ratings                                             (:45)
-    --test  rubi        -> rubi_ratings_both + update_c                              (:199, :313)
+    --test  rubi        -> rubi_ratings_both (rubibceboth) | rubi_ratings (other losses) + update_c   (:199, :141, :313)
+    direct_minus_ratings(_both) (:142, :201) are served too (test(model_type="direct_minus_c"))
 The reference builds a TF1 graph and the CLI talks to it through
 `sess.run(fetches, feed_dict)`; here the same attribute names are plain fetch
 handles and `Session.run` dispatches them to the C-ABI kernels, so a caller
 written against the reference keeps working.  The fast path (`train_step`,
 `Evaluator`) avoids the per-step host synchronisation `sess.run` implies.
 
-Everything else in model.py (bpr / rubi / rubibce / userc losses, BIASMF,
+Everything else in model.py (bpr / rubi / userc losses, BIASMF,
 IPS_BPRMF, CausalE) is out of scope and raises NotImplementedError.
 """
 import math
@@ -44,7 +46,8 @@ def xavier_uniform(shape, generator, device):
 
 
 class BPRMF(object):
-    _TRAIN = {"normalbce": ("bce", ops.LOSS_NORMALBCE), "rubibceboth": ("two_bce_both", ops.LOSS_RUBIBCEBOTH)}
+    _TRAIN = {"normalbce": ("bce", ops.LOSS_NORMALBCE), "rubibceboth": ("two_bce_both", ops.LOSS_RUBIBCEBOTH),
+              "rubibce": ("two_bce", ops.LOSS_RUBIBCE)}
 
     def __init__(self, args, data_config, device=None, seed=12345, weights=None):
         self.n_users = data_config['n_users']
@@ -86,9 +89,12 @@ class BPRMF(object):
         # inference handles
         self.batch_ratings = Fetch("batch_ratings", "ratings", ops.SCORE_NORMAL)
         self.rubi_ratings_both = Fetch("rubi_ratings_both", "ratings", ops.SCORE_RUBI_BOTH)
-        for name in ("opt", "opt_two", "opt_two_bce", "opt2", "opt2_bce", "opt3", "opt3_bce", "opt_userc_bce",
+        self.rubi_ratings = Fetch("rubi_ratings", "ratings", ops.SCORE_RUBI)                               # :141
+        self.direct_minus_ratings = Fetch("direct_minus_ratings", "ratings", ops.SCORE_DIRECT_MINUS)      # :142
+        self.direct_minus_ratings_both = Fetch("direct_minus_ratings_both", "ratings", ops.SCORE_DIRECT_MINUS_BOTH)   # :201
+        for name in ("opt", "opt_two", "opt2", "opt2_bce", "opt3", "opt3_bce", "opt_userc_bce",
                      "user_const_ratings", "item_const_ratings", "user_rand_ratings", "item_rand_ratings",
-                     "rubi_ratings", "direct_minus_ratings", "rubi_ratings_userc", "rubi_ratings_both_poptest"):
+                     "rubi_ratings_userc", "rubi_ratings_both_poptest"):
             setattr(self, name, Fetch(name, "unsupported"))
         self._statistics_params()
 
@@ -122,7 +128,7 @@ class BPRMF(object):
     # ------------------------------------------------------------------ fast path
     def kind_of(self, train):
         if train not in self._TRAIN:
-            raise NotImplementedError("--train %s is not on the MI355X hot path (normalbce | rubibceboth)" % train)
+            raise NotImplementedError("--train %s is not on the MI355X hot path (normalbce | rubibce | rubibceboth)" % train)
         return self._TRAIN[train][1]
 
     def to_device_batch(self, users, pos_items, neg_items):
@@ -163,8 +169,9 @@ class BPRMF(object):
         self.sync()
         uid = torch.as_tensor(list(user_batch), dtype=torch.int32, device=self.device)
         sig_u = sig_i = None
-        if kind == ops.SCORE_RUBI_BOTH:
+        if kind != ops.SCORE_NORMAL:
             sig_i = ops.branch_sigmoid(self.item_embedding, self.w)
+        if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH):
             sig_u = ops.branch_sigmoid(self.user_embedding, self.w_user, uid)
         return ops.score_matrix(kind, self.user_embedding, uid, self.item_embedding, sig_u, sig_i, self.rubi_c)
 

@@ -9,7 +9,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, SCORE_NORMAL, SCORE_RUBI_BOTH, MAX_TOPK,  # noqa: F401
+from ._lib import (LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, LOSS_RUBIBCE, SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI,  # noqa: F401
+                   SCORE_DIRECT_MINUS, SCORE_DIRECT_MINUS_BOTH, MAX_TOPK,
                    Hyper, MacrError, check)
 
 
@@ -285,6 +286,7 @@ class MFState(object):
         self.batch_cap = 0
         self.ws = None
         self.pending_B = 0
+        self.pending_kind = LOSS_RUBIBCEBOTH
         self.reserve(batch_cap)
 
     def reserve(self, B):
@@ -303,15 +305,15 @@ class MFState(object):
 
     def step(self, kind, u, i, j, losses=None, defer=False):
         """One training step; u,i,j int32 device tensors.  Returns the (3,) device loss tensor.
-        defer=True (rubibceboth): leave the dense Adam pass pending so that the next step runs it under its
+        defer=True (rubibceboth, rubibce): leave the dense Adam pass pending so that the next step runs it under its
         (B,B) kernel (include/macr_hip.h, MACR_STEP_DEFER); call flush() before reading the parameters."""
         B = u.numel()
         if self.pending_B and self.pending_B != B:
             self.flush()
         self.reserve(B)
         out = self.losses if losses is None else losses
-        defer = bool(defer) and kind == LOSS_RUBIBCEBOTH
-        if self.pending_B and kind != LOSS_RUBIBCEBOTH:
+        defer = bool(defer) and kind != LOSS_NORMALBCE          # the (B,B) losses hide the Adam pass under their (B,B) kernel
+        if self.pending_B and kind != self.pending_kind:
             self.flush()
         flags = (_lib.STEP_DEFER if defer else 0) | (_lib.STEP_PENDING if self.pending_B else 0)
         check(_lib.lib().macr_mf_train_step(
@@ -319,13 +321,14 @@ class MFState(object):
             *self._tables(), _ptr(self.adam_pow), ctypes.byref(self.hyper),
             _ptr(out, _f32), flags, _ptr(self.ws), self.ws.numel(), _stream()))
         self.pending_B = B if defer else 0
+        self.pending_kind = kind
         return out
 
     def flush(self):
         """Complete a pending dense Adam pass (no-op when nothing is pending)."""
         if self.pending_B:
             check(_lib.lib().macr_mf_train_flush(
-                self.pending_B, self.d, self.P.shape[0], self.Q.shape[0], *self._tables(),
+                self.pending_kind, self.pending_B, self.d, self.P.shape[0], self.Q.shape[0], *self._tables(),
                 ctypes.byref(self.hyper), _ptr(self.ws), self.ws.numel(), _stream()))
             self.pending_B = 0
 

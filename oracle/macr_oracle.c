@@ -32,9 +32,13 @@
 
 #define ORC_LOSS_NORMALBCE   0   /* macr_mf/model.py:277-287, LightGCN.py:415-429 */
 #define ORC_LOSS_RUBIBCEBOTH 1   /* macr_mf/model.py:185-222, LightGCN.py:495-532 */
+#define ORC_LOSS_RUBIBCE     2    /* --train rubibce  macr_mf/model.py:158-183: item branch only */
 
 #define ORC_SCORE_NORMAL    0    /* batch_ratings      model.py:45,  LightGCN.py:166 */
 #define ORC_SCORE_RUBI_BOTH 1    /* rubi_ratings_both  model.py:199, LightGCN.py:509 */
+#define ORC_SCORE_RUBI      2    /* rubi_ratings       model.py:141  (batch_ratings - c) * sig_i                  */
+#define ORC_SCORE_DIRECT_MINUS 3 /* direct_minus_ratings       model.py:142  batch_ratings - c * sig_i            */
+#define ORC_SCORE_DIRECT_MINUS_BOTH 4 /* direct_minus_ratings_both :201  batch_ratings - c * sig_i * sig_u        */
 
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -75,6 +79,9 @@ void orc_scatter_add_rows(float *dense, const int32_t *idx, int B, int d, const 
  *   L_item = mean(-log(sig(si)+1e-10) - log(1-sig(sj)+1e-10))            :213
  *   L_user = mean(-log(sig(su)+1e-10) - log(1-sig(su)+1e-10))            :215
  *   mf = L_ori + alpha*L_item + beta*L_user                              :217
+ * kind = ORC_LOSS_RUBIBCE        macr_mf/model.py:158-183 -- the same graph without the user branch:
+ *   pos = p(B,) * sig(si)(B,1), neg = n(B,) * sig(sj)(B,1) (again (B,B), :172-173), L_ori :174, L_item :176,
+ *   mf = L_ori + alpha*L_item :178; w_user receives no gradient.  Restated as RUBIBCEBOTH with sig(su) := 1.
  * The l2 regulariser (:219-221) is handled by orc_l2_reg because LightGCN
  * regularises the *ego* rows, not the propagated ones (LightGCN.py:525-527).
  *
@@ -94,10 +101,10 @@ void orc_pair_loss_grad(int kind, int B, int d,
         for (int k = 0; k < d; ++k) {
             ap += (double)(u[k] * a[k]);
             an += (double)(u[k] * b[k]);
-            if (kind == ORC_LOSS_RUBIBCEBOTH) {
+            if (kind != ORC_LOSS_NORMALBCE) {
                 asi += (double)(a[k] * w[k]);
                 asj += (double)(b[k] * w[k]);
-                asu += (double)(u[k] * wu[k]);
+                if (kind == ORC_LOSS_RUBIBCEBOTH) asu += (double)(u[k] * wu[k]);
             }
         }
         p[r] = (float)ap; n[r] = (float)an;
@@ -123,7 +130,8 @@ void orc_pair_loss_grad(int kind, int B, int d,
         float *ssi = (float *)malloc(sizeof(float) * B), *ssj = (float *)malloc(sizeof(float) * B);
         float *ssu = (float *)malloc(sizeof(float) * B);
         for (int r = 0; r < B; ++r) {
-            ssi[r] = sigmoidf_(si[r]); ssj[r] = sigmoidf_(sj[r]); ssu[r] = sigmoidf_(su[r]);
+            ssi[r] = sigmoidf_(si[r]); ssj[r] = sigmoidf_(sj[r]);
+            ssu[r] = kind == ORC_LOSS_RUBIBCEBOTH ? sigmoidf_(su[r]) : 1.0f;     /* RUBIBCE: no user factor */
             a[r] = ssi[r] * ssu[r];            /* row factor of `pos` (model.py:204) */
             b[r] = ssj[r] * ssu[r];            /* row factor of `neg` (model.py:205) */
         }
@@ -162,7 +170,7 @@ void orc_pair_loss_grad(int kind, int B, int d,
         double l_item = 0, l_user = 0;
         for (int r = 0; r < B; ++r) {
             l_item += (double)(-logf(ssi[r] + eps) + -logf((1.0f - ssj[r]) + eps));
-            l_user += (double)(-logf(ssu[r] + eps) + -logf((1.0f - ssu[r]) + eps));
+            if (kind == ORC_LOSS_RUBIBCEBOTH) l_user += (double)(-logf(ssu[r] + eps) + -logf((1.0f - ssu[r]) + eps));
             float da_f = (float)(da[r] * inv_b2), db_f = (float)(db[r] * inv_b2);
             dp[r] = (float)(dpd[r] * inv_b2);
             dn[r] = (float)(dnd[r] * inv_b2);
@@ -170,12 +178,12 @@ void orc_pair_loss_grad(int kind, int B, int d,
             float dsig_u = ssu[r] * (1.0f - ssu[r]);
             dsi[r] = da_f * dsig_i * ssu[r] + (alpha / (float)B) * dneglog_sig(ssi[r], eps);
             dsj[r] = db_f * dsig_j * ssu[r] + (alpha / (float)B) * dneglog_1msig(ssj[r], eps);
-            dsu[r] = (da_f * ssi[r] + db_f * ssj[r]) * dsig_u +
+            dsu[r] = kind != ORC_LOSS_RUBIBCEBOTH ? 0.0f : (da_f * ssi[r] + db_f * ssj[r]) * dsig_u +
                      (beta / (float)B) * (dneglog_sig(ssu[r], eps) + dneglog_1msig(ssu[r], eps));
         }
         float Lo = (float)(l_ori * inv_b2), Li = (float)(l_item / B), Lu = (float)(l_user / B);
         mf_parts[1] = Lo; mf_parts[2] = Li; mf_parts[3] = Lu;
-        mf_parts[0] = Lo + alpha * Li + beta * Lu;
+        mf_parts[0] = kind == ORC_LOSS_RUBIBCEBOTH ? Lo + alpha * Li + beta * Lu : Lo + alpha * Li;
         free(a); free(b); free(ssi); free(ssj); free(ssu);
         free(da); free(db); free(dpd); free(dnd);
     }
@@ -188,8 +196,8 @@ void orc_pair_loss_grad(int kind, int B, int d,
             float gu_k = dp[r] * a[k] + dn[r] * b[k];
             float ga_k = dp[r] * u[k];
             float gb_k = dn[r] * u[k];
-            if (kind == ORC_LOSS_RUBIBCEBOTH) {
-                gu_k += dsu[r] * wu[k];
+            if (kind != ORC_LOSS_NORMALBCE) {
+                if (kind == ORC_LOSS_RUBIBCEBOTH) gu_k += dsu[r] * wu[k];
                 ga_k += dsi[r] * w[k];
                 gb_k += dsj[r] * w[k];
                 dwd[k] += (double)(a[k] * dsi[r]) + (double)(b[k] * dsj[r]);
@@ -198,7 +206,7 @@ void orc_pair_loss_grad(int kind, int B, int d,
             gu[k] = gu_k; ga[k] = ga_k; gb[k] = gb_k;
         }
     }
-    if (kind == ORC_LOSS_RUBIBCEBOTH)
+    if (kind != ORC_LOSS_NORMALBCE)
         for (int k = 0; k < d; ++k) { dw[k] += (float)dwd[k]; dwu[k] += (float)dwud[k]; }
     free(dwd); free(dwud);
     free(dp); free(dn); free(dsi); free(dsj); free(dsu);
@@ -277,10 +285,10 @@ void orc_mf_train_step(int kind, int B, int d, int n_users, int n_items,
     float lr_t = orc_adam_lr_t(lr, power);
     orc_adam_dense(P, mP, vP, gP, (size_t)n_users * d, lr_t, b1, b2, eps);
     orc_adam_dense(Q, mQ, vQ, gQ, (size_t)n_items * d, lr_t, b1, b2, eps);
-    if (kind == ORC_LOSS_RUBIBCEBOTH) {           /* w, w_user only get gradients here */
+    if (kind != ORC_LOSS_NORMALBCE)               /* w only gets a gradient in the branch losses */
         orc_adam_dense(w, mw, vw, gw, d, lr_t, b1, b2, eps);
+    if (kind == ORC_LOSS_RUBIBCEBOTH)             /* w_user: gradient None outside rubibceboth -> untouched */
         orc_adam_dense(wu, mwu, vwu, gwu, d, lr_t, b1, b2, eps);
-    }
     power[0] *= b1; power[1] *= b2;
     losses[1] = parts[0]; losses[2] = reg; losses[0] = parts[0] + reg;   /* model.py:73,:94 */
     free(eu); free(ei); free(ej); free(deu); free(dei); free(dej); free(fwd);
@@ -389,6 +397,37 @@ void orc_branch_sigmoid(const float *rows, int n, int d, const float *w, float *
     }
 }
 
+/* Test-time score of one (user, item) from its dot product `acc`; each operation rounds on its own (no fused
+ * multiply-add), in the order the reference's expression evaluates:
+ *   NORMAL             acc                                                    model.py:45
+ *   RUBI_BOTH          ((acc - c) * sig_i) * sig_u                            model.py:199
+ *   RUBI               (acc - c) * sig_i                                      model.py:141
+ *   DIRECT_MINUS       acc - (c * sig_i)                                      model.py:142
+ *   DIRECT_MINUS_BOTH  acc - ((c * sig_i) * sig_u)                            model.py:201 */
+static inline float orc_score_epilogue(int kind, float acc, float c, float sgi, float su) {
+    volatile float t;
+    switch (kind) {
+        case ORC_SCORE_RUBI_BOTH: t = acc - c; t = t * sgi; t = t * su; return t;
+        case ORC_SCORE_RUBI: t = acc - c; t = t * sgi; return t;
+        case ORC_SCORE_DIRECT_MINUS: t = c * sgi; t = acc - t; return t;
+        case ORC_SCORE_DIRECT_MINUS_BOTH: t = c * sgi; t = t * su; t = acc - t; return t;
+        default: return acc;
+    }
+}
+
+/* Dense (U,N) scores: the literal sess.run(model.<ratings>, {users, pos_items: all items}) (macr_mf/train.py:224-251). */
+void orc_score_matrix(int kind, int U, int N, int d, const float *Urows, const float *Irows,
+                      const float *sig_u, const float *sig_i, float c, float *out) {
+#pragma omp parallel for schedule(static)
+    for (int u = 0; u < U; ++u)
+        for (int it = 0; it < N; ++it) {
+            const float *ur = Urows + (size_t)u * d, *ir = Irows + (size_t)it * d;
+            float acc = 0.0f;
+            for (int k = 0; k < d; ++k) acc = fmaf(ur[k], ir[k], acc);
+            out[(size_t)u * N + it] = orc_score_epilogue(kind, acc, c, sig_i ? sig_i[it] : 1.0f, sig_u ? sig_u[u] : 1.0f);
+        }
+}
+
 /* ---------------------------------------------------------------------------
  * Full-catalogue scoring + train-item masking + top-K.
  *   NORMAL    : S[u,i] = U[u].I[i]                              model.py:45
@@ -425,7 +464,7 @@ void orc_score_topk(int kind, int U, int N, int d, const float *Urows, const flo
             float acc = 0.0f;
             for (int k = 0; k < d; ++k) acc = fmaf(ur[k], ir[k], acc);
             float s = acc;
-            if (kind == ORC_SCORE_RUBI_BOTH) { s = acc - c; s = s * sig_i[it]; s = s * sig_u[u]; }
+            s = orc_score_epilogue(kind, acc, c, sig_i ? sig_i[it] : 1.0f, sig_u ? sig_u[u] : 1.0f);
             /* insert: strictly greater moves ahead of equal (earlier id stays first) */
             if (cnt < K || s > bv[cnt - 1]) {
                 int pos = cnt < K ? cnt : K - 1;

@@ -14,8 +14,8 @@ _SRC = os.path.join(_HERE, "macr_oracle.c")
 _LIB = os.path.join(_HERE, "_build", "libmacr_oracle.so")
 _REF_LIB = os.path.join(_HERE, "_ref", "libref_eval.so")
 
-LOSS_NORMALBCE, LOSS_RUBIBCEBOTH = 0, 1
-SCORE_NORMAL, SCORE_RUBI_BOTH = 0, 1
+LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, LOSS_RUBIBCE = 0, 1, 2
+SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINUS_BOTH = 0, 1, 2, 3, 4
 
 _f = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _d = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -59,6 +59,8 @@ def lib():
         L.orc_branch_sigmoid.argtypes = [_f, _ci, _ci, _f, _f]
         L.orc_score_topk.argtypes = [_ci, _ci, _ci, _ci, _f, _f, _vp, _vp, _cf, _vp, _vp, _ci,
                                      _ci, _ci, _f, _i, _i]
+        L.orc_score_matrix.argtypes = [_ci, _ci, _ci, _ci, _f, _f, _vp, _vp, _cf, _f]
+        L.orc_score_matrix.restype = None
         L.orc_topk_scores.argtypes = [_ci, _ci, _f, _vp, _vp, _ci, _f, _i, _i]
         L.orc_topk_merge.argtypes = [_ci, _ci, _ci, _f, _i, _f, _i, _i]
         L.orc_metrics_foldout.argtypes = [_ci, _ci, _i, _i, _i, _f]
@@ -184,6 +186,18 @@ def score_topk(kind, Urows, Irows, K, sig_u=None, sig_i=None, c=0.0, mask=None, 
     lib().orc_score_topk(kind, U, N, d, Urows, Irows, _ptr(su), _ptr(si), c, _ptr(mp), _ptr(mi),
                          item_offset, K, int(fill_masked), val, idx, cnt)
     return val, idx, cnt
+
+
+def score_matrix(kind, Urows, Irows, sig_u=None, sig_i=None, c=0.0):
+    """Dense (U,N) test-time scores of the given kind (model.py:45, :141-142, :199-201)."""
+    Urows, Irows = _f32(Urows), _f32(Irows)
+    U, d = Urows.shape
+    N = Irows.shape[0]
+    su = _f32(sig_u) if sig_u is not None else None
+    si = _f32(sig_i) if sig_i is not None else None
+    out = np.empty((U, N), np.float32)
+    lib().orc_score_matrix(kind, U, N, d, Urows, Irows, _ptr(su), _ptr(si), c, out)
+    return out
 
 
 def topk_scores(scores, K, mask=None):

@@ -12,7 +12,7 @@ import oracle
 
 G10 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G10_model_steps.npz"))
 ALPHA, BETA, DECAY, BS = (float(G10["hyper"][0]), float(G10["hyper"][1]), float(G10["hyper"][2]), int(G10["hyper"][3]))
-KINDS = {"normalbce": oracle.LOSS_NORMALBCE, "rubibceboth": oracle.LOSS_RUBIBCEBOTH}
+KINDS = {"normalbce": oracle.LOSS_NORMALBCE, "rubibceboth": oracle.LOSS_RUBIBCEBOTH, "rubibce": oracle.LOSS_RUBIBCE}
 
 
 def g(key):
@@ -42,12 +42,14 @@ def test_oracle_mf_step_matches_reference_graph(tag, loss):
         pre = "mf_%s/%s/%s/" % (tag, loss, dt)
         close_grad(st.m[0] / 0.1, g(pre + "dP"), "dP " + dt, rtol)
         close_grad(st.m[1] / 0.1, g(pre + "dQ"), "dQ " + dt, rtol)
-        if loss == "rubibceboth":
+        if loss != "normalbce":
             close_grad(st.m[2] / 0.1, g(pre + "dw").reshape(-1), "dw " + dt, rtol)
+        else:                                                  # normalbce: w receives no gradient (model.py:95)
+            assert not g(pre + "dw").any() and not st.m[2].any()
+        if loss == "rubibceboth":
             close_grad(st.m[3] / 0.1, g(pre + "dwu").reshape(-1), "dwu " + dt, rtol)
-        else:                                                  # normalbce: w, w_user receive no gradient (model.py:95)
-            assert not g(pre + "dw").any() and not g(pre + "dwu").any()
-            assert not st.m[2].any() and not st.m[3].any()
+        else:                                                  # w_user: only rubibceboth's graph reaches it
+            assert not g(pre + "dwu").any() and not st.m[3].any()
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -77,3 +79,18 @@ def test_oracle_lightgcn_step_matches_reference_graph(tag, loss, kind):
     if kind == oracle.LOSS_RUBIBCEBOTH:
         close_grad(st.m[1] / 0.1, g(pre + "dw").reshape(-1), "dw", rtol=3e-4)
         close_grad(st.m[2] / 0.1, g(pre + "dwu").reshape(-1), "dwu", rtol=3e-4)
+
+
+@pytest.mark.parametrize("c", [0.0, 40.0])
+def test_oracle_score_kinds_match_reference_graph(c):
+    """Test-time score tensors of model.py:45, :141-142, :199-201 for all users x all items (64 x 64, d = 32)."""
+    P, Q, w, wu = (g("mf_scores/%s" % k) for k in ("P", "Q", "w", "wu"))
+    sig_i = oracle.branch_sigmoid(Q, w.reshape(-1))
+    sig_u = oracle.branch_sigmoid(P, wu.reshape(-1))
+    for name, kind in (("batch_ratings", oracle.SCORE_NORMAL), ("rubi_ratings_both", oracle.SCORE_RUBI_BOTH),
+                       ("rubi_ratings", oracle.SCORE_RUBI), ("direct_minus_ratings", oracle.SCORE_DIRECT_MINUS),
+                       ("direct_minus_ratings_both", oracle.SCORE_DIRECT_MINUS_BOTH)):
+        got = oracle.score_matrix(kind, P, Q, sig_u, sig_i, c)
+        for dt, rtol in (("f32", 2e-6), ("f64", 2e-6)):
+            want = g("mf_scores/c%g/%s/%s" % (c, dt, name))
+            np.testing.assert_allclose(got, want, rtol=rtol, atol=2e-6 * np.abs(want).max(), err_msg="%s %s" % (name, dt))
