@@ -125,6 +125,7 @@ typedef struct macr_hyper {
  * -------------------------------------------------------------------------*/
 #define MACR_STEP_DEFER   1
 #define MACR_STEP_PENDING 2
+#define MACR_STEP_LOSS_ONLY 4    /* macr_lgcn_train_step only: compute the losses, update nothing (see there) */
 
 size_t macr_mf_train_workspace_bytes(int B, int d);
 
@@ -199,6 +200,9 @@ int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *rowptr, const
  *   T (dev) fp32[N*d] = [user_embedding ; item_embedding], updated in place
  *   mT,vT Adam slots;  workspace (dev) >= macr_lgcn_train_workspace_bytes(B,N,d,plan_host) bytes
  *   losses (dev) fp32[3] = {loss, mf_loss, emb_loss}
+ *   flags  0, or MACR_STEP_LOSS_ONLY: sess.run([loss_X, mf_loss_X, emb_loss_X]) without opt_X -- the
+ *          reference's per-log-interval "test loss" pass (LightGCN.py:799-819, train_thread_test :620-647):
+ *          propagation + forward of the loss; T, w, wu, the slots and adam_pow are left untouched.
  * -------------------------------------------------------------------------*/
 size_t macr_lgcn_train_workspace_bytes(int B, int N, int d, const void *plan_host);
 
@@ -209,7 +213,7 @@ int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, 
                          float *T, float *w, float *wu, float *mT, float *vT,
                          float *mw, float *vw, float *mwu, float *vwu,
                          float *adam_pow, const macr_hyper *hp,
-                         float *losses, void *workspace, size_t workspace_bytes, void *stream);
+                         float *losses, int flags, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * out[r] = sigmoid(rows[r] . w)   -- the test-time branch factors
@@ -234,6 +238,9 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  *   sig_u     (dev) fp32[U]  sigmoid(e_u . w_user)  per query  (RUBI_BOTH only)
  *   sig_i     (dev) fp32[n_local] sigmoid(e_i . w)  per local item (RUBI_BOTH)
  *   c         the constant `rubi_c` set by update_c (model.py:313)
+ *   c_dev     (dev, may be NULL) fp32[1]: if given, the kernels read c from it at RUN time and ignore `c`: a
+ *              call sequence captured into a hipGraph then serves every c of a sweep (macr_mf/tune.py:545-578,
+ *              LightGCN_tune.py:852-870) -- the caller rewrites the scalar between replays
  *   mask_ptr  (dev) int32[U+1], mask_idx (dev) int32[*]: per query, ascending
  *              GLOBAL item ids to exclude (the user's train items); may be NULL
  *   n_splits  >= 1: number of (U,K) result lists in out_val/out_idx; 0 = let the
@@ -266,7 +273,7 @@ size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
 
 int macr_score_topk(int score_kind, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
-                    const float *sig_u, const float *sig_i, float c,
+                    const float *sig_u, const float *sig_i, float c, const float *c_dev,
                     const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
                     int item_offset, int K, int n_splits, float *out_val, int32_t *out_idx,
                     void *workspace, size_t workspace_bytes, void *stream);
@@ -285,7 +292,7 @@ int    macr_mask_bits_build(int U, int n_local, const int32_t *mask_ptr, const i
  * sess.run(model.rubi_ratings_both, ...) -> (U,N) fp32 contract). */
 int macr_score_matrix(int score_kind, int U, int n_local, int d,
                       const float *users_tab, const int32_t *user_ids, const float *items,
-                      const float *sig_u, const float *sig_i, float c,
+                      const float *sig_u, const float *sig_i, float c, const float *c_dev,
                       float *out_scores, void *stream);
 
 /* ---------------------------------------------------------------------------

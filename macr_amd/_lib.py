@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MACR_HIP_LIB") or os.path.join(_HERE, "csrc", "libmac
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH = 0, -1, -2, -3, -4
 LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, LOSS_RUBIBCE = 0, 1, 2
-STEP_DEFER, STEP_PENDING = 1, 2
+STEP_DEFER, STEP_PENDING, STEP_LOSS_ONLY = 1, 2, 4
 SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINUS_BOTH = 0, 1, 2, 3, 4
 MAX_TOPK = 32
 ABI_VERSION = 6
@@ -49,14 +49,14 @@ SIGNATURES = {
     "macr_lgcn_work_floats": (_z, [_i, _i, _p]),
     "macr_lgcn_propagate": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "macr_lgcn_train_workspace_bytes": (_z, [_i, _i, _i, _p]),
-    "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 2 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _p, _z, _p]),
+    "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 2 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _i, _p, _z, _p]),
     "macr_branch_sigmoid": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "macr_score_topk_splits": (_i, [_i, _i, _i]),
     "macr_score_topk_workspace_bytes": (_z, [_i, _i, _i]),
-    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _z, _p]),
     "macr_mask_bits_bytes": (_z, [_i, _i]),
     "macr_mask_bits_build": (_i, [_i, _i, _p, _p, _i, _p, _p]),
-    "macr_score_matrix": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
+    "macr_score_matrix": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),
     "macr_topk_scores": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "macr_topk_merge": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "macr_metrics_foldout": (_i, [_i, _i, _p, _p, _p, _p, _i, _p]),

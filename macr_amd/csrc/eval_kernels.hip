@@ -111,11 +111,13 @@ __device__ __forceinline__ void compact_buffer(uint64_t *keys, uint32_t *cnt, fl
 template <int D, int KIND>
 __global__ __launch_bounds__(512, 2) void k_score_topk(
     int U, int n_local, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
-    const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
+    const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val,
+    const float *__restrict__ c_dev,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_idx, int item_offset, int K,
     int n_splits, float *__restrict__ out_val, int32_t *__restrict__ out_idx, uint32_t *shared_thr,
     const int32_t *run_flag) {
     if (run_flag && *run_flag == 0) return;             // fallback launch: only when a candidate list overflowed
+    const float c = c_dev ? *c_dev : c_val;             // device-resident c: one captured graph serves a whole c sweep
     constexpr int NKH = D / kUnitK > 0 ? D / kUnitK : 1;     // k-halves per tile (D=32 -> 1 short unit)
     constexpr int UK = D < kUnitK ? D : kUnitK;              // k extent of one unit
     constexpr int NT = UK / 2;                               // MFMA steps per unit
@@ -465,11 +467,13 @@ __global__ __launch_bounds__(256) void k_mask_bits(int U, int n_local, const int
 template <int D, int KIND, int MODE>
 __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     int U, int n_local, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
-    const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
+    const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val,
+    const float *__restrict__ c_dev,
     const uint32_t *__restrict__ mask_bits, int item_offset,
     int ublocks, const float *__restrict__ tau, float *__restrict__ maxima, uint64_t *__restrict__ lists,
     int32_t *__restrict__ counts, int cap, int32_t *overflow) {
     using C = StreamCfg<D>;
+    const float c = c_dev ? *c_dev : c_val;
     constexpr int RS = C::RS, NT = C::NT;
     constexpr int kStep = MODE == kModeMax ? (1 << kSampleLog2) : 1;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -844,8 +848,9 @@ __global__ __launch_bounds__(256) void k_score_matrix(int U, int n_local, const 
                                                       const int32_t *__restrict__ user_ids,
                                                       const float *__restrict__ items,
                                                       const float *__restrict__ sig_u,
-                                                      const float *__restrict__ sig_i, float c,
-                                                      float *__restrict__ out) {
+                                                      const float *__restrict__ sig_i, float c_val,
+                                                      const float *__restrict__ c_dev, float *__restrict__ out) {
+    const float c = c_dev ? *c_dev : c_val;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = lane & 31, h = lane >> 5;
     const int q = blockIdx.y * 32 + col;
@@ -1206,7 +1211,7 @@ static inline bool score_kind_valid(int k) { return k >= MACR_SCORE_NORMAL && k 
 
 extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const float *users_tab,
                                const int32_t *user_ids, const float *items, const float *sig_u,
-                               const float *sig_i, float c, const int32_t *mask_ptr, const int32_t *mask_idx,
+                               const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
                                const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, float *out_val,
                                int32_t *out_idx, void *workspace, size_t workspace_bytes, void *stream) {
     // MACR_TOPK_FALLBACK=1 in the environment runs the fallback kernel unconditionally (tests of that path)
@@ -1263,7 +1268,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         // A catalogue (shard) whose every tile range fits a candidate list needs no threshold: tau = -inf lists every unmasked item
         // and the selection kernel ranks them -- no sampling pass, no k_tau.
         if (!list_all) {
-        pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits, item_offset,
+        pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
                                             geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow);
         MACR_CHECK_LAUNCH("score_sample", st);
         const int tau_regs = (geo.slots0 * 32 + 63) / 64;
@@ -1275,7 +1280,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         else k_tau<32><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
         MACR_CHECK_LAUNCH("tau", st);
         }
-        pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, mask_bits, item_offset,
+        pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
                                             geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow);
         MACR_CHECK_LAUNCH("score_stream", st);
         k_select<<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow,
@@ -1290,7 +1295,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_old);
         MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem_old, hipGetErrorString(e));
-        kern<<<ublocks * n_splits, 512, smem_old, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c,
+        kern<<<ublocks * n_splits, 512, smem_old, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
                                                         mask_ptr, mask_idx, item_offset, K, n_splits, out_val, out_idx,
                                                         n_splits > 1 ? ws.shared_thr : nullptr, force_fallback ? nullptr : ws.overflow);
     });
@@ -1300,7 +1305,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
 
 extern "C" int macr_score_matrix(int score_kind, int U, int n_local, int d, const float *users_tab,
                                  const int32_t *user_ids, const float *items, const float *sig_u,
-                                 const float *sig_i, float c, float *out_scores, void *stream) {
+                                 const float *sig_i, float c, const float *c_dev, float *out_scores, void *stream) {
     hipStream_t st = as_stream(stream);
     MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "score_matrix: score_kind=%d", score_kind);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_matrix: U=%d n_local=%d", U, n_local);
@@ -1310,7 +1315,7 @@ extern "C" int macr_score_matrix(int score_kind, int U, int n_local, int d, cons
                  "score_matrix: score_kind %d needs sig_i%s", score_kind, score_uses_sig_u(score_kind) ? " and sig_u" : "");
     dim3 grid((n_local + 127) / 128, (U + 31) / 32);
     MACR_DISPATCH_DK(d, score_kind, (k_score_matrix<D, KIND><<<grid, 256, 0, st>>>(
-                                        U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, out_scores)));
+                                        U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, out_scores)));
     MACR_CHECK_LAUNCH("score_matrix", st);
     return MACR_OK;
 }

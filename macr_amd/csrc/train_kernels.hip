@@ -193,6 +193,8 @@ __device__ __forceinline__ void finalize_losses(const LossArgs &L, int lane) {
     }
 }
 
+__global__ __launch_bounds__(64) void k_finalize_losses(LossArgs L) { finalize_losses(L, threadIdx.x); }
+
 // Block 0 also reduces the loss partials of the step into losses[3] (when L.losses is set).
 __global__ __launch_bounds__(256) void k_adam_dense(AdamArgs a, const StepScalars *scal, LossArgs L) {
     __shared__ float4 s_red[256];
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(256) void k_pair_normal(
     __shared__ int s_pos[kChunkT];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bool act = lane < WaveRow<D>::kActive;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && adam_pow_out) {      // (NULL: loss-only pass, no step is taken)
         const float p1 = adam_pow_in[0], p2 = adam_pow_in[1];
         scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
         adam_pow_out[0] = p1 * b1;
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(256) void k_pair_normal(
             const float sp = sigmoid_acc(p), sn = sigmoid_acc(n);
             if (lane == 0) bce += -logf(sp + eps) + -logf((1.0f - sn) + eps);
             const float dp = dneglog_sig(sp, eps) * invB, dn = dneglog_1msig(sn, eps) * invB;
-            if (act) {
+            if (act && gU) {                                    // gU == NULL: forward only (loss-only pass)
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     const int k = lane + 64 * e;
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(256) void k_pair_normal(
             }
         }
         __syncthreads();
-        combine_positive_rows<D>(s_pos, s_gi, gI);
+        if (gI) combine_positive_rows<D>(s_pos, s_gi, gI);
         __syncthreads();
     }
     const float s0 = block_sum(sq, red);
@@ -976,7 +978,7 @@ __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const 
                     const int k = lane + 64 * e;
                     const float x = T[(size_t)rows[q] * D + k];
                     sq = fmaf(x, x, sq);
-                    MACR_ATOMIC_ADD(G + (size_t)rows[q] * D + k, coef * x);
+                    if (G) MACR_ATOMIC_ADD(G + (size_t)rows[q] * D + k, coef * x);
                 }
             }
         }
@@ -1126,11 +1128,19 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
                        float *gU, float *gI, int32_t *tU, int32_t *tI, float coef, int reg_on_gathered,
                        float *adam_pow, const macr_hyper *hp, const PairWs &ws, hipStream_t st,
                        const PendingAdam *pa = nullptr, const AdamArgs *pending = nullptr,
-                       long long n_pending_blocks = 0, const LossArgs *finalize = nullptr) {
+                       long long n_pending_blocks = 0, const LossArgs *finalize = nullptr, bool loss_only = false) {
     const int grid = ws.nblk_pair;
     const int user_branch = kind == MACR_LOSS_RUBIBCEBOTH;
     BatchSort sort = batch_sort_args(ws, B, u, i, j);
-    if (ws.staged) sort.B = 0;
+    if (ws.staged || loss_only) sort.B = 0;
+    if (kind == MACR_LOSS_NORMALBCE && loss_only) {            // forward of the per-pair loss, nothing written but partials
+        const int nb = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;
+        MACR_DISPATCH_D(d, (k_pair_normal<D><<<nb, 256, 0, st>>>(B, u, i, j, Usrc, Isrc, nullptr, nullptr, nullptr, nullptr,
+                                                                ws.part, coef, reg_on_gathered, adam_pow, nullptr,
+                                                                ws.scal, hp->lr, hp->beta1, hp->beta2)));
+        MACR_CHECK_LAUNCH("pair_normal", st);
+        return MACR_OK;
+    }
     if (kind == MACR_LOSS_NORMALBCE) {
         if (ws.staged) {
             MACR_DISPATCH_LPR(d, (k_pair_normal_stage<LPR><<<ws.nblk_bwd, 256, 0, st>>>(
@@ -1162,6 +1172,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
         default: launch_bxb_rows<4>(ws, B, pending, n_pending_blocks, sort, st); break;
     }
     MACR_CHECK_LAUNCH(pending ? "bxb+adam" : "bxb", st);
+    if (loss_only) return MACR_OK;
     LossArgs L;
     if (finalize) L = *finalize; else L.losses = nullptr;
     if (ws.staged) {
@@ -1344,8 +1355,8 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
                                     const void *plan_dev, const void *plan_host, const int32_t *u,
                                     const int32_t *i, const int32_t *j, float *T, float *w, float *wu, float *mT,
                                     float *vT, float *mw, float *vw, float *mwu, float *vwu, float *adam_pow,
-                                    const macr_hyper *hp, float *losses, void *workspace, size_t workspace_bytes,
-                                    void *stream) {
+                                    const macr_hyper *hp, float *losses, int flags, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
     MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || loss_kind == MACR_LOSS_RUBIBCEBOTH, MACR_E_INVALID,
                  "lgcn_train_step: loss_kind=%d", loss_kind);
     MACR_REQUIRE(B > 0 && n_users > 0 && n_items > 0 && n_layers >= 0, MACR_E_INVALID,
@@ -1354,6 +1365,8 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     MACR_REQUIRE(rowptr && col && val && u && i && j && T && mT && vT && adam_pow && losses && workspace,
                  MACR_E_INVALID, "lgcn_train_step: null pointer");
     MACR_REQUIRE(w && wu && mw && vw && mwu && vwu, MACR_E_INVALID, "lgcn_train_step: null branch vectors");
+    MACR_REQUIRE((flags & ~MACR_STEP_LOSS_ONLY) == 0, MACR_E_INVALID, "lgcn_train_step: flags=%d", flags);
+    const bool loss_only = flags & MACR_STEP_LOSS_ONLY;
     if (int e = validate_hyper(hp, "lgcn_train_step")) return e;
     const int N = n_users + n_items;
     MACR_REQUIRE((plan_dev == nullptr) == (plan_host == nullptr), MACR_E_INVALID,
@@ -1370,6 +1383,28 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     const size_t nd = (size_t)N * d;
     // forward propagation (LightGCN.py:288-309)
     if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, T, ws.E, ws.work, st)) return e;
+    LossArgs L;
+    L.part = ws.pair.part;
+    L.part2 = ws.pair.part2; L.n_part2 = ws.pair.nblk_bwd;
+    L.lpart = ws.pair.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.pair.nrb * ws.pair.ncb : 0;
+    L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
+    L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
+    const float coef = hp->decay / (float)hp->batch_size_cfg;
+    if (loss_only) {
+        // the reference's "test loss" pass (LightGCN.py:799-819): loss_X, mf_loss_X, emb_loss_X without opt_X
+        float *Ei0 = ws.E + (size_t)n_users * d;
+        if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, ws.E, Ei0, w, wu, nullptr, nullptr, nullptr,
+                                nullptr, 0.0f, 0, adam_pow, hp, ws.pair, st, nullptr, nullptr, 0, nullptr, true))
+            return e;
+        MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, u, i, j, T, nullptr, coef,
+                                                                                   ws.pair.part2)));
+        MACR_CHECK_LAUNCH("reg_scatter", st);
+        L.n_part = loss_kind == MACR_LOSS_NORMALBCE
+                       ? ((B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024) : ws.pair.nblk_pair;
+        k_finalize_losses<<<1, 64, 0, st>>>(L);
+        MACR_CHECK_LAUNCH("finalize_losses", st);
+        return MACR_OK;
+    }
     fill_words(ws.dE, nd, 0u, st);
     // pair loss on the propagated rows; items live at rows n_users.. of E
     float *Ei = ws.E + (size_t)n_users * d, *dEi = ws.dE + (size_t)n_users * d;
@@ -1379,7 +1414,6 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
     if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st)) return e;
     // l2 regulariser on the ego rows (LightGCN.py:525-528)
-    const float coef = hp->decay / (float)hp->batch_size_cfg;
     MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, u, i, j, T, ws.G, coef,
                                                                                ws.pair.part2)));
     MACR_CHECK_LAUNCH("reg_scatter", st);
@@ -1393,12 +1427,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         add_seg(a, w, mw, vw, ws.pair.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
         add_seg(a, wu, mwu, vwu, ws.pair.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
     }
-    LossArgs L;
-    L.part = ws.pair.part; L.n_part = loss_kind == MACR_LOSS_NORMALBCE ? ws.pair.nblk_bwd : ws.pair.nblk_pair;
-    L.part2 = ws.pair.part2; L.n_part2 = ws.pair.nblk_bwd;
-    L.lpart = ws.pair.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.pair.nrb * ws.pair.ncb : 0;
-    L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
-    L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
+    L.n_part = loss_kind == MACR_LOSS_NORMALBCE ? ws.pair.nblk_bwd : ws.pair.nblk_pair;
     k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.pair.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;

@@ -80,17 +80,30 @@ class Evaluator(object):
         per_user = ops.metrics_mf(idx, cnt, self.gt, list(Ks))      # (U,4,nK) float64
         return ops.colmean(per_user)
 
+    def _c_scalar(self, c):
+        """The evaluator's device copy of c: kernels read it at run time (macr_score_topk c_dev), so the captured
+        graph of an evaluation serves every c of a sweep -- only this scalar is rewritten between replays."""
+        if getattr(self, "_c_dev", None) is None:
+            self._c_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._c_host = None
+        if self._c_host != float(c):
+            self._c_dev.fill_(float(c))
+            self._c_host = float(c)
+        return self._c_dev
+
     def _means(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
         """The device part of an evaluation.  An evaluator ranks the same queries against the same (in-place updated)
         tables every epoch, and the ~14 launches of one evaluation are issued from Python between two host
         synchronisations: on one GPU the sequence is captured once into a HIP graph and replayed (one launch instead
-        of ~90 us of launch gaps per evaluation).  Anything that changes the sequence -- other tensors, K, c -- is
-        another graph; `use_graph = False` (or several ranks) runs the launches directly."""
+        of ~90 us of launch gaps per evaluation).  c is not part of the sequence: the kernels read it from a device
+        scalar at run time, so the c sweep of the tuners (tune.py:545-578) replays ONE graph.  Anything else that changes
+        the sequence -- other tensors, K -- is another graph; `use_graph = False` (or several ranks) launches directly."""
         fn = self._mf_means if flavour == "mf" else self._lgcn_means
+        c = self._c_scalar(c)
         if not self.use_graph or sharding.world()[1] > 1:
             return fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
         key = (flavour, kind, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
-               Ks, None if w is None else w.data_ptr(), None if wu is None else wu.data_ptr(), float(c),
+               Ks, None if w is None else w.data_ptr(), None if wu is None else wu.data_ptr(),
                torch.cuda.current_stream().cuda_stream)
         entry = self._graphs.get(key)
         if entry is None:
@@ -108,7 +121,7 @@ class Evaluator(object):
                 out = fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
             # the graph bakes in the addresses of everything it touched: keep the inputs and the cached scratch
             # (ranking workspace, mask bitmaps) alive for as long as the graph exists, whatever the caches do later
-            keep = [users_tab, user_ids, items_tab, w, wu, ops._topk_ws_cache.get(items_tab.device)]
+            keep = [users_tab, user_ids, items_tab, w, wu, c, ops._topk_ws_cache.get(items_tab.device)]
             for csr in [self.mask] + list(self.mask.__dict__.get("_row_ranges", {}).values()):
                 keep.extend(csr.__dict__.get("_mask_bits", {}).values())
             entry = self._graphs[key] = (g, out, keep)

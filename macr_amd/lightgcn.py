@@ -34,6 +34,12 @@ class LightGCN(object):
         self.n_users = data_config['n_users']
         self.n_items = data_config['n_items']
         self.norm_adj = data_config['norm_adj']
+        # the backward pass through the propagation reuses the forward operator (dE0 = A^T dE = A dE): true for the
+        # symmetric `pre` and `plain` matrices, false for the row-normalised norm / gcmc / mean ones (D^-1 A)
+        asym = abs(self.norm_adj - self.norm_adj.T)
+        if asym.nnz and asym.max() > 1e-6 * abs(self.norm_adj).max():
+            raise NotImplementedError("--adj_type %s is not symmetric; the HIP path propagates gradients with the forward "
+                                      "operator and supports pre | plain" % args.adj_type)
         self.n_nonzero_elems = self.norm_adj.count_nonzero()
         self.lr = args.lr
         self.emb_dim = args.embed_size
@@ -109,11 +115,13 @@ class LightGCN(object):
         host = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory()
         return host.to(self.device, non_blocking=True)
 
-    def train_step(self, kind, batch, losses=None):
-        """-> (3,) device tensor {loss, mf_loss, emb_loss}; invalidates the cached propagated table."""
-        for st in self._opt.values():
-            st._E = None
-        return self._opt[kind].step(kind, batch[0], batch[1], batch[2], losses)
+    def train_step(self, kind, batch, losses=None, loss_only=False):
+        """-> (3,) device tensor {loss, mf_loss, emb_loss}; invalidates the cached propagated table.
+        loss_only=True: the reference's "test loss" pass (LightGCN.py:799-819) -- losses of the batch, no update."""
+        if not loss_only:
+            for st in self._opt.values():
+                st._E = None
+        return self._opt[kind].step(kind, batch[0], batch[1], batch[2], losses, loss_only=loss_only)
 
     def opt_state(self, kind):
         return self._opt[kind]
@@ -129,8 +137,9 @@ class LightGCN(object):
         ua, ia = self.propagated()
         ia = ia.contiguous()
         sig_u = sig_i = None
-        if kind == ops.SCORE_RUBI_BOTH:
+        if kind != ops.SCORE_NORMAL:
             sig_i = ops.branch_sigmoid(ia, self.w)
+        if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH):
             sig_u = ops.branch_sigmoid(ua, self.w_user, uid)
         return ops.score_matrix(kind, ua, uid, ia, sig_u, sig_i, self.rubi_c)
 
@@ -140,3 +149,13 @@ class LightGCN(object):
             for name in ("mT", "vT", "mw", "vw", "mwu", "vwu", "adam_pow"):
                 sd["opt%d.%s" % (kind, name)] = getattr(st, name)
         return sd
+
+    def load_state_dict(self, sd):
+        self.T.copy_(sd["T"]); self.w.copy_(sd["w"]); self.w_user.copy_(sd["w_user"]); self.rubi_c = float(sd["rubi_c"])
+        for kind, st in self._opt.items():
+            st._E = None
+            for name in ("mT", "vT", "mw", "vw", "mwu", "vwu", "adam_pow"):
+                getattr(st, name).copy_(sd["opt%d.%s" % (kind, name)])
+
+    def parameters(self):
+        return [self.T, self.w, self.w_user]

@@ -175,6 +175,10 @@ class BPRMF(object):
             sig_u = ops.branch_sigmoid(self.user_embedding, self.w_user, uid)
         return ops.score_matrix(kind, self.user_embedding, uid, self.item_embedding, sig_u, sig_i, self.rubi_c)
 
+    def parameters(self):
+        self.sync()
+        return [self.user_embedding, self.item_embedding, self.w, self.w_user]
+
     def state_dict(self):
         self.sync()
         sd = {"user_embedding": self.user_embedding, "item_embedding": self.item_embedding, "w": self.w,

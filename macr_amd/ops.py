@@ -160,9 +160,17 @@ def _topk_workspace(U, n_local, d, device):
     return ws
 
 
+def _c_args(c):
+    """c as (float by value, device pointer or None): a 1-element fp32 device tensor is read by the kernels at run time."""
+    if isinstance(c, torch.Tensor):
+        return 0.0, _ptr(c, _f32)
+    return float(c), None
+
+
 def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.0, mask=None,
                item_offset=0, n_splits=0):
-    """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K)."""
+    """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K).
+    c: python float, or a 1-element fp32 device tensor (read at run time: graph replays follow its value)."""
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
     n_local, d = items.shape
     if n_splits <= 0:
@@ -173,9 +181,10 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     mi = _ptr(mask.idx, _i32) if mask is not None else None
     mb = _ptr(mask.mask_bits(U, n_local, item_offset)) if mask is not None else None
     ws = _topk_workspace(U, n_local, d, items.device)
+    cv, cp = _c_args(c)
     check(_lib.lib().macr_score_topk(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
                                      _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
-                                     float(c), mp, mi, mb, item_offset, K, n_splits, _ptr(vals), _ptr(idx),
+                                     cv, cp, mp, mi, mb, item_offset, K, n_splits, _ptr(vals), _ptr(idx),
                                      _ptr(ws), ws.numel(), _stream()))
     return vals, idx
 
@@ -184,9 +193,10 @@ def score_matrix(kind, users_tab, user_ids, items, sig_u=None, sig_i=None, c=0.0
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
     n_local, d = items.shape
     out = torch.empty((U, n_local), dtype=_f32, device=items.device)
+    cv, cp = _c_args(c)
     check(_lib.lib().macr_score_matrix(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
                                        _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
-                                       float(c), _ptr(out), _stream()))
+                                       cv, cp, _ptr(out), _stream()))
     return out
 
 
@@ -359,18 +369,21 @@ class LGCNState(object):
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.T.device)
             self.batch_cap = B
 
-    def step(self, kind, u, i, j, losses=None):
+    def step(self, kind, u, i, j, losses=None, loss_only=False):
+        """One training step; loss_only=True computes {loss, mf_loss, emb_loss} of the batch and updates nothing
+        (the reference's "test loss" pass, LightGCN.py:799-819)."""
         B = u.numel()
         self.reserve(B)
         out = self.losses if losses is None else losses
-        self._E = None
+        if not loss_only:
+            self._E = None
         pd, ph = self.adj._plan_ptrs()
         check(_lib.lib().macr_lgcn_train_step(
             kind, B, self.d, self.n_users, self.n_items, self.n_layers, _ptr(self.adj.ptr, _i32),
             _ptr(self.adj.idx, _i32), _ptr(self.adj.val, _f32), pd, ph, _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
             _ptr(self.T), _ptr(self.w), _ptr(self.wu), _ptr(self.mT), _ptr(self.vT), _ptr(self.mw), _ptr(self.vw),
             _ptr(self.mwu), _ptr(self.vwu), _ptr(self.adam_pow), ctypes.byref(self.hyper), _ptr(out, _f32),
-            _ptr(self.ws), self.ws.numel(), _stream()))
+            _lib.STEP_LOSS_ONLY if loss_only else 0, _ptr(self.ws), self.ws.numel(), _stream()))
         return out
 
     def propagated(self):

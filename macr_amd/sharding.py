@@ -56,3 +56,23 @@ def max_over_ranks(x, device):
     t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def is_main():
+    """True on rank 0 (and without a process group): the rank that prints, logs and writes checkpoints."""
+    return world()[0] == 0
+
+
+def broadcast_params(tensors, src=0, group=None):
+    """Make every rank hold rank `src`'s copy of the model before an item-sharded evaluation: the ranks of a CLI run
+    train replicas on identical batches, but floating-point atomics add in a different order on every GPU, so the
+    replicas drift apart bit by bit -- and a sharded ranking must score ONE model."""
+    if world()[1] == 1:
+        return
+    for t in tensors:
+        if t.is_cuda and dist.get_backend(group) == "gloo":     # test rig: several ranks on one GPU
+            h = t.cpu()
+            dist.broadcast(h, src, group=group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src, group=group)

@@ -8,9 +8,12 @@ Same flags, log line formats, early stopping and weight-file naming as the refer
 (LightGCN.py:649-904).  The propagation (SpMM), the training step and the evaluator run on the HIP
 kernels; the sampler is the reference's host sampler (python `random` + numpy.random streams),
 overlapped with the device step because kernel launches are asynchronous (the reference needs a
-helper thread for that, :567-647).  Differences: the per-log-interval "test loss" pass (:799-819)
-is not run (pure logging; prints nan in the `--test normal` line), TensorBoard graph dumps are
-dropped, checkpoints are torch files.
+helper thread for that, :567-647).  The per-log-interval "test loss" pass (:799-819) runs as
+loss-only steps (MACR_STEP_LOSS_ONLY) on sample_test() batches, so the host RNG streams stay aligned
+with the reference for a whole run.  Differences: TensorBoard graph dumps are dropped; checkpoints are
+torch files (same directory and file naming), which --pretrain 1 and the additive --resume 1 read back;
+under torch.distributed.run every rank trains a replica, rank 0 prints / logs / saves, and the
+evaluation is item-sharded over the ranks after a broadcast of rank 0's parameters.
 """
 import logging
 import os
@@ -56,14 +59,19 @@ def pick_adjacency(adj_type):
     return mean_adj + sp.eye(mean_adj.shape[0])
 
 
-def train_epoch(model, kind, n_batch, loss_log, device_sampler=None):
+def train_epoch(model, kind, n_batch, loss_log, device_sampler=None, test_loss=False):
+    """n_batch steps (LightGCN.py:765-790).  test_loss=True is the reference's second pass of n_batch loss-only
+    runs on data_generator.sample_test() batches (:799-819): same RNG consumption, no parameter update."""
     for idx in range(n_batch):
-        if device_sampler is not None:
+        if test_loss:
+            users, pos_items, neg_items = data_generator.sample_test()
+            batch = model.to_device_batch(users, pos_items, neg_items)
+        elif device_sampler is not None:
             batch = device_sampler.sample()
         else:
             users, pos_items, neg_items = data_generator.sample()
             batch = model.to_device_batch(users, pos_items, neg_items)
-        model.train_step(kind, batch, loss_log[idx])
+        model.train_step(kind, batch, loss_log[idx], loss_only=test_loss)
     per_step = loss_log[:n_batch].cpu().numpy()
     loss = mf_loss = emb_loss = 0.
     for row in per_step:
@@ -73,8 +81,24 @@ def train_epoch(model, kind, n_batch, loss_log, device_sampler=None):
     return loss, mf_loss, emb_loss
 
 
+def _weights_dir(model):
+    layer = '-'.join(str(l) for l in model.weight_size)
+    return '%sweights/%s/%s/%s/l%s_r%s' % (args.weights_path, args.dataset, model.model_type, layer, str(args.lr),
+                                          '-'.join(str(r) for r in model.regs))
+
+
+def _saved_epochs(path):
+    """epochs of the weights_<saveID>-<epoch>.pt files in `path` (LightGCN.py:892 naming), ascending"""
+    pre, out = 'weights_{}-'.format(args.saveID), []
+    for f in os.listdir(path) if os.path.isdir(path) else []:
+        if f.startswith(pre) and f.endswith('.pt') and f[len(pre):-3].isdigit():
+            out.append(int(f[len(pre):-3]))
+    return sorted(out)
+
+
 def main(sweep=False):
     """sweep=True is LightGCN_tune.py: evaluate np.linspace(--start, --end, --step) values of c."""
+    from macr_amd import sharding
     seed = args.seed
     random.seed(seed)
     os.environ['PYTHONHASHSEED'] = str(seed)
@@ -85,25 +109,52 @@ def main(sweep=False):
         raise SystemExit("macr_lightgcn/LightGCN.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", args.gpu_id)) % max(torch.cuda.device_count(), 1))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
-        torch.distributed.init_process_group("nccl")
+        torch.distributed.init_process_group(os.environ.get("MACR_DIST_BACKEND", "nccl"))
+    main_rank = sharding.is_main()           # several ranks: replicas train, ONE prints / logs / writes (rank 0)
+
+    def say(text, end='\n'):
+        if main_rank:
+            print(text, end=end)
+            logging.info(text)
+
     config = dict(n_users=data_generator.n_users, n_items=data_generator.n_items)
     config['norm_adj'] = pick_adjacency(args.adj_type)
-    if args.pretrain != 0:
-        raise NotImplementedError("--pretrain %d restores TF weights in the reference; out of scope" % args.pretrain)
     model = LightGCN(data_config=config, pretrain_data=None, seed=seed)
-    print('using xavier initialization')
-    print('without pretraining.')
     sess = Session(model)
     kind = model.kind_of(args.loss)
-    weights_save_path = None
-    if args.save_flag == 1:
-        layer = '-'.join(str(l) for l in model.weight_size)
-        weights_save_path = '%sweights/%s/%s/%s/l%s_r%s' % (args.weights_path, args.dataset, model.model_type, layer,
-                                                            str(args.lr), '-'.join(str(r) for r in model.regs))
-        ensureDir(weights_save_path)
-        os.makedirs(weights_save_path, exist_ok=True)      # tf.train.Saver created this level itself
+    weights_save_path = _weights_dir(model)
 
-    cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch = 0., 0, 0, 0, 0
+    if args.pretrain == 1:
+        # LightGCN.py:707-719: restore a saved model, evaluate c = 0 and the best c, exit.  The reference hard-codes
+        # the file ("Your Path") and best_c = 45; here: the epoch in best_epoch_<saveID>.txt (else the newest file) and --c.
+        epochs = _saved_epochs(weights_save_path)
+        if not epochs:
+            raise SystemExit("--pretrain 1: no weights_%s-<epoch>.pt under %s" % (args.saveID, weights_save_path))
+        best_file = weights_save_path + '/best_epoch_{}.txt'.format(args.saveID)
+        pick = epochs[-1]
+        if os.path.exists(best_file):
+            e = int(open(best_file).read().strip() or -1)
+            pick = e if e in epochs else pick
+        model.load_state_dict(torch.load(weights_save_path + '/weights_{}-{}.pt'.format(args.saveID, pick),
+                                         map_location=model.device))
+        users_to_test = list(data_generator.test_set.keys())
+        for c in [0, args.c]:
+            model.update_c(sess, c)
+            ret = test(sess, model, users_to_test, method="rubiboth")
+            say('c:{}: recall={}, hit={}, ndcg={}'.format(c, str(ret["recall"]), str(ret['hr']), str(ret['ndcg'])))
+        return
+    print('using xavier initialization')
+    print('without pretraining.')
+    start_epoch = 1
+    if args.resume == 1:
+        epochs = _saved_epochs(weights_save_path)
+        if epochs:
+            model.load_state_dict(torch.load(weights_save_path + '/weights_{}-{}.pt'.format(args.saveID, epochs[-1]),
+                                             map_location=model.device))
+            start_epoch = epochs[-1] + 1
+            say('resumed from epoch %d' % epochs[-1])
+
+    cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch, best_c_hr = 0., 0, 0, 0, 0, 0.
     n_batch = data_generator.n_train // args.batch_size + 1
     loss_log = torch.zeros((n_batch, 3), dtype=torch.float32, device=model.device)
     device_sampler = None
@@ -113,7 +164,7 @@ def main(sweep=False):
                                        args.batch_size, model.device, seed=seed, pool=data_generator.exist_users)
     elif args.sampler != "reference":
         raise SystemExit("--sampler must be reference or device")
-    for epoch in range(1, args.epoch + 1):
+    for epoch in range(start_epoch, args.epoch + 1):
         t1 = time()
         loss, mf_loss, emb_loss = train_epoch(model, kind, n_batch, loss_log, device_sampler)
         if np.isnan(loss):
@@ -121,29 +172,29 @@ def main(sweep=False):
             sys.exit()
         if (epoch % args.log_interval) != 0:
             if args.verbose > 0 and epoch % args.verbose == 0:
-                perf_str = 'Epoch %d [%.1fs]: train==[%.5f=%.5f + %.5f]' % (epoch, time() - t1, loss, mf_loss, emb_loss)
-                print(perf_str)
-                logging.info(perf_str)
+                say('Epoch %d [%.1fs]: train==[%.5f=%.5f + %.5f]' % (epoch, time() - t1, loss, mf_loss, emb_loss))
             continue
 
+        # the reference's "test loss" pass (:799-819): n_batch loss-only runs on sample_test() batches
+        loss_test, mf_loss_test, emb_loss_test = train_epoch(model, kind, n_batch, loss_log, test_loss=True)
         t2 = time()
         users_to_test = list(data_generator.test_set.keys())
+        sharding.broadcast_params(model.parameters())       # item-sharded evaluation scores ONE model (rank 0's)
         perf_str = ''
         if args.test == 'normal':
             ret = test(sess, model, users_to_test, drop_flag=True)
             t3 = time()
-            nan = float('nan')           # the reference's test-loss pass (:799-819) is not run
             if args.verbose > 0:
                 perf_str = 'Epoch %d [%.1fs + %.1fs]: test==[%.5f=%.5f + %.5f + %.5f], recall=[%s], hr=[%s], ndcg=[%s]\n' % (
-                    epoch, t2 - t1, t3 - t2, nan, nan, nan, 0.0,
+                    epoch, t2 - t1, t3 - t2, loss_test, mf_loss_test, emb_loss_test, 0.0,
                     ', '.join('%.5f' % r for r in ret['recall']), ', '.join('%.5f' % r for r in ret['hr']),
                     ', '.join('%.5f' % r for r in ret['ndcg']))
-                print(perf_str, end='')
-                logging.info(perf_str)
+                say(perf_str, end='')
             if ret['hr'][0] > best_hr_norm:
                 best_hr_norm, best_epoch = ret['hr'][0], epoch
         elif args.test == 'rubiboth':
-            print('Epoch %d' % epoch)
+            if main_rank:
+                print('Epoch %d' % epoch)
             best_hr = 0
             c_values = np.linspace(args.start, args.end, args.step) if sweep else [args.c]
             for c in c_values:
@@ -156,8 +207,9 @@ def main(sweep=False):
                         c, ret['recall'][0], ret['recall'][-1], ret['hr'][0], ret['hr'][-1], ret['ndcg'][0],
                         ret['ndcg'][-1])
             ret['hr'][0] = best_hr
-            print(perf_str, end='')
-            logging.info(perf_str)
+            if best_hr > best_c_hr:                      # config['best_c_epoch'] of the reference (:880)
+                best_c_hr, best_c_epoch = best_hr, epoch
+            say(perf_str, end='')
         else:
             raise NotImplementedError("--test %s is outside the MI355X hot path (normal | rubiboth)" % args.test)
 
@@ -165,12 +217,16 @@ def main(sweep=False):
                                                                     expected_order='acc', flag_step=10)
         if ret['hr'][0] == cur_best_pre_0:
             best_epoch = epoch
-        if args.save_flag == 1:
+        if args.save_flag == 1 and main_rank:
+            ensureDir(weights_save_path)
+            os.makedirs(weights_save_path, exist_ok=True)      # tf.train.Saver created this level itself
             torch.save(model.state_dict(), weights_save_path + '/weights_{}-{}.pt'.format(args.saveID, epoch))
             print('save the weights in path: ', weights_save_path)
         if should_stop and args.early_stop == 1:
-            with open(weights_save_path + '/best_epoch_{}.txt'.format(args.saveID), 'w') as f:
-                f.write(str(best_c_epoch if args.test != 'normal' else best_epoch))
+            if main_rank:
+                os.makedirs(weights_save_path, exist_ok=True)
+                with open(weights_save_path + '/best_epoch_{}.txt'.format(args.saveID), 'w') as f:
+                    f.write(str(best_c_epoch if args.test != 'normal' else best_epoch))
             break
 
 

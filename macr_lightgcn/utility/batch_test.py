@@ -20,6 +20,7 @@ N_TRAIN, N_TEST = data_generator.n_train, data_generator.n_test
 BATCH_SIZE = args.batch_size
 
 _METHODS = {"normal": ops.SCORE_NORMAL, "rubiboth": ops.SCORE_RUBI_BOTH}
+_MAX_CACHED = 4
 _evaluators = {}
 
 
@@ -32,9 +33,11 @@ def test(sess, model, users_to_test, drop_flag=False, train_set_flag=0, method="
         raise NotImplementedError("method %r is outside the MI355X hot path (normal | rubiboth)" % method)
     if train_set_flag != 0:
         raise NotImplementedError("train_set_flag != 0 is unused by the reference CLI")
-    key = (len(users_to_test), users_to_test[0] if len(users_to_test) else -1)
+    key = hash(tuple(users_to_test))             # the whole list: the reference's test() is stateless
     ev = _evaluators.get(key)
     if ev is None:
+        if len(_evaluators) >= _MAX_CACHED:
+            _evaluators.clear()
         mask, gt = data_generator.eval_lists(users_to_test)
         ev = _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
                                  torch.tensor(list(users_to_test), dtype=torch.int32, device=model.device))

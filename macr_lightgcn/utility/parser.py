@@ -1,7 +1,7 @@
 """Command-line flags of the LightGCN CLI -- same names, types and defaults as the reference's
 macr_lightgcn/utility/parser.py:10-104.  On the MI355X hot path: --alg_type lightgcn, --adj_type pre,
 --loss {bce,bceboth}, --test {normal,rubiboth}; the remaining flags are accepted for compatibility.
-Additive: --seed."""
+Additive: --seed, --sampler, --resume."""
 import argparse
 
 _FLAGS = [
@@ -10,7 +10,7 @@ _FLAGS = [
     ("proj_path", None, '', "(compat)"),
     ("dataset", None, 'gowalla', "dataset name"),
     ("valid_set", None, 'test', "valid | test"),
-    ("pretrain", int, 0, "0: train from scratch (restores are out of scope)"),
+    ("pretrain", int, 0, "0: train from scratch; 1: load the best saved weights, evaluate c = 0 and the best c, exit"),
     ("verbose", int, 1, "print interval (epochs)"),
     ("is_norm", int, 1, "(compat)"),
     ("epoch", int, 1000, "number of epochs"),
@@ -44,6 +44,7 @@ _FLAGS = [
     ("step", int, 20, "LightGCN_tune.py: number of c values"),
     ("out", int, 0, "(compat)"),
     ("seed", int, 12345, "[new] seed of python/numpy/torch RNGs (the reference hard-codes 12345)"),
+    ("resume", int, 0, "[new] 1: load the newest checkpoint of this run's checkpoint directory and continue training"),
     ("sampler", str, "reference", "[new] reference: the reference's random/numpy streams (host); device: GPU sampler"),
 ]
 

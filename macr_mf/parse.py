@@ -52,6 +52,7 @@ _FLAGS = [
     ("out", int, 0, "(compat)"),
     # additive
     ("seed", int, 12345, "[new] seed of python/numpy/torch RNGs (the reference hard-codes 12345)"),
+    ("resume", int, 0, "[new] 1: load the newest checkpoint of this run's checkpoint directory and continue training"),
     ("sampler", str, "reference", "[new] reference: the reference's python `random` stream (host); device: GPU sampler"),
 ]
 

@@ -29,8 +29,11 @@ from macr_amd.metrics_host import (precision_at_k, dcg_at_k, ndcg_at_k, recall_a
 
 logging.getLogger().setLevel(logging.INFO)
 
-_MODEL_TYPES = {'o': ops.SCORE_NORMAL, 'rubi_both': ops.SCORE_RUBI_BOTH}
+# model_type of the reference's test() (train.py:222-259) -> score kind
+_MODEL_TYPES = {'o': ops.SCORE_NORMAL, 'rubi_both': ops.SCORE_RUBI_BOTH, 'rubi_c': ops.SCORE_RUBI,
+                'direct_minus_c': ops.SCORE_DIRECT_MINUS}
 _evaluators = {}
+_MAX_CACHED = 4
 
 
 def test(sess, model, test_users, batch_test_flag=False, model_type='o', valid_set="test",
@@ -39,10 +42,12 @@ def test(sess, model, test_users, batch_test_flag=False, model_type='o', valid_s
     catalogue minus its train items and returns the mean precision / recall / ndcg / hit_ratio at Ks.
     sess, batch_test_flag, item_pop_test, pop_exp are accepted for compatibility."""
     if model_type not in _MODEL_TYPES:
-        raise NotImplementedError("model_type %r is outside the MI355X hot path ('o' | 'rubi_both')" % model_type)
-    key = (valid_set, len(test_users), test_users[0] if len(test_users) else -1)
+        raise NotImplementedError("model_type %r is outside the MI355X hot path (%s)" % (model_type, sorted(_MODEL_TYPES)))
+    key = (valid_set, hash(tuple(test_users)))       # the whole list: the reference's test() is stateless
     ev = _evaluators.get(key)
     if ev is None:
+        if len(_evaluators) >= _MAX_CACHED:
+            _evaluators.clear()
         mask, gt = data.eval_lists(test_users, valid_set)
         ev = _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
                                  torch.tensor(list(test_users), dtype=torch.int32, device=model.device))
@@ -90,8 +95,18 @@ def train_epoch(model, kind, n_batch, loss_log, device_sampler=None):
     return loss, mf_loss, reg_loss
 
 
+def _saved_epochs():
+    """epochs of the <epoch>_ckpt.pt files of this run's checkpoint directory (train.py:588-591 naming), ascending"""
+    d, out = _ckpt_dir(), []
+    for f in os.listdir(d) if os.path.isdir(d) else []:
+        if f.endswith('_ckpt.pt') and f[:-8].isdigit():
+            out.append(int(f[:-8]))
+    return sorted(out)
+
+
 def main(sweep=False):
     """sweep=True is macr_mf/tune.py: evaluate np.linspace(--start, --end, --step) values of c instead of --c."""
+    from macr_amd import sharding
     seed = args.seed
     random.seed(seed)
     os.environ['PYTHONHASHSEED'] = str(seed)
@@ -105,18 +120,59 @@ def main(sweep=False):
     dev_index = int(os.environ.get("LOCAL_RANK", args.cuda)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
-        torch.distributed.init_process_group("nccl")        # item-sharded evaluation across the node's GPUs
+        # item-sharded evaluation across the node's GPUs (MACR_DIST_BACKEND=gloo: test rig, several ranks on one GPU)
+        torch.distributed.init_process_group(os.environ.get("MACR_DIST_BACKEND", "nccl"))
+    main_rank = sharding.is_main()           # several ranks: replicas train, ONE prints / logs / writes (rank 0)
+
+    def say(text):
+        if main_rank:
+            print(text)
+            logging.info(text)
+
     config = dict(n_users=data.n_users, n_items=data.n_items)
     model = BPRMF(args, config, seed=seed)
-    print('MF model.')
+    if main_rank:
+        print('MF model.')
     sess = Session(model)
     kind = model.kind_of(args.train)
+    rubi_type = "rubi_both" if args.train == 'rubibceboth' else "rubi_c"        # train.py:548-556
+
     if args.pretrain != 0:
-        raise NotImplementedError("--pretrain 1 restores a hard-coded TF checkpoint in the reference; out of scope")
+        # train.py:605-611: restore a saved model and evaluate it.  The reference hard-codes the file
+        # (mf_<dataset>_checkpoint/wd_1e-05_lr_0.001_0/299_ckpt.ckpt); here: this run's checkpoint directory, the epoch
+        # in best_epoch.txt (else the newest file), c from best_c.txt (else --c).
+        epochs = _saved_epochs()
+        if not epochs:
+            raise SystemExit("--pretrain 1: no <epoch>_ckpt.pt under %s" % _ckpt_dir())
+        pick, c = epochs[-1], args.c
+        if os.path.exists(_ckpt_dir() + 'best_epoch.txt'):
+            e = int(open(_ckpt_dir() + 'best_epoch.txt').read().strip() or -1)
+            pick = e if e in epochs else pick
+        if os.path.exists(_ckpt_dir() + 'best_c.txt'):
+            c = float(open(_ckpt_dir() + 'best_c.txt').read().strip())
+        print('#load existing models.')
+        model.load_state_dict(torch.load(_ckpt_dir() + '{}_ckpt.pt'.format(pick), map_location=model.device))
+        users_to_test = list((data.test_user_list if args.valid_set == "test" else data.valid_user_list).keys())
+        if args.test == "rubi":
+            model.update_c(sess, c)
+            ret = test(sess, model, users_to_test, model_type=rubi_type, valid_set=args.valid_set)
+        else:
+            ret = test(sess, model, users_to_test, valid_set=args.valid_set)
+        say('epoch %d c:%.2f recall=[%.5f, %.5f], precision=[%.5f, %.5f], hit=[%.5f, %.5f], ndcg=[%.5f, %.5f]' % (
+            pick, c, ret['recall'][0], ret['recall'][-1], ret['precision'][0], ret['precision'][-1],
+            ret['hit_ratio'][0], ret['hit_ratio'][-1], ret['ndcg'][0], ret['ndcg'][-1]))
+        return ret
 
     config["best_hr"], config["best_ndcg"], config['best_recall'], config['best_pre'], config["best_epoch"] = 0, 0, 0, 0, 0
     config['best_c_hr'], config['best_c_epoch'], config['best_c'] = 0, 0, 0.0
     stopping_step = 0
+    start_epoch = 0
+    if args.resume == 1:
+        epochs = _saved_epochs()
+        if epochs:
+            model.load_state_dict(torch.load(_ckpt_dir() + '{}_ckpt.pt'.format(epochs[-1]), map_location=model.device))
+            start_epoch = epochs[-1] + 1
+            say('resumed from epoch %d' % epochs[-1])
     n_batch = data.n_train // args.batch_size + 1
     loss_log = torch.zeros((n_batch, 3), dtype=torch.float32, device=model.device)
     device_sampler = None
@@ -126,7 +182,7 @@ def main(sweep=False):
                                        model.device, seed=seed)
     elif args.sampler != "reference":
         raise SystemExit("--sampler must be reference or device")
-    for epoch in range(args.epoch):
+    for epoch in range(start_epoch, args.epoch):
         t1 = time()
         loss, mf_loss, reg_loss = train_epoch(model, kind, n_batch, loss_log, device_sampler)
         if np.isnan(loss):
@@ -134,35 +190,33 @@ def main(sweep=False):
             sys.exit()
         if (epoch + 1) % args.log_interval != 0:
             if args.verbose > 0 and epoch % args.verbose == 0:
-                perf_str = 'Epoch %d [%.1fs]: train==[%.5f=%.5f + %.5f]' % (epoch, time() - t1, loss, mf_loss, reg_loss)
-                print(perf_str)
-                logging.info(perf_str)
+                say('Epoch %d [%.1fs]: train==[%.5f=%.5f + %.5f]' % (epoch, time() - t1, loss, mf_loss, reg_loss))
             continue
 
         t2 = time()
         users_to_test = list((data.test_user_list if args.valid_set == "test" else data.valid_user_list).keys())
+        sharding.broadcast_params(model.parameters())       # item-sharded evaluation scores ONE model (rank 0's)
         tail = ('train==[%.8f=%.8f + %.8f], recall=[%.5f, %.5f], precision=[%.5f, %.5f], hit=[%.5f, %.5f], '
                 'ndcg=[%.5f, %.5f]')
         def report(head, ret):
             if args.verbose > 0:
-                perf_str = head + tail % (loss, mf_loss, reg_loss, ret['recall'][0], ret['recall'][-1],
-                                          ret['precision'][0], ret['precision'][-1], ret['hit_ratio'][0],
-                                          ret['hit_ratio'][-1], ret['ndcg'][0], ret['ndcg'][-1])
-                print(perf_str)
-                logging.info(perf_str)
+                say(head + tail % (loss, mf_loss, reg_loss, ret['recall'][0], ret['recall'][-1],
+                                   ret['precision'][0], ret['precision'][-1], ret['hit_ratio'][0],
+                                   ret['hit_ratio'][-1], ret['ndcg'][0], ret['ndcg'][-1]))
 
         if args.test in ("normal", "rubi_user_wise"):
             ret = test(sess, model, users_to_test, valid_set=args.valid_set)
             report('Epoch %d [%.1fs + %.1fs]: ' % (epoch, t2 - t1, time() - t2), ret)
         elif args.test == "rubi":
-            print('Epoch %d' % epoch)
-            if args.train != 'rubibceboth':
-                raise NotImplementedError("--test rubi needs --train rubibceboth on the hot path")
+            if main_rank:
+                print('Epoch %d' % epoch)
+            if kind == ops.LOSS_NORMALBCE:
+                raise NotImplementedError("--test rubi needs a branch loss (--train rubibceboth | rubibce)")
             c_values = np.linspace(args.start, args.end, args.step) if sweep else [args.c]
             best = (0, 0, 0, 0, 0.0)               # train.py:540-544: bests start at 0
             for c in c_values:                      # tune.py:545-578: the best c of the sweep drives early stopping
                 model.update_c(sess, c)
-                ret = test(sess, model, users_to_test, model_type="rubi_both", valid_set=args.valid_set)
+                ret = test(sess, model, users_to_test, model_type=rubi_type, valid_set=args.valid_set)
                 report('c:%.2f [%.1fs + %.1fs]: ' % (c, t2 - t1, time() - t2), ret)
                 if ret['hit_ratio'][0] > best[0]:
                     best = (ret['hit_ratio'][0], ret['recall'][0], ret['precision'][0], ret['ndcg'][0], c)
@@ -174,21 +228,20 @@ def main(sweep=False):
 
         config, stopping_step, should_stop = early_stop(ret['hit_ratio'][0], ret['ndcg'][0], ret['recall'][0],
                                                         ret['precision'][0], epoch, config, stopping_step)
-        if args.save_flag == 1:
+        if args.save_flag == 1 and main_rank:
             os.makedirs(_ckpt_dir(), exist_ok=True)
             torch.save(model.state_dict(), _ckpt_dir() + '{}_ckpt.pt'.format(epoch))
         if should_stop and args.early_stop == 1:
-            msg = "{} dataset best epoch{}: hr:{} ndcg:{} recall:{} precision:{}".format(
+            say("{} dataset best epoch{}: hr:{} ndcg:{} recall:{} precision:{}".format(
                 args.dataset, config['best_epoch'], config['best_hr'], config['best_ndcg'], config['best_recall'],
-                config['best_pre'])
-            print(msg)
-            logging.info(msg)
-            os.makedirs(_ckpt_dir(), exist_ok=True)
-            with open(_ckpt_dir() + 'best_epoch.txt', 'w') as f:
-                print(config['best_epoch'], file=f)
-            if args.test == 'rubi':
-                with open(_ckpt_dir() + 'best_c.txt', 'w') as f:
-                    print(config['best_c'], file=f)
+                config['best_pre']))
+            if main_rank:
+                os.makedirs(_ckpt_dir(), exist_ok=True)
+                with open(_ckpt_dir() + 'best_epoch.txt', 'w') as f:
+                    print(config['best_epoch'], file=f)
+                if args.test == 'rubi':
+                    with open(_ckpt_dir() + 'best_c.txt', 'w') as f:
+                        print(config['best_c'], file=f)
             break
 
 

@@ -20,7 +20,7 @@ def test_mf_flags_match_reference_defaults():
     for k, v in ref.items():
         assert k in ours, k
         assert ours[k] == v and type(ours[k]) is type(v), (k, ours[k], v)
-    assert set(ours) - set(ref) == {"seed", "sampler"}            # additive flags only
+    assert set(ours) - set(ref) == {"seed", "sampler", "resume"}  # additive flags only
 
 
 def test_lightgcn_flags_match_reference_defaults():
@@ -30,7 +30,7 @@ def test_lightgcn_flags_match_reference_defaults():
     for k, v in ref.items():
         assert k in ours, k
         assert ours[k] == v and type(ours[k]) is type(v), (k, ours[k], v)
-    assert set(ours) - set(ref) == {"seed", "sampler"}
+    assert set(ours) - set(ref) == {"seed", "sampler", "resume"}
     args = mod.parse_args("--layer_size [64,64] --Ks [20] --loss bceboth --test rubiboth --gpu_id 0".split())
     assert args.layer_size == "[64,64]" and args.loss == "bceboth"
 

@@ -342,6 +342,35 @@ def test_lgcn_train_step_matches_oracle(ops, kind, d, B):
         np.testing.assert_allclose(state.T.cpu().numpy(), To, rtol=0, atol=0.02 * lr * (t + 1))
 
 
+@pytest.mark.parametrize("kind", [oracle.LOSS_NORMALBCE, oracle.LOSS_RUBIBCEBOTH])
+def test_lgcn_loss_only_pass(ops, kind):
+    """MACR_STEP_LOSS_ONLY (the reference's "test loss" pass, LightGCN.py:799-819): the losses of a batch, equal to
+    the losses the oracle's next step reports for that batch, with the model, the slots and the step count untouched."""
+    n_users, n_items, L, d, B = 500, 200, 2, 64, 300
+    A = toy_graph(n_users, n_items, 5)
+    P, Q, w, wu, u, i, j = make_problem(3, n_users, n_items, d, B)
+    T = np.concatenate([P, Q]).astype(np.float32)
+    alpha, beta, decay, lr = 1e-2, 1e-3, 1e-4, 1e-3
+    state = ops.LGCNState(dev(T), n_users, n_items, dev(w), dev(wu), ops.CSR.from_scipy(A, "cuda"), L,
+                          ops.make_hyper(lr, decay, alpha, beta, B), B)
+    state.step(kind, dev(u), dev(i), dev(j))                       # one real step so that slots and powers are not trivial
+    before = {n: getattr(state, n).clone() for n in ("T", "w", "wu", "mT", "vT", "mw", "vw", "mwu", "vwu", "adam_pow")}
+    rs = np.random.RandomState(8)
+    u2 = rs.choice(n_users, B, replace=False).astype(np.int32)
+    i2 = (rs.zipf(1.3, B) % n_items).astype(np.int32)
+    j2 = rs.randint(0, n_items, B).astype(np.int32)
+    got = state.step(kind, dev(u2), dev(i2), dev(j2), loss_only=True).cpu().numpy()
+    for n, t in before.items():
+        assert torch.equal(getattr(state, n), t), n
+    To, wo, wuo = state.T.cpu().numpy().copy(), state.w.cpu().numpy().copy(), state.wu.cpu().numpy().copy()
+    st = oracle.AdamState([To.shape, (d,), (d,)])
+    want = oracle.lgcn_train_step(kind, n_users, n_items, L, A.indptr, A.indices, A.data, u2, i2, j2, To, wo, wuo, st,
+                                  lr, decay, alpha, beta, B)
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    real = state.step(kind, dev(u2), dev(i2), dev(j2)).cpu().numpy()  # and the real step still works afterwards
+    np.testing.assert_allclose(real, want, rtol=1e-5)
+
+
 # ----------------------------------------------------------------------------- evaluator
 def random_mask(rs, U, n_items, mean_len, heavy=()):
     lists = []

@@ -291,3 +291,120 @@ def test_cli_evaluations_identical_with_and_without_graph_replay(tmp_path):
     # two training runs differ in the last bits (float atomics), so rankings may flip for a handful of users; the
     # regression moved the second and third evaluation by 2.5-6 %
     np.testing.assert_allclose(np.asarray(logs[0]), np.asarray(logs[1]), rtol=5e-3)
+
+
+# ----------------------------------------------------------------------------- (f) rows: tuner, checkpoints, variants
+def test_c_sweep_replays_one_graph_and_equals_separate_evaluations(ops):
+    """tune.py:545-578 / LightGCN_tune.py:852-870: every c of a sweep goes through ONE evaluator.  c lives in a device
+    scalar the kernels read at run time, so the sweep replays a single captured graph; each c must give exactly what
+    a fresh, graph-free evaluation of that c gives."""
+    from macr_amd.evaluator import Evaluator
+    rs = np.random.RandomState(5)
+    d, n_users, n_items, U = 64, 4000, 3000, 1500
+    P = dev((rs.standard_normal((n_users, d)) * 0.4).astype(np.float32))
+    Q = dev((rs.standard_normal((n_items, d)) * 0.4).astype(np.float32))
+    w, wu = dev((rs.standard_normal(d) * 0.3).astype(np.float32)), dev((rs.standard_normal(d) * 0.3).astype(np.float32))
+    users = np.sort(rs.choice(n_users, U, replace=False)).astype(np.int32)
+    mask = [sorted(rs.choice(n_items, 20, replace=False).tolist()) for _ in range(U)]
+    gt = [sorted(rs.choice(n_items, 5, replace=False).tolist()) for _ in range(U)]
+    uid = dev(users)
+    ev = Evaluator(mask, gt, n_items, torch.device("cuda"))
+    sweep = {}
+    for c in np.linspace(-5.0, 40.0, 10):
+        sweep[float(c)] = ev.test_mf(ops.SCORE_RUBI_BOTH, P, uid, Q, [5, 20], w, wu, float(c))
+    assert ev.use_graph and len(ev._graphs) == 1                  # one capture served all ten values
+    for c, got in sweep.items():
+        fresh = Evaluator(mask, gt, n_items, torch.device("cuda"))
+        fresh.use_graph = False
+        want = fresh.test_mf(ops.SCORE_RUBI_BOTH, P, uid, Q, [5, 20], w, wu, c)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (c, k)
+    vals = [tuple(v["hit_ratio"]) for v in sweep.values()]
+    assert len(set(vals)) > 1                                     # c does change the ranking
+
+
+def _metric_tail(line):
+    return line.split("recall=[")[1]
+
+
+def test_mf_cli_tune_pretrain_resume(tmp_path):
+    """f1/f3: tune.py sweeps c; checkpoints written by train.py are read back by --pretrain 1 (evaluate, exit) and by
+    the additive --resume 1 (continue training); a reloaded model evaluates to the digits it was saved with."""
+    os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
+    common = ["--dataset", "addressa", "--batch_size", "1024", "--cuda", "0", "--saveID", "r", "--log_interval", "2",
+              "--lr", "0.001", "--train", "rubibceboth", "--test", "rubi", "--alpha", "1e-3", "--beta", "1e-3"]
+    out = _run_cli([os.path.join(REPO, "macr_mf", "tune.py")] + common + ["--epoch", "4", "--start", "20", "--end", "40",
+                   "--step", "3"], str(tmp_path))
+    lines = [l for l in out.splitlines() if l.startswith("c:")]
+    assert [l[:7] for l in lines] == ["c:20.00", "c:30.00", "c:40.00"] * 2, out
+    last40 = lines[-1]
+    ck = tmp_path / "mf_addressa_checkpoint/wd_1e-05_lr_0.001_r"
+    assert os.path.exists(ck / "1_ckpt.pt") and os.path.exists(ck / "3_ckpt.pt")
+    out2 = _run_cli([os.path.join(REPO, "macr_mf", "train.py")] + common + ["--pretrain", "1", "--c", "40"], str(tmp_path))
+    got = [l for l in out2.splitlines() if l.startswith("epoch 3 c:40.00")]
+    assert len(got) == 1 and _metric_tail(got[0]) == _metric_tail(last40), (got, last40)
+    out3 = _run_cli([os.path.join(REPO, "macr_mf", "train.py")] + common + ["--resume", "1", "--epoch", "6", "--c", "40"],
+                    str(tmp_path))
+    assert "resumed from epoch 3" in out3
+    assert [l.split()[1] for l in out3.splitlines() if l.startswith("Epoch ")] == ["4", "5"], out3
+    assert os.path.exists(ck / "5_ckpt.pt")
+
+
+def test_mf_cli_rubibce(tmp_path):
+    """--train rubibce --test rubi: opt_two_bce (model.py:67-69,:158-183) scored with rubi_ratings (:141, test()
+    model_type 'rubi_c', train.py:551)."""
+    os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
+    out = _run_cli([os.path.join(REPO, "macr_mf", "train.py"), "--dataset", "addressa", "--batch_size", "1024", "--cuda", "0",
+                    "--saveID", "b", "--log_interval", "2", "--lr", "0.001", "--epoch", "2", "--train", "rubibce", "--test",
+                    "rubi", "--c", "30", "--alpha", "1e-3", "--save_flag", "0"], str(tmp_path))
+    line = [l for l in out.splitlines() if l.startswith("c:30.00")]
+    assert len(line) == 1 and 0.0 < float(line[0].split("hit=[")[1].split(",")[0]) < 1.0, out
+
+
+def test_lightgcn_cli_test_loss_pretrain(tmp_path):
+    """--test normal prints the reference's test-loss columns (LightGCN.py:799-819) -- finite numbers from the
+    loss-only pass -- and --pretrain 1 reads the saved weights back (:707-719)."""
+    common = ["--data_path", os.path.join(REPO, "data") + "/", "--dataset", "addressa", "--verbose", "1", "--layer_size",
+              "[64,64]", "--Ks", "[20]", "--lr", "0.001", "--batch_size", "1024", "--gpu_id", "0", "--log_interval", "2",
+              "--alpha", "1e-2", "--beta", "1e-3", "--weights_path", str(tmp_path) + "/", "--saveID", "q"]
+    out = _run_cli([os.path.join(REPO, "macr_lightgcn", "LightGCN.py")] + common + ["--loss", "bce", "--test", "normal",
+                   "--epoch", "2"], str(tmp_path))
+    line = [l for l in out.splitlines() if "test==[" in l]
+    assert len(line) == 1, out
+    nums = line[0].split("test==[")[1].split("]")[0].replace("=", "+").split("+")
+    vals = [float(x) for x in nums]
+    assert all(np.isfinite(vals)) and vals[0] > 0 and abs(vals[0] - (vals[1] + vals[2])) < 1e-4, line
+    out2 = _run_cli([os.path.join(REPO, "macr_lightgcn", "LightGCN.py")] + common + ["--loss", "bce", "--test", "normal",
+                    "--pretrain", "1", "--c", "10"], str(tmp_path))
+    assert out2.count("c:0: recall=") == 1 and out2.count("c:10.0: recall=") == 1, out2
+
+
+def test_lightgcn_rejects_asymmetric_adjacency(tmp_path):
+    """The backward pass reuses the forward SpMM (A symmetric); --adj_type norm (D^-1 A) would train on wrong gradients."""
+    env = dict(os.environ, PYTHONUNBUFFERED="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "macr_lightgcn", "LightGCN.py"), "--data_path",
+                          os.path.join(REPO, "data") + "/", "--dataset", "addressa", "--layer_size", "[64,64]", "--Ks", "[20]",
+                          "--loss", "bce", "--test", "normal", "--epoch", "1", "--adj_type", "norm", "--save_flag", "0"],
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "not symmetric" in out.stderr
+
+
+def test_mf_cli_two_ranks_one_gpu(tmp_path):
+    """torch.distributed.run with two ranks (gloo rig on one GPU): replicas train, rank 0 alone prints and saves, the
+    evaluation is item-sharded after a broadcast of rank 0's parameters -- same metrics as the single-rank run up to
+    the run-to-run noise of floating-point atomics."""
+    os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
+    args_ = [os.path.join(REPO, "macr_mf", "train.py"), "--dataset", "addressa", "--batch_size", "1024", "--cuda", "0",
+             "--saveID", "m", "--log_interval", "2", "--lr", "0.001", "--epoch", "2", "--train", "rubibceboth", "--test", "rubi",
+             "--c", "40", "--alpha", "1e-3", "--beta", "1e-3"]
+    one = _run_cli(args_, str(tmp_path))
+    env = dict(os.environ, MACR_DIST_BACKEND="gloo", PYTHONUNBUFFERED="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533"] + args_, cwd=str(tmp_path), env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+    l1 = [l for l in one.splitlines() if l.startswith("c:40.00")]
+    l2 = [l for l in two.stdout.splitlines() if l.startswith("c:40.00")]
+    assert len(l1) == 1 and len(l2) == 1, two.stdout                       # rank 0 alone reports
+    h1, h2 = (float(l.split("hit=[")[1].split(",")[0]) for l in (l1[0], l2[0]))
+    assert abs(h1 - h2) <= 0.02 * max(h1, 1e-3), (h1, h2)
