@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
 struct BatchSort {
     const int32_t *u, *i, *j;
     int B;
+    int rb0;                            // (B,B) launch: first row block of the launch (row-sharded training), else 0
     int32_t *perm, *us, *is, *js;       // [B] each
 };
 
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
         adam_block<true>(adam, (long long)ablk, scal->lr_t, s_red);
         return;
     }
-    const int cb = bblk % ncb, rb = bblk / ncb, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int cb = bblk % ncb, rb = sort.rb0 + bblk / ncb, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const float *p = fwd, *n = fwd + Bp, *a = fwd + 2 * (size_t)Bp, *b = fwd + 3 * (size_t)Bp;
     const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
     const v2f one = {1.0f, 1.0f}, eps = {1e-10f, 1e-10f};
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
 // stores the row (whole run in one chunk: plain store; gP/gQ rows are zero between steps) or adds it atomically
 // (runs cut into several chunks).
 template <int LPR>
-__global__ __launch_bounds__(256) void k_seg_reduce(int n, int n_users, const uint32_t *__restrict__ sk,
+__global__ __launch_bounds__(256) void k_seg_reduce(int n, int n_users, uint32_t key_end, const uint32_t *__restrict__ sk,
                                                     const uint32_t *__restrict__ sv, const float *__restrict__ stage,
                                                     float *gU, float *gI, int32_t *tU, int32_t *tI) {
     constexpr int d = 4 * LPR, RPB = RowGroup<LPR>::kRowsPerBlock, CH = LPR < 16 ? LPR : 16;
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(256) void k_seg_reduce(int n, int n_users, const ui
     const int cnt_eq = __popcll(eq & gmask);                        // equal keys are contiguous from the head (sorted)
     const int lim = (int)(p % CH) == 0 ? CH : CH - (int)(p % CH);
     const int len = cnt_eq < lim ? cnt_eq : lim;
-    const bool head = in && (key0 != prev || (p % CH) == 0);
+    const bool head = in && key0 < key_end && (key0 != prev || (p % CH) == 0);     // keys >= key_end: not this rank's rows
     if (head) {
         const uint32_t next = (p + len < n) ? sk[p + len] : 0xffffffffu;
         const bool multi = key0 == prev || next == key0;
@@ -1042,7 +1043,7 @@ struct PairWs {
     size_t bytes;
 };
 
-static PairWs carve_pair_ws(void *base, int B, int d) {
+static PairWs carve_pair_ws(void *base, int B, int d, bool force_staged = false) {
     PairWs w;
     const int lpr = d / 4, rpb = 256 / lpr;
     w.Bp = (int)align_up((size_t)B, 256);
@@ -1050,7 +1051,7 @@ static PairWs carve_pair_ws(void *base, int B, int d) {
     w.nrb = w.Bp / (64 * w.rows);
     w.ncb = w.Bp / 256;
     w.nblk_pair = (B + rpb - 1) / rpb;
-    w.staged = use_staging(B);
+    w.staged = force_staged || use_staging(B);
     if (w.staged) w.nblk_bwd = w.nblk_pair < 4096 ? w.nblk_pair : 4096;                      // grid-strided row groups
     else w.nblk_bwd = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;   // 16 consecutive slots per block pass
     char *p = static_cast<char *>(base);
@@ -1101,7 +1102,7 @@ static void launch_bxb_rows(const PairWs &ws, int B, const AdamArgs *pending, lo
 
 static BatchSort batch_sort_args(const PairWs &ws, int B, const int32_t *u, const int32_t *i, const int32_t *j) {
     BatchSort s;
-    s.u = u; s.i = i; s.j = j; s.B = B;
+    s.u = u; s.i = i; s.j = j; s.B = B; s.rb0 = 0;
     s.perm = ws.perm; s.us = ws.us; s.is = ws.is; s.js = ws.js;
     return s;
 }
@@ -1115,8 +1116,8 @@ static int launch_ref_sort_reduce(int B, int d, int n_urows, int n_irows, const 
     const int flip = launch_radix_sort(ws.ska, ws.sva, ws.skb, ws.svb, n, (uint32_t)(n_urows + n_irows - 1), ws.ghist, st);
     MACR_CHECK_LAUNCH("ref_sort", st);
     const uint32_t *sk = flip ? ws.skb : ws.ska, *sv = flip ? ws.svb : ws.sva;
-    MACR_DISPATCH_LPR(d, (k_seg_reduce<LPR><<<(n + 256 / LPR - 1) / (256 / LPR), 256, 0, st>>>(n, n_urows, sk, sv, ws.stage,
-                                                                                              gU, gI, tU, tI)));
+    MACR_DISPATCH_LPR(d, (k_seg_reduce<LPR><<<(n + 256 / LPR - 1) / (256 / LPR), 256, 0, st>>>(
+                             n, n_urows, (uint32_t)(n_urows + n_irows), sk, sv, ws.stage, gU, gI, tU, tI)));
     MACR_CHECK_LAUNCH("seg_reduce", st);
     return MACR_OK;
 }
@@ -1317,6 +1318,190 @@ extern "C" int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int
     LossArgs L;
     L.losses = nullptr;
     hipStream_t st = as_stream(stream);
+    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
+    MACR_CHECK_LAUNCH("adam_dense", st);
+    return MACR_OK;
+}
+
+// ============================================================================
+// Row-sharded training (BASELINE configs[4]: 10 M x 1 M rows, d = 128 over 8 GPUs).
+// The reference keeps each table in ONE tf.Variable (macr_mf/model.py:112-113); what does not fit or should not be
+// streamed by one GPU is the dense Adam pass -- 24*d bytes of EVERY row per step (33.8 GB at that size).  Rows of P
+// and Q, their Adam slots and gradient scratch are therefore range-sharded over the ranks, and a step becomes
+//   gather    every rank writes the batch rows it owns into a zero [3][B][d] buffer  -> all-reduce(sum) = every rank
+//             holds the batch's 3B rows (exactly one owner per row)
+//   forward   per-pair dots and branch factors for the whole batch, on every rank (B*(12d+12) bytes: negligible,
+//             deterministic, so no exchange of p, n, a, b is needed)
+//   bxb       rank r evaluates row blocks [r*nrb/W, (r+1)*nrb/W) of the (B,B) term into zeroed partial arrays
+//             -> all-reduce(sum) of the partials (a few MB) = complete row and column sums everywhere
+//   backward  gradient rows of the whole batch into the staging buffer, on every rank (again negligible)
+//   apply     each rank sorts the references to ITS rows, segment-reduces them into its gradient shard and runs the
+//             dense Adam pass over its shard only: the 24*d*rows bytes per step are divided by W
+// The collectives live on the host side (macr_amd/sharded_train.py, torch.distributed = RCCL over xGMI); these entry
+// points are the device half.  Results equal the single-GPU step up to summation order.
+// ============================================================================
+namespace macr {
+__global__ __launch_bounds__(256) void k_rows_gather_owned(int B, int lpr, const float *__restrict__ P, int u_lo, int u_hi,
+                                                           const float *__restrict__ Q, int i_lo, int i_hi,
+                                                           const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+                                                           const int32_t *__restrict__ j, float *__restrict__ rows3) {
+    const long long n4 = 3LL * B * lpr;
+    for (long long g = blockIdx.x * 256LL + threadIdx.x; g < n4; g += gridDim.x * 256LL) {
+        const long long ref = g / lpr;
+        const int sub = (int)(g % lpr), role = (int)(ref / B), t = (int)(ref % B);
+        const int row = role == 0 ? u[t] : role == 1 ? i[t] : j[t];
+        const int lo = role == 0 ? u_lo : i_lo, hi = role == 0 ? u_hi : i_hi;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (row >= lo && row < hi) v = ld4((role == 0 ? P : Q) + ((size_t)(row - lo) * lpr + sub) * 4);
+        st4(rows3 + (size_t)g * 4, v);
+    }
+}
+__global__ __launch_bounds__(256) void k_iota3(int B, int32_t *__restrict__ a) {
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < B; t += gridDim.x * 256) { a[t] = t; a[B + t] = t; a[2 * (size_t)B + t] = B + t; }
+}
+// sort keys of the references to THIS rank's rows (others: key_end, which k_seg_reduce ignores); value = staging row
+__global__ __launch_bounds__(256) void k_shard_keys(int B, int u_lo, int n_u, int i_lo, int n_i, const int32_t *__restrict__ u,
+                                                    const int32_t *__restrict__ i, const int32_t *__restrict__ j,
+                                                    uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+    const uint32_t none = (uint32_t)(n_u + n_i);
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < B; t += gridDim.x * 256) {
+        const int ru = u[t] - u_lo, ri = i[t] - i_lo, rj = j[t] - i_lo;
+        key[t] = (ru >= 0 && ru < n_u) ? (uint32_t)ru : none;                         val[t] = (uint32_t)t;
+        key[B + t] = (ri >= 0 && ri < n_i) ? (uint32_t)(n_u + ri) : none;             val[B + t] = (uint32_t)(B + t);
+        key[2 * (size_t)B + t] = (rj >= 0 && rj < n_i) ? (uint32_t)(n_u + rj) : none; val[2 * (size_t)B + t] = (uint32_t)(2 * (size_t)B + t);
+    }
+}
+struct ShardWs { PairWs pair; int32_t *iota; size_t bytes; };
+static ShardWs carve_shard_ws(void *base, int B, int d) {
+    ShardWs w;
+    w.pair = carve_pair_ws(base, B, d, true);
+    w.iota = base ? reinterpret_cast<int32_t *>(static_cast<char *>(base) + w.pair.bytes) : nullptr;
+    w.bytes = w.pair.bytes + align_up(3 * (size_t)B * 4, 256);
+    return w;
+}
+static inline int grid_for(long long n) { const long long g = (n + 255) / 256; return (int)(g < 4096 ? (g > 0 ? g : 1) : 4096); }
+}  // namespace macr
+
+#define MACR_SHARD_COMMON(who)                                                                                         \
+    MACR_REQUIRE(B > 0 && dim_supported(d), B > 0 ? MACR_E_UNSUPPORTED : MACR_E_INVALID, who ": B=%d d=%d", B, d);      \
+    MACR_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID, who ": workspace"); \
+    ShardWs sw = carve_shard_ws(workspace, B, d);                                                                      \
+    MACR_REQUIRE(workspace_bytes >= sw.bytes, MACR_E_WORKSPACE, who ": workspace %zu < %zu bytes", workspace_bytes, sw.bytes); \
+    const PairWs &ws = sw.pair;                                                                                        \
+    hipStream_t st = as_stream(stream)
+
+extern "C" size_t macr_shard_workspace_bytes(int B, int d) {
+    if (B <= 0 || !dim_supported(d)) return 0;
+    return carve_shard_ws(nullptr, B, d).bytes;
+}
+
+extern "C" int macr_shard_gather(int B, int d, const float *P_loc, int u_lo, int u_hi, const float *Q_loc, int i_lo, int i_hi,
+                                 const int32_t *u, const int32_t *i, const int32_t *j, float *rows3, void *stream) {
+    MACR_REQUIRE(B > 0 && dim_supported(d) && P_loc && Q_loc && u && i && j && rows3 && u_lo <= u_hi && i_lo <= i_hi,
+                 MACR_E_INVALID, "shard_gather: bad argument");
+    k_rows_gather_owned<<<grid_for(3LL * B * (d / 4)), 256, 0, as_stream(stream)>>>(B, d / 4, P_loc, u_lo, u_hi, Q_loc, i_lo, i_hi,
+                                                                                 u, i, j, rows3);
+    MACR_CHECK_LAUNCH("shard_gather", as_stream(stream));
+    return MACR_OK;
+}
+
+extern "C" int macr_shard_forward(int loss_kind, int B, int d, const float *rows3, const float *w, const float *wu,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE, MACR_E_UNSUPPORTED,
+                 "shard_forward: loss_kind=%d (the (B,B) losses only)", loss_kind);
+    MACR_REQUIRE(rows3 && w && wu, MACR_E_INVALID, "shard_forward: null pointer");
+    MACR_SHARD_COMMON("shard_forward");
+    k_iota3<<<grid_for(B), 256, 0, st>>>(B, sw.iota);
+    PendingAdam none = {};
+    const int user_branch = loss_kind == MACR_LOSS_RUBIBCEBOTH;
+    const float *Isrc = rows3 + (size_t)B * d;
+    MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, false><<<ws.nblk_pair, 256, 0, st>>>(B, ws.Bp, sw.iota, sw.iota + B, sw.iota + 2 * (size_t)B,
+                                                                              rows3, Isrc, w, wu, ws.fwd, ws.part, 1, ws.gw, none,
+                                                                              user_branch)));
+    MACR_CHECK_LAUNCH("pair_fwd", st);
+    return MACR_OK;
+}
+
+/* rank's share of the (B,B) term; the partial arrays (returned region) must then be summed over the ranks */
+extern "C" int macr_shard_bxb(int B, int d, int rank, int world, void **partials, size_t *partial_bytes,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(world >= 1 && rank >= 0 && rank < world, MACR_E_INVALID, "shard_bxb: rank %d of %d", rank, world);
+    MACR_SHARD_COMMON("shard_bxb");
+    char *lo = reinterpret_cast<char *>(ws.lpart), *hi = reinterpret_cast<char *>(ws.colpart) + (size_t)ws.nrb * 2 * ws.Bp * 4;
+    fill_words(lo, (size_t)(hi - lo) / 4, 0u, st);
+    if (partials) *partials = lo;
+    if (partial_bytes) *partial_bytes = (size_t)(hi - lo);
+    const int rb0 = (int)((long long)ws.nrb * rank / world), rb1 = (int)((long long)ws.nrb * (rank + 1) / world);
+    if (rb1 > rb0) {
+        BatchSort sort = batch_sort_args(ws, 0, nullptr, nullptr, nullptr);
+        sort.rb0 = rb0;
+        const int nb = (rb1 - rb0) * ws.ncb;
+        const bool full = B % 256 == 0;
+        AdamArgs none; none.n_seg = 0;
+#define MACR_BXB_ROWS_LAUNCH(R)                                                                                               \
+        if (full) k_bxb<R, true, false><<<nb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort); \
+        else      k_bxb<R, false, false><<<nb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort)
+        switch (ws.rows) { case 1: MACR_BXB_ROWS_LAUNCH(1); break; case 2: MACR_BXB_ROWS_LAUNCH(2); break; default: MACR_BXB_ROWS_LAUNCH(4); break; }
+#undef MACR_BXB_ROWS_LAUNCH
+    }
+    MACR_CHECK_LAUNCH("bxb", st);
+    return MACR_OK;
+}
+
+/* gradient rows of the whole batch into the staging buffer of the workspace; losses (dev) fp32[3]; the branch-vector
+ * partial rows (returned region) are replicated work: broadcast rank 0's so that w, w_user stay bit-identical */
+extern "C" int macr_shard_backward(int loss_kind, int B, int d, const float *rows3, const float *w, const float *wu,
+                                   float *adam_pow, const macr_hyper *hp, float *losses, void **branch_grads,
+                                   size_t *branch_bytes, void *workspace, size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE, MACR_E_UNSUPPORTED,
+                 "shard_backward: loss_kind=%d", loss_kind);
+    MACR_REQUIRE(rows3 && w && wu && adam_pow && losses, MACR_E_INVALID, "shard_backward: null pointer");
+    if (int e = validate_hyper(hp, "shard_backward")) return e;
+    MACR_SHARD_COMMON("shard_backward");
+    LossArgs L;
+    L.part = ws.part; L.n_part = ws.nblk_pair; L.part2 = nullptr; L.n_part2 = 0;
+    L.lpart = ws.lpart; L.n_lpart = ws.nrb * ws.ncb;
+    L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
+    L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
+    const float coef = hp->decay / (float)hp->batch_size_cfg;
+    const float *Isrc = rows3 + (size_t)B * d;
+    MACR_DISPATCH_LPR(d, (k_pair_bwd_stage<LPR><<<ws.nblk_bwd + 1, 256, 0, st>>>(
+                             B, ws.Bp, ws.nrb, ws.ncb, sw.iota, sw.iota + B, sw.iota + 2 * (size_t)B, rows3, Isrc, w, wu, ws.fwd,
+                             ws.rowpart, ws.colpart, ws.stage, ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal, hp->lr,
+                             hp->beta1, hp->beta2, L)));
+    MACR_CHECK_LAUNCH("pair_bwd", st);
+    if (branch_grads) *branch_grads = ws.gw;
+    if (branch_bytes) *branch_bytes = (size_t)kBranchSlots * 2 * d * 4;
+    return MACR_OK;
+}
+
+/* this rank's rows: sort the references to them, one owner per row sums its staging rows, dense Adam over the shard */
+extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int i_lo,
+                                const int32_t *u, const int32_t *i, const int32_t *j, float *P, float *Q, float *w, float *wu,
+                                float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu, float *vwu,
+                                float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ, const macr_hyper *hp,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(n_users_loc >= 0 && n_items_loc >= 0 && u && i && j && P && Q && w && wu && mP && vP && mQ && vQ && mw && vw &&
+                     mwu && vwu && gP && gQ && touchedP && touchedQ, MACR_E_INVALID, "shard_apply: bad argument");
+    if (int e = validate_hyper(hp, "shard_apply")) return e;
+    MACR_SHARD_COMMON("shard_apply");
+    const int n = 3 * B;
+    k_shard_keys<<<grid_for(B), 256, 0, st>>>(B, u_lo, n_users_loc, i_lo, n_items_loc, u, i, j, ws.ska, ws.sva);
+    const int flip = launch_radix_sort(ws.ska, ws.sva, ws.skb, ws.svb, n, (uint32_t)(n_users_loc + n_items_loc), ws.ghist, st);
+    MACR_CHECK_LAUNCH("ref_sort", st);
+    const uint32_t *sk = flip ? ws.skb : ws.ska, *sv = flip ? ws.svb : ws.sva;
+    MACR_DISPATCH_LPR(d, (k_seg_reduce<LPR><<<(n + 256 / LPR - 1) / (256 / LPR), 256, 0, st>>>(
+                             n, n_users_loc, (uint32_t)(n_users_loc + n_items_loc), sk, sv, ws.stage, gP, gQ, touchedP, touchedQ)));
+    MACR_CHECK_LAUNCH("seg_reduce", st);
+    AdamArgs a;
+    long long nb = 0;
+    a.n_seg = 0; a.lpr = d / 4; a.lpr_shift = d == 32 ? 3 : d == 64 ? 4 : d == 128 ? 5 : 6;
+    a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
+    if (n_users_loc) add_seg(a, P, mP, vP, gP, touchedP, n_users_loc, nb);
+    if (n_items_loc) add_seg(a, Q, mQ, vQ, gQ, touchedQ, n_items_loc, nb);
+    add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
+    if (loss_kind == MACR_LOSS_RUBIBCEBOTH) add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
+    LossArgs L; L.losses = nullptr;
     k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;

@@ -242,6 +242,38 @@ def test_mf_large_batch_staged_path_is_deterministic(ops):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("kind_name,B,d", [("LOSS_RUBIBCEBOTH", 777, 64), ("LOSS_RUBIBCE", 256, 32), ("LOSS_RUBIBCEBOTH", 2048, 128)])
+def test_row_shard_entry_points_world1(ops, kind_name, B, d):
+    """The macr_shard_* device entry points (row-sharded training) on one rank owning everything: gather, forward,
+    (B,B) row blocks, backward into the staging buffer, sorted segment reduce + Adam -- against the oracle step."""
+    from macr_amd import sharded_train
+    kind = getattr(ops, kind_name)
+    n_users, n_items = 900, 350
+    P, Q, w, wu, u, i, j = make_problem(B + d, n_users, n_items, d, B)
+    lr, decay, alpha, beta, bs = 1e-3, 1e-5, 1e-2, 1e-3, 512
+    st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
+    Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
+    hyper = ops.make_hyper(lr, decay, alpha, beta, bs)
+    model = sharded_train.RowShardedMF(dev(P), dev(Q), dev(w), dev(wu),
+                                       sharded_train.HipBackend(kind, d, hyper, torch.device("cuda")), rank=0, world=1)
+    rs = np.random.RandomState(4)
+    for t in range(3):
+        if t:
+            u = rs.choice(n_users, B, replace=B > n_users).astype(np.int32)
+            i = (rs.zipf(1.3, B) % n_items).astype(np.int32)
+            j = rs.randint(0, n_items, B).astype(np.int32)
+        want = oracle.mf_train_step(getattr(oracle, kind_name), u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, bs)
+        got = model.step(dev(u), dev(i), dev(j)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5)
+        if t == 0:
+            np.testing.assert_allclose(model.mP.cpu().numpy() / 0.1, st.m[0] / 0.1, rtol=2e-4, atol=2e-6 * np.abs(st.m[0] / 0.1).max())
+            np.testing.assert_allclose(model.mQ.cpu().numpy() / 0.1, st.m[1] / 0.1, rtol=2e-4, atol=2e-6 * np.abs(st.m[1] / 0.1).max())
+    for name, mine, theirs in (("P", model.P, Po), ("Q", model.Q, Qo), ("w", model.w, wo), ("wu", model.wu, wuo)):
+        np.testing.assert_allclose(mine.cpu().numpy(), theirs, rtol=0, atol=2e-3 * lr * 3, err_msg=name)
+    assert float(model.gP.abs().max()) == 0.0 and float(model.gQ.abs().max()) == 0.0
+    assert int(model.tP.sum()) == 0 and int(model.tQ.sum()) == 0
+
+
 def test_mf_deferred_mode_flushes_on_batch_size_change(ops):
     P, Q, w, wu, u, i, j = make_problem(5, 300, 50, 64, 200)
     hyper = ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, 1024)

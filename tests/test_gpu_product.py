@@ -408,3 +408,18 @@ def test_mf_cli_two_ranks_one_gpu(tmp_path):
     assert len(l1) == 1 and len(l2) == 1, two.stdout                       # rank 0 alone reports
     h1, h2 = (float(l.split("hit=[")[1].split(",")[0]) for l in (l1[0], l2[0]))
     assert abs(h1 - h2) <= 0.02 * max(h1, 1e-3), (h1, h2)
+
+
+def test_row_sharded_training_two_ranks_one_gpu(tmp_path):
+    """configs[4]'s training path at test size: P, Q and their Adam state range-sharded over two ranks (gloo rig on one
+    GPU), the macr_shard_* device entry points, three collectives per step; losses and the reassembled tables must
+    equal the single-GPU step and the oracle within the single-GPU tolerances."""
+    import json
+    env = dict(os.environ, PYTHONUNBUFFERED="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(REPO, "tests", "shard_worker.py")],
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"], res
+    assert res["world"] == 2 and res["rows_on_rank0"] < 0.51 * res["rows_total"]     # a rank holds half of the rows
