@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pos", default="zipf", choices=["zipf", "uniform"], help="positive-item distribution (diagnostic)")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluator leg (diagnostic)")
+    ap.add_argument("--regions", type=int, default=0, help="number of timed K-step regions (0 = as many as fit in ~60 ms); the median is reported")
     ap.add_argument("--no-e2e", action="store_true", help="skip the sampler-inclusive end-to-end leg (diagnostic)")
     ap.add_argument("--no-defer", action="store_true", help="complete every step's Adam pass inside the step instead of under the next step's (B,B) kernel (diagnostic)")
     ap.add_argument("--presorted", action="store_true", help="feed batches already ordered by positive item (diagnostic; the step orders its batch on the device either way)")
@@ -143,7 +144,7 @@ def main():
 
     regions = [timed_region()]
     # a 20-step region is under a millisecond: repeat the SAME K-step region until ~60 ms are on the clock, report the median
-    n_rep = int(min(200, max(1, round(0.06 / max(regions[0], 1e-6)))))
+    n_rep = args.regions if args.regions > 0 else int(min(200, max(1, round(0.06 / max(regions[0], 1e-6)))))
     n_rep = int(sharding.max_over_ranks(float(n_rep), dev))
     regions += [timed_region() for _ in range(n_rep - 1)]
     elapsed = float(np.median(regions))

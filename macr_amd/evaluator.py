@@ -35,10 +35,10 @@ class Evaluator(object):
         self.gt = ops.CSR.from_lists(gt_lists, device)
 
     # ------------------------------------------------------------------ ranking
-    def rank(self, kind, users_tab, user_ids, items_tab, K, w=None, wu=None, c=0.0, fill_masked=False):
-        """Top-K item ids for every query user: (val (U,K), idx (U,K), cnt (U,)).
-        users_tab/items_tab: full embedding tables (replicated on every rank); this rank scores
-        only its contiguous item shard and the shards' top-K are all-gathered and merged."""
+    def rank_local(self, kind, users_tab, user_ids, items_tab, K, w=None, wu=None, c=0.0):
+        """This rank's item shard: (val, idx) of shape (U,K) with GLOBAL item ids.
+        users_tab/items_tab: full embedding tables (replicated on every rank); a rank scores only its contiguous
+        item shard."""
         rank, ws = sharding.world()
         lo, hi = sharding.item_shard_range(items_tab.shape[0], rank, ws)
         items_local = items_tab[lo:hi]
@@ -61,8 +61,14 @@ class Evaluator(object):
                                             sig_i, c, self.mask.row_range(a, b), lo))
             vals = torch.cat([p[0] for p in parts], dim=1)
             idx = torch.cat([p[1] for p in parts], dim=1)
+        return vals, idx
+
+    def rank(self, kind, users_tab, user_ids, items_tab, K, w=None, wu=None, c=0.0, fill_masked=False):
+        """Top-K item ids for every query user: (val (U,K), idx (U,K), cnt (U,)); the shards' top-K are all-gathered
+        (one collective) and merged."""
+        vals, idx = self.rank_local(kind, users_tab, user_ids, items_tab, K, w, wu, c)
         fill = self.mask if fill_masked else None
-        if ws == 1:
+        if sharding.world()[1] == 1:
             return ops.topk_merge(vals, idx, fill)
         lv, li, _ = ops.topk_merge(vals, idx)                        # merge this shard's splits
         gv, gi = sharding.gather_topk(lv, li)                        # (W,U,K) over RCCL / xGMI
@@ -75,10 +81,20 @@ class Evaluator(object):
         m = self._means("mf", kind, users_tab, user_ids, items_tab, tuple(Ks), w, wu, c).cpu().numpy()
         return {'precision': m[0].copy(), 'recall': m[1].copy(), 'ndcg': m[2].copy(), 'hit_ratio': m[3].copy()}
 
-    def _mf_means(self, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
-        _, idx, cnt = self.rank(kind, users_tab, user_ids, items_tab, max(Ks), w, wu, c)
-        per_user = ops.metrics_mf(idx, cnt, self.gt, list(Ks))      # (U,4,nK) float64
-        return ops.colmean(per_user)
+    def _finish(self, flavour, vals, idx, Ks):
+        """(W,U,K) lists (splits of one shard, or the gathered shards) -> column means of the per-user metrics"""
+        if flavour == "mf":
+            _, ix, cnt = ops.topk_merge(vals, idx)
+            return ops.colmean(ops.metrics_mf(ix, cnt, self.gt, list(Ks)))                  # (U,4,nK) float64 -> (4,nK)
+        _, ix, _ = ops.topk_merge(vals, idx, self.mask)                                      # -inf fill, batch_test.py:124-134
+        return ops.colmean(ops.metrics_foldout(ix, self.gt, hr_in_ap_slot=True))            # (U,5*max_top) fp32
+
+    def _direct(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
+        vals, idx = self.rank_local(kind, users_tab, user_ids, items_tab, max(Ks), w, wu, c)
+        if sharding.world()[1] > 1:
+            lv, li, _ = ops.topk_merge(vals, idx)
+            vals, idx = sharding.gather_topk(lv, li)
+        return self._finish(flavour, vals, idx, Ks)
 
     def _c_scalar(self, c):
         """The evaluator's device copy of c: kernels read it at run time (macr_score_topk c_dev), so the captured
@@ -97,36 +113,57 @@ class Evaluator(object):
         synchronisations: on one GPU the sequence is captured once into a HIP graph and replayed (one launch instead
         of ~90 us of launch gaps per evaluation).  c is not part of the sequence: the kernels read it from a device
         scalar at run time, so the c sweep of the tuners (tune.py:545-578) replays ONE graph.  Anything else that changes
-        the sequence -- other tensors, K -- is another graph; `use_graph = False` (or several ranks) launches directly."""
-        fn = self._mf_means if flavour == "mf" else self._lgcn_means
+        the sequence -- other tensors, K -- is another graph; `use_graph = False` launches directly.  With several ranks
+        the sequence is two graphs around the one collective (all-gather of the shards' top-K)."""
         c = self._c_scalar(c)
-        if not self.use_graph or sharding.world()[1] > 1:
-            return fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
+        world = sharding.world()[1]
+        if not self.use_graph:
+            return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
         key = (flavour, kind, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
                Ks, None if w is None else w.data_ptr(), None if wu is None else wu.data_ptr(),
-               torch.cuda.current_stream().cuda_stream)
+               torch.cuda.current_stream().cuda_stream, world)
         entry = self._graphs.get(key)
         if entry is None:
-            # capturing costs about two evaluations: callers that keep changing the sequence (a c sweep evaluates
-            # dozens of c values per epoch) are better off launching directly
+            # capturing costs about two evaluations: callers that keep changing the sequence are better off launching directly
             self._graph_misses += 1
             if self._graph_misses > 6:
                 self.use_graph = False
                 self._graphs.clear()
-                return fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
-            fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)          # warm-up: allocations, caches, attributes
+                return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
+            self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)     # warm-up: allocations, caches, attributes
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = fn(kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
-            # the graph bakes in the addresses of everything it touched: keep the inputs and the cached scratch
-            # (ranking workspace, mask bitmaps) alive for as long as the graph exists, whatever the caches do later
+            K = max(Ks)
+            if world == 1:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    vals, idx = self.rank_local(kind, users_tab, user_ids, items_tab, K, w, wu, c)
+                    out = self._finish(flavour, vals, idx, Ks)
+                stages = (g, None, None, None)
+            else:
+                # several ranks: the collective stays outside -- one graph up to this shard's merged lists, the
+                # all-gather (RCCL), one graph from the gathered lists to the means
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    vals, idx = self.rank_local(kind, users_tab, user_ids, items_tab, K, w, wu, c)
+                    lv, li, _ = ops.topk_merge(vals, idx)
+                gv, gi = sharding.gather_topk(lv, li)                    # static inputs of the second graph
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb):
+                    out = self._finish(flavour, gv, gi, Ks)
+                stages = (ga, (lv, li), (gv, gi), gb)
+            # the graphs bake in the addresses of everything they touched: keep the inputs and the cached scratch
+            # (ranking workspace, mask bitmaps) alive for as long as they exist, whatever the caches do later
             keep = [users_tab, user_ids, items_tab, w, wu, c, ops._topk_ws_cache.get(items_tab.device)]
             for csr in [self.mask] + list(self.mask.__dict__.get("_row_ranges", {}).values()):
                 keep.extend(csr.__dict__.get("_mask_bits", {}).values())
-            entry = self._graphs[key] = (g, out, keep)
-        entry[0].replay()
-        return entry[1]
+            entry = self._graphs[key] = (stages, out, keep)
+        (ga, local, gathered, gb), out = entry[0], entry[1]
+        ga.replay()
+        if gb is not None:
+            nv, ni = sharding.gather_topk(local[0], local[1])
+            gathered[0].copy_(nv); gathered[1].copy_(ni)
+            gb.replay()
+        return out
 
     # ------------------------------------------------------------------ LightGCN flavour
     def test_lgcn(self, kind, users_tab, user_ids, items_tab, Ks, w=None, wu=None, c=0.0):
@@ -137,11 +174,6 @@ class Evaluator(object):
         final = self._means("lgcn", kind, users_tab, user_ids, items_tab, tuple(Ks), w, wu, c).cpu().numpy()
         final = final.reshape(5, max_top)[:, top_show - 1]
         return {'hr': final[2].copy(), 'recall': final[1].copy(), 'ndcg': final[3].copy()}
-
-    def _lgcn_means(self, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
-        _, idx, _ = self.rank(kind, users_tab, user_ids, items_tab, max(Ks), w, wu, c, fill_masked=True)
-        per_user = ops.metrics_foldout(idx, self.gt, hr_in_ap_slot=True)      # (U,5*max_top) fp32
-        return ops.colmean(per_user)
 
 
 def eval_score_matrix_foldout(score_matrix, test_items, top_k=20, thread_num=None):

@@ -3,8 +3,8 @@
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The
 catalogue is cut into `world` contiguous item ranges; every rank ranks ALL
 query users against its own range (fused scoring + top-K), then the per-shard
-top-K lists -- U*K*(4+4) bytes per rank, a few MB -- are exchanged with ONE
-all-gather and merged.  The merge is exact because the global top-K is a subset
+top-K lists -- U*K*(4+4) bytes per rank, a few MB, (score, id) packed in 64-bit
+words -- are exchanged with ONE all-gather and merged.  The merge is exact because the global top-K is a subset
 of the union of the per-shard top-Ks, and the tie rule (score desc, id asc) is
 applied identically everywhere, so 1/2/4/8-GPU results are identical.
 
@@ -31,8 +31,9 @@ def item_shard_range(n_items, rank, world_size):
 def gather_topk(local_val, local_idx, group=None):
     """All-gather per-shard (U,K) lists -> (W,U,K) tensors, identical on every rank.
 
-    A direct all-gather (fully connected xGMI, one hop) of a few MB: latency-bound, no
-    bucketing or ring tuning needed at this size."""
+    ONE direct all-gather (fully connected xGMI, one hop) of U*K*8 bytes per rank: score and id travel packed in one
+    64-bit word each (fp32 bits in the high half, int32 id in the low half), so the exchange is a single collective
+    -- latency-bound, no bucketing or ring tuning needed at this size."""
     rank, ws = world()
     if ws == 1:
         return local_val.unsqueeze(0), local_idx.unsqueeze(0)
@@ -40,12 +41,13 @@ def gather_topk(local_val, local_idx, group=None):
         # test rig only (several ranks sharing one GPU cannot use RCCL): gloo gathers host tensors
         v, i = gather_topk(local_val.cpu(), local_idx.cpu(), group)
         return v.to(local_val.device), i.to(local_idx.device)
-    vals = torch.empty((ws,) + tuple(local_val.shape), dtype=local_val.dtype, device=local_val.device)
-    idxs = torch.empty((ws,) + tuple(local_idx.shape), dtype=local_idx.dtype, device=local_idx.device)
+    packed = torch.stack([local_idx.contiguous().view(torch.int32), local_val.contiguous().view(torch.int32)], dim=-1)
+    packed = packed.contiguous().view(torch.int64).squeeze(-1)                 # (U,K) int64, little endian: idx | val
+    out = torch.empty((ws,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
     # output viewed as the concatenation along dim 0: the form every backend (nccl/RCCL, gloo) accepts
-    dist.all_gather_into_tensor(vals.view((-1,) + tuple(local_val.shape[1:])), local_val.contiguous(), group=group)
-    dist.all_gather_into_tensor(idxs.view((-1,) + tuple(local_idx.shape[1:])), local_idx.contiguous(), group=group)
-    return vals, idxs
+    dist.all_gather_into_tensor(out.view((-1,) + tuple(packed.shape[1:])), packed, group=group)
+    halves = out.view(torch.int32).view((ws,) + tuple(packed.shape) + (2,))
+    return halves[..., 1].contiguous().view(torch.float32), halves[..., 0].contiguous()
 
 
 def max_over_ranks(x, device):

@@ -213,7 +213,8 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     two ranks on ONE GPU through the gloo test rig; the single-rank run is the reference for the eval metrics."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--workload", "addressa", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--eval-reps", "1"]
+    common = ["--workload", "addressa", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--eval-reps", "1",
+              "--regions", "1", "--no-e2e"]            # same number of training steps in both runs: same model
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, cwd=root, capture_output=True, text=True,
                          timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
