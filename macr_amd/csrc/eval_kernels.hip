@@ -427,7 +427,17 @@ inline size_t score_topk_smem_bytes() {
 // (ds_read_b128) and 16 lanes x 16 B cover all 64 banks once.
 // ----------------------------------------------------------------------------
 constexpr int kModeMax = 0, kModeList = 1;
-constexpr int kSampleLog2 = 3;                       // pass 0 visits tiles t with t % 8 == 0
+// Pass 0 visits tiles t with t % 2^s == 0.  s = 3 for catalogues up to 512 tiles; s = 4 beyond (measured on the
+// Gowalla shape, 1281 tiles: sampling pass 116 -> 69 us, listing pass and selection unchanged -- tau sits at about rank
+// 16 K = 320 of a user's scores, inside the 512-entry lists; s = 5 would put it at 640).  On 275 tiles (ML-10M shape) the
+// pass is at its floor either way and the weaker tau of s = 4 only lengthens the selection (29 -> 44 us).
+static inline int sample_log2(int n_local) {
+#ifdef MACR_SAMPLE_LOG2
+    return MACR_SAMPLE_LOG2;
+#else
+    return (n_local + kTileItems - 1) / kTileItems > 512 ? 4 : 3;
+#endif
+}
 
 template <int D>
 struct StreamCfg {
@@ -471,11 +481,11 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     const float *__restrict__ c_dev,
     const uint32_t *__restrict__ mask_bits, int item_offset,
     int ublocks, const float *__restrict__ tau, float *__restrict__ maxima, uint64_t *__restrict__ lists,
-    int32_t *__restrict__ counts, int cap, int32_t *overflow) {
+    int32_t *__restrict__ counts, int cap, int32_t *overflow, int sample_log2) {
     using C = StreamCfg<D>;
     const float c = c_dev ? *c_dev : c_val;
     constexpr int RS = C::RS, NT = C::NT;
-    constexpr int kStep = MODE == kModeMax ? (1 << kSampleLog2) : 1;
+    const int kStep = MODE == kModeMax ? (1 << sample_log2) : 1;
     extern __shared__ __align__(16) unsigned char smem[];
     float *s_a = reinterpret_cast<float *>(smem);                       // [2][32][RS]
     float *s_sig = s_a + 2 * kTileItems * RS;                           // [2][32]
@@ -1117,7 +1127,7 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
     StreamGeo g;
     g.ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
     const int resident = d <= 64 ? 512 : 256;                 // 8-wave blocks resident on 256 CUs
-    const int T1 = (n_local + kTileItems - 1) / kTileItems, T0 = (T1 + (1 << kSampleLog2) - 1) >> kSampleLog2;
+    const int T1 = (n_local + kTileItems - 1) / kTileItems, sl = sample_log2(n_local), T0 = (T1 + (1 << sl) - 1) >> sl;
     auto plan = [&](int T, int &grid, int &slots) {
         const long long W = (long long)g.ublocks * T;
         long long G = resident;
@@ -1269,7 +1279,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         // and the selection kernel ranks them -- no sampling pass, no k_tau.
         if (!list_all) {
         pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
-                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow);
+                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, sample_log2(n_local));
         MACR_CHECK_LAUNCH("score_sample", st);
         const int tau_regs = (geo.slots0 * 32 + 63) / 64;
         if (tau_regs <= 1) k_tau<1><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
@@ -1281,7 +1291,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         MACR_CHECK_LAUNCH("tau", st);
         }
         pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
-                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow);
+                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, sample_log2(n_local));
         MACR_CHECK_LAUNCH("score_stream", st);
         k_select<<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow,
                                                        out_val, out_idx);
