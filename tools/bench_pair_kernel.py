@@ -13,7 +13,7 @@ gen = torch.Generator(device=dev).manual_seed(1)
 P = synth.xavier_table(n_users, d, gen, dev); Q = synth.xavier_table(n_items, d, gen, dev)
 w = synth.xavier_table(d, 1, gen, dev).reshape(-1); wu = synth.xavier_table(d, 1, gen, dev).reshape(-1)
 out = []
-for logB in (12, 14, 16, 18, 20):
+for logB in ([int(a) for a in sys.argv[1:]] or (12, 14, 16, 18, 20)):       # argv: only these log2(B) (profiling runs)
     B = 1 << logB
     for kind, name in ((ops.LOSS_NORMALBCE, "normalbce"),):
         state = ops.MFState(P, Q, w, wu, ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, B), B)

@@ -1,0 +1,7 @@
+#!/bin/bash
+# All rocprofv3 evidence of a round in one gpurun call (kernel trace + PMC passes each):
+#   bench (default workload), LightGCN at Yelp2018 shapes (SpMM), the pair kernels at B = 2^20.
+bash tools/profile.sh bench python $PWD/bench.py --steps 200 --warmup 20 --regions 3 --no-cpu-baseline
+bash tools/profile.sh lgcn python $PWD/tools/bench_lgcn.py
+bash tools/profile.sh pair20 python $PWD/tools/bench_pair_kernel.py 20
+python tools/bench_pair_kernel.py > gpurun_out/pair_scale.json 2> gpurun_out/pair_scale.err

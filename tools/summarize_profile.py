@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof (tools/profile.sh) into the small, committed files under profiles/:
-  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (all kernels of the bench run)
+"""Condense gpurun_out/prof_<run> (tools/profile.sh) into the small, committed files under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (all kernels of the run)
   profiles/<tag>_pmc.json           per-kernel averages of the PMC passes
   profiles/pmc_latest.json          {workload: {kernel: HBM bytes per launch}} read by bench.py (`traffic`)
+Usage:  python tools/summarize_profile.py condense <dir>        (on the GPU box: raw counter tables -> averages)
+        python tools/summarize_profile.py <run> <tag> [workload] (here: gpurun_out/prof_<run> -> profiles/<tag>_*)
 HBM bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE reports half of a wide coalesced
 read stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated."""
 import collections
@@ -14,7 +16,6 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -43,15 +44,39 @@ def pmc_avgs(path):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
 
-def main(tag, workload="gowalla"):
+def condense(src):
+    """raw per-dispatch counter tables -> <sub>/avgs.json (+ the kernel durations of the SQ pass), raw tables removed"""
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        p = os.path.join(src, sub, "bench_counter_collection.csv")
+        if os.path.exists(p):
+            json.dump(pmc_avgs(p), open(os.path.join(src, sub, "avgs.json"), "w"))
+            os.remove(p)
+    trace = os.path.join(src, "pmc_sq", "bench_kernel_trace.csv")
+    if os.path.exists(trace):
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(trace)):
+            k = short(r["Kernel_Name"])
+            if k:
+                dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        json.dump({k: sum(v) / len(v) for k, v in dur.items()}, open(os.path.join(src, "pmc_sq", "durations.json"), "w"))
+    for sub in ("trace", "pmc_fetch", "pmc_write", "pmc_sq"):
+        t = os.path.join(src, sub, "bench_kernel_trace.csv")
+        if os.path.exists(t):
+            os.remove(t)
+
+
+def main(run, tag, workload=None):
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + run)
     os.makedirs(DST, exist_ok=True)
-    shutil.copyfile(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, tag + "_kernel_stats.csv"))
-    shutil.copyfile(os.path.join(SRC, "bench_trace.json"), os.path.join(DST, tag + "_bench_under_rocprof.json"))
+    shutil.copyfile(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(DST, tag + "_kernel_stats.csv"))
+    out_txt = os.path.join(src, "stdout_trace.txt")
+    if os.path.exists(out_txt) and os.path.getsize(out_txt):
+        shutil.copyfile(out_txt, os.path.join(DST, tag + "_under_rocprof.json"))
     pmc = {}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-        p = os.path.join(SRC, sub, "bench_counter_collection.csv")
+        p = os.path.join(src, sub, "avgs.json")
         if os.path.exists(p):
-            for k, d in pmc_avgs(p).items():
+            for k, d in json.load(open(p)).items():
                 pmc.setdefault(k, {}).update(d)
     traffic = {}
     for k, d in pmc.items():
@@ -60,29 +85,29 @@ def main(tag, workload="gowalla"):
             traffic[k] = d["hbm_bytes_per_launch"]
     # GRBM_GUI_ACTIVE per nanosecond of kernel time: proportional to the clock the kernel ran at (DVFS).  This
     # rocprofv3 sums the counter over an unknown number of instances, so only RATIOS between kernels are used.
-    trace = os.path.join(SRC, "pmc_sq", "bench_kernel_trace.csv")
-    if os.path.exists(trace):
-        dur = collections.defaultdict(list)
-        for r in csv.DictReader(open(trace)):
-            k = short(r["Kernel_Name"])
-            if k:
-                dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    durp = os.path.join(src, "pmc_sq", "durations.json")
+    if os.path.exists(durp):
+        dur = json.load(open(durp))
         for k, d in pmc.items():
             if k in dur and "GRBM_GUI_ACTIVE" in d:
-                d["avg_ns_under_pmc"] = sum(dur[k]) / len(dur[k])
-                d["gui_active_per_ns"] = d["GRBM_GUI_ACTIVE"] / d["avg_ns_under_pmc"]
+                d["avg_ns_under_pmc"] = dur[k]
+                d["gui_active_per_ns"] = d["GRBM_GUI_ACTIVE"] / dur[k]
         top = max((d.get("gui_active_per_ns", 0) for d in pmc.values()), default=0)
         for d in pmc.values():
             if top and "gui_active_per_ns" in d:
                 d["clock_rel_to_fastest_kernel"] = d["gui_active_per_ns"] / top
     json.dump(pmc, open(os.path.join(DST, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
-    latest_path = os.path.join(DST, "pmc_latest.json")
-    latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
-    latest[workload] = traffic
-    json.dump(latest, open(latest_path, "w"), indent=1, sort_keys=True)
+    if workload:
+        latest_path = os.path.join(DST, "pmc_latest.json")
+        latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
+        latest[workload] = traffic
+        json.dump(latest, open(latest_path, "w"), indent=1, sort_keys=True)
     for k, d in sorted(pmc.items()):
         print(k, {c: round(v, 1) for c, v in d.items()})
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:])
+    if sys.argv[1] == "condense":
+        condense(sys.argv[2])
+    else:
+        main(*sys.argv[1:])
