@@ -427,15 +427,18 @@ inline size_t score_topk_smem_bytes() {
 // (ds_read_b128) and 16 lanes x 16 B cover all 64 banks once.
 // ----------------------------------------------------------------------------
 constexpr int kModeMax = 0, kModeList = 1;
-// Pass 0 visits tiles t with t % 2^s == 0.  s = 3 for catalogues up to 512 tiles; s = 4 beyond (measured on the
-// Gowalla shape, 1281 tiles: sampling pass 116 -> 69 us, listing pass and selection unchanged -- tau sits at about rank
-// 16 K = 320 of a user's scores, inside the 512-entry lists; s = 5 would put it at 640).  On 275 tiles (ML-10M shape) the
-// pass is at its floor either way and the weaker tau of s = 4 only lengthens the selection (29 -> 44 us).
+// Pass 0 visits tiles t with t % 2^s == 0; s = 3.  Measured with s = 4 on the Gowalla shape (1281 tiles): the
+// sampling pass drops from 116 to 69 us with the listing pass and the selection unchanged on a freshly initialised
+// model -- but after ~800 training steps on popularity-skewed data the best items of a user sit in a few adjacent
+// tiles, a 1/16 sample misses most of them, tau comes out too low, the candidate lists overflow and the exact
+// fallback kernel runs (4.3 ms instead of 4 us; profiles/r02a_kernel_stats.csv caught it).  A 50 us gain is not worth
+// that cliff: every 8th tile stays.  -DMACR_SAMPLE_LOG2=n rebuilds with another rate for experiments.
 static inline int sample_log2(int n_local) {
 #ifdef MACR_SAMPLE_LOG2
     return MACR_SAMPLE_LOG2;
 #else
-    return (n_local + kTileItems - 1) / kTileItems > 512 ? 4 : 3;
+    (void)n_local;
+    return 3;
 #endif
 }
 
