@@ -11,12 +11,16 @@
  *     (tests/golden/make_golden.py: G5-G8) and against the reference's C++
  *     evaluator compiled from /root/reference into oracle/_ref.
  *   - adjacency / propagation: PINNED against G4 (reference get_adj_mat).
- *   - model-step half (losses, gradients, Adam): PARITY UNPINNED.  The
- *     reference computes these inside TensorFlow 1.14, which cannot be run in
- *     this environment and for which the reference ships no golden values.
- *     The restatement follows the reference graph line by line (citations
- *     below) and its gradients are cross-checked against autograd of a literal
- *     re-expression of that graph (tests/test_oracle_model.py).
+ *   - model-step half: losses, gradients, propagation and the test-time score
+ *     formulas PINNED against fixture G10 (tests/golden/make_golden_model.py):
+ *     the reference's own graph-building code (macr_mf/model.py loss builders,
+ *     LightGCN._create_lightgcn_embed / create_bce_loss*) executed on injected
+ *     tensors through a functional stand-in for the tensorflow module, with
+ *     autograd gradients of that execution (tests/test_oracle_pinned.py).
+ *     The optimizer -- tf.train.AdamOptimizer's update rule, epsilon placement,
+ *     bias correction and its dense net effect on IndexedSlices -- stays PARITY
+ *     UNPINNED: TensorFlow 1.14 cannot be run in this environment and the
+ *     reference ships no golden values; orc_adam_dense follows SURVEY.md A.2.
  *
  * All tensors are fp32 row-major, indices int32, like the TF placeholders
  * (macr_mf/model.py:27-29).  Reductions over many elements accumulate in
