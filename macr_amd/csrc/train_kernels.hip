@@ -86,7 +86,11 @@ struct LossArgs {
     float *losses;
 };
 
-constexpr int kAdamVecPerBlock = 256 * 4;   // each thread handles 4 float4 per segment pass
+#ifndef MACR_ADAM_ITERS
+#define MACR_ADAM_ITERS 4
+#endif
+constexpr int kAdamIters = MACR_ADAM_ITERS;          // float4 per thread and array (2, 4, 8 measured: no difference)
+constexpr int kAdamVecPerBlock = 256 * kAdamIters;
 constexpr int kBranchSlots = 8;             // partial rows of the branch-vector gradients (pair_bwd adds, Adam consumes)
 
 __device__ __forceinline__ void adam4(float4 &th, float4 &m, float4 &v, const float4 gr, float lr_t, float b1,
@@ -133,11 +137,11 @@ __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, flo
     }
     // Table segment.  All of a thread's loads are issued before anything is consumed (12 float4 + 4 flags in
     // flight per lane): the pass is bound by memory-level parallelism, not by its arithmetic.
-    float4 th[4], m[4], v[4];
-    int flag[4];
-    long long vi[4];
+    float4 th[kAdamIters], m[kAdamIters], v[kAdamIters];
+    int flag[kAdamIters];
+    long long vi[kAdamIters];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < kAdamIters; ++it) {
         vi[it] = base + (long long)it * 256;
         flag[it] = 0;
         if (vi[it] < sg.n_vec) {
@@ -145,9 +149,9 @@ __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, flo
             th[it] = ld4(sg.theta + vi[it] * 4); m[it] = ld4(sg.m + vi[it] * 4); v[it] = ld4(sg.v + vi[it] * 4);
         }
     }
-    float4 gr[4];
+    float4 gr[kAdamIters];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < kAdamIters; ++it) {
         gr[it] = make_float4(0, 0, 0, 0);
         if (flag[it]) {                      // implies vi < n_vec
             gr[it] = ld4(sg.g + vi[it] * 4);
@@ -158,7 +162,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, flo
         }
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < kAdamIters; ++it) {
         if (vi[it] < sg.n_vec) {
             adam4(th[it], m[it], v[it], gr[it], lr_t, a.b1, a.b2, a.eps);
             st4(sg.theta + vi[it] * 4, th[it]); st4(sg.m + vi[it] * 4, m[it]); st4(sg.v + vi[it] * 4, v[it]);
@@ -411,7 +415,9 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
     const int nsort = (sort.B + kBucketSpan - 1) / kBucketSpan;
     if ((int)blockIdx.x >= nbxb && (int)blockIdx.x < nbxb + nsort) {     // these blocks group the batch for pair_bwd
         __builtin_amdgcn_s_setprio(3);         // a chain of latencies beside VALU-bound waves: go first when ready
+#ifndef MACR_ABL_NOGROUP
         batch_bucket_block<4>(sort, blockIdx.x - nbxb, s_hist);
+#endif
         return;
     }
     const bool is_adam = ADAM && (int)blockIdx.x >= nbxb + nsort;
@@ -419,7 +425,9 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
     if (is_adam) {
         // the bxb waves are older and would win every issue slot: the Adam waves (a handful of VALU instructions
         // between long memory waits) go first whenever they are ready
+#ifndef MACR_ABL_ADAM_NOPRIO
         __builtin_amdgcn_s_setprio(3);
+#endif
         adam_block<true>(adam, (long long)ablk, scal->lr_t, s_red);
         return;
     }
@@ -1088,6 +1096,9 @@ static void launch_bxb_rows(const PairWs &ws, int B, const AdamArgs *pending, lo
                             const BatchSort &sort, hipStream_t st) {
     const int nbxb = ws.ncb * ws.nrb, nsort = (sort.B + kBucketSpan - 1) / kBucketSpan;
     const bool full = B % 256 == 0;
+#ifdef MACR_ABL_XNOADAM
+    n_adam_blocks = 0;                 // timing probe: the ADAM instantiation of the kernel without any Adam block (wrong results)
+#endif
     if (pending) {
         const unsigned grid = (unsigned)(nbxb + nsort + n_adam_blocks);
         if (full) k_bxb<R, true, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal, sort);
