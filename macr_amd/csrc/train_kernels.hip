@@ -93,14 +93,35 @@ constexpr int kAdamIters = MACR_ADAM_ITERS;          // float4 per thread and ar
 constexpr int kAdamVecPerBlock = 256 * kAdamIters;
 constexpr int kBranchSlots = 8;             // partial rows of the branch-vector gradients (pair_bwd adds, Adam consumes)
 
+// theta -= (lr_t*m) / (sqrt(v)+eps), one element.  Default: v_sqrt_f32 (<= 1 ulp; denormal v flushes to 0, where eps = 1e-8
+// is the whole denominator anyway) and a reciprocal-based quotient with one residual correction (q0 = n*rcp(d),
+// q = q0 + (n - d*q0)*rcp(d): correctly rounded in all but rare cases, <= 1 ulp always) -- 13 VALU instructions per
+// element instead of the 33 of the IEEE sqrtf and division expansions (scaling for denormals, +-1 ulp candidates,
+// v_div_scale/fmas/fixup).  Stand-alone the pass is bound by memory and does not care; riding in the VALU-bound (B,B)
+// launch every instruction counts (PMC: the pass was 49 % of that kernel's VALU instructions): 23.1 -> see DESIGN.md.
+// The quotient is a step of size ~lr added to theta: 1 ulp of it is ~1e-10, below the resolution of theta itself, and
+// tf.train.AdamOptimizer's own rounding is not pinned by anything the reference ships.  -DMACR_ADAM_IEEE restores the
+// correctly rounded forms (the oracle uses those; tests compare with tolerances either way).
+__device__ __forceinline__ float adam_update(float th, float m, float v, float lr_t, float eps) {
+#ifdef MACR_ADAM_IEEE
+    return th - (lr_t * m) / (sqrtf(v) + eps);
+#else
+    const float d = __builtin_amdgcn_sqrtf(v) + eps, n = lr_t * m;
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q0 = n * r;
+    const float q = fmaf(fmaf(-d, q0, n), r, q0);
+    return th - q;
+#endif
+}
+
 __device__ __forceinline__ void adam4(float4 &th, float4 &m, float4 &v, const float4 gr, float lr_t, float b1,
                                       float b2, float eps) {
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
     m.x = m.x * b1 + gr.x * omb1; m.y = m.y * b1 + gr.y * omb1; m.z = m.z * b1 + gr.z * omb1; m.w = m.w * b1 + gr.w * omb1;
     v.x = v.x * b2 + (gr.x * gr.x) * omb2; v.y = v.y * b2 + (gr.y * gr.y) * omb2;
     v.z = v.z * b2 + (gr.z * gr.z) * omb2; v.w = v.w * b2 + (gr.w * gr.w) * omb2;
-    th.x -= (lr_t * m.x) / (sqrtf(v.x) + eps); th.y -= (lr_t * m.y) / (sqrtf(v.y) + eps);
-    th.z -= (lr_t * m.z) / (sqrtf(v.z) + eps); th.w -= (lr_t * m.w) / (sqrtf(v.w) + eps);
+    th.x = adam_update(th.x, m.x, v.x, lr_t, eps); th.y = adam_update(th.y, m.y, v.y, lr_t, eps);
+    th.z = adam_update(th.z, m.z, v.z, lr_t, eps); th.w = adam_update(th.w, m.w, v.w, lr_t, eps);
 }
 
 // One block's share of the pass: block `blk` of the segment list.  s_red (256 float4) is only used by
