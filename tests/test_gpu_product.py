@@ -424,3 +424,31 @@ def test_row_sharded_training_two_ranks_one_gpu(tmp_path):
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["ok"], res
     assert res["world"] == 2 and res["rows_on_rank0"] < 0.51 * res["rows_total"]     # a rank holds half of the rows
+
+
+def test_injected_weights_round_trip(ops):
+    """a1: parity runs inject the reference's initial values (`weights=`): the model must hold exactly those numbers,
+    share them between its optimizer instances, and hand them back through state_dict()."""
+    import types
+    from macr_amd.mf import BPRMF
+    rs = np.random.RandomState(3)
+    n_users, n_items, d = 70, 40, 64
+    wts = {"user_embedding": rs.standard_normal((n_users, d)).astype(np.float32),
+           "item_embedding": rs.standard_normal((n_items, d)).astype(np.float32),
+           "w": rs.standard_normal((d, 1)).astype(np.float32), "w_user": rs.standard_normal((d, 1)).astype(np.float32)}
+    args = types.SimpleNamespace(regs=1e-5, embed_size=d, lr=1e-3, batch_size=32, verbose=0, c=40.0, alpha=1e-2, beta=1e-3)
+    m = BPRMF(args, dict(n_users=n_users, n_items=n_items), weights=wts)
+    assert np.array_equal(m.user_embedding.cpu().numpy(), wts["user_embedding"])
+    assert np.array_equal(m.item_embedding.cpu().numpy(), wts["item_embedding"])
+    assert np.array_equal(m.w.cpu().numpy(), wts["w"].reshape(-1)) and np.array_equal(m.w_user.cpu().numpy(), wts["w_user"].reshape(-1))
+    for kind in (ops.LOSS_NORMALBCE, ops.LOSS_RUBIBCEBOTH, ops.LOSS_RUBIBCE):      # one storage behind every optimizer
+        st = m.opt_state(kind)
+        assert st.P.data_ptr() == m.user_embedding.data_ptr() and st.w.data_ptr() == m.w.data_ptr()
+    sd = m.state_dict()
+    assert np.array_equal(sd["user_embedding"].cpu().numpy(), wts["user_embedding"])
+    # without injection: Xavier-uniform, inside the limit sqrt(6 / (rows + d))
+    m2 = BPRMF(args, dict(n_users=n_users, n_items=n_items), seed=5)
+    L = np.sqrt(6.0 / (n_users + d))
+    x = m2.user_embedding.cpu().numpy()
+    assert np.abs(x).max() <= L and np.abs(x).max() > 0.9 * L
+    assert np.abs(m2.w.cpu().numpy()).max() <= np.sqrt(6.0 / (d + 1))
