@@ -317,6 +317,30 @@ int macr_score_topk(int score_kind, int U, int n_local, int d,
                     int item_offset, int K, int n_splits, float *out_val, int32_t *out_idx,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * The same ranking for SEVERAL values of c at once -- the c sweep of the tuners
+ * (macr_mf/tune.py:545-578, macr_lightgcn/LightGCN_tune.py:852-870: test() once per
+ * np.linspace(start, end, step) value).  c only enters the score epilogue, so ONE
+ * listing pass (the MFMA work, the staging of the item tiles) serves up to
+ * MACR_MAX_SWEEP values; per value there remain the sampling pass, the threshold, the
+ * appends into its own candidate lists and the selection.
+ *   c_dev     (dev) fp32[n_c], 1 <= n_c <= MACR_MAX_SWEEP, read at run time
+ *   mask_bits (dev) the bitmap of macr_mask_bits_build (required when a mask is given)
+ *   out_val/out_idx (dev) [n_c][U][K]: per value of c, per query, K (score,id) pairs as
+ *              macr_score_topk writes them (one list per value: n_splits = 1)
+ *   workspace >= macr_score_topk_sweep_workspace_bytes(U, n_local, d, n_c), 256-B aligned
+ * score_kind: any kind that uses c (not MACR_SCORE_NORMAL).  Results per value are
+ * identical to macr_score_topk with that c.
+ * -------------------------------------------------------------------------*/
+#define MACR_MAX_SWEEP 4
+size_t macr_score_topk_sweep_workspace_bytes(int U, int n_local, int d, int n_c);
+int macr_score_topk_sweep(int score_kind, int U, int n_local, int d,
+                          const float *users_tab, const int32_t *user_ids, const float *items,
+                          const float *sig_u, const float *sig_i, int n_c, const float *c_dev,
+                          const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
+                          int item_offset, int K, float *out_val, int32_t *out_idx,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* The train-item mask as the ranking kernels read it: mask_bits[tile][query] has bit (i % 32)
  * set when the query masks item 32*tile + i of the shard.  The mask of an evaluator never
  * changes during training (macr_mf/train.py:119-138 filters the same train lists every

@@ -448,6 +448,7 @@ struct StreamCfg {
     static constexpr int NT = D / 2;                 // MFMA steps per tile
     static constexpr int LD4 = (kTileItems * D / 4 + 511) / 512;   // float4 per thread per tile
     static constexpr size_t smem = (size_t)2 * kTileItems * RS * 4 + 2 * kTileItems * 4 + kUsersPerBlock * 4;
+    static constexpr size_t smem_sweep = smem + (size_t)(4 - 1) * kUsersPerBlock * 4;      // one counter array per c (kMaxSweep)
 };
 
 // Initialises the head of the ranking workspace in ONE launch: [0, n_zero) words <- 0 (counts, flags), the next n_tau
@@ -477,22 +478,35 @@ __global__ __launch_bounds__(256) void k_mask_bits(int U, int n_local, const int
     }
 }
 
-template <int D, int KIND, int MODE>
+// c sweep (macr_score_topk_sweep): ONE listing pass serves up to kMaxSweep values of c -- c only enters the epilogue, so
+// the MFMA work, the staging of the item tiles and the barriers are shared, and per (score, c) there is one epilogue,
+// one compare and (for the ~8K listed items per user and c) one append into that c's own lists.
+constexpr int kMaxSweep = 4;
+struct SweepArgs {
+    int n_c;                                  // values of c in this launch (<= kMaxSweep)
+    const float *tau[kMaxSweep];              // [U] per c
+    uint64_t *lists[kMaxSweep];               // [slots][U][cap] per c
+    int32_t *counts[kMaxSweep];               // [slots][U] per c
+    int32_t *overflow[kMaxSweep];             // one flag per c
+};
+
+template <int D, int KIND, int MODE, int NC = 1>
 __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     int U, int n_local, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
     const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val,
     const float *__restrict__ c_dev,
     const uint32_t *__restrict__ mask_bits, int item_offset,
     int ublocks, const float *__restrict__ tau, float *__restrict__ maxima, uint64_t *__restrict__ lists,
-    int32_t *__restrict__ counts, int cap, int32_t *overflow, int sample_log2) {
+    int32_t *__restrict__ counts, int cap, int32_t *overflow, int sample_log2, SweepArgs sw) {
     using C = StreamCfg<D>;
+    static_assert(NC == 1 || MODE == kModeList, "the sweep shares the listing pass only");
     const float c = c_dev ? *c_dev : c_val;
     constexpr int RS = C::RS, NT = C::NT;
     const int kStep = MODE == kModeMax ? (1 << sample_log2) : 1;
     extern __shared__ __align__(16) unsigned char smem[];
     float *s_a = reinterpret_cast<float *>(smem);                       // [2][32][RS]
     float *s_sig = s_a + 2 * kTileItems * RS;                           // [2][32]
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_sig + 2 * kTileItems);   // [256]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_sig + 2 * kTileItems);   // [NC][256]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -518,7 +532,10 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     const int q = ub * kUsersPerBlock + uslot;
     const bool q_ok = q < U;
 
-    if (MODE == kModeList && tid < kUsersPerBlock) s_cnt[tid] = 0u;
+    if (MODE == kModeList && tid < kUsersPerBlock) {
+#pragma unroll
+        for (int g = 0; g < NC; ++g) s_cnt[g * kUsersPerBlock + tid] = 0u;
+    }
     float bfrag[NT];
     {
         const float *urow = users_tab + (size_t)(q_ok ? (user_ids ? user_ids[q] : q) : 0) * D;
@@ -531,8 +548,16 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     }
     const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
     // listing test: score >= tau_s (NaN = never: padding users, poisoned scores)
-    const float tau_s = (MODE == kModeList && q_ok) ? tau[q] : __builtin_nanf("");
+    const float tau_s = (MODE == kModeList && NC == 1 && q_ok) ? tau[q] : __builtin_nanf("");
     uint64_t *my_list = lists + ((size_t)split * U + (q_ok ? q : 0)) * cap;
+    float tau_g[NC], c_g[NC];                 // sweep: per-c threshold and constant (NC > 1)
+    if (NC > 1) {
+#pragma unroll
+        for (int g = 0; g < NC; ++g) {
+            tau_g[g] = (g < sw.n_c && q_ok) ? sw.tau[g][q] : __builtin_nanf("");
+            c_g[g] = g < sw.n_c ? c_dev[g] : 0.f;
+        }
+    }
 
     int t = i0 * kStep;
     // staging: thread -> (item row, float4 column); k=4c..4c+3 lands as (h=0: t=2c,2c+1 <- x,z) (h=1: <- y,w)
@@ -632,6 +657,30 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 #else
         float v[16];
         uint64_t hit = 0ull;                                // OR of the compare masks: scalar unit, not VALU
+        if (NC > 1) {
+            // one epilogue + compare per (score, c); appends go to the lists of that c
+#pragma unroll
+            for (int g = 0; g < NC; ++g) {
+                if (g >= sw.n_c) break;                     // wave-uniform
+                uint64_t hg = 0ull;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = score_epilogue<KIND>(acc[r], c_g[g], sgi[r], su);
+                    hg |= __ballot(v[r] >= tau_g[g]);
+                }
+                if (hg) {
+                    uint64_t *lst = sw.lists[g] + ((size_t)split * U + (q_ok ? q : 0)) * cap;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (v[r] >= tau_g[g]) {
+                            const uint32_t pos = atomicAdd(&s_cnt[g * kUsersPerBlock + uslot], 1u);
+                            if (pos < (uint32_t)cap) lst[pos] = make_key(v[r], gid0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                            else *sw.overflow[g] = 1;
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             v[r] = acc[r];
@@ -639,11 +688,12 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
             if (MODE == kModeMax) cmax[r] = fmaxf(cmax[r], v[r]);
             else hit |= __ballot(v[r] >= tau_s);
         }
+        }
 #ifdef MACR_ABL_S_NOAPPEND
         if (v[3] == 12345.f) *overflow = 1;
         hit = 0ull;
 #endif
-        if (MODE == kModeList && hit) {                     // one wave-uniform branch per tile
+        if (MODE == kModeList && NC == 1 && hit) {          // one wave-uniform branch per tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (v[r] >= tau_s) {
@@ -671,7 +721,14 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
         }
     } else if (tid < kUsersPerBlock) {
         const int qq = ub * kUsersPerBlock + tid;
-        if (qq < U) counts[(size_t)split * U + qq] = (int32_t)min(s_cnt[tid], (uint32_t)cap);
+        if (NC == 1) {
+            if (qq < U) counts[(size_t)split * U + qq] = (int32_t)min(s_cnt[tid], (uint32_t)cap);
+        } else {
+#pragma unroll
+            for (int g = 0; g < NC; ++g)
+                if (g < sw.n_c && qq < U)
+                    sw.counts[g][(size_t)split * U + qq] = (int32_t)min(s_cnt[g * kUsersPerBlock + tid], (uint32_t)cap);
+        }
     }
     }   // segments
 }
@@ -1282,7 +1339,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         // and the selection kernel ranks them -- no sampling pass, no k_tau.
         if (!list_all) {
         pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
-                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, sample_log2(n_local));
+                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, sample_log2(n_local), SweepArgs{});
         MACR_CHECK_LAUNCH("score_sample", st);
         const int tau_regs = (geo.slots0 * 32 + 63) / 64;
         if (tau_regs <= 1) k_tau<1><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
@@ -1294,7 +1351,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         MACR_CHECK_LAUNCH("tau", st);
         }
         pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
-                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, sample_log2(n_local));
+                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, sample_log2(n_local), SweepArgs{});
         MACR_CHECK_LAUNCH("score_stream", st);
         k_select<<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow,
                                                        out_val, out_idx);
@@ -1311,6 +1368,99 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         kern<<<ublocks * n_splits, 512, smem_old, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
                                                         mask_ptr, mask_idx, item_offset, K, n_splits, out_val, out_idx,
                                                         n_splits > 1 ? ws.shared_thr : nullptr, force_fallback ? nullptr : ws.overflow);
+    });
+    MACR_CHECK_LAUNCH("score_topk", st);
+    return MACR_OK;
+}
+
+/* ---- c sweep -------------------------------------------------------------------------------------------------- */
+extern "C" size_t macr_score_topk_sweep_workspace_bytes(int U, int n_local, int d, int n_c) {
+    if (U <= 0 || n_local <= 0 || !dim_supported(d) || n_c < 1 || n_c > kMaxSweep) return 0;
+    const StreamGeo geo = stream_geo(U, n_local, d);
+    return (size_t)n_c * align_up(carve_topk_ws(nullptr, U, n_local, geo).bytes, 256);
+}
+
+extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, const float *users_tab,
+                                     const int32_t *user_ids, const float *items, const float *sig_u, const float *sig_i,
+                                     int n_c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
+                                     const uint32_t *mask_bits_in, int item_offset, int K, float *out_val, int32_t *out_idx,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(score_kind_valid(score_kind) && score_uses_sig_i(score_kind), MACR_E_INVALID,
+                 "score_topk_sweep: score_kind=%d does not depend on c", score_kind);
+    MACR_REQUIRE(n_c >= 1 && n_c <= kMaxSweep, MACR_E_UNSUPPORTED, "score_topk_sweep: n_c=%d outside [1,%d]", n_c, kMaxSweep);
+    MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk_sweep: U=%d n_local=%d", U, n_local);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk_sweep: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "score_topk_sweep: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
+    MACR_REQUIRE(users_tab && items && out_val && out_idx && c_dev && sig_i && (!score_uses_sig_u(score_kind) || sig_u),
+                 MACR_E_INVALID, "score_topk_sweep: null pointer");
+    MACR_REQUIRE(mask_bits_in || !mask_ptr, MACR_E_INVALID, "score_topk_sweep: pass the mask bitmap (macr_mask_bits_build) with the mask");
+    MACR_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID, "score_topk_sweep: workspace");
+    const StreamGeo geo = stream_geo(U, n_local, d);
+    const size_t one = align_up(carve_topk_ws(nullptr, U, n_local, geo).bytes, 256);
+    MACR_REQUIRE(workspace_bytes >= one * n_c, MACR_E_WORKSPACE, "score_topk_sweep: workspace %zu < %zu bytes", workspace_bytes, one * n_c);
+    static const bool force_fallback = getenv("MACR_TOPK_FALLBACK") && getenv("MACR_TOPK_FALLBACK")[0] == '1';
+    hipStream_t st = as_stream(stream);
+    const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock, sel_blocks = (U + kSelWaves - 1) / kSelWaves;
+    const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= carve_topk_ws(nullptr, U, n_local, geo).cap;
+    TopkWs ws[kMaxSweep];
+    SweepArgs sw;
+    sw.n_c = n_c;
+    for (int g = 0; g < kMaxSweep; ++g) {
+        ws[g] = carve_topk_ws(static_cast<char *>(workspace) + (size_t)(g < n_c ? g : 0) * one, U, n_local, geo);
+        sw.tau[g] = ws[g].tau; sw.lists[g] = ws[g].lists; sw.counts[g] = ws[g].counts; sw.overflow[g] = ws[g].overflow;
+    }
+    MACR_DISPATCH_DK(d, score_kind, {
+        auto pass0 = k_score_stream<D, KIND, kModeMax>;
+        auto pass1 = k_score_stream<D, KIND, kModeList, kMaxSweep>;
+        const size_t smem = StreamCfg<D>::smem, smem1 = StreamCfg<D>::smem_sweep;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
+        MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk_sweep: cannot reserve %zu B of LDS: %s", smem1, hipGetErrorString(e));
+        for (int g = 0; g < n_c; ++g) {           // per c: workspace head, sampling pass, threshold
+            const size_t n_zero = ws[g].header_bytes / 4;
+            const size_t n_tau = (reinterpret_cast<char *>(ws[g].maxima) - reinterpret_cast<char *>(ws[g].tau)) / 4;
+            const size_t n_max = list_all ? 0 : ws[g].maxima_bytes / 4;
+            const size_t total = n_zero + n_tau + n_max;
+            const unsigned grid = (unsigned)((total + 256 * 8 - 1) / (256 * 8) < 2048 ? (total + 256 * 8 - 1) / (256 * 8) : 2048);
+            k_topk_ws_init<<<grid ? grid : 1, 256, 0, st>>>(reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + (size_t)g * one),
+                                                         n_zero, n_tau, 0xff800000u, list_all ? 1 : 0, n_max);
+            MACR_CHECK_LAUNCH("ws_init", st);
+            if (list_all) continue;
+            pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev + g, mask_bits_in,
+                                                item_offset, geo.ublocks, ws[g].tau, ws[g].maxima, ws[g].lists, ws[g].counts,
+                                                ws[g].cap, ws[g].overflow, sample_log2(n_local), SweepArgs{});
+            MACR_CHECK_LAUNCH("score_sample", st);
+            const int tau_regs = (geo.slots0 * 32 + 63) / 64;
+            if (tau_regs <= 1) k_tau<1><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
+            else if (tau_regs <= 2) k_tau<2><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
+            else if (tau_regs <= 4) k_tau<4><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
+            else if (tau_regs <= 8) k_tau<8><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
+            else if (tau_regs <= 16) k_tau<16><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
+            else k_tau<32><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
+            MACR_CHECK_LAUNCH("tau", st);
+        }
+        // ONE listing pass for all n_c values
+        pass1<<<geo.grid1, 512, smem1, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev, mask_bits_in,
+                                             item_offset, geo.ublocks, ws[0].tau, ws[0].maxima, ws[0].lists, ws[0].counts,
+                                             ws[0].cap, ws[0].overflow, sample_log2(n_local), sw);
+        MACR_CHECK_LAUNCH("score_stream", st);
+        for (int g = 0; g < n_c; ++g) {
+            k_select<<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, 1, K, ws[g].cap, ws[g].lists, ws[g].counts, ws[g].overflow,
+                                                           out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K);
+            MACR_CHECK_LAUNCH("select", st);
+        }
+    });
+    // per-c fallback, armed by that c's overflow flag
+    const size_t smem_old = score_topk_smem_bytes();
+    MACR_DISPATCH_DK(d, score_kind, {
+        auto kern = k_score_topk<D, KIND>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_old);
+        MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk_sweep: cannot reserve %zu B of LDS: %s", smem_old, hipGetErrorString(e));
+        for (int g = 0; g < n_c; ++g)
+            kern<<<ublocks, 512, smem_old, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev + g, mask_ptr, mask_idx,
+                                                 item_offset, K, 1, out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K,
+                                                 nullptr, force_fallback ? nullptr : ws[g].overflow);
     });
     MACR_CHECK_LAUNCH("score_topk", st);
     return MACR_OK;

@@ -165,6 +165,65 @@ class Evaluator(object):
             gb.replay()
         return out
 
+    # ------------------------------------------------------------------ c sweep (tuners)
+    def _sweep_direct(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c_dev):
+        sig_i = ops.branch_sigmoid(items_tab, w)
+        sig_u = ops.branch_sigmoid(users_tab, wu, user_ids) if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH) else None
+        vals, idx = ops.score_topk_sweep(kind, users_tab, user_ids, items_tab, max(Ks), sig_u, sig_i, c_dev, self.mask, 0)
+        return torch.stack([self._finish(flavour, vals[g:g + 1], idx[g:g + 1], Ks) for g in range(c_dev.numel())])
+
+    def sweep_means(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, cs):
+        """Column means of the per-user metrics for every c of `cs`, (len(cs), ...).  On one GPU the values go through
+        the shared-listing-pass kernel in groups of up to four (one captured graph per group size, the group's values
+        in a device array the kernels read at run time); item-sharded runs evaluate c by c."""
+        from . import _lib
+        cs = [float(c) for c in cs]
+        if sharding.world()[1] > 1 or kind == ops.SCORE_NORMAL or self.n_queries > self.max_queries_per_pass:
+            return torch.stack([self._means(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c).clone() for c in cs])
+        outs = []
+        for a in range(0, len(cs), _lib.MAX_SWEEP):
+            chunk = cs[a:a + _lib.MAX_SWEEP]
+            n = len(chunk)
+            bufs = self.__dict__.setdefault("_c_sweep", {})
+            if n not in bufs:
+                bufs[n] = torch.zeros(n, dtype=torch.float32, device=self.device)
+            c_dev = bufs[n]
+            c_dev.copy_(torch.tensor(chunk, dtype=torch.float32), non_blocking=False)
+            if not self.use_graph:
+                outs.append(self._sweep_direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c_dev).clone())
+                continue
+            key = ("sweep", n, flavour, kind, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(),
+                   items_tab.data_ptr(), Ks, w.data_ptr(), None if wu is None else wu.data_ptr(),
+                   torch.cuda.current_stream().cuda_stream)
+            entry = self._graphs.get(key)
+            if entry is None:
+                self._sweep_direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c_dev)       # warm-up
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._sweep_direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c_dev)
+                keep = [users_tab, user_ids, items_tab, w, wu, c_dev, ops._sweep_ws_cache.get(items_tab.device)]
+                keep.extend(self.mask.__dict__.get("_mask_bits", {}).values())
+                entry = self._graphs[key] = ((g, None, None, None), out, keep)
+            entry[0][0].replay()
+            outs.append(entry[1].clone())
+        return torch.cat(outs)
+
+    def test_mf_sweep(self, kind, users_tab, user_ids, items_tab, Ks, w, wu, cs):
+        """test_mf for every c of `cs` -> list of result dicts (the c sweep of macr_mf/tune.py:545-578)."""
+        m = self.sweep_means("mf", kind, users_tab, user_ids, items_tab, tuple(Ks), w, wu, cs).cpu().numpy()
+        return [{'precision': x[0].copy(), 'recall': x[1].copy(), 'ndcg': x[2].copy(), 'hit_ratio': x[3].copy()} for x in m]
+
+    def test_lgcn_sweep(self, kind, users_tab, user_ids, items_tab, Ks, w, wu, cs):
+        top_show = np.sort(np.asarray(Ks))
+        max_top = int(top_show.max())
+        m = self.sweep_means("lgcn", kind, users_tab, user_ids, items_tab, tuple(Ks), w, wu, cs).cpu().numpy()
+        out = []
+        for x in m:
+            final = x.reshape(5, max_top)[:, top_show - 1]
+            out.append({'hr': final[2].copy(), 'recall': final[1].copy(), 'ndcg': final[3].copy()})
+        return out
+
     # ------------------------------------------------------------------ LightGCN flavour
     def test_lgcn(self, kind, users_tab, user_ids, items_tab, Ks, w=None, wu=None, c=0.0):
         """-> {'hr','recall','ndcg'}: np.ndarray(len(Ks)) (batch_test.py:134-161): C++-style fp32 prefix

@@ -189,6 +189,31 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     return vals, idx
 
 
+_sweep_ws_cache = {}
+
+
+def score_topk_sweep(kind, users_tab, user_ids, items, K, sig_u, sig_i, c_dev, mask=None, item_offset=0):
+    """The fused ranking for SEVERAL values of c with ONE listing pass (macr_score_topk_sweep; tune.py:545-578).
+    c_dev: fp32 device tensor of 1.._lib.MAX_SWEEP values.  Returns (vals, idx) of shape (n_c, U, K)."""
+    U = users_tab.shape[0] if user_ids is None else user_ids.numel()
+    n_local, d = items.shape
+    n_c = c_dev.numel()
+    vals = torch.empty((n_c, U, K), dtype=_f32, device=items.device)
+    idx = torch.empty((n_c, U, K), dtype=_i32, device=items.device)
+    mp = _ptr(mask.ptr, _i32) if mask is not None else None
+    mi = _ptr(mask.idx, _i32) if mask is not None else None
+    mb = _ptr(mask.mask_bits(U, n_local, item_offset)) if mask is not None else None
+    need = _lib.lib().macr_score_topk_sweep_workspace_bytes(U, n_local, d, n_c)
+    ws = _sweep_ws_cache.get(items.device)
+    if ws is None or ws.numel() < need:
+        ws = _sweep_ws_cache[items.device] = torch.empty(need, dtype=torch.uint8, device=items.device)
+    check(_lib.lib().macr_score_topk_sweep(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
+                                           _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32), n_c,
+                                           _ptr(c_dev, _f32), mp, mi, mb, item_offset, K, _ptr(vals), _ptr(idx),
+                                           _ptr(ws), ws.numel(), _stream()))
+    return vals, idx
+
+
 def score_matrix(kind, users_tab, user_ids, items, sig_u=None, sig_i=None, c=0.0):
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
     n_local, d = items.shape

@@ -197,9 +197,10 @@ def main(sweep=False):
                 print('Epoch %d' % epoch)
             best_hr = 0
             c_values = np.linspace(args.start, args.end, args.step) if sweep else [args.c]
-            for c in c_values:
+            rets = test_sweep(sess, model, users_to_test, c_values, method=args.test) if sweep else None
+            for k, c in enumerate(c_values):
                 model.update_c(sess, c)
-                ret = test(sess, model, users_to_test, method=args.test)
+                ret = rets[k] if sweep else test(sess, model, users_to_test, method=args.test)
                 if ret['hr'][0] > best_hr:
                     best_hr = ret['hr'][0]
                 if args.verbose > 0:

@@ -47,3 +47,21 @@ def test(sess, model, users_to_test, drop_flag=False, train_set_flag=0, method="
                               model.rubi_c)
     # the reference indexes the result with the ORIGINAL order of Ks after sorting columns (:153-161)
     return {k: np.asarray(v) for k, v in ret.items()}
+
+
+def test_sweep(sess, model, users_to_test, cs, method="rubiboth"):
+    """test() for every c of `cs` (the loop of LightGCN_tune.py:852-870) -> list of result dicts; the values share the
+    listing pass in groups of four (macr_score_topk_sweep)."""
+    if _METHODS.get(method, ops.SCORE_NORMAL) == ops.SCORE_NORMAL:
+        raise NotImplementedError("method %r has no c to sweep" % method)
+    key = hash(tuple(users_to_test))
+    if key not in _evaluators:
+        if len(_evaluators) >= _MAX_CACHED:
+            _evaluators.clear()
+        mask, gt = data_generator.eval_lists(users_to_test)
+        _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
+                            torch.tensor(list(users_to_test), dtype=torch.int32, device=model.device))
+    evaluator, uid = _evaluators[key]
+    ua, ia = model.propagated()
+    rets = evaluator.test_lgcn_sweep(_METHODS[method], ua, uid, ia.contiguous(), model.Ks, model.w, model.w_user, list(cs))
+    return [{k: np.asarray(v) for k, v in r.items()} for r in rets]

@@ -57,6 +57,24 @@ def test(sess, model, test_users, batch_test_flag=False, model_type='o', valid_s
                              model.w, model.w_user, model.rubi_c)
 
 
+def test_sweep(sess, model, test_users, cs, model_type='rubi_both', valid_set="test"):
+    """test() for every c of `cs` (the loop of macr_mf/tune.py:545-578) -> list of result dicts, one per c.  c only
+    enters the score epilogue, so the values share the listing pass in groups of four (macr_score_topk_sweep)."""
+    if model_type not in _MODEL_TYPES or _MODEL_TYPES[model_type] == ops.SCORE_NORMAL:
+        raise NotImplementedError("model_type %r has no c to sweep" % model_type)
+    key = (valid_set, hash(tuple(test_users)))
+    if key not in _evaluators:                       # build (and cache) the evaluator exactly as test() does
+        if len(_evaluators) >= _MAX_CACHED:
+            _evaluators.clear()
+        mask, gt = data.eval_lists(test_users, valid_set)
+        _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
+                            torch.tensor(list(test_users), dtype=torch.int32, device=model.device))
+    evaluator, uid = _evaluators[key]
+    model.sync()
+    return evaluator.test_mf_sweep(_MODEL_TYPES[model_type], model.user_embedding, uid, model.item_embedding, Ks,
+                                   model.w, model.w_user, list(cs))
+
+
 def early_stop(hr, ndcg, recall, precision, cur_epoch, config, stopping_step, flag_step=10):
     """Patience-10 early stopping on HR with `>=` (macr_mf/train.py:313-330)."""
     if hr >= config['best_hr']:
@@ -214,9 +232,11 @@ def main(sweep=False):
                 raise NotImplementedError("--test rubi needs a branch loss (--train rubibceboth | rubibce)")
             c_values = np.linspace(args.start, args.end, args.step) if sweep else [args.c]
             best = (0, 0, 0, 0, 0.0)               # train.py:540-544: bests start at 0
-            for c in c_values:                      # tune.py:545-578: the best c of the sweep drives early stopping
+            # tune.py:545-578: one test() per c; here the values of a sweep share the listing pass in groups of four
+            rets = test_sweep(sess, model, users_to_test, c_values, model_type=rubi_type, valid_set=args.valid_set) if sweep else None
+            for k, c in enumerate(c_values):        # the best c of the sweep drives early stopping
                 model.update_c(sess, c)
-                ret = test(sess, model, users_to_test, model_type=rubi_type, valid_set=args.valid_set)
+                ret = rets[k] if sweep else test(sess, model, users_to_test, model_type=rubi_type, valid_set=args.valid_set)
                 report('c:%.2f [%.1fs + %.1fs]: ' % (c, t2 - t1, time() - t2), ret)
                 if ret['hit_ratio'][0] > best[0]:
                     best = (ret['hit_ratio'][0], ret['recall'][0], ret['precision'][0], ret['ndcg'][0], c)

@@ -452,3 +452,62 @@ def test_injected_weights_round_trip(ops):
     x = m2.user_embedding.cpu().numpy()
     assert np.abs(x).max() <= L and np.abs(x).max() > 0.9 * L
     assert np.abs(m2.w.cpu().numpy()).max() <= np.sqrt(6.0 / (d + 1))
+
+
+@pytest.mark.parametrize("kind_name", ["SCORE_RUBI_BOTH", "SCORE_RUBI", "SCORE_DIRECT_MINUS_BOTH"])
+def test_shared_listing_pass_sweep_equals_single_c(ops, kind_name):
+    """f1: macr_score_topk_sweep ranks up to four values of c with ONE listing pass; every value must give exactly the
+    lists macr_score_topk gives for that c (ids and score bits), and Evaluator.test_mf_sweep the metrics of separate
+    test_mf calls -- 7 values: a group of four and a group of three."""
+    from macr_amd.evaluator import Evaluator
+    kind = getattr(ops, kind_name)
+    rs = np.random.RandomState(9)
+    d, n_users, n_items, U, K = 64, 3000, 5000, 1100, 20
+    P = dev((rs.standard_normal((n_users, d)) * 0.4).astype(np.float32))
+    Q = dev((rs.standard_normal((n_items, d)) * 0.4).astype(np.float32))
+    w, wu = dev((rs.standard_normal(d) * 0.3).astype(np.float32)), dev((rs.standard_normal(d) * 0.3).astype(np.float32))
+    users = np.sort(rs.choice(n_users, U, replace=False)).astype(np.int32)
+    mask = [sorted(rs.choice(n_items, 25, replace=False).tolist()) for _ in range(U)]
+    gt = [sorted(rs.choice(n_items, 5, replace=False).tolist()) for _ in range(U)]
+    uid = dev(users)
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    sig_i = ops.branch_sigmoid(Q, w)
+    sig_u = ops.branch_sigmoid(P, wu, uid)
+    cs = [-3.0, 0.0, 12.5, 40.0]
+    sv, si = ops.score_topk_sweep(kind, P, uid, Q, K, sig_u, sig_i, dev(np.asarray(cs, np.float32)), mcsr, 0)
+    for g, c in enumerate(cs):
+        v1, i1 = ops.score_topk(kind, P, uid, Q, K, sig_u, sig_i, c, mcsr, 0)
+        mv, mi, _ = ops.topk_merge(v1, i1)
+        assert torch.equal(si[g], mi), (kind_name, c)
+        assert torch.equal(sv[g].view(torch.int32), mv.view(torch.int32)), (kind_name, c)
+    ev = Evaluator(mask, gt, n_items, torch.device("cuda"))
+    cs7 = list(np.linspace(-5.0, 40.0, 7))
+    for rep in range(2):                                   # second round: graph replays
+        got = ev.test_mf_sweep(kind, P, uid, Q, [5, 20], w, wu, cs7)
+    for c, res in zip(cs7, got):
+        fresh = Evaluator(mask, gt, n_items, torch.device("cuda"))
+        fresh.use_graph = False
+        want = fresh.test_mf(kind, P, uid, Q, [5, 20], w, wu, float(c))
+        for k in want:
+            assert np.array_equal(res[k], want[k]), (kind_name, c, k)
+
+
+def test_lightgcn_tune_cli(tmp_path):
+    """LightGCN_tune.py (LightGCN_tune.py:852-870): the c values of a sweep share the listing pass; every line of the
+    sweep must equal what LightGCN.py --pretrain 1 reports for that c on the saved weights."""
+    common = ["--data_path", os.path.join(REPO, "data") + "/", "--dataset", "addressa", "--verbose", "1", "--layer_size",
+              "[64,64]", "--Ks", "[20]", "--lr", "0.001", "--batch_size", "1024", "--gpu_id", "0", "--log_interval", "2",
+              "--alpha", "1e-2", "--beta", "1e-3", "--weights_path", str(tmp_path) + "/", "--saveID", "s", "--loss", "bceboth",
+              "--test", "rubiboth"]
+    out = _run_cli([os.path.join(REPO, "macr_lightgcn", "LightGCN_tune.py")] + common + ["--epoch", "2", "--start", "0", "--end",
+                   "40", "--step", "5"], str(tmp_path))
+    lines = [l for l in out.splitlines() if l.startswith("c:")]
+    assert [l.split()[0] for l in lines] == ["c:0.00", "c:10.00", "c:20.00", "c:30.00", "c:40.00"], out
+    out2 = _run_cli([os.path.join(REPO, "macr_lightgcn", "LightGCN.py")] + common + ["--pretrain", "1", "--c", "40"], str(tmp_path))
+    # --pretrain prints full-precision arrays; compare hit@20 of c=0 and c=40 with the sweep's lines at 5 digits
+    def hit_of(line):
+        return float(line.split("hit=[")[1].split(",")[0].rstrip("]"))
+    pre = {l.split(":")[1]: l for l in out2.splitlines() if l.startswith("c:")}
+    for c_key, sweep_line in (("0", lines[0]), ("40.0", lines[-1])):
+        hr = float(pre[c_key].split("hit=[")[1].split("]")[0].split()[0])
+        assert abs(hr - hit_of(sweep_line)) < 6e-6, (pre[c_key], sweep_line)
