@@ -52,6 +52,16 @@ __device__ __host__ inline PlanView view_plan(const void *plan, const PlanHeader
     return v;
 }
 
+// Sum of val[e] * X[col[e]] over e in [beg, end) for one row (or one 512-nnz slice of a hub row), by one wave: the
+// 64/LPR lane groups take neighbours grp, grp+NG, ... (each group in ascending order: the summation tree is fixed).
+// The wave first fetches the indices and values of up to 64 neighbours with ONE coalesced load each (lane l <- entry
+// beg+l) and hands them to the groups by shuffles, then keeps FOUR row gathers in flight per group.  The first
+// version loaded col/val per group (16 lanes reading the same word, a dependent trip in front of every pair of row
+// gathers) and kept two gathers in flight: a wave with the average 39 neighbours needed ~10 dependent trips.
+// Measured on Yelp2018 shapes (tools/bench_lgcn.py): 75 -> 56.5 us per layer, LightGCN step 376 -> 305 us.  Depth 2: 59 us,
+// 8: 67 us, 16: 96 us (padding entries of the last round gather too); guarding the padded gathers with a wave-uniform
+// test costs more than it saves (70 us: the guards become branches with their own waits).
+#ifdef MACR_ABL_SPMM_V1
 template <int LPR>
 __device__ __forceinline__ float4 gather_range(const int32_t *__restrict__ col, const float *__restrict__ val,
                                                const float *__restrict__ X, int beg, int end, int sub, int grp) {
@@ -75,6 +85,48 @@ __device__ __forceinline__ float4 gather_range(const int32_t *__restrict__ col, 
     }
     return acc;
 }
+#else
+template <int LPR>
+__device__ __forceinline__ float4 gather_range(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                               const float *__restrict__ X, int beg, int end, int sub, int grp) {
+    constexpr int d = 4 * LPR;
+    constexpr int NG = kWave / LPR;                 // neighbour groups per wave
+    constexpr int PER = kWave / NG;                 // neighbours per group in a 64-entry chunk (= LPR)
+#ifndef MACR_SPMM_DEPTH
+#define MACR_SPMM_DEPTH 4
+#endif
+    constexpr int DEPTH = MACR_SPMM_DEPTH < PER ? MACR_SPMM_DEPTH : PER;      // row gathers in flight per group
+    const int lane = threadIdx.x & 63;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = beg; base < end; base += kWave) {           // wave-uniform
+        const int n = end - base < kWave ? end - base : kWave;  // entries of this chunk
+        const int ec = base + (lane < n ? lane : n - 1);
+        const int cv = col[ec];
+        const float av = lane < n ? val[ec] : 0.f;              // padding entries add 0 * X[valid row]
+        // group grp takes entries grp, grp+NG, ... of the chunk; rounds of DEPTH gathers in flight
+#pragma unroll
+        for (int k0 = 0; k0 < PER; k0 += DEPTH) {
+            if (k0 * NG >= n) break;                            // wave-uniform: nothing left in this chunk
+            int c[DEPTH]; float a[DEPTH]; float4 x[DEPTH];
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                const int src = (k0 + k) * NG + grp;            // < 64: PER is a multiple of DEPTH
+                c[k] = __shfl(cv, src, kWave); a[k] = __shfl(av, src, kWave);
+            }
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) x[k] = ld4(X + (size_t)c[k] * d + 4 * sub);
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) acc = fma4(a[k], x[k], acc);
+        }
+    }
+#pragma unroll
+    for (int m = LPR; m < kWave; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
+        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
+    }
+    return acc;
+}
+#endif
 
 template <int LPR>
 __device__ __forceinline__ void write_row(int r, int sub, float4 acc, float *Y, const float *S_in, float *S_out, float scale) {
