@@ -993,25 +993,40 @@ __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const 
                                                      const int32_t *__restrict__ i, const int32_t *__restrict__ j,
                                                      const float *__restrict__ T, float *G, float coef,
                                                      float *__restrict__ part) {
+    // u, i, j: the batch grouped by positive item when the caller has it (batch_bucket_block): a block owns kChunkT
+    // consecutive slots and adds equal positive rows of its chunk once (combine_positive_rows) -- the hot item of a
+    // batch is referenced hundreds of times, and that many atomics on one row serialise (19.6 -> see DESIGN.md)
     constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float red[16];
+    __shared__ float s_gi[kChunkT][D];
+    __shared__ int s_pos[kChunkT];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bool act = lane < WaveRow<D>::kActive;
     float sq = 0.f;
-    for (int t = blockIdx.x * 4 + wid; t < B; t += gridDim.x * 4) {
-        const int rows[3] = {u[t], i[t] + item_off, j[t] + item_off};
-        if (act) {
+    for (int chunk = blockIdx.x; chunk * kChunkT < B; chunk += gridDim.x) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < kChunkT / 4; ++q) {
+            const int slot = wid * (kChunkT / 4) + q, t = chunk * kChunkT + slot;
+            if (t >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
+            const int ru = u[t], ri = i[t] + item_off, rj = j[t] + item_off;
+            if (act) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     const int k = lane + 64 * e;
-                    const float x = T[(size_t)rows[q] * D + k];
-                    sq = fmaf(x, x, sq);
-                    if (G) MACR_ATOMIC_ADD(G + (size_t)rows[q] * D + k, coef * x);
+                    const float xu = T[(size_t)ru * D + k], xi = T[(size_t)ri * D + k], xj = T[(size_t)rj * D + k];
+                    sq = fmaf(xu, xu, fmaf(xi, xi, fmaf(xj, xj, sq)));
+                    if (G) {
+                        MACR_ATOMIC_ADD(G + (size_t)ru * D + k, coef * xu);
+                        MACR_ATOMIC_ADD(G + (size_t)rj * D + k, coef * xj);
+                        s_gi[slot][k] = coef * xi;
+                    }
                 }
             }
+            if (lane == 0) s_pos[slot] = ri;
         }
+        __syncthreads();
+        if (G) combine_positive_rows<D>(s_pos, s_gi, G);
+        __syncthreads();
     }
     const float s0 = block_sum(sq, red);
     if (threadIdx.x == 0) part[(size_t)blockIdx.x * kPartStride] = s0;    // slot 0 only
@@ -1631,7 +1646,9 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
     if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st)) return e;
     // l2 regulariser on the ego rows (LightGCN.py:525-528)
-    MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, u, i, j, T, ws.G, coef,
+    // (the batch grouped by positive item, as the pair launch left it in the workspace, when there is one)
+    const int32_t *gu = ws.pair.staged ? u : ws.pair.us, *gi = ws.pair.staged ? i : ws.pair.is, *gj = ws.pair.staged ? j : ws.pair.js;
+    MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, gu, gi, gj, T, ws.G, coef,
                                                                                ws.pair.part2)));
     MACR_CHECK_LAUNCH("reg_scatter", st);
     AdamArgs a;
