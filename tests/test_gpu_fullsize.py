@@ -223,3 +223,46 @@ def test_config4_shard_eval(ops):
     gv = torch.stack([p[0] for p in parts]); gi = torch.stack([p[1] for p in parts])
     m2 = ops.topk_merge(gv, gi)
     assert torch.equal(m2[1], idx) and torch.equal(m2[0], val)
+
+
+def test_config4_shard_size_training_step(ops):
+    """configs[4] training at ONE rank's size: 1 250 000 user rows + 125 000 item rows, d = 128 (what a rank of 8 holds
+    of the 10 M x 1 M tables), B = 8192, through the row-shard entry points (macr_shard_*: gather, forward, (B,B) row
+    blocks, backward into the staging buffer, radix sort of the references, segment reduce, dense Adam over the
+    shard) -- two steps against the oracle: losses 1e-5, the gradient (first-step m) and the updated rows the batch
+    touched, plus untouched rows (dense Adam moves every row: bitwise equal to a zero-gradient step of the oracle)."""
+    from macr_amd import sharded_train
+    n_users, n_items, d, B = 1_250_000, 125_000, 128, 8192
+    rs = np.random.RandomState(8)
+    P = (rs.standard_normal((n_users, d)) * 0.05).astype(np.float32)
+    Q = (rs.standard_normal((n_items, d)) * 0.05).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.2).astype(np.float32), (rs.standard_normal(d) * 0.2).astype(np.float32)
+    lr, decay, alpha, beta = 1e-3, 1e-5, 1e-3, 1e-3
+    hyper = ops.make_hyper(lr, decay, alpha, beta, B)
+    kind = ops.LOSS_RUBIBCEBOTH
+    model = sharded_train.RowShardedMF(dev(P), dev(Q), dev(w), dev(wu),
+                                       sharded_train.HipBackend(kind, d, hyper, torch.device("cuda")), rank=0, world=1)
+    st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
+    Po, Qo, wo, wuo = P, Q, w.copy(), wu.copy()                    # the oracle updates in place
+    touched_u, touched_i = set(), set()
+    for t in range(2):
+        u = rs.choice(n_users, B, replace=False).astype(np.int32)
+        i = (rs.zipf(1.2, B) % n_items).astype(np.int32)            # Zipf positives: hot rows in the segment reduce
+        j = rs.randint(0, n_items, B).astype(np.int32)
+        touched_u.update(u.tolist()); touched_i.update(i.tolist()); touched_i.update(j.tolist())
+        want = oracle.mf_train_step(oracle.LOSS_RUBIBCEBOTH, u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, B)
+        got = model.step(dev(u), dev(i), dev(j)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, err_msg="step %d" % t)
+    ru = np.fromiter(touched_u, np.int64)[:4000]
+    ri = np.fromiter(touched_i, np.int64)[:4000]
+    tol = 2e-3 * lr * 2
+    np.testing.assert_allclose(model.P[torch.from_numpy(ru).cuda()].cpu().numpy(), Po[ru], rtol=0, atol=tol)
+    np.testing.assert_allclose(model.Q[torch.from_numpy(ri).cuda()].cpu().numpy(), Qo[ri], rtol=0, atol=tol)
+    np.testing.assert_allclose(model.mQ[torch.from_numpy(ri).cuda()].cpu().numpy(), st.m[1][ri], rtol=1e-3,
+                               atol=2e-6 * np.abs(st.m[1][ri]).max())
+    # rows no batch touched: m = v = 0, theta unchanged by a zero-gradient Adam step -- on both sides, bit for bit
+    free = np.setdiff1d(np.arange(0, n_users, 997), np.fromiter(touched_u, np.int64))
+    assert np.array_equal(model.P[torch.from_numpy(free).cuda()].cpu().numpy(), Po[free])
+    assert float(model.mP[torch.from_numpy(free).cuda()].abs().max()) == 0.0
+    np.testing.assert_allclose(model.w.cpu().numpy(), wo, rtol=0, atol=tol)
+    assert int(model.tP.sum()) == 0 and int(model.tQ.sum()) == 0
