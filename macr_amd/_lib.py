@@ -76,9 +76,18 @@ SIGNATURES = {
 _lib = None
 
 
+def _load_hip_runtime_first():
+    """PyTorch-ROCm ships its own libamdhip64 and must be the one that brings the HIP runtime into the process: if this
+    library is loaded first it pulls in /opt/rocm's copy, torch then loads its bundled one, and kernels launched from
+    here fail with "no ROCm-capable device is detected" (two runtimes in one process; seen when build() and smoke()
+    run in the same interpreter).  Importing torch first makes the dynamic loader reuse the runtime torch loaded."""
+    import torch  # noqa: F401
+
+
 def lib():
     global _lib
     if _lib is None:
+        _load_hip_runtime_first()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "macr_amd: HIP extension %s is missing.  Build it with "
@@ -115,6 +124,7 @@ _compat = None
 def compat_lib():
     global _compat
     if _compat is None:
+        _load_hip_runtime_first()
         if not os.path.exists(COMPAT_LIB_PATH):
             raise RuntimeError("macr_amd: %s is missing; build it with `python -m macr_amd.build`" % COMPAT_LIB_PATH)
         L = ctypes.CDLL(COMPAT_LIB_PATH)
