@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     6
+#define MACR_ABI_VERSION     7
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -56,6 +56,7 @@ extern "C" {
 
 /* largest K the top-K kernels are built for (the reference uses 20; parser default max 30) */
 #define MACR_MAX_TOPK 32
+#define MACR_SEED_WIDTH 32       /* threshold seeds per query of macr_score_topk (seed_idx / seed_out) */
 
 int         macr_abi_version(void);
 const char *macr_last_error(void);          /* thread-local, valid until the next call     */
@@ -287,6 +288,18 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  *              balances its own grid over (query block, item tile) ranges; the merged
  *              result of the whole shard is list 0, further lists hold only padding.
  *              (n_splits > 1 still shapes the grid of the fallback kernel, below.)
+ *   seed_idx  (dev, may be NULL) int32[U*MACR_SEED_WIDTH]: per query, GLOBAL ids of items that ranked high for it before --
+ *              what seed_out held after the previous call for the same queries (an evaluator ranks the same users against
+ *              slowly moving tables every epoch).  When given, the per-query threshold is the K-th largest EXACT current
+ *              score of its seeds (a valid lower bound of the K-th best score for any set of distinct unmasked items; the
+ *              result does not depend on the seeds, only the time does) and the sampling pass and its selection kernel are
+ *              skipped.  Seeds are checked on the device: an id that is -1, outside this shard, masked or repeated does
+ *              not count, and a query left with fewer than K seeds lists every unmasked item.  Seeds from a ranking the
+ *              tables have moved far away from cost a repair round (below), never a wrong result.
+ *   seed_out  (dev, may be NULL, may be seed_idx itself) int32[U*MACR_SEED_WIDTH] <- the best MACR_SEED_WIDTH candidates the
+ *              selection saw per query, best first, -1 padded (the first K of them are out_idx): the next call's seed_idx.
+ *   stats     (dev, may be NULL) int32[2], written by the call: [0] blocks of 256 queries the repair round listed again,
+ *              [1] 1 if the exact fallback kernel ran.  A caller that seeds uses [0] to tell stale seeds from good ones.
  *   out_val (dev) fp32 [n_splits*U*K], out_idx (dev) int32 [n_splits*U*K]:
  *              per list, per query: K (score,id) pairs, score descending, ties
  *              by ascending id, unused slots (-inf, -1).  Feed to macr_topk_merge
@@ -301,20 +314,28 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  * product being a k-ascending fp32 fma chain (gfx950 fp32 MFMA arithmetic).
  * sig_i is needed by every kind but NORMAL, sig_u by RUBI_BOTH and DIRECT_MINUS_BOTH.
  * d in {32,64,128,256}; 1 <= K <= MACR_MAX_TOPK.
- * Launches: a sampling pass over every 8th item tile (per-query lower bound tau of
+ * Launches (without seeds): a sampling pass over every 8th item tile (per-query lower bound tau of
  * the K-th best score), the listing pass over all tiles (items scoring >= tau go to
- * per-query candidate lists), a selection kernel (exact top K of each list), and a
- * fallback launch of the running-top-K kernel whose blocks return at once unless a
- * candidate list overflowed (exact for any input).  No host synchronisation.
+ * per-query candidate lists), a selection kernel (exact top K of each list); then the
+ * REPAIR round for queries whose list overflowed (threshold too loose): their K-th listed
+ * score becomes their threshold and the listing pass + selection run again for the blocks
+ * of 128 queries that hold them (three launches that return at once when nothing
+ * overflowed); and a fallback launch of the running-top-K kernel whose blocks return at
+ * once unless a list overflowed again (exact for any input).  With seeds: one kernel
+ * (k_tau_seed) instead of the sampling pass and its selection, and a listing pass that gives a
+ * block of queries up to the repair round as soon as its lists grow faster than a usable
+ * threshold allows (stale seeds).  No host synchronisation.
  * -------------------------------------------------------------------------*/
 int    macr_score_topk_splits(int U, int n_local, int d);
+int    macr_score_topk_uses_seeds(int U, int n_local, int d);   /* 0: this shape lists every unmasked item, seed_idx is ignored */
 size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
 
 int macr_score_topk(int score_kind, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
                     const float *sig_u, const float *sig_i, float c, const float *c_dev,
                     const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
-                    int item_offset, int K, int n_splits, float *out_val, int32_t *out_idx,
+                    int item_offset, int K, int n_splits, const int32_t *seed_idx, int32_t *seed_out,
+                    float *out_val, int32_t *out_idx, int32_t *stats,
                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------

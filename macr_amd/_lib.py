@@ -16,7 +16,7 @@ STEP_DEFER, STEP_PENDING, STEP_LOSS_ONLY = 1, 2, 4
 SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINUS_BOTH = 0, 1, 2, 3, 4
 MAX_TOPK = 32
 MAX_SWEEP = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MacrError(RuntimeError):
@@ -59,8 +59,9 @@ SIGNATURES = {
     "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 2 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _i, _p, _z, _p]),
     "macr_branch_sigmoid": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "macr_score_topk_splits": (_i, [_i, _i, _i]),
+    "macr_score_topk_uses_seeds": (_i, [_i, _i, _i]),
     "macr_score_topk_workspace_bytes": (_z, [_i, _i, _i]),
-    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "macr_score_topk_sweep_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "macr_score_topk_sweep": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _z, _p]),
     "macr_mask_bits_bytes": (_z, [_i, _i]),

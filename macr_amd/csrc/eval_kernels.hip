@@ -36,6 +36,7 @@ constexpr int kUnitK = 64;        // k-extent staged in LDS at a time
 constexpr int kUnitStride = kUnitK + 1;   // odd stride: conflict-free fragment reads
 constexpr int kWavesPerBlock = 8;
 constexpr int kUsersPerBlock = 32 * kWavesPerBlock;
+constexpr int kSelRegs = 16;                       // k_select ranks up to 64*kSelRegs = 1024 candidates per user (more: repair round)
 
 // Wave-cooperative compaction of one user's candidate buffer (<= 64 keys, one per lane): keep the
 // best K, publish the new count and the admission threshold (K-th best score, or -inf while fewer
@@ -115,7 +116,9 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     const float *__restrict__ c_dev,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_idx, int item_offset, int K,
     int n_splits, float *__restrict__ out_val, int32_t *__restrict__ out_idx, uint32_t *shared_thr,
-    const int32_t *run_flag) {
+    const int32_t *run_flag, int32_t *stats) {
+    // run_flag[0]: a candidate list overflowed twice (this kernel must run); run_flag[1]: user blocks the repair round re-listed
+    if (stats && run_flag && blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = run_flag[1]; stats[1] = run_flag[0]; }
     if (run_flag && *run_flag == 0) return;             // fallback launch: only when a candidate list overflowed
     const float c = c_dev ? *c_dev : c_val;             // device-resident c: one captured graph serves a whole c sweep
     constexpr int NKH = D / kUnitK > 0 ? D / kUnitK : 1;     // k-halves per tile (D=32 -> 1 short unit)
@@ -490,15 +493,24 @@ struct SweepArgs {
     int32_t *overflow[kMaxSweep];             // one flag per c
 };
 
-template <int D, int KIND, int MODE, int NC = 1>
+template <int D, int KIND, int MODE, int NC = 1, bool REPAIR = false>
 __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     int U, int n_local, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
     const float *__restrict__ items, const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val,
     const float *__restrict__ c_dev,
     const uint32_t *__restrict__ mask_bits, int item_offset,
     int ublocks, const float *__restrict__ tau, float *__restrict__ maxima, uint64_t *__restrict__ lists,
-    int32_t *__restrict__ counts, int cap, int32_t *overflow, int sample_log2, SweepArgs sw) {
+    int32_t *__restrict__ counts, int cap, int32_t *overflow, int ovf_per_user, int sample_log2,
+    const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev, int32_t *blk_flag, SweepArgs sw) {
     using C = StreamCfg<D>;
+    // Seeded first round (blk_flag != NULL): "these seeds are stale" is decided early.  2, 8 and 32 tiles into a user
+    // block's range every wave compares what its 32 users have listed with what a usable threshold lists (a projected
+    // kSelRegs*64 candidates per user over the shard is the most k_select can rank); one wave over that and the block
+    // stops listing and marks the user block in blk_flag, its sibling blocks (same user block, other tile ranges) see
+    // the mark within 8 tiles and stop too, and the repair round (sampling pass, k_tau, listing, selection) takes the
+    // user block over: stale seeds waste ~6 % of a listing pass instead of all of it.
+    constexpr bool kEarlyStop = MODE == kModeList && NC == 1 && !REPAIR;
+    constexpr int kCheckTiles = 8;
     static_assert(NC == 1 || MODE == kModeList, "the sweep shares the listing pass only");
     const float c = c_dev ? *c_dev : c_val;
     constexpr int RS = C::RS, NT = C::NT;
@@ -518,16 +530,30 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     // block and begin the next ("segments"); the k-th block overlapping a user block writes that block's
     // result slot k (lists / counts / maxima are [slot][user]).
     const int T = (tiles_total + kStep - 1) / kStep;                    // visited tiles per user block
-    const long long W = (long long)ublocks * T, G = gridDim.x, b = blockIdx.x;
+    // Repair round (ub_map != NULL): only the *n_ub_dev user blocks of ub_map are listed again, by as many blocks of the
+    // grid as keep a block's tile range at least as long as in the full launch (so a user block never spans more
+    // result slots than the workspace has); the others leave at once.
+    int n_ub = ublocks;
+    long long G = gridDim.x;
+    const long long b = blockIdx.x;
+    if (REPAIR) {                                  // (an instantiation of its own: the profiler tells the rounds apart)
+        n_ub = *n_ub_dev;
+        if (n_ub == 0) return;
+        G = (long long)n_ub * G / ublocks;
+        if (G < 1) G = 1;
+        if (b >= G) return;
+    }
+    const long long W = (long long)n_ub * T;
     const long long w_end = W * (b + 1) / G;
     for (long long w = W * b / G; w < w_end;) {
-    const int ub = (int)(w / T), i0 = (int)(w - (long long)ub * T);
+    const int ubv = (int)(w / T), i0 = (int)(w - (long long)ubv * T);
     const int i1 = (int)min((long long)T, i0 + (w_end - w));
     w += i1 - i0;
-    long long first = (long long)ub * T * G / W;                        // the block holding this user block's first tile
-    while (W * (first + 1) / G <= (long long)ub * T) ++first;
-    while (W * first / G > (long long)ub * T) --first;
+    long long first = (long long)ubv * T * G / W;                       // the block holding this user block's first tile
+    while (W * (first + 1) / G <= (long long)ubv * T) ++first;
+    while (W * first / G > (long long)ubv * T) --first;
     const int split = (int)(b - first);
+    const int ub = REPAIR ? ub_map[ubv] : ubv;
     const int t_hi = min(i1 * kStep, tiles_total);
     const int q = ub * kUsersPerBlock + uslot;
     const bool q_ok = q < U;
@@ -536,6 +562,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 #pragma unroll
         for (int g = 0; g < NC; ++g) s_cnt[g * kUsersPerBlock + tid] = 0u;
     }
+    const int t_first = i0 * kStep;
     float bfrag[NT];
     {
         const float *urow = users_tab + (size_t)(q_ok ? (user_ids ? user_ids[q] : q) : 0) * D;
@@ -548,7 +575,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     }
     const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
     // listing test: score >= tau_s (NaN = never: padding users, poisoned scores)
-    const float tau_s = (MODE == kModeList && NC == 1 && q_ok) ? tau[q] : __builtin_nanf("");
+    float tau_s = (MODE == kModeList && NC == 1 && q_ok) ? tau[q] : __builtin_nanf("");       // +inf once her list is full
     uint64_t *my_list = lists + ((size_t)split * U + (q_ok ? q : 0)) * cap;
     float tau_g[NC], c_g[NC];                 // sweep: per-c threshold and constant (NC > 1)
     if (NC > 1) {
@@ -699,11 +726,38 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
                 if (v[r] >= tau_s) {
                     const uint32_t pos = atomicAdd(&s_cnt[uslot], 1u);
                     if (pos < (uint32_t)cap) my_list[pos] = make_key(v[r], gid0 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    else *overflow = 1;
+                    else { overflow[ovf_per_user ? q : 0] = 1; tau_s = INFINITY; }     // full: stop listing for her
                 }
             }
         }
 #endif
+        bool stop = false;                                   // block-uniform
+        if (kEarlyStop && blk_flag) {
+            const int done = t - t_first + 1;                // tiles of this range processed
+#ifdef MACR_ABL_STOPNOW
+            const bool check = done == MACR_ABL_STOPNOW;
+#else
+            const bool check = done == 2 || done == kCheckTiles || done == 4 * kCheckTiles;
+#endif
+            if (check || (done & 7) == 0) {
+                bool mine = false;
+                if (check) {
+                    uint32_t a = h == 0 ? s_cnt[uslot] : 0u; // appended so far by this wave's 32 users
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, kWave);
+                    const float usable = 32.f * (float)(done * kTileItems) * (float)(kSelRegs * 64) / (float)n_local;
+                    mine = (float)a > usable + 64.f;
+#if defined(MACR_ABL_STOPNOW) && !defined(MACR_ABL_STOPCRIT)
+                    mine = true;
+#endif
+                } else if (tid == 0) {                       // a sibling block (same users, other tiles) gave up
+                    mine = __hip_atomic_load(blk_flag + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                }
+                stop = __syncthreads_or(mine) != 0;          // (a barrier of its own: every wave gets the same answer)
+                // agent-scope store: the sibling blocks run on other XCDs, whose L2 a plain store would not reach before the kernel ends
+                if (stop && tid == 0) __hip_atomic_store(blk_flag + ub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
 #ifndef MACR_ABL_S_NOSTAGE
         if (has_next) store_tile(buf ^ 1);
         __syncthreads();
@@ -711,6 +765,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
         tm_cur = tm_next;
         buf ^= 1;
         t = tn;
+        if (kEarlyStop && stop) break;
     }
     if (MODE == kModeMax) {
         if (q_ok) {
@@ -734,6 +789,72 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 }
 
 // ----------------------------------------------------------------------------
+// k_tau_seed: thresholds from SEED items instead of a sampling pass.  Any K distinct unmasked items of a user give a
+// valid lower bound of her K-th best score: the smallest of their K scores.  An evaluator ranks the same users against
+// slowly moving tables epoch after epoch, so the best items of the PREVIOUS evaluation are nearly the best now.  A
+// user has kSeedWidth = 32 seeds (the top 32 candidates k_select saw last time, more than K so that some of them may
+// have dropped out of the top since): tau = the K-th largest of their exact current scores -- 32 dot products per
+// user, one lane each, instead of the sampling pass and k_tau (112 + 27 us on the Gowalla shape), with a threshold
+// at rank ~K instead of ~8K (shorter candidate lists, cheaper selection).
+// Exactness: the dot product is the k-ascending fmaf chain of the MFMA kernels and the epilogue the same function, so
+// a seed item's score here is bit-identical to its score in the listing pass and passes `score >= tau`.
+// Seeds are checked, not trusted: an id that is -1 / outside this shard / masked / a repetition of an earlier lane's
+// id / scores NaN does not count; a user with fewer than K good seeds gets tau = -inf (everything unmasked is listed:
+// fewer than K items for users who never had K candidates, the repair round for anyone else).
+// One 32-lane half per user, lane l = seed l.
+// ----------------------------------------------------------------------------
+constexpr int kSeedWidth = MACR_SEED_WIDTH;
+static_assert(kSeedWidth == 32, "one 32-lane half per user");
+template <int D, int KIND>
+__global__ __launch_bounds__(256) void k_tau_seed(int U, int n_local, const float *__restrict__ users_tab,
+                                                  const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                                  const float *__restrict__ sig_u, const float *__restrict__ sig_i,
+                                                  float c_val, const float *__restrict__ c_dev,
+                                                  const uint32_t *__restrict__ mask_bits, int item_offset, int K,
+                                                  const int32_t *__restrict__ seed, float *__restrict__ tau) {
+    const float c = c_dev ? *c_dev : c_val;
+    const int q = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (q >= U) return;                                   // whole 32-lane halves leave together
+    const int it = seed[(size_t)q * kSeedWidth + l] - item_offset;
+    bool ok = it >= 0 && it < n_local;
+    if (ok && mask_bits) ok = ((mask_bits[(size_t)(it >> 5) * U + q] >> (it & 31)) & 1u) == 0u;    // a masked item is no candidate
+    float v = -INFINITY;
+    if (ok) {
+        const float *ur = users_tab + (size_t)(user_ids ? user_ids[q] : q) * D, *ir = items + (size_t)it * D;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k4 = 0; k4 < D / 4; ++k4) {
+            const float4 a = ld4(ur + 4 * k4), b = ld4(ir + 4 * k4);
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        }
+        v = acc;
+        if (score_uses_sig_i(KIND)) v = score_epilogue<KIND>(v, c, sig_i[it], score_uses_sig_u(KIND) ? sig_u[q] : 1.0f);
+        ok = v == v;                                      // NaN: no bound from this seed
+    }
+    // rotation inside the half: drop repetitions of an earlier lane's id, then rank the good seeds by score
+    const int half = threadIdx.x & 32;
+#pragma unroll
+    for (int m = 1; m < 32; ++m) {
+        const int o = (l + m) & 31;
+        const int oit = __shfl(it, half | o, kWave);
+        const bool ook = __shfl((int)ok, half | o, kWave) != 0;     // the other's state BEFORE this loop drops anything:
+        if (ook && oit == it && o < l) ok = false;                   // of equal ids the lowest lane survives (it never drops)
+    }
+    int rank = 0;
+#pragma unroll
+    for (int m = 1; m < 32; ++m) {
+        const int o = (l + m) & 31;
+        const float ov = __shfl(v, half | o, kWave);
+        const bool ook = __shfl((int)ok, half | o, kWave) != 0;
+        rank += (ook && (ov > v || (ov == v && o < l))) ? 1 : 0;
+    }
+    const uint64_t good = __ballot(ok) >> half & 0xffffffffull;
+    const uint64_t kth = __ballot(ok && rank == K - 1) >> half & 0xffffffffull;       // exactly one lane if >= K good seeds
+    const float t = __shfl(v, half | (kth ? __builtin_ctzll(kth) : 0), kWave);
+    if (l == 0) tau[q] = (__popcll(good) >= K && kth) ? t : -INFINITY;
+}
+
+// ----------------------------------------------------------------------------
 // k_tau: one wave per user.  tau = the K-th largest of the user's n_splits*32 class maxima of pass 0
 // (-inf while fewer than K classes saw an unmasked item: everything is listed then).
 // MSB-first radix select on the order-preserving integer image of the floats; the state is one 64-bit
@@ -744,12 +865,14 @@ constexpr int kSelWaves = 4;
 
 // The one-wave-per-user kernels are bound by the CU's single scalar unit: their loops are unrolled over a
 // COMPILE-TIME register count (no per-register guards) and the count is dispatched outside.
-template <int NREG>
+template <int NREG, bool REPAIR = false>
 __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int K, const float *__restrict__ maxima,
-                                                        float *__restrict__ tau) {
+                                                        const int32_t *__restrict__ blk_flag, float *__restrict__ tau) {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x * kSelWaves + wid;
     if (q >= U) return;
+    // repair round: only the users of re-listed user blocks were sampled; their threshold is raised, never lowered
+    if (REPAIR && blk_flag[q / kUsersPerBlock] == 0) return;
     const int n = n_splits * 32;
     uint32_t key[NREG];
 #pragma unroll
@@ -791,7 +914,7 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int
         }
         t_out = orderable_f32(prefix);                            // (all 32 bits decided when equal maxima remain)
     }
-    if (lane == 0) tau[q] = t_out;
+    if (lane == 0) tau[q] = REPAIR ? fmaxf(tau[q], t_out) : t_out;
 }
 
 // ----------------------------------------------------------------------------
@@ -800,13 +923,16 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int
 // survivors and writes them as (score, id) rows to out_val/out_idx[0][u][:]; the other splits' rows are
 // padded with (-inf, -1).
 // ----------------------------------------------------------------------------
-constexpr int kSelRegs = 16;                       // up to 1024 candidates per user (more: fallback)
 
 // Gather, select and sort for one user with NREG keys per lane (n <= 64*NREG); see k_select.
 template <int NREG>
 __device__ __forceinline__ void select_user(int q, int lane, int U, int n_splits, int n_out, int K, int cap, int n, int incl,
                                             const uint64_t *__restrict__ lists, uint64_t *s_top,
-                                            float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+                                            float *__restrict__ out_val, int32_t *__restrict__ out_idx,
+                                            int32_t *__restrict__ seed_out) {
+    // with seed_out the best kSeedWidth (>= K) candidates are ranked: the first K are the result, all of them the seeds
+    // of the caller's next ranking (macr_score_topk seed_idx)
+    const int Ksel = seed_out ? kSeedWidth : K;
     // element e of the gathered order lives in split s(e) at position e - offset(s); the addresses are resolved
     // first (uniform loop over the splits), then all loads are issued back to back
     size_t rel[NREG];
@@ -825,11 +951,11 @@ __device__ __forceinline__ void select_user(int q, int lane, int U, int n_splits
     for (int j = 0; j < NREG; ++j) key[j] = j * 64 + lane < n ? lists[rel[j]] : 0ull;
     // K-th largest of the n keys (distinct: ids differ): MSB-first radix select on lane masks
     uint64_t kth = 0ull;
-    if (n >= K) {
+    if (n >= Ksel) {
         uint64_t cand[NREG];
 #pragma unroll
         for (int j = 0; j < NREG; ++j) cand[j] = __ballot(j * 64 + lane < n);
-        int remaining = K, alive = n;
+        int remaining = Ksel, alive = n;
         for (int bit = 63; bit >= 0 && alive > 1; --bit) {          // ends as soon as one candidate is left
             const uint32_t m = 1u << (bit & 31);
             uint64_t ones[NREG];
@@ -861,7 +987,7 @@ __device__ __forceinline__ void select_user(int q, int lane, int U, int n_splits
         }
         kth = ((uint64_t)hi << 32) | lo;
     }
-    // survivors (exactly min(n, K)) -> LDS by prefix popcount, then one wave-wide sort
+    // survivors (exactly min(n, Ksel)) -> LDS by prefix popcount, then one wave-wide sort
     int base = 0;
 #pragma unroll
     for (int j = 0; j < NREG; ++j) {
@@ -884,13 +1010,21 @@ __device__ __forceinline__ void select_user(int q, int lane, int U, int n_splits
             out_idx[((size_t)s * U + q) * K + lane] = -1;
         }
     }
+    if (seed_out && lane < kSeedWidth) seed_out[(size_t)q * kSeedWidth + lane] = k1 ? key_id(k1) : -1;
 }
 
+template <bool REPAIR>
 __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, int n_out, int K, int cap,
                                                            const uint64_t *__restrict__ lists,
                                                            const int32_t *__restrict__ counts, int32_t *overflow,
-                                                           float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+                                                           int ovf_per_user, const int32_t *__restrict__ run_if,
+                                                           const int32_t *__restrict__ skip_blk,
+                                                           float *__restrict__ out_val, int32_t *__restrict__ out_idx,
+                                                           int32_t *__restrict__ seed_out) {
     __shared__ uint64_t s_top[kSelWaves][64];
+    if (REPAIR && *run_if == 0) return;               // second selection: only after a repair round
+    // first selection: a user block the listing pass gave up on (stale seeds) is ranked after the repair round only
+    if (!REPAIR && skip_blk && skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] != 0) return;
     // wave-uniform values are made so explicitly (readfirstlane): the selection state then lives in SGPRs
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x * kSelWaves + wid;
@@ -902,11 +1036,38 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
     for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, kWave); if (lane >= m) incl += o; }
     const int n_all = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, kWave));
     const int n = n_all < kSelRegs * 64 ? n_all : kSelRegs * 64;
-    if (n_all > kSelRegs * 64 && lane == 0) *overflow = 1;
+    if (n_all > kSelRegs * 64 && lane == 0) overflow[ovf_per_user ? q : 0] = 1;
     // the common case (a few hundred candidates) runs the 4-keys-per-lane instance: these kernels are bound by the
     // CU's scalar unit and by registers, both proportional to the register count
-    if (n <= 256) select_user<4>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx);
-    else select_user<kSelRegs>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx);
+    if (n <= 256) select_user<4>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+    else select_user<kSelRegs>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+}
+
+// ----------------------------------------------------------------------------
+// k_repair_plan: what to do about candidate lists that overflowed.  A threshold can be far too loose for some users
+// (seeds from a ranking the model has since moved away from; a sampling pass that missed the popular tiles): their
+// lists were cut at `cap` entries in the listing pass, or held more than k_select ranks.  The entries that WERE
+// listed are distinct unmasked items, and k_select has just written their top K: its K-th score is a lower bound of
+// the user's K-th best score and, being rank K among >= cap listed items, a far tighter threshold.  One block per
+// user block: flagged users get that threshold, a user block with any flagged user is appended to ub_map (the
+// listing pass then runs again for those user blocks only) and the list lengths of its users are cleared.
+// When the thresholds came from seeds, the re-listed user blocks are also SAMPLED first (the sampling pass and k_tau
+// restricted to them): a first list that took everything holds the first `cap` items of its tile range, whose K-th
+// best is at quantile K/cap of the catalogue -- on 41k items ~1600 candidates, more than k_select ranks -- while the
+// sampled threshold sits at rank ~8K whatever happened before.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(kUsersPerBlock) void k_repair_plan(int U, int K, int n_slots, const int32_t *__restrict__ user_ovf,
+                                                                const float *__restrict__ out_val, float *__restrict__ tau,
+                                                                int32_t *__restrict__ counts, int32_t *__restrict__ ub_map,
+                                                                int32_t *__restrict__ blk_flag, int32_t *n_ub) {
+    const int ub = blockIdx.x, q = ub * kUsersPerBlock + threadIdx.x;
+    const bool stopped = blk_flag[ub] != 0;               // the listing pass gave up on this user block (stale seeds)
+    const bool f = q < U && (user_ovf[q] != 0 || stopped);
+    if (f && !stopped) tau[q] = fmaxf(tau[q], out_val[(size_t)q * K + (K - 1)]);      // (a stopped block was not ranked)
+    if (!__syncthreads_or(f)) return;
+    if (q < U)
+        for (int sl = 0; sl < n_slots; ++sl) counts[(size_t)sl * U + q] = 0;
+    if (threadIdx.x == 0) { ub_map[atomicAdd(n_ub, 1)] = ub; blk_flag[ub] = 1; }
 }
 
 // ----------------------------------------------------------------------------
@@ -1204,10 +1365,11 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
     return g;
 }
 
-// Workspace of macr_score_topk: counts[S1][U] | flags | shared_thr[U] (fallback kernel) | tau[U] | maxima[S0][U][32] |
+// Workspace of macr_score_topk: counts[S1][U] | flags | shared_thr[U] (fallback kernel) | user_ovf[U] | ub_map[ublocks] |
+// tau[U] | maxima[S0][U][32] |
 // mask_bits[tiles][U] | lists[S1][U][cap]
 struct TopkWs {
-    float *tau, *maxima; int32_t *counts; int32_t *overflow; uint32_t *shared_thr, *mask_bits; uint64_t *lists;
+    float *tau, *maxima; int32_t *counts; int32_t *overflow, *user_ovf, *ub_map, *blk_flag; uint32_t *shared_thr, *mask_bits; uint64_t *lists;
     int cap; size_t header_bytes, maxima_bytes, mask_bytes, bytes;
 };
 static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g) {
@@ -1221,6 +1383,9 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g) 
     w.counts = static_cast<int32_t *>(take((size_t)g.slots1 * U * 4));
     w.overflow = static_cast<int32_t *>(take(256));
     w.shared_thr = static_cast<uint32_t *>(take((size_t)U * 4));
+    w.user_ovf = static_cast<int32_t *>(take((size_t)U * 4));           // per-user "list overflowed" flags of the first round
+    w.ub_map = static_cast<int32_t *>(take((size_t)g.ublocks * 4));     // user blocks of the repair round (overflow[1] of them)
+    w.blk_flag = static_cast<int32_t *>(take((size_t)g.ublocks * 4));   // 1 = this user block is in ub_map
     w.header_bytes = off;                                   // zeroed at the start of every call
     w.tau = static_cast<float *>(take((size_t)U * 4));
     w.maxima_bytes = (size_t)g.slots0 * U * 32 * 4;         // set to NaN (0xff bytes) at the start of every call
@@ -1236,6 +1401,13 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g) 
 extern "C" size_t macr_score_topk_workspace_bytes(int U, int n_local, int d) {
     if (U <= 0 || n_local <= 0 || !dim_supported(d)) return 0;
     return carve_topk_ws(nullptr, U, n_local, stream_geo(U, n_local, d)).bytes;
+}
+
+extern "C" int macr_score_topk_uses_seeds(int U, int n_local, int d) {
+    if (U <= 0 || n_local <= 0 || !dim_supported(d)) return 0;
+    const StreamGeo geo = stream_geo(U, n_local, d);
+    const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= carve_topk_ws(nullptr, U, n_local, geo).cap;
+    return list_all ? 0 : 1;             // a shard this small lists every unmasked item: no thresholds, nothing to seed
 }
 
 extern "C" size_t macr_mask_bits_bytes(int U, int n_local) {
@@ -1261,6 +1433,20 @@ extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
     return 1;
 }
 
+namespace macr {
+template <bool REPAIR>
+static void launch_k_tau(int tau_regs, int blocks, hipStream_t st, int U, int slots0, int K, const float *maxima,
+                         const int32_t *blk_flag, float *tau) {
+    const int th = 64 * kSelWaves;
+    if (tau_regs <= 1) k_tau<1, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
+    else if (tau_regs <= 2) k_tau<2, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
+    else if (tau_regs <= 4) k_tau<4, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
+    else if (tau_regs <= 8) k_tau<8, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
+    else if (tau_regs <= 16) k_tau<16, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
+    else k_tau<32, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
+}
+}  // namespace macr
+
 #define MACR_DISPATCH_K(Dv, kind, ...)                                                                    \
     switch (kind) {                                                                                       \
         case MACR_SCORE_NORMAL:            { constexpr int D = Dv, KIND = MACR_SCORE_NORMAL; __VA_ARGS__; } break;            \
@@ -1282,8 +1468,10 @@ static inline bool score_kind_valid(int k) { return k >= MACR_SCORE_NORMAL && k 
 extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const float *users_tab,
                                const int32_t *user_ids, const float *items, const float *sig_u,
                                const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
-                               const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, float *out_val,
-                               int32_t *out_idx, void *workspace, size_t workspace_bytes, void *stream) {
+                               const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, const int32_t *seed_idx,
+                               int32_t *seed_out, float *out_val, int32_t *out_idx, int32_t *stats, void *workspace,
+                               size_t workspace_bytes,
+                               void *stream) {
     // MACR_TOPK_FALLBACK=1 in the environment runs the fallback kernel unconditionally (tests of that path)
     static const bool force_fallback = getenv("MACR_TOPK_FALLBACK") && getenv("MACR_TOPK_FALLBACK")[0] == '1';
     MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "score_topk: score_kind=%d", score_kind);
@@ -1329,33 +1517,67 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
     MACR_DISPATCH_DK(d, score_kind, {
         auto pass0 = k_score_stream<D, KIND, kModeMax>;
         auto pass1 = k_score_stream<D, KIND, kModeList>;
+        auto pass0r = k_score_stream<D, KIND, kModeMax, 1, true>;
+        auto pass1r = k_score_stream<D, KIND, kModeList, 1, true>;
         const size_t smem = StreamCfg<D>::smem;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass0),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipSuccess;
+        for (const void *f : {reinterpret_cast<const void *>(pass0), reinterpret_cast<const void *>(pass1),
+                              reinterpret_cast<const void *>(pass0r), reinterpret_cast<const void *>(pass1r)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
-        // A catalogue (shard) whose every tile range fits a candidate list needs no threshold: tau = -inf lists every unmasked item
-        // and the selection kernel ranks them -- no sampling pass, no k_tau.
-        if (!list_all) {
-        pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
-                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, sample_log2(n_local), SweepArgs{});
-        MACR_CHECK_LAUNCH("score_sample", st);
         const int tau_regs = (geo.slots0 * 32 + 63) / 64;
-        if (tau_regs <= 1) k_tau<1><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
-        else if (tau_regs <= 2) k_tau<2><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
-        else if (tau_regs <= 4) k_tau<4><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
-        else if (tau_regs <= 8) k_tau<8><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
-        else if (tau_regs <= 16) k_tau<16><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
-        else k_tau<32><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws.maxima, ws.tau);
-        MACR_CHECK_LAUNCH("tau", st);
+        auto launch_tau = [&](bool rep) {
+            if (rep) launch_k_tau<true>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau);
+            else launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau);
+        };
+        const bool seeded = !list_all && seed_idx;
+        if (seeded) {
+            // thresholds from the exact scores of the caller's seed items (its previous top K): no sampling pass, no k_tau
+            k_tau_seed<D, KIND><<<(U + 7) / 8, 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
+                                                               mask_bits, item_offset, K, seed_idx, ws.tau);
+            MACR_CHECK_LAUNCH("tau_seed", st);
+        } else if (!list_all) {
+            // (a catalogue (shard) whose every tile range fits a candidate list needs no threshold: tau = -inf lists every
+            // unmasked item and the selection kernel ranks them -- no sampling pass, no k_tau)
+            pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
+                                                geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, 0,
+                                                sample_log2(n_local), nullptr, nullptr, nullptr, SweepArgs{});
+            MACR_CHECK_LAUNCH("score_sample", st);
+            launch_tau(false);
+            MACR_CHECK_LAUNCH("tau", st);
         }
+        // Round 1 flags overflowing lists per user; the repair round lists the user blocks of those users again with the
+        // threshold their cut lists imply (k_repair_plan); only a second overflow arms the exact fallback kernel.
+        const bool repair = !list_all;
         pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
-                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, sample_log2(n_local), SweepArgs{});
+                                            geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
+                                            repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, 0, nullptr, nullptr,
+                                            seeded ? ws.blk_flag : nullptr, SweepArgs{});
         MACR_CHECK_LAUNCH("score_stream", st);
-        k_select<<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow,
-                                                       out_val, out_idx);
+        k_select<false><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts,
+                                                              repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, nullptr,
+                                                              seeded ? ws.blk_flag : nullptr, out_val, out_idx, seed_out);
         MACR_CHECK_LAUNCH("select", st);
+        if (repair) {
+            k_repair_plan<<<geo.ublocks, kUsersPerBlock, 0, st>>>(U, K, geo.slots1, ws.user_ovf, out_val, ws.tau, ws.counts,
+                                                                 ws.ub_map, ws.blk_flag, ws.overflow + 1);
+            MACR_CHECK_LAUNCH("repair_plan", st);
+            if (seeded) {
+                pass0r<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits,
+                                                     item_offset, geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
+                                                     ws.overflow, 0, sample_log2(n_local), ws.ub_map, ws.overflow + 1, nullptr, SweepArgs{});
+                MACR_CHECK_LAUNCH("score_sample2", st);
+                launch_tau(true);
+                MACR_CHECK_LAUNCH("tau2", st);
+            }
+            pass1r<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
+                                                 geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, 0, 0,
+                                                 ws.ub_map, ws.overflow + 1, nullptr, SweepArgs{});
+            MACR_CHECK_LAUNCH("score_stream2", st);
+            k_select<true><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow, 0,
+                                                           ws.overflow + 1, nullptr, out_val, out_idx, seed_out);
+            MACR_CHECK_LAUNCH("select2", st);
+        }
     });
     // Fallback, armed by the overflow flag on the device (its blocks return at once otherwise): the running
     // top-K kernel is exact for any score order.
@@ -1367,7 +1589,8 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS: %s", smem_old, hipGetErrorString(e));
         kern<<<ublocks * n_splits, 512, smem_old, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
                                                         mask_ptr, mask_idx, item_offset, K, n_splits, out_val, out_idx,
-                                                        n_splits > 1 ? ws.shared_thr : nullptr, force_fallback ? nullptr : ws.overflow);
+                                                        n_splits > 1 ? ws.shared_thr : nullptr, force_fallback ? nullptr : ws.overflow,
+                                                        stats);
     });
     MACR_CHECK_LAUNCH("score_topk", st);
     return MACR_OK;
@@ -1429,25 +1652,20 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
             if (list_all) continue;
             pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev + g, mask_bits_in,
                                                 item_offset, geo.ublocks, ws[g].tau, ws[g].maxima, ws[g].lists, ws[g].counts,
-                                                ws[g].cap, ws[g].overflow, sample_log2(n_local), SweepArgs{});
+                                                ws[g].cap, ws[g].overflow, 0, sample_log2(n_local), nullptr, nullptr, nullptr, SweepArgs{});
             MACR_CHECK_LAUNCH("score_sample", st);
             const int tau_regs = (geo.slots0 * 32 + 63) / 64;
-            if (tau_regs <= 1) k_tau<1><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
-            else if (tau_regs <= 2) k_tau<2><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
-            else if (tau_regs <= 4) k_tau<4><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
-            else if (tau_regs <= 8) k_tau<8><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
-            else if (tau_regs <= 16) k_tau<16><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
-            else k_tau<32><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots0, K, ws[g].maxima, ws[g].tau);
+            launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws[g].maxima, nullptr, ws[g].tau);
             MACR_CHECK_LAUNCH("tau", st);
         }
         // ONE listing pass for all n_c values
         pass1<<<geo.grid1, 512, smem1, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev, mask_bits_in,
                                              item_offset, geo.ublocks, ws[0].tau, ws[0].maxima, ws[0].lists, ws[0].counts,
-                                             ws[0].cap, ws[0].overflow, sample_log2(n_local), sw);
+                                             ws[0].cap, ws[0].overflow, 0, sample_log2(n_local), nullptr, nullptr, nullptr, sw);
         MACR_CHECK_LAUNCH("score_stream", st);
         for (int g = 0; g < n_c; ++g) {
-            k_select<<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, 1, K, ws[g].cap, ws[g].lists, ws[g].counts, ws[g].overflow,
-                                                           out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K);
+            k_select<false><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, 1, K, ws[g].cap, ws[g].lists, ws[g].counts, ws[g].overflow,
+                                                           0, nullptr, nullptr, out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K, nullptr);
             MACR_CHECK_LAUNCH("select", st);
         }
     });
@@ -1460,7 +1678,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
         for (int g = 0; g < n_c; ++g)
             kern<<<ublocks, 512, smem_old, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev + g, mask_ptr, mask_idx,
                                                  item_offset, K, 1, out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K,
-                                                 nullptr, force_fallback ? nullptr : ws[g].overflow);
+                                                 nullptr, force_fallback ? nullptr : ws[g].overflow, nullptr);
     });
     MACR_CHECK_LAUNCH("score_topk", st);
     return MACR_OK;

@@ -26,12 +26,23 @@ class Evaluator(object):
         assert len(mask_lists) == len(gt_lists)
         self.n_queries = len(gt_lists)
         self.n_items = n_items
+        device = torch.device(device)
         self.device = device
         self.mask = ops.CSR.from_lists(mask_lists, device)
         self.max_queries_per_pass = 131072       # bounds the ranking workspace (~1.5 GB of candidate lists)
         self.use_graph = os.environ.get("MACR_EVAL_GRAPH", "1") != "0"    # replay the evaluation as one HIP graph (_means)
+        self.use_seeds = os.environ.get("MACR_EVAL_SEEDS", "1") != "0"    # thresholds from the previous top K (rank_local)
         self._graphs = {}
         self._graph_misses = 0
+        # seeding policy: thresholds come from the previous ranking unless that went badly last time
+        self._seeded_now = True                   # what the ranking about to be launched does (if it has seeds at all)
+        self._seed_skip, self._seed_backoff = 0, 1
+        self._stats = torch.zeros(2, dtype=torch.int32, device=device)          # macr_score_topk stats of the last ranking
+        self._stats_host = torch.zeros(2, dtype=torch.int32)
+        if device.type == "cuda":
+            self._stats_host = self._stats_host.pin_memory()
+        self._stats_evt = None
+        self._last_seeded = False
         self.gt = ops.CSR.from_lists(gt_lists, device)
 
     # ------------------------------------------------------------------ ranking
@@ -49,7 +60,20 @@ class Evaluator(object):
             sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199,:201
         U = self.n_queries
         if U <= self.max_queries_per_pass:
-            vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, self.mask, lo)
+            # Seeds: the ids this shard returned last time (same queries, tables that moved by a few training steps).
+            # Their exact current scores bound every query's K-th best score from below far more tightly than a
+            # sampling pass does, for a tenth of its time (k_tau_seed); the ranking itself does not depend on them.
+            # Seeds the tables have moved away from (early epochs) cost a repair round, so the evaluator watches how
+            # many query blocks were listed twice (_seed_feedback) and goes back to the sampling pass for a while.
+            seeds = self.__dict__.setdefault("_seeds", {})
+            use = self.use_seeds and self._shape_uses_seeds(hi - lo, items_tab.shape[1])
+            seed = seeds.get((K, lo, hi)) if use else None
+            seeded = self._ranked_seeded = seed is not None and self._seeded_now
+            if use and seed is None:
+                seed = seeds[(K, lo, hi)] = torch.full((U, ops.SEED_WIDTH), -1, dtype=torch.int32, device=self.device)
+            # the ranking leaves its best SEED_WIDTH candidates per query in `seed` (in place): the next ranking's seeds
+            vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, self.mask, lo,
+                                       seed=seed if seeded else None, seed_out=seed, stats=self._stats)
         else:
             # the ranking workspace (candidate lists, mask bitmap) grows with the number of queries: rank them in
             # chunks; every query is independent of the chunking
@@ -63,10 +87,61 @@ class Evaluator(object):
             idx = torch.cat([p[1] for p in parts], dim=1)
         return vals, idx
 
+    def _seed_feedback(self):
+        """Decide, before a ranking is launched, whether it takes its thresholds from the seeds.  The previous seeded
+        ranking reports whether blocks of 256 queries had to be listed twice because a seeded threshold was too loose
+        (macr_score_topk stats).  The repair round costs about as much as an unseeded ranking however few blocks it
+        lists, so one of them means the model still moves too far between two evaluations for seeds to pay (early
+        epochs): the next 1, 2, 4 ... 16 evaluations use the sampling pass before seeds are tried again.  The choice only
+        moves time around: every mode returns the same ranking."""
+        if not self.use_seeds:
+            self._seeded_now = False
+            return False
+        if self._stats_evt is not None:
+            self._stats_evt.synchronize()         # normally long complete: the caller has read the previous metrics
+            self._stats_evt = None
+            if self._last_seeded:
+                relisted, fell_back = int(self._stats_host[0]), int(self._stats_host[1])
+                if fell_back or relisted > 0:
+                    self._seed_skip = self._seed_backoff
+                    self._seed_backoff = min(16, 2 * self._seed_backoff)
+                else:
+                    self._seed_backoff = 1
+        if self._seed_skip > 0:
+            self._seed_skip -= 1
+            self._seeded_now = False
+        else:
+            self._seeded_now = True
+        return self._seeded_now
+
+    def _shape_uses_seeds(self, n_local, d):
+        """False for shards small enough that the ranking lists every unmasked item (no thresholds to seed)"""
+        key = (n_local, d)
+        cache = self.__dict__.setdefault("_uses_seeds", {})
+        if key not in cache:
+            from . import _lib
+            cache[key] = bool(_lib.lib().macr_score_topk_uses_seeds(self.n_queries, n_local, d))
+        return cache[key]
+
+    def _has_seeds(self, K, n_items):
+        rank, ws = sharding.world()
+        return (K,) + tuple(sharding.item_shard_range(n_items, rank, ws)) in self.__dict__.get("_seeds", {})
+
+    def _stats_readback(self, seeded):
+        """after a ranking was launched: its stats travel to the host behind it (no synchronisation here)"""
+        self._last_seeded = seeded
+        if seeded and self.device.type == "cuda":           # only a seeded ranking's stats steer anything
+            self._stats_host.copy_(self._stats, non_blocking=True)
+            self._stats_evt = torch.cuda.Event()
+            self._stats_evt.record()
+
     def rank(self, kind, users_tab, user_ids, items_tab, K, w=None, wu=None, c=0.0, fill_masked=False):
         """Top-K item ids for every query user: (val (U,K), idx (U,K), cnt (U,)); the shards' top-K are all-gathered
         (one collective) and merged."""
+        self._seed_feedback()
+        self._ranked_seeded = False
         vals, idx = self.rank_local(kind, users_tab, user_ids, items_tab, K, w, wu, c)
+        self._stats_readback(self._ranked_seeded)
         fill = self.mask if fill_masked else None
         if sharding.world()[1] == 1:
             return ops.topk_merge(vals, idx, fill)
@@ -117,16 +192,25 @@ class Evaluator(object):
         the sequence is two graphs around the one collective (all-gather of the shards' top-K)."""
         c = self._c_scalar(c)
         world = sharding.world()[1]
+        # (no seeds yet for this K and shard: the first ranking samples, and leaves them)
+        seeded = self._seed_feedback() and self.n_queries <= self.max_queries_per_pass and self._has_seeds(max(Ks), items_tab.shape[0])
+        self._seeded_now = seeded        # the warm-up run of a capture creates the seeds: the capture itself must not pick them up
+        try:
+            return self._means_launch(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, world, seeded)
+        finally:
+            self._stats_readback(seeded)
+
+    def _means_launch(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, world, seeded):
         if not self.use_graph:
             return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
-        key = (flavour, kind, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
+        key = (flavour, kind, seeded, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
                Ks, None if w is None else w.data_ptr(), None if wu is None else wu.data_ptr(),
                torch.cuda.current_stream().cuda_stream, world)
         entry = self._graphs.get(key)
         if entry is None:
             # capturing costs about two evaluations: callers that keep changing the sequence are better off launching directly
             self._graph_misses += 1
-            if self._graph_misses > 6:
+            if self._graph_misses > 12:
                 self.use_graph = False
                 self._graphs.clear()
                 return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
@@ -154,6 +238,7 @@ class Evaluator(object):
             # the graphs bake in the addresses of everything they touched: keep the inputs and the cached scratch
             # (ranking workspace, mask bitmaps) alive for as long as they exist, whatever the caches do later
             keep = [users_tab, user_ids, items_tab, w, wu, c, ops._topk_ws_cache.get(items_tab.device)]
+            keep.extend(self.__dict__.get("_seeds", {}).values())
             for csr in [self.mask] + list(self.mask.__dict__.get("_row_ranges", {}).values()):
                 keep.extend(csr.__dict__.get("_mask_bits", {}).values())
             entry = self._graphs[key] = (stages, out, keep)

@@ -148,6 +148,7 @@ def score_topk_splits(U, n_local, d):
     return _lib.lib().macr_score_topk_splits(U, n_local, d)
 
 
+SEED_WIDTH = 32          # MACR_SEED_WIDTH
 _topk_ws_cache = {}
 
 
@@ -168,9 +169,14 @@ def _c_args(c):
 
 
 def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.0, mask=None,
-               item_offset=0, n_splits=0):
+               item_offset=0, n_splits=0, seed=None, seed_out=None, stats=None):
     """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K).
-    c: python float, or a 1-element fp32 device tensor (read at run time: graph replays follow its value)."""
+    c: python float, or a 1-element fp32 device tensor (read at run time: graph replays follow its value).
+    seed: optional (U, SEED_WIDTH) int32 device tensor of global item ids per query -- what seed_out received last time:
+    thresholds then come from the seeds' exact scores instead of a sampling pass -- same result, less time.
+    seed_out: optional (U, SEED_WIDTH) int32 device tensor <- the best candidates per query (may be `seed` itself).
+    stats: optional int32[2] device tensor <- (query blocks listed twice because a threshold was too loose, 1 if the
+    exact fallback kernel ran)."""
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
     n_local, d = items.shape
     if n_splits <= 0:
@@ -184,8 +190,8 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     cv, cp = _c_args(c)
     check(_lib.lib().macr_score_topk(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
                                      _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
-                                     cv, cp, mp, mi, mb, item_offset, K, n_splits, _ptr(vals), _ptr(idx),
-                                     _ptr(ws), ws.numel(), _stream()))
+                                     cv, cp, mp, mi, mb, item_offset, K, n_splits, _ptr(seed, _i32, True), _ptr(seed_out, _i32, True), _ptr(vals), _ptr(idx),
+                                     _ptr(stats, _i32, True), _ptr(ws), ws.numel(), _stream()))
     return vals, idx
 
 

@@ -685,3 +685,74 @@ def test_errors_are_loud(ops):
         ops.branch_sigmoid(dev(np.zeros((4, 48), np.float32)), dev(np.zeros(48, np.float32)))   # unsupported d
     with pytest.raises(ops.MacrError):
         ops.branch_sigmoid(torch.zeros(4, 64), torch.zeros(64))             # CPU tensors: no fallback
+
+
+def test_seeded_thresholds_do_not_change_the_ranking(ops):
+    """macr_score_topk with seed ids (k_tau_seed): whatever the seeds -- the best candidates of the previous ranking,
+    random items, masked, repeated or invalid ids -- the result is the exact ranking (the seeds only decide how tight
+    the threshold is); bit-equal to the oracle."""
+    rs = np.random.RandomState(31)
+    U, N, d, K, S = 900, 6000, 64, 20, ops.SEED_WIDTH
+    P = (rs.standard_normal((U, d)) * 0.4).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.4).astype(np.float32)
+    Q2 = (Q + rs.standard_normal((N, d)).astype(np.float32) * 0.05).astype(np.float32)       # the tables moved a little
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    mask = random_mask(rs, U, N, 30, heavy=(5,))                 # user 5 keeps 4 candidates (< K)
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    sig_i = ops.branch_sigmoid(dev(Q2), dev(w)); sig_u = ops.branch_sigmoid(dev(P), dev(wu))
+    wv, wi, wc = oracle.score_topk(oracle.SCORE_RUBI_BOTH, P, Q2, K, sig_u.cpu().numpy(), sig_i.cpu().numpy(), 30.0,
+                                   oracle.csr_from_lists(mask))
+    # previous ranking on the OLD tables leaves its best S candidates per query: the first K are its result
+    so = ops.branch_sigmoid(dev(Q), dev(w))
+    prev = torch.full((U, S), -7, dtype=torch.int32, device="cuda")
+    v0, i0 = ops.score_topk(ops.SCORE_RUBI_BOTH, dev(P), None, dev(Q), K, sig_u, so, 30.0, mcsr, seed_out=prev)
+    assert torch.equal(prev[:, :K], i0[0]) and int(prev.min()) >= -1
+    ov, oi, _ = oracle.score_topk(oracle.SCORE_RUBI_BOTH, P, Q, S, sig_u.cpu().numpy(), so.cpu().numpy(), 30.0, oracle.csr_from_lists(mask))
+    assert np.array_equal(prev.cpu().numpy(), oi)                # ... and all S are the exact top S
+    rnd = torch.from_numpy(np.stack([rs.choice(N, S, replace=False) for _ in range(U)]).astype(np.int32)).cuda()
+    bad = prev.clone(); bad[::7, 3] = -1; bad[1::7, 0] = N + 5; bad[2::7, 4] = bad[2::7, 9]        # invalid and repeated ids
+    bad[3::7, 1] = torch.tensor([mask[q][0] for q in range(3, U, 7)], dtype=torch.int32, device="cuda")   # and masked items
+    worst = prev.clone(); worst[:, K - 2:] = worst[:, K - 2:K - 1]   # K-1 distinct seeds: one short of a bound
+    stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    seen = {}
+    for name, seed in (("previous", prev), ("random", rnd), ("damaged", bad), ("too few", worst), ("none", None)):
+        out = None if seed is None else seed.clone()
+        v, ix = ops.score_topk(ops.SCORE_RUBI_BOTH, dev(P), None, dev(Q2), K, sig_u, sig_i, 30.0, mcsr, seed=out, seed_out=out,
+                               stats=stats)
+        val, idx, cnt = ops.topk_merge(v, ix)
+        assert np.array_equal(idx.cpu().numpy(), wi), name
+        assert np.array_equal(val.cpu().numpy().view(np.uint32), wv.view(np.uint32)), name
+        if out is not None:                                      # in place: the seeds of the next ranking
+            assert torch.equal(out[:, :K], ix[0]), name
+        seen[name] = stats.cpu().numpy().copy()
+    # good seeds and the sampling pass list a few dozen items per query.  A damaged set still bounds (K of its 32 seeds
+    # are good).  Random seeds put the threshold deep in the catalogue, too few seeds give none: those query blocks are
+    # listed again behind a sampling pass -- and that is enough (no exact fallback).
+    assert seen["previous"].tolist() == [0, 0] and seen["none"].tolist() == [0, 0] and seen["damaged"].tolist() == [0, 0]
+    assert seen["random"][0] > 0 and seen["random"][1] == 0
+    assert seen["too few"][0] == (U + 255) // 256 and seen["too few"][1] == 0
+
+
+def test_score_topk_second_overflow_arms_the_exact_kernel(ops):
+    """Scores that rise with the item id: whatever a first (cut) list holds is the bottom of its tile range.
+    With seeds (the lowest ids) the repair round samples the re-listed query blocks and its thresholds hold; without
+    seeds on a catalogue whose sampled tiles score below everything else, the sampled thresholds are useless, the
+    thresholds taken from the cut lists are loose again, the lists overflow a second time and the running top-K
+    kernel ranks.  Exact either way."""
+    rs = np.random.RandomState(77)
+    U, N, d, K = 200, 4096 * 3, 64, 20
+    P = np.abs(rs.standard_normal((U, d)) * 0.5).astype(np.float32)
+    Q = (np.abs(rs.standard_normal((N, d)) * 0.5) * (1.0 + 4.0 * np.arange(N)[:, None] / N)).astype(np.float32)
+    mask = random_mask(rs, U, N, 10)
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    low = np.stack([np.array([x for x in range(90) if x not in set(mask[q])][:ops.SEED_WIDTH]) for q in range(U)]).astype(np.int32)
+    stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for name, items, seed, want_stats in (("seeded", Q, dev(low), [(U + 255) // 256, 0]),
+                                          ("sampled tiles negative", np.where(((np.arange(N) // 32) % 8 == 0)[:, None], -Q, Q), None,
+                                           [(U + 255) // 256, 1])):
+        wv, wi, _ = oracle.score_topk(oracle.SCORE_NORMAL, P, items, K, mask=oracle.csr_from_lists(mask))
+        v, ix = ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(items), K, mask=mcsr, seed=seed, stats=stats)
+        val, idx, _ = ops.topk_merge(v, ix)
+        assert np.array_equal(idx.cpu().numpy(), wi), name
+        assert np.array_equal(val.cpu().numpy().view(np.uint32), wv.view(np.uint32)), name
+        assert stats.cpu().numpy().tolist() == want_stats, name

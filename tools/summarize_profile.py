@@ -24,10 +24,16 @@ def short(name):
     if not m:
         return None
     k = m.group(1)
-    if k == "score_stream":          # k_score_stream<D, KIND, MODE>: MODE 0 is the sampling pass
-        t = re.search(r"k_score_stream<\s*\d+\s*,\s*\d+\s*,\s*(\d+)", name)
+    if k == "score_stream":          # k_score_stream<D, KIND, MODE, NC, REPAIR>: MODE 0 is the sampling pass, REPAIR the
+        t = re.search(r"k_score_stream<\s*\d+\s*,\s*\d+\s*,\s*(\d+)\s*,\s*\d+\s*,\s*(true|false|0|1)", name)   # repair round
         if t and t.group(1) == "0":
             k = "score_sample"
+        if t and t.group(2) in ("true", "1"):
+            k += "2"
+    if k == "select" and re.search(r"k_select<\s*(true|1)\s*>", name):
+        k = "select2"
+    if k == "tau" and re.search(r"k_tau<\s*\d+\s*,\s*(true|1)\s*>", name):
+        k = "tau2"
     if k == "bxb":                   # k_bxb<R, FULL, ADAM>: ADAM=true carries the deferred Adam blocks
         t = re.search(r"k_bxb<\s*\d+\s*,\s*(?:true|false|\d+)\s*,\s*(true|1)", name)
         if t:
