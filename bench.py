@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="gowalla", choices=["addressa", "gowalla", "ml10m", "yelp2018"])
     ap.add_argument("--train", default="rubibceboth", choices=["normalbce", "rubibceboth"])
-    ap.add_argument("--eval-reps", type=int, default=5)
+    ap.add_argument("--eval-reps", type=int, default=20, help="timed evaluations (more than one period of the seeding policy's back-off)")
     ap.add_argument("--eval-settle", type=int, default=6, help="untimed evaluations (with the training steps between them) before the timed ones")
     ap.add_argument("--eval-train-steps", type=int, default=20,
                     help="untimed training steps between two timed evaluations (the evaluator seeds its thresholds with the "

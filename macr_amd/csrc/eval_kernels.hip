@@ -430,12 +430,19 @@ inline size_t score_topk_smem_bytes() {
 // (ds_read_b128) and 16 lanes x 16 B cover all 64 banks once.
 // ----------------------------------------------------------------------------
 constexpr int kModeMax = 0, kModeList = 1;
-// Pass 0 visits tiles t with t % 2^s == 0; s = 3.  Measured with s = 4 on the Gowalla shape (1281 tiles): the
-// sampling pass drops from 116 to 69 us with the listing pass and the selection unchanged on a freshly initialised
-// model -- but after ~800 training steps on popularity-skewed data the best items of a user sit in a few adjacent
-// tiles, a 1/16 sample misses most of them, tau comes out too low, the candidate lists overflow and the exact
-// fallback kernel runs (4.3 ms instead of 4 us; profiles/r02a_kernel_stats.csv caught it).  A 50 us gain is not worth
-// that cliff: every 8th tile stays.  -DMACR_SAMPLE_LOG2=n rebuilds with another rate for experiments.
+// Pass 0 is a SAMPLE of the catalogue: one "virtual tile" per window of 2^s consecutive tiles, made of every 2^s-th
+// item of the window (items w*32*2^s + 2^s*j + phase, j = 0..31, phase = w % 2^s) -- a 1/2^s sample spread evenly
+// over the item ids; s = 3.  It used to be every 8th TILE (32 consecutive items): cheaper to stage, but item ids
+// follow popularity, a trained model's best items sit in a few adjacent tiles, and a tile-granular sample either
+// holds most of a user's top items or none of them (measured after ~800 training steps with a 1/16 tile sample: tau
+// so low that the candidate lists overflowed, profiles/r02a_kernel_stats.csv).  The strided sample has the variance
+// of a uniform one: the rank of the K-th best sampled item is K*2^s +- sqrt(K)*2^s = 160 +- 36 for K = 20.
+// s = 4 was measured with the strided sample too (Gowalla shape): the sampling pass drops from 103 to 67 us, but the
+// lists double (rank 320 +- 70), k_select needs 8 keys per lane instead of 4 (22 -> 42 us; ML-10M shape, 70 k users:
+// 23 -> 56 us) and on a model whose users all rank the catalogue alike the candidates of a user land in ONE tile
+// range and a few users run over the 512-entry list of that range: 1-3 query blocks re-listed per evaluation.
+// Net gain 16 us at best: every 8th item stays.  The train-item mask of a virtual tile is one word of a second
+// bitmap that k_mask_bits builds beside the per-tile one.  -DMACR_SAMPLE_LOG2=n rebuilds with another rate.
 static inline int sample_log2(int n_local) {
 #ifdef MACR_SAMPLE_LOG2
     return MACR_SAMPLE_LOG2;
@@ -444,6 +451,8 @@ static inline int sample_log2(int n_local) {
     return 3;
 #endif
 }
+static inline int n_tiles(int n_local) { return (n_local + kTileItems - 1) / kTileItems; }
+static inline int n_windows(int n_local) { const int sl = sample_log2(n_local); return (n_tiles(n_local) + (1 << sl) - 1) >> sl; }
 
 template <int D>
 struct StreamCfg {
@@ -468,16 +477,22 @@ __global__ __launch_bounds__(256) void k_topk_ws_init(uint32_t *__restrict__ bas
     }
 }
 
-// mask_bits[tile][user] |= 1 << (item % 32) for every masked item of the shard; one wave per user.
+// mask_bits[tile][user] |= 1 << (item % 32) for every masked item of the shard, and the same for the sampling pass's
+// virtual tiles (sample_log2); one wave per user.
 __global__ __launch_bounds__(256) void k_mask_bits(int U, int n_local, const int32_t *__restrict__ mask_ptr,
                                                    const int32_t *__restrict__ mask_idx, int item_offset,
-                                                   uint32_t *__restrict__ mask_bits) {
+                                                   uint32_t *__restrict__ mask_bits, int tiles, int sl) {
     const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= U) return;
     const int e0 = mask_ptr[q], e1 = mask_ptr[q + 1];
+    uint32_t *sample_bits = mask_bits + (size_t)tiles * U;       // [window][user]: bit j = item j of the window's virtual tile
     for (int e = e0 + lane; e < e1; e += 64) {
         const int it = mask_idx[e] - item_offset;
-        if (it >= 0 && it < n_local) atomicOr(&mask_bits[(size_t)(it >> 5) * U + q], 1u << (it & 31));
+        if (it >= 0 && it < n_local) {
+            atomicOr(&mask_bits[(size_t)(it >> 5) * U + q], 1u << (it & 31));
+            const int w = it >> (5 + sl), rem = it - (w << (5 + sl));
+            if ((rem & ((1 << sl) - 1)) == (w & ((1 << sl) - 1))) atomicOr(&sample_bits[(size_t)w * U + q], 1u << (rem >> sl));
+        }
     }
 }
 
@@ -597,11 +612,19 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 #pragma unroll
         for (int k = 0; k < C::LD4; ++k) {
             const int e = tid + 512 * k, row = (e / (D / 4)) & (kTileItems - 1), c4 = e % (D / 4);
-            const int it = min(tile * kTileItems + row, n_local - 1);
+            // sampling pass: `tile` is the first tile of a window, item j of the virtual tile = every kStep-th of the window
+            const int it = MODE == kModeMax ? min(tile * kTileItems + kStep * row + ((tile >> sample_log2) & (kStep - 1)), n_local - 1)
+                                            : min(tile * kTileItems + row, n_local - 1);
             stg[k] = ld4(items + (size_t)it * D + 4 * c4);
         }
-        if (score_uses_sig_i(KIND)) sg = sig_i[min(tile * kTileItems + (tid & (kTileItems - 1)), n_local - 1)];
-        tm_next = (mask_bits && q_ok) ? mask_bits[(size_t)tile * U + q] : 0u;      // masked items of (tile, user)
+        if (score_uses_sig_i(KIND)) {
+            const int row = tid & (kTileItems - 1);
+            sg = sig_i[MODE == kModeMax ? min(tile * kTileItems + kStep * row + ((tile >> sample_log2) & (kStep - 1)), n_local - 1)
+                                        : min(tile * kTileItems + row, n_local - 1)];
+        }
+        // masked items of (tile, user); sampling pass: of (window, user), the second bitmap behind the per-tile one
+        if (MODE == kModeMax) tm_next = (mask_bits && q_ok) ? mask_bits[((size_t)tiles_total + (tile >> sample_log2)) * U + q] : 0u;
+        else tm_next = (mask_bits && q_ok) ? mask_bits[(size_t)tile * U + q] : 0u;
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -647,8 +670,10 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 #ifdef MACR_ABL_S_NOMASK
         tmask = 0;
 #endif
-        const int valid = n_local - t * kTileItems;                 // < 32 only in the last tile of the shard
-        if (valid < kTileItems) tmask |= ~0u << valid;
+        // < 32 only in the last tile (window) of the shard
+        const int valid = MODE == kModeMax ? (n_local - t * kTileItems - ((t >> sample_log2) & (kStep - 1)) + kStep - 1) >> sample_log2
+                                           : n_local - t * kTileItems;
+        if (valid < kTileItems) tmask |= valid > 0 ? ~0u << valid : ~0u;
 
         const float *ua = s_a + ((size_t)buf * kTileItems + col) * RS + h * NT;
         f32x16 acc;
@@ -1040,6 +1065,7 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
     // the common case (a few hundred candidates) runs the 4-keys-per-lane instance: these kernels are bound by the
     // CU's scalar unit and by registers, both proportional to the register count
     if (n <= 256) select_user<4>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+    else if (n <= 512) select_user<8>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
     else select_user<kSelRegs>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
 }
 
@@ -1390,7 +1416,7 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g) 
     w.tau = static_cast<float *>(take((size_t)U * 4));
     w.maxima_bytes = (size_t)g.slots0 * U * 32 * 4;         // set to NaN (0xff bytes) at the start of every call
     w.maxima = static_cast<float *>(take(w.maxima_bytes));
-    w.mask_bytes = (size_t)((n_local + kTileItems - 1) / kTileItems) * U * 4;
+    w.mask_bytes = (size_t)(n_tiles(n_local) + n_windows(n_local)) * U * 4;
     w.mask_bits = static_cast<uint32_t *>(take(w.mask_bytes));
     w.lists = static_cast<uint64_t *>(take((size_t)g.slots1 * U * w.cap * 8));
     w.bytes = off;
@@ -1412,7 +1438,7 @@ extern "C" int macr_score_topk_uses_seeds(int U, int n_local, int d) {
 
 extern "C" size_t macr_mask_bits_bytes(int U, int n_local) {
     if (U <= 0 || n_local <= 0) return 0;
-    return (size_t)((n_local + kTileItems - 1) / kTileItems) * U * 4;
+    return (size_t)(n_tiles(n_local) + n_windows(n_local)) * U * 4;      // per-tile words, then per-window words (sampling pass)
 }
 
 extern "C" int macr_mask_bits_build(int U, int n_local, const int32_t *mask_ptr, const int32_t *mask_idx, int item_offset,
@@ -1421,7 +1447,8 @@ extern "C" int macr_mask_bits_build(int U, int n_local, const int32_t *mask_ptr,
     MACR_REQUIRE(mask_ptr && mask_idx && mask_bits, MACR_E_INVALID, "mask_bits_build: null pointer");
     hipStream_t st = as_stream(stream);
     fill_words(mask_bits, macr_mask_bits_bytes(U, n_local) / 4, 0u, st);
-    k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, mask_bits);
+    k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, mask_bits, n_tiles(n_local),
+                                             sample_log2(n_local));
     MACR_CHECK_LAUNCH("mask_bits", st);
     return MACR_OK;
 }
@@ -1510,7 +1537,8 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
     MACR_REQUIRE(!mask_bits_in || mask_ptr, MACR_E_INVALID, "score_topk: mask_bits without the CSR mask it was built from");
     if (mask_ptr && !mask_bits_in) {
         fill_words(ws.mask_bits, ws.mask_bytes / 4, 0u, st);
-        k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, ws.mask_bits);
+        k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, ws.mask_bits, n_tiles(n_local),
+                                                 sample_log2(n_local));
         MACR_CHECK_LAUNCH("mask_bits", st);
         mask_bits = ws.mask_bits;
     }

@@ -487,17 +487,24 @@ def test_score_topk_item_sharding_equals_unsharded(ops):
     assert np.array_equal(ref_i.cpu().numpy(), wi)
 
 
+def sampled_items(N):
+    """bool[N]: the items the ranking's sampling pass looks at (eval_kernels.hip sample_log2: every 2^s-th item of a window
+    of 2^s tiles, phase = window index mod 2^s)"""
+    S = 8
+    idx = np.arange(N)
+    return (idx % (32 * S)) % S == (idx // (32 * S)) % S
+
+
 @pytest.mark.parametrize("splits", [1, 3])
 def test_score_topk_overflowing_lists_fall_back_to_running_topk(ops, splits):
-    """Adversarial score order for the fixed-threshold stream: every sampled tile (multiples of 8) scores far
+    """Adversarial score order for the fixed-threshold stream: every sampled item scores far
     below the rest, so the thresholds learnt from the samples admit ~everything and the candidate lists overflow;
     the device-armed fallback (running top-K kernel) must still return the exact ranking."""
     rs = np.random.RandomState(5)
     U, N, d, K = 300, 4096 * 3, 64, 20
     P = np.abs(rs.standard_normal((U, d)) * 0.5).astype(np.float32)
     Q = np.abs(rs.standard_normal((N, d)) * 0.5).astype(np.float32)
-    tile = np.arange(N) // 32
-    Q[tile % 8 == 0] *= -1.0                          # all-positive factors: these items score negative
+    Q[sampled_items(N)] *= -1.0                       # all-positive factors: these items score negative
     mask_lists = random_mask(rs, U, N, 10)
     mptr, midx = oracle.csr_from_lists(mask_lists)
     mask = ops.CSR(dev(mptr), dev(midx))
@@ -736,7 +743,7 @@ def test_seeded_thresholds_do_not_change_the_ranking(ops):
 def test_score_topk_second_overflow_arms_the_exact_kernel(ops):
     """Scores that rise with the item id: whatever a first (cut) list holds is the bottom of its tile range.
     With seeds (the lowest ids) the repair round samples the re-listed query blocks and its thresholds hold; without
-    seeds on a catalogue whose sampled tiles score below everything else, the sampled thresholds are useless, the
+    seeds on a catalogue whose sampled items score below everything else, the sampled thresholds are useless, the
     thresholds taken from the cut lists are loose again, the lists overflow a second time and the running top-K
     kernel ranks.  Exact either way."""
     rs = np.random.RandomState(77)
@@ -748,7 +755,7 @@ def test_score_topk_second_overflow_arms_the_exact_kernel(ops):
     low = np.stack([np.array([x for x in range(90) if x not in set(mask[q])][:ops.SEED_WIDTH]) for q in range(U)]).astype(np.int32)
     stats = torch.zeros(2, dtype=torch.int32, device="cuda")
     for name, items, seed, want_stats in (("seeded", Q, dev(low), [(U + 255) // 256, 0]),
-                                          ("sampled tiles negative", np.where(((np.arange(N) // 32) % 8 == 0)[:, None], -Q, Q), None,
+                                          ("sampled tiles negative", np.where(sampled_items(N)[:, None], -Q, Q), None,
                                            [(U + 255) // 256, 1])):
         wv, wi, _ = oracle.score_topk(oracle.SCORE_NORMAL, P, items, K, mask=oracle.csr_from_lists(mask))
         v, ix = ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(items), K, mask=mcsr, seed=seed, stats=stats)
