@@ -66,7 +66,7 @@ class Evaluator(object):
             # Seeds the tables have moved away from (early epochs) cost a repair round, so the evaluator watches how
             # many query blocks were listed twice (_seed_feedback) and goes back to the sampling pass for a while.
             seeds = self.__dict__.setdefault("_seeds", {})
-            use = self.use_seeds and self._shape_uses_seeds(hi - lo, items_tab.shape[1])
+            use = self.use_seeds and ws == 1 and self._shape_uses_seeds(hi - lo, items_tab.shape[1])
             seed = seeds.get((K, lo, hi)) if use else None
             seeded = self._ranked_seeded = seed is not None and self._seeded_now
             if use and seed is None:
@@ -94,7 +94,10 @@ class Evaluator(object):
         lists, so one of them means the model still moves too far between two evaluations for seeds to pay (early
         epochs): the next 1, 2, 4 ... 16 evaluations use the sampling pass before seeds are tried again.  The choice only
         moves time around: every mode returns the same ranking."""
-        if not self.use_seeds:
+        # Several ranks: no seeds.  The policy's state is per shard, so ranks would switch between the seeded and the
+        # sampled launch sequence -- and capture the other graph, with its extra warm-up collectives -- at different
+        # evaluations: mismatched all-gathers.  (A 1/8 shard's sampling pass is 13 us; there is little to win.)
+        if not self.use_seeds or sharding.world()[1] > 1:
             self._seeded_now = False
             return False
         if self._stats_evt is not None:
