@@ -128,25 +128,88 @@ __device__ __forceinline__ float4 gather_range(const int32_t *__restrict__ col, 
 }
 #endif
 
+// gather_range for a ROW-SPARSE X: only rows with active[row] != 0 are non-zero (the gradient of a LightGCN batch
+// touches <= 3B rows of the table), so the other neighbours are dropped before anything is gathered.  Per 64-entry
+// chunk: one byte gather of the flags, a ballot, the surviving (col, val) pairs are packed into the wave's 512 bytes
+// of LDS in entry order and the groups take them from there.  A chunk without an active neighbour costs its index
+// load and the flag gather.  (The summation tree differs from gather_range's -- same terms, other grouping.)
 template <int LPR>
-__device__ __forceinline__ void write_row(int r, int sub, float4 acc, float *Y, const float *S_in, float *S_out, float scale) {
+__device__ __forceinline__ float4 gather_range_active(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                      const float *__restrict__ X, const uint8_t *__restrict__ active,
+                                                      int beg, int end, int sub, int grp, int2 *s_ent) {
+    constexpr int d = 4 * LPR;
+    constexpr int NG = kWave / LPR;
+    constexpr int PER = kWave / NG;
+    constexpr int DEPTH = 4 < PER ? 4 : PER;
+    const int lane = threadIdx.x & 63;
+    const uint64_t below = (1ull << lane) - 1ull;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = beg; base < end; base += kWave) {           // wave-uniform
+        const int n = end - base < kWave ? end - base : kWave;
+        const int ec = base + (lane < n ? lane : n - 1);
+        const int cv = col[ec];
+        const bool act = lane < n && active[cv] != 0;
+        const uint64_t m = __ballot(act);
+        if (m == 0ull) continue;                                // wave-uniform
+        const float av = val[ec];
+        const int na = __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous chunk's reads of s_ent are done
+        if (act) s_ent[__popcll(m & below)] = make_int2(cv, __float_as_int(av));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int2 pad = s_ent[0];                              // a valid row for the unguarded gathers of padding slots
+#pragma unroll
+        for (int k0 = 0; k0 < PER; k0 += DEPTH) {
+            if (k0 * NG >= na) break;                           // wave-uniform
+            int c[DEPTH]; float a[DEPTH]; float4 x[DEPTH];
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                const int src = (k0 + k) * NG + grp;
+                const int2 e = s_ent[src < na ? src : 0];
+                c[k] = src < na ? e.x : pad.x;
+                a[k] = src < na ? __int_as_float(e.y) : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) x[k] = ld4(X + (size_t)c[k] * d + 4 * sub);
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) acc = fma4(a[k], x[k], acc);
+        }
+    }
+#pragma unroll
+    for (int m = LPR; m < kWave; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
+        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
+    }
+    return acc;
+}
+
+// s_on: 0 = S_in[r] is to be taken as zero (a row-sparse S_in whose inactive rows were never written)
+template <int LPR>
+__device__ __forceinline__ void write_row(int r, int sub, float4 acc, float *Y, const float *S_in, float *S_out, float scale,
+                                          bool s_on = true) {
     constexpr int d = 4 * LPR;
     const size_t o = (size_t)r * d + 4 * sub;
     if (Y) st4(Y + o, acc);
     if (S_out) {
-        const float4 s = ld4(S_in + o);
+        const float4 s = s_on ? ld4(S_in + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         st4(S_out + o, make_float4((s.x + acc.x) * scale, (s.y + acc.y) * scale, (s.z + acc.z) * scale, (s.w + acc.w) * scale));
     }
 }
 
 // Y = A X (if Y), S_out = (S_in + A X) * scale (if S_out; may alias S_in: updated in place row by row).
-template <int LPR>
+// SPARSE (a LightGCN training step only needs the propagated rows of its batch, and its gradient enters the backward
+// propagation with <= 3B non-zero rows; rows[] = 1 for those rows):
+//   kSparseOut  only rows with rows[r] != 0 are computed (the LAST forward layer: nothing else is read afterwards)
+//   kSparseIn   X and S_in are row-sparse: only rows with rows[.] != 0 are read (the FIRST backward layer)
+constexpr int kDense = 0, kSparseOut = 1, kSparseIn = 2;
+template <int LPR, int SPARSE>
 __global__ __launch_bounds__(256) void k_spmm_csr(int N, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col, const float *__restrict__ val,
                                                   const void *__restrict__ plan, PlanHeader ph,
                                                   const float *__restrict__ X, float *Y, const float *S_in,
-                                                  float *S_out, float scale, float *__restrict__ slab) {
+                                                  float *S_out, float scale, float *__restrict__ slab,
+                                                  const uint8_t *__restrict__ rows) {
     constexpr int d = 4 * LPR;
+    __shared__ int2 s_ent[SPARSE == kSparseIn ? 4 * kWave : 1];
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR, grp = lane / LPR;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -159,9 +222,12 @@ __global__ __launch_bounds__(256) void k_spmm_csr(int N, const int32_t *__restri
         if (w >= N) return;
         r = w; beg = rowptr[r]; end = rowptr[r + 1];
     }
-    const float4 acc = gather_range<LPR>(col, val, X, beg, end, sub, grp);
+    if (SPARSE == kSparseOut && rows[r] == 0) return;
+    const float4 acc = SPARSE == kSparseIn
+                           ? gather_range_active<LPR>(col, val, X, rows, beg, end, sub, grp, s_ent + (threadIdx.x >> 6) * kWave)
+                           : gather_range<LPR>(col, val, X, beg, end, sub, grp);
     if (grp == 0) {
-        if (slot < 0) write_row<LPR>(r, sub, acc, Y, S_in, S_out, scale);
+        if (slot < 0) write_row<LPR>(r, sub, acc, Y, S_in, S_out, scale, SPARSE != kSparseIn || rows[r] != 0);
         else st4(slab + (size_t)slot * d + 4 * sub, acc);
     }
 }
@@ -169,10 +235,10 @@ __global__ __launch_bounds__(256) void k_spmm_csr(int N, const int32_t *__restri
 // Sums the chunk partials of every split (hub) row and applies the epilogue.  One wave per hub row:
 // the 64/LPR groups take interleaved slots (two loads in flight each), then combine by shuffles --
 // a fixed summation tree, so the result is deterministic.
-template <int LPR>
+template <int LPR, int SPARSE>
 __global__ __launch_bounds__(256) void k_spmm_fixup(const void *__restrict__ plan, PlanHeader ph,
                                                     const float *__restrict__ slab, float *Y, const float *S_in,
-                                                    float *S_out, float scale) {
+                                                    float *S_out, float scale, const uint8_t *__restrict__ rows) {
     constexpr int d = 4 * LPR;
     constexpr int NG = kWave / LPR;
     const int lane = threadIdx.x & 63;
@@ -180,6 +246,7 @@ __global__ __launch_bounds__(256) void k_spmm_fixup(const void *__restrict__ pla
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     const PlanView pv = view_plan(plan, ph);
     if (k >= pv.n_split) return;
+    if (SPARSE == kSparseOut && rows[pv.split_row[k]] == 0) return;
     const int s0 = pv.split_slot0[k], s1 = pv.split_slot0[k + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
     int s = s0 + grp;
@@ -194,7 +261,7 @@ __global__ __launch_bounds__(256) void k_spmm_fixup(const void *__restrict__ pla
         acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
         acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
     }
-    if (grp == 0) write_row<LPR>(pv.split_row[k], sub, acc, Y, S_in, S_out, scale);
+    if (grp == 0) write_row<LPR>(pv.split_row[k], sub, acc, Y, S_in, S_out, scale, SPARSE != kSparseIn || rows[pv.split_row[k]] != 0);
 }
 
 // out = in * scale   (n_layers == 0 degenerate case) -- float4 per lane
@@ -206,9 +273,11 @@ __global__ void k_scale_copy(size_t n_vec, const float *__restrict__ in, float *
 }
 
 // work: [2*N*d] layer buffers followed by [n_slots*d] slab when a plan is given.
+// sparse_rows (may be NULL) with mode kSparseOut: only the flagged rows of E are wanted (computed in the last layer);
+// with mode kSparseIn: E0 is row-sparse, only its flagged rows are non-zero (and only they are read).
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
                      const void *plan_dev, const void *plan_host_header, const float *E0, float *E, float *work,
-                     hipStream_t st) {
+                     hipStream_t st, const uint8_t *sparse_rows, int sparse_mode) {
     const size_t nd = (size_t)N * d;
     float *bufA = work, *bufB = work + nd;            // alternating layer outputs
     float *slab = work + 2 * nd;
@@ -228,13 +297,34 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
         const bool last = (l == n_layers - 1);
         float *Y = last ? nullptr : ((l & 1) ? bufB : bufA);
         const float scale = last ? inv : 1.0f;        // running sum lives in E; first layer reads E0 as S_in
-        MACR_DISPATCH_LPR(d, (k_spmm_csr<LPR><<<grid, 256, 0, st>>>(N, rowptr, col, val, plan_dev, ph, X, Y, S_in, E,
-                                                                   scale, slab)));
-        MACR_CHECK_LAUNCH("spmm_csr", st);
-        if (plan_dev && ph.n_split > 0) {
-            MACR_DISPATCH_LPR(d, (k_spmm_fixup<LPR><<<(ph.n_split + 3) / 4, 256, 0, st>>>(
-                                     plan_dev, ph, slab, Y, S_in, E, scale)));
-            MACR_CHECK_LAUNCH("spmm_fixup", st);
+        const int mode = !sparse_rows ? kDense
+                         : (sparse_mode == kSparseOut && last) ? kSparseOut
+                         : (sparse_mode == kSparseIn && l == 0) ? kSparseIn : kDense;
+        const int n_fix = (ph.n_split + 3) / 4;
+        if (mode == kSparseOut) {
+            MACR_DISPATCH_LPR(d, (k_spmm_csr<LPR, kSparseOut><<<grid, 256, 0, st>>>(N, rowptr, col, val, plan_dev, ph, X, Y, S_in, E,
+                                                                                    scale, slab, sparse_rows)));
+            MACR_CHECK_LAUNCH("spmm_csr_rows", st);
+            if (plan_dev && ph.n_split > 0) {
+                MACR_DISPATCH_LPR(d, (k_spmm_fixup<LPR, kSparseOut><<<n_fix, 256, 0, st>>>(plan_dev, ph, slab, Y, S_in, E, scale, sparse_rows)));
+                MACR_CHECK_LAUNCH("spmm_fixup", st);
+            }
+        } else if (mode == kSparseIn) {
+            MACR_DISPATCH_LPR(d, (k_spmm_csr<LPR, kSparseIn><<<grid, 256, 0, st>>>(N, rowptr, col, val, plan_dev, ph, X, Y, S_in, E,
+                                                                                   scale, slab, sparse_rows)));
+            MACR_CHECK_LAUNCH("spmm_csr_sparse", st);
+            if (plan_dev && ph.n_split > 0) {
+                MACR_DISPATCH_LPR(d, (k_spmm_fixup<LPR, kSparseIn><<<n_fix, 256, 0, st>>>(plan_dev, ph, slab, Y, S_in, E, scale, sparse_rows)));
+                MACR_CHECK_LAUNCH("spmm_fixup", st);
+            }
+        } else {
+            MACR_DISPATCH_LPR(d, (k_spmm_csr<LPR, kDense><<<grid, 256, 0, st>>>(N, rowptr, col, val, plan_dev, ph, X, Y, S_in, E,
+                                                                                scale, slab, nullptr)));
+            MACR_CHECK_LAUNCH("spmm_csr", st);
+            if (plan_dev && ph.n_split > 0) {
+                MACR_DISPATCH_LPR(d, (k_spmm_fixup<LPR, kDense><<<n_fix, 256, 0, st>>>(plan_dev, ph, slab, Y, S_in, E, scale, nullptr)));
+                MACR_CHECK_LAUNCH("spmm_fixup", st);
+            }
         }
         X = Y;
         S_in = E;
@@ -319,5 +409,5 @@ extern "C" int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *ro
     MACR_REQUIRE(E != E0, MACR_E_INVALID, "lgcn_propagate: E must not alias E0");
     if (int e = check_plan(plan_dev, plan_host, N, "lgcn_propagate")) return e;
     return macr::launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, E0, E, work,
-                                  macr::as_stream(stream));
+                                  macr::as_stream(stream), nullptr, 0);
 }

@@ -1041,7 +1041,25 @@ namespace macr {
 
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
                      const void *plan_dev, const void *plan_host_header, const float *E0, float *E, float *work,
-                     hipStream_t st);   // spmm_kernels.hip
+                     hipStream_t st, const uint8_t *sparse_rows, int sparse_mode);   // spmm_kernels.hip
+constexpr int kSparseOut = 1, kSparseIn = 2;                                          // = spmm_kernels.hip
+
+// rows[r] = 1 for every table row a LightGCN batch refers to (users u, items n_users + i, n_users + j), and -- when dE is
+// given -- those rows of dE are zeroed: the only rows of the gradient buffer the step ever reads (pair_bwd accumulates
+// into them, the first backward SpMM and its epilogue read flagged rows only).  One lane group per row reference.
+template <int D>
+__global__ __launch_bounds__(256) void k_mark_rows(int B, int n_users, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+                                                   const int32_t *__restrict__ j, uint8_t *__restrict__ rows, float *__restrict__ dE) {
+    constexpr int LPR = D / 4;
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t ref = t / LPR;
+    const int sub = (int)(t % LPR);
+    if (ref >= (size_t)3 * B) return;
+    const int which = (int)(ref / B), b = (int)(ref % B);
+    const int r = which == 0 ? u[b] : n_users + (which == 1 ? i[b] : j[b]);
+    if (dE) st4(dE + (size_t)r * D + 4 * sub, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (sub == 0) rows[r] = 1;
+}
 
 #define MACR_DISPATCH_D(d, ...)                                  \
     switch (d) {                                                 \
@@ -1556,7 +1574,7 @@ extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, in
 
 // ---- LightGCN ---------------------------------------------------------------
 namespace macr {
-struct LgcnWs { float *E, *dE, *G, *work; PairWs pair; size_t bytes; };
+struct LgcnWs { float *E, *dE, *G, *work; uint8_t *rows; PairWs pair; size_t bytes; };
 static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, int n_slots) {
     LgcnWs w;
     char *p = static_cast<char *>(base);
@@ -1567,6 +1585,7 @@ static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, int n_slots) {
     w.dE = static_cast<float *>(take(nd));
     w.G = static_cast<float *>(take(nd));
     w.work = static_cast<float *>(take(2 * nd + align_up((size_t)n_slots * d * 4, 256)));
+    w.rows = static_cast<uint8_t *>(take(align_up((size_t)N, 256)));       // 1 = a row of the current batch
     w.pair = carve_pair_ws(p ? p + off : nullptr, B, d);
     off += w.pair.bytes;
     w.bytes = off;
@@ -1613,8 +1632,23 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
                  "lgcn_train_step: workspace must be 256-byte aligned");
     hipStream_t st = as_stream(stream);
     const size_t nd = (size_t)N * d;
+    // The step reads the propagated table at the <= 3B rows of its batch only, and its gradient enters the backward
+    // propagation with the same <= 3B non-zero rows: the last forward layer is computed for those rows only and the first
+    // backward layer gathers only from them (spmm_kernels.hip kSparseOut / kSparseIn).  MACR_LGCN_DENSE=1 in the
+    // environment keeps every layer dense (ablation; the forward result is bit-identical either way).
+    static const bool dense_layers = getenv("MACR_LGCN_DENSE") && getenv("MACR_LGCN_DENSE")[0] == '1';
+    const bool sparse = !dense_layers && n_layers > 0;
+    if (sparse) {
+        fill_words(reinterpret_cast<uint32_t *>(ws.rows), (N + 3) / 4, 0u, st);
+        const size_t threads = (size_t)3 * B * (d / 4);
+        MACR_DISPATCH_D(d, (k_mark_rows<D><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(B, n_users, u, i, j, ws.rows,
+                                                                                             loss_only ? nullptr : ws.dE)));
+        MACR_CHECK_LAUNCH("mark_rows", st);
+    }
     // forward propagation (LightGCN.py:288-309)
-    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, T, ws.E, ws.work, st)) return e;
+    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, T, ws.E, ws.work, st,
+                                 sparse ? ws.rows : nullptr, kSparseOut))
+        return e;
     LossArgs L;
     L.part = ws.pair.part;
     L.part2 = ws.pair.part2; L.n_part2 = ws.pair.nblk_bwd;
@@ -1637,14 +1671,16 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         MACR_CHECK_LAUNCH("finalize_losses", st);
         return MACR_OK;
     }
-    fill_words(ws.dE, nd, 0u, st);
+    if (!sparse) fill_words(ws.dE, nd, 0u, st);
     // pair loss on the propagated rows; items live at rows n_users.. of E
     float *Ei = ws.E + (size_t)n_users * d, *dEi = ws.dE + (size_t)n_users * d;
     if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, ws.E, Ei, w, wu, ws.dE, dEi, nullptr, nullptr,
                             0.0f, 0, adam_pow, hp, ws.pair, st))
         return e;
     // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
-    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st)) return e;
+    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st,
+                                 sparse ? ws.rows : nullptr, kSparseIn))
+        return e;
     // l2 regulariser on the ego rows (LightGCN.py:525-528)
     // (the batch grouped by positive item, as the pair launch left it in the workspace, when there is one)
     const int32_t *gu = ws.pair.staged ? u : ws.pair.us, *gi = ws.pair.staged ? i : ws.pair.is, *gj = ws.pair.staged ? j : ws.pair.js;
