@@ -127,6 +127,8 @@ typedef struct macr_hyper {
 #define MACR_STEP_DEFER   1
 #define MACR_STEP_PENDING 2
 #define MACR_STEP_LOSS_ONLY 4    /* macr_lgcn_train_step only: compute the losses, update nothing (see there) */
+#define MACR_STEP_DENSE_LAYERS 8 /* macr_lgcn_train_step only: every propagation layer dense (default: the last forward layer
+                                    computes the batch's rows only, the first backward layer gathers from them only) */
 
 size_t macr_mf_train_workspace_bytes(int B, int d);
 

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MACR_HIP_LIB") or os.path.join(_HERE, "csrc", "libmac
 
 OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH = 0, -1, -2, -3, -4
 LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, LOSS_RUBIBCE = 0, 1, 2
-STEP_DEFER, STEP_PENDING, STEP_LOSS_ONLY = 1, 2, 4
+STEP_DEFER, STEP_PENDING, STEP_LOSS_ONLY, STEP_DENSE_LAYERS = 1, 2, 4, 8
 SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINUS_BOTH = 0, 1, 2, 3, 4
 MAX_TOPK = 32
 MAX_SWEEP = 4

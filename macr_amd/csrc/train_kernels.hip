@@ -1616,7 +1616,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     MACR_REQUIRE(rowptr && col && val && u && i && j && T && mT && vT && adam_pow && losses && workspace,
                  MACR_E_INVALID, "lgcn_train_step: null pointer");
     MACR_REQUIRE(w && wu && mw && vw && mwu && vwu, MACR_E_INVALID, "lgcn_train_step: null branch vectors");
-    MACR_REQUIRE((flags & ~MACR_STEP_LOSS_ONLY) == 0, MACR_E_INVALID, "lgcn_train_step: flags=%d", flags);
+    MACR_REQUIRE((flags & ~(MACR_STEP_LOSS_ONLY | MACR_STEP_DENSE_LAYERS)) == 0, MACR_E_INVALID, "lgcn_train_step: flags=%d", flags);
     const bool loss_only = flags & MACR_STEP_LOSS_ONLY;
     if (int e = validate_hyper(hp, "lgcn_train_step")) return e;
     const int N = n_users + n_items;
@@ -1634,10 +1634,10 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     const size_t nd = (size_t)N * d;
     // The step reads the propagated table at the <= 3B rows of its batch only, and its gradient enters the backward
     // propagation with the same <= 3B non-zero rows: the last forward layer is computed for those rows only and the first
-    // backward layer gathers only from them (spmm_kernels.hip kSparseOut / kSparseIn).  MACR_LGCN_DENSE=1 in the
-    // environment keeps every layer dense (ablation; the forward result is bit-identical either way).
+    // backward layer gathers only from them (spmm_kernels.hip kSparseOut / kSparseIn).  MACR_STEP_DENSE_LAYERS, or
+    // MACR_LGCN_DENSE=1 in the environment, keeps every layer dense (the forward result is bit-identical either way).
     static const bool dense_layers = getenv("MACR_LGCN_DENSE") && getenv("MACR_LGCN_DENSE")[0] == '1';
-    const bool sparse = !dense_layers && n_layers > 0;
+    const bool sparse = !dense_layers && !(flags & MACR_STEP_DENSE_LAYERS) && n_layers > 0;
     if (sparse) {
         fill_words(reinterpret_cast<uint32_t *>(ws.rows), (N + 3) / 4, 0u, st);
         const size_t threads = (size_t)3 * B * (d / 4);

@@ -400,9 +400,10 @@ class LGCNState(object):
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.T.device)
             self.batch_cap = B
 
-    def step(self, kind, u, i, j, losses=None, loss_only=False):
+    def step(self, kind, u, i, j, losses=None, loss_only=False, dense_layers=False):
         """One training step; loss_only=True computes {loss, mf_loss, emb_loss} of the batch and updates nothing
-        (the reference's "test loss" pass, LightGCN.py:799-819)."""
+        (the reference's "test loss" pass, LightGCN.py:799-819).  dense_layers=True: every propagation layer dense
+        (default: batch-row-sparse last forward / first backward layer, same result up to summation order)."""
         B = u.numel()
         self.reserve(B)
         out = self.losses if losses is None else losses
@@ -414,7 +415,8 @@ class LGCNState(object):
             _ptr(self.adj.idx, _i32), _ptr(self.adj.val, _f32), pd, ph, _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
             _ptr(self.T), _ptr(self.w), _ptr(self.wu), _ptr(self.mT), _ptr(self.vT), _ptr(self.mw), _ptr(self.vw),
             _ptr(self.mwu), _ptr(self.vwu), _ptr(self.adam_pow), ctypes.byref(self.hyper), _ptr(out, _f32),
-            _lib.STEP_LOSS_ONLY if loss_only else 0, _ptr(self.ws), self.ws.numel(), _stream()))
+            (_lib.STEP_LOSS_ONLY if loss_only else 0) | (_lib.STEP_DENSE_LAYERS if dense_layers else 0), _ptr(self.ws),
+            self.ws.numel(), _stream()))
         return out
 
     def propagated(self):

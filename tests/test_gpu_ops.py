@@ -763,3 +763,44 @@ def test_score_topk_second_overflow_arms_the_exact_kernel(ops):
         assert np.array_equal(idx.cpu().numpy(), wi), name
         assert np.array_equal(val.cpu().numpy().view(np.uint32), wv.view(np.uint32)), name
         assert stats.cpu().numpy().tolist() == want_stats, name
+
+
+@pytest.mark.parametrize("L,hubs", [(1, False), (2, True), (3, True)])
+def test_lgcn_batch_row_sparse_layers_equal_dense_layers(ops, L, hubs):
+    """The LightGCN step computes its last forward layer for the batch's rows only and gathers, in the first backward
+    layer, from the batch's rows only (spmm_kernels.hip kSparseOut / kSparseIn).  Against MACR_STEP_DENSE_LAYERS on the
+    same state: identical losses (the forward values are bit-identical), gradients and updated tables equal up to the
+    summation order of the first backward layer -- with hub rows that the plan splits, and with 1, 2 and 3 layers."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(12)
+    n_users, n_items, d, B = 3000, 1200, 64, 512
+    rows = rs.randint(0, n_users, 30000); cols = (rs.zipf(1.25, 30000) % n_items) if hubs else rs.randint(0, n_items, 30000)
+    R = sp.coo_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n_users, n_items)).tocsr()
+    R.data[:] = 1.0
+    N = n_users + n_items
+    A = sp.bmat([[None, R], [R.T, None]]).tocsr()
+    deg = np.asarray(A.sum(1)).ravel(); dinv = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1)), 0.0)
+    A = (sp.diags(dinv) @ A @ sp.diags(dinv)).tocsr().astype(np.float32); A.sort_indices()
+    if hubs:
+        assert np.diff(A.indptr).max() > 512                                # at least one row is split by the plan
+    T0 = (rs.standard_normal((N, d)) * 0.1).astype(np.float32)
+    w0, wu0 = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    adj = ops.CSR.from_scipy(A, "cuda")
+    hyper = ops.make_hyper(1e-3, 1e-4, 1e-2, 1e-3, B)
+    states = [ops.LGCNState(dev(T0.copy()), n_users, n_items, dev(w0.copy()), dev(wu0.copy()), adj, L, hyper, B) for _ in range(2)]
+    for t in range(3):
+        u = rs.choice(n_users, B, replace=False).astype(np.int32)
+        i = (rs.zipf(1.25, B) % n_items).astype(np.int32)
+        j = rs.randint(0, n_items, B).astype(np.int32)
+        la = states[0].step(ops.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j)).cpu().numpy().copy()
+        lb = states[1].step(ops.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j), dense_layers=True).cpu().numpy().copy()
+        if t == 0:
+            assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+            ga, gb = states[0].mT.cpu().numpy() / 0.1, states[1].mT.cpu().numpy() / 0.1
+            np.testing.assert_allclose(ga, gb, rtol=2e-5, atol=2e-7 * np.abs(gb).max())
+        np.testing.assert_allclose(la, lb, rtol=2e-6)
+        np.testing.assert_allclose(states[0].T.cpu().numpy(), states[1].T.cpu().numpy(), rtol=0, atol=2e-3 * 1e-3 * (t + 1))
+    # the loss-only pass takes the sparse forward too
+    lo_a = states[0].step(ops.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j), loss_only=True).cpu().numpy().copy()
+    lo_b = states[0].step(ops.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j), loss_only=True, dense_layers=True).cpu().numpy().copy()
+    assert np.array_equal(lo_a.view(np.uint32), lo_b.view(np.uint32))
