@@ -111,13 +111,14 @@ __device__ __forceinline__ void block_digit_offsets(uint32_t *s_hist, uint32_t *
 // A workgroup of 16 waves owns a tile of kSortTile keys (1024 per wave: every phase is a chain of memory and LDS
 // latencies, so a wave's share is kept short and the number of tiles -- the length of the histogram scan -- small).
 // ghist[digit][block]: per-workgroup digit counts, then (after k_rs_scan) the global start of (digit, block).
+template <int TILE>
 static __global__ __launch_bounds__(1024) void k_rs_count(const uint32_t *__restrict__ kin, int n, int shift,
                                                           uint32_t *__restrict__ ghist, int nblk) {
     __shared__ uint32_t s_hist[kRadix];
     if (threadIdx.x < kRadix) s_hist[threadIdx.x] = 0;
     __syncthreads();
-    const int lo = blockIdx.x * kSortTile, hi = lo + kSortTile < n ? lo + kSortTile : n;
-    constexpr int NQ = kSortTile / 1024;
+    const int lo = blockIdx.x * TILE, hi = lo + TILE < n ? lo + TILE : n;
+    constexpr int NQ = TILE / 1024;
     uint32_t k[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { const int p = lo + q * 1024 + threadIdx.x; k[q] = kin[p < hi ? p : hi - 1]; }
@@ -156,13 +157,14 @@ static __global__ __launch_bounds__(1024) void k_rs_scan(uint32_t *__restrict__ 
     }
 }
 
+template <int TILE>
 static __global__ __launch_bounds__(1024) void k_rs_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                             uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int n,
                                                             int shift, const uint32_t *__restrict__ ghist, int nblk) {
     __shared__ uint32_t s_hist[16 * kRadix + 4];
     const int t = threadIdx.x, wid = t >> 6;
-    constexpr int per = kSortTile / 16;
-    const int blo = blockIdx.x * kSortTile, bhi = blo + kSortTile < n ? blo + kSortTile : n;
+    constexpr int per = TILE / 16;
+    const int blo = blockIdx.x * TILE, bhi = blo + TILE < n ? blo + TILE : n;
     const int lo = blo + wid * per < bhi ? blo + wid * per : bhi;
     const int hi = lo + per < bhi ? lo + per : bhi;
     for (int k = t; k < 16 * kRadix; k += 1024) s_hist[k] = 0;
@@ -179,17 +181,26 @@ static inline int key_bits_for(uint32_t max_key) {
     return b;
 }
 
+// Small arrays take 2048-key tiles: with 16384-key tiles the 24 576 references of a B = 8192 batch are two workgroups
+// (two CUs) per pass, ~30 us each; twelve workgroups bring a pass to the launch-bound floor.
+constexpr int kSortTileSmall = 2048, kSortSmallMax = 1 << 17;
+static inline int sort_tile_for(int n) { return n <= kSortSmallMax ? kSortTileSmall : kSortTile; }
+static inline size_t sort_hist_words(int n) { const int t = sort_tile_for(n); return (size_t)kRadix * ((n + t - 1) / t); }
+
 // Sorts n pairs held in (ka,va) with (kb,vb) as the second buffer; returns 0 if the result is in (ka,va), 1 if in
-// (kb,vb).  ghist: 256 * ceil(n / kSortTile) words.
+// (kb,vb).  ghist: sort_hist_words(n) words.
 static inline int launch_radix_sort(uint32_t *ka, uint32_t *va, uint32_t *kb, uint32_t *vb, int n, uint32_t max_key,
                                     uint32_t *ghist, hipStream_t st) {
-    const int nblk = (n + kSortTile - 1) / kSortTile, bits = key_bits_for(max_key);
+    const int tile = sort_tile_for(n);
+    const int nblk = (n + tile - 1) / tile, bits = key_bits_for(max_key);
     int flip = 0;
     for (int shift = 0; shift < bits; shift += 8) {
         uint32_t *kin = flip ? kb : ka, *vin = flip ? vb : va, *kout = flip ? ka : kb, *vout = flip ? va : vb;
-        k_rs_count<<<nblk, 1024, 0, st>>>(kin, n, shift, ghist, nblk);
+        if (tile == kSortTileSmall) k_rs_count<kSortTileSmall><<<nblk, 1024, 0, st>>>(kin, n, shift, ghist, nblk);
+        else k_rs_count<kSortTile><<<nblk, 1024, 0, st>>>(kin, n, shift, ghist, nblk);
         k_rs_scan<<<1, 1024, 0, st>>>(ghist, kRadix * nblk);
-        k_rs_scatter<<<nblk, 1024, 0, st>>>(kin, vin, kout, vout, n, shift, ghist, nblk);
+        if (tile == kSortTileSmall) k_rs_scatter<kSortTileSmall><<<nblk, 1024, 0, st>>>(kin, vin, kout, vout, n, shift, ghist, nblk);
+        else k_rs_scatter<kSortTile><<<nblk, 1024, 0, st>>>(kin, vin, kout, vout, n, shift, ghist, nblk);
         flip ^= 1;
     }
     return flip;

@@ -1092,7 +1092,7 @@ struct PairWs {
     bool staged;        // large-batch path: staging + sorted references + segment reduce
     int32_t *perm, *us, *is, *js;            // small path: the batch grouped by positive item  [B] each
     uint32_t *ska, *sva, *skb, *svb;         // staged: sort buffers [3B] each
-    uint32_t *ghist;                         // staged: [256 * ceil(3B / kSortTile)]
+    uint32_t *ghist;                         // staged: [sort_hist_words(3B)]
     float *stage;                            // staged: [3][B][d] gradient rows in batch order
     int nblk_bwd;
     float *fwd;         // [7*Bp]
@@ -1134,7 +1134,7 @@ static PairWs carve_pair_ws(void *base, int B, int d, bool force_staged = false)
     if (w.staged) {
         w.ska = static_cast<uint32_t *>(take(nsort * 4)); w.sva = static_cast<uint32_t *>(take(nsort * 4));
         w.skb = static_cast<uint32_t *>(take(nsort * 4)); w.svb = static_cast<uint32_t *>(take(nsort * 4));
-        w.ghist = static_cast<uint32_t *>(take((size_t)kRadix * ((nsort + kSortTile - 1) / kSortTile) * 4));
+        w.ghist = static_cast<uint32_t *>(take(sort_hist_words((int)nsort) * 4));
         w.stage = static_cast<float *>(take(nsort * d * 4));
     } else {
         w.perm = static_cast<int32_t *>(take((size_t)B * 4)); w.us = static_cast<int32_t *>(take((size_t)B * 4));
