@@ -235,11 +235,10 @@ def main():
         from macr_amd.sampler import DeviceSampler
         lists = synth.interaction_lists(cfg["n_users"], cfg["n_items"], cfg["n_train"] / cfg["n_users"], seed=4242 + rank)
         smp = DeviceSampler(lists, cfg["n_users"], cfg["n_items"], B, dev, seed=99 + rank)
-        buf = torch.empty((3, B), dtype=torch.int32, device=dev)
 
         def run_e2e(n):
             for s_ in range(n):
-                smp.sample(out=buf)                      # same stream: the step reads what the sampler just wrote
+                buf = smp.sample()                       # same stream; one launch draws the next 32 batches (macr_sample_triples_many)
                 state.step(kind, buf[0], buf[1], buf[2], loss_log[s_ % n_batches], defer=not args.no_defer)
             state.flush()
         run_e2e(args.warmup)
@@ -252,8 +251,8 @@ def main():
             e2e.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))
         t_e2e = float(np.median(e2e))
         end_to_end = {"interactions_per_s": world * B * args.steps / t_e2e, "ms_per_step": 1e3 * t_e2e / args.steps,
-                      "sampler": "device (macr_sample_triples: users without replacement, uniform positive of the user's "
-                                 "train list, rejection-sampled negative), one launch per step on the step's stream",
+                      "sampler": "device (macr_sample_triples_many: users without replacement, uniform positive of the user's "
+                                 "train list, rejection-sampled negative), one launch per 32 steps on the step's stream",
                       "host_sampler_note": "--sampler reference keeps the reference's python stream at ~1 M triples/s (host bound)"}
 
     # ------------------------------------------------------------- evaluator: full catalogue, masked, top-20 + metrics

@@ -51,6 +51,8 @@ __global__ __launch_bounds__(256) void k_sample_triples(uint64_t seed, uint64_t 
                                                         int32_t *__restrict__ out) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= B) return;
+    step += blockIdx.y;                                   // macr_sample_triples_many: one grid row per step
+    out += (size_t)blockIdx.y * 3 * B;
     const uint64_t key = mix64(seed * 0x9e3779b97f4a7c15ull + step);
     uint32_t slot;
     if (B <= n_pool) slot = feistel_perm((uint32_t)t, (uint32_t)n_pool, pool_bits, key);
@@ -80,6 +82,23 @@ extern "C" int macr_sample_triples(uint64_t seed, uint64_t step, int B, int n_it
     if (bits & 1) ++bits;                           // even width: two equal Feistel halves
     hipStream_t st = as_stream(stream);
     k_sample_triples<<<(B + 255) / 256, 256, 0, st>>>(seed, step, B, n_items, pool, n_pool, bits, train_ptr, train_idx, out);
+    MACR_CHECK_LAUNCH("sample_triples", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_sample_triples_many(uint64_t seed, uint64_t step0, int n_steps, int B, int n_items, const int32_t *pool,
+                                        int n_pool, const int32_t *train_ptr, const int32_t *train_idx, int32_t *out,
+                                        void *stream) {
+    using namespace macr;
+    MACR_REQUIRE(B > 0 && n_items > 0 && n_pool > 0 && n_steps > 0 && n_steps <= 65535, MACR_E_INVALID,
+                 "sample_triples_many: B=%d n_items=%d n_pool=%d n_steps=%d", B, n_items, n_pool, n_steps);
+    MACR_REQUIRE(train_ptr && train_idx && out, MACR_E_INVALID, "sample_triples_many: null pointer");
+    int bits = 1;
+    while ((1u << bits) < (unsigned)n_pool) ++bits;
+    if (bits & 1) ++bits;
+    hipStream_t st = as_stream(stream);
+    k_sample_triples<<<dim3((B + 255) / 256, n_steps), 256, 0, st>>>(seed, step0, B, n_items, pool, n_pool, bits, train_ptr,
+                                                                      train_idx, out);
     MACR_CHECK_LAUNCH("sample_triples", st);
     return MACR_OK;
 }

@@ -166,6 +166,16 @@ def test_device_sampler_distribution(ops):
     b = DeviceSampler(train, n_users, n_items, B, torch.device("cuda"), seed=3).sample().cpu().numpy()
     c = DeviceSampler(train, n_users, n_items, B, torch.device("cuda"), seed=4).sample().cpu().numpy()
     assert np.array_equal(a, b) and not np.array_equal(a, c)       # pure function of (seed, step)
+    # batches drawn ahead, 32 or 5 per launch (macr_sample_triples_many), are the batches of one launch per step
+    one = DeviceSampler(train, n_users, n_items, B, torch.device("cuda"), seed=3, ahead=1)
+    many = DeviceSampler(train, n_users, n_items, B, torch.device("cuda"), seed=3)
+    five = DeviceSampler(train, n_users, n_items, B, torch.device("cuda"), seed=3, ahead=5)
+    into = torch.empty((3, B), dtype=torch.int32, device="cuda")
+    for step in range(70):
+        want = one.sample().clone()
+        assert torch.equal(many.sample(), want) and torch.equal(five.sample(), want), step
+        if step % 9 == 0:                           # a caller-owned buffer takes a launch of its own, same stream of batches
+            assert torch.equal(one.sample(out=into), many.sample()) and five.sample() is not None
     big = DeviceSampler(train, n_users, n_items, 2048, torch.device("cuda"), seed=1, pool=list(range(0, 500, 2)))
     u, i, j = big.sample().cpu().numpy()           # B > pool: with replacement, only pool users
     assert set(u.tolist()) <= set(range(0, 500, 2)) and len(u) == 2048
