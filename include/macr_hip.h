@@ -202,9 +202,13 @@ int macr_sample_triples(uint64_t seed, uint64_t step, int B, int n_items, const 
                         const int32_t *train_ptr, const int32_t *train_idx, int32_t *out, void *stream);
 /* The batches of steps step0 .. step0 + n_steps - 1 in ONE launch: out [n_steps][3][B], batch k identical to what
  * macr_sample_triples(seed, step0 + k, ...) draws (the generator is keyed by (seed, step, triple)).  A training loop
- * that draws a few dozen batches ahead pays one launch per few dozen steps instead of 8 us per step. */
+ * that draws a few dozen batches ahead pays one launch per few dozen steps instead of 8 us per step.
+ *   excl_ptr / excl_idx (dev, may be NULL = the lists the positives come from): per user id, ascending item ids a
+ *   negative must avoid -- Data.sample_test of the LightGCN loader draws positives from the TEST lists and negatives
+ *   outside test and train lists (utility/load_data.py:214-254). */
 int macr_sample_triples_many(uint64_t seed, uint64_t step0, int n_steps, int B, int n_items, const int32_t *pool,
-                             int n_pool, const int32_t *train_ptr, const int32_t *train_idx, int32_t *out, void *stream);
+                             int n_pool, const int32_t *train_ptr, const int32_t *train_idx,
+                             const int32_t *excl_ptr, const int32_t *excl_idx, int32_t *out, void *stream);
 
 /* ---------------------------------------------------------------------------
  * SpMM plan (host side, built once per graph -- the adjacency never changes).

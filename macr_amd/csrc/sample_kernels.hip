@@ -48,6 +48,8 @@ __global__ __launch_bounds__(256) void k_sample_triples(uint64_t seed, uint64_t 
                                                         const int32_t *__restrict__ pool, int n_pool, int pool_bits,
                                                         const int32_t *__restrict__ train_ptr,
                                                         const int32_t *__restrict__ train_idx,
+                                                        const int32_t *__restrict__ excl_ptr,
+                                                        const int32_t *__restrict__ excl_idx,
                                                         int32_t *__restrict__ out) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= B) return;
@@ -60,12 +62,16 @@ __global__ __launch_bounds__(256) void k_sample_triples(uint64_t seed, uint64_t 
     const int user = pool ? pool[slot] : (int)slot;
     const int beg = train_ptr[user], len = train_ptr[user + 1] - beg;
     const int pos = len > 0 ? train_idx[beg + (int)below(draw(key, t, 1), (uint32_t)len)] : 0;
+    // negatives avoid the user's exclusion list: the list the positive came from, or a second one (the test-set sampler of
+    // LightGCN excludes test AND train items, utility/load_data.py:233-239)
+    const int32_t *xi = excl_ptr ? excl_idx : train_idx;
+    const int xbeg = excl_ptr ? excl_ptr[user] : beg, xlen = excl_ptr ? excl_ptr[user + 1] - xbeg : len;
     int neg = 0;
     for (uint32_t n = 2; n < 2 + 4096; ++n) {       // bounded: a user owning (almost) the whole catalogue cannot hang the GPU
         neg = (int)below(draw(key, t, n), (uint32_t)n_items);
-        int lo = 0, hi = len;                       // binary search in the ascending train list
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (train_idx[beg + mid] < neg) lo = mid + 1; else hi = mid; }
-        if (!(lo < len && train_idx[beg + lo] == neg)) break;
+        int lo = 0, hi = xlen;                      // binary search in the ascending list
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (xi[xbeg + mid] < neg) lo = mid + 1; else hi = mid; }
+        if (!(lo < xlen && xi[xbeg + lo] == neg)) break;
     }
     out[t] = user; out[B + t] = pos; out[2 * (size_t)B + t] = neg;
 }
@@ -81,24 +87,25 @@ extern "C" int macr_sample_triples(uint64_t seed, uint64_t step, int B, int n_it
     while ((1u << bits) < (unsigned)n_pool) ++bits;
     if (bits & 1) ++bits;                           // even width: two equal Feistel halves
     hipStream_t st = as_stream(stream);
-    k_sample_triples<<<(B + 255) / 256, 256, 0, st>>>(seed, step, B, n_items, pool, n_pool, bits, train_ptr, train_idx, out);
+    k_sample_triples<<<(B + 255) / 256, 256, 0, st>>>(seed, step, B, n_items, pool, n_pool, bits, train_ptr, train_idx, nullptr, nullptr, out);
     MACR_CHECK_LAUNCH("sample_triples", st);
     return MACR_OK;
 }
 
 extern "C" int macr_sample_triples_many(uint64_t seed, uint64_t step0, int n_steps, int B, int n_items, const int32_t *pool,
-                                        int n_pool, const int32_t *train_ptr, const int32_t *train_idx, int32_t *out,
-                                        void *stream) {
+                                        int n_pool, const int32_t *train_ptr, const int32_t *train_idx,
+                                        const int32_t *excl_ptr, const int32_t *excl_idx, int32_t *out, void *stream) {
     using namespace macr;
     MACR_REQUIRE(B > 0 && n_items > 0 && n_pool > 0 && n_steps > 0 && n_steps <= 65535, MACR_E_INVALID,
                  "sample_triples_many: B=%d n_items=%d n_pool=%d n_steps=%d", B, n_items, n_pool, n_steps);
     MACR_REQUIRE(train_ptr && train_idx && out, MACR_E_INVALID, "sample_triples_many: null pointer");
+    MACR_REQUIRE((excl_ptr == nullptr) == (excl_idx == nullptr), MACR_E_INVALID, "sample_triples_many: excl_ptr without excl_idx");
     int bits = 1;
     while ((1u << bits) < (unsigned)n_pool) ++bits;
     if (bits & 1) ++bits;
     hipStream_t st = as_stream(stream);
     k_sample_triples<<<dim3((B + 255) / 256, n_steps), 256, 0, st>>>(seed, step0, B, n_items, pool, n_pool, bits, train_ptr,
-                                                                      train_idx, out);
+                                                                      train_idx, excl_ptr, excl_idx, out);
     MACR_CHECK_LAUNCH("sample_triples", st);
     return MACR_OK;
 }

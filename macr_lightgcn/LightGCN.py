@@ -61,9 +61,12 @@ def pick_adjacency(adj_type):
 
 def train_epoch(model, kind, n_batch, loss_log, device_sampler=None, test_loss=False):
     """n_batch steps (LightGCN.py:765-790).  test_loss=True is the reference's second pass of n_batch loss-only
-    runs on data_generator.sample_test() batches (:799-819): same RNG consumption, no parameter update."""
+    runs on data_generator.sample_test() batches (:799-819): same RNG consumption, no parameter update
+    (with a device_sampler: that sampler's batches -- `--sampler device` builds one over the test lists)."""
     for idx in range(n_batch):
-        if test_loss:
+        if test_loss and device_sampler is not None:
+            batch = device_sampler.sample()
+        elif test_loss:
             users, pos_items, neg_items = data_generator.sample_test()
             batch = model.to_device_batch(users, pos_items, neg_items)
         elif device_sampler is not None:
@@ -157,11 +160,18 @@ def main(sweep=False):
     cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch, best_c_hr = 0., 0, 0, 0, 0, 0.
     n_batch = data_generator.n_train // args.batch_size + 1
     loss_log = torch.zeros((n_batch, 3), dtype=torch.float32, device=model.device)
-    device_sampler = None
+    device_sampler = test_sampler = None
     if args.sampler == "device":
         from macr_amd.sampler import DeviceSampler
         device_sampler = DeviceSampler(data_generator.train_items, data_generator.n_users, data_generator.n_items,
                                        args.batch_size, model.device, seed=seed, pool=data_generator.exist_users)
+        # sample_test (utility/load_data.py:214-254): users with test items, a positive from the user's TEST list, a
+        # negative outside her test and train lists
+        test_users = sorted(data_generator.test_set.keys())
+        both = {u: list(data_generator.test_set[u]) + list(data_generator.train_items.get(u, [])) for u in test_users}
+        test_sampler = DeviceSampler({u: sorted(data_generator.test_set[u]) for u in test_users}, data_generator.n_users,
+                                     data_generator.n_items, args.batch_size, model.device, seed=seed + 1, pool=test_users,
+                                     exclude=both)
     elif args.sampler != "reference":
         raise SystemExit("--sampler must be reference or device")
     for epoch in range(start_epoch, args.epoch + 1):
@@ -176,7 +186,7 @@ def main(sweep=False):
             continue
 
         # the reference's "test loss" pass (:799-819): n_batch loss-only runs on sample_test() batches
-        loss_test, mf_loss_test, emb_loss_test = train_epoch(model, kind, n_batch, loss_log, test_loss=True)
+        loss_test, mf_loss_test, emb_loss_test = train_epoch(model, kind, n_batch, loss_log, test_sampler, test_loss=True)
         t2 = time()
         users_to_test = list(data_generator.test_set.keys())
         sharding.broadcast_params(model.parameters())       # item-sharded evaluation scores ONE model (rank 0's)

@@ -176,6 +176,14 @@ def test_device_sampler_distribution(ops):
         assert torch.equal(many.sample(), want) and torch.equal(five.sample(), want), step
         if step % 9 == 0:                           # a caller-owned buffer takes a launch of its own, same stream of batches
             assert torch.equal(one.sample(out=into), many.sample()) and five.sample() is not None
+    # LightGCN's sample_test: positives from the TEST lists, negatives outside test and train lists
+    test_l = {u: sorted(rs.choice(n_items, size=3, replace=False).tolist()) for u in range(0, n_users, 3)}
+    both = {u: test_l[u] + train[u] for u in test_l}
+    ts = DeviceSampler(test_l, n_users, n_items, 128, torch.device("cuda"), seed=8, pool=sorted(test_l), exclude=both)
+    for step in range(40):
+        u, i, j = ts.sample().cpu().numpy()
+        for uu, ii, jj in zip(u, i, j):
+            assert uu in test_l and ii in test_l[uu] and jj not in test_l[uu] and jj not in train[uu]
     big = DeviceSampler(train, n_users, n_items, 2048, torch.device("cuda"), seed=1, pool=list(range(0, 500, 2)))
     u, i, j = big.sample().cpu().numpy()           # B > pool: with replacement, only pool users
     assert set(u.tolist()) <= set(range(0, 500, 2)) and len(u) == 2048
