@@ -545,11 +545,21 @@ def test_score_topk_random_shapes(ops, seed):
     c = float(rs.choice([0.0, 3.0, 40.0]))
     want_v, want_i, want_c = oracle.score_topk(kind, P[user_ids], Q, K, sig_u, sig_i, c, (mptr, midx), off)
     mask = ops.CSR(dev(mptr), dev(midx if len(midx) else np.zeros(1, np.int32)))
-    vals, idx = ops.score_topk(kind, dev(P), dev(user_ids), dev(Q), K, sig_u_hip, sig_i_hip, c, mask, off)
+    seeds = torch.full((U, ops.SEED_WIDTH), -1, dtype=torch.int32, device="cuda")
+    vals, idx = ops.score_topk(kind, dev(P), dev(user_ids), dev(Q), K, sig_u_hip, sig_i_hip, c, mask, off, seed_out=seeds)
     gv, gi, gc = ops.topk_merge(vals, idx)
     assert np.array_equal(gi.cpu().numpy(), want_i), (U, N, d, K, off, kind, per_user)
     assert np.array_equal(gc.cpu().numpy(), want_c)
     assert np.array_equal(gv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+    # ... and the same ranking again with its own best candidates as threshold seeds (in place), on slightly moved tables
+    Q2 = (Q + rs.standard_normal(Q.shape).astype(np.float32) * 0.02).astype(np.float32)
+    sig_i2 = ops.branch_sigmoid(dev(Q2), dev(w))
+    want_v2, want_i2, want_c2 = oracle.score_topk(kind, P[user_ids], Q2, K, sig_u, sig_i2.cpu().numpy(), c, (mptr, midx), off)
+    vals, idx = ops.score_topk(kind, dev(P), dev(user_ids), dev(Q2), K, sig_u_hip, sig_i2, c, mask, off, seed=seeds, seed_out=seeds)
+    gv, gi, gc = ops.topk_merge(vals, idx)
+    assert np.array_equal(gi.cpu().numpy(), want_i2), ("seeded", U, N, d, K, off, kind, per_user)
+    assert np.array_equal(gc.cpu().numpy(), want_c2)
+    assert np.array_equal(gv.cpu().numpy().view(np.uint32), want_v2.view(np.uint32))
 
 
 def test_score_topk_all_scores_tie(ops):
