@@ -266,3 +266,52 @@ def test_config4_shard_size_training_step(ops):
     assert float(model.mP[torch.from_numpy(free).cuda()].abs().max()) == 0.0
     np.testing.assert_allclose(model.w.cpu().numpy(), wo, rtol=0, atol=tol)
     assert int(model.tP.sum()) == 0 and int(model.tQ.sum()) == 0
+
+
+@pytest.mark.parametrize("workload", ["gowalla", "ml10m"])
+def test_fullsize_seeded_rankings_at_every_staleness(ops, workload):
+    """Threshold seeds at full size (512 resident workgroups, 61 blocks of 256 queries on Gowalla shapes): the ranking
+    leaves its best candidates, the tables then move by a little, by a lot, or are replaced, and the seeded ranking
+    (good seeds; seeds that are stale for SOME query blocks: early stop of single blocks, repair round for those; seeds
+    that are stale everywhere: every block stops within a few tiles) must equal the unseeded ranking of the same
+    tables in every id and every score bit, for all users.  stats tell which path ran."""
+    from macr_amd import synth
+    cfg = synth.WORKLOADS[workload]
+    d, K = cfg["d"], 20
+    rs = np.random.RandomState(4)
+    P = (rs.standard_normal((cfg["n_users"], d)) * 0.3).astype(np.float32)
+    Q = (rs.standard_normal((cfg["n_items"], d)) * 0.3).astype(np.float32)
+    Q[:, 0] += np.sort(rs.standard_normal(cfg["n_items"]))[::-1].astype(np.float32)
+    P[:, 0] = np.abs(P[:, 0])
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    users, mask, gt = synth.eval_problem(cfg, seed=3)
+    U = len(users)
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    uid, Pd, wd, wud = dev(users), dev(P), dev(w), dev(wu)
+    sig_u = ops.branch_sigmoid(Pd, wud, uid)
+    seeds = torch.full((U, ops.SEED_WIDTH), -1, dtype=torch.int32, device="cuda")
+    stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    Qd = dev(Q)
+    ops.score_topk(ops.SCORE_RUBI_BOTH, Pd, uid, Qd, K, sig_u, ops.branch_sigmoid(Qd, wd), 40.0, mcsr, seed_out=seeds)
+    blocks = (U + 255) // 256
+    seen = []
+    for name, noise, rows in (("drift", 0.003, None), ("partly stale", 0.6, slice(0, cfg["n_items"] // 9)), ("replaced", None, None)):
+        Q2 = Q.copy()
+        if noise is None:
+            Q2 = (rs.standard_normal(Q.shape) * 0.3).astype(np.float32)
+        elif rows is None:
+            Q2 += rs.standard_normal(Q.shape).astype(np.float32) * noise
+        else:
+            Q2[rows] += rs.standard_normal(Q2[rows].shape).astype(np.float32) * noise
+        Q2d = dev(Q2)
+        sig_i = ops.branch_sigmoid(Q2d, wd)
+        v0, i0 = ops.score_topk(ops.SCORE_RUBI_BOTH, Pd, uid, Q2d, K, sig_u, sig_i, 40.0, mcsr)
+        sd = seeds.clone()
+        v1, i1 = ops.score_topk(ops.SCORE_RUBI_BOTH, Pd, uid, Q2d, K, sig_u, sig_i, 40.0, mcsr, seed=sd, seed_out=sd, stats=stats)
+        assert torch.equal(i0, i1), name
+        assert torch.equal(v0.view(torch.int32), v1.view(torch.int32)), name
+        assert torch.equal(sd[:, :K], i1[0]), name
+        seen.append(stats.tolist())
+    assert seen[0] == [0, 0], seen                        # seeds that hold: no block listed twice
+    assert seen[2][0] == blocks and seen[2][1] == 0, seen  # replaced tables: every block re-listed, no exact fallback
+    assert seen[1][1] == 0, seen
