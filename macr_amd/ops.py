@@ -14,7 +14,11 @@ from ._lib import (LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, LOSS_RUBIBCE, SCORE_NORMAL,
                    Hyper, MacrError, check)
 
 
-def _stream():
+def _stream(device_index=None):
+    """the current HIP stream of the device as a void*.  torch.cuda.current_stream() costs ~8 us of Python per call --
+    a quarter of a 36 us training step -- so the per-step callers pass their device index and take the raw handle."""
+    if device_index is not None:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(device_index))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -339,10 +343,18 @@ class MFState(object):
             self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.P.device)
             self.batch_cap = B
 
+    _TABLE_NAMES = ("P", "Q", "w", "wu", "mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu", "gP", "gQ", "tP", "tQ")
+
     def _tables(self):
-        return (_ptr(self.P), _ptr(self.Q), _ptr(self.w), _ptr(self.wu), _ptr(self.mP), _ptr(self.vP), _ptr(self.mQ),
-                _ptr(self.vQ), _ptr(self.mw), _ptr(self.vw), _ptr(self.mwu), _ptr(self.vwu), _ptr(self.gP),
-                _ptr(self.gQ), _ptr(self.tP), _ptr(self.tQ))
+        """the 16 table pointers of the C calls, rebuilt only when one of the tensors was replaced (a step is ~36 us:
+        sixteen data_ptr() round trips per call were 8 us of it)"""
+        ids = tuple(id(getattr(self, n)) for n in self._TABLE_NAMES) + (id(self.adam_pow),)
+        if getattr(self, "_tab_ids", None) != ids:
+            self._tab_ptrs = tuple(_ptr(getattr(self, n)) for n in self._TABLE_NAMES)
+            self._tab_ids = ids
+            self._dev_index = self.P.device.index if self.P.device.index is not None else torch.cuda.current_device()
+            self._pow_ptr = _ptr(self.adam_pow)
+        return self._tab_ptrs
 
     def step(self, kind, u, i, j, losses=None, defer=False):
         """One training step; u,i,j int32 device tensors.  Returns the (3,) device loss tensor.
@@ -357,10 +369,11 @@ class MFState(object):
         if self.pending_B and kind != self.pending_kind:
             self.flush()
         flags = (_lib.STEP_DEFER if defer else 0) | (_lib.STEP_PENDING if self.pending_B else 0)
+        tabs = self._tables()
         check(_lib.lib().macr_mf_train_step(
             kind, B, self.d, self.P.shape[0], self.Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
-            *self._tables(), _ptr(self.adam_pow), ctypes.byref(self.hyper),
-            _ptr(out, _f32), flags, _ptr(self.ws), self.ws.numel(), _stream()))
+            *tabs, self._pow_ptr, ctypes.byref(self.hyper),
+            _ptr(out, _f32), flags, _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
         self.pending_B = B if defer else 0
         self.pending_kind = kind
         return out
@@ -370,7 +383,7 @@ class MFState(object):
         if self.pending_B:
             check(_lib.lib().macr_mf_train_flush(
                 self.pending_kind, self.pending_B, self.d, self.P.shape[0], self.Q.shape[0], *self._tables(),
-                ctypes.byref(self.hyper), _ptr(self.ws), self.ws.numel(), _stream()))
+                ctypes.byref(self.hyper), _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
             self.pending_B = 0
 
 
