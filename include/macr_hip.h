@@ -214,8 +214,8 @@ int macr_sample_triples_many(uint64_t seed, uint64_t step0, int n_steps, int B, 
  * SpMM plan (host side, built once per graph -- the adjacency never changes).
  * Interaction graphs have hub rows (items with 10^4..10^5 neighbours); the plan
  * cuts rows longer than 512 non-zeros into work items of 512 so that no single
- * wavefront serialises a hub, and lists the rows whose partial sums a fix-up
- * kernel combines (in fixed order: deterministic, no atomics).
+ * wavefront serialises a hub; the piece of a hub row that finishes last sums the
+ * partial rows in fixed order (deterministic whichever piece that is).
  *   rowptr_host (HOST) int32[N+1]
  *   plan_host   (HOST) >= macr_spmm_plan_bytes(N, rowptr_host) bytes, written by
  *               macr_spmm_plan_build; the caller uploads a copy to the device and
@@ -236,7 +236,8 @@ size_t macr_lgcn_work_floats(int N, int d, const void *plan_host);   /* size of 
  *   rowptr (dev) int32[N+1], col (dev) int32[nnz], val (dev) fp32[nnz]
  *   plan_dev (dev) / plan_host (HOST): the SpMM plan, or both NULL
  *   E0 (dev) fp32[N*d] in, E (dev) fp32[N*d] out
- *   work (dev) fp32[macr_lgcn_work_floats(N, d, plan_host)] scratch
+ *   work (dev) fp32[macr_lgcn_work_floats(N, d, plan_host)] scratch.  ZERO-FILL IT ONCE before its first use: with a
+ *            plan it holds the hub rows' arrival counters, which every call leaves at zero again.
  * The same call is the backward pass (A symmetric): feed dE, get dE0.
  * -------------------------------------------------------------------------*/
 int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col,
@@ -249,7 +250,9 @@ int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *rowptr, const
  * the regulariser on the ego rows (:525-527), dense gradients through the
  * propagation, Adam (:186 / :201).
  *   T (dev) fp32[N*d] = [user_embedding ; item_embedding], updated in place
- *   mT,vT Adam slots;  workspace (dev) >= macr_lgcn_train_workspace_bytes(B,N,d,plan_host) bytes
+ *   mT,vT Adam slots;  workspace (dev) >= macr_lgcn_train_workspace_bytes(B,N,d,plan_host) bytes, ZERO-FILLED ONCE
+ *          before its first use (the batch-row flags and the hub rows' arrival counters are zero
+ *          between steps: every step leaves them that way)
  *   losses (dev) fp32[3] = {loss, mf_loss, emb_loss}
  *   flags  0, or MACR_STEP_LOSS_ONLY: sess.run([loss_X, mf_loss_X, emb_loss_X]) without opt_X -- the
  *          reference's per-log-interval "test loss" pass (LightGCN.py:799-819, train_thread_test :620-647):

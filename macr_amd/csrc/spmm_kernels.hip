@@ -5,37 +5,54 @@
 // stack/reduce_mean of :306-307.  A_hat = D^-1/2 A D^-1/2 in CSR
 // (macr_lightgcn/utility/load_data.py:112-121), X is the (N,d) embedding table.
 //
-// One wave per WORK ITEM; the wave is split into 64/LPR neighbour groups, each
-// group streams one neighbour row as LPR lanes x float4 (a coalesced 256-B read at
-// d=64), two neighbours in flight per group.  The groups' partial rows are combined
-// with cross-lane shuffles; group 0 writes the row.
-// Work items come from a static plan (the graph never changes): a row with at most
-// kChunk non-zeros is one item and is written with the fused epilogue; a longer row
-// (interaction graphs have hub items with 10^4..10^5 neighbours -- Addressa item 0 has
-// 7077, the Zipf synthetic Yelp-size graph 1.2e5) is cut into kChunk-sized items whose
-// partial rows go to a scratch slab and are summed, in slot order (deterministic, no
-// atomics), by a small fix-up kernel that also applies the epilogue.  Without the split
-// one wave serialises the whole hub row: 1.65 ms per layer instead of ~0.1 ms.
-// HBM-bound: compulsory bytes per layer nnz*8 + (N+1)*4 + 2*N*d*4;
-// X itself is Infinity-Cache resident for every real dataset.
+// THE WAVE IS THE ROW.  Lane l owns column l of the output row (columns l, l+64, ... at d >= 128; at d = 32 the two
+// half-waves take alternate neighbours and are added at the end).  A neighbour row is then ONE coalesced dword load
+// per lane whose base address is wave-uniform: column index and weight come out of the chunk's index registers
+// (lane l <- entry base+l, one coalesced load each) with v_readlane, the address is scalar arithmetic, the product is
+// a v_fmac with a scalar weight.  No cross-lane shuffles, no reduction tree, a row pads to a multiple of 8 entries.
+//
+// What a gather costs on this chip (tools/ta_bench.hip, every CU loaded, L1/L2-resident rows): a wave-level
+// `global_load_dwordx4` takes ~16 cycles of its CU's vector memory pipe HOWEVER MANY LANES ARE ENABLED, a
+// `global_load_dword` (64 lanes x 4 B = one 256-byte row) ~5 cycles; rows that miss the XCD's 4 MB L2 arrive at
+// ~10 TB/s chip-wide (17 cycles per 256-byte row and CU) whatever the instruction.  The first two versions of this
+// file gathered float4 per lane, four rows per instruction, in rounds of 16 entries: 857 k wave loads for the 683 k
+// the Yelp2018-shape graph needs (every row pads to a multiple of 16), plus ~78 pipe cycles per work item for its
+// descriptor, index, S_in and 16-lane float4 epilogue accesses.  Measured on the way (DESIGN.md section 4 has the table):
+// redirecting every gather to 64 L1-resident rows took a layer from 60 to 46 us -- the kernel sits on the vector
+// memory pipe, and the misses (29 % of the gathered rows at a 17.8 MB table) cost as much as all hits together; pinning
+// the two sides of the bipartite graph to XCD halves, non-temporal loads for cold rows / index streams, hub pieces
+// ordered by source range, and a persistent variant that kept two gather rounds in flight across row boundaries
+// all lowered FETCH_SIZE or the trip count and were slower or equal in time.
+//
+// Work items come from a static plan (the graph never changes): a row with at most kChunk non-zeros is one item; a
+// longer row (interaction graphs have hub items with 10^4..10^5 neighbours -- Addressa item 0 has 7077, the Zipf
+// synthetic Yelp-size graph 3*10^4) is cut into kChunk-sized PIECES whose partial rows go to a scratch slab; the piece
+// that finishes LAST (one counter per hub row) sums the partials in slot order -- deterministic whichever piece that
+// is -- and applies the epilogue.  (Until round 3 a fix-up kernel did that: four more launches per training step.)
+// HBM-bound: compulsory bytes per layer nnz*8 + (N+1)*4 + 2*N*d*4.
 #include "common.hpp"
 
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 namespace macr {
 
-constexpr int kChunk = 512;       // non-zeros per work item
+constexpr int kChunk = 512;       // non-zeros per work item (kernel-development knob: MACR_SPMM_CHUNK in the environment)
 
 struct PlanHeader {               // all int32, followed by the arrays below
-    int32_t magic, n_items, n_split, n_slots, N, reserved[3];
+    int32_t magic, n_items, n_split, n_slots, N, chunk, reserved[2];
 };
-constexpr int32_t kPlanMagic = 0x4d414352;   // "MACR"
-// layout after the header:  item_row[n_items] item_beg[n_items] item_end[n_items] item_slot[n_items]
-//                           split_row[n_split] split_slot0[n_split+1]
+constexpr int32_t kPlanMagic = 0x4d414354;   // "MACT" (layout 3)
+// layout after the header (32 bytes, so the descriptors are 16-byte aligned):
+//   item[n_items] = {row, beg, end, slot}   the n_slots pieces of the split rows first (slot >= 0), then the other rows
+//                                           (slot = -1), longest first
+//   split_row[n_split] split_slot0[n_split+1]   hub row k owns slots split_slot0[k] .. split_slot0[k+1]-1
+//   slot_split[n_slots]                         the hub row (index k) a slot belongs to
 
 struct PlanView {
-    const int32_t *item_row, *item_beg, *item_end, *item_slot, *split_row, *split_slot0;
+    const int4 *item;
+    const int32_t *split_row, *split_slot0, *slot_split;
     int n_items, n_split, n_slots;
 };
 
@@ -43,225 +60,266 @@ __device__ __host__ inline PlanView view_plan(const void *plan, const PlanHeader
     const int32_t *p = reinterpret_cast<const int32_t *>(plan) + sizeof(PlanHeader) / 4;
     PlanView v;
     v.n_items = h.n_items; v.n_split = h.n_split; v.n_slots = h.n_slots;
-    v.item_row = p; p += h.n_items;
-    v.item_beg = p; p += h.n_items;
-    v.item_end = p; p += h.n_items;
-    v.item_slot = p; p += h.n_items;
+    v.item = reinterpret_cast<const int4 *>(p); p += 4 * (size_t)h.n_items;
     v.split_row = p; p += h.n_split;
-    v.split_slot0 = p;
+    v.split_slot0 = p; p += h.n_split + 1;
+    v.slot_split = p;
     return v;
 }
 
-// Sum of val[e] * X[col[e]] over e in [beg, end) for one row (or one 512-nnz slice of a hub row), by one wave: the
-// 64/LPR lane groups take neighbours grp, grp+NG, ... (each group in ascending order: the summation tree is fixed).
-// The wave first fetches the indices and values of up to 64 neighbours with ONE coalesced load each (lane l <- entry
-// beg+l) and hands them to the groups by shuffles, then keeps FOUR row gathers in flight per group.  The first
-// version loaded col/val per group (16 lanes reading the same word, a dependent trip in front of every pair of row
-// gathers) and kept two gathers in flight: a wave with the average 39 neighbours needed ~10 dependent trips.
-// Measured on Yelp2018 shapes (tools/bench_lgcn.py): 75 -> 56.5 us per layer, LightGCN step 376 -> 305 us.  Depth 2: 59 us,
-// 8: 67 us, 16: 96 us (padding entries of the last round gather too); guarding the padded gathers with a wave-uniform
-// test costs more than it saves (70 us: the guards become branches with their own waits).
-#ifdef MACR_ABL_SPMM_V1
-template <int LPR>
-__device__ __forceinline__ float4 gather_range(const int32_t *__restrict__ col, const float *__restrict__ val,
-                                               const float *__restrict__ X, int beg, int end, int sub, int grp) {
-    constexpr int d = 4 * LPR;
-    constexpr int NG = kWave / LPR;                 // neighbour groups per wave
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int e = beg + grp;
-    for (; e + NG < end; e += 2 * NG) {             // two neighbours per group in flight
-        const int c0 = col[e], c1 = col[e + NG];
-        const float a0 = val[e], a1 = val[e + NG];
-        const float4 x0 = ld4(X + (size_t)c0 * d + 4 * sub);
-        const float4 x1 = ld4(X + (size_t)c1 * d + 4 * sub);
-        acc = fma4(a0, x0, acc);
-        acc = fma4(a1, x1, acc);
-    }
-    if (e < end) acc = fma4(val[e], ld4(X + (size_t)col[e] * d + 4 * sub), acc);
-#pragma unroll
-    for (int m = LPR; m < kWave; m <<= 1) {
-        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
-        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
-    }
-    return acc;
-}
-#else
-template <int LPR>
-__device__ __forceinline__ float4 gather_range(const int32_t *__restrict__ col, const float *__restrict__ val,
-                                               const float *__restrict__ X, int beg, int end, int sub, int grp) {
-    constexpr int d = 4 * LPR;
-    constexpr int NG = kWave / LPR;                 // neighbour groups per wave
-    constexpr int PER = kWave / NG;                 // neighbours per group in a 64-entry chunk (= LPR)
-#ifndef MACR_SPMM_DEPTH
-#define MACR_SPMM_DEPTH 4
-#endif
-    constexpr int DEPTH = MACR_SPMM_DEPTH < PER ? MACR_SPMM_DEPTH : PER;      // row gathers in flight per group
-    const int lane = threadIdx.x & 63;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = beg; base < end; base += kWave) {           // wave-uniform
-        const int n = end - base < kWave ? end - base : kWave;  // entries of this chunk
-        const int ec = base + (lane < n ? lane : n - 1);
-        const int cv = col[ec];
-        const float av = lane < n ? val[ec] : 0.f;              // padding entries add 0 * X[valid row]
-        // group grp takes entries grp, grp+NG, ... of the chunk; rounds of DEPTH gathers in flight
-#pragma unroll
-        for (int k0 = 0; k0 < PER; k0 += DEPTH) {
-            if (k0 * NG >= n) break;                            // wave-uniform: nothing left in this chunk
-            int c[DEPTH]; float a[DEPTH]; float4 x[DEPTH];
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) {
-                const int src = (k0 + k) * NG + grp;            // < 64: PER is a multiple of DEPTH
-                c[k] = __shfl(cv, src, kWave); a[k] = __shfl(av, src, kWave);
-            }
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) x[k] = ld4(X + (size_t)c[k] * d + 4 * sub);
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) acc = fma4(a[k], x[k], acc);
-        }
-    }
-#pragma unroll
-    for (int m = LPR; m < kWave; m <<= 1) {
-        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
-        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
-    }
-    return acc;
-}
-#endif
-
-// gather_range for a ROW-SPARSE X: only rows with active[row] != 0 are non-zero (the gradient of a LightGCN batch
-// touches <= 3B rows of the table), so the other neighbours are dropped before anything is gathered.  Per 64-entry
-// chunk: one byte gather of the flags, a ballot, the surviving (col, val) pairs are packed into the wave's 512 bytes
-// of LDS in entry order and the groups take them from there.  A chunk without an active neighbour costs its index
-// load and the flag gather.  (The summation tree differs from gather_range's -- same terms, other grouping.)
-template <int LPR>
-__device__ __forceinline__ float4 gather_range_active(const int32_t *__restrict__ col, const float *__restrict__ val,
-                                                      const float *__restrict__ X, const uint8_t *__restrict__ active,
-                                                      int beg, int end, int sub, int grp, int2 *s_ent) {
-    constexpr int d = 4 * LPR;
-    constexpr int NG = kWave / LPR;
-    constexpr int PER = kWave / NG;
-    constexpr int DEPTH = 4 < PER ? 4 : PER;
-    const int lane = threadIdx.x & 63;
-    const uint64_t below = (1ull << lane) - 1ull;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = beg; base < end; base += kWave) {           // wave-uniform
-        const int n = end - base < kWave ? end - base : kWave;
-        const int ec = base + (lane < n ? lane : n - 1);
-        const int cv = col[ec];
-        const bool act = lane < n && active[cv] != 0;
-        const uint64_t m = __ballot(act);
-        if (m == 0ull) continue;                                // wave-uniform
-        const float av = val[ec];
-        const int na = __popcll(m);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous chunk's reads of s_ent are done
-        if (act) s_ent[__popcll(m & below)] = make_int2(cv, __float_as_int(av));
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int2 pad = s_ent[0];                              // a valid row for the unguarded gathers of padding slots
-#pragma unroll
-        for (int k0 = 0; k0 < PER; k0 += DEPTH) {
-            if (k0 * NG >= na) break;                           // wave-uniform
-            int c[DEPTH]; float a[DEPTH]; float4 x[DEPTH];
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) {
-                const int src = (k0 + k) * NG + grp;
-                const int2 e = s_ent[src < na ? src : 0];
-                c[k] = src < na ? e.x : pad.x;
-                a[k] = src < na ? __int_as_float(e.y) : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) x[k] = ld4(X + (size_t)c[k] * d + 4 * sub);
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) acc = fma4(a[k], x[k], acc);
-        }
-    }
-#pragma unroll
-    for (int m = LPR; m < kWave; m <<= 1) {
-        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
-        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
-    }
-    return acc;
-}
-
-// s_on: 0 = S_in[r] is to be taken as zero (a row-sparse S_in whose inactive rows were never written)
-template <int LPR>
-__device__ __forceinline__ void write_row(int r, int sub, float4 acc, float *Y, const float *S_in, float *S_out, float scale,
-                                          bool s_on = true) {
-    constexpr int d = 4 * LPR;
-    const size_t o = (size_t)r * d + 4 * sub;
-    if (Y) st4(Y + o, acc);
-    if (S_out) {
-        const float4 s = s_on ? ld4(S_in + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-        st4(S_out + o, make_float4((s.x + acc.x) * scale, (s.y + acc.y) * scale, (s.z + acc.z) * scale, (s.w + acc.w) * scale));
-    }
-}
-
-// Y = A X (if Y), S_out = (S_in + A X) * scale (if S_out; may alias S_in: updated in place row by row).
-// SPARSE (a LightGCN training step only needs the propagated rows of its batch, and its gradient enters the backward
-// propagation with <= 3B non-zero rows; rows[] = 1 for those rows):
-//   kSparseOut  only rows with rows[r] != 0 are computed (the LAST forward layer: nothing else is read afterwards)
+// SPARSE modes (a LightGCN training step only needs the propagated rows of its batch, and its gradient enters the
+// backward propagation with <= 3B non-zero rows):
+//   kSparseOut  only the rows the batch refers to (and every hub row) are computed (the LAST forward layer: nothing
+//               else is read afterwards).  One wave per batch reference -- a row referred to twice is computed twice,
+//               to the same values; the hub rows, which hold the repeats of a popularity-skewed batch, are left to
+//               their pieces.  (Building a duplicate-free row list first costs more than it saves: the atomics that
+//               detect a row's first reference queue on the hot items' cache lines, ~24 ns each: 45 us per batch.)
 //   kSparseIn   X and S_in are row-sparse: only rows with rows[.] != 0 are read (the FIRST backward layer)
 constexpr int kDense = 0, kSparseOut = 1, kSparseIn = 2;
-template <int LPR, int SPARSE>
-__global__ __launch_bounds__(256) void k_spmm_csr(int N, const int32_t *__restrict__ rowptr,
-                                                  const int32_t *__restrict__ col, const float *__restrict__ val,
-                                                  const void *__restrict__ plan, PlanHeader ph,
-                                                  const float *__restrict__ X, float *Y, const float *S_in,
-                                                  float *S_out, float scale, float *__restrict__ slab,
-                                                  const uint8_t *__restrict__ rows) {
-    constexpr int d = 4 * LPR;
-    __shared__ int2 s_ent[SPARSE == kSparseIn ? 4 * kWave : 1];
-    const int lane = threadIdx.x & 63;
-    const int sub = lane % LPR, grp = lane / LPR;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int r, beg, end, slot = -1;
-    if (plan) {
-        const PlanView pv = view_plan(plan, ph);
-        if (w >= pv.n_items) return;
-        r = pv.item_row[w]; beg = pv.item_beg[w]; end = pv.item_end[w]; slot = pv.item_slot[w];
-    } else {
-        if (w >= N) return;
-        r = w; beg = rowptr[r]; end = rowptr[r + 1];
+
+struct SparseCtx {                // device pointers
+    const uint8_t *rows;          // [N] 1 = a row of the current batch
+    const int32_t *u, *i, *j;     // the batch: rows u[b], n_users + i[b], n_users + j[b]
+    int B, n_users;
+    int chunk;                    // rows longer than this are hub rows (cut into pieces by the plan); INT_MAX without a plan
+};
+
+struct SpmmArgs {
+    int N, n_items, n_slots;
+    const int32_t *rowptr, *col;
+    const float *val;
+    const int4 *items;            // NULL: no plan, item w = row w
+    const int32_t *split_row, *split_slot0, *slot_split;
+    int32_t *piece_cnt;           // [n_split] arrivals per hub row; zero between launches (the finisher resets its counter)
+    const float *X;
+    float *Y;
+    const float *S_in;
+    float *S_out;
+    float scale;
+    float *slab;                  // [n_slots][d] partial rows of the pieces
+    SparseCtx sp;
+};
+
+// Element (row c, column k) of a table below 4 GB (checked by the launcher): wave-uniform base + 32-bit byte offset, i.e.
+// one VALU instruction per gathered row (`v_lshl_add_u32` + `global_load_dword v, v_off, s[base]`) and no scalar one --
+// a CU has ONE scalar unit for its four SIMDs, and 64-bit address arithmetic per neighbour kept it busy.
+template <int D>
+__device__ __forceinline__ float ld_elem(const float *__restrict__ X, int c, int k) {
+    const uint32_t off = ((uint32_t)c * (uint32_t)D + (uint32_t)k) * 4u;
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(X) + off);
+}
+
+__device__ __forceinline__ bool row_flag(const uint8_t *__restrict__ rows, int r) { return rows[r] != 0; }
+
+// Lane geometry: D >= 64: lane l holds columns l + 64 v (v < NV), one entry per step; D = 32: lane l holds column
+// l % 32, the half-waves take alternate entries (two per step).
+template <int D> struct RowGeom {
+    static constexpr bool kHalf = D == 32;
+    static constexpr int NV = kHalf ? 1 : D / 64;
+    static constexpr int EPS = kHalf ? 2 : 1;       // entries per step
+    static constexpr int MAXNB = NV >= 4 ? 1 : NV == 2 ? 2 : 4;   // batches in flight: at most 32 row registers
+};
+
+// NB batches of 8 steps starting at entry e0 of the chunk held in (cv, av), all loads issued before the first use.
+// The batch count is a template parameter: a batch under a run-time guard makes its registers merge with the skipped
+// path, and the compiler resolves such a merge by waiting for the loads on the spot.
+template <int D, int NB>
+__device__ __forceinline__ void gather_batches(int cv, float av, int e0, const float *__restrict__ X, int lane,
+                                               float (&acc)[RowGeom<D>::NV]) {
+    using G = RowGeom<D>;
+    float x[NB * 8][G::NV]; float a[NB * 8];
+#pragma unroll
+    for (int k = 0; k < NB * 8; ++k) {
+        if (G::kHalf) {
+            const int c0 = __builtin_amdgcn_readlane(cv, e0 + 2 * k), c1 = __builtin_amdgcn_readlane(cv, e0 + 2 * k + 1);
+            const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), e0 + 2 * k));
+            const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), e0 + 2 * k + 1));
+            const int c = lane < 32 ? c0 : c1;
+            a[k] = lane < 32 ? a0 : a1;
+            x[k][0] = ld_elem<D>(X, c, lane & 31);
+        } else {
+            const int c = __builtin_amdgcn_readlane(cv, e0 + k);  // wave-uniform
+            a[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), e0 + k));
+#pragma unroll
+            for (int v = 0; v < G::NV; ++v) x[k][v] = ld_elem<D>(X, c, lane + 64 * v);
+        }
     }
-    if (SPARSE == kSparseOut && rows[r] == 0) return;
-    const float4 acc = SPARSE == kSparseIn
-                           ? gather_range_active<LPR>(col, val, X, rows, beg, end, sub, grp, s_ent + (threadIdx.x >> 6) * kWave)
-                           : gather_range<LPR>(col, val, X, beg, end, sub, grp);
-    if (grp == 0) {
-        if (slot < 0) write_row<LPR>(r, sub, acc, Y, S_in, S_out, scale, SPARSE != kSparseIn || rows[r] != 0);
-        else st4(slab + (size_t)slot * d + 4 * sub, acc);
+#pragma unroll
+    for (int k = 0; k < NB * 8; ++k) {
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) acc[v] = fmaf(a[k], x[k][v], acc[v]);
     }
 }
 
-// Sums the chunk partials of every split (hub) row and applies the epilogue.  One wave per hub row:
-// the 64/LPR groups take interleaved slots (two loads in flight each), then combine by shuffles --
-// a fixed summation tree, so the result is deterministic.
-template <int LPR, int SPARSE>
-__global__ __launch_bounds__(256) void k_spmm_fixup(const void *__restrict__ plan, PlanHeader ph,
-                                                    const float *__restrict__ slab, float *Y, const float *S_in,
-                                                    float *S_out, float scale, const uint8_t *__restrict__ rows) {
-    constexpr int d = 4 * LPR;
-    constexpr int NG = kWave / LPR;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane % LPR, grp = lane / LPR;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const PlanView pv = view_plan(plan, ph);
-    if (k >= pv.n_split) return;
-    if (SPARSE == kSparseOut && rows[pv.split_row[k]] == 0) return;
-    const int s0 = pv.split_slot0[k], s1 = pv.split_slot0[k + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
-    int s = s0 + grp;
-    for (; s + NG < s1; s += 2 * NG) {
-        acc = add4(acc, ld4(slab + (size_t)s * d + 4 * sub));
-        acc2 = add4(acc2, ld4(slab + (size_t)(s + NG) * d + 4 * sub));
-    }
-    if (s < s1) acc = add4(acc, ld4(slab + (size_t)s * d + 4 * sub));
-    acc = add4(acc, acc2);
+// The same for a ROW-SPARSE X: `m` marks the chunk's entries whose source row is active; the steps walk its set bits in
+// ascending order (when the mask runs out, the last entry is repeated with weight 0).
+template <int D, int NB>
+__device__ __forceinline__ void gather_batches_masked(int cv, float av, uint64_t &m, const float *__restrict__ X, int lane,
+                                                      float (&acc)[RowGeom<D>::NV]) {
+    using G = RowGeom<D>;
+    float x[NB * 8][G::NV]; float a[NB * 8];
+    int idx = 0;
+    auto next = [&](int &c, float &w) {                          // wave-uniform
+        const bool on = m != 0ull;
+        idx = on ? __builtin_ctzll(m) : idx;
+        m &= m - 1ull;
+        c = __builtin_amdgcn_readlane(cv, idx);
+        const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), idx));
+        w = on ? t : 0.f;
+    };
 #pragma unroll
-    for (int m = LPR; m < kWave; m <<= 1) {
-        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
-        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
+    for (int k = 0; k < NB * 8; ++k) {
+        if (G::kHalf) {
+            int c0, c1; float a0, a1;
+            next(c0, a0); next(c1, a1);
+            const int c = lane < 32 ? c0 : c1;
+            a[k] = lane < 32 ? a0 : a1;
+            x[k][0] = ld_elem<D>(X, c, lane & 31);
+        } else {
+            int c;
+            next(c, a[k]);
+#pragma unroll
+            for (int v = 0; v < G::NV; ++v) x[k][v] = ld_elem<D>(X, c, lane + 64 * v);
+        }
     }
-    if (grp == 0) write_row<LPR>(pv.split_row[k], sub, acc, Y, S_in, S_out, scale, SPARSE != kSparseIn || rows[pv.split_row[k]] != 0);
+#pragma unroll
+    for (int k = 0; k < NB * 8; ++k) {
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) acc[v] = fmaf(a[k], x[k][v], acc[v]);
+    }
+}
+
+// Y = A X (if Y), S_out = (S_in + A X) * scale (if S_out).  S_out may alias S_in in the dense modes (a row is read and
+// written by its own wave only); in kSparseOut mode a row may be computed by several waves, so it must not.
+template <int D, int SPARSE>
+__global__ __launch_bounds__(256) void k_spmm_row(const SpmmArgs A) {
+    using G = RowGeom<D>;
+    constexpr int NV = G::NV;
+    constexpr int EPB = 8 * G::EPS;                              // entries per batch
+    constexpr int MAXNB = G::MAXNB;
+    const int lane = threadIdx.x & 63;
+    const int colofs = G::kHalf ? (lane & 31) : lane;
+    const bool writer = !G::kHalf || lane < 32;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: scalar loads below
+    const int32_t *__restrict__ col = A.col;
+    const float *__restrict__ val = A.val;
+    const float *__restrict__ X = A.X;
+    int r, beg, end, slot = -1;
+    if (SPARSE == kSparseOut) {
+        if (w < A.n_slots) {                                     // every piece of every hub row (they come first in the plan)
+            const int4 it = A.items[w];
+            r = it.x; beg = it.y; end = it.z; slot = it.w;
+        } else {
+            const int k = w - A.n_slots;                         // batch reference k
+            if (k >= 3 * A.sp.B) return;
+            const int which = k / A.sp.B, b = k - which * A.sp.B;
+            r = which == 0 ? A.sp.u[b] : A.sp.n_users + (which == 1 ? A.sp.i[b] : A.sp.j[b]);
+            beg = A.rowptr[r]; end = A.rowptr[r + 1];
+            if (end - beg > A.sp.chunk) return;                  // a hub row: its pieces compute it
+        }
+    } else if (A.items) {
+        if (w >= A.n_items) return;
+        const int4 it = A.items[w];
+        r = it.x; beg = it.y; end = it.z; slot = it.w;
+    } else {
+        if (w >= A.N) return;
+        r = w; beg = A.rowptr[r]; end = A.rowptr[r + 1];
+    }
+    const bool s_on = A.S_out && (SPARSE != kSparseIn || row_flag(A.sp.rows, r));     // else S_in[r] counts as zero
+    float s[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s[v] = (s_on && slot < 0) ? A.S_in[(size_t)r * D + colofs + 64 * v] : 0.f;   // used last, asked for first
+    float acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+    // lane l <- column and weight of entry b+l of a chunk; padding lanes repeat the last entry (weight dropped below)
+    auto load_chunk = [&](int b, int &c, float &a) {
+        const int m = end - b < kWave ? end - b : kWave;
+        const int ec = b + (lane < m ? lane : m - 1);
+        c = col[ec];
+        a = val[ec];
+    };
+    int cv = 0; float a0 = 0.f;
+    if (beg < end) {
+        load_chunk(beg, cv, a0);
+        // the first chunk's indices have to be HERE before the loop: the compiler places its wait for them inside the
+        // loop, where it would also hold every later chunk until its own prefetch (issued just before) has arrived
+        asm volatile("" : "+v"(cv), "+v"(a0));
+    }
+    for (int base = beg; base < end; base += kWave) {           // wave-uniform
+        const int n = end - base < kWave ? end - base : kWave;  // entries of this chunk
+        int cvn = 0; float a0n = 0.f;
+        if (base + kWave < end) load_chunk(base + kWave, cvn, a0n);   // the next chunk's indices travel with this chunk's rows
+        const float av = lane < n ? a0 : 0.f;                   // padding entries add 0 * X[a valid row]
+        if (SPARSE == kSparseIn) {
+            uint64_t m = __ballot(lane < n && row_flag(A.sp.rows, cv));
+            while (m != 0ull) {                                 // wave-uniform
+                const int left = __popcll(m);
+                if (MAXNB >= 4 && left > 3 * EPB) gather_batches_masked<D, MAXNB >= 4 ? 4 : 1>(cv, av, m, X, lane, acc);
+                else if (MAXNB >= 4 && left > 2 * EPB) gather_batches_masked<D, MAXNB >= 4 ? 3 : 1>(cv, av, m, X, lane, acc);
+                else if (MAXNB >= 2 && left > EPB) gather_batches_masked<D, MAXNB >= 2 ? 2 : 1>(cv, av, m, X, lane, acc);
+                else gather_batches_masked<D, 1>(cv, av, m, X, lane, acc);
+            }
+        } else {
+            for (int e0 = 0; e0 < n; e0 += MAXNB * EPB) {       // wave-uniform
+                const int left = n - e0;
+                if (MAXNB >= 4 && left > 3 * EPB) gather_batches<D, MAXNB >= 4 ? 4 : 1>(cv, av, e0, X, lane, acc);
+                else if (MAXNB >= 4 && left > 2 * EPB) gather_batches<D, MAXNB >= 4 ? 3 : 1>(cv, av, e0, X, lane, acc);
+                else if (MAXNB >= 2 && left > EPB) gather_batches<D, MAXNB >= 2 ? 2 : 1>(cv, av, e0, X, lane, acc);
+                else gather_batches<D, 1>(cv, av, e0, X, lane, acc);
+            }
+        }
+        cv = cvn; a0 = a0n;
+    }
+    if (G::kHalf) acc[0] += __shfl_xor(acc[0], 32, kWave);
+    if (slot >= 0) {
+        // A piece of a hub row.  Its partial row goes to the slab write-through (system-scope stores: past this XCD's
+        // L2), then the row's counter is bumped; the piece that arrives last reads all partials (system-scope loads: not
+        // from its own XCD's possibly stale L2) and sums them in slot order.
+        if (writer) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                __hip_atomic_store(A.slab + (size_t)slot * D + colofs + 64 * v, acc[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the partial is out before the arrival is counted
+        const int k = A.slot_split[slot];
+        const int s0 = A.split_slot0[k], s1 = A.split_slot0[k + 1];
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(A.piece_cnt + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != s1 - s0 - 1) return;
+        if (lane == 0) __hip_atomic_store(A.piece_cnt + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+        constexpr int PF = 32 / NV;                              // partial rows in flight
+        for (int sl = s0; sl < s1; sl += PF) {                   // wave-uniform
+            float p[PF][NV];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int sq = sl + q < s1 ? sl + q : s1 - 1;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    p[q][v] = __hip_atomic_load(A.slab + (size_t)sq * D + colofs + 64 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += sl + q < s1 ? p[q][v] : 0.f;
+            }
+        }
+        if (s_on) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s[v] = A.S_in[(size_t)r * D + colofs + 64 * v];
+        }
+    }
+    if (writer) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const size_t o = (size_t)r * D + colofs + 64 * v;
+            if (A.Y) A.Y[o] = acc[v];
+            if (A.S_out) A.S_out[o] = (s[v] + acc[v]) * A.scale;
+        }
+    }
 }
 
 // out = in * scale   (n_layers == 0 degenerate case) -- float4 per lane
@@ -272,91 +330,108 @@ __global__ void k_scale_copy(size_t n_vec, const float *__restrict__ in, float *
     }
 }
 
-// work: [2*N*d] layer buffers followed by [n_slots*d] slab when a plan is given.
-// sparse_rows (may be NULL) with mode kSparseOut: only the flagged rows of E are wanted (computed in the last layer);
+// work: [3*N*d] two alternating layer buffers and the running layer sum (the last layer writes E from it: no layer
+// updates its output in place), [n_slots*d] slab and [n_split] arrival counters (zero between calls) when a plan is given.
+// sp (may be NULL) with mode kSparseOut: only the flagged rows of E are wanted (computed in the last layer);
 // with mode kSparseIn: E0 is row-sparse, only its flagged rows are non-zero (and only they are read).
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
                      const void *plan_dev, const void *plan_host_header, const float *E0, float *E, float *work,
-                     hipStream_t st, const uint8_t *sparse_rows, int sparse_mode) {
+                     hipStream_t st, const SparseCtx *sp, int sparse_mode) {
     const size_t nd = (size_t)N * d;
     float *bufA = work, *bufB = work + nd;            // alternating layer outputs
-    float *slab = work + 2 * nd;
+    float *sum = work + 2 * nd;                       // E0 + A E0 + ... up to the layer before the last
     const float inv = 1.0f / (float)(n_layers + 1);
     if (n_layers == 0) {
         k_scale_copy<<<1024, 256, 0, st>>>(nd / 4, E0, E, 1.0f);
         MACR_CHECK_LAUNCH("scale_copy", st);
         return MACR_OK;
     }
+    MACR_REQUIRE(nd * 4 < ((size_t)1 << 32), MACR_E_UNSUPPORTED, "lgcn propagate: table of %zu bytes (rows are addressed with 32-bit byte offsets)", nd * 4);
     PlanHeader ph = {};
     if (plan_dev) ph = *static_cast<const PlanHeader *>(plan_host_header);
+    SpmmArgs a = {};
+    a.N = N; a.rowptr = rowptr; a.col = col; a.val = val;
+    if (plan_dev) {
+        const PlanView pv = view_plan(plan_dev, ph);
+        a.n_items = ph.n_items; a.n_slots = ph.n_slots;
+        a.items = pv.item; a.split_row = pv.split_row; a.split_slot0 = pv.split_slot0; a.slot_split = pv.slot_split;
+        a.slab = work + 3 * nd;
+        a.piece_cnt = reinterpret_cast<int32_t *>(a.slab + (size_t)ph.n_slots * d);
+    }
     const int n_waves = plan_dev ? ph.n_items : N;
-    const int grid = (n_waves + 3) / 4;
     const float *X = E0;
     const float *S_in = E0;
     for (int l = 0; l < n_layers; ++l) {
         const bool last = (l == n_layers - 1);
         float *Y = last ? nullptr : ((l & 1) ? bufB : bufA);
         const float scale = last ? inv : 1.0f;        // running sum lives in E; first layer reads E0 as S_in
-        const int mode = !sparse_rows ? kDense
+        const int mode = !sp ? kDense
                          : (sparse_mode == kSparseOut && last) ? kSparseOut
                          : (sparse_mode == kSparseIn && l == 0) ? kSparseIn : kDense;
-        const int n_fix = (ph.n_split + 3) / 4;
-        if (mode == kSparseOut) {
-            MACR_DISPATCH_LPR(d, (k_spmm_csr<LPR, kSparseOut><<<grid, 256, 0, st>>>(N, rowptr, col, val, plan_dev, ph, X, Y, S_in, E,
-                                                                                    scale, slab, sparse_rows)));
-            MACR_CHECK_LAUNCH("spmm_csr_rows", st);
-            if (plan_dev && ph.n_split > 0) {
-                MACR_DISPATCH_LPR(d, (k_spmm_fixup<LPR, kSparseOut><<<n_fix, 256, 0, st>>>(plan_dev, ph, slab, Y, S_in, E, scale, sparse_rows)));
-                MACR_CHECK_LAUNCH("spmm_fixup", st);
-            }
-        } else if (mode == kSparseIn) {
-            MACR_DISPATCH_LPR(d, (k_spmm_csr<LPR, kSparseIn><<<grid, 256, 0, st>>>(N, rowptr, col, val, plan_dev, ph, X, Y, S_in, E,
-                                                                                   scale, slab, sparse_rows)));
-            MACR_CHECK_LAUNCH("spmm_csr_sparse", st);
-            if (plan_dev && ph.n_split > 0) {
-                MACR_DISPATCH_LPR(d, (k_spmm_fixup<LPR, kSparseIn><<<n_fix, 256, 0, st>>>(plan_dev, ph, slab, Y, S_in, E, scale, sparse_rows)));
-                MACR_CHECK_LAUNCH("spmm_fixup", st);
-            }
-        } else {
-            MACR_DISPATCH_LPR(d, (k_spmm_csr<LPR, kDense><<<grid, 256, 0, st>>>(N, rowptr, col, val, plan_dev, ph, X, Y, S_in, E,
-                                                                                scale, slab, nullptr)));
-            MACR_CHECK_LAUNCH("spmm_csr", st);
-            if (plan_dev && ph.n_split > 0) {
-                MACR_DISPATCH_LPR(d, (k_spmm_fixup<LPR, kDense><<<n_fix, 256, 0, st>>>(plan_dev, ph, slab, Y, S_in, E, scale, nullptr)));
-                MACR_CHECK_LAUNCH("spmm_fixup", st);
-            }
+        a.X = X; a.Y = Y; a.S_in = S_in; a.S_out = last ? E : sum; a.scale = scale;
+        if (mode != kDense) a.sp = *sp;
+        const int waves = mode == kSparseOut ? (plan_dev ? ph.n_slots : 0) + 3 * sp->B : n_waves;
+        const int grid = (waves + 3) / 4;
+        const char *name = mode == kSparseOut ? "spmm_csr_rows" : mode == kSparseIn ? "spmm_csr_sparse" : "spmm_csr";
+#define MACR_SPMM_ROW(D_)                                                                     \
+    do {                                                                                      \
+        if (mode == kSparseOut) k_spmm_row<D_, kSparseOut><<<grid, 256, 0, st>>>(a);          \
+        else if (mode == kSparseIn) k_spmm_row<D_, kSparseIn><<<grid, 256, 0, st>>>(a);       \
+        else k_spmm_row<D_, kDense><<<grid, 256, 0, st>>>(a);                                 \
+    } while (0)
+        switch (d) {
+            case 32: MACR_SPMM_ROW(32); break;
+            case 64: MACR_SPMM_ROW(64); break;
+            case 128: MACR_SPMM_ROW(128); break;
+            case 256: MACR_SPMM_ROW(256); break;
         }
+#undef MACR_SPMM_ROW
+        MACR_CHECK_LAUNCH(name, st);
         X = Y;
-        S_in = E;
+        S_in = sum;
     }
     return MACR_OK;
 }
 
+static int plan_chunk() {
+    static const int c = getenv("MACR_SPMM_CHUNK") && atoi(getenv("MACR_SPMM_CHUNK")) >= 64 ? atoi(getenv("MACR_SPMM_CHUNK")) : kChunk;
+    return c;
+}
+
 static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) {
-    std::vector<int32_t> irow, ibeg, iend, islot, srow, sslot0;
+    struct Item { int32_t row, beg, end, slot; };
+    std::vector<Item> items;
+    std::vector<int32_t> srow, sslot0, sslot_split;
+    const int chunk = plan_chunk();
     int n_slots = 0;
     for (int r = 0; r < N; ++r) {
         const int beg = rowptr[r], end = rowptr[r + 1];
-        if (end - beg <= kChunk) {
-            irow.push_back(r); ibeg.push_back(beg); iend.push_back(end); islot.push_back(-1);
+        if (end - beg <= chunk) {
+            items.push_back({r, beg, end, -1});
         } else {
-            srow.push_back(r); sslot0.push_back(n_slots);
-            for (int b = beg; b < end; b += kChunk) {
-                irow.push_back(r); ibeg.push_back(b); iend.push_back(b + kChunk < end ? b + kChunk : end);
-                islot.push_back(n_slots++);
+            sslot0.push_back(n_slots);
+            for (int b = beg; b < end; b += chunk) {
+                items.push_back({r, b, b + chunk < end ? b + chunk : end, n_slots++});
+                sslot_split.push_back((int32_t)srow.size());
             }
+            srow.push_back(r);
         }
     }
     sslot0.push_back(n_slots);
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
+        const bool pa = a.slot >= 0, pb = b.slot >= 0;          // the pieces of the split rows first (in slot order)
+        if (pa != pb) return pa;
+        if (pa) return false;
+        return a.end - a.beg > b.end - b.beg;                   // then the longest rows
+    });
     PlanHeader h = {};
-    h.magic = kPlanMagic; h.n_items = (int32_t)irow.size(); h.n_split = (int32_t)srow.size(); h.n_slots = n_slots; h.N = N;
+    h.magic = kPlanMagic; h.n_items = (int32_t)items.size(); h.n_split = (int32_t)srow.size(); h.n_slots = n_slots; h.N = N;
+    h.chunk = chunk;
     out.assign(reinterpret_cast<int32_t *>(&h), reinterpret_cast<int32_t *>(&h) + sizeof(h) / 4);
-    out.insert(out.end(), irow.begin(), irow.end());
-    out.insert(out.end(), ibeg.begin(), ibeg.end());
-    out.insert(out.end(), iend.begin(), iend.end());
-    out.insert(out.end(), islot.begin(), islot.end());
+    for (const Item &it : items) { out.push_back(it.row); out.push_back(it.beg); out.push_back(it.end); out.push_back(it.slot); }
     out.insert(out.end(), srow.begin(), srow.end());
     out.insert(out.end(), sslot0.begin(), sslot0.end());
+    out.insert(out.end(), sslot_split.begin(), sslot_split.end());
 }
 
 }  // namespace macr
@@ -366,12 +441,13 @@ using namespace macr;
 // ---- plan (host) ----------------------------------------------------------------
 extern "C" size_t macr_spmm_plan_bytes(int N, const int32_t *rowptr_host) {
     if (N <= 0 || !rowptr_host) return 0;
-    size_t items = 0, split = 0;
+    const int chunk = plan_chunk();
+    size_t items = 0, split = 0, slots = 0;
     for (int r = 0; r < N; ++r) {
         const int len = rowptr_host[r + 1] - rowptr_host[r];
-        if (len <= kChunk) items += 1; else { items += (len + kChunk - 1) / kChunk; split += 1; }
+        if (len <= chunk) items += 1; else { items += (len + chunk - 1) / chunk; slots += (len + chunk - 1) / chunk; split += 1; }
     }
-    return sizeof(PlanHeader) + 4 * (4 * items + split + split + 1);
+    return sizeof(PlanHeader) + 4 * (4 * items + split + split + 1 + slots);   // header, int4 descriptors, split_row, split_slot0, slot_split
 }
 
 extern "C" int macr_spmm_plan_build(int N, const int32_t *rowptr_host, void *plan_host, size_t plan_bytes) {
@@ -384,8 +460,11 @@ extern "C" int macr_spmm_plan_build(int N, const int32_t *rowptr_host, void *pla
 }
 
 extern "C" size_t macr_lgcn_work_floats(int N, int d, const void *plan_host) {
-    size_t n = (size_t)2 * N * d;
-    if (plan_host) n += (size_t)static_cast<const PlanHeader *>(plan_host)->n_slots * d;
+    size_t n = (size_t)3 * N * d;
+    if (plan_host) {
+        const PlanHeader *h = static_cast<const PlanHeader *>(plan_host);
+        n += (size_t)h->n_slots * d + (size_t)h->n_split + 64;         // slab, arrival counters
+    }
     return n;
 }
 

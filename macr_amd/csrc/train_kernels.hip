@@ -992,7 +992,9 @@ template <int D>
 __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const int32_t *__restrict__ u,
                                                      const int32_t *__restrict__ i, const int32_t *__restrict__ j,
                                                      const float *__restrict__ T, float *G, float coef,
-                                                     float *__restrict__ part) {
+                                                     float *__restrict__ part, uint8_t *__restrict__ rows) {
+    // rows (may be NULL): the row flags k_mark_rows set for this batch; nothing reads them after this kernel has
+    // started, so it clears them for the next step.
     // u, i, j: the batch grouped by positive item when the caller has it (batch_bucket_block): a block owns kChunkT
     // consecutive slots and adds equal positive rows of its chunk once (combine_positive_rows) -- the hot item of a
     // batch is referenced hundreds of times, and that many atomics on one row serialise (19.6 -> see DESIGN.md)
@@ -1009,6 +1011,7 @@ __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const 
             const int slot = wid * (kChunkT / 4) + q, t = chunk * kChunkT + slot;
             if (t >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
             const int ru = u[t], ri = i[t] + item_off, rj = j[t] + item_off;
+            if (rows && lane < 3) rows[lane == 0 ? ru : lane == 1 ? ri : rj] = 0;
             if (act) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
@@ -1039,14 +1042,21 @@ __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const 
 // ============================================================================
 namespace macr {
 
+struct SparseCtx {                // = spmm_kernels.hip
+    const uint8_t *rows;          // [N] 1 = a row of the current batch
+    const int32_t *u, *i, *j;     // the batch: rows u[b], n_users + i[b], n_users + j[b]
+    int B, n_users;
+    int chunk;                    // rows longer than this are hub rows (cut into pieces by the plan); INT_MAX without a plan
+};
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
                      const void *plan_dev, const void *plan_host_header, const float *E0, float *E, float *work,
-                     hipStream_t st, const uint8_t *sparse_rows, int sparse_mode);   // spmm_kernels.hip
+                     hipStream_t st, const SparseCtx *sp, int sparse_mode);           // spmm_kernels.hip
 constexpr int kSparseOut = 1, kSparseIn = 2;                                          // = spmm_kernels.hip
 
 // rows[r] = 1 for every table row a LightGCN batch refers to (users u, items n_users + i, n_users + j), and -- when dE is
 // given -- those rows of dE are zeroed: the only rows of the gradient buffer the step ever reads (pair_bwd accumulates
 // into them, the first backward SpMM and its epilogue read flagged rows only).  One lane group per row reference.
+// rows[] is zero on entry: k_reg_scatter, the last kernel of a step that walks the batch, clears the flags again.
 template <int D>
 __global__ __launch_bounds__(256) void k_mark_rows(int B, int n_users, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
                                                    const int32_t *__restrict__ j, uint8_t *__restrict__ rows, float *__restrict__ dE) {
@@ -1575,7 +1585,7 @@ extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, in
 // ---- LightGCN ---------------------------------------------------------------
 namespace macr {
 struct LgcnWs { float *E, *dE, *G, *work; uint8_t *rows; PairWs pair; size_t bytes; };
-static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, int n_slots) {
+static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, int n_slots, int n_split) {
     LgcnWs w;
     char *p = static_cast<char *>(base);
     const size_t nd = align_up((size_t)N * d * 4, 256);
@@ -1584,8 +1594,9 @@ static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, int n_slots) {
     w.E = static_cast<float *>(take(nd));
     w.dE = static_cast<float *>(take(nd));
     w.G = static_cast<float *>(take(nd));
-    w.work = static_cast<float *>(take(2 * nd + align_up((size_t)n_slots * d * 4, 256)));
-    w.rows = static_cast<uint8_t *>(take(align_up((size_t)N, 256)));       // 1 = a row of the current batch
+    // layer buffers, partial rows of the hub pieces, their arrival counters (= macr_lgcn_work_floats; zero between steps)
+    w.work = static_cast<float *>(take(3 * nd + align_up(((size_t)n_slots * d + n_split + 64) * 4, 256)));
+    w.rows = static_cast<uint8_t *>(take(align_up((size_t)N, 256)));       // 1 = a row of the current batch (zero between steps)
     w.pair = carve_pair_ws(p ? p + off : nullptr, B, d);
     off += w.pair.bytes;
     w.bytes = off;
@@ -1593,12 +1604,12 @@ static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, int n_slots) {
 }
 }  // namespace macr
 
-struct PlanHeaderLite { int32_t magic, n_items, n_split, n_slots, N, reserved[3]; };   // = spmm_kernels.hip PlanHeader
+struct PlanHeaderLite { int32_t magic, n_items, n_split, n_slots, N, chunk, reserved[2]; };   // = spmm_kernels.hip PlanHeader
 
 extern "C" size_t macr_lgcn_train_workspace_bytes(int B, int N, int d, const void *plan_host) {
     if (B <= 0 || N <= 0 || !dim_supported(d)) return 0;
-    const int n_slots = plan_host ? static_cast<const PlanHeaderLite *>(plan_host)->n_slots : 0;
-    return carve_lgcn_ws(nullptr, B, N, d, n_slots).bytes;
+    const PlanHeaderLite *ph = static_cast<const PlanHeaderLite *>(plan_host);
+    return carve_lgcn_ws(nullptr, B, N, d, ph ? ph->n_slots : 0, ph ? ph->n_split : 0).bytes;
 }
 
 extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
@@ -1622,10 +1633,9 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     const int N = n_users + n_items;
     MACR_REQUIRE((plan_dev == nullptr) == (plan_host == nullptr), MACR_E_INVALID,
                  "lgcn_train_step: plan needs both its device copy and its host copy (or neither)");
-    const int n_slots = plan_host ? static_cast<const PlanHeaderLite *>(plan_host)->n_slots : 0;
-    MACR_REQUIRE(!plan_host || static_cast<const PlanHeaderLite *>(plan_host)->N == N, MACR_E_INVALID,
-                 "lgcn_train_step: plan does not belong to this graph");
-    LgcnWs ws = carve_lgcn_ws(workspace, B, N, d, n_slots);
+    const PlanHeaderLite *ph = static_cast<const PlanHeaderLite *>(plan_host);
+    MACR_REQUIRE(!ph || ph->N == N, MACR_E_INVALID, "lgcn_train_step: plan does not belong to this graph");
+    LgcnWs ws = carve_lgcn_ws(workspace, B, N, d, ph ? ph->n_slots : 0, ph ? ph->n_split : 0);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "lgcn_train_step: workspace %zu < %zu bytes",
                  workspace_bytes, ws.bytes);
     MACR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
@@ -1638,8 +1648,8 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     // MACR_LGCN_DENSE=1 in the environment, keeps every layer dense (the forward result is bit-identical either way).
     static const bool dense_layers = getenv("MACR_LGCN_DENSE") && getenv("MACR_LGCN_DENSE")[0] == '1';
     const bool sparse = !dense_layers && !(flags & MACR_STEP_DENSE_LAYERS) && n_layers > 0;
+    const SparseCtx sp = {ws.rows, u, i, j, B, n_users, ph ? ph->chunk : 0x7fffffff};
     if (sparse) {
-        fill_words(reinterpret_cast<uint32_t *>(ws.rows), (N + 3) / 4, 0u, st);
         const size_t threads = (size_t)3 * B * (d / 4);
         MACR_DISPATCH_D(d, (k_mark_rows<D><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(B, n_users, u, i, j, ws.rows,
                                                                                              loss_only ? nullptr : ws.dE)));
@@ -1647,7 +1657,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     }
     // forward propagation (LightGCN.py:288-309)
     if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, T, ws.E, ws.work, st,
-                                 sparse ? ws.rows : nullptr, kSparseOut))
+                                 sparse ? &sp : nullptr, kSparseOut))
         return e;
     LossArgs L;
     L.part = ws.pair.part;
@@ -1662,8 +1672,8 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, ws.E, Ei0, w, wu, nullptr, nullptr, nullptr,
                                 nullptr, 0.0f, 0, adam_pow, hp, ws.pair, st, nullptr, nullptr, 0, nullptr, true))
             return e;
-        MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, u, i, j, T, nullptr, coef,
-                                                                                   ws.pair.part2)));
+        MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, u, i, j, T, nullptr, coef, ws.pair.part2,
+                                                                                   sparse ? ws.rows : nullptr)));
         MACR_CHECK_LAUNCH("reg_scatter", st);
         L.n_part = loss_kind == MACR_LOSS_NORMALBCE
                        ? ((B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024) : ws.pair.nblk_pair;
@@ -1679,13 +1689,13 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         return e;
     // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
     if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st,
-                                 sparse ? ws.rows : nullptr, kSparseIn))
+                                 sparse ? &sp : nullptr, kSparseIn))
         return e;
     // l2 regulariser on the ego rows (LightGCN.py:525-528)
     // (the batch grouped by positive item, as the pair launch left it in the workspace, when there is one)
     const int32_t *gu = ws.pair.staged ? u : ws.pair.us, *gi = ws.pair.staged ? i : ws.pair.is, *gj = ws.pair.staged ? j : ws.pair.js;
-    MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, gu, gi, gj, T, ws.G, coef,
-                                                                               ws.pair.part2)));
+    MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, gu, gi, gj, T, ws.G, coef, ws.pair.part2,
+                                                                               sparse ? ws.rows : nullptr)));
     MACR_CHECK_LAUNCH("reg_scatter", st);
     AdamArgs a;
     a.n_seg = 0;

@@ -296,7 +296,7 @@ def lgcn_propagate(adj, E0, n_layers, out=None, work=None):
     pd, ph = adj._plan_ptrs()
     need = _lib.lib().macr_lgcn_work_floats(N, d, ph)
     if work is None or work.numel() < need:
-        work = torch.empty(need, dtype=_f32, device=E0.device)
+        work = torch.zeros(need, dtype=_f32, device=E0.device)       # zero once: the hub rows' arrival counters live in it
     check(_lib.lib().macr_lgcn_propagate(N, d, n_layers, _ptr(adj.ptr, _i32), _ptr(adj.idx, _i32),
                                          _ptr(adj.val, _f32), pd, ph, _ptr(E0, _f32), _ptr(out, _f32),
                                          _ptr(work, _f32), _stream()))
@@ -410,7 +410,9 @@ class LGCNState(object):
             nbytes = _lib.lib().macr_lgcn_train_workspace_bytes(B, self.T.shape[0], self.d, self.adj._plan_ptrs()[1])
             if nbytes == 0:
                 raise MacrError(_lib.E_UNSUPPORTED, "embed_size %d not in {32,64,128,256}" % self.d)
-            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.T.device)
+            # zero once (include/macr_hip.h): row flags and the hub rows' arrival counters are
+            # zero between steps -- every step leaves them that way
+            self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.T.device)
             self.batch_cap = B
 
     def step(self, kind, u, i, j, losses=None, loss_only=False, dense_layers=False):
@@ -438,7 +440,7 @@ class LGCNState(object):
             # persistent buffers: the evaluator replays its launches as a graph keyed on tensor addresses
             if getattr(self, "_E_buf", None) is None:
                 self._E_buf = torch.empty_like(self.T)
-                self._E_work = torch.empty(_lib.lib().macr_lgcn_work_floats(self.T.shape[0], self.d, self.adj._plan_ptrs()[1]),
+                self._E_work = torch.zeros(_lib.lib().macr_lgcn_work_floats(self.T.shape[0], self.d, self.adj._plan_ptrs()[1]),
                                            dtype=_f32, device=self.T.device)
             self._E = lgcn_propagate(self.adj, self.T, self.n_layers, out=self._E_buf, work=self._E_work)
         return self._E

@@ -30,9 +30,9 @@ def short(name):
             k = "score_sample"
         if t and t.group(2) in ("true", "1"):
             k += "2"
-    if k == "spmm_csr":              # k_spmm_csr<LPR, SPARSE>: 1 = flagged output rows only, 2 = row-sparse input
-        t = re.search(r"k_spmm_csr<\s*\d+\s*,\s*(\d+)", name)
-        k += {"1": "_rows", "2": "_sparse"}.get(t.group(1) if t else "0", "")
+    if k == "spmm_row":              # k_spmm_row<D, SPARSE>: 1 = flagged output rows only, 2 = row-sparse input
+        t = re.search(r"k_spmm_row<\s*\d+\s*,\s*(\d+)", name)
+        k = "spmm_csr" + {"1": "_rows", "2": "_sparse"}.get(t.group(1) if t else "0", "")   # (the names the benches use)
     if k == "select" and re.search(r"k_select<\s*(true|1)\s*>", name):
         k = "select2"
     if k == "tau" and re.search(r"k_tau<\s*\d+\s*,\s*(true|1)\s*>", name):
