@@ -41,29 +41,35 @@ namespace macr {
 constexpr int kChunk = 512;       // non-zeros per work item (kernel-development knob: MACR_SPMM_CHUNK in the environment)
 
 struct PlanHeader {               // all int32, followed by the arrays below
-    int32_t magic, n_items, n_split, n_slots, N, chunk, reserved[2];
+    int32_t magic, n_items, n_split, n_slots, N, chunk, n_groups, reserved;
 };
-constexpr int32_t kPlanMagic = 0x4d414354;   // "MACT" (layout 3)
+constexpr int32_t kPlanMagic = 0x4d414355;   // "MACU" (layout 4)
+constexpr int kGroup = 16;        // pieces per group
 // layout after the header (32 bytes, so the descriptors are 16-byte aligned):
-//   item[n_items] = {row, beg, end, slot}   the n_slots pieces of the split rows first (slot >= 0), then the other rows
-//                                           (slot = -1), longest first
-//   split_row[n_split] split_slot0[n_split+1]   hub row k owns slots split_slot0[k] .. split_slot0[k+1]-1
-//   slot_split[n_slots]                         the hub row (index k) a slot belongs to
+//   item[n_items] = {row, beg, end, slot}   the n_slots pieces of the split rows first (slot >= 0, in slot order), then
+//                                           the other rows (slot = -1), longest first
+//   slot_group[n_slots]                     the group a piece belongs to (kGroup consecutive pieces of one row)
+//   group_slot0[n_groups+1]                 group g owns slots group_slot0[g] .. group_slot0[g+1]-1
+//   group_split[n_groups]                   the hub row (index k) of a group
+//   split_group0[n_split+1]                 hub row k owns groups split_group0[k] .. split_group0[k+1]-1
+//   split_row[n_split]                      its row
 
 struct PlanView {
     const int4 *item;
-    const int32_t *split_row, *split_slot0, *slot_split;
-    int n_items, n_split, n_slots;
+    const int32_t *slot_group, *group_slot0, *group_split, *split_group0, *split_row;
+    int n_items, n_split, n_slots, n_groups;
 };
 
 __device__ __host__ inline PlanView view_plan(const void *plan, const PlanHeader &h) {
     const int32_t *p = reinterpret_cast<const int32_t *>(plan) + sizeof(PlanHeader) / 4;
     PlanView v;
-    v.n_items = h.n_items; v.n_split = h.n_split; v.n_slots = h.n_slots;
+    v.n_items = h.n_items; v.n_split = h.n_split; v.n_slots = h.n_slots; v.n_groups = h.n_groups;
     v.item = reinterpret_cast<const int4 *>(p); p += 4 * (size_t)h.n_items;
-    v.split_row = p; p += h.n_split;
-    v.split_slot0 = p; p += h.n_split + 1;
-    v.slot_split = p;
+    v.slot_group = p; p += h.n_slots;
+    v.group_slot0 = p; p += h.n_groups + 1;
+    v.group_split = p; p += h.n_groups;
+    v.split_group0 = p; p += h.n_split + 1;
+    v.split_row = p;
     return v;
 }
 
@@ -89,14 +95,16 @@ struct SpmmArgs {
     const int32_t *rowptr, *col;
     const float *val;
     const int4 *items;            // NULL: no plan, item w = row w
-    const int32_t *split_row, *split_slot0, *slot_split;
-    int32_t *piece_cnt;           // [n_split] arrivals per hub row; zero between launches (the finisher resets its counter)
+    const int32_t *slot_group, *group_slot0, *group_split, *split_group0;
+    int n_groups;
+    int32_t *arrivals;            // [n_groups + n_split] arrival counters of the groups, then of the hub rows; zero between
+                                  // launches (whoever arrives last resets the counter)
     const float *X;
     float *Y;
     const float *S_in;
     float *S_out;
     float scale;
-    float *slab;                  // [n_slots][d] partial rows of the pieces
+    float *slab;                  // [n_slots + n_groups][d] partial rows of the pieces, then of the groups
     SparseCtx sp;
 };
 
@@ -105,6 +113,9 @@ struct SpmmArgs {
 // a CU has ONE scalar unit for its four SIMDs, and 64-bit address arithmetic per neighbour kept it busy.
 template <int D>
 __device__ __forceinline__ float ld_elem(const float *__restrict__ X, int c, int k) {
+#ifdef MACR_ABL_SPMM_ROWMASK                                      // timing probe (wrong results): gather from the first few rows only
+    c &= MACR_ABL_SPMM_ROWMASK;
+#endif
     const uint32_t off = ((uint32_t)c * (uint32_t)D + (uint32_t)k) * 4u;
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(X) + off);
 }
@@ -120,34 +131,50 @@ template <int D> struct RowGeom {
     static constexpr int MAXNB = NV >= 4 ? 1 : NV == 2 ? 2 : 4;   // batches in flight: at most 32 row registers
 };
 
-// NB batches of 8 steps starting at entry e0 of the chunk held in (cv, av), all loads issued before the first use.
+// NB batches of 8 steps starting at entry `pos` of the CSR arrays, all loads issued before the first use; entries
+// at and behind `left` get weight 0 (their columns belong to the next row: valid rows).  Column indices and weights
+// arrive by SCALAR loads (pos is wave-uniform) -- straight into the registers the address arithmetic and the fma
+// take them from.  The version before took them out of the lanes of a coalesced vector load with v_readlane: 4 VALU
+// instructions per neighbour, two of them 8-cycle v_readlanes -- PMC: the VALU was busy 82 % of the layer's time, and
+// neither L1-resident rows nor shorter hub chains changed its 54 us.
 // The batch count is a template parameter: a batch under a run-time guard makes its registers merge with the skipped
 // path, and the compiler resolves such a merge by waiting for the loads on the spot.
-template <int D, int NB>
-__device__ __forceinline__ void gather_batches(int cv, float av, int e0, const float *__restrict__ X, int lane,
+// SAFE: the window may reach behind the end of the arrays (the last rows of the matrix): every index is clamped.
+template <int D, int NB, bool SAFE = false>
+__device__ __forceinline__ void gather_batches(const int32_t *__restrict__ col, const float *__restrict__ val, int pos,
+                                               int left, int last, const float *__restrict__ X, int lane,
                                                float (&acc)[RowGeom<D>::NV]) {
     using G = RowGeom<D>;
-    float x[NB * 8][G::NV]; float a[NB * 8];
+    constexpr int NE = NB * 8 * G::EPS;                          // entries
+    int c[NE]; float a[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int q = SAFE ? (pos + e < last ? pos + e : last) : pos + e;
+        c[e] = col[q]; a[e] = val[q];
+    }
+    // weights of entries at and behind `left` are dropped -- only the window's last batch can hold any; the select works
+    // on the bit patterns so that it stays a scalar instruction
+    auto wgt = [&](int e) {
+        if (e < NE - 8 * G::EPS) return a[e];
+        return __builtin_bit_cast(float, e < left ? __builtin_bit_cast(int, a[e]) : 0);
+    };
+    float x[NB * 8][G::NV]; float w[NB * 8];
 #pragma unroll
     for (int k = 0; k < NB * 8; ++k) {
         if (G::kHalf) {
-            const int c0 = __builtin_amdgcn_readlane(cv, e0 + 2 * k), c1 = __builtin_amdgcn_readlane(cv, e0 + 2 * k + 1);
-            const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), e0 + 2 * k));
-            const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), e0 + 2 * k + 1));
-            const int c = lane < 32 ? c0 : c1;
-            a[k] = lane < 32 ? a0 : a1;
-            x[k][0] = ld_elem<D>(X, c, lane & 31);
+            const float a0 = wgt(2 * k), a1 = wgt(2 * k + 1);
+            w[k] = lane < 32 ? a0 : a1;
+            x[k][0] = ld_elem<D>(X, lane < 32 ? c[2 * k] : c[2 * k + 1], lane & 31);
         } else {
-            const int c = __builtin_amdgcn_readlane(cv, e0 + k);  // wave-uniform
-            a[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), e0 + k));
+            w[k] = wgt(k);                                       // wave-uniform
 #pragma unroll
-            for (int v = 0; v < G::NV; ++v) x[k][v] = ld_elem<D>(X, c, lane + 64 * v);
+            for (int v = 0; v < G::NV; ++v) x[k][v] = ld_elem<D>(X, c[k], lane + 64 * v);
         }
     }
 #pragma unroll
     for (int k = 0; k < NB * 8; ++k) {
 #pragma unroll
-        for (int v = 0; v < G::NV; ++v) acc[v] = fmaf(a[k], x[k][v], acc[v]);
+        for (int v = 0; v < G::NV; ++v) acc[v] = fmaf(w[k], x[k][v], acc[v]);
     }
 }
 
@@ -191,8 +218,33 @@ __device__ __forceinline__ void gather_batches_masked(int cv, float av, uint64_t
 
 // Y = A X (if Y), S_out = (S_in + A X) * scale (if S_out).  S_out may alias S_in in the dense modes (a row is read and
 // written by its own wave only); in kSparseOut mode a row may be computed by several waves, so it must not.
+// Every read-only array is a kernel parameter of its own with __restrict__: pointers that arrive inside a struct carry no
+// no-alias guarantee, and a load the compiler cannot prove unclobbered by the stores of an earlier loop iteration is
+// no longer a scalar load but a vector load + v_readfirstlane with a wait right behind it (measured: 61 -> 98 us).
+struct SpmmScalars {
+    int N, n_items, n_slots, n_groups;
+    float scale;
+    int B, n_users, chunk;        // SparseCtx
+};
 template <int D, int SPARSE>
-__global__ __launch_bounds__(256) void k_spmm_row(const SpmmArgs A) {
+__global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int32_t *__restrict__ rowptr,
+                                                  const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                  const int4 *__restrict__ items, const int32_t *__restrict__ slot_group,
+                                                  const int32_t *__restrict__ group_slot0,
+                                                  const int32_t *__restrict__ group_split,
+                                                  const int32_t *__restrict__ split_group0, int32_t *arrivals,
+                                                  const float *__restrict__ X, float *Y, const float *S_in, float *S_out,
+                                                  float *slab, const uint8_t *__restrict__ sp_rows,
+                                                  const int32_t *__restrict__ sp_u, const int32_t *__restrict__ sp_i,
+                                                  const int32_t *__restrict__ sp_j) {
+    struct {                       // (the names the body uses)
+        int N, n_items, n_slots, n_groups; float scale;
+        const int32_t *rowptr; const int4 *items;
+        const int32_t *slot_group, *group_slot0, *group_split, *split_group0; int32_t *arrivals;
+        float *Y; const float *S_in; float *S_out; float *slab;
+        struct { const uint8_t *rows; const int32_t *u, *i, *j; int B, n_users, chunk; } sp;
+    } A = {P.N, P.n_items, P.n_slots, P.n_groups, P.scale, rowptr, items, slot_group, group_slot0, group_split, split_group0,
+           arrivals, Y, S_in, S_out, slab, {sp_rows, sp_u, sp_i, sp_j, P.B, P.n_users, P.chunk}};
     using G = RowGeom<D>;
     constexpr int NV = G::NV;
     constexpr int EPB = 8 * G::EPS;                              // entries per batch
@@ -200,31 +252,40 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmArgs A) {
     const int lane = threadIdx.x & 63;
     const int colofs = G::kHalf ? (lane & 31) : lane;
     const bool writer = !G::kHalf || lane < 32;
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: scalar loads below
-    const int32_t *__restrict__ col = A.col;
-    const float *__restrict__ val = A.val;
-    const float *__restrict__ X = A.X;
-    int r, beg, end, slot = -1;
-    if (SPARSE == kSparseOut) {
-        if (w < A.n_slots) {                                     // every piece of every hub row (they come first in the plan)
-            const int4 it = A.items[w];
-            r = it.x; beg = it.y; end = it.z; slot = it.w;
-        } else {
-            const int k = w - A.n_slots;                         // batch reference k
-            if (k >= 3 * A.sp.B) return;
+    // One wave per item.  (PERSISTENT waves -- wave w takes items w, w + W, ... and asks for the next descriptor before it
+    // works on the current one -- were measured twice and lost: 67-75 us against 61 for a Yelp2018-shape layer.  With
+    // the gathers compiled out the layer still takes 29 of its 52 us: launch, arguments, descriptor, S_in, stores -- a
+    // chain of ~3 dependent trips per item that a persistent wave walks just as serially.)
+    const int total = SPARSE == kSparseOut ? A.n_slots + 3 * A.sp.B : A.items ? A.n_items : A.N;
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };      // wave-uniform: scalar loads below
+    // {row, beg, end, slot}; row = -1: nothing to do.  Each source loads inside its own branch and pins the values there
+    // (empty asm): left alone, the compiler merges the branches into ONE load through a selected pointer, which has lost
+    // its no-alias provenance and is then a vector load with a wait behind it.
+    auto pin = [](int4 &d) { asm volatile("" : "+s"(d.x), "+s"(d.y), "+s"(d.z), "+s"(d.w)); };
+    auto fetch = [&](int w) {
+        int4 d;
+        if (SPARSE == kSparseOut && w >= A.n_slots) {            // batch reference (the pieces of the hub rows come first)
+            const int k = w - A.n_slots;
             const int which = k / A.sp.B, b = k - which * A.sp.B;
-            r = which == 0 ? A.sp.u[b] : A.sp.n_users + (which == 1 ? A.sp.i[b] : A.sp.j[b]);
-            beg = A.rowptr[r]; end = A.rowptr[r + 1];
-            if (end - beg > A.sp.chunk) return;                  // a hub row: its pieces compute it
+            const int r = which == 0 ? A.sp.u[b] : A.sp.n_users + (which == 1 ? A.sp.i[b] : A.sp.j[b]);
+            const int beg = A.rowptr[r], end = A.rowptr[r + 1];
+            d = make_int4(end - beg > A.sp.chunk ? -1 : r, beg, end, -1);     // a hub row: its pieces compute it
+            pin(d);
+        } else if (A.items) {
+            d = A.items[w];
+            pin(d);
+        } else {
+            d = make_int4(w, A.rowptr[w], A.rowptr[w + 1], -1);
+            pin(d);
         }
-    } else if (A.items) {
-        if (w >= A.n_items) return;
-        const int4 it = A.items[w];
-        r = it.x; beg = it.y; end = it.z; slot = it.w;
-    } else {
-        if (w >= A.N) return;
-        r = w; beg = A.rowptr[r]; end = A.rowptr[r + 1];
-    }
+        return d;
+    };
+    const int w = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= total) return;
+    const int4 cur = fetch(w);
+    const int r = cur.x, beg = cur.y, slot = cur.w;
+    int end = cur.z;
+    if (r < 0) return;
     const bool s_on = A.S_out && (SPARSE != kSparseIn || row_flag(A.sp.rows, r));     // else S_in[r] counts as zero
     float s[NV];
 #pragma unroll
@@ -232,26 +293,26 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmArgs A) {
     float acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.f;
-    // lane l <- column and weight of entry b+l of a chunk; padding lanes repeat the last entry (weight dropped below)
-    auto load_chunk = [&](int b, int &c, float &a) {
-        const int m = end - b < kWave ? end - b : kWave;
-        const int ec = b + (lane < m ? lane : m - 1);
-        c = col[ec];
-        a = val[ec];
-    };
-    int cv = 0; float a0 = 0.f;
-    if (beg < end) {
-        load_chunk(beg, cv, a0);
-        // the first chunk's indices have to be HERE before the loop: the compiler places its wait for them inside the
-        // loop, where it would also hold every later chunk until its own prefetch (issued just before) has arrived
-        asm volatile("" : "+v"(cv), "+v"(a0));
-    }
-    for (int base = beg; base < end; base += kWave) {           // wave-uniform
-        const int n = end - base < kWave ? end - base : kWave;  // entries of this chunk
-        int cvn = 0; float a0n = 0.f;
-        if (base + kWave < end) load_chunk(base + kWave, cvn, a0n);   // the next chunk's indices travel with this chunk's rows
-        const float av = lane < n ? a0 : 0.f;                   // padding entries add 0 * X[a valid row]
-        if (SPARSE == kSparseIn) {
+    if (SPARSE == kSparseIn) {
+        // lane l <- column and weight of entry b+l of a chunk; padding lanes repeat the last entry (their weight is dropped)
+        auto load_chunk = [&](int b, int &c, float &a) {
+            const int m = end - b < kWave ? end - b : kWave;
+            const int ec = b + (lane < m ? lane : m - 1);
+            c = col[ec];
+            a = val[ec];
+        };
+        int cv = 0; float a0 = 0.f;
+        if (beg < end) {
+            load_chunk(beg, cv, a0);
+            // the first chunk's indices have to be HERE before the loop: the compiler places its wait for them inside
+            // the loop, where it would also hold every later chunk until its own prefetch (issued just before) has arrived
+            asm volatile("" : "+v"(cv), "+v"(a0));
+        }
+        for (int base = beg; base < end; base += kWave) {       // wave-uniform
+            const int n = end - base < kWave ? end - base : kWave;
+            int cvn = 0; float a0n = 0.f;
+            if (base + kWave < end) load_chunk(base + kWave, cvn, a0n);   // the next chunk's indices travel with this chunk's rows
+            const float av = lane < n ? a0 : 0.f;
             uint64_t m = __ballot(lane < n && row_flag(A.sp.rows, cv));
             while (m != 0ull) {                                 // wave-uniform
                 const int left = __popcll(m);
@@ -260,51 +321,85 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmArgs A) {
                 else if (MAXNB >= 2 && left > EPB) gather_batches_masked<D, MAXNB >= 2 ? 2 : 1>(cv, av, m, X, lane, acc);
                 else gather_batches_masked<D, 1>(cv, av, m, X, lane, acc);
             }
-        } else {
-            for (int e0 = 0; e0 < n; e0 += MAXNB * EPB) {       // wave-uniform
-                const int left = n - e0;
-                if (MAXNB >= 4 && left > 3 * EPB) gather_batches<D, MAXNB >= 4 ? 4 : 1>(cv, av, e0, X, lane, acc);
-                else if (MAXNB >= 4 && left > 2 * EPB) gather_batches<D, MAXNB >= 4 ? 3 : 1>(cv, av, e0, X, lane, acc);
-                else if (MAXNB >= 2 && left > EPB) gather_batches<D, MAXNB >= 2 ? 2 : 1>(cv, av, e0, X, lane, acc);
-                else gather_batches<D, 1>(cv, av, e0, X, lane, acc);
-            }
+            cv = cvn; a0 = a0n;
         }
-        cv = cvn; a0 = a0n;
+    } else {
+        const int last = A.rowptr[A.N] - 1;                     // the arrays' last entry
+#ifdef MACR_ABL_SPMM_NOGATHER
+        end = beg;
+#endif
+        for (int pos = beg; pos < end; pos += MAXNB * EPB) {    // wave-uniform
+            const int left = end - pos;
+            if (pos + MAXNB * EPB - 1 > last) {                 // (a window that could leave the arrays)
+                for (int q = pos; q < end && q < pos + MAXNB * EPB; q += EPB)
+                    gather_batches<D, 1, true>(col, val, q, end - q, last, X, lane, acc);
+            }
+            else if (MAXNB >= 4 && left > 3 * EPB) gather_batches<D, MAXNB >= 4 ? 4 : 1>(col, val, pos, left, last, X, lane, acc);
+            else if (MAXNB >= 4 && left > 2 * EPB) gather_batches<D, MAXNB >= 4 ? 3 : 1>(col, val, pos, left, last, X, lane, acc);
+            else if (MAXNB >= 2 && left > EPB) gather_batches<D, MAXNB >= 2 ? 2 : 1>(col, val, pos, left, last, X, lane, acc);
+            else gather_batches<D, 1>(col, val, pos, left, last, X, lane, acc);
+        }
     }
     if (G::kHalf) acc[0] += __shfl_xor(acc[0], 32, kWave);
     if (slot >= 0) {
-        // A piece of a hub row.  Its partial row goes to the slab write-through (system-scope stores: past this XCD's
-        // L2), then the row's counter is bumped; the piece that arrives last reads all partials (system-scope loads: not
-        // from its own XCD's possibly stale L2) and sums them in slot order.
-        if (writer) {
+        // A piece of a hub row.  Partial rows go to the slab write-through (system-scope stores: past this XCD's L2), then
+        // an arrival counter is bumped; whoever arrives LAST reads the partials (system-scope loads: not from its own
+        // XCD's possibly stale L2) and sums them in slot order -- the same sum whichever wave that is.  Two levels: the
+        // kGroup pieces of a group, then the groups of the row.  (One level over 512-entry pieces was the layer's
+        // critical path: a wave gets 1/32 of its CU's memory pipe, and the 512 + 59 dependent loads of the largest
+        // hub's last piece took ~60 us whatever the other 70 000 rows did.)
+        auto publish = [&](int at) {
+            if (writer) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
-                __hip_atomic_store(A.slab + (size_t)slot * D + colofs + 64 * v, acc[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the partial is out before the arrival is counted
-        const int k = A.slot_split[slot];
-        const int s0 = A.split_slot0[k], s1 = A.split_slot0[k + 1];
-        int old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(A.piece_cnt + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (old != s1 - s0 - 1) return;
-        if (lane == 0) __hip_atomic_store(A.piece_cnt + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                for (int v = 0; v < NV; ++v)
+                    __hip_atomic_store(A.slab + (size_t)at * D + colofs + 64 * v, acc[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partial is out before the arrival is counted
+        };
+        auto last_of = [&](int counter, int expected) {          // wave-uniform
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(A.arrivals + counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != expected - 1) return false;
+            if (lane == 0) __hip_atomic_store(A.arrivals + counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            return true;
+        };
+        auto sum_range = [&](int p0, int p1) {                   // acc = sum of slab rows [p0, p1), p1 - p0 <= kGroup
+            float p[kGroup][NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = 0.f;
-        constexpr int PF = 32 / NV;                              // partial rows in flight
-        for (int sl = s0; sl < s1; sl += PF) {                   // wave-uniform
-            float p[PF][NV];
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int sq = sl + q < s1 ? sl + q : s1 - 1;
+            for (int q = 0; q < kGroup; ++q) {
+                const int sq = p0 + q < p1 ? p0 + q : p1 - 1;
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
                     p[q][v] = __hip_atomic_load(A.slab + (size_t)sq * D + colofs + 64 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
 #pragma unroll
-            for (int q = 0; q < PF; ++q) {
+            for (int v = 0; v < NV; ++v) acc[v] = 0.f;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) acc[v] += sl + q < s1 ? p[q][v] : 0.f;
+            for (int q = 0; q < kGroup; ++q) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += p0 + q < p1 ? p[q][v] : 0.f;
+            }
+        };
+        const int g = A.slot_group[slot];
+        const int s0 = A.group_slot0[g], s1 = A.group_slot0[g + 1];
+        const int k = A.group_split[g];
+        const int g0 = A.split_group0[k], g1 = A.split_group0[k + 1];
+        if (s1 - s0 > 1) {
+            publish(slot);
+            if (!last_of(g, s1 - s0)) return;
+            sum_range(s0, s1);
+        }
+        if (g1 - g0 > 1) {
+            publish(A.n_slots + g);
+            if (!last_of(A.n_groups + k, g1 - g0)) return;
+            for (int q0 = g0; q0 < g1; q0 += kGroup) {           // wave-uniform; more than kGroup groups: 256 * chunk non-zeros
+                float part[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) part[v] = q0 == g0 ? 0.f : acc[v];
+                sum_range(A.n_slots + q0, A.n_slots + (q0 + kGroup < g1 ? q0 + kGroup : g1));
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += part[v];
             }
         }
         if (s_on) {
@@ -312,6 +407,9 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmArgs A) {
             for (int v = 0; v < NV; ++v) s[v] = A.S_in[(size_t)r * D + colofs + 64 * v];
         }
     }
+#ifdef MACR_ABL_SPMM_NOSTORE
+    if (acc[0] != 123.f) return;
+#endif
     if (writer) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -354,9 +452,10 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
     if (plan_dev) {
         const PlanView pv = view_plan(plan_dev, ph);
         a.n_items = ph.n_items; a.n_slots = ph.n_slots;
-        a.items = pv.item; a.split_row = pv.split_row; a.split_slot0 = pv.split_slot0; a.slot_split = pv.slot_split;
+        a.items = pv.item; a.slot_group = pv.slot_group; a.group_slot0 = pv.group_slot0; a.group_split = pv.group_split;
+        a.split_group0 = pv.split_group0; a.n_groups = ph.n_groups;
         a.slab = work + 3 * nd;
-        a.piece_cnt = reinterpret_cast<int32_t *>(a.slab + (size_t)ph.n_slots * d);
+        a.arrivals = reinterpret_cast<int32_t *>(a.slab + ((size_t)ph.n_slots + ph.n_groups) * d);
     }
     const int n_waves = plan_dev ? ph.n_items : N;
     const float *X = E0;
@@ -373,11 +472,14 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
         const int waves = mode == kSparseOut ? (plan_dev ? ph.n_slots : 0) + 3 * sp->B : n_waves;
         const int grid = (waves + 3) / 4;
         const char *name = mode == kSparseOut ? "spmm_csr_rows" : mode == kSparseIn ? "spmm_csr_sparse" : "spmm_csr";
-#define MACR_SPMM_ROW(D_)                                                                     \
-    do {                                                                                      \
-        if (mode == kSparseOut) k_spmm_row<D_, kSparseOut><<<grid, 256, 0, st>>>(a);          \
-        else if (mode == kSparseIn) k_spmm_row<D_, kSparseIn><<<grid, 256, 0, st>>>(a);       \
-        else k_spmm_row<D_, kDense><<<grid, 256, 0, st>>>(a);                                 \
+        const SpmmScalars ps = {a.N, a.n_items, a.n_slots, a.n_groups, a.scale, a.sp.B, a.sp.n_users, a.sp.chunk};
+#define MACR_SPMM_ARGS ps, a.rowptr, a.col, a.val, a.items, a.slot_group, a.group_slot0, a.group_split, a.split_group0, \
+                       a.arrivals, a.X, a.Y, a.S_in, a.S_out, a.slab, a.sp.rows, a.sp.u, a.sp.i, a.sp.j
+#define MACR_SPMM_ROW(D_)                                                                                  \
+    do {                                                                                                   \
+        if (mode == kSparseOut) k_spmm_row<D_, kSparseOut><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);          \
+        else if (mode == kSparseIn) k_spmm_row<D_, kSparseIn><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);       \
+        else k_spmm_row<D_, kDense><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);                                 \
     } while (0)
         switch (d) {
             case 32: MACR_SPMM_ROW(32); break;
@@ -386,6 +488,7 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
             case 256: MACR_SPMM_ROW(256); break;
         }
 #undef MACR_SPMM_ROW
+#undef MACR_SPMM_ARGS
         MACR_CHECK_LAUNCH(name, st);
         X = Y;
         S_in = sum;
@@ -401,7 +504,7 @@ static int plan_chunk() {
 static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) {
     struct Item { int32_t row, beg, end, slot; };
     std::vector<Item> items;
-    std::vector<int32_t> srow, sslot0, sslot_split;
+    std::vector<int32_t> slot_group, group_slot0, group_split, split_group0, split_row;
     const int chunk = plan_chunk();
     int n_slots = 0;
     for (int r = 0; r < N; ++r) {
@@ -409,15 +512,23 @@ static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) 
         if (end - beg <= chunk) {
             items.push_back({r, beg, end, -1});
         } else {
-            sslot0.push_back(n_slots);
+            split_group0.push_back((int32_t)group_split.size());
+            int in_group = kGroup;
             for (int b = beg; b < end; b += chunk) {
+                if (in_group == kGroup) {                       // a new group of this row
+                    group_slot0.push_back(n_slots);
+                    group_split.push_back((int32_t)split_row.size());
+                    in_group = 0;
+                }
+                slot_group.push_back((int32_t)group_split.size() - 1);
                 items.push_back({r, b, b + chunk < end ? b + chunk : end, n_slots++});
-                sslot_split.push_back((int32_t)srow.size());
+                ++in_group;
             }
-            srow.push_back(r);
+            split_row.push_back(r);
         }
     }
-    sslot0.push_back(n_slots);
+    group_slot0.push_back(n_slots);
+    split_group0.push_back((int32_t)group_split.size());
     std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
         const bool pa = a.slot >= 0, pb = b.slot >= 0;          // the pieces of the split rows first (in slot order)
         if (pa != pb) return pa;
@@ -425,13 +536,15 @@ static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) 
         return a.end - a.beg > b.end - b.beg;                   // then the longest rows
     });
     PlanHeader h = {};
-    h.magic = kPlanMagic; h.n_items = (int32_t)items.size(); h.n_split = (int32_t)srow.size(); h.n_slots = n_slots; h.N = N;
-    h.chunk = chunk;
+    h.magic = kPlanMagic; h.n_items = (int32_t)items.size(); h.n_split = (int32_t)split_row.size(); h.n_slots = n_slots; h.N = N;
+    h.chunk = chunk; h.n_groups = (int32_t)group_split.size();
     out.assign(reinterpret_cast<int32_t *>(&h), reinterpret_cast<int32_t *>(&h) + sizeof(h) / 4);
     for (const Item &it : items) { out.push_back(it.row); out.push_back(it.beg); out.push_back(it.end); out.push_back(it.slot); }
-    out.insert(out.end(), srow.begin(), srow.end());
-    out.insert(out.end(), sslot0.begin(), sslot0.end());
-    out.insert(out.end(), sslot_split.begin(), sslot_split.end());
+    out.insert(out.end(), slot_group.begin(), slot_group.end());
+    out.insert(out.end(), group_slot0.begin(), group_slot0.end());
+    out.insert(out.end(), group_split.begin(), group_split.end());
+    out.insert(out.end(), split_group0.begin(), split_group0.end());
+    out.insert(out.end(), split_row.begin(), split_row.end());
 }
 
 }  // namespace macr
@@ -441,13 +554,9 @@ using namespace macr;
 // ---- plan (host) ----------------------------------------------------------------
 extern "C" size_t macr_spmm_plan_bytes(int N, const int32_t *rowptr_host) {
     if (N <= 0 || !rowptr_host) return 0;
-    const int chunk = plan_chunk();
-    size_t items = 0, split = 0, slots = 0;
-    for (int r = 0; r < N; ++r) {
-        const int len = rowptr_host[r + 1] - rowptr_host[r];
-        if (len <= chunk) items += 1; else { items += (len + chunk - 1) / chunk; slots += (len + chunk - 1) / chunk; split += 1; }
-    }
-    return sizeof(PlanHeader) + 4 * (4 * items + split + split + 1 + slots);   // header, int4 descriptors, split_row, split_slot0, slot_split
+    std::vector<int32_t> v;
+    build_plan(N, rowptr_host, v);
+    return v.size() * 4;
 }
 
 extern "C" int macr_spmm_plan_build(int N, const int32_t *rowptr_host, void *plan_host, size_t plan_bytes) {
@@ -463,7 +572,7 @@ extern "C" size_t macr_lgcn_work_floats(int N, int d, const void *plan_host) {
     size_t n = (size_t)3 * N * d;
     if (plan_host) {
         const PlanHeader *h = static_cast<const PlanHeader *>(plan_host);
-        n += (size_t)h->n_slots * d + (size_t)h->n_split + 64;         // slab, arrival counters
+        n += ((size_t)h->n_slots + h->n_groups) * d + (size_t)h->n_groups + h->n_split + 64;   // slab, arrival counters
     }
     return n;
 }

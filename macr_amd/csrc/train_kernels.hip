@@ -1584,8 +1584,10 @@ extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, in
 
 // ---- LightGCN ---------------------------------------------------------------
 namespace macr {
+struct PlanHeaderLite { int32_t magic, n_items, n_split, n_slots, N, chunk, n_groups, reserved; };   // = spmm_kernels.hip PlanHeader
 struct LgcnWs { float *E, *dE, *G, *work; uint8_t *rows; PairWs pair; size_t bytes; };
-static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, int n_slots, int n_split) {
+static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, const PlanHeaderLite *ph) {
+    const size_t n_slots = ph ? (size_t)ph->n_slots + ph->n_groups : 0, n_split = ph ? (size_t)ph->n_groups + ph->n_split : 0;
     LgcnWs w;
     char *p = static_cast<char *>(base);
     const size_t nd = align_up((size_t)N * d * 4, 256);
@@ -1604,12 +1606,11 @@ static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, int n_slots, int n_
 }
 }  // namespace macr
 
-struct PlanHeaderLite { int32_t magic, n_items, n_split, n_slots, N, chunk, reserved[2]; };   // = spmm_kernels.hip PlanHeader
 
 extern "C" size_t macr_lgcn_train_workspace_bytes(int B, int N, int d, const void *plan_host) {
     if (B <= 0 || N <= 0 || !dim_supported(d)) return 0;
     const PlanHeaderLite *ph = static_cast<const PlanHeaderLite *>(plan_host);
-    return carve_lgcn_ws(nullptr, B, N, d, ph ? ph->n_slots : 0, ph ? ph->n_split : 0).bytes;
+    return carve_lgcn_ws(nullptr, B, N, d, ph).bytes;
 }
 
 extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
@@ -1635,7 +1636,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
                  "lgcn_train_step: plan needs both its device copy and its host copy (or neither)");
     const PlanHeaderLite *ph = static_cast<const PlanHeaderLite *>(plan_host);
     MACR_REQUIRE(!ph || ph->N == N, MACR_E_INVALID, "lgcn_train_step: plan does not belong to this graph");
-    LgcnWs ws = carve_lgcn_ws(workspace, B, N, d, ph ? ph->n_slots : 0, ph ? ph->n_split : 0);
+    LgcnWs ws = carve_lgcn_ws(workspace, B, N, d, ph);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "lgcn_train_step: workspace %zu < %zu bytes",
                  workspace_bytes, ws.bytes);
     MACR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,

@@ -61,8 +61,11 @@ def pick_adjacency(adj_type):
 
 def train_epoch(model, kind, n_batch, loss_log, device_sampler=None, test_loss=False):
     """n_batch steps (LightGCN.py:765-790).  test_loss=True is the reference's second pass of n_batch loss-only
-    runs on data_generator.sample_test() batches (:799-819): same RNG consumption, no parameter update
-    (with a device_sampler: that sampler's batches -- `--sampler device` builds one over the test lists)."""
+    runs on data_generator.sample_test() batches (:799-819), no parameter update (with a device_sampler: that
+    sampler's batches -- `--sampler device` builds one over the test lists).
+    RNG consumption with the host sampler: the reference fetches one batch ahead (:762-764 / :799-801, then one
+    `sample_thread` per iteration :767 / :804), so a pass draws n_batch + 1 batches and throws the last one away; the
+    extra draw below keeps the python `random` / numpy streams -- and so every later epoch's batches -- the same."""
     for idx in range(n_batch):
         if test_loss and device_sampler is not None:
             batch = device_sampler.sample()
@@ -75,6 +78,8 @@ def train_epoch(model, kind, n_batch, loss_log, device_sampler=None, test_loss=F
             users, pos_items, neg_items = data_generator.sample()
             batch = model.to_device_batch(users, pos_items, neg_items)
         model.train_step(kind, batch, loss_log[idx], loss_only=test_loss)
+    if device_sampler is None:                                  # the reference's discarded look-ahead batch
+        data_generator.sample_test() if test_loss else data_generator.sample()
     per_step = loss_log[:n_batch].cpu().numpy()
     loss = mf_loss = emb_loss = 0.
     for row in per_step:

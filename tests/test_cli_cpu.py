@@ -41,3 +41,38 @@ def test_early_stopping_helper():
     for v in [0.1, 0.2, 0.2] + [0.15] * 10:
         best, step, stop = mod.early_stopping(v, best, step, expected_order='acc', flag_step=10)
     assert best == 0.2 and step == 10 and stop
+
+
+def test_lightgcn_epoch_consumes_the_reference_number_of_sampler_draws():
+    """macr_lightgcn/LightGCN.py:762-778 / :799-812 fetch one batch ahead: a training pass draws n_batch + 1 batches from
+    Data.sample() and a test-loss pass n_batch + 1 from Data.sample_test(); the host RNG streams of a whole run only stay
+    those of the reference if this CLI draws as many (in a subprocess: the module parses sys.argv at import)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, types
+sys.argv = ["LightGCN.py", "--data_path", "%s/", "--dataset", "addressa", "--batch_size", "1024"]
+sys.path.insert(0, "%s")
+import LightGCN as cli
+calls = {"sample": 0, "sample_test": 0}
+dg = cli.data_generator
+orig, orig_t = dg.sample, dg.sample_test
+dg.sample = lambda: (calls.__setitem__("sample", calls["sample"] + 1), orig())[1]
+dg.sample_test = lambda: (calls.__setitem__("sample_test", calls["sample_test"] + 1), orig_t())[1]
+class FakeLog(list):
+    def __getitem__(self, k):
+        return self if isinstance(k, slice) else None
+    def cpu(self): return self
+    def numpy(self):
+        import numpy as np
+        return np.zeros((3, 3))
+class FakeModel(object):
+    def to_device_batch(self, u, i, j): return (u, i, j)
+    def train_step(self, kind, batch, out, loss_only=False): pass
+cli.train_epoch(FakeModel(), 0, 3, FakeLog())
+cli.train_epoch(FakeModel(), 0, 3, FakeLog(), test_loss=True)
+print(calls["sample"], calls["sample_test"])
+''' % (os.path.join(REPO, "data"), os.path.join(REPO, "macr_lightgcn"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-2:] == ["4", "4"], out.stdout
