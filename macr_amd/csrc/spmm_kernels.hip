@@ -128,7 +128,10 @@ template <int D> struct RowGeom {
     static constexpr bool kHalf = D == 32;
     static constexpr int NV = kHalf ? 1 : D / 64;
     static constexpr int EPS = kHalf ? 2 : 1;       // entries per step
-    static constexpr int MAXNB = NV >= 4 ? 1 : NV == 2 ? 2 : 4;   // batches in flight: at most 32 row registers
+#ifndef MACR_SPMM_MAXNB
+#define MACR_SPMM_MAXNB 4
+#endif
+    static constexpr int MAXNB = NV >= 4 ? 1 : NV == 2 ? 2 : MACR_SPMM_MAXNB;   // batches in flight: at most 32 row registers
 };
 
 // NB batches of 8 steps starting at entry `pos` of the CSR arrays, all loads issued before the first use; entries
@@ -341,6 +344,9 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
         }
     }
     if (G::kHalf) acc[0] += __shfl_xor(acc[0], 32, kWave);
+#ifdef MACR_ABL_SPMM_NOPIECE
+    if (slot >= 0) return;
+#endif
     if (slot >= 0) {
         // A piece of a hub row.  Partial rows go to the slab write-through (system-scope stores: past this XCD's L2), then
         // an arrival counter is bumped; whoever arrives LAST reads the partials (system-scope loads: not from its own

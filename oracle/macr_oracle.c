@@ -621,3 +621,69 @@ void orc_metrics_mf(int U, int Kmax, const int32_t *rankings, const int32_t *cnt
         }
     }
 }
+
+/* ---------------------------------------------------------------------------
+ * Device sampler: the CHECKER of macr_amd/csrc/sample_kernels.hip.
+ * The law is the reference's -- macr_mf/load_data.py:543-566 (Data.sample: B distinct users by rd.sample, or
+ * rd.choice when B exceeds the user count; a uniform positive of the user's train list, item 0 for an empty list
+ * :551-552; a uniform negative outside that list by rejection :554-558), macr_lightgcn/utility/load_data.py:174-212
+ * (sample: users from exist_users) and :214-254 (sample_test: positives from the test list, negatives outside test
+ * AND train lists) -- the STREAM is the kernel's own counter-based generator, restated here operation by operation
+ * (all integer arithmetic: results are compared bit for bit):
+ *   key     = mix64(seed * 0x9e3779b97f4a7c15 + step)                      splitmix64 finaliser
+ *   draw(n) = high 32 bits of mix64(key ^ (triple << 32 | n))
+ *   users   : B <= n_pool: image of `triple` under a 4-round Feistel permutation of [0, n_pool) (cycle walking
+ *             over the next even power of two) -- distinct users; else below(draw(0), n_pool)
+ *   pos     = list[below(draw(1), len)], 0 for an empty list
+ *   neg     = first of below(draw(2)), below(draw(3)), ... (at most 4096 tries) outside the exclusion list
+ *   below(r, range) = (r * range) >> 32
+ * -------------------------------------------------------------------------*/
+static inline uint64_t orc_mix64(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+static inline uint32_t orc_draw(uint64_t key, uint32_t t, uint32_t n) {
+    return (uint32_t)(orc_mix64(key ^ ((uint64_t)t << 32 | n)) >> 32);
+}
+static inline uint32_t orc_below(uint32_t r, uint32_t range) { return (uint32_t)(((uint64_t)r * range) >> 32); }
+static uint32_t orc_feistel_perm(uint32_t x, uint32_t n, int bits, uint64_t key) {
+    const int hb = (bits + 1) / 2;
+    const uint32_t mask = (1u << hb) - 1u;
+    do {
+        uint32_t l = x >> hb, r = x & mask;
+        for (int round = 0; round < 4; ++round) {
+            const uint32_t f = (uint32_t)(orc_mix64(key + 0x1234567ull * (uint64_t)(round + 1) + r) >> 17) & mask;
+            const uint32_t nl = r, nr = l ^ f;
+            l = nl; r = nr;
+        }
+        x = (l << hb) | r;
+    } while (x >= n);
+    return x;
+}
+/* out: (3, B) int32 = users, positives, negatives of batch `step`.  pool / excl_ptr / excl_idx may be NULL. */
+void orc_sample_triples(uint64_t seed, uint64_t step, int B, int n_items, const int32_t *pool, int n_pool,
+                        const int32_t *train_ptr, const int32_t *train_idx,
+                        const int32_t *excl_ptr, const int32_t *excl_idx, int32_t *out) {
+    int bits = 1;
+    while ((1u << bits) < (unsigned)n_pool) ++bits;
+    if (bits & 1) ++bits;
+    const uint64_t key = orc_mix64(seed * 0x9e3779b97f4a7c15ull + step);
+    for (int t = 0; t < B; ++t) {
+        uint32_t slot;
+        if (B <= n_pool) slot = orc_feistel_perm((uint32_t)t, (uint32_t)n_pool, bits, key);
+        else slot = orc_below(orc_draw(key, (uint32_t)t, 0), (uint32_t)n_pool);
+        const int user = pool ? pool[slot] : (int)slot;
+        const int beg = train_ptr[user], len = train_ptr[user + 1] - beg;
+        const int pos = len > 0 ? train_idx[beg + (int)orc_below(orc_draw(key, (uint32_t)t, 1), (uint32_t)len)] : 0;
+        const int32_t *xi = excl_ptr ? excl_idx : train_idx;
+        const int xbeg = excl_ptr ? excl_ptr[user] : beg, xlen = excl_ptr ? excl_ptr[user + 1] - xbeg : len;
+        int neg = 0;
+        for (uint32_t n = 2; n < 2 + 4096; ++n) {
+            neg = (int)orc_below(orc_draw(key, (uint32_t)t, n), (uint32_t)n_items);
+            if (!in_sorted(xi + xbeg, xlen, neg)) break;
+        }
+        out[t] = user; out[B + t] = pos; out[2 * (size_t)B + t] = neg;
+    }
+}

@@ -65,6 +65,8 @@ def lib():
         L.orc_topk_merge.argtypes = [_ci, _ci, _ci, _f, _i, _f, _i, _i]
         L.orc_metrics_foldout.argtypes = [_ci, _ci, _i, _i, _i, _f]
         L.orc_metrics_mf.argtypes = [_ci, _ci, _i, _vp, _i, _i, _i, _ci, _d]
+        L.orc_sample_triples.argtypes = [ctypes.c_uint64, ctypes.c_uint64, _ci, _ci, _vp, _ci, _i, _i, _vp, _vp, _i]
+        L.orc_sample_triples.restype = None
         for fn in ("orc_gather_rows", "orc_scatter_add_rows", "orc_pair_loss_grad", "orc_adam_dense",
                    "orc_mf_train_step", "orc_spmm_csr", "orc_lgcn_propagate", "orc_lgcn_train_step",
                    "orc_branch_sigmoid", "orc_score_topk", "orc_topk_scores", "orc_topk_merge", "orc_metrics_foldout",
@@ -239,6 +241,19 @@ def metrics_mf(rankings, cnt, gt, Ks):
 
 
 # ------------------------------------------------------------------ reference C++ evaluator (oracle/_ref)
+def sample_triples(seed, step, B, n_items, train, pool=None, exclude=None, n_pool=None):
+    """Batch `step` of the device sampler's stream (macr_amd/csrc/sample_kernels.hip) -> (3, B) int32 users, positives,
+    negatives.  train / exclude: (ptr, idx) CSR of ascending item lists per user id; pool: user ids to draw from."""
+    tp, ti = _i32(train[0]), _i32(train[1])
+    pool = None if pool is None else _i32(pool)
+    n_pool = (len(tp) - 1 if pool is None else len(pool)) if n_pool is None else n_pool
+    ex = (None, None) if exclude is None else (_i32(exclude[0]), _i32(exclude[1]))
+    out = np.empty((3, B), np.int32)
+    lib().orc_sample_triples(int(seed), int(step), B, n_items, _ptr(pool), n_pool, tp, ti if len(ti) else np.zeros(1, np.int32),
+                             _ptr(ex[0]), _ptr(ex[1]), out)
+    return out
+
+
 def have_ref():
     return os.path.exists(_REF_LIB)
 

@@ -189,6 +189,44 @@ def test_device_sampler_distribution(ops):
     assert set(u.tolist()) <= set(range(0, 500, 2)) and len(u) == 2048
 
 
+def test_device_sampler_equals_its_oracle_bit_for_bit(ops):
+    """k_sample_triples against oracle.sample_triples (oracle/macr_oracle.c::orc_sample_triples: splitmix64 draws, the
+    4-round Feistel permutation with cycle walking, multiply-shift ranges, rejection + binary search) -- integer work, so
+    equality is exact; the oracle's LAW is checked against the reference samplers in tests/test_sampler_law.py."""
+    import oracle
+    from macr_amd.sampler import DeviceSampler
+    rs = np.random.RandomState(5)
+    dev = torch.device("cuda")
+    for n_users, n_items, B in [(500, 200, 256), (500, 200, 500), (37, 1000, 37), (300, 64, 1024), (70000, 9000, 8192)]:
+        train = {u: sorted(rs.choice(n_items, size=rs.randint(0, min(40, n_items // 2)), replace=False).tolist())
+                 for u in range(n_users)}
+        train[1] = list(range(n_items - 1))
+        csr = oracle.csr_from_lists([train[u] for u in range(n_users)])
+        for ahead in (1, 7):
+            smp = DeviceSampler(train, n_users, n_items, B, dev, seed=77 + ahead, ahead=ahead)
+            for step in range(10):
+                got = smp.sample().cpu().numpy()
+                assert np.array_equal(got, oracle.sample_triples(77 + ahead, step, B, n_items, csr)), (n_users, B, ahead, step)
+    # a user pool (LightGCN's exist_users) and an exclusion list (sample_test)
+    n_users, n_items, B = 400, 150, 128
+    train = {u: sorted(rs.choice(n_items, size=rs.randint(1, 30), replace=False).tolist()) for u in range(n_users)}
+    test_l = {u: sorted(rs.choice(np.setdiff1d(np.arange(n_items), train[u]), size=3, replace=False).tolist())
+              for u in range(0, n_users, 3)}
+    both = {u: sorted(set(test_l[u]) | set(train[u])) for u in test_l}
+    pool = sorted(test_l)
+    ts = DeviceSampler(test_l, n_users, n_items, B, dev, seed=8, pool=pool, exclude=both)
+    tl = oracle.csr_from_lists([test_l.get(u, []) for u in range(n_users)])
+    ex = oracle.csr_from_lists([both.get(u, []) for u in range(n_users)])
+    for step in range(40):
+        want = oracle.sample_triples(8, step, B, n_items, tl, pool=np.asarray(pool, np.int32), exclude=ex)
+        assert np.array_equal(ts.sample().cpu().numpy(), want), step
+    ps = DeviceSampler(train, n_users, n_items, 300, dev, seed=9, pool=list(range(0, n_users, 2)))   # B > pool: with replacement
+    tr = oracle.csr_from_lists([train[u] for u in range(n_users)])
+    for step in range(5):
+        want = oracle.sample_triples(9, step, 300, n_items, tr, pool=np.arange(0, n_users, 2, dtype=np.int32))
+        assert np.array_equal(ps.sample().cpu().numpy(), want), step
+
+
 # ----------------------------------------------------------------------------- command lines
 def _run_cli(cmd, cwd):
     env = dict(os.environ, PYTHONUNBUFFERED="1")

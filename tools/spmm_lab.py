@@ -11,11 +11,12 @@ name = sys.argv[1] if len(sys.argv) > 1 else "yelp2018"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 cfg = synth.WORKLOADS[name]
 dev = torch.device("cuda"); n_u, n_i, d, L = cfg["n_users"], cfg["n_items"], 64, 2
-cache = "/tmp/spmm_lab_%s.npz" % name
+zipf = os.environ.get("LAB_ZIPF", "1") != "0"          # LAB_ZIPF=0: uniform item popularity (a graph without hub rows)
+cache = "/tmp/spmm_lab_%s_%d.npz" % (name, zipf)
 if os.path.exists(cache):
     A = sp.load_npz(cache)
 else:
-    lists = synth.interaction_lists(n_u, n_i, cfg["n_train"] / n_u, seed=9)
+    lists = synth.interaction_lists(n_u, n_i, cfg["n_train"] / n_u, seed=9, zipf=zipf)
     rows = np.repeat(np.arange(n_u), [len(l) for l in lists]); cols = np.concatenate(lists)
     R = sp.csr_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n_u, n_i))
     A = sp.bmat([[None, R], [R.T, None]], format="csr", dtype=np.float32)
