@@ -3,12 +3,15 @@
 Index work (top-K ids, merges) must be bit-exact; floating-point model arithmetic
 uses the tolerances of BASELINE.json's north star (per-step loss 1e-5 relative).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import oracle
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 gpu = pytest.mark.gpu
 pytestmark = gpu
 
@@ -87,6 +90,52 @@ def test_mf_train_step_matches_oracle(ops, kind, B, d, n_users, n_items):
     np.testing.assert_allclose(state.adam_pow.cpu().numpy(), st.power, rtol=1e-6)
     if kind == oracle.LOSS_NORMALBCE:        # branch vectors get no gradient -> bitwise untouched
         assert np.array_equal(state.w.cpu().numpy(), w) and np.array_equal(state.wu.cpu().numpy(), wu)
+
+
+@pytest.mark.parametrize("kind", [oracle.LOSS_NORMALBCE, oracle.LOSS_RUBIBCEBOTH])
+@pytest.mark.parametrize("defer", [False, True])
+def test_mf_twenty_step_trajectory_stays_on_the_oracle(ops, kind, defer):
+    """Teacher-forced drift: 20 steps on the same batches, HIP (its Adam pass uses v_sqrt / v_rcp + one Newton step, <= 1
+    ulp; -DMACR_ADAM_IEEE restores sqrtf and division -- this test passes either way) against the oracle (IEEE).  The
+    difference must not build up over a trajectory: tables within 0.2 % of ONE step per step taken, losses 1e-5."""
+    B, d, n_users, n_items = 512, 64, 2000, 600
+    P, Q, w, wu, u, i, j = make_problem(77, n_users, n_items, d, B)
+    alpha, beta, decay, lr, bs = 1e-2, 1e-3, 1e-5, 1e-3, 1024
+    st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
+    Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
+    state = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), ops.make_hyper(lr, decay, alpha, beta, bs), B)
+    rs = np.random.RandomState(21)
+    steps = 20
+    for t in range(steps):
+        u = rs.choice(n_users, B, replace=False).astype(np.int32)
+        i = (rs.zipf(1.4, B) - 1).clip(0, n_items - 1).astype(np.int32)
+        j = rs.randint(0, n_items, B).astype(np.int32)
+        want = oracle.mf_train_step(kind, u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, bs)
+        got = state.step(kind, dev(u), dev(i), dev(j), defer=defer).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0, err_msg="step %d" % t)
+    if defer:
+        state.flush()
+    for name, mine, theirs in (("P", state.P, Po), ("Q", state.Q, Qo), ("w", state.w, wo), ("wu", state.wu, wuo)):
+        diff = np.abs(mine.cpu().numpy() - theirs).max()
+        assert diff <= 2e-3 * lr * steps, (name, diff)
+        # and the typical row is far inside the bound: nothing drifts systematically
+        assert np.abs(mine.cpu().numpy() - theirs).mean() <= 1e-4 * lr * steps, name
+    for name, mine, theirs in (("mP", state.mP, st.m[0]), ("mQ", state.mQ, st.m[1]), ("vP", state.vP, st.v[0]),
+                               ("vQ", state.vQ, st.v[1])):
+        np.testing.assert_allclose(mine.cpu().numpy(), theirs, rtol=2e-4, atol=2e-6 * np.abs(theirs).max(), err_msg=name)
+
+
+def test_mf_trajectory_with_ieee_adam():
+    """The same 20-step trajectory test against the build whose Adam pass keeps IEEE sqrtf and division
+    (macr_amd/csrc/libmacr_hip_ieee.so, -DMACR_ADAM_IEEE) -- in a process of its own: a process binds one library."""
+    import subprocess
+    import sys
+    lib = os.path.join(REPO, "macr_amd", "csrc", "libmacr_hip_ieee.so")
+    assert os.path.exists(lib), "build it: make -C macr_amd/csrc"
+    env = dict(os.environ, MACR_HIP_LIB=lib)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                          "twenty_step_trajectory"], env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0 and "4 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("scale", [0.45, 0.6, 1.2])
