@@ -23,7 +23,7 @@
  *   - errors: the reference has no error channel.  Here a failed call fills
  *     its output with -1 (rankings) / NaN (results), prints one line to
  *     stderr and sets macr_eval_compat_status() (0 = last call succeeded);
- *   - top_k <= MACR_MAX_TOPK (32); thread_num is ignored.
+ *   - top_k <= MACR_MAX_TOPK_SCORES (128); thread_num is ignored.
  * ==========================================================================*/
 #ifndef MACR_EVAL_COMPAT_H
 #define MACR_EVAL_COMPAT_H

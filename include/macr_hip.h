@@ -56,6 +56,7 @@ extern "C" {
 
 /* largest K the top-K kernels are built for (the reference uses 20; parser default max 30) */
 #define MACR_MAX_TOPK 32
+#define MACR_MAX_TOPK_SCORES 128   /* macr_topk_scores only (c_top_k_array_index of the reference has no bound) */
 #define MACR_SEED_WIDTH 32       /* threshold seeds per query of macr_score_topk (seed_idx / seed_out) */
 
 int         macr_abi_version(void);

@@ -875,7 +875,13 @@ __global__ __launch_bounds__(256) void k_tau_seed(int U, int n_local, const floa
     }
     const uint64_t good = __ballot(ok) >> half & 0xffffffffull;
     const uint64_t kth = __ballot(ok && rank == K - 1) >> half & 0xffffffffull;       // exactly one lane if >= K good seeds
-    const float t = __shfl(v, half | (kth ? __builtin_ctzll(kth) : 0), kWave);
+    float t = __shfl(v, half | (kth ? __builtin_ctzll(kth) : 0), kWave);
+    // Two ulps of slack below the K-th seed score.  The argument above rests on this kernel's scalar fmaf chain being
+    // bit-identical to the MFMA accumulation of the listing pass (it is on gfx950: tested); should another compiler or
+    // chip round one of them differently by an ulp, a threshold set EXACTLY at a seed's score would list fewer than K
+    // items for that user and nothing downstream would notice.  Any lower threshold is as valid, it only lengthens lists.
+    const uint32_t ot = f32_orderable(t);
+    t = orderable_f32(ot > 0x007fffffu + 2u ? ot - 2u : 0x007fffffu);       // (0x007fffff is -inf in that order)
     if (l == 0) tau[q] = (__popcll(good) >= K && kth) ? t : -INFINITY;
 }
 
@@ -1189,6 +1195,109 @@ __global__ __launch_bounds__(256) void k_topk_scores(const float *__restrict__ s
     if (lane < K) {
         out_idx[(size_t)row * K + lane] = key ? key_id(key) : -1;
         if (out_val) out_val[(size_t)row * K + lane] = key ? key_score(key) : -INFINITY;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_topk_scores_wide: the same for MACR_MAX_TOPK < K <= MACR_MAX_TOPK_SCORES (c_top_k_array_index has no bound on
+// top_k, tools.h:13-22; the reference's CLIs use 20, its tuning scripts up to 100).  One wave per row; candidates above
+// the running threshold collect in a 256-key LDS buffer; when it could overflow, the K-th largest is found by the MSB-first
+// radix select on lane masks (four keys per lane) and the best K move to the front.  The final K are ordered by rank
+// counting (every key against every other: K <= 128).  Not a hot path: correctness first.
+// ----------------------------------------------------------------------------
+constexpr int kWideCap = 256;
+// keep the best K of keys[0..n) (n <= kWideCap, distinct keys) at the front; returns the K-th largest (0: n < K)
+__device__ __forceinline__ uint64_t keep_best_wide(uint64_t *keys, int n, int K) {
+    constexpr int NREG = kWideCap / 64;
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (n <= K) return 0ull;                               // (uniform)
+    uint64_t key[NREG], cand[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+        key[j] = j * 64 + lane < n ? keys[j * 64 + lane] : 0ull;
+        cand[j] = __ballot(j * 64 + lane < n);
+    }
+    int remaining = K, alive = n;
+    for (int bit = 63; bit >= 0 && alive > 1; --bit) {
+        uint64_t ones[NREG];
+        int n1 = 0;
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) { ones[j] = __ballot((key[j] >> bit) & 1ull) & cand[j]; n1 += __popcll(ones[j]); }
+        if (n1 >= remaining) {
+            alive = n1;
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) cand[j] = ones[j];
+        } else {
+            remaining -= n1; alive -= n1;
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) cand[j] &= ~ones[j];
+        }
+    }
+    uint64_t kth = 0ull;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j)
+        if (cand[j]) {                                     // (uniform) exactly one register holds the one candidate left
+            const int src = __ffsll((long long)cand[j]) - 1;
+            kth = ((uint64_t)__shfl((uint32_t)(key[j] >> 32), src, kWave) << 32) | __shfl((uint32_t)key[j], src, kWave);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+        const bool keep = key[j] != 0ull && key[j] >= kth;
+        const uint64_t km = __ballot(keep);
+        if (keep) keys[base + __popcll(km & ((1ull << lane) - 1ull))] = key[j];
+        base += __popcll(km);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return kth;
+}
+
+__global__ __launch_bounds__(256) void k_topk_scores_wide(const float *__restrict__ scores, int cols, int rows, int K,
+                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+    __shared__ uint64_t s_keys[4][kWideCap];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= rows) return;
+    const float *src = scores + (size_t)row * cols;
+    uint64_t *keys = s_keys[wid];
+    int cnt = 0;
+    uint64_t thr_key = 0ull;                        // admission: key > thr_key
+    for (int base = 0; base < cols; base += kWave) {
+        const int cidx = base + lane;
+        const uint64_t key = cidx < cols ? make_key(src[cidx], cidx) : 0ull;
+        bool cand = key > thr_key;
+        uint64_t bal = __ballot(cand);
+        if (bal == 0ull) continue;
+        if (cnt + __popcll(bal) > kWideCap) {
+            const uint64_t kth = keep_best_wide(keys, cnt, K);
+            if (kth) { thr_key = kth; cnt = K; }
+            cand = key > thr_key;
+            bal = __ballot(cand);
+        }
+        if (cand) keys[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+        cnt += __popcll(bal);
+    }
+    if (keep_best_wide(keys, cnt, K)) cnt = K;
+    // order the cnt <= K <= 128 survivors: rank = number of larger keys
+    uint64_t mine[2]; int rank[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) mine[h] = h * 64 + lane < cnt ? keys[h * 64 + lane] : 0ull;
+    for (int e = 0; e < cnt; ++e) {
+        const uint64_t other = keys[e];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rank[h] += other > mine[h] ? 1 : 0;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (mine[h]) {
+            out_idx[(size_t)row * K + rank[h]] = key_id(mine[h]);
+            if (out_val) out_val[(size_t)row * K + rank[h]] = key_score(mine[h]);
+        }
+    for (int e = cnt + lane; e < K; e += kWave) {          // fewer than K columns
+        out_idx[(size_t)row * K + e] = -1;
+        if (out_val) out_val[(size_t)row * K + e] = -INFINITY;
     }
 }
 
@@ -1734,8 +1843,9 @@ extern "C" int macr_topk_scores(const float *scores, int cols, int rows, int K, 
     hipStream_t st = as_stream(stream);
     MACR_REQUIRE(scores && out_idx, MACR_E_INVALID, "topk_scores: null pointer");
     MACR_REQUIRE(cols > 0 && rows > 0, MACR_E_INVALID, "topk_scores: cols=%d rows=%d", cols, rows);
-    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "topk_scores: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
-    k_topk_scores<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val);
+    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK_SCORES, MACR_E_UNSUPPORTED, "topk_scores: K=%d outside [1,%d]", K, MACR_MAX_TOPK_SCORES);
+    if (K <= MACR_MAX_TOPK) k_topk_scores<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val);
+    else k_topk_scores_wide<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val);
     MACR_CHECK_LAUNCH("topk_scores", st);
     return MACR_OK;
 }

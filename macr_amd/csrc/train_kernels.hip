@@ -1132,7 +1132,10 @@ static PairWs carve_pair_ws(void *base, int B, int d, bool force_staged = false)
     w.scal = static_cast<StepScalars *>(take(sizeof(StepScalars)));
     w.gw = static_cast<float *>(take((size_t)kBranchSlots * 2 * d * 4));
     w.fwd = static_cast<float *>(take((size_t)7 * w.Bp * 4));
-    const int npart = w.nblk_pair > w.nblk_bwd ? w.nblk_pair : w.nblk_bwd;
+    // (the loss-only normalbce pass launches min(ceil(B / kChunkT), 1024) blocks whatever path the workspace is carved for)
+    const int nblk_loss = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;
+    int npart = w.nblk_pair > w.nblk_bwd ? w.nblk_pair : w.nblk_bwd;
+    npart = npart > nblk_loss ? npart : nblk_loss;
     w.part = static_cast<float *>(take((size_t)npart * kPartStride * 4));
     w.part2 = static_cast<float *>(take((size_t)npart * kPartStride * 4));
     w.lpart = static_cast<float *>(take((size_t)w.nrb * w.ncb * 4));

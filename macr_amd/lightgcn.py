@@ -63,6 +63,9 @@ class LightGCN(object):
         # parameters (:221-254): ego table T = [user_embedding ; item_embedding], branch vectors
         gen = torch.Generator().manual_seed(seed)
         d = self.emb_dim
+        # an --embed_size outside {32,64,128,256} runs at the next supported width with zero columns (ops.padded_dim:
+        # exact -- the propagation is linear, zero columns stay zero); the Xavier limits are those of the d-wide shapes
+        dp = self.d_pad = ops.padded_dim(d)
         if weights is not None:
             as_t = lambda a: torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
             T = torch.cat([as_t(weights['user_embedding']), as_t(weights['item_embedding'])]).contiguous()
@@ -72,6 +75,7 @@ class LightGCN(object):
                            xavier_uniform((self.n_items, d), gen, device)]).contiguous()
             w = xavier_uniform((d, 1), gen, device).reshape(-1)
             wu = xavier_uniform((d, 1), gen, device).reshape(-1)
+        T, w, wu = ops.pad_cols(T, dp), ops.pad_cols(w, dp), ops.pad_cols(wu, dp)
         self.rubi_c = 0.0
         adj = ops.CSR.from_scipy(self.norm_adj, device)
         hyper = ops.make_hyper(self.lr, self.decay, self.alpha, self.beta, self.batch_size)

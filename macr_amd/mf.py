@@ -101,18 +101,21 @@ class BPRMF(object):
     def init_weights(self, seed, weights=None):
         gen = torch.Generator().manual_seed(seed)
         dev, d = self.device, self.emb_dim
+        # an --embed_size outside {32,64,128,256} runs at the next supported width with zero columns (ops.padded_dim:
+        # exact); the Xavier limits are those of the d-wide shapes
+        dp = self.d_pad = ops.padded_dim(d)
         out = dict()
         if weights is not None:      # injected (parity runs): numpy/torch arrays
             as_t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).to(dev).contiguous()
-            out['user_embedding'] = as_t(weights['user_embedding'])
-            out['item_embedding'] = as_t(weights['item_embedding'])
-            self.w = as_t(weights['w']).reshape(-1)
-            self.w_user = as_t(weights['w_user']).reshape(-1)
+            out['user_embedding'] = ops.pad_cols(as_t(weights['user_embedding']), dp)
+            out['item_embedding'] = ops.pad_cols(as_t(weights['item_embedding']), dp)
+            self.w = ops.pad_cols(as_t(weights['w']).reshape(-1), dp)
+            self.w_user = ops.pad_cols(as_t(weights['w_user']).reshape(-1), dp)
         else:
-            out['user_embedding'] = xavier_uniform((self.n_users, d), gen, dev)
-            out['item_embedding'] = xavier_uniform((self.n_items, d), gen, dev)
-            self.w = xavier_uniform((d, 1), gen, dev).reshape(-1)
-            self.w_user = xavier_uniform((d, 1), gen, dev).reshape(-1)
+            out['user_embedding'] = ops.pad_cols(xavier_uniform((self.n_users, d), gen, dev), dp)
+            out['item_embedding'] = ops.pad_cols(xavier_uniform((self.n_items, d), gen, dev), dp)
+            self.w = ops.pad_cols(xavier_uniform((d, 1), gen, dev).reshape(-1), dp)
+            self.w_user = ops.pad_cols(xavier_uniform((d, 1), gen, dev).reshape(-1), dp)
         return out
 
     def _statistics_params(self):

@@ -287,6 +287,31 @@ def colmean(x):
     return out.reshape(x.shape[1:])
 
 
+# ------------------------------------------------------------------ embedding widths
+SUPPORTED_DIMS = (32, 64, 128, 256)
+
+
+def padded_dim(d):
+    """The width the kernels run an `--embed_size d` model at: the next of 32 / 64 / 128 / 256.  The host models keep
+    their tables (and branch vectors) at that width with the extra columns ZERO; they stay exactly zero through training
+    (every term of their gradient is a product with a zero column, Adam of a zero gradient on zero slots is zero) and add
+    exact zeros to every dot product, so losses, parameters and rankings are those of the d-wide model
+    (the reference accepts any integer: macr_mf/parse.py:27, utility/parser.py:32)."""
+    for s in SUPPORTED_DIMS:
+        if d <= s:
+            return s
+    raise MacrError(_lib.E_UNSUPPORTED, "embed_size %d > %d" % (d, SUPPORTED_DIMS[-1]))
+
+
+def pad_cols(t, width):
+    """(rows, d) or (d,) tensor -> contiguous tensor of `width` columns, zero-filled on the right"""
+    if t.shape[-1] == width:
+        return t.contiguous()
+    out = torch.zeros(t.shape[:-1] + (width,), dtype=t.dtype, device=t.device)
+    out[..., :t.shape[-1]] = t
+    return out
+
+
 # ------------------------------------------------------------------ LightGCN propagation
 def lgcn_propagate(adj, E0, n_layers, out=None, work=None):
     """E = mean(E0, A E0, ..., A^L E0)  (LightGCN.py:288-309); also its own backward."""
@@ -345,13 +370,22 @@ class MFState(object):
 
     _TABLE_NAMES = ("P", "Q", "w", "wu", "mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu", "gP", "gQ", "tP", "tQ")
 
+    def __setattr__(self, name, value):
+        # assigning one of the tables (state.P = ...) drops the cached raw pointers
+        if name in self._TABLE_NAMES or name == "adam_pow":
+            object.__setattr__(self, "_tab_ptrs", None)
+        object.__setattr__(self, name, value)
+
+    def invalidate(self):
+        """Forget the cached raw pointers.  Needed only after a table's STORAGE was swapped behind the same tensor object
+        (`t.data = ...`, `t.set_(...)`, `t.resize_(...)`); assigning a new tensor to an attribute is noticed by itself."""
+        self._tab_ptrs = None
+
     def _tables(self):
         """the 16 table pointers of the C calls, rebuilt only when one of the tensors was replaced (a step is ~36 us:
         sixteen data_ptr() round trips per call were 8 us of it)"""
-        ids = tuple(id(getattr(self, n)) for n in self._TABLE_NAMES) + (id(self.adam_pow),)
-        if getattr(self, "_tab_ids", None) != ids:
-            self._tab_ptrs = tuple(_ptr(getattr(self, n)) for n in self._TABLE_NAMES)
-            self._tab_ids = ids
+        if getattr(self, "_tab_ptrs", None) is None:
+            object.__setattr__(self, "_tab_ptrs", tuple(_ptr(getattr(self, n)) for n in self._TABLE_NAMES))
             self._dev_index = self.P.device.index if self.P.device.index is not None else torch.cuda.current_device()
             self._pow_ptr = _ptr(self.adam_pow)
         return self._tab_ptrs

@@ -151,9 +151,14 @@ def main(sweep=False):
             ret = test(sess, model, users_to_test, method="rubiboth")
             say('c:{}: recall={}, hit={}, ndcg={}'.format(c, str(ret["recall"]), str(ret['hr']), str(ret['ndcg'])))
         return
+    if args.pretrain != 0:
+        # the reference's -1 / -2 modes load embeddings of another model (LightGCN.py:665-693): outside this path
+        raise SystemExit("--pretrain %d is not supported (0: train, 1: evaluate saved weights)" % args.pretrain)
     print('using xavier initialization')
     print('without pretraining.')
     start_epoch = 1
+    cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch, best_c_hr = 0., 0, 0, 0, 0, 0.
+    resumed = None                                   # the bookkeeping of the interrupted run (saved next to its weights)
     if args.resume == 1:
         epochs = _saved_epochs(weights_save_path)
         if epochs:
@@ -161,8 +166,13 @@ def main(sweep=False):
                                              map_location=model.device))
             start_epoch = epochs[-1] + 1
             say('resumed from epoch %d' % epochs[-1])
+            side = weights_save_path + '/train_state_{}-{}.pt'.format(args.saveID, epochs[-1])
+            if os.path.exists(side):
+                resumed = torch.load(side, weights_only=False)
+                cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch, best_c_hr = resumed['bests']
+                random.setstate(resumed['py_random'])
+                np.random.set_state(resumed['np_random'])
 
-    cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch, best_c_hr = 0., 0, 0, 0, 0, 0.
     n_batch = data_generator.n_train // args.batch_size + 1
     loss_log = torch.zeros((n_batch, 3), dtype=torch.float32, device=model.device)
     device_sampler = test_sampler = None
@@ -179,6 +189,10 @@ def main(sweep=False):
                                      exclude=both)
     elif args.sampler != "reference":
         raise SystemExit("--sampler must be reference or device")
+    if device_sampler is not None and start_epoch > 1:
+        # the batch of step k is a function of (seed, k): continue the sequences instead of replaying epoch 1's batches
+        device_sampler.step = resumed['sampler_step'] if resumed else (start_epoch - 1) * n_batch
+        test_sampler.step = resumed['test_sampler_step'] if resumed else ((start_epoch - 1) // args.log_interval) * n_batch
     for epoch in range(start_epoch, args.epoch + 1):
         t1 = time()
         loss, mf_loss, emb_loss = train_epoch(model, kind, n_batch, loss_log, device_sampler)
@@ -237,6 +251,12 @@ def main(sweep=False):
             ensureDir(weights_save_path)
             os.makedirs(weights_save_path, exist_ok=True)      # tf.train.Saver created this level itself
             torch.save(model.state_dict(), weights_save_path + '/weights_{}-{}.pt'.format(args.saveID, epoch))
+            # what --resume 1 needs besides the model: best-so-far / early-stopping state and where the samplers stand
+            torch.save({'bests': (cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch, best_c_hr),
+                        'py_random': random.getstate(), 'np_random': np.random.get_state(),
+                        'sampler_step': device_sampler.step if device_sampler is not None else 0,
+                        'test_sampler_step': test_sampler.step if test_sampler is not None else 0},
+                       weights_save_path + '/train_state_{}-{}.pt'.format(args.saveID, epoch))
             print('save the weights in path: ', weights_save_path)
         if should_stop and args.early_stop == 1:
             if main_rank:

@@ -185,12 +185,20 @@ def main(sweep=False):
     config['best_c_hr'], config['best_c_epoch'], config['best_c'] = 0, 0, 0.0
     stopping_step = 0
     start_epoch = 0
+    resumed = None                                   # the bookkeeping of the interrupted run (saved next to its checkpoint)
     if args.resume == 1:
         epochs = _saved_epochs()
         if epochs:
             model.load_state_dict(torch.load(_ckpt_dir() + '{}_ckpt.pt'.format(epochs[-1]), map_location=model.device))
             start_epoch = epochs[-1] + 1
             say('resumed from epoch %d' % epochs[-1])
+            side = _ckpt_dir() + '{}_train_state.pt'.format(epochs[-1])
+            if os.path.exists(side):
+                resumed = torch.load(side, weights_only=False)
+                config.update(resumed['config'])
+                stopping_step = resumed['stopping_step']
+                random.setstate(resumed['py_random'])
+                np.random.set_state(resumed['np_random'])
     n_batch = data.n_train // args.batch_size + 1
     loss_log = torch.zeros((n_batch, 3), dtype=torch.float32, device=model.device)
     device_sampler = None
@@ -200,6 +208,9 @@ def main(sweep=False):
                                        model.device, seed=seed)
     elif args.sampler != "reference":
         raise SystemExit("--sampler must be reference or device")
+    if device_sampler is not None and start_epoch:
+        # the batch of step k is a function of (seed, k): continue the sequence instead of replaying epoch 0's batches
+        device_sampler.step = resumed['sampler_step'] if resumed else start_epoch * n_batch
     for epoch in range(start_epoch, args.epoch):
         t1 = time()
         loss, mf_loss, reg_loss = train_epoch(model, kind, n_batch, loss_log, device_sampler)
@@ -251,6 +262,11 @@ def main(sweep=False):
         if args.save_flag == 1 and main_rank:
             os.makedirs(_ckpt_dir(), exist_ok=True)
             torch.save(model.state_dict(), _ckpt_dir() + '{}_ckpt.pt'.format(epoch))
+            # what --resume 1 needs besides the model: best-so-far / early-stopping state and where the samplers stand
+            torch.save({'config': {k: v for k, v in config.items() if k.startswith('best_')}, 'stopping_step': stopping_step,
+                        'py_random': random.getstate(), 'np_random': np.random.get_state(),
+                        'sampler_step': device_sampler.step if device_sampler is not None else 0},
+                       _ckpt_dir() + '{}_train_state.pt'.format(epoch))
         if should_stop and args.early_stop == 1:
             say("{} dataset best epoch{}: hr:{} ndcg:{} recall:{} precision:{}".format(
                 args.dataset, config['best_epoch'], config['best_hr'], config['best_ndcg'], config['best_recall'],

@@ -40,7 +40,7 @@ def test_version_and_error_plumbing(lib):
     assert rc == _lib.E_INVALID and b"null pointer" in lib.macr_last_error()
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    rc = lib.macr_topk_scores(p, 10, 10, 64, p, None, None)
+    rc = lib.macr_topk_scores(p, 10, 10, 129, p, None, None)       # K > MACR_MAX_TOPK_SCORES
     assert rc == _lib.E_UNSUPPORTED
     rc = lib.macr_branch_sigmoid(p, None, 1, 48, p, p, None)
     assert rc == _lib.E_UNSUPPORTED and b"d=48" in lib.macr_last_error()

@@ -738,15 +738,26 @@ def test_golden_cpp_evaluator_cases_through_the_reference_abi(golden_dir):
         assert L.macr_eval_compat_status() == 0, L.macr_eval_compat_error()
         np.testing.assert_allclose(res, z[name + "_results"], rtol=2e-7, atol=0)
     # no error channel in the reference: a failed call poisons its output and sets the status
-    bad = np.zeros((2, 40), np.float32)
-    out = np.zeros((2, 40), np.int32)
-    L.c_top_k_array_index(bad.ctypes.data, 40, 2, 40, 1, out.ctypes.data)           # top_k > MACR_MAX_TOPK
+    bad = np.zeros((2, 200), np.float32)
+    out = np.zeros((2, 200), np.int32)
+    L.c_top_k_array_index(bad.ctypes.data, 200, 2, 200, 1, out.ctypes.data)         # top_k > MACR_MAX_TOPK_SCORES
     assert L.macr_eval_compat_status() != 0 and (out == -1).all()
+    # top_k beyond 32 (tools.h:13-22 has no bound; the tuning scripts rank 100): the wide kernel, same tie rule
+    rs = np.random.RandomState(3)
+    for cols, k in [(744, 100), (90, 64), (5000, 128), (50, 50), (33, 33)]:
+        sc = rs.standard_normal((37, cols)).astype(np.float32)
+        sc[:, ::7] = np.round(sc[:, ::7])                                            # ties
+        sc[3, : cols // 2] = -np.inf
+        out = np.zeros((37, k), np.int32)
+        L.c_top_k_array_index(sc.ctypes.data, cols, 37, k, 4, out.ctypes.data)
+        assert L.macr_eval_compat_status() == 0, L.macr_eval_compat_error()
+        want = oracle.topk_scores(sc, k)[1]
+        assert np.array_equal(out, want), (cols, k)
 
 
 def test_errors_are_loud(ops):
     with pytest.raises(ops.MacrError):
-        ops.topk_scores(dev(np.zeros((2, 5), np.float32)), 64)              # K > MACR_MAX_TOPK
+        ops.topk_scores(dev(np.zeros((2, 5), np.float32)), 129)             # K > MACR_MAX_TOPK_SCORES
     with pytest.raises(ops.MacrError):
         ops.branch_sigmoid(dev(np.zeros((4, 48), np.float32)), dev(np.zeros(48, np.float32)))   # unsupported d
     with pytest.raises(ops.MacrError):

@@ -512,6 +512,79 @@ def test_injected_weights_round_trip(ops):
     assert np.abs(m2.w.cpu().numpy()).max() <= np.sqrt(6.0 / (d + 1))
 
 
+@pytest.mark.parametrize("d", [20, 48, 100, 200])
+def test_any_embed_size_runs_zero_padded_and_exact(ops, d):
+    """--embed_size is any integer in the reference (macr_mf/parse.py:27, utility/parser.py:32).  The models run other
+    widths at the next of 32/64/128/256 with zero columns (ops.padded_dim): losses and parameters are the oracle's at
+    width d, the padding stays exactly zero, and the ranking is the oracle's bit for bit."""
+    import types
+    import scipy.sparse as sp
+    from macr_amd.mf import BPRMF
+    from macr_amd.lightgcn import LightGCN
+    from macr_amd.evaluator import Evaluator
+    rs = np.random.RandomState(d)
+    n_users, n_items, B, K = 300, 120, 64, 20
+    wts = {"user_embedding": (rs.standard_normal((n_users, d)) * 0.3).astype(np.float32),
+           "item_embedding": (rs.standard_normal((n_items, d)) * 0.3).astype(np.float32),
+           "w": (rs.standard_normal((d, 1)) * 0.3).astype(np.float32), "w_user": (rs.standard_normal((d, 1)) * 0.3).astype(np.float32)}
+    lr, decay, alpha, beta = 1e-3, 1e-5, 1e-2, 1e-3
+    args = types.SimpleNamespace(regs=decay, embed_size=d, lr=lr, batch_size=B, verbose=0, c=40.0, alpha=alpha, beta=beta)
+    m = BPRMF(args, dict(n_users=n_users, n_items=n_items), weights=wts)
+    dp = ops.padded_dim(d)
+    assert m.user_embedding.shape == (n_users, dp) and m.w.shape == (dp,)
+    Po, Qo = wts["user_embedding"].copy(), wts["item_embedding"].copy()
+    wo, wuo = wts["w"].reshape(-1).copy(), wts["w_user"].reshape(-1).copy()
+    st = oracle.AdamState([Po.shape, Qo.shape, (d,), (d,)])
+    kind = ops.LOSS_RUBIBCEBOTH
+    for t in range(3):
+        u = rs.choice(n_users, B, replace=False).astype(np.int32)
+        i = rs.randint(0, n_items, B).astype(np.int32); j = rs.randint(0, n_items, B).astype(np.int32)
+        want = oracle.mf_train_step(kind, u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, B)
+        got = m.train_step(kind, m.to_device_batch(u, i, j)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5)
+    m.sync()
+    P, Q = m.user_embedding.cpu().numpy(), m.item_embedding.cpu().numpy()
+    np.testing.assert_allclose(P[:, :d], Po, rtol=0, atol=2e-3 * lr * 3)
+    np.testing.assert_allclose(Q[:, :d], Qo, rtol=0, atol=2e-3 * lr * 3)
+    np.testing.assert_allclose(m.w.cpu().numpy()[:d], wo, rtol=0, atol=2e-3 * lr * 3)
+    assert not P[:, d:].any() and not Q[:, d:].any() and not m.w.cpu().numpy()[d:].any() and not m.w_user.cpu().numpy()[d:].any()
+    # ranking of the padded model == oracle ranking of its first d columns, ids and score bits
+    users = np.arange(0, n_users, 3, dtype=np.int32)
+    mask = [sorted(rs.choice(n_items, 10, replace=False).tolist()) for _ in users]
+    gt = [sorted(rs.choice(n_items, 4, replace=False).tolist()) for _ in users]
+    ev = Evaluator(mask, gt, n_items, torch.device("cuda"))
+    uid = torch.from_numpy(users).cuda()
+    val, idx, cnt = ev.rank(ops.SCORE_RUBI_BOTH, m.user_embedding, uid, m.item_embedding, K, m.w, m.w_user, 40.0)
+    sig_i = ops.branch_sigmoid(m.item_embedding, m.w).cpu().numpy()
+    sig_u = ops.branch_sigmoid(m.user_embedding, m.w_user, uid).cpu().numpy()
+    wv, wi, wc = oracle.score_topk(oracle.SCORE_RUBI_BOTH, np.ascontiguousarray(P[users, :d]), np.ascontiguousarray(Q[:, :d]), K,
+                                   sig_u, sig_i, 40.0, oracle.csr_from_lists(mask))
+    assert np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(val.cpu().numpy().view(np.uint32), wv.view(np.uint32))
+    # LightGCN: propagation is linear, zero columns stay zero
+    R = (rs.rand(n_users, n_items) < 0.08).astype(np.float32)
+    R[:, 0] = 1
+    A = sp.bmat([[None, sp.csr_matrix(R)], [sp.csr_matrix(R.T), None]]).tocsr()
+    deg = np.asarray(A.sum(1)).ravel()
+    dinv = np.where(deg > 0, np.power(np.maximum(deg, 1), -0.5), 0).astype(np.float32)
+    A = (sp.diags(dinv) @ A @ sp.diags(dinv)).tocsr().astype(np.float32); A.sort_indices()
+    largs = types.SimpleNamespace(adj_type="pre", alg_type="lightgcn", lr=lr, embed_size=d, batch_size=B, layer_size="[%d,%d]" % (d, d),
+                                  regs="[%g]" % decay, verbose=0, Ks="[20]", alpha=alpha, beta=beta, dataset="x", node_dropout_flag=0)
+    lg = LightGCN(dict(n_users=n_users, n_items=n_items, norm_adj=A), largs, weights=wts)
+    To = np.concatenate([wts["user_embedding"], wts["item_embedding"]]).astype(np.float32)
+    wo, wuo = wts["w"].reshape(-1).copy(), wts["w_user"].reshape(-1).copy()
+    lst = oracle.AdamState([To.shape, (d,), (d,)])
+    for t in range(2):
+        u = rs.choice(n_users, B, replace=False).astype(np.int32)
+        i = rs.randint(0, n_items, B).astype(np.int32); j = rs.randint(0, n_items, B).astype(np.int32)
+        want = oracle.lgcn_train_step(kind, n_users, n_items, 2, A.indptr, A.indices, A.data, u, i, j, To, wo, wuo, lst,
+                                      lr, decay, alpha, beta, B)
+        got = lg.train_step(kind, lg.to_device_batch(u, i, j)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5)
+    T = lg.T.cpu().numpy()
+    np.testing.assert_allclose(T[:, :d], To, rtol=0, atol=0.02 * lr * 2)
+    assert not T[:, d:].any()
+
+
 @pytest.mark.parametrize("kind_name", ["SCORE_RUBI_BOTH", "SCORE_RUBI", "SCORE_DIRECT_MINUS_BOTH"])
 def test_shared_listing_pass_sweep_equals_single_c(ops, kind_name):
     """f1: macr_score_topk_sweep ranks up to four values of c with ONE listing pass; every value must give exactly the

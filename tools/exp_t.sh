@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fullsize.py tests/test_gpu_product.py -x -q -k "trajectory or fullsize_train or sampler" 2>&1 | tail -15
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -15
