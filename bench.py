@@ -53,7 +53,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="gowalla", choices=["addressa", "gowalla", "ml10m", "yelp2018"])
+    ap.add_argument("--workload", default="gowalla", choices=["addressa", "gowalla", "ml10m", "yelp2018", "config4"],
+                    help="config4 = BASELINE configs[4]: 10 M users x 1 M items, d=128, ONE model row-sharded over the ranks "
+                         "(training) and item-sharded (evaluation); every other workload trains replicas")
+    ap.add_argument("--c4-users", type=int, default=10_000_000)
+    ap.add_argument("--c4-items", type=int, default=1_000_000)
+    ap.add_argument("--c4-eval-users", type=int, default=100_000)
     ap.add_argument("--train", default="rubibceboth", choices=["normalbce", "rubibceboth"])
     ap.add_argument("--eval-reps", type=int, default=20, help="timed evaluations (more than one period of the seeding policy's back-off)")
     ap.add_argument("--eval-settle", type=int, default=6, help="untimed evaluations (with the training steps between them) before the timed ones")
@@ -85,6 +90,170 @@ def algorithmic_bytes(kernel, cfg, B):
     return None
 
 
+def bench_config4(args, rank, world, dev):
+    """BASELINE configs[4]: synthetic 10 M users x 1 M items, d = 128, B = 8192, `rubibceboth`, ONE model whose rows are
+    range-sharded over the ranks (macr_amd/sharded_train.py: three batch-sized collectives per step, dense Adam on the
+    rank's shard) and whose evaluation is item-sharded (one all-gather of per-shard top-K).  `value` = interactions/s of
+    that one model = B * steps / time: the work is fixed, more ranks divide it -- strong scaling.  At --gpus 1 the whole
+    22.5 GB of tables, Adam slots and gradient scratch sit on the one GPU (the > 2^32-byte case of every kernel)."""
+    import math
+    from macr_amd import ops, sharding, synth, sharded_train
+    from macr_amd.evaluator import Evaluator
+    n_users, n_items, d, B = args.c4_users, args.c4_items, 128, 8192
+    lr, regs, alpha, beta, c = 1e-3, 1e-5, 1e-3, 1e-3, 40.0
+    u_lo, u_hi = sharded_train.row_range(n_users, rank, world)
+    i_lo, i_hi = sharded_train.row_range(n_items, rank, world)
+    gen = torch.Generator(device=dev).manual_seed(4000 + rank)
+
+    def xavier_rows(rows_local, rows_global):
+        lim = math.sqrt(6.0 / (rows_global + d))
+        return ((torch.rand((rows_local, d), generator=gen, device=dev, dtype=torch.float32) * 2 - 1) * lim).contiguous()
+    gen_all = torch.Generator(device=dev).manual_seed(12345)          # identical on every rank: branch vectors and batches
+    w = synth.xavier_table(d, 1, gen_all, dev).reshape(-1)
+    wu = synth.xavier_table(d, 1, gen_all, dev).reshape(-1)
+    hyper = ops.make_hyper(lr, regs, alpha, beta, B)
+    model = sharded_train.RowShardedMF(None, None, w, wu, sharded_train.HipBackend(ops.LOSS_RUBIBCEBOTH, d, hyper, dev),
+                                       rank=rank, world=world,
+                                       shards=(xavier_rows(u_hi - u_lo, n_users), xavier_rows(i_hi - i_lo, n_items), n_users, n_items))
+    n_batches = min(args.steps + args.warmup, 32)
+    batches = synth.train_batches(n_batches, n_users, n_items, B, gen_all, dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def run_steps(n, first):
+        out = None
+        for s in range(n):
+            k = (first + s) % n_batches
+            out = model.step(batches[k, 0], batches[k, 1], batches[k, 2])
+        return out
+    run_steps(args.warmup, 0)
+
+    def timed_region():
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps, args.warmup)
+        torch.cuda.synchronize(); barrier()
+        return sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    regions = [timed_region()]
+    n_rep = args.regions if args.regions > 0 else int(min(50, max(1, round(0.25 / max(regions[0], 1e-6)))))
+    n_rep = int(sharding.max_over_ranks(float(n_rep), dev))
+    regions += [timed_region() for _ in range(n_rep - 1)]
+    elapsed = float(np.median(regions))
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = B * args.steps / elapsed
+    last = run_steps(1, 0).cpu().numpy()
+    if not np.isfinite(last).all():
+        raise SystemExit("ERROR: loss is nan.")
+    # per-kernel events (rank-local launches) and per-collective events
+    n_prof = 8
+    model.collective_ms = {}
+    ops.timing_begin()
+    run_steps(n_prof, 0)
+    marks = ops.timing_end(max_n=n_prof * 40)
+    torch.cuda.synchronize()
+    coll = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in model.collective_ms.items()}
+    model.collective_ms = None
+    ku = {}
+    for name, ms in marks:
+        e = ku.setdefault(name, [0, 0.0]); e[0] += 1; e[1] += ms
+    kern = {n_: {"launches_per_step": c_ / n_prof, "event_us": 1e3 * t / c_} for n_, (c_, t) in ku.items()}
+    rows_local = (u_hi - u_lo) + (i_hi - i_lo)
+    adam_bytes = 24.0 * d * rows_local
+    adam_us = kern.get("adam_dense", {}).get("event_us")
+    roofline = None
+    if adam_us:
+        gbps = adam_bytes / (adam_us * 1e-6) / 1e9
+        roofline = {"kernel": "adam_dense", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbps / HBM_PEAK_GBS, "traffic": None, "avg_us": adam_us, "algorithmic_bytes": adam_bytes,
+                    "note": "TF-style dense Adam over this rank's %d rows (24*d bytes per row and step); event-timed, "
+                            "includes ~3 us of event overhead" % rows_local}
+    step_bytes = B * (24 * d + 12) + 24.0 * d * (n_users + n_items)
+    # ------------------------------------------------------------- evaluation: item shards + one all-gather
+    eval_out = {}
+    if not args.no_eval:
+        rs = np.random.RandomState(777)
+        U = min(args.c4_eval_users, n_users)
+        users = np.sort(rs.choice(n_users, U, replace=False)).astype(np.int64)
+        mask_lists = synth.interaction_lists(U, n_items, 30.0, seed=778)
+        gt_lists = [sorted(set(rs.randint(0, n_items, 50).tolist()) - set(m)) for m in mask_lists]
+        ev = Evaluator(mask_lists, gt_lists, n_items, dev)
+        ev.local_items_range = (i_lo, i_hi)
+        ud = torch.from_numpy(users).to(dev)
+        Pq = torch.zeros((U, d), dtype=torch.float32, device=dev)       # the query users' rows: every rank adds the ones it owns
+
+        def query_rows():
+            own = (ud >= u_lo) & (ud < u_hi)
+            Pq.zero_()
+            Pq[own] = model.P[ud[own] - u_lo]
+            if world > 1:
+                torch.distributed.all_reduce(Pq)
+
+        def run_eval():
+            query_rows()
+            return ev.test_mf(ops.SCORE_RUBI_BOTH, Pq, None, model.Q, [20], model.w, model.wu, c)
+        ret = run_eval(); ret = run_eval()
+        times = []
+        for r_ in range(max(2, min(args.eval_reps, 5))):
+            run_steps(2, 2 * r_)
+            barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ret = run_eval()
+            torch.cuda.synchronize(); barrier()
+            times.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))
+        t_ev = float(np.median(times))
+        flops_rank = 2.0 * U * (i_hi - i_lo) * d
+        eval_out = {"eval_users_per_s": U / t_ev, "eval_ms_per_pass": 1e3 * t_ev, "eval_users": U,
+                    "eval_metrics": {k: float(v[0]) for k, v in ret.items()},
+                    "roofline_eval": {"bound": "mfma", "flops_per_rank": flops_rank, "achieved": flops_rank / t_ev / 1e12,
+                                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_rank / t_ev / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                      "note": "whole evaluation incl. the query-row exchange, the all-gather and the metrics, per rank"}}
+    # ------------------------------------------------------------- CPU baseline (N = 1): the oracle on a 1/64 row sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        nu, ni = n_users // 64, n_items // 64
+        rs = np.random.RandomState(5)
+        Pc = (rs.standard_normal((nu, d)) * 0.02).astype(np.float32); Qc = (rs.standard_normal((ni, d)) * 0.02).astype(np.float32)
+        wc, wuc = w.cpu().numpy().copy(), wu.cpu().numpy().copy()
+        st = oracle.AdamState([Pc.shape, Qc.shape, (d,), (d,)])
+        hb = batches[:4].cpu().numpy()
+        t0, n_cpu = time.perf_counter(), 0
+        while time.perf_counter() - t0 < args.cpu_seconds and n_cpu < 16:
+            k = n_cpu % 4
+            oracle.mf_train_step(ops.LOSS_RUBIBCEBOTH, (hb[k, 0] % nu).astype(np.int32), (hb[k, 1] % ni).astype(np.int32),
+                                 (hb[k, 2] % ni).astype(np.int32), Pc, Qc, wc, wuc, st, lr, regs, alpha, beta, B)
+            n_cpu += 1
+        cpu = {"value": n_cpu * B / (time.perf_counter() - t0), "unit": "interactions/s", "cores": os.cpu_count() or 1, "kind": "port",
+               "sample": "%d oracle steps (B=%d, d=%d) on tables of 1/64 of the rows (%d + %d): the dense Adam pass of the "
+                         "full tables would be 64x that part of a step" % (n_cpu, B, d, nu, ni)}
+    if rank == 0:
+        out = {"metric": "train interactions/sec + eval users/sec (full-catalog top-K@20)",
+               "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "configs[4]: synthetic %d users x %d items, MACR-MF rubibceboth d=%d batch=%d c=%g; ONE model, "
+                                      "rows range-sharded over %d rank(s) (training), item-sharded evaluation of %d query users"
+                                      % (n_users, n_items, d, B, c, world, args.c4_eval_users),
+                          "parallelism": "row-sharded x%d: all-reduce of the batch's 3B rows (%.1f MB) + all-reduce of the (B,B) "
+                                         "partials + broadcast of the branch-vector partials per step; evaluation: all-reduce of "
+                                         "the query rows + one all-gather of per-shard top-K" % (world, 3 * B * d * 4 / 1e6),
+                          "global_batch": B},
+               "rows_per_rank": rows_local, "bytes_per_rank": 4.0 * d * rows_local * 4 + 4.0 * rows_local,
+               "collectives_ms": coll, "kernels": kern, "roofline": roofline,
+               "roofline_step": {"bound": "hbm", "algorithmic_bytes": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                                 "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1) / HBM_PEAK_GBS},
+               "timed_regions": {"n": len(regions), "reported": "median", "min_ms_per_step": 1e3 * min(regions) / args.steps,
+                                 "max_ms_per_step": 1e3 * max(regions) / args.steps},
+               "cpu_baseline": cpu, "last_losses": [float(x) for x in last]}
+        out.update(eval_out)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -111,6 +280,8 @@ def main():
     from macr_amd import ops, sharding, synth
     from macr_amd.evaluator import Evaluator
 
+    if args.workload == "config4":
+        return bench_config4(args, rank, world, dev)
     cfg = synth.WORKLOADS[args.workload]
     B, d = cfg["batch"], cfg["d"]
     kind = ops.LOSS_RUBIBCEBOTH if args.train == "rubibceboth" else ops.LOSS_NORMALBCE
@@ -396,6 +567,11 @@ def main():
                        "parallelism": "replicas x%d (train) / item-sharded x%d + RCCL all-gather (eval)" % (world, world),
                        "global_batch": B * world},
             "eval_users_per_s": eval_users_per_s,
+            "sharded_figure": {"name": "eval_users_per_s", "value": eval_users_per_s, "scaling": "strong",
+                               "note": "`value` counts N independent training replicas (these configs' step fits one GPU: "
+                                       "replicas only, SURVEY.md 8e); the path of this workload that SHARDS over the ranks is the "
+                                       "item-sharded evaluation -- its users/s is the figure a scaling curve should be read from. "
+                                       "--workload config4 trains ONE row-sharded model (strong scaling)"},
             "eval_ms_per_pass": None if ev_elapsed is None else 1e3 * ev_elapsed / args.eval_reps,
             "eval_note": None if ev_elapsed is None else "graph replays; the tables move by --eval-train-steps (%d) untimed training steps "
                          "between two timed evaluations; the evaluator seeds its thresholds with the previous evaluation's best "

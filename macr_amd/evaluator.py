@@ -44,15 +44,27 @@ class Evaluator(object):
         self._stats_evt = None
         self._last_seeded = False
         self.gt = ops.CSR.from_lists(gt_lists, device)
+        # (lo, hi): the `items_tab` the methods below receive is ALREADY this rank's shard, rows [lo, hi) of a catalogue
+        # whose full table exists nowhere (row-sharded training, BASELINE configs[4]); None: a replicated full table
+        self.local_items_range = None
+
+    def _shard(self, items_tab):
+        """(lo, hi, this rank's rows of the item table)"""
+        if self.local_items_range is not None:
+            lo, hi = self.local_items_range
+            assert items_tab.shape[0] == hi - lo
+            return lo, hi, items_tab
+        rank, ws = sharding.world()
+        lo, hi = sharding.item_shard_range(items_tab.shape[0], rank, ws)
+        return lo, hi, items_tab[lo:hi]
 
     # ------------------------------------------------------------------ ranking
     def rank_local(self, kind, users_tab, user_ids, items_tab, K, w=None, wu=None, c=0.0):
         """This rank's item shard: (val, idx) of shape (U,K) with GLOBAL item ids.
         users_tab/items_tab: full embedding tables (replicated on every rank); a rank scores only its contiguous
         item shard."""
-        rank, ws = sharding.world()
-        lo, hi = sharding.item_shard_range(items_tab.shape[0], rank, ws)
-        items_local = items_tab[lo:hi]
+        ws = sharding.world()[1]
+        lo, hi, items_local = self._shard(items_tab)
         sig_u = sig_i = None
         if kind != ops.SCORE_NORMAL:
             sig_i = ops.branch_sigmoid(items_local, w)              # sigmoid(e_i . w)      model.py:141-142,:199-201
@@ -127,6 +139,8 @@ class Evaluator(object):
         return cache[key]
 
     def _has_seeds(self, K, n_items):
+        if self.local_items_range is not None:
+            return (K,) + tuple(self.local_items_range) in self.__dict__.get("_seeds", {})
         rank, ws = sharding.world()
         return (K,) + tuple(sharding.item_shard_range(n_items, rank, ws)) in self.__dict__.get("_seeds", {})
 

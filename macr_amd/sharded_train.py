@@ -99,15 +99,22 @@ class RowShardedMF(object):
     """This rank's shard of the MF model + its optimizer state.  P_full / Q_full (any rank-identical source) are only
     sliced at construction; afterwards a rank holds rows [u_lo,u_hi) of P and [i_lo,i_hi) of Q, nothing else."""
 
-    def __init__(self, P_full, Q_full, w, wu, backend, rank=None, world=None, group=None):
+    def __init__(self, P_full, Q_full, w, wu, backend, rank=None, world=None, group=None, shards=None):
+        """shards=(P_shard, Q_shard, n_users, n_items): this rank's rows directly (P_full / Q_full are ignored) -- for
+        tables whose full copy exists nowhere (10 M x 1 M rows, d = 128)."""
         r, ws = sharding.world()
         self.rank, self.world, self.group = (r if rank is None else rank), (ws if world is None else world), group
-        self.n_users, self.n_items = P_full.shape[0], Q_full.shape[0]
+        self.n_users, self.n_items = (shards[2], shards[3]) if shards else (P_full.shape[0], Q_full.shape[0])
         self.u_lo, self.u_hi = row_range(self.n_users, self.rank, self.world)
         self.i_lo, self.i_hi = row_range(self.n_items, self.rank, self.world)
         clone = lambda t: t.clone().contiguous()
-        self.P, self.Q = clone(P_full[self.u_lo:self.u_hi]), clone(Q_full[self.i_lo:self.i_hi])
+        if shards:
+            self.P, self.Q = shards[0].contiguous(), shards[1].contiguous()
+            assert self.P.shape[0] == self.u_hi - self.u_lo and self.Q.shape[0] == self.i_hi - self.i_lo
+        else:
+            self.P, self.Q = clone(P_full[self.u_lo:self.u_hi]), clone(Q_full[self.i_lo:self.i_hi])
         self.w, self.wu = clone(w.reshape(-1)), clone(wu.reshape(-1))
+        self.collective_ms = None                   # bench: {"rows": [...], "partials": [...], "branch": [...]} event times
         z = torch.zeros_like
         self.mP, self.vP, self.mQ, self.vQ = z(self.P), z(self.P), z(self.Q), z(self.Q)
         self.mw, self.vw, self.mwu, self.vwu = z(self.w), z(self.w), z(self.wu), z(self.wu)
@@ -120,38 +127,46 @@ class RowShardedMF(object):
     def _host_rig(self, t):
         return t.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"
 
-    def _all_reduce(self, t):
-        if self.world == 1:
+    def _timed(self, name, fn):
+        """run a collective; with collective_ms set, bracket it with events on the current stream (read them after a sync)"""
+        if self.collective_ms is None or not torch.cuda.is_available():
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        self.collective_ms.setdefault(name, []).append((e0, e1))
+
+    def _all_reduce(self, t, name="all_reduce"):
+        if self.world == 1 and not sharding.force_collectives():
             return
         if self._host_rig(t):                       # test rig: several ranks on one GPU cannot use RCCL
             h = t.cpu()
             dist.all_reduce(h, group=self.group)
             t.copy_(h)
         else:
-            dist.all_reduce(t, group=self.group)
+            self._timed(name, lambda: dist.all_reduce(t, group=self.group))
 
-    def _broadcast(self, t, src=0):
-        if self.world == 1:
+    def _broadcast(self, t, src=0, name="broadcast"):
+        if self.world == 1 and not sharding.force_collectives():
             return
         if self._host_rig(t):
             h = t.cpu()
             dist.broadcast(h, src, group=self.group)
             t.copy_(h)
         else:
-            dist.broadcast(t, src, group=self.group)
+            self._timed(name, lambda: dist.broadcast(t, src, group=self.group))
 
     # ------------------------------------------------------------------ one step
     def step(self, u, i, j):
         """u, i, j: the SAME batch on every rank (int32, global row ids).  Returns {loss, mf_loss, reg_loss} (3,)."""
         be = self.backend
         rows3 = be.gather(self, u, i, j)
-        self._all_reduce(rows3)                                   # 1. the batch's rows, everywhere
+        self._all_reduce(rows3, "rows")                           # 1. the batch's rows, everywhere
         partials = be.forward_and_bxb(self, rows3, self.rank, self.world)
         if partials is not None:
-            self._all_reduce(partials)                            # 3. row / column sums of the (B,B) term
+            self._all_reduce(partials, "partials")                # 3. row / column sums of the (B,B) term
         losses, branch = be.backward(self, rows3)
         if branch is not None:
-            self._broadcast(branch)                               # 4. one copy of the branch-vector gradients
+            self._broadcast(branch, 0, "branch")                  # 4. one copy of the branch-vector gradients
         be.apply(self, u, i, j)                                   # 5. local segment reduce + dense Adam on the shard
         return losses
 

@@ -11,8 +11,17 @@ applied identically everywhere, so 1/2/4/8-GPU results are identical.
 This module is host logic only (works with gloo/CPU tensors for tests and with
 nccl/HIP tensors in production); the merge kernel itself is macr_topk_merge.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def force_collectives():
+    """MACR_FORCE_COLLECTIVES=1: issue every collective even in a world of ONE rank (a test rig: one GPU can then drive the
+    RCCL code paths -- all_gather_into_tensor on packed int64 device tensors, device all-reduces and broadcasts -- that
+    otherwise first run on a multi-GPU node)."""
+    return os.environ.get("MACR_FORCE_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def world():
@@ -35,7 +44,7 @@ def gather_topk(local_val, local_idx, group=None):
     64-bit word each (fp32 bits in the high half, int32 id in the low half), so the exchange is a single collective
     -- latency-bound, no bucketing or ring tuning needed at this size."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not force_collectives():
         return local_val.unsqueeze(0), local_idx.unsqueeze(0)
     if local_val.is_cuda and dist.get_backend(group) == "gloo":
         # test rig only (several ranks sharing one GPU cannot use RCCL): gloo gathers host tensors
@@ -53,7 +62,7 @@ def gather_topk(local_val, local_idx, group=None):
 def max_over_ranks(x, device):
     """max of a python float over ranks (bench timing contract)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not force_collectives():
         return x
     t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -69,7 +78,7 @@ def broadcast_params(tensors, src=0, group=None):
     """Make every rank hold rank `src`'s copy of the model before an item-sharded evaluation: the ranks of a CLI run
     train replicas on identical batches, but floating-point atomics add in a different order on every GPU, so the
     replicas drift apart bit by bit -- and a sharded ranking must score ONE model."""
-    if world()[1] == 1:
+    if world()[1] == 1 and not force_collectives():
         return
     for t in tensors:
         if t.is_cuda and dist.get_backend(group) == "gloo":     # test rig: several ranks on one GPU

@@ -319,3 +319,55 @@ def test_fullsize_seeded_rankings_at_every_staleness(ops, workload):
     assert seen[0] == [0, 0], seen                        # seeds that hold: no block listed twice
     assert seen[2][0] == blocks and seen[2][1] == 0, seen  # replaced tables: every block re-listed, no exact fallback
     assert seen[1][1] == 0, seen
+
+
+def test_a_table_beyond_four_gib(ops):
+    """configs[4] on one GPU: a user table of 9 M x 128 fp32 = 4.6 GB, every batch user beyond the 2^32-byte mark of the
+    table (and of its Adam slots and gradient scratch).  The oracle runs on the COMPACT problem -- the rows the batch
+    refers to, renumbered -- which is the same step: TF's dense Adam leaves a row without gradient and with zero slots
+    exactly where it was.  Touched rows against the oracle, a sample of untouched rows (both sides of the 4 GiB mark)
+    bit-unchanged; once through macr_mf_train_step, once through the row-sharded entry points (world = 1)."""
+    from macr_amd import sharded_train
+    n_users, n_items, d, B = 9_000_000, 50_000, 128, 4096
+    assert n_users * d * 4 > 2 ** 32
+    lr, decay, alpha, beta = 1e-3, 1e-5, 1e-3, 1e-3
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    rs = np.random.RandomState(12)
+    first_high = 2 ** 32 // (d * 4) + 1                                    # first row that lies entirely beyond 4 GiB
+    u = np.sort(rs.choice(np.arange(first_high, n_users), B, replace=False)).astype(np.int32)
+    rs.shuffle(u)
+    i = (rs.zipf(1.3, B) % n_items).astype(np.int32)
+    j = rs.randint(0, n_items, B).astype(np.int32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    hyper = ops.make_hyper(lr, decay, alpha, beta, B)
+    probe = np.concatenate([np.arange(0, 64), np.arange(first_high - 32, first_high + 32), rs.randint(0, n_users, 256)])
+    probe = np.setdiff1d(probe, u).astype(np.int64)
+    for path in ("single", "sharded"):
+        P = (torch.randn((n_users, d), generator=gen, device="cuda") * 0.05).contiguous()
+        Q = (torch.randn((n_items, d), generator=gen, device="cuda") * 0.05).contiguous()
+        # compact oracle problem: the batch's user rows 0..B-1
+        Pc = P[torch.from_numpy(u.astype(np.int64)).cuda()].cpu().numpy()
+        Qc = Q.cpu().numpy().copy()
+        before = P[torch.from_numpy(probe).cuda()].clone()
+        st = oracle.AdamState([Pc.shape, Qc.shape, (d,), (d,)])
+        wo, wuo = w.copy(), wu.copy()
+        want = oracle.mf_train_step(1, np.arange(B, dtype=np.int32), i, j, Pc, Qc, wo, wuo, st, lr, decay, alpha, beta, B)
+        if path == "single":
+            state = ops.MFState(P, Q, dev(w), dev(wu), hyper, B)
+            got = state.step(1, dev(u), dev(i), dev(j)).cpu().numpy()
+            Pn, Qn = state.P, state.Q
+        else:
+            model = sharded_train.RowShardedMF(None, None, dev(w), dev(wu), sharded_train.HipBackend(1, d, hyper, torch.device("cuda")),
+                                               rank=0, world=1, shards=(P, Q, n_users, n_items))
+            got = model.step(dev(u), dev(i), dev(j)).cpu().numpy()
+            Pn, Qn = model.P, model.Q
+        np.testing.assert_allclose(got, want, rtol=1e-5, err_msg=path)
+        np.testing.assert_allclose(Pn[torch.from_numpy(u.astype(np.int64)).cuda()].cpu().numpy(), Pc, rtol=0, atol=2e-3 * lr, err_msg=path)
+        np.testing.assert_allclose(Qn.cpu().numpy(), Qc, rtol=0, atol=2e-3 * lr, err_msg=path)
+        assert torch.equal(Pn[torch.from_numpy(probe).cuda()], before), path       # no gradient, zero slots: untouched
+        del P, Q, Pn, Qn
+        if path == "single":
+            del state
+        else:
+            del model
+        torch.cuda.empty_cache()

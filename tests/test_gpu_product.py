@@ -484,6 +484,20 @@ def test_row_sharded_training_two_ranks_one_gpu(tmp_path):
     assert res["world"] == 2 and res["rows_on_rank0"] < 0.51 * res["rows_total"]     # a rank holds half of the rows
 
 
+def test_rccl_code_paths_in_a_world_of_one(tmp_path):
+    """The collectives of the multi-GPU paths on backend "nccl" (RCCL) with device tensors, driven from ONE GPU
+    (MACR_FORCE_COLLECTIVES=1: world-size-1 collectives are issued instead of skipped): the packed int64 all-gather of
+    per-shard top-K lists, max_over_ranks, broadcast_params, and a row-sharded training step's two all-reduces and its
+    broadcast -- results equal to the single-GPU step."""
+    import json
+    env = dict(os.environ, PYTHONUNBUFFERED="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "rccl_world1_worker.py")], cwd=str(tmp_path), env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"], res
+
+
 def test_injected_weights_round_trip(ops):
     """a1: parity runs inject the reference's initial values (`weights=`): the model must hold exactly those numbers,
     share them between its optimizer instances, and hand them back through state_dict()."""

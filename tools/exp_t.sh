@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -k "four_gib" 2>&1 | tail -12
