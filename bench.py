@@ -62,9 +62,10 @@ def parse():
     ap.add_argument("--train", default="rubibceboth", choices=["normalbce", "rubibceboth"])
     ap.add_argument("--eval-reps", type=int, default=20, help="timed evaluations (more than one period of the seeding policy's back-off)")
     ap.add_argument("--eval-settle", type=int, default=6, help="untimed evaluations (with the training steps between them) before the timed ones")
-    ap.add_argument("--eval-train-steps", type=int, default=20,
+    ap.add_argument("--eval-train-steps", type=int, default=-1,
                     help="untimed training steps between two timed evaluations (the evaluator seeds its thresholds with the "
-                         "previous evaluation's ranking, so the tables must move as they do in a training run)")
+                         "previous evaluation's ranking, so the tables must move as they do in a training run).  Default -1 = "
+                         "what the CLIs do between two evaluations: --log_interval 10 epochs of n_train // batch + 1 steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pos", default="zipf", choices=["zipf", "uniform"], help="positive-item distribution (diagnostic)")
@@ -284,6 +285,8 @@ def main():
         return bench_config4(args, rank, world, dev)
     cfg = synth.WORKLOADS[args.workload]
     B, d = cfg["batch"], cfg["d"]
+    if args.eval_train_steps < 0:
+        args.eval_train_steps = 10 * (cfg["n_train"] // B + 1)
     kind = ops.LOSS_RUBIBCEBOTH if args.train == "rubibceboth" else ops.LOSS_NORMALBCE
     gen = torch.Generator(device=dev).manual_seed(12345 + rank)
     P = synth.xavier_table(cfg["n_users"], d, gen, dev)

@@ -95,6 +95,40 @@ __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + ex
 __device__ __forceinline__ float dneglog_sig(float s, float eps) { return -((s * (1.0f - s)) / (s + eps)); }
 __device__ __forceinline__ float dneglog_1msig(float s, float eps) { return (s * (1.0f - s)) / ((1.0f - s) + eps); }
 
+// ---- Adam (shared by the dense pass of train_kernels.hip and the fused epilogue of spmm_kernels.hip) -------------
+struct StepScalars {
+    float lr_t;          // lr * sqrt(1-beta2^t) / (1-beta1^t)   (TF 1.14 Adam)
+    float pad[3];
+};
+
+// theta -= (lr_t*m) / (sqrt(v)+eps), one element.  Default: v_sqrt_f32 (<= 1 ulp; denormal v flushes to 0, where eps = 1e-8
+// is the whole denominator anyway) and a reciprocal-based quotient with one residual correction (q0 = n*rcp(d),
+// q = q0 + (n - d*q0)*rcp(d): correctly rounded in all but rare cases, <= 1 ulp always) -- 13 VALU instructions per
+// element instead of the 33 of the IEEE sqrtf and division expansions (scaling for denormals, +-1 ulp candidates,
+// v_div_scale/fmas/fixup).  Stand-alone the pass is bound by memory and does not care; riding in the VALU-bound (B,B)
+// launch every instruction counts (PMC: the pass was 49 % of that kernel's VALU instructions): 23.1 -> see DESIGN.md.
+// The quotient is a step of size ~lr added to theta: 1 ulp of it is ~1e-10, below the resolution of theta itself, and
+// tf.train.AdamOptimizer's own rounding is not pinned by anything the reference ships.  -DMACR_ADAM_IEEE restores the
+// correctly rounded forms (the oracle uses those; tests compare with tolerances either way).
+__device__ __forceinline__ float adam_update(float th, float m, float v, float lr_t, float eps) {
+#ifdef MACR_ADAM_IEEE
+    return th - (lr_t * m) / (sqrtf(v) + eps);
+#else
+    const float d = __builtin_amdgcn_sqrtf(v) + eps, n = lr_t * m;
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q0 = n * r;
+    const float q = fmaf(fmaf(-d, q0, n), r, q0);
+    return th - q;
+#endif
+}
+
+// m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; theta -= lr_t*m/(sqrt(v)+eps)      (TF 1.14 Adam), one element
+__device__ __forceinline__ void adam1(float &th, float &m, float &v, float g, float lr_t, float b1, float b2, float eps) {
+    m = m * b1 + g * (1.0f - b1);
+    v = v * b2 + (g * g) * (1.0f - b2);
+    th = adam_update(th, m, v, lr_t, eps);
+}
+
 // ---- test-time score epilogue (macr_mf/model.py:45, :141-142, :199-201) ---------------------------------
 // Every operation rounds on its own, in the order the reference's expression evaluates (the empty asm pins the
 // product in a register: hipcc would otherwise contract `v - c*s` into one fma -- __fmul_rn does not prevent that

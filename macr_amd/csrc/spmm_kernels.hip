@@ -84,10 +84,27 @@ __device__ __host__ inline PlanView view_plan(const void *plan, const PlanHeader
 constexpr int kDense = 0, kSparseOut = 1, kSparseIn = 2;
 
 struct SparseCtx {                // device pointers
-    const uint8_t *rows;          // [N] 1 = a row of the current batch
+    int32_t *cnt;                 // [N] how often the current batch refers to a row (0: not a row of the batch).  The last
+                                  // forward layer COUNTS (one wave per reference), the first backward layer reads the
+                                  // counts as flags, the fused epilogue of the last backward layer consumes and clears them
     const int32_t *u, *i, *j;     // the batch: rows u[b], n_users + i[b], n_users + j[b]
     int B, n_users;
     int chunk;                    // rows longer than this are hub rows (cut into pieces by the plan); INT_MAX without a plan
+    int count;                    // kSparseOut: 1 = count the references into cnt (a training step), 0 = leave it alone
+};
+
+// The optimizer, fused into the epilogue of the LAST backward layer (a LightGCN training step; LightGCN.py:186/:201 are
+// dense Adam over the ego table T): the wave that finishes row r holds its gradient (S_in[r] + A X[r]) * scale in
+// registers and applies it on the spot -- together with the ego-row regulariser coef * cnt[r] * T[r] (LightGCN.py:525-528:
+// one term per reference) and the row's share cnt[r] * |T[r]|^2 of emb_loss -- instead of writing G for a separate pass
+// over the table (125 MB of traffic and two more launches per step).  It also clears cnt[r] and the row dE[r] of the
+// gradient buffer the pair kernels accumulate into: both are zero again when the next step starts.
+struct AdamFuse {
+    float *T, *m, *v;             // ego table and its Adam slots, updated in place (NULL: no fusion)
+    const StepScalars *scal;      // lr_t of this step (written by pair_bwd)
+    float b1, b2, eps, coef;      // coef = decay / batch_size
+    float *dE;                    // gradient buffer of the pair kernels (rows of the batch are zeroed)
+    double *emb_acc;              // [2048] partial sums of cnt * |T row|^2 (emb_loss), slot = row % 2048
 };
 
 struct SpmmArgs {
@@ -120,7 +137,7 @@ __device__ __forceinline__ float ld_elem(const float *__restrict__ X, int c, int
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(X) + off);
 }
 
-__device__ __forceinline__ bool row_flag(const uint8_t *__restrict__ rows, int r) { return rows[r] != 0; }
+__device__ __forceinline__ bool row_flag(const int32_t *cnt, int r) { return cnt[r] != 0; }
 
 // Lane geometry: D >= 64: lane l holds columns l + 64 v (v < NV), one entry per step; D = 32: lane l holds column
 // l % 32, the half-waves take alternate entries (two per step).
@@ -227,9 +244,10 @@ __device__ __forceinline__ void gather_batches_masked(int cv, float av, uint64_t
 struct SpmmScalars {
     int N, n_items, n_slots, n_groups;
     float scale;
-    int B, n_users, chunk;        // SparseCtx
+    int B, n_users, chunk, count; // SparseCtx
+    float b1, b2, eps, coef;      // AdamFuse
 };
-template <int D, int SPARSE>
+template <int D, int SPARSE, bool FUSE>
 __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int32_t *__restrict__ rowptr,
                                                   const int32_t *__restrict__ col, const float *__restrict__ val,
                                                   const int4 *__restrict__ items, const int32_t *__restrict__ slot_group,
@@ -237,17 +255,18 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
                                                   const int32_t *__restrict__ group_split,
                                                   const int32_t *__restrict__ split_group0, int32_t *arrivals,
                                                   const float *__restrict__ X, float *Y, const float *S_in, float *S_out,
-                                                  float *slab, const uint8_t *__restrict__ sp_rows,
+                                                  float *slab, int32_t *sp_cnt,
                                                   const int32_t *__restrict__ sp_u, const int32_t *__restrict__ sp_i,
-                                                  const int32_t *__restrict__ sp_j) {
+                                                  const int32_t *__restrict__ sp_j, float *fT, float *fm, float *fv,
+                                                  const StepScalars *__restrict__ fscal, float *fdE, double *femb) {
     struct {                       // (the names the body uses)
         int N, n_items, n_slots, n_groups; float scale;
         const int32_t *rowptr; const int4 *items;
         const int32_t *slot_group, *group_slot0, *group_split, *split_group0; int32_t *arrivals;
         float *Y; const float *S_in; float *S_out; float *slab;
-        struct { const uint8_t *rows; const int32_t *u, *i, *j; int B, n_users, chunk; } sp;
+        struct { int32_t *rows; const int32_t *u, *i, *j; int B, n_users, chunk, count; } sp;
     } A = {P.N, P.n_items, P.n_slots, P.n_groups, P.scale, rowptr, items, slot_group, group_slot0, group_split, split_group0,
-           arrivals, Y, S_in, S_out, slab, {sp_rows, sp_u, sp_i, sp_j, P.B, P.n_users, P.chunk}};
+           arrivals, Y, S_in, S_out, slab, {sp_cnt, sp_u, sp_i, sp_j, P.B, P.n_users, P.chunk, P.count}};
     using G = RowGeom<D>;
     constexpr int NV = G::NV;
     constexpr int EPB = 8 * G::EPS;                              // entries per batch
@@ -271,6 +290,9 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
             const int k = w - A.n_slots;
             const int which = k / A.sp.B, b = k - which * A.sp.B;
             const int r = which == 0 ? A.sp.u[b] : A.sp.n_users + (which == 1 ? A.sp.i[b] : A.sp.j[b]);
+            // count the reference (no value returned: nothing waits).  Positives only when the pair kernels cannot
+            // (count == 2): they repeat, and pair_bwd counts them with one atomic per distinct row of a chunk
+            if ((A.sp.count == 2 || (A.sp.count == 1 && which != 1)) && lane == 0) atomicAdd(A.sp.rows + r, 1);
             const int beg = A.rowptr[r], end = A.rowptr[r + 1];
             d = make_int4(end - beg > A.sp.chunk ? -1 : r, beg, end, -1);     // a hub row: its pieces compute it
             pin(d);
@@ -289,10 +311,21 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
     const int r = cur.x, beg = cur.y, slot = cur.w;
     int end = cur.z;
     if (r < 0) return;
-    const bool s_on = A.S_out && (SPARSE != kSparseIn || row_flag(A.sp.rows, r));     // else S_in[r] counts as zero
+    const bool s_on = (A.S_out || FUSE) && (SPARSE != kSparseIn || row_flag(A.sp.rows, r));   // else S_in[r] counts as zero
     float s[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) s[v] = (s_on && slot < 0) ? A.S_in[(size_t)r * D + colofs + 64 * v] : 0.f;   // used last, asked for first
+    // fused optimizer: the row's parameter, its Adam slots and its reference count travel with the first gathers too
+    float th0[NV], m0[NV], v0[NV];
+    int c0 = 0;
+    if (FUSE && slot < 0) {
+        c0 = A.sp.rows[r];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const size_t o = (size_t)r * D + colofs + 64 * v;
+            th0[v] = fT[o]; m0[v] = fm[o]; v0[v] = fv[o];
+        }
+    }
     float acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.f;
@@ -416,6 +449,39 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
 #ifdef MACR_ABL_SPMM_NOSTORE
     if (acc[0] != 123.f) return;
 #endif
+    if (FUSE) {
+        // gradient of row r -> Adam on T[r] (see AdamFuse)
+        if (slot >= 0) {                                         // the finisher of a hub row asks now
+            c0 = A.sp.rows[r];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const size_t o = (size_t)r * D + colofs + 64 * v;
+                th0[v] = fT[o]; m0[v] = fm[o]; v0[v] = fv[o];
+            }
+        }
+        const int c = __builtin_amdgcn_readfirstlane(c0);       // references of the batch to this row (wave-uniform)
+        const float lr_t = fscal->lr_t;
+        float sq = 0.f;
+        if (writer) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const size_t o = (size_t)r * D + colofs + 64 * v;
+                float th = th0[v], m = m0[v], vv = v0[v];
+                float g = (s[v] + acc[v]) * A.scale;
+                if (c) { g = fmaf(P.coef * (float)c, th, g); sq = fmaf(th, th, sq); fdE[o] = 0.f; }
+                adam1(th, m, vv, g, lr_t, P.b1, P.b2, P.eps);
+                fT[o] = th; fm[o] = m; fv[o] = vv;
+            }
+        }
+        if (c) {                                                 // wave-uniform
+            sq = wave_sum(sq);
+            if (lane == 0) {
+                atomicAdd(femb + (r & 2047), (double)c * (double)sq);
+                A.sp.rows[r] = 0;
+            }
+        }
+        return;
+    }
     if (writer) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -440,7 +506,7 @@ __global__ void k_scale_copy(size_t n_vec, const float *__restrict__ in, float *
 // with mode kSparseIn: E0 is row-sparse, only its flagged rows are non-zero (and only they are read).
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
                      const void *plan_dev, const void *plan_host_header, const float *E0, float *E, float *work,
-                     hipStream_t st, const SparseCtx *sp, int sparse_mode) {
+                     hipStream_t st, const SparseCtx *sp, int sparse_mode, const AdamFuse *fuse) {
     const size_t nd = (size_t)N * d;
     float *bufA = work, *bufB = work + nd;            // alternating layer outputs
     float *sum = work + 2 * nd;                       // E0 + A E0 + ... up to the layer before the last
@@ -473,19 +539,24 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
         const int mode = !sp ? kDense
                          : (sparse_mode == kSparseOut && last) ? kSparseOut
                          : (sparse_mode == kSparseIn && l == 0) ? kSparseIn : kDense;
-        a.X = X; a.Y = Y; a.S_in = S_in; a.S_out = last ? E : sum; a.scale = scale;
-        if (mode != kDense) a.sp = *sp;
+        const bool fused = last && fuse && fuse->T;          // the optimizer in this layer's epilogue: nothing is stored to E
+        a.X = X; a.Y = Y; a.S_in = S_in; a.S_out = fused ? nullptr : last ? E : sum; a.scale = scale;
+        if (mode != kDense || fused) a.sp = *sp;
+        const AdamFuse af = fused ? *fuse : AdamFuse{};
         const int waves = mode == kSparseOut ? (plan_dev ? ph.n_slots : 0) + 3 * sp->B : n_waves;
         const int grid = (waves + 3) / 4;
-        const char *name = mode == kSparseOut ? "spmm_csr_rows" : mode == kSparseIn ? "spmm_csr_sparse" : "spmm_csr";
-        const SpmmScalars ps = {a.N, a.n_items, a.n_slots, a.n_groups, a.scale, a.sp.B, a.sp.n_users, a.sp.chunk};
+        const char *name = mode == kSparseOut ? "spmm_csr_rows" : mode == kSparseIn ? "spmm_csr_sparse" : fused ? "spmm_csr+adam" : "spmm_csr";
+        const SpmmScalars ps = {a.N, a.n_items, a.n_slots, a.n_groups, a.scale, a.sp.B, a.sp.n_users, a.sp.chunk, a.sp.count,
+                                af.b1, af.b2, af.eps, af.coef};
 #define MACR_SPMM_ARGS ps, a.rowptr, a.col, a.val, a.items, a.slot_group, a.group_slot0, a.group_split, a.split_group0, \
-                       a.arrivals, a.X, a.Y, a.S_in, a.S_out, a.slab, a.sp.rows, a.sp.u, a.sp.i, a.sp.j
-#define MACR_SPMM_ROW(D_)                                                                                  \
-    do {                                                                                                   \
-        if (mode == kSparseOut) k_spmm_row<D_, kSparseOut><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);          \
-        else if (mode == kSparseIn) k_spmm_row<D_, kSparseIn><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);       \
-        else k_spmm_row<D_, kDense><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);                                 \
+                       a.arrivals, a.X, a.Y, a.S_in, a.S_out, a.slab, a.sp.cnt, a.sp.u, a.sp.i, a.sp.j, af.T, af.m, af.v,  \
+                       af.scal, af.dE, af.emb_acc
+#define MACR_SPMM_ROW(D_)                                                                                         \
+    do {                                                                                                          \
+        if (mode == kSparseOut) k_spmm_row<D_, kSparseOut, false><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);          \
+        else if (mode == kSparseIn) k_spmm_row<D_, kSparseIn, false><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);       \
+        else if (fused) k_spmm_row<D_, kDense, true><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);                       \
+        else k_spmm_row<D_, kDense, false><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);                                 \
     } while (0)
         switch (d) {
             case 32: MACR_SPMM_ROW(32); break;
@@ -603,5 +674,5 @@ extern "C" int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *ro
     MACR_REQUIRE(E != E0, MACR_E_INVALID, "lgcn_propagate: E must not alias E0");
     if (int e = check_plan(plan_dev, plan_host, N, "lgcn_propagate")) return e;
     return macr::launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, E0, E, work,
-                                  macr::as_stream(stream), nullptr, 0);
+                                  macr::as_stream(stream), nullptr, 0, nullptr);
 }

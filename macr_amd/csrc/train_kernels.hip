@@ -30,11 +30,6 @@ namespace macr {
 // ----------------------------------------------------------------------------
 // Small per-step scalar block living at the start of the workspace.
 // ----------------------------------------------------------------------------
-struct StepScalars {
-    float lr_t;          // lr * sqrt(1-beta2^t) / (1-beta1^t)   (TF 1.14 Adam)
-    float pad[3];
-};
-
 // Partial-sum slots written by the pair kernels (one set per block), reduced by adam_dense block 0.
 // slot 0: sum of squares (regulariser)   1: L_item terms   2: L_user terms   3: per-pair BCE (normalbce)
 constexpr int kPartStride = 4;
@@ -92,27 +87,6 @@ struct LossArgs {
 constexpr int kAdamIters = MACR_ADAM_ITERS;          // float4 per thread and array (2, 4, 8 measured: no difference)
 constexpr int kAdamVecPerBlock = 256 * kAdamIters;
 constexpr int kBranchSlots = 8;             // partial rows of the branch-vector gradients (pair_bwd adds, Adam consumes)
-
-// theta -= (lr_t*m) / (sqrt(v)+eps), one element.  Default: v_sqrt_f32 (<= 1 ulp; denormal v flushes to 0, where eps = 1e-8
-// is the whole denominator anyway) and a reciprocal-based quotient with one residual correction (q0 = n*rcp(d),
-// q = q0 + (n - d*q0)*rcp(d): correctly rounded in all but rare cases, <= 1 ulp always) -- 13 VALU instructions per
-// element instead of the 33 of the IEEE sqrtf and division expansions (scaling for denormals, +-1 ulp candidates,
-// v_div_scale/fmas/fixup).  Stand-alone the pass is bound by memory and does not care; riding in the VALU-bound (B,B)
-// launch every instruction counts (PMC: the pass was 49 % of that kernel's VALU instructions): 23.1 -> see DESIGN.md.
-// The quotient is a step of size ~lr added to theta: 1 ulp of it is ~1e-10, below the resolution of theta itself, and
-// tf.train.AdamOptimizer's own rounding is not pinned by anything the reference ships.  -DMACR_ADAM_IEEE restores the
-// correctly rounded forms (the oracle uses those; tests compare with tolerances either way).
-__device__ __forceinline__ float adam_update(float th, float m, float v, float lr_t, float eps) {
-#ifdef MACR_ADAM_IEEE
-    return th - (lr_t * m) / (sqrtf(v) + eps);
-#else
-    const float d = __builtin_amdgcn_sqrtf(v) + eps, n = lr_t * m;
-    const float r = __builtin_amdgcn_rcpf(d);
-    const float q0 = n * r;
-    const float q = fmaf(fmaf(-d, q0, n), r, q0);
-    return th - q;
-#endif
-}
 
 __device__ __forceinline__ void adam4(float4 &th, float4 &m, float4 &v, const float4 gr, float lr_t, float b1,
                                       float b2, float eps) {
@@ -192,7 +166,7 @@ __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, flo
 }
 
 // deterministic reduction of the step's loss partials (double) by the calling wave -> losses[3]
-__device__ __forceinline__ void finalize_losses(const LossArgs &L, int lane) {
+__device__ __forceinline__ void finalize_losses(const LossArgs &L, int lane, double sq_extra = 0.0) {
     double sq = 0, li = 0, lu = 0, bce = 0, lo = 0;
     for (int k = lane; k < L.n_part; k += 64) {
         const float *o = L.part + (size_t)k * kPartStride;
@@ -200,7 +174,7 @@ __device__ __forceinline__ void finalize_losses(const LossArgs &L, int lane) {
     }
     for (int k = lane; k < L.n_part2; k += 64) sq += L.part2[(size_t)k * kPartStride];
     for (int k = lane; k < L.n_lpart; k += 64) lo += L.lpart[k];
-    sq = wave_sum_d(sq); li = wave_sum_d(li); lu = wave_sum_d(lu); bce = wave_sum_d(bce); lo = wave_sum_d(lo);
+    sq = wave_sum_d(sq) + sq_extra; li = wave_sum_d(li); lu = wave_sum_d(lu); bce = wave_sum_d(bce); lo = wave_sum_d(lo);
     if (lane == 0) {
         const double Bd = (double)L.B;
         float mf;
@@ -580,7 +554,9 @@ struct WaveRow {
 // not (the batch arrives bucketed by the low byte of the positive item, batch_bucket_block, so the hottest item of a
 // batch costs (#chunks it spans) serialised atomics instead of (#references)).
 template <int D>
-__device__ __forceinline__ void combine_positive_rows(const int *s_pos, const float (*s_gi)[D], float *gI) {
+__device__ __forceinline__ void combine_positive_rows(const int *s_pos, const float (*s_gi)[D], float *gI,
+                                                      int32_t *cnt = nullptr) {
+    // cnt (LightGCN): cnt[row] += the row's references in this chunk, one atomic per DISTINCT row of the chunk
     // thread = (element k, part): part p of NP handles the distinct rows whose FIRST slot L has L % NP == p
     constexpr int NP = D >= 256 ? 1 : 256 / D;
     const int k = threadIdx.x % D, part = threadIdx.x / D;
@@ -595,10 +571,12 @@ __device__ __forceinline__ void combine_positive_rows(const int *s_pos, const fl
         for (int s0 = 0; s0 < L; ++s0) first = first && rows[s0] != rows[L];
         if (!first) continue;
         float acc = s_gi[L][k];
+        int mult = 1;
 #pragma unroll
         for (int s2 = L + 1; s2 < kChunkT; ++s2)
-            if (rows[s2] == rows[L]) acc += s_gi[s2][k];
+            if (rows[s2] == rows[L]) { acc += s_gi[s2][k]; ++mult; }
         MACR_ATOMIC_ADD(gI + (size_t)rows[L] * D + k, acc);
+        if (cnt && k == 0) atomicAdd(cnt + rows[L], mult);
     }
 }
 
@@ -621,7 +599,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     const float *__restrict__ rowpart, const float *__restrict__ colpart,
     float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *__restrict__ wpart,
     float alpha, float beta, float coef, float *adam_pow, StepScalars *scal, float lr, float b1, float b2,
-    LossArgs L) {
+    LossArgs L, int32_t *cnt_pos) {
     constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float s_w[4][2][D];
     __shared__ float s_gi[kChunkT][D];
@@ -714,7 +692,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
             }
         }
         __syncthreads();
-        combine_positive_rows<D>(s_pos, s_gi, gI);
+        combine_positive_rows<D>(s_pos, s_gi, gI, cnt_pos);
         __syncthreads();
     }
     if (act) {
@@ -742,7 +720,7 @@ __global__ __launch_bounds__(256) void k_pair_normal(
     const float *__restrict__ Usrc, const float *__restrict__ Isrc,
     float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *__restrict__ part, float coef,
     int reg_on_gathered, const float *__restrict__ adam_pow_in, float *adam_pow_out, StepScalars *scal,
-    float lr, float b1, float b2) {
+    float lr, float b1, float b2, int32_t *cnt_pos) {
     constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float red[16];
     __shared__ float s_gi[kChunkT][D];
@@ -793,7 +771,7 @@ __global__ __launch_bounds__(256) void k_pair_normal(
             }
         }
         __syncthreads();
-        if (gI) combine_positive_rows<D>(s_pos, s_gi, gI);
+        if (gI) combine_positive_rows<D>(s_pos, s_gi, gI, cnt_pos);
         __syncthreads();
     }
     const float s0 = block_sum(sq, red);
@@ -992,9 +970,7 @@ template <int D>
 __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const int32_t *__restrict__ u,
                                                      const int32_t *__restrict__ i, const int32_t *__restrict__ j,
                                                      const float *__restrict__ T, float *G, float coef,
-                                                     float *__restrict__ part, uint8_t *__restrict__ rows) {
-    // rows (may be NULL): the row flags k_mark_rows set for this batch; nothing reads them after this kernel has
-    // started, so it clears them for the next step.
+                                                     float *__restrict__ part) {
     // u, i, j: the batch grouped by positive item when the caller has it (batch_bucket_block): a block owns kChunkT
     // consecutive slots and adds equal positive rows of its chunk once (combine_positive_rows) -- the hot item of a
     // batch is referenced hundreds of times, and that many atomics on one row serialise (19.6 -> see DESIGN.md)
@@ -1011,7 +987,6 @@ __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const 
             const int slot = wid * (kChunkT / 4) + q, t = chunk * kChunkT + slot;
             if (t >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
             const int ru = u[t], ri = i[t] + item_off, rj = j[t] + item_off;
-            if (rows && lane < 3) rows[lane == 0 ? ru : lane == 1 ? ri : rj] = 0;
             if (act) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
@@ -1043,32 +1018,42 @@ __global__ __launch_bounds__(256) void k_reg_scatter(int B, int item_off, const 
 namespace macr {
 
 struct SparseCtx {                // = spmm_kernels.hip
-    const uint8_t *rows;          // [N] 1 = a row of the current batch
+    int32_t *cnt;                 // [N] references of the current batch per row (0: not a row of the batch)
     const int32_t *u, *i, *j;     // the batch: rows u[b], n_users + i[b], n_users + j[b]
     int B, n_users;
     int chunk;                    // rows longer than this are hub rows (cut into pieces by the plan); INT_MAX without a plan
+    int count;                    // kSparseOut: 1 = count the references into cnt
+};
+struct AdamFuse {                 // = spmm_kernels.hip: dense Adam on the ego table in the epilogue of the last backward layer
+    float *T, *m, *v;
+    const StepScalars *scal;
+    float b1, b2, eps, coef;
+    float *dE;
+    double *emb_acc;
 };
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
                      const void *plan_dev, const void *plan_host_header, const float *E0, float *E, float *work,
-                     hipStream_t st, const SparseCtx *sp, int sparse_mode);           // spmm_kernels.hip
+                     hipStream_t st, const SparseCtx *sp, int sparse_mode, const AdamFuse *fuse);   // spmm_kernels.hip
 constexpr int kSparseOut = 1, kSparseIn = 2;                                          // = spmm_kernels.hip
+constexpr int kEmbSlots = 2048;
 
-// rows[r] = 1 for every table row a LightGCN batch refers to (users u, items n_users + i, n_users + j), and -- when dE is
-// given -- those rows of dE are zeroed: the only rows of the gradient buffer the step ever reads (pair_bwd accumulates
-// into them, the first backward SpMM and its epilogue read flagged rows only).  One lane group per row reference.
-// rows[] is zero on entry: k_reg_scatter, the last kernel of a step that walks the batch, clears the flags again.
-template <int D>
-__global__ __launch_bounds__(256) void k_mark_rows(int B, int n_users, const int32_t *__restrict__ u, const int32_t *__restrict__ i,
-                                                   const int32_t *__restrict__ j, uint8_t *__restrict__ rows, float *__restrict__ dE) {
-    constexpr int LPR = D / 4;
-    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const size_t ref = t / LPR;
-    const int sub = (int)(t % LPR);
-    if (ref >= (size_t)3 * B) return;
-    const int which = (int)(ref / B), b = (int)(ref % B);
-    const int r = which == 0 ? u[b] : n_users + (which == 1 ? i[b] : j[b]);
-    if (dE) st4(dE + (size_t)r * D + 4 * sub, make_float4(0.f, 0.f, 0.f, 0.f));
-    if (sub == 0) rows[r] = 1;
+// The tail of a fused LightGCN step: Adam on the branch vectors (their gradients are the partial rows pair_bwd left) and
+// the losses -- emb_loss from the sums of cnt * |T row|^2 the fused epilogue accumulated (cleared here for the next step).
+__global__ __launch_bounds__(256) void k_lgcn_finalize(AdamArgs a, const StepScalars *scal, LossArgs L, double *emb_acc) {
+    __shared__ float4 s_red[256];
+    if (blockIdx.x < a.n_seg) { adam_block<true>(a, a.seg[blockIdx.x].first_block, scal->lr_t, s_red); return; }
+    // the whole block reads the slots (all loads in flight at once), one wave finishes
+    __shared__ double s_sq[4];
+    double sq = 0.0;
+    double part[kEmbSlots / 256];
+#pragma unroll
+    for (int k = 0; k < kEmbSlots / 256; ++k) part[k] = emb_acc[k * 256 + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < kEmbSlots / 256; ++k) { sq += part[k]; emb_acc[k * 256 + threadIdx.x] = 0.0; }
+    sq = wave_sum_d(sq);
+    if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x < 64) finalize_losses(L, threadIdx.x, s_sq[0] + s_sq[1] + s_sq[2] + s_sq[3]);
 }
 
 #define MACR_DISPATCH_D(d, ...)                                  \
@@ -1207,7 +1192,8 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
                        float *gU, float *gI, int32_t *tU, int32_t *tI, float coef, int reg_on_gathered,
                        float *adam_pow, const macr_hyper *hp, const PairWs &ws, hipStream_t st,
                        const PendingAdam *pa = nullptr, const AdamArgs *pending = nullptr,
-                       long long n_pending_blocks = 0, const LossArgs *finalize = nullptr, bool loss_only = false) {
+                       long long n_pending_blocks = 0, const LossArgs *finalize = nullptr, bool loss_only = false,
+                       int32_t *cnt_pos = nullptr) {
     const int grid = ws.nblk_pair;
     const int user_branch = kind == MACR_LOSS_RUBIBCEBOTH;
     BatchSort sort = batch_sort_args(ws, B, u, i, j);
@@ -1216,7 +1202,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
         const int nb = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;
         MACR_DISPATCH_D(d, (k_pair_normal<D><<<nb, 256, 0, st>>>(B, u, i, j, Usrc, Isrc, nullptr, nullptr, nullptr, nullptr,
                                                                 ws.part, coef, reg_on_gathered, adam_pow, nullptr,
-                                                                ws.scal, hp->lr, hp->beta1, hp->beta2)));
+                                                                ws.scal, hp->lr, hp->beta1, hp->beta2, nullptr)));
         MACR_CHECK_LAUNCH("pair_normal", st);
         return MACR_OK;
     }
@@ -1232,7 +1218,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
         MACR_CHECK_LAUNCH("batch_sort", st);
         MACR_DISPATCH_D(d, (k_pair_normal<D><<<ws.nblk_bwd, 256, 0, st>>>(B, ws.us, ws.is, ws.js, Usrc, Isrc, gU, gI, tU, tI,
                                                                       ws.part, coef, reg_on_gathered, adam_pow, adam_pow,
-                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2)));
+                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2, cnt_pos)));
         MACR_CHECK_LAUNCH("pair_normal", st);
         return MACR_OK;
     }
@@ -1264,7 +1250,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
     MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd + 1, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, ws.perm, ws.us, ws.is, ws.js,
                                                                       Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, gU,
                                                                       gI, tU, tI, ws.gw, hp->alpha, hp->beta, coef, adam_pow,
-                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2, L)));
+                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2, L, cnt_pos)));
     MACR_CHECK_LAUNCH("pair_bwd", st);
     return MACR_OK;
 }
@@ -1588,7 +1574,7 @@ extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, in
 // ---- LightGCN ---------------------------------------------------------------
 namespace macr {
 struct PlanHeaderLite { int32_t magic, n_items, n_split, n_slots, N, chunk, n_groups, reserved; };   // = spmm_kernels.hip PlanHeader
-struct LgcnWs { float *E, *dE, *G, *work; uint8_t *rows; PairWs pair; size_t bytes; };
+struct LgcnWs { float *E, *dE, *G, *work; int32_t *cnt; double *emb_acc; PairWs pair; size_t bytes; };
 static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, const PlanHeaderLite *ph) {
     const size_t n_slots = ph ? (size_t)ph->n_slots + ph->n_groups : 0, n_split = ph ? (size_t)ph->n_groups + ph->n_split : 0;
     LgcnWs w;
@@ -1601,7 +1587,8 @@ static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, const PlanHeaderLit
     w.G = static_cast<float *>(take(nd));
     // layer buffers, partial rows of the hub pieces, their arrival counters (= macr_lgcn_work_floats; zero between steps)
     w.work = static_cast<float *>(take(3 * nd + align_up(((size_t)n_slots * d + n_split + 64) * 4, 256)));
-    w.rows = static_cast<uint8_t *>(take(align_up((size_t)N, 256)));       // 1 = a row of the current batch (zero between steps)
+    w.cnt = static_cast<int32_t *>(take(align_up((size_t)N * 4, 256)));    // references of the current batch per row (zero between steps)
+    w.emb_acc = static_cast<double *>(take(kEmbSlots * 8));                 // emb_loss partial sums (zero between steps)
     w.pair = carve_pair_ws(p ? p + off : nullptr, B, d);
     off += w.pair.bytes;
     w.bytes = off;
@@ -1651,17 +1638,18 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     // backward layer gathers only from them (spmm_kernels.hip kSparseOut / kSparseIn).  MACR_STEP_DENSE_LAYERS, or
     // MACR_LGCN_DENSE=1 in the environment, keeps every layer dense (the forward result is bit-identical either way).
     static const bool dense_layers = getenv("MACR_LGCN_DENSE") && getenv("MACR_LGCN_DENSE")[0] == '1';
-    const bool sparse = !dense_layers && !(flags & MACR_STEP_DENSE_LAYERS) && n_layers > 0;
-    const SparseCtx sp = {ws.rows, u, i, j, B, n_users, ph ? ph->chunk : 0x7fffffff};
-    if (sparse) {
-        const size_t threads = (size_t)3 * B * (d / 4);
-        MACR_DISPATCH_D(d, (k_mark_rows<D><<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(B, n_users, u, i, j, ws.rows,
-                                                                                             loss_only ? nullptr : ws.dE)));
-        MACR_CHECK_LAUNCH("mark_rows", st);
-    }
+    // (one layer: it would be the row-sparse first AND the fused last backward layer at once, reading the reference counts
+    // as flags while other waves clear them -- such a model runs its layers dense)
+    const bool sparse = !dense_layers && !(flags & MACR_STEP_DENSE_LAYERS) && n_layers > 1;
+    // The forward's last layer has one wave per batch reference; in a training step those waves also COUNT the references
+    // per row (ws.cnt): the flags of the first backward layer and the multiplicities of the ego-row regulariser.
+    // Positives repeat (a popularity-skewed batch refers to its hottest item hundreds of times, and that many atomics
+    // on one counter queue up): they are counted where the batch is already grouped -- one atomic per distinct row of
+    // a 16-slot chunk in pair_bwd / pair_normal -- unless the batch takes the staged path (count = 2: all three here).
+    const SparseCtx sp = {ws.cnt, u, i, j, B, n_users, ph ? ph->chunk : 0x7fffffff, loss_only ? 0 : ws.pair.staged ? 2 : 1};
     // forward propagation (LightGCN.py:288-309)
     if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, T, ws.E, ws.work, st,
-                                 sparse ? &sp : nullptr, kSparseOut))
+                                 sparse ? &sp : nullptr, kSparseOut, nullptr))
         return e;
     LossArgs L;
     L.part = ws.pair.part;
@@ -1676,8 +1664,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, ws.E, Ei0, w, wu, nullptr, nullptr, nullptr,
                                 nullptr, 0.0f, 0, adam_pow, hp, ws.pair, st, nullptr, nullptr, 0, nullptr, true))
             return e;
-        MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, u, i, j, T, nullptr, coef, ws.pair.part2,
-                                                                                   sparse ? ws.rows : nullptr)));
+        MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, u, i, j, T, nullptr, coef, ws.pair.part2)));
         MACR_CHECK_LAUNCH("reg_scatter", st);
         L.n_part = loss_kind == MACR_LOSS_NORMALBCE
                        ? ((B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024) : ws.pair.nblk_pair;
@@ -1685,33 +1672,52 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         MACR_CHECK_LAUNCH("finalize_losses", st);
         return MACR_OK;
     }
+    // dE: the gradient w.r.t. the propagated table; the pair kernels ADD into the rows of the batch.  Dense layers: the
+    // whole buffer is cleared here; sparse layers: those rows are zero already (the fused epilogue of the previous step
+    // cleared them, the workspace starts zeroed) and no other row is ever read.
     if (!sparse) fill_words(ws.dE, nd, 0u, st);
     // pair loss on the propagated rows; items live at rows n_users.. of E
     float *Ei = ws.E + (size_t)n_users * d, *dEi = ws.dE + (size_t)n_users * d;
     if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, ws.E, Ei, w, wu, ws.dE, dEi, nullptr, nullptr,
-                            0.0f, 0, adam_pow, hp, ws.pair, st))
+                            0.0f, 0, adam_pow, hp, ws.pair, st, nullptr, nullptr, 0, nullptr, false,
+                            sparse && !ws.pair.staged ? ws.cnt + n_users : nullptr))
         return e;
-    // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
-    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st,
-                                 sparse ? &sp : nullptr, kSparseIn))
-        return e;
-    // l2 regulariser on the ego rows (LightGCN.py:525-528)
-    // (the batch grouped by positive item, as the pair launch left it in the workspace, when there is one)
-    const int32_t *gu = ws.pair.staged ? u : ws.pair.us, *gi = ws.pair.staged ? i : ws.pair.is, *gj = ws.pair.staged ? j : ws.pair.js;
-    MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, gu, gi, gj, T, ws.G, coef, ws.pair.part2,
-                                                                               sparse ? ws.rows : nullptr)));
-    MACR_CHECK_LAUNCH("reg_scatter", st);
     AdamArgs a;
     a.n_seg = 0;
     a.lpr = d / 4; a.lpr_shift = d == 32 ? 3 : d == 64 ? 4 : d == 128 ? 5 : 6;
     a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
     long long nb = 0;
+    L.n_part = loss_kind == MACR_LOSS_NORMALBCE ? ws.pair.nblk_bwd : ws.pair.nblk_pair;
+    if (sparse) {
+        // backward through the propagation with the optimizer in the last layer's epilogue (spmm_kernels.hip AdamFuse):
+        // gradient row + ego-row regulariser (LightGCN.py:525-528) -> Adam on T, no G, no separate pass over the table
+        const AdamFuse fuse = {T, mT, vT, ws.pair.scal, hp->beta1, hp->beta2, hp->adam_eps, coef, ws.dE, ws.emb_acc};
+        if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st, &sp,
+                                     kSparseIn, &fuse))
+            return e;
+        if (loss_kind == MACR_LOSS_RUBIBCEBOTH) {
+            add_seg(a, w, mw, vw, ws.pair.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
+            add_seg(a, wu, mwu, vwu, ws.pair.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
+        }
+        L.n_part2 = 0;                                  // emb_loss comes from ws.emb_acc
+        k_lgcn_finalize<<<a.n_seg + 1, 256, 0, st>>>(a, ws.pair.scal, L, ws.emb_acc);
+        MACR_CHECK_LAUNCH("lgcn_finalize", st);
+        return MACR_OK;
+    }
+    // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
+    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st, nullptr,
+                                 kSparseIn, nullptr))
+        return e;
+    // l2 regulariser on the ego rows (LightGCN.py:525-528)
+    // (the batch grouped by positive item, as the pair launch left it in the workspace, when there is one)
+    const int32_t *gu = ws.pair.staged ? u : ws.pair.us, *gi = ws.pair.staged ? i : ws.pair.is, *gj = ws.pair.staged ? j : ws.pair.js;
+    MACR_DISPATCH_D(d, (k_reg_scatter<D><<<ws.pair.nblk_bwd, 256, 0, st>>>(B, n_users, gu, gi, gj, T, ws.G, coef, ws.pair.part2)));
+    MACR_CHECK_LAUNCH("reg_scatter", st);
     add_seg(a, T, mT, vT, ws.G, nullptr, N, nb);
     if (loss_kind == MACR_LOSS_RUBIBCEBOTH) {
         add_seg(a, w, mw, vw, ws.pair.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
         add_seg(a, wu, mwu, vwu, ws.pair.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
     }
-    L.n_part = loss_kind == MACR_LOSS_NORMALBCE ? ws.pair.nblk_bwd : ws.pair.nblk_pair;
     k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.pair.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;
