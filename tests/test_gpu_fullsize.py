@@ -346,8 +346,8 @@ def test_a_table_beyond_four_gib(ops):
         P = (torch.randn((n_users, d), generator=gen, device="cuda") * 0.05).contiguous()
         Q = (torch.randn((n_items, d), generator=gen, device="cuda") * 0.05).contiguous()
         # compact oracle problem: the batch's user rows 0..B-1
-        Pc = P[torch.from_numpy(u.astype(np.int64)).cuda()].cpu().numpy()
-        Qc = Q.cpu().numpy().copy()
+        Pc = np.ascontiguousarray(P[torch.from_numpy(u.astype(np.int64)).cuda()].cpu().numpy(), dtype=np.float32)
+        Qc = np.ascontiguousarray(Q.cpu().numpy(), dtype=np.float32).copy()
         before = P[torch.from_numpy(probe).cuda()].clone()
         st = oracle.AdamState([Pc.shape, Qc.shape, (d,), (d,)])
         wo, wuo = w.copy(), wu.copy()

@@ -11,10 +11,10 @@ OUT=$ROOT/gpurun_out/prof_$tag
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o bench -- "$@" > $OUT/stdout_trace.txt 2> $OUT/trace.err
-rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o bench -- "$@" > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o bench -- "$@" > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o bench -- "$@" > /dev/null 2> $OUT/pmc_sq.err
+timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o bench -- "$@" > $OUT/stdout_trace.txt 2> $OUT/trace.err
+timeout 600 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o bench -- "$@" > /dev/null 2> $OUT/pmc_fetch.err
+timeout 600 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o bench -- "$@" > /dev/null 2> $OUT/pmc_write.err
+timeout 600 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o bench -- "$@" > /dev/null 2> $OUT/pmc_sq.err
 cd $ROOT
 # per-kernel averages instead of the raw per-dispatch tables (the merge back is capped at 64 MiB)
 python tools/summarize_profile.py condense $OUT

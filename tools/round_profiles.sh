@@ -1,5 +1,5 @@
 #!/bin/bash
-# All rocprofv3 evidence of a round in one gpurun call (kernel trace + PMC passes each):
+# All rocprofv3 evidence of a round in one gpurun call (kernel trace + PMC passes each, every pass under `timeout`):
 #   bench (default workload), LightGCN at Yelp2018 shapes (SpMM), the pair kernels at B = 2^20.
 bash tools/profile.sh bench python $PWD/bench.py --steps 200 --warmup 20 --regions 3 --no-cpu-baseline
 bash tools/profile.sh lgcn python $PWD/tools/bench_lgcn.py
