@@ -606,6 +606,7 @@ static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) 
     }
     group_slot0.push_back(n_slots);
     split_group0.push_back((int32_t)group_split.size());
+    // (row order instead of length order: 4 % less FETCH_SIZE, same or longer layer time -- measured, not kept)
     std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
         const bool pa = a.slot >= 0, pb = b.slot >= 0;          // the pieces of the split rows first (in slot order)
         if (pa != pb) return pa;

@@ -31,8 +31,10 @@ def short(name):
         if t and t.group(2) in ("true", "1"):
             k += "2"
     if k == "spmm_row":              # k_spmm_row<D, SPARSE>: 1 = flagged output rows only, 2 = row-sparse input
-        t = re.search(r"k_spmm_row<\s*\d+\s*,\s*(\d+)", name)
+        t = re.search(r"k_spmm_row<\s*\d+\s*,\s*(\d+)\s*,\s*(true|false|0|1)", name)
         k = "spmm_csr" + {"1": "_rows", "2": "_sparse"}.get(t.group(1) if t else "0", "")   # (the names the benches use)
+        if t and t.group(2) in ("true", "1"):
+            k += "+adam"                 # FUSE: the optimizer in the epilogue of the last backward layer
     if k == "select" and re.search(r"k_select<\s*(true|1)\s*>", name):
         k = "select2"
     if k == "tau" and re.search(r"k_tau<\s*\d+\s*,\s*(true|1)\s*>", name):
