@@ -39,6 +39,13 @@ def _ptr(t, dtype=None, allow_none=False):
 _f32, _i32, _f64 = torch.float32, torch.int32, torch.float64
 
 
+def _require_f32(**tensors):
+    """the kernels read fp32 tables through raw pointers: any other dtype is refused here, not reinterpreted"""
+    for name, t in tensors.items():
+        if t.dtype != _f32:
+            raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+
+
 class CSR(object):
     """int32 CSR on the device: ptr[rows+1], idx[nnz] (+ optional fp32 val[nnz])."""
 
@@ -340,6 +347,7 @@ class MFState(object):
     macr_mf/model.py:107-122,:59-60.  Adam slots start at zero, beta powers at (beta1,beta2)."""
 
     def __init__(self, P, Q, w, wu, hyper, batch_cap):
+        _require_f32(P=P, Q=Q, w=w, wu=wu)
         dev = P.device
         self.P, self.Q = P.contiguous(), Q.contiguous()
         self.w, self.wu = w.reshape(-1).contiguous(), wu.reshape(-1).contiguous()
@@ -426,6 +434,7 @@ class LGCNState(object):
     branch vectors, Adam slots, the `pre` adjacency (utility/load_data.py:112-121)."""
 
     def __init__(self, T, n_users, n_items, w, wu, adj, n_layers, hyper, batch_cap):
+        _require_f32(T=T, w=w, wu=wu)
         self.T = T.contiguous()
         self.n_users, self.n_items, self.n_layers = n_users, n_items, n_layers
         self.w, self.wu = w.reshape(-1).contiguous(), wu.reshape(-1).contiguous()

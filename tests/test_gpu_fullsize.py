@@ -343,8 +343,8 @@ def test_a_table_beyond_four_gib(ops):
     probe = np.concatenate([np.arange(0, 64), np.arange(first_high - 32, first_high + 32), rs.randint(0, n_users, 256)])
     probe = np.setdiff1d(probe, u).astype(np.int64)
     for path in ("single", "sharded"):
-        P = (torch.randn((n_users, d), generator=gen, device="cuda") * 0.05).contiguous()
-        Q = (torch.randn((n_items, d), generator=gen, device="cuda") * 0.05).contiguous()
+        P = (torch.randn((n_users, d), generator=gen, device="cuda", dtype=torch.float32) * 0.05).contiguous()
+        Q = (torch.randn((n_items, d), generator=gen, device="cuda", dtype=torch.float32) * 0.05).contiguous()
         # compact oracle problem: the batch's user rows 0..B-1
         Pc = np.ascontiguousarray(P[torch.from_numpy(u.astype(np.int64)).cuda()].cpu().numpy(), dtype=np.float32)
         Qc = np.ascontiguousarray(Q.cpu().numpy(), dtype=np.float32).copy()

@@ -874,3 +874,14 @@ def test_lgcn_batch_row_sparse_layers_equal_dense_layers(ops, L, hubs):
     lo_a = states[0].step(ops.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j), loss_only=True).cpu().numpy().copy()
     lo_b = states[0].step(ops.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j), loss_only=True, dense_layers=True).cpu().numpy().copy()
     assert np.array_equal(lo_a.view(np.uint32), lo_b.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_tables_of_another_dtype_are_refused(ops):
+    """the kernels read fp32 through raw pointers: a float64 table (e.g. made under another default dtype) must be
+    refused by the host layer, never reinterpreted"""
+    P = torch.zeros((64, 64), dtype=torch.float64, device="cuda")
+    Q = torch.zeros((32, 64), dtype=torch.float32, device="cuda")
+    w = torch.zeros(64, dtype=torch.float32, device="cuda")
+    with pytest.raises(TypeError):
+        ops.MFState(P, Q, w, w.clone(), ops.make_hyper(1e-3, 1e-5, 1e-3, 1e-3, 16), 16)

@@ -13,7 +13,15 @@ import torch
 
 import oracle
 
-torch.set_default_dtype(torch.float64)
+
+@pytest.fixture(autouse=True, scope="module")
+def _float64_autograd():
+    """the autograd cross-checks of this module run in float64; the default goes back to what it was afterwards (a
+    module-level set_default_dtype leaks into every test collected with this file)"""
+    before = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(before)
 
 
 def literal_normalbce(users, pos_items, neg_items, decay, batch_size):
