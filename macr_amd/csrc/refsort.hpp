@@ -184,7 +184,13 @@ static inline int key_bits_for(uint32_t max_key) {
 // Small arrays take 2048-key tiles: with 16384-key tiles the 24 576 references of a B = 8192 batch are two workgroups
 // (two CUs) per pass, ~30 us each; twelve workgroups bring a pass to the launch-bound floor.
 constexpr int kSortTileSmall = 2048, kSortSmallMax = 1 << 17;
-static inline int sort_tile_for(int n) { return n <= kSortSmallMax ? kSortTileSmall : kSortTile; }
+// In between, 8192-key tiles (measured, ref_sort of 3B references: B = 2^16 98 -> 69 us, 2^18 109 -> 88 us; 2^20 176 -> 207 us)
+constexpr int kSortTileMid = 8192, kSortMidMax = 1 << 20;
+static inline int sort_tile_for(int n) {
+    static const char *env = getenv("MACR_SORT_TILE");          // measurements: 2048 | 8192 | 16384 for every size
+    if (env) { const int t = atoi(env); if (t == kSortTileSmall || t == kSortTileMid || t == kSortTile) return t; }
+    return n <= kSortSmallMax ? kSortTileSmall : n <= kSortMidMax ? kSortTileMid : kSortTile;
+}
 static inline size_t sort_hist_words(int n) { const int t = sort_tile_for(n); return (size_t)kRadix * ((n + t - 1) / t); }
 
 // Sorts n pairs held in (ka,va) with (kb,vb) as the second buffer; returns 0 if the result is in (ka,va), 1 if in
@@ -197,9 +203,11 @@ static inline int launch_radix_sort(uint32_t *ka, uint32_t *va, uint32_t *kb, ui
     for (int shift = 0; shift < bits; shift += 8) {
         uint32_t *kin = flip ? kb : ka, *vin = flip ? vb : va, *kout = flip ? ka : kb, *vout = flip ? va : vb;
         if (tile == kSortTileSmall) k_rs_count<kSortTileSmall><<<nblk, 1024, 0, st>>>(kin, n, shift, ghist, nblk);
+        else if (tile == kSortTileMid) k_rs_count<kSortTileMid><<<nblk, 1024, 0, st>>>(kin, n, shift, ghist, nblk);
         else k_rs_count<kSortTile><<<nblk, 1024, 0, st>>>(kin, n, shift, ghist, nblk);
         k_rs_scan<<<1, 1024, 0, st>>>(ghist, kRadix * nblk);
         if (tile == kSortTileSmall) k_rs_scatter<kSortTileSmall><<<nblk, 1024, 0, st>>>(kin, vin, kout, vout, n, shift, ghist, nblk);
+        else if (tile == kSortTileMid) k_rs_scatter<kSortTileMid><<<nblk, 1024, 0, st>>>(kin, vin, kout, vout, n, shift, ghist, nblk);
         else k_rs_scatter<kSortTile><<<nblk, 1024, 0, st>>>(kin, vin, kout, vout, n, shift, ghist, nblk);
         flip ^= 1;
     }

@@ -62,6 +62,8 @@ struct AdamSeg {
     int n_parts;             // > 0: g holds n_parts partial rows (stride part_stride floats) to be summed
     int part_stride;
     int32_t *touched;        // NULL: gradient is dense, always read, left untouched
+    const uint32_t *sv;      // INDEXED pass (large batches): sorted reference list (values = staging rows) and the staging
+    const float *stage;      //   buffer; a flag with a length field names a row's references instead of a row of g
     long long n_vec;         // number of float4 in the segment
     long long first_block;   // first block index serving this segment
 };
@@ -100,7 +102,15 @@ __device__ __forceinline__ void adam4(float4 &th, float4 &m, float4 &v, const fl
 
 // One block's share of the pass: block `blk` of the segment list.  s_red (256 float4) is only used by
 // partial-row segments (PARTS).
-template <bool PARTS>
+// Row flags of the large-batch path (k_seg_reduce<LPR, true>): 0 = no gradient; 1 = the row of g holds it; otherwise
+// (length << kRefShift) | position: the row's gradient is the sum of `length` (<= kRefRun) staging rows, the ones the sorted
+// reference list names from `position` on.  An INDEXED pass sums them itself, in list order -- the order k_seg_reduce
+// sums in, so the two paths give the same bits -- and the gradient never exists as a row in memory: nothing writes it,
+// reads it back or clears it.
+constexpr int kRefShift = 26;
+constexpr uint32_t kRefMaxRefs = 1u << kRefShift;       // positions must fit below the length field
+
+template <bool PARTS, bool INDEXED = false>
 __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, float lr_t, float4 *s_red) {
     int s = 0;
 #pragma unroll
@@ -148,7 +158,22 @@ __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, flo
 #pragma unroll
     for (int it = 0; it < kAdamIters; ++it) {
         gr[it] = make_float4(0, 0, 0, 0);
-        if (flag[it]) {                      // implies vi < n_vec
+        if (INDEXED && (flag[it] >> kRefShift)) {
+            const int len = flag[it] >> kRefShift;
+            const uint32_t *sv = sg.sv + (flag[it] & (int)(kRefMaxRefs - 1));
+            const float *src = sg.stage + 4 * (vi[it] & (a.lpr - 1));
+            const size_t d = (size_t)4 * a.lpr;
+            float4 acc = make_float4(0, 0, 0, 0);
+            int k = 0;
+            for (; k + 4 <= len; k += 4) {
+                const uint32_t r0 = sv[k], r1 = sv[k + 1], r2 = sv[k + 2], r3 = sv[k + 3];
+                const float4 x0 = ld4(src + r0 * d), x1 = ld4(src + r1 * d), x2 = ld4(src + r2 * d), x3 = ld4(src + r3 * d);
+                acc = add4(add4(add4(add4(acc, x0), x1), x2), x3);
+            }
+            for (; k < len; ++k) acc = add4(acc, ld4(src + sv[k] * d));
+            gr[it] = acc;
+            if ((vi[it] & (a.lpr - 1)) == 0) sg.touched[vi[it] >> a.lpr_shift] = 0;
+        } else if (flag[it]) {               // implies vi < n_vec
             gr[it] = ld4(sg.g + vi[it] * 4);
             if (sg.touched) {                // consume: gradient row and flag back to zero
                 st4(sg.g + vi[it] * 4, make_float4(0, 0, 0, 0));
@@ -195,9 +220,10 @@ __device__ __forceinline__ void finalize_losses(const LossArgs &L, int lane, dou
 __global__ __launch_bounds__(64) void k_finalize_losses(LossArgs L) { finalize_losses(L, threadIdx.x); }
 
 // Block 0 also reduces the loss partials of the step into losses[3] (when L.losses is set).
+template <bool INDEXED>
 __global__ __launch_bounds__(256) void k_adam_dense(AdamArgs a, const StepScalars *scal, LossArgs L) {
     __shared__ float4 s_red[256];
-    adam_block<true>(a, blockIdx.x, scal->lr_t, s_red);
+    adam_block<true, INDEXED>(a, blockIdx.x, scal->lr_t, s_red);
     if (blockIdx.x == 0 && L.losses && threadIdx.x < 64) finalize_losses(L, threadIdx.x);
 }
 
@@ -797,7 +823,9 @@ constexpr int kSmallBatchMax = 8192;
 
 __global__ __launch_bounds__(256) void k_refs_init(int B, int n_users, const int32_t *__restrict__ u,
                                                    const int32_t *__restrict__ i, const int32_t *__restrict__ j,
-                                                   uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+                                                   uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                   uint32_t *__restrict__ n_work) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_work = 0u;           // work list of k_seg_scan, empty again
     for (int t = blockIdx.x * 256 + threadIdx.x; t < B; t += gridDim.x * 256) {
         key[t] = (uint32_t)u[t];                       val[t] = (uint32_t)t;
         key[B + t] = (uint32_t)(n_users + i[t]);       val[B + t] = (uint32_t)(B + t);
@@ -935,6 +963,8 @@ __global__ __launch_bounds__(256) void k_seg_reduce(int n, int n_users, uint32_t
     if (head) {
         const uint32_t next = (p + len < n) ? sk[p + len] : 0xffffffffu;
         const bool multi = key0 == prev || next == key0;
+        const bool is_user = key0 < (uint32_t)n_users;
+        const size_t row = is_user ? key0 : key0 - (uint32_t)n_users;
         float4 acc = make_float4(0, 0, 0, 0);
         int k = 0;
         for (; k + 4 <= len; k += 4) {
@@ -948,8 +978,6 @@ __global__ __launch_bounds__(256) void k_seg_reduce(int n, int n_users, uint32_t
             const uint32_t r = __shfl(vs, gbase + k, kWave);
             acc = add4(acc, ld4(stage + (size_t)r * d + 4 * g.sub));
         }
-        const bool is_user = key0 < (uint32_t)n_users;
-        const size_t row = is_user ? key0 : key0 - (uint32_t)n_users;
         float *dst = (is_user ? gU : gI) + row * d + 4 * g.sub;
         if (multi) {
             MACR_ATOMIC_ADD(dst + 0, acc.x); MACR_ATOMIC_ADD(dst + 1, acc.y);
@@ -958,6 +986,95 @@ __global__ __launch_bounds__(256) void k_seg_reduce(int n, int n_users, uint32_t
             st4(dst, acc);
         }
         if (g.sub == 0 && key0 != prev && tU) (is_user ? tU : tI)[row] = 1;
+    }
+}
+
+// The same de-duplication for a step whose Adam pass follows at once (adam_block INDEXED): nothing is summed for a row
+// with at most kRefRun references -- its flag names them, (count << kRefShift) | position of the first, and the pass
+// sums them.  One THREAD per position looks for the first reference of a row (k_seg_reduce spends a lane group per
+// position on that: 238 us at 3 M references even with nothing to sum) and counts the run.  Rows with more references
+// (the hot items of a popularity-skewed batch) get flag 1 and their gradient row in gU/gI as before: the thread finds
+// the end of the run by galloping + bisection in the sorted keys and appends one work item per kLongSpan references,
+// which k_seg_sum adds up, one wave per item.
+constexpr int kRefRun = 16;            // <= 31: the count shares the flag word with a position below kRefMaxRefs
+constexpr int kLongSpan = 64;
+
+__global__ __launch_bounds__(256) void k_seg_scan(int n, int n_users, uint32_t key_end, const uint32_t *__restrict__ sk,
+                                                  int32_t *tU, int32_t *tI, uint32_t *__restrict__ work,
+                                                  uint32_t *__restrict__ n_work) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t key = sk[p];
+    const uint32_t prev = p > 0 ? sk[p - 1] : 0xffffffffu;
+    if (key >= key_end || key == prev) return;                        // not the first reference of one of this rank's rows
+    const int lim = kRefRun + 1 < n - p ? kRefRun + 1 : (int)(n - p);
+    int len = 1;
+    for (bool more = true; more && len < lim;) {                      // four keys per trip: most runs end in the first
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = len + k < lim ? sk[p + len + k] : ~key;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (more && w[k] == key) ++len; else more = false;
+        }
+    }
+    const bool is_user = key < (uint32_t)n_users;
+    int32_t *flag = (is_user ? tU : tI) + (is_user ? key : key - (uint32_t)n_users);
+    if (len <= kRefRun) {
+        *flag = (len << kRefShift) | (int)p;
+        return;
+    }
+    *flag = 1;
+    // end of the run: first position q > p with sk[q] != key
+    long long lo = p + len, step = kRefRun;                           // sk[lo - 1] == key
+    while (lo + step <= n && sk[lo + step - 1] == key) { lo += step; step *= 2; }
+    long long hi = lo + step < n ? lo + step : n;                     // sk[hi] != key or hi == n; answer in [lo, hi]
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (sk[mid] == key) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t total = (uint32_t)(lo - p), items = (total + kLongSpan - 1) / kLongSpan;
+    const uint32_t at = atomicAdd(n_work, 2 * items);
+    for (uint32_t k = 0; k < items; ++k) {
+        const uint32_t span = total - k * kLongSpan < (uint32_t)kLongSpan ? total - k * kLongSpan : (uint32_t)kLongSpan;
+        work[at + 2 * k] = (uint32_t)p + k * kLongSpan;
+        work[at + 2 * k + 1] = span;
+    }
+}
+
+// One wave per work item (first position, count <= kLongSpan): its 64 / LPR lane groups sum every (64 / LPR)-th staging
+// row of the span, the groups' sums meet through shuffles, the first group adds the result into the gradient row.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_seg_sum(const uint32_t *__restrict__ work, const uint32_t *__restrict__ n_work,
+                                                 int n_users, const uint32_t *__restrict__ sk, const uint32_t *__restrict__ sv,
+                                                 const float *__restrict__ stage, float *gU, float *gI) {
+    constexpr int d = 4 * LPR, G = kWave / LPR;
+    const int lane = threadIdx.x & 63, sub = lane % LPR, grp = lane / LPR;
+    const uint32_t nw = *n_work >> 1;
+    for (uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6); e < nw; e += gridDim.x * 4) {
+        const uint32_t p = work[2 * e], len = work[2 * e + 1];
+        const uint32_t key = sk[p];
+        const float *src = stage + 4 * sub;
+        float4 acc = make_float4(0, 0, 0, 0);
+        uint32_t k = grp;
+        for (; k + 3 * G < len; k += 4 * G) {
+            const uint32_t r0 = sv[p + k], r1 = sv[p + k + G], r2 = sv[p + k + 2 * G], r3 = sv[p + k + 3 * G];
+            const float4 x0 = ld4(src + (size_t)r0 * d), x1 = ld4(src + (size_t)r1 * d);
+            const float4 x2 = ld4(src + (size_t)r2 * d), x3 = ld4(src + (size_t)r3 * d);
+            acc = add4(add4(add4(add4(acc, x0), x1), x2), x3);
+        }
+        for (; k < len; k += G) acc = add4(acc, ld4(src + (size_t)sv[p + k] * d));
+#pragma unroll
+        for (int m = LPR; m < kWave; m <<= 1) {
+            acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
+            acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
+        }
+        if (grp == 0) {
+            const bool is_user = key < (uint32_t)n_users;
+            float *dst = (is_user ? gU : gI) + (size_t)(is_user ? key : key - (uint32_t)n_users) * d + 4 * sub;
+            MACR_ATOMIC_ADD(dst + 0, acc.x); MACR_ATOMIC_ADD(dst + 1, acc.y);
+            MACR_ATOMIC_ADD(dst + 2, acc.z); MACR_ATOMIC_ADD(dst + 3, acc.w);
+        }
     }
 }
 
@@ -1088,6 +1205,7 @@ struct PairWs {
     int32_t *perm, *us, *is, *js;            // small path: the batch grouped by positive item  [B] each
     uint32_t *ska, *sva, *skb, *svb;         // staged: sort buffers [3B] each
     uint32_t *ghist;                         // staged: [sort_hist_words(3B)]
+    uint32_t *n_work;                        // staged: length of k_seg_scan's work list
     float *stage;                            // staged: [3][B][d] gradient rows in batch order
     int nblk_bwd;
     float *fwd;         // [7*Bp]
@@ -1128,11 +1246,12 @@ static PairWs carve_pair_ws(void *base, int B, int d, bool force_staged = false)
     w.colpart = static_cast<float *>(take((size_t)w.nrb * 2 * w.Bp * 4));
     const size_t nsort = 3 * (size_t)B;
     w.ska = w.sva = w.skb = w.svb = nullptr;
-    w.perm = w.us = w.is = w.js = nullptr; w.ghist = nullptr; w.stage = nullptr;
+    w.perm = w.us = w.is = w.js = nullptr; w.ghist = nullptr; w.stage = nullptr; w.n_work = nullptr;
     if (w.staged) {
         w.ska = static_cast<uint32_t *>(take(nsort * 4)); w.sva = static_cast<uint32_t *>(take(nsort * 4));
         w.skb = static_cast<uint32_t *>(take(nsort * 4)); w.svb = static_cast<uint32_t *>(take(nsort * 4));
         w.ghist = static_cast<uint32_t *>(take(sort_hist_words((int)nsort) * 4));
+        w.n_work = static_cast<uint32_t *>(take(4));
         w.stage = static_cast<float *>(take(nsort * d * 4));
     } else {
         w.perm = static_cast<int32_t *>(take((size_t)B * 4)); w.us = static_cast<int32_t *>(take((size_t)B * 4));
@@ -1171,14 +1290,25 @@ static BatchSort batch_sort_args(const PairWs &ws, int B, const int32_t *u, cons
 }
 
 // staged path: sort the 3B references by row, then one owner per row sums its staging rows into gU/gI
+// sv_sorted != NULL: INDEX mode -- rows whose references lie in one chunk get a flag naming them instead of a sum
+// (*sv_sorted = the sorted list's values, for the indexed Adam pass that must follow)
 static int launch_ref_sort_reduce(int B, int d, int n_urows, int n_irows, const int32_t *u, const int32_t *i,
                                   const int32_t *j, float *gU, float *gI, int32_t *tU, int32_t *tI, const PairWs &ws,
-                                  hipStream_t st) {
+                                  hipStream_t st, const uint32_t **sv_sorted = nullptr) {
     const int n = 3 * B;
-    k_refs_init<<<(B + 255) / 256 < 2048 ? (B + 255) / 256 : 2048, 256, 0, st>>>(B, n_urows, u, i, j, ws.ska, ws.sva);
+    k_refs_init<<<(B + 255) / 256 < 2048 ? (B + 255) / 256 : 2048, 256, 0, st>>>(B, n_urows, u, i, j, ws.ska, ws.sva, ws.n_work);
     const int flip = launch_radix_sort(ws.ska, ws.sva, ws.skb, ws.svb, n, (uint32_t)(n_urows + n_irows - 1), ws.ghist, st);
     MACR_CHECK_LAUNCH("ref_sort", st);
     const uint32_t *sk = flip ? ws.skb : ws.ska, *sv = flip ? ws.svb : ws.sva;
+    if (sv_sorted) {
+        *sv_sorted = sv;
+        uint32_t *work = flip ? ws.ska : ws.skb;                       // the buffer the sort no longer needs
+        k_seg_scan<<<(n + 255) / 256, 256, 0, st>>>(n, n_urows, (uint32_t)(n_urows + n_irows), sk, tU, tI, work, ws.n_work);
+        MACR_CHECK_LAUNCH("seg_index", st);
+        MACR_DISPATCH_LPR(d, (k_seg_sum<LPR><<<1024, 256, 0, st>>>(work, ws.n_work, n_urows, sk, sv, ws.stage, gU, gI)));
+        MACR_CHECK_LAUNCH("seg_sum", st);
+        return MACR_OK;
+    }
     MACR_DISPATCH_LPR(d, (k_seg_reduce<LPR><<<(n + 256 / LPR - 1) / (256 / LPR), 256, 0, st>>>(
                              n, n_urows, (uint32_t)(n_urows + n_irows), sk, sv, ws.stage, gU, gI, tU, tI)));
     MACR_CHECK_LAUNCH("seg_reduce", st);
@@ -1193,7 +1323,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
                        float *adam_pow, const macr_hyper *hp, const PairWs &ws, hipStream_t st,
                        const PendingAdam *pa = nullptr, const AdamArgs *pending = nullptr,
                        long long n_pending_blocks = 0, const LossArgs *finalize = nullptr, bool loss_only = false,
-                       int32_t *cnt_pos = nullptr) {
+                       int32_t *cnt_pos = nullptr, const uint32_t **sv_sorted = nullptr) {
     const int grid = ws.nblk_pair;
     const int user_branch = kind == MACR_LOSS_RUBIBCEBOTH;
     BatchSort sort = batch_sort_args(ws, B, u, i, j);
@@ -1212,7 +1342,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
                                      B, u, i, j, Usrc, Isrc, ws.stage, ws.part, coef, reg_on_gathered, adam_pow, adam_pow,
                                      ws.scal, hp->lr, hp->beta1, hp->beta2)));
             MACR_CHECK_LAUNCH("pair_normal", st);
-            return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st);
+            return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st, sv_sorted);
         }
         k_batch_sort<<<(B + kBucketSpan - 1) / kBucketSpan, 256, 0, st>>>(sort);
         MACR_CHECK_LAUNCH("batch_sort", st);
@@ -1245,7 +1375,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
                                  B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, ws.stage,
                                  ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal, hp->lr, hp->beta1, hp->beta2, L)));
         MACR_CHECK_LAUNCH("pair_bwd", st);
-        return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st);
+        return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st, sv_sorted);
     }
     MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd + 1, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, ws.perm, ws.us, ws.is, ws.js,
                                                                       Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, gU,
@@ -1259,6 +1389,7 @@ static void add_seg(AdamArgs &a, float *theta, float *m, float *v, float *g, int
                     long long &next_block, int n_parts = 0, int part_stride = 0) {
     AdamSeg &s = a.seg[a.n_seg++];
     s.theta = theta; s.m = m; s.v = v; s.g = g; s.touched = touched;
+    s.sv = nullptr; s.stage = nullptr;
     s.n_parts = n_parts; s.part_stride = part_stride;
     s.n_vec = rows * a.lpr;
     s.first_block = next_block;
@@ -1349,13 +1480,27 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
         mf_adam_args(a, nb, true, loss_kind, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
                      touchedP, touchedQ, hp, ws);
     }
+    // Large batches, step complete in this call: the reference sort is followed by the Adam pass at once, which can sum
+    // a row's staged gradient rows itself instead of reading a row some kernel wrote for it (adam_block INDEXED).
+    // (MACR_SEG_UNFUSED=1: the segment reduce writes every row, as in deferred mode -- for A/B measurements and tests.)
+    const char *unfused = getenv("MACR_SEG_UNFUSED");
+    const bool indexed = ws.staged && !flags && (size_t)3 * B <= kRefMaxRefs && !(unfused && unfused[0] == '1');
+    const uint32_t *sv_sorted = nullptr;
     if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, P, Q, w, wu, gP, gQ, touchedP, touchedQ, coef, 1,
-                            adam_pow, hp, ws, st, pending ? &pa : nullptr, pending ? &a : nullptr, nb, defer ? &L : nullptr))
+                            adam_pow, hp, ws, st, pending ? &pa : nullptr, pending ? &a : nullptr, nb, defer ? &L : nullptr,
+                            false, nullptr, indexed ? &sv_sorted : nullptr))
         return e;
     if (defer) return MACR_OK;
     mf_adam_args(a, nb, true, loss_kind, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
                  touchedP, touchedQ, hp, ws);
-    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
+    if (indexed) {
+        a.seg[0].sv = a.seg[1].sv = sv_sorted;
+        a.seg[0].stage = a.seg[1].stage = ws.stage;
+        k_adam_dense<true><<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
+        MACR_CHECK_LAUNCH("adam_indexed", st);
+        return MACR_OK;
+    }
+    k_adam_dense<false><<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;
 }
@@ -1382,7 +1527,7 @@ extern "C" int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int
     LossArgs L;
     L.losses = nullptr;
     hipStream_t st = as_stream(stream);
-    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
+    k_adam_dense<false><<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;
 }
@@ -1566,7 +1711,7 @@ extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, in
     add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
     if (loss_kind == MACR_LOSS_RUBIBCEBOTH) add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
     LossArgs L; L.losses = nullptr;
-    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
+    k_adam_dense<false><<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;
 }
@@ -1718,7 +1863,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         add_seg(a, w, mw, vw, ws.pair.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
         add_seg(a, wu, mwu, vwu, ws.pair.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
     }
-    k_adam_dense<<<(unsigned)nb, 256, 0, st>>>(a, ws.pair.scal, L);
+    k_adam_dense<false><<<(unsigned)nb, 256, 0, st>>>(a, ws.pair.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;
 }

@@ -810,19 +810,35 @@ def test_seeded_thresholds_do_not_change_the_ranking(ops):
     assert seen["too few"][0] == (U + 255) // 256 and seen["too few"][1] == 0
 
 
+def listing_visit_rank(N):
+    """int[N]: position of every item in the order the listing pass visits the catalogue (eval_kernels.hip
+    k_score_stream: visit v is tile (v * S) mod T of 32 items, S the first number coprime to T from 0.618 T on)"""
+    from math import gcd
+    T = (N + 31) // 32
+    S = max(int(np.float32(0.6180339) * np.float32(T)), 1)
+    while gcd(S, T) != 1:
+        S += 1
+    rank = np.empty(T, np.int64)
+    rank[(np.arange(T, dtype=np.int64) * S) % T] = np.arange(T)
+    idx = np.arange(N)
+    return rank[idx // 32] * 32 + idx % 32
+
+
 def test_score_topk_second_overflow_arms_the_exact_kernel(ops):
-    """Scores that rise with the item id: whatever a first (cut) list holds is the bottom of its tile range.
-    With seeds (the lowest ids) the repair round samples the re-listed query blocks and its thresholds hold; without
-    seeds on a catalogue whose sampled items score below everything else, the sampled thresholds are useless, the
-    thresholds taken from the cut lists are loose again, the lists overflow a second time and the running top-K
-    kernel ranks.  Exact either way."""
+    """Scores that rise along the order the listing pass visits the catalogue in: whatever a first (cut) list holds is
+    the bottom of its range of visits.  With seeds (the earliest-visited items) the repair round samples the re-listed
+    query blocks and its thresholds hold; without seeds on a catalogue whose sampled items score below everything else,
+    the sampled thresholds are useless, the thresholds taken from the cut lists are loose again, the lists overflow a
+    second time and the running top-K kernel ranks.  Exact either way."""
     rs = np.random.RandomState(77)
     U, N, d, K = 200, 4096 * 3, 64, 20
+    vrank = listing_visit_rank(N)
     P = np.abs(rs.standard_normal((U, d)) * 0.5).astype(np.float32)
-    Q = (np.abs(rs.standard_normal((N, d)) * 0.5) * (1.0 + 4.0 * np.arange(N)[:, None] / N)).astype(np.float32)
+    Q = (np.abs(rs.standard_normal((N, d)) * 0.5) * (1.0 + 4.0 * vrank[:, None] / N)).astype(np.float32)
     mask = random_mask(rs, U, N, 10)
     mcsr = ops.CSR.from_lists(mask, "cuda")
-    low = np.stack([np.array([x for x in range(90) if x not in set(mask[q])][:ops.SEED_WIDTH]) for q in range(U)]).astype(np.int32)
+    first = np.argsort(vrank)[:90]
+    low = np.stack([np.array([x for x in first if x not in set(mask[q])][:ops.SEED_WIDTH]) for q in range(U)]).astype(np.int32)
     stats = torch.zeros(2, dtype=torch.int32, device="cuda")
     for name, items, seed, want_stats in (("seeded", Q, dev(low), [(U + 255) // 256, 0]),
                                           ("sampled tiles negative", np.where(sampled_items(N)[:, None], -Q, Q), None,
@@ -885,3 +901,49 @@ def test_tables_of_another_dtype_are_refused(ops):
     w = torch.zeros(64, dtype=torch.float32, device="cuda")
     with pytest.raises(TypeError):
         ops.MFState(P, Q, w, w.clone(), ops.make_hyper(1e-3, 1e-5, 1e-3, 1e-3, 16), 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hot", [False, True])
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("kind", ["normalbce", "rubibceboth"])
+def test_large_batch_indexed_adam_equals_segment_reduce(ops, d, kind, hot, monkeypatch):
+    """B > 8192, a step complete in one call: the Adam pass sums the staged gradient rows of every row with at most 16
+    references itself (adam_block INDEXED; k_seg_scan writes the flags that name them), rows with more go through gP/gQ
+    (k_seg_sum).  MACR_SEG_UNFUSED=1 brings k_seg_reduce back, which writes every row's sum to gP/gQ in chunks of its
+    own: same step up to the order of the additions; scratch and flags clean after every step on both paths.  hot: Zipf
+    positives (one item with thousands of references: the gallop + bisection for the end of its run, many work items),
+    otherwise no row above 16 references (no work item at all)."""
+    rs = np.random.RandomState(5 + d)
+    n_users, n_items, B = 30000, (9000 if hot else 60000), 20000
+    K = ops.LOSS_NORMALBCE if kind == "normalbce" else ops.LOSS_RUBIBCEBOTH
+    P0 = (rs.standard_normal((n_users, d)) * 0.1).astype(np.float32)
+    Q0 = (rs.standard_normal((n_items, d)) * 0.1).astype(np.float32)
+    w0, wu0 = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    hyper = ops.make_hyper(1e-3, 1e-4, 1e-2, 1e-3, B)
+    states = [ops.MFState(dev(P0), dev(Q0), dev(w0), dev(wu0), hyper, B) for _ in range(2)]
+    for t in range(3):
+        u = rs.randint(0, n_users, B).astype(np.int32)
+        i = ((rs.zipf(1.2, B) % n_items) if hot else rs.randint(0, n_items, B)).astype(np.int32)
+        j = rs.randint(0, n_items, B).astype(np.int32)
+        most = max(np.bincount(np.concatenate([i, j])).max(), np.bincount(u).max())
+        assert most > 1000 if hot else most <= 16
+        out = []
+        for k, st in enumerate(states):
+            if k == 1:
+                monkeypatch.setenv("MACR_SEG_UNFUSED", "1")
+            else:
+                monkeypatch.delenv("MACR_SEG_UNFUSED", raising=False)
+            ops.timing_begin()
+            out.append(st.step(K, dev(u), dev(i), dev(j)).cpu().numpy().copy())
+            names = {n for n, _ in ops.timing_end(64)}
+            want = {"adam_indexed", "seg_index", "seg_sum"} if k == 0 else {"adam_dense", "seg_reduce"}
+            assert names & {"adam_indexed", "seg_index", "seg_sum", "adam_dense", "seg_reduce"} == want, names
+        np.testing.assert_allclose(out[0], out[1], rtol=1e-6)
+        for name in ("P", "Q", "mP", "vP", "mQ", "vQ", "w", "wu"):
+            a, b = getattr(states[0], name), getattr(states[1], name)
+            tol = 1e-3 * 1e-3 if name in ("P", "Q", "w", "wu") else 2e-5 * float(b.abs().max())
+            torch.testing.assert_close(a, b, rtol=0, atol=tol, msg=lambda m: "%s step %d: %s" % (name, t, m))
+        for st in states:
+            assert not st.tP.any() and not st.tQ.any() and not st.gP.any() and not st.gQ.any()
+    monkeypatch.delenv("MACR_SEG_UNFUSED", raising=False)

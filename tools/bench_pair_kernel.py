@@ -32,11 +32,15 @@ for logB in ([int(a) for a in sys.argv[1:]] or (12, 14, 16, 18, 20)):       # ar
         pair_us = us.get("pair_normal", 0.0)
         bytes_pair = B * (24 * d + 12)
         bytes_adam = 24 * d * (n_users + n_items)
-        grad_us = pair_us + us.get("ref_sort", 0.0) + us.get("seg_reduce", 0.0) + us.get("batch_sort", 0.0)
+        # (B > 8192: "seg_index" + "adam_indexed" when the Adam pass sums the staged rows itself, "seg_reduce" +
+        #  "adam_dense" under MACR_SEG_UNFUSED=1)
+        grad_us = pair_us + us.get("ref_sort", 0.0) + us.get("seg_reduce", 0.0) + us.get("seg_index", 0.0) + us.get("batch_sort", 0.0)
+        adam_us = us.get("adam_dense", 0.0) + us.get("adam_indexed", 0.0)
         out.append({"B": B, "loss": name, "kernels_us": {k: round(v, 1) for k, v in us.items()},
                     "pair_GBps": bytes_pair / (pair_us * 1e-6) / 1e9, "pair_frac_of_8TBps": bytes_pair / (pair_us * 1e-6) / 8e12,
                     "gradient_path_us": round(grad_us, 1),          # pair kernel + reference sort + segment reduce
                     "gradient_path_frac_of_8TBps": bytes_pair / (grad_us * 1e-6) / 8e12,
-                    "adam_GBps": bytes_adam / (us["adam_dense"] * 1e-6) / 1e9})
+                    "adam_GBps": bytes_adam / (adam_us * 1e-6) / 1e9,
+                    "step_us": round(sum(us.values()), 1)})
         del state
 print(json.dumps(out))

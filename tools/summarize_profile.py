@@ -35,6 +35,10 @@ def short(name):
         k = "spmm_csr" + {"1": "_rows", "2": "_sparse"}.get(t.group(1) if t else "0", "")   # (the names the benches use)
         if t and t.group(2) in ("true", "1"):
             k += "+adam"                 # FUSE: the optimizer in the epilogue of the last backward layer
+    if k == "adam_dense" and re.search(r"k_adam_dense<\s*(true|1)\s*>", name):
+        k = "adam_indexed"           # the pass that sums the staged gradient rows of a large batch itself
+    if k == "seg_scan":
+        k = "seg_index"
     if k == "select" and re.search(r"k_select<\s*(true|1)\s*>", name):
         k = "select2"
     if k == "tau" and re.search(r"k_tau<\s*\d+\s*,\s*(true|1)\s*>", name):
