@@ -345,6 +345,22 @@ int    macr_score_topk_splits(int U, int n_local, int d);
 int    macr_score_topk_uses_seeds(int U, int n_local, int d);   /* 0: this shape lists every unmasked item, seed_idx is ignored */
 size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
 
+/* How the listing pass of macr_score_topk forms its candidate lists.  The ranking returned is the fp32 ranking either
+ * way, bit for bit (scores, ids, tie order): a filter only decides which (query, item) pairs get a closer look.
+ *   MACR_EVAL_FILTER_F32   the (U, N) product on the fp32 matrix cores; a listed score is the final score.
+ *   MACR_EVAL_FILTER_BF16  the product on two-term bf16 splits of the operands (hi*hi + hi*lo + lo*hi: 5x fewer
+ *                          matrix-core cycles), every score compared with the query's threshold LESS a rigorous bound of
+ *                          the error (1e-4 |u| max|q| + roundings); the
+ *                          selection re-computes the fp32 score of each query's 64 best candidates and ranks those,
+ *                          after checking that nothing else can belong to the top K; a query that fails the check goes
+ *                          through the fp32 repair round.
+ *   MACR_EVAL_FILTER_ENV   (default) follow MACR_EVAL_FILTER=f32|bf16 in the environment, f32 when unset.
+ * Process-wide; not meant to be flipped while rankings are in flight on other threads. */
+#define MACR_EVAL_FILTER_ENV  0
+#define MACR_EVAL_FILTER_F32  1
+#define MACR_EVAL_FILTER_BF16 2
+int macr_set_eval_filter(int mode);
+
 int macr_score_topk(int score_kind, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
                     const float *sig_u, const float *sig_i, float c, const float *c_dev,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "macr_branch_sigmoid": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "macr_score_topk_splits": (_i, [_i, _i, _i]),
     "macr_score_topk_uses_seeds": (_i, [_i, _i, _i]),
+    "macr_set_eval_filter": (_i, [_i]),
     "macr_score_topk_workspace_bytes": (_z, [_i, _i, _i]),
     "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "macr_score_topk_sweep_workspace_bytes": (_z, [_i, _i, _i, _i]),

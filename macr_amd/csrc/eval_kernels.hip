@@ -840,6 +840,279 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 // fewer than K items for users who never had K candidates, the repair round for anyone else).
 // One 32-lane half per user, lane l = seed l.
 // ----------------------------------------------------------------------------
+
+// ============================================================================
+// bf16 FILTER for the listing pass (opt-in: MACR_EVAL_FILTER=bf16 / macr_set_eval_filter).
+// The listing pass only has to find, per user, a superset of her best K items; the ranking is decided on exact fp32
+// scores.  So the (U, N) product may run on the bf16 matrix cores -- 16x the fp32 MFMA rate -- as long as nothing that
+// belongs to the exact top K is lost:
+//   * every operand as TWO bf16 numbers, x ~ hi + lo (hi = bf16(x), lo = bf16(x - hi), round to nearest even:
+//     |x - hi - lo| <= 2^-16 |x|; k_bf16_prep), the product as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (products
+//     exact, fp32 accumulation): 3 MFMAs of 32 cycles per 16 k instead of 8 of 64 -- 5.3x fewer matrix-core cycles --
+//     and |s_bf16 - s_fp32| <= (3.1 * 2^-16 + 6 d 2^-24) sum_k |u_k q_k| <= kFilterRel * |u| * max_i |q_i|  (Cauchy-Schwarz).
+//     (One bf16 per operand -- 16x -- was built first: its bound, 2^-7 |u| max|q|, is wider than the gap between a user's
+//     K-th and 64th best score whenever a few popular items have long rows, and most users failed the check below.)
+//     every epilogue (common.hpp score_epilogue) is 1-Lipschitz in s (sigmoids <= 1) and adds <= 3 roundings of values
+//     bounded by |s| + |c|.  margin_u = filter_margin(|u|, max|q|, c) bounds |score_bf16 - score_fp32| for every item;
+//   * the pass lists every item with score_bf16 >= tau_u - margin_u (tau_u a valid fp32 threshold: >= K unmasked items
+//     score >= tau_u), i.e. every item whose fp32 score is >= tau_u;
+//   * k_select_b takes the 64 best listed items by bf16 score, checks that the 64th lies more than 2 margin_u below the
+//     K-th (32nd with seeds) -- then no item outside the 64 can belong to the exact top K -- computes the fp32 score of
+//     those 64 with the k-ascending fmaf chain and the exact epilogue of every other kernel here, and ranks them.
+//     A user for whom the check fails (dozens of scores inside a margin) is flagged like a user whose list overflowed:
+//     the repair round lists her user block again with the fp32 kernels.
+// The result is the fp32 ranking, bit for bit; tests compare both filters with the oracle.
+// ============================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr float kFilterRel = 1.0e-4f;        // > 3.1 * 2^-16 + 6 * 256 * 2^-24
+constexpr float kFilterAbs = 4.8e-7f;        // > 2^-21: epilogue roundings, relative to |u| max|q| + |c|
+
+__device__ __forceinline__ float filter_margin(float unorm, float qmax, float c) {
+    const float b = unorm * qmax * 1.0001f;
+    return kFilterRel * b + kFilterAbs * (b + fabsf(c)) + 1e-37f;
+}
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float f) {          // round to nearest even; NaN stays NaN
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// Rows of the item table (shard) and the query users' rows -> bf16 copies; |u| per query user; max |q| over the items
+// (atomicMax on the float's bits: norms are >= 0).  One 8-lane group per 64 columns... one lane converts 8 columns.
+template <int D>
+__global__ __launch_bounds__(256) void k_bf16_prep(int U, int n_local, const float *__restrict__ users_tab,
+                                                   const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                                   uint4 *__restrict__ users_bf, uint4 *__restrict__ items_bf,
+                                                   float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
+    constexpr int LPRB = D / 8, RPB = 256 / LPRB;            // lanes per row, rows per block
+    __shared__ float s_max[4];
+    const int sub = threadIdx.x % LPRB, slot = threadIdx.x / LPRB;
+    const long long row = (long long)blockIdx.x * RPB + slot;
+    const bool is_item = row < n_local;
+    const long long q = row - n_local;
+    float sq = 0.f;
+    if (is_item || q < U) {
+        const float *src = is_item ? items + (size_t)row * D : users_tab + (size_t)(user_ids ? user_ids[q] : q) * D;
+        const float4 a = ld4(src + 8 * sub), b = ld4(src + 8 * sub + 4);
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t hi[8], lo[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hi[k] = bf16_rne_bits(x[k]);
+            lo[k] = bf16_rne_bits(x[k] - __uint_as_float(hi[k] << 16));       // (x - hi is exact in fp32)
+        }
+        // row layout: hi[D] then lo[D]
+        uint4 *dst = is_item ? items_bf + (size_t)row * 2 * LPRB : users_bf + (size_t)q * 2 * LPRB;
+        dst[sub] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+        dst[LPRB + sub] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+        sq = dot4(a, a) + dot4(b, b);
+    }
+    sq = group_sum<LPRB>(sq);
+    float nrm = sqrtf(sq) * 1.0001f;                          // (rounded up: the margin must not be short)
+    if (!(nrm == nrm)) nrm = INFINITY;                        // a NaN row: margin +inf, everything of that user is listed / re-scored
+    if (!is_item && q < U && sub == 0) unorm[q] = nrm;
+    float m = is_item ? nrm : 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        if (m > 0.f) atomicMax(qmax_bits, __float_as_uint(m));
+    }
+}
+
+template <int D>
+struct StreamCfgB {
+    static constexpr int RSB = 2 * D + 8;                     // LDS row (hi[D], lo[D]) stride in bf16: 4D + 16 bytes, conflict-free 16-byte reads
+    static constexpr int NS = D / 16;                         // k slabs per tile (32x32x16), three MFMAs each
+    static constexpr int UNITS = kTileItems * 2 * D / 8;      // 16-byte units per tile
+    static constexpr int LDU = (UNITS + 511) / 512;
+    static constexpr size_t smem = (size_t)2 * kTileItems * RSB * 2 + 2 * kTileItems * 4 + kUsersPerBlock * 4;
+};
+
+// The listing pass of k_score_stream (MODE = list, one c, first round) on bf16 copies of the operands; see above.
+template <int D, int KIND>
+__global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_b(
+    int U, int n_local, const uint4 *__restrict__ users_bf, const uint4 *__restrict__ items_bf,
+    const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
+    const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val, const float *__restrict__ c_dev,
+    const uint32_t *__restrict__ mask_bits, int item_offset, int ublocks, const float *__restrict__ tau,
+    uint64_t *__restrict__ lists, int32_t *__restrict__ counts, int cap, int32_t *overflow, int ovf_per_user,
+    int32_t *blk_flag) {
+    using C = StreamCfgB<D>;
+    constexpr int kCheckTiles = 8;
+    const float c = c_dev ? *c_dev : c_val;
+    constexpr int RSB = C::RSB, NS = C::NS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __bf16 *s_a = reinterpret_cast<__bf16 *>(smem);                                   // [2][32][RSB]
+    float *s_sig = reinterpret_cast<float *>(smem + (size_t)2 * kTileItems * RSB * 2);  // [2][32]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_sig + 2 * kTileItems);          // [256]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int uslot = wid * 32 + col;
+    const int T = (n_local + kTileItems - 1) / kTileItems;
+    const long long G = gridDim.x, b = blockIdx.x;
+    int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream (scattered tile ranges)
+    S = S < 1 ? 1 : S;
+    for (;; ++S) {
+        int x = S, y = T;
+        while (y) { const int r = x % y; x = y; y = r; }
+        if (x == 1) break;
+    }
+    auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T); };
+    const float qmax = __uint_as_float(*qmax_bits);
+    const long long W = (long long)ublocks * T;
+    const long long w_end = W * (b + 1) / G;
+    for (long long w = W * b / G; w < w_end;) {
+    const int ub = (int)(w / T), i0 = (int)(w - (long long)ub * T);
+    const int i1 = (int)min((long long)T, i0 + (w_end - w));
+    w += i1 - i0;
+    long long first = (long long)ub * T * G / W;
+    while (W * (first + 1) / G <= (long long)ub * T) ++first;
+    while (W * first / G > (long long)ub * T) --first;
+    const int split = (int)(b - first);
+    const int q = ub * kUsersPerBlock + uslot;
+    const bool q_ok = q < U;
+
+    if (tid < kUsersPerBlock) s_cnt[tid] = 0u;
+    bf16x8 bhi[NS], blo[NS];
+    {
+        const uint4 *urow = users_bf + (size_t)(q_ok ? q : 0) * (2 * D / 8);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            uint4 v = urow[2 * sI + h], l = urow[D / 8 + 2 * sI + h];
+            if (!q_ok) { v = make_uint4(0u, 0u, 0u, 0u); l = v; }
+            bhi[sI] = *reinterpret_cast<bf16x8 *>(&v);
+            blo[sI] = *reinterpret_cast<bf16x8 *>(&l);
+        }
+    }
+    const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
+    // listing test: score_bf16 >= tau - margin (NaN = never: padding users)
+    float tau_s = __builtin_nanf("");
+    if (q_ok) tau_s = tau[q] - 1.01f * filter_margin(unorm[q], qmax, c);
+    uint64_t *my_list = lists + ((size_t)split * U + (q_ok ? q : 0)) * cap;
+
+    int vi = i0, t = visit(i0);
+    uint4 stg[C::LDU];
+    float sg = 0.f;
+    uint32_t tm_next = 0u;
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int k = 0; k < C::LDU; ++k) {
+            const int e = tid + 512 * k, row = (e / (2 * D / 8)) & (kTileItems - 1), c8 = e % (2 * D / 8);
+            const int it = min(tile * kTileItems + row, n_local - 1);
+            stg[k] = items_bf[(size_t)it * (2 * D / 8) + c8];
+        }
+        if (score_uses_sig_i(KIND)) sg = sig_i[min(tile * kTileItems + (tid & (kTileItems - 1)), n_local - 1)];
+        tm_next = (mask_bits && q_ok) ? mask_bits[(size_t)tile * U + q] : 0u;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < C::LDU; ++k) {
+            asm volatile("" : "+v"(stg[k].x), "+v"(stg[k].y), "+v"(stg[k].z), "+v"(stg[k].w));
+            const int e = tid + 512 * k, row = e / (2 * D / 8), c8 = e % (2 * D / 8);
+            if (row < kTileItems)
+                *reinterpret_cast<uint4 *>(s_a + ((size_t)buf * kTileItems + row) * RSB + 8 * c8) = stg[k];
+        }
+        if (score_uses_sig_i(KIND)) {
+            asm volatile("" : "+v"(sg));
+            if (tid < kTileItems) s_sig[buf * kTileItems + tid] = sg;
+        }
+    };
+
+    int buf = 0;
+    if (vi < i1) { load_tile(t); store_tile(0); }
+    uint32_t tm_cur = tm_next;
+    __syncthreads();
+    const float kNone = __builtin_nanf("");
+    while (vi < i1) {
+        const bool has_next = vi + 1 < i1;
+        const int tn = has_next ? visit(vi + 1) : t;
+        if (has_next) load_tile(tn);
+
+        const int gid0 = t * kTileItems + item_offset;
+        uint32_t tmask = tm_cur;
+        const int valid = n_local - t * kTileItems;           // < 32 only in the last tile of the shard
+        if (valid < kTileItems) tmask |= valid > 0 ? ~0u << valid : ~0u;
+
+        const __bf16 *ua = s_a + ((size_t)buf * kTileItems + col) * RSB + 8 * h;
+        f32x16 acc;
+        if (__any(tmask != 0)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = ((tmask >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1u) ? kNone : 0.f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(ua + 16 * sI);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(ua + D + 16 * sI);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhi[sI], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blo[sI], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhi[sI], acc, 0, 0, 0);
+        }
+
+        float sgi[16];
+        if (score_uses_sig_i(KIND)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(sgi + 4 * g) = *reinterpret_cast<const float4 *>(s_sig + buf * kTileItems + 8 * g + 4 * h);
+        }
+        float v[16];
+        uint64_t hit = 0ull;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[r] = acc[r];
+            if (score_uses_sig_i(KIND)) v[r] = score_epilogue<KIND>(v[r], c, sgi[r], su);
+            hit |= __ballot(v[r] >= tau_s);
+        }
+        if (hit) {                                            // one wave-uniform branch per tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (v[r] >= tau_s) {
+                    const uint32_t pos = atomicAdd(&s_cnt[uslot], 1u);
+                    if (pos < (uint32_t)cap) my_list[pos] = make_key(v[r], gid0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    else { overflow[ovf_per_user ? q : 0] = 1; tau_s = INFINITY; }
+                }
+            }
+        }
+        bool stop = false;                                    // block-uniform; see k_score_stream (stale seeds)
+        if (blk_flag) {
+            const int done = vi - i0 + 1;
+            const bool check = done == 2 || done == kCheckTiles || done == 4 * kCheckTiles;
+            if (check || (done & 7) == 0) {
+                bool mine = false;
+                if (check) {
+                    uint32_t a = h == 0 ? s_cnt[uslot] : 0u;
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, kWave);
+                    const float usable = 32.f * (float)(done * kTileItems) * (float)(kSelRegs * 64) / (float)n_local;
+                    mine = (float)a > usable + 64.f;
+                } else if (tid == 0) {
+                    mine = __hip_atomic_load(blk_flag + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                }
+                stop = __syncthreads_or(mine) != 0;
+                if (stop && tid == 0) __hip_atomic_store(blk_flag + ub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (has_next) store_tile(buf ^ 1);
+        __syncthreads();
+        tm_cur = tm_next;
+        buf ^= 1;
+        t = tn; ++vi;
+        if (stop) break;
+    }
+    if (tid < kUsersPerBlock) {
+        const int qq = ub * kUsersPerBlock + tid;
+        if (qq < U) counts[(size_t)split * U + qq] = (int32_t)min(s_cnt[tid], (uint32_t)cap);
+    }
+    }   // segments
+}
+
 constexpr int kSeedWidth = MACR_SEED_WIDTH;
 static_assert(kSeedWidth == 32, "one 32-lane half per user");
 template <int D, int KIND>
@@ -1066,6 +1339,9 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
                                                            int32_t *__restrict__ seed_out) {
     __shared__ uint64_t s_top[kSelWaves][64];
     if (REPAIR && *run_if == 0) return;               // second selection: only after a repair round
+    // ... and only for the user blocks that were listed again (skip_blk = blk_flag: 1 = in the repair round); the other
+    // users' results stand -- after a bf16-filtered first round their lists hold bf16 scores, not ranking material
+    if (REPAIR && skip_blk && skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] == 0) return;
     // first selection: a user block the listing pass gave up on (stale seeds) is ranked after the repair round only
     if (!REPAIR && skip_blk && skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] != 0) return;
     // wave-uniform values are made so explicitly (readfirstlane): the selection state then lives in SGPRs
@@ -1085,6 +1361,143 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
     if (n <= 256) select_user<4>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
     else if (n <= 512) select_user<8>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
     else select_user<kSelRegs>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+}
+
+
+// k_select_b: the selection after a bf16-filtered listing pass (see k_score_stream_b): the 64 best candidates by bf16
+// score, the margin check, their exact fp32 scores, the ranking.  One wave per user.
+template <int NREG>
+__device__ __forceinline__ uint64_t gather_top64(int q, int lane, int U, int n_splits, int cap, int n, int incl,
+                                                 const uint64_t *__restrict__ lists, uint64_t *s_top) {
+    size_t rel[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) rel[j] = (size_t)q * cap + (j * 64 + lane);
+    for (int s = 1; s < n_splits; ++s) {
+        const int off = __builtin_amdgcn_readlane(incl, s - 1);
+        if (off >= n) break;
+        const size_t base = ((size_t)s * U + q) * cap - off;
+#pragma unroll
+        for (int j = 0; j < NREG; ++j)
+            if (j * 64 + lane >= off) rel[j] = base + (j * 64 + lane);
+    }
+    uint64_t key[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) key[j] = j * 64 + lane < n ? lists[rel[j]] : 0ull;
+    uint64_t kth = 0ull;
+    if (n > 64) {                                                   // the 64th largest of the n keys (distinct: ids differ)
+        uint64_t cand[NREG];
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) cand[j] = __ballot(j * 64 + lane < n);
+        int remaining = 64, alive = n;
+        for (int bit = 63; bit >= 0 && alive > 1; --bit) {
+            const uint32_t m = 1u << (bit & 31);
+            uint64_t ones[NREG];
+            int n1 = 0;
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) {
+                const uint32_t word = bit >= 32 ? (uint32_t)(key[j] >> 32) : (uint32_t)key[j];
+                ones[j] = __ballot((word & m) != 0u) & cand[j];
+                n1 += __popcll(ones[j]);
+            }
+            if (n1 >= remaining) {
+                alive = n1;
+#pragma unroll
+                for (int j = 0; j < NREG; ++j) cand[j] = ones[j];
+            } else {
+                remaining -= n1; alive -= n1;
+#pragma unroll
+                for (int j = 0; j < NREG; ++j) cand[j] &= ~ones[j];
+            }
+        }
+        uint32_t hi = 0, lo = 0;
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) {
+            if (cand[j]) {
+                const int src_lane = __ffsll((long long)cand[j]) - 1;
+                hi = __shfl((uint32_t)(key[j] >> 32), src_lane, kWave);
+                lo = __shfl((uint32_t)key[j], src_lane, kWave);
+            }
+        }
+        kth = ((uint64_t)hi << 32) | lo;
+    }
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+        const bool keep = key[j] != 0ull && key[j] >= kth;
+        const uint64_t km = __ballot(keep);
+        if (km) {
+            if (keep) s_top[base + __popcll(km & ((1ull << lane) - 1ull))] = key[j];
+            base += __popcll(km);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint64_t k1 = lane < base ? s_top[lane] : 0ull;
+    return wave_sort_desc(k1);                                      // lane i: the (i+1)-th best candidate by bf16 score (0 = none)
+}
+
+template <int D, int KIND>
+__global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local, int n_splits, int n_out, int K, int cap,
+                                                             const uint64_t *__restrict__ lists, const int32_t *__restrict__ counts,
+                                                             int32_t *overflow, int ovf_per_user, const int32_t *__restrict__ skip_blk,
+                                                             const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
+                                                             const float *__restrict__ items, const float *__restrict__ sig_u,
+                                                             const float *__restrict__ sig_i, float c_val, const float *__restrict__ c_dev,
+                                                             int item_offset, const float *__restrict__ unorm,
+                                                             const uint32_t *__restrict__ qmax_bits,
+                                                             float *__restrict__ out_val, int32_t *__restrict__ out_idx,
+                                                             int32_t *__restrict__ seed_out) {
+    __shared__ uint64_t s_top[kSelWaves][64];
+    if (skip_blk && skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] != 0) return;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x * kSelWaves + wid;
+    if (q >= U) return;
+    const float c = c_dev ? *c_dev : c_val;
+    const int my_c = lane < n_splits ? counts[(size_t)lane * U + q] : 0;
+    int incl = my_c;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, kWave); if (lane >= m) incl += o; }
+    const int n_all = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, kWave));
+    const int n = n_all < kSelRegs * 64 ? n_all : kSelRegs * 64;
+    bool flag = n_all > kSelRegs * 64;
+    uint64_t ka;
+    if (n <= 256) ka = gather_top64<4>(q, lane, U, n_splits, cap, n, incl, lists, s_top[wid]);
+    else if (n <= 512) ka = gather_top64<8>(q, lane, U, n_splits, cap, n, incl, lists, s_top[wid]);
+    else ka = gather_top64<kSelRegs>(q, lane, U, n_splits, cap, n, incl, lists, s_top[wid]);
+    // no item outside these 64 may belong to the exact top R (R = K, or the seed width when seeds are written)
+    const int R = seed_out ? kSeedWidth : K;
+    const uint32_t hi_r = __shfl((uint32_t)(ka >> 32), R - 1, kWave), hi_last = __shfl((uint32_t)(ka >> 32), 63, kWave);
+    if (n > 64) {
+        const float a_r = orderable_f32(hi_r), a_last = orderable_f32(hi_last);
+        const float m2 = 2.02f * filter_margin(unorm[q], __uint_as_float(*qmax_bits), c);
+        if (!(a_last < a_r - m2)) flag = true;
+    }
+    if (flag && lane == 0) overflow[ovf_per_user ? q : 0] = 1;
+    // exact scores of the candidates: the arithmetic of k_tau_seed / the fp32 listing pass
+    uint64_t ke = 0ull;
+    if (ka) {
+        const int id = key_id(ka), it = id - item_offset;
+        const float *ur = users_tab + (size_t)(user_ids ? user_ids[q] : q) * D, *ir = items + (size_t)it * D;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k4 = 0; k4 < D / 4; ++k4) {
+            const float4 a = ld4(ur + 4 * k4), b = ld4(ir + 4 * k4);
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        }
+        float v = acc;
+        if (score_uses_sig_i(KIND)) v = score_epilogue<KIND>(v, c, sig_i[it], score_uses_sig_u(KIND) ? sig_u[q] : 1.0f);
+        if (v == v) ke = make_key(v, id);                     // (a NaN score is no candidate: the fp32 listing test fails on it too)
+    }
+    ke = wave_sort_desc(ke);
+    if (lane < K) {
+        out_val[(size_t)q * K + lane] = ke ? key_score(ke) : -INFINITY;
+        out_idx[(size_t)q * K + lane] = ke ? key_id(ke) : -1;
+        for (int s = 1; s < n_out; ++s) {
+            out_val[((size_t)s * U + q) * K + lane] = -INFINITY;
+            out_idx[((size_t)s * U + q) * K + lane] = -1;
+        }
+    }
+    if (seed_out && lane < kSeedWidth) seed_out[(size_t)q * kSeedWidth + lane] = ke ? key_id(ke) : -1;
+    (void)n_local;
 }
 
 // ----------------------------------------------------------------------------
@@ -1517,9 +1930,10 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
 // mask_bits[tiles][U] | lists[S1][U][cap]
 struct TopkWs {
     float *tau, *maxima; int32_t *counts; int32_t *overflow, *user_ovf, *ub_map, *blk_flag; uint32_t *shared_thr, *mask_bits; uint64_t *lists;
+    uint4 *users_bf, *items_bf; float *unorm;        // bf16 filter: operand copies, |u| per query user (max |q|: overflow[8], zeroed per call)
     int cap; size_t header_bytes, maxima_bytes, mask_bytes, bytes;
 };
-static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g) {
+static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g, int d = 0) {
     TopkWs w;
     char *p = static_cast<char *>(base);
     size_t off = 0;
@@ -1540,6 +1954,9 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g) 
     w.mask_bytes = (size_t)(n_tiles(n_local) + n_windows(n_local)) * U * 4;
     w.mask_bits = static_cast<uint32_t *>(take(w.mask_bytes));
     w.lists = static_cast<uint64_t *>(take((size_t)g.slots1 * U * w.cap * 8));
+    w.users_bf = static_cast<uint4 *>(take((size_t)U * d * 4));          // (hi[d], lo[d]) bf16 per row
+    w.items_bf = static_cast<uint4 *>(take((size_t)n_local * d * 4));
+    w.unorm = static_cast<float *>(take((size_t)U * 4));
     w.bytes = off;
     return w;
 }
@@ -1547,7 +1964,20 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g) 
 
 extern "C" size_t macr_score_topk_workspace_bytes(int U, int n_local, int d) {
     if (U <= 0 || n_local <= 0 || !dim_supported(d)) return 0;
-    return carve_topk_ws(nullptr, U, n_local, stream_geo(U, n_local, d)).bytes;
+    return carve_topk_ws(nullptr, U, n_local, stream_geo(U, n_local, d), d).bytes;
+}
+
+// 0 = follow MACR_EVAL_FILTER in the environment (default f32), 1 = f32, 2 = bf16
+static int g_eval_filter = 0;
+extern "C" int macr_set_eval_filter(int mode) {
+    MACR_REQUIRE(mode >= 0 && mode <= 2, MACR_E_INVALID, "set_eval_filter: mode=%d", mode);
+    g_eval_filter = mode;
+    return MACR_OK;
+}
+static bool eval_filter_bf16() {
+    if (g_eval_filter) return g_eval_filter == 2;
+    const char *e = getenv("MACR_EVAL_FILTER");
+    return e && (e[0] == 'b' || e[0] == 'B');
 }
 
 extern "C" int macr_score_topk_uses_seeds(int U, int n_local, int d) {
@@ -1638,11 +2068,13 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
     MACR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
                  "score_topk: workspace must be 256-byte aligned");
     const StreamGeo geo = stream_geo(U, n_local, d);
-    TopkWs ws = carve_topk_ws(workspace, U, n_local, geo);
+    TopkWs ws = carve_topk_ws(workspace, U, n_local, geo, d);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "score_topk: workspace %zu < %zu bytes", workspace_bytes,
                  ws.bytes);
     // workspace head: counts, flag, shared_thr <- 0; tau <- -inf on the list-everything path; maxima <- NaN
     const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
+    // (a shard small enough to list everything has nothing to filter)
+    const bool filter_bf16 = !list_all && eval_filter_bf16();
     {
         const size_t n_zero = ws.header_bytes / 4;
         const size_t n_tau = (reinterpret_cast<char *>(ws.maxima) - reinterpret_cast<char *>(ws.tau)) / 4;
@@ -1698,6 +2130,29 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         // Round 1 flags overflowing lists per user; the repair round lists the user blocks of those users again with the
         // threshold their cut lists imply (k_repair_plan); only a second overflow arms the exact fallback kernel.
         const bool repair = !list_all;
+        if (filter_bf16) {
+            // bf16-filtered first round (k_score_stream_b): operand copies, listing on the bf16 matrix cores, then the
+            // selection re-scores its 64 best candidates in fp32
+            uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws.overflow + 8);
+            k_bf16_prep<D><<<(unsigned)(((size_t)n_local + U + 256 / (D / 8) - 1) / (256 / (D / 8))), 256, 0, st>>>(
+                U, n_local, users_tab, user_ids, items, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits);
+            MACR_CHECK_LAUNCH("bf16_prep", st);
+            auto pass1b = k_score_stream_b<D, KIND>;
+            const size_t smem_b = StreamCfgB<D>::smem;
+            MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass1b), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)smem_b) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_b);
+            pass1b<<<geo.grid1, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev,
+                                                   mask_bits, item_offset, geo.ublocks, ws.tau, ws.lists, ws.counts, ws.cap,
+                                                   repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
+                                                   seeded ? ws.blk_flag : nullptr);
+            MACR_CHECK_LAUNCH("score_stream_b", st);
+            k_select_b<D, KIND><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts,
+                                                                      repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
+                                                                      seeded ? ws.blk_flag : nullptr, users_tab, user_ids, items,
+                                                                      sig_u, sig_i, c, c_dev, item_offset, ws.unorm, qmax_bits,
+                                                                      out_val, out_idx, seed_out);
+            MACR_CHECK_LAUNCH("select_b", st);
+        } else {
         pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
                                             geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
                                             repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, 0, nullptr, nullptr,
@@ -1707,6 +2162,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
                                                               repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, nullptr,
                                                               seeded ? ws.blk_flag : nullptr, out_val, out_idx, seed_out);
         MACR_CHECK_LAUNCH("select", st);
+        }
         if (repair) {
             k_repair_plan<<<geo.ublocks, kUsersPerBlock, 0, st>>>(U, K, geo.slots1, ws.user_ovf, out_val, ws.tau, ws.counts,
                                                                  ws.ub_map, ws.blk_flag, ws.overflow + 1);
@@ -1724,7 +2180,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
                                                  ws.ub_map, ws.overflow + 1, nullptr, SweepArgs{});
             MACR_CHECK_LAUNCH("score_stream2", st);
             k_select<true><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow, 0,
-                                                           ws.overflow + 1, nullptr, out_val, out_idx, seed_out);
+                                                           ws.overflow + 1, ws.blk_flag, out_val, out_idx, seed_out);
             MACR_CHECK_LAUNCH("select2", st);
         }
     });

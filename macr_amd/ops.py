@@ -159,6 +159,17 @@ def score_topk_splits(U, n_local, d):
     return _lib.lib().macr_score_topk_splits(U, n_local, d)
 
 
+EVAL_FILTER_ENV, EVAL_FILTER_F32, EVAL_FILTER_BF16 = 0, 1, 2
+
+
+def set_eval_filter(mode):
+    """How macr_score_topk's listing pass forms its candidate lists (include/macr_hip.h MACR_EVAL_FILTER_*): "f32", "bf16"
+    (bf16 matrix cores + fp32 re-scoring of the best candidates: the same ranking, bit for bit) or "env" (default:
+    MACR_EVAL_FILTER in the environment, f32 when unset)."""
+    mode = {"env": EVAL_FILTER_ENV, "f32": EVAL_FILTER_F32, "bf16": EVAL_FILTER_BF16}.get(mode, mode)
+    check(_lib.lib().macr_set_eval_filter(int(mode)))
+
+
 SEED_WIDTH = 32          # MACR_SEED_WIDTH
 _topk_ws_cache = {}
 

@@ -17,6 +17,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=["f32", "bf16"])
+def eval_filter(request, ops):
+    """run the test once per candidate filter of the listing pass (include/macr_hip.h MACR_EVAL_FILTER_*): the ranking
+    must be the fp32 ranking bit for bit either way"""
+    ops.set_eval_filter(request.param)
+    yield request.param
+    ops.set_eval_filter("env")
+
+
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
@@ -26,7 +35,7 @@ SYNTH128 = dict(n_users=40000, n_items=30011, d=128, batch=8192, n_train=1600000
 
 
 @pytest.mark.parametrize("workload", ["gowalla", "ml10m", "synthetic-d128"])
-def test_fullsize_eval(ops, workload):
+def test_fullsize_eval(ops, workload, eval_filter):
     """configs[1] (15 424 query users x 40 981 items), configs[2] shapes (13 878 x 8 790) and a d=128 catalogue as in
     configs[4]; c=40, K=20.  The oracle ranks every 97th user, properties cover all of them."""
     from macr_amd import synth
@@ -186,7 +195,7 @@ def test_yelp_size_lightgcn_train_step(ops, kind):
         np.testing.assert_allclose(state.wu.cpu().numpy(), wuo, rtol=0, atol=4e-3 * cfg["lr"])
 
 
-def test_config4_shard_eval(ops):
+def test_config4_shard_eval(ops, eval_filter):
     """configs[4] (10 M x 1 M, d = 128, item-sharded over 8 GPUs), ONE rank's share at full size: 20 000 query users
     against a 125 000-item shard whose global ids start at item_offset.  The oracle ranks every 97th user bit for
     bit; all users: the shard's result is independent of how the listing is split, sub-shards merge to the same
@@ -273,7 +282,7 @@ def test_config4_shard_size_training_step(ops):
 
 
 @pytest.mark.parametrize("workload", ["gowalla", "ml10m"])
-def test_fullsize_seeded_rankings_at_every_staleness(ops, workload):
+def test_fullsize_seeded_rankings_at_every_staleness(ops, workload, eval_filter):
     """Threshold seeds at full size (512 resident workgroups, 61 blocks of 256 queries on Gowalla shapes): the ranking
     leaves its best candidates, the tables then move by a little, by a lot, or are replaced, and the seeded ranking
     (good seeds; seeds that are stale for SOME query blocks: early stop of single blocks, repair round for those; seeds

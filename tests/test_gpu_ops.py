@@ -24,6 +24,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=["f32", "bf16"])
+def eval_filter(request, ops):
+    """run the test once per candidate filter of the listing pass (include/macr_hip.h MACR_EVAL_FILTER_*): the ranking
+    must be the fp32 ranking bit for bit either way"""
+    ops.set_eval_filter(request.param)
+    yield request.param
+    ops.set_eval_filter("env")
+
+
 def dev(a, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     if dtype is not None:
@@ -469,7 +478,7 @@ def random_mask(rs, U, n_items, mean_len, heavy=()):
     (300, 1000, 64, 20, 1, 0), (300, 1000, 64, 20, 3, 0), (257, 2085, 64, 20, 8, 0), (40, 744, 64, 20, 0, 0),
     (1, 33, 64, 20, 1, 0), (5, 17, 64, 20, 1, 0), (64, 1000, 32, 5, 2, 0), (100, 900, 128, 32, 4, 0),
     (70, 500, 256, 1, 1, 0), (300, 1000, 64, 20, 2, 5000), (513, 4099, 64, 30, 0, 0)])
-def test_score_topk_bit_exact(ops, kind, U, N, d, K, splits, off):
+def test_score_topk_bit_exact(ops, kind, U, N, d, K, splits, off, eval_filter):
     rs = np.random.RandomState(U + N + d + K)
     n_users = U + 50
     P = (rs.standard_normal((n_users, d)) * 0.5).astype(np.float32)
@@ -508,7 +517,7 @@ def test_score_topk_bit_exact(ops, kind, U, N, d, K, splits, off):
         assert np.array_equal(picked[valid].view(np.uint32), want_v[valid].view(np.uint32))
 
 
-def test_score_topk_item_sharding_equals_unsharded(ops):
+def test_score_topk_item_sharding_equals_unsharded(ops, eval_filter):
     """Item-sharded scoring + merge == single-shard scoring (the 1/2/4/8-GPU contract)."""
     rs = np.random.RandomState(0)
     U, N, d, K = 777, 5003, 64, 20
@@ -545,7 +554,7 @@ def sampled_items(N):
 
 
 @pytest.mark.parametrize("splits", [1, 3])
-def test_score_topk_overflowing_lists_fall_back_to_running_topk(ops, splits):
+def test_score_topk_overflowing_lists_fall_back_to_running_topk(ops, splits, eval_filter):
     """Adversarial score order for the fixed-threshold stream: every sampled item scores far
     below the rest, so the thresholds learnt from the samples admit ~everything and the candidate lists overflow;
     the device-armed fallback (running top-K kernel) must still return the exact ranking."""
@@ -565,7 +574,7 @@ def test_score_topk_overflowing_lists_fall_back_to_running_topk(ops, splits):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_score_topk_random_shapes(ops, seed):
+def test_score_topk_random_shapes(ops, seed, eval_filter):
     """Randomised shapes through the streaming ranking: query counts around the 256-user block, catalogues around
     the 32-item tile / the 8-tile sampling stride / the list-everything limit, every d, K up to 32, shards with
     an offset, heavy and empty masks, duplicated item rows (exact ties)."""
@@ -611,7 +620,7 @@ def test_score_topk_random_shapes(ops, seed):
     assert np.array_equal(gv.cpu().numpy().view(np.uint32), want_v2.view(np.uint32))
 
 
-def test_score_topk_all_scores_tie(ops):
+def test_score_topk_all_scores_tie(ops, eval_filter):
     """Zero user vectors: every item scores 0 (and -0), the threshold equals every score, the candidate lists
     overflow and the fallback ranks by ascending id among the unmasked items."""
     rs = np.random.RandomState(2)
@@ -764,7 +773,7 @@ def test_errors_are_loud(ops):
         ops.branch_sigmoid(torch.zeros(4, 64), torch.zeros(64))             # CPU tensors: no fallback
 
 
-def test_seeded_thresholds_do_not_change_the_ranking(ops):
+def test_seeded_thresholds_do_not_change_the_ranking(ops, eval_filter):
     """macr_score_topk with seed ids (k_tau_seed): whatever the seeds -- the best candidates of the previous ranking,
     random items, masked, repeated or invalid ids -- the result is the exact ranking (the seeds only decide how tight
     the threshold is); bit-equal to the oracle."""
@@ -824,7 +833,7 @@ def listing_visit_rank(N):
     return rank[idx // 32] * 32 + idx % 32
 
 
-def test_score_topk_second_overflow_arms_the_exact_kernel(ops):
+def test_score_topk_second_overflow_arms_the_exact_kernel(ops, eval_filter):
     """Scores that rise along the order the listing pass visits the catalogue in: whatever a first (cut) list holds is
     the bottom of its range of visits.  With seeds (the earliest-visited items) the repair round samples the re-listed
     query blocks and its thresholds hold; without seeds on a catalogue whose sampled items score below everything else,

@@ -23,6 +23,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=["f32", "bf16"])
+def eval_filter(request, ops):
+    """run the test once per candidate filter of the listing pass (include/macr_hip.h MACR_EVAL_FILTER_*): the ranking
+    must be the fp32 ranking bit for bit either way"""
+    ops.set_eval_filter(request.param)
+    yield request.param
+    ops.set_eval_filter("env")
+
+
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
@@ -75,7 +84,7 @@ def test_G6_lgcn_evaluator_on_hip(ops, dataset):
 
 # ----------------------------------------------------------------------------- fused path, end to end on Addressa
 @pytest.mark.parametrize("kind", [0, 1])
-def test_fused_evaluators_match_oracle_on_addressa(ops, kind):
+def test_fused_evaluators_match_oracle_on_addressa(ops, kind, eval_filter):
     from macr_amd.evaluator import Evaluator
     data = MFData(dataset_args("addressa"))
     users = list(data.test_user_list.keys())
@@ -658,7 +667,7 @@ def test_lightgcn_tune_cli(tmp_path):
         assert abs(hr - hit_of(sweep_line)) < 6e-6, (pre[c_key], sweep_line)
 
 
-def test_evaluator_seeds_follow_the_model_and_back_off_when_it_jumps(ops):
+def test_evaluator_seeds_follow_the_model_and_back_off_when_it_jumps(ops, eval_filter):
     """Evaluator.rank_local seeds every ranking's thresholds with the best candidates of the previous one.  Tables that
     drift a little between two evaluations keep the seeds good (no query block listed twice); a model that jumps
     (new item table) makes them stale: that evaluation pays a repair round, the next one goes back to the sampling pass
