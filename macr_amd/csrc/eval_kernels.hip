@@ -865,7 +865,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 // ============================================================================
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 constexpr float kFilterRel = 1.0e-4f;        // > 3.1 * 2^-16 + 6 * 256 * 2^-24
-constexpr float kFilterAbs = 4.8e-7f;        // > 2^-21: epilogue roundings, relative to |u| max|q| + |c|
+constexpr float kFilterAbs = 1.0e-6f;        // > 2^-20: roundings of the epilogue / of the test on the raw product, relative to |u| max|q| + |c|
 
 __device__ __forceinline__ float filter_margin(float unorm, float qmax, float c) {
     const float b = unorm * qmax * 1.0001f;
@@ -928,13 +928,34 @@ struct StreamCfgB {
     static constexpr int RSB = 2 * D + 8;                     // LDS row (hi[D], lo[D]) stride in bf16: 4D + 16 bytes, conflict-free 16-byte reads
     static constexpr int NS = D / 16;                         // k slabs per tile (32x32x16), three MFMAs each
     static constexpr int UNITS = kTileItems * 2 * D / 8;      // 16-byte units per tile
-    static constexpr int LDU = (UNITS + 511) / 512;
-    static constexpr size_t smem = (size_t)2 * kTileItems * RSB * 2 + 2 * kTileItems * 4 + kUsersPerBlock * 4;
+    static constexpr size_t smem = (size_t)2 * kTileItems * RSB * 2 + 4 * kTileItems * 4 + kUsersPerBlock * 4 + 16;
 };
 
+// The listing test of k_score_stream_b in the domain of the RAW product: score(acc) >= tau  <=>  acc >= fma(X_u, Y_i, Z_u)
+// (sigmoids > 0), one fma + one compare per score instead of the epilogue + compare; the epilogue runs for the hits only.
+//   RUBI_BOTH  (acc - c) s_i s_u >= tau   X = tau / s_u   Y = 1 / s_i   Z = c
+//   RUBI       (acc - c) s_i     >= tau   X = tau         Y = 1 / s_i   Z = c
+//   DIRECT_MINUS       acc - c s_i     >= tau   X = c        Y = s_i    Z = tau
+//   DIRECT_MINUS_BOTH  acc - c s_i s_u >= tau   X = c s_u    Y = s_i    Z = tau
+// The roundings of X, Y and the fma are inside the slack the threshold already carries (filter_margin's absolute term).
+// A sigmoid below 1e-30 (1/s overflows, tau/s is 0/0 for tau = 0) sends the tile / the wave through the plain epilogue.
+// Masked items are not poisoned in the accumulator here (16 selects per tile and wave): the mask is tested for the hits.
+template <int KIND>
+__device__ __forceinline__ float filter_y(float sig) {
+    return (KIND == MACR_SCORE_RUBI_BOTH || KIND == MACR_SCORE_RUBI) ? 1.0f / sig : sig;
+}
+
 // The listing pass of k_score_stream (MODE = list, one c, first round) on bf16 copies of the operands; see above.
+// A wave owns UG groups of 32 users.  UG = 1 (8 waves per 256-user block, four waves per SIMD up to d = 64) is what runs:
+// measured on the Gowalla shape, UG = 2 (4-wave blocks, every item fragment read from LDS feeding 6 MFMAs, 198 VGPRs, two
+// waves per SIMD) took 362 us against 291 -- the pass is a chain of latencies (LDS reads, the barrier, the trip of the
+// next tile), and waves in flight hide them better than longer MFMA runs do; two tiles per barrier (spills at 128 VGPRs)
+// and a tile fetched two visits ahead (the register copies wait for the loads) were slower too.
+template <int D>
+struct StreamGroupsB { static constexpr int UG = 1, NW = kUsersPerBlock / (32 * UG), THREADS = 64 * NW; };
+
 template <int D, int KIND>
-__global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_b(
+__global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_score_stream_b(
     int U, int n_local, const uint4 *__restrict__ users_bf, const uint4 *__restrict__ items_bf,
     const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
     const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val, const float *__restrict__ c_dev,
@@ -942,17 +963,20 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_b(
     uint64_t *__restrict__ lists, int32_t *__restrict__ counts, int cap, int32_t *overflow, int ovf_per_user,
     int32_t *blk_flag) {
     using C = StreamCfgB<D>;
+    constexpr int UG = StreamGroupsB<D>::UG, THREADS = StreamGroupsB<D>::THREADS;
+    constexpr int LDU = (C::UNITS + THREADS - 1) / THREADS;
     constexpr int kCheckTiles = 8;
     const float c = c_dev ? *c_dev : c_val;
     constexpr int RSB = C::RSB, NS = C::NS;
     extern __shared__ __align__(16) unsigned char smem[];
     __bf16 *s_a = reinterpret_cast<__bf16 *>(smem);                                   // [2][32][RSB]
     float *s_sig = reinterpret_cast<float *>(smem + (size_t)2 * kTileItems * RSB * 2);  // [2][32]
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_sig + 2 * kTileItems);          // [256]
+    float *s_y = s_sig + 2 * kTileItems;                                               // [2][32]  filter_y(sig_i)
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_y + 2 * kTileItems);            // [256]
+    int *s_slow = reinterpret_cast<int *>(s_cnt + kUsersPerBlock);                    // [2]  tile holds a sigmoid < 1e-30
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int uslot = wid * 32 + col;
     const int T = (n_local + kTileItems - 1) / kTileItems;
     const long long G = gridDim.x, b = blockIdx.x;
     int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream (scattered tile ranges)
@@ -963,6 +987,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_b(
         if (x == 1) break;
     }
     auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T); };
+    auto visit_after = [&](int tile) { const int n = tile + S; return n >= T ? n - T : n; };     // visit(i + 1) from visit(i)
     const float qmax = __uint_as_float(*qmax_bits);
     const long long W = (long long)ublocks * T;
     const long long w_end = W * (b + 1) / G;
@@ -974,109 +999,147 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_b(
     while (W * (first + 1) / G <= (long long)ub * T) ++first;
     while (W * first / G > (long long)ub * T) --first;
     const int split = (int)(b - first);
-    const int q = ub * kUsersPerBlock + uslot;
-    const bool q_ok = q < U;
 
-    if (tid < kUsersPerBlock) s_cnt[tid] = 0u;
-    bf16x8 bhi[NS], blo[NS];
-    {
-        const uint4 *urow = users_bf + (size_t)(q_ok ? q : 0) * (2 * D / 8);
+    for (int k = tid; k < kUsersPerBlock; k += THREADS) s_cnt[k] = 0u;
+    // per user group g: users (wid * UG + g) * 32 + col
+    int uslot[UG], q[UG];
+    bool q_ok[UG];
+    bf16x8 bhi[UG][NS], blo[UG][NS];
+    float su[UG], tau_s[UG], fx[UG], fz[UG];
+    uint64_t *my_list[UG];
+    bool wave_slow = false;
+#pragma unroll
+    for (int g = 0; g < UG; ++g) {
+        uslot[g] = (wid * UG + g) * 32 + col;
+        q[g] = ub * kUsersPerBlock + uslot[g];
+        q_ok[g] = q[g] < U;
+        const uint4 *urow = users_bf + (size_t)(q_ok[g] ? q[g] : 0) * (2 * D / 8);
 #pragma unroll
         for (int sI = 0; sI < NS; ++sI) {
             uint4 v = urow[2 * sI + h], l = urow[D / 8 + 2 * sI + h];
-            if (!q_ok) { v = make_uint4(0u, 0u, 0u, 0u); l = v; }
-            bhi[sI] = *reinterpret_cast<bf16x8 *>(&v);
-            blo[sI] = *reinterpret_cast<bf16x8 *>(&l);
+            if (!q_ok[g]) { v = make_uint4(0u, 0u, 0u, 0u); l = v; }
+            bhi[g][sI] = *reinterpret_cast<bf16x8 *>(&v);
+            blo[g][sI] = *reinterpret_cast<bf16x8 *>(&l);
         }
+        su[g] = (score_uses_sig_u(KIND) && q_ok[g]) ? sig_u[q[g]] : 1.0f;
+        // listing test: score_bf16 >= tau - margin (NaN = never: padding users)
+        tau_s[g] = __builtin_nanf("");
+        if (q_ok[g]) tau_s[g] = tau[q[g]] - 1.01f * filter_margin(unorm[q[g]], qmax, c);
+        // the test on the raw product (filter_y): acc >= fma(fx, Y_i, fz)
+        fx[g] = 0.f; fz[g] = tau_s[g];
+        if (KIND == MACR_SCORE_RUBI_BOTH) { fx[g] = tau_s[g] / su[g]; fz[g] = c; }
+        else if (KIND == MACR_SCORE_RUBI) { fx[g] = tau_s[g]; fz[g] = c; }
+        else if (KIND == MACR_SCORE_DIRECT_MINUS) { fx[g] = c; }
+        else if (KIND == MACR_SCORE_DIRECT_MINUS_BOTH) { fx[g] = c * su[g]; }
+        if (KIND == MACR_SCORE_RUBI_BOTH) wave_slow = wave_slow || __any(q_ok[g] && !(su[g] > 1e-30f));
+        my_list[g] = lists + ((size_t)split * U + (q_ok[g] ? q[g] : 0)) * cap;
     }
-    const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
-    // listing test: score_bf16 >= tau - margin (NaN = never: padding users)
-    float tau_s = __builtin_nanf("");
-    if (q_ok) tau_s = tau[q] - 1.01f * filter_margin(unorm[q], qmax, c);
-    uint64_t *my_list = lists + ((size_t)split * U + (q_ok ? q : 0)) * cap;
 
     int vi = i0, t = visit(i0);
-    uint4 stg[C::LDU];
+    uint4 stg[LDU];
     float sg = 0.f;
-    uint32_t tm_next = 0u;
+    uint32_t tm_next[UG];
     auto load_tile = [&](int tile) {
 #pragma unroll
-        for (int k = 0; k < C::LDU; ++k) {
-            const int e = tid + 512 * k, row = (e / (2 * D / 8)) & (kTileItems - 1), c8 = e % (2 * D / 8);
+        for (int k = 0; k < LDU; ++k) {
+            const int e = tid + THREADS * k, row = (e / (2 * D / 8)) & (kTileItems - 1), c8 = e % (2 * D / 8);
             const int it = min(tile * kTileItems + row, n_local - 1);
             stg[k] = items_bf[(size_t)it * (2 * D / 8) + c8];
         }
         if (score_uses_sig_i(KIND)) sg = sig_i[min(tile * kTileItems + (tid & (kTileItems - 1)), n_local - 1)];
-        tm_next = (mask_bits && q_ok) ? mask_bits[(size_t)tile * U + q] : 0u;
+#pragma unroll
+        for (int g = 0; g < UG; ++g) tm_next[g] = (mask_bits && q_ok[g]) ? mask_bits[(size_t)tile * U + q[g]] : 0u;
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int k = 0; k < C::LDU; ++k) {
+        for (int k = 0; k < LDU; ++k) {
             asm volatile("" : "+v"(stg[k].x), "+v"(stg[k].y), "+v"(stg[k].z), "+v"(stg[k].w));
-            const int e = tid + 512 * k, row = e / (2 * D / 8), c8 = e % (2 * D / 8);
+            const int e = tid + THREADS * k, row = e / (2 * D / 8), c8 = e % (2 * D / 8);
             if (row < kTileItems)
                 *reinterpret_cast<uint4 *>(s_a + ((size_t)buf * kTileItems + row) * RSB + 8 * c8) = stg[k];
         }
         if (score_uses_sig_i(KIND)) {
             asm volatile("" : "+v"(sg));
-            if (tid < kTileItems) s_sig[buf * kTileItems + tid] = sg;
+            if (tid < 64) {                                   // (wave 0; lanes 32-63 hold copies of the tile's 32 values)
+                const bool tiny = !(sg > 1e-30f);
+                if (tid < kTileItems) { s_sig[buf * kTileItems + tid] = sg; s_y[buf * kTileItems + tid] = filter_y<KIND>(sg); }
+                const bool any_tiny = __any(tiny);
+                if (tid == 0) s_slow[buf] = any_tiny ? 1 : 0;
+            }
         }
     };
 
     int buf = 0;
     if (vi < i1) { load_tile(t); store_tile(0); }
-    uint32_t tm_cur = tm_next;
+    uint32_t tm_cur[UG];
+#pragma unroll
+    for (int g = 0; g < UG; ++g) tm_cur[g] = tm_next[g];
     __syncthreads();
-    const float kNone = __builtin_nanf("");
     while (vi < i1) {
         const bool has_next = vi + 1 < i1;
-        const int tn = has_next ? visit(vi + 1) : t;
+        const int tn = has_next ? visit_after(t) : t;
         if (has_next) load_tile(tn);
 
         const int gid0 = t * kTileItems + item_offset;
-        uint32_t tmask = tm_cur;
         const int valid = n_local - t * kTileItems;           // < 32 only in the last tile of the shard
-        if (valid < kTileItems) tmask |= valid > 0 ? ~0u << valid : ~0u;
+        const uint32_t tail = valid < kTileItems ? (valid > 0 ? ~0u << valid : ~0u) : 0u;
 
         const __bf16 *ua = s_a + ((size_t)buf * kTileItems + col) * RSB + 8 * h;
-        f32x16 acc;
-        if (__any(tmask != 0)) {
+        f32x16 acc[UG];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = ((tmask >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1u) ? kNone : 0.f;
-        } else {
+        for (int g = 0; g < UG; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        }
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 #pragma unroll
         for (int sI = 0; sI < NS; ++sI) {
             const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(ua + 16 * sI);
             const bf16x8 al = *reinterpret_cast<const bf16x8 *>(ua + D + 16 * sI);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhi[sI], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blo[sI], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhi[sI], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < UG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhi[g][sI], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < UG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blo[g][sI], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < UG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhi[g][sI], acc[g], 0, 0, 0);
         }
 
-        float sgi[16];
+        const bool slow = score_uses_sig_i(KIND) && (wave_slow || s_slow[buf] != 0);       // wave-uniform, practically never
+        float yi[16];
         if (score_uses_sig_i(KIND)) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4 *>(sgi + 4 * g) = *reinterpret_cast<const float4 *>(s_sig + buf * kTileItems + 8 * g + 4 * h);
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<float4 *>(yi + 4 * k) = *reinterpret_cast<const float4 *>(s_y + buf * kTileItems + 8 * k + 4 * h);
         }
-        float v[16];
-        uint64_t hit = 0ull;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = acc[r];
-            if (score_uses_sig_i(KIND)) v[r] = score_epilogue<KIND>(v[r], c, sgi[r], su);
-            hit |= __ballot(v[r] >= tau_s);
-        }
-        if (hit) {                                            // one wave-uniform branch per tile
+        for (int g = 0; g < UG; ++g) {
+            uint32_t hit = 0u;                                // bit r: some lane's score r passes (scalar unit)
+            if (!slow) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (v[r] >= tau_s) {
-                    const uint32_t pos = atomicAdd(&s_cnt[uslot], 1u);
-                    if (pos < (uint32_t)cap) my_list[pos] = make_key(v[r], gid0 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    else { overflow[ovf_per_user ? q : 0] = 1; tau_s = INFINITY; }
+                for (int r = 0; r < 16; ++r)
+                    hit |= __ballot(acc[g][r] >= (score_uses_sig_i(KIND) ? fmaf(fx[g], yi[r], fz[g]) : fz[g])) ? 1u << r : 0u;
+            } else {
+                hit = 0xffffu;                                // every score through the epilogue below
+            }
+            if (hit) {                                        // one wave-uniform branch per tile and group
+                const uint32_t tmask = tm_cur[g] | tail;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (!((hit >> r) & 1u)) continue;         // wave-uniform: nobody's score r passes
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    bool pass = slow || acc[g][r] >= (score_uses_sig_i(KIND) ? fmaf(fx[g], yi[r], fz[g]) : fz[g]);
+                    pass = pass && ((tmask >> row) & 1u) == 0u;   // masked (train) items, rows past the end of the shard
+                    if (pass) {
+                        float v = acc[g][r];
+                        if (score_uses_sig_i(KIND)) v = score_epilogue<KIND>(v, c, s_sig[buf * kTileItems + row], su[g]);
+                        if (v >= tau_s[g]) {
+                            const uint32_t pos = atomicAdd(&s_cnt[uslot[g]], 1u);
+                            if (pos < (uint32_t)cap) my_list[g][pos] = make_key(v, gid0 + row);
+                            else {                            // full: stop listing for her
+                                overflow[ovf_per_user ? q[g] : 0] = 1;
+                                tau_s[g] = INFINITY; fz[g] = INFINITY;
+                                if (KIND == MACR_SCORE_RUBI_BOTH || KIND == MACR_SCORE_RUBI) fx[g] = INFINITY;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -1087,11 +1150,15 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_b(
             if (check || (done & 7) == 0) {
                 bool mine = false;
                 if (check) {
-                    uint32_t a = h == 0 ? s_cnt[uslot] : 0u;
+                    uint32_t a = 0u;                          // appended so far by this wave's 32 UG users
+                    if (h == 0) {
+#pragma unroll
+                        for (int g = 0; g < UG; ++g) a += s_cnt[uslot[g]];
+                    }
 #pragma unroll
                     for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, kWave);
-                    const float usable = 32.f * (float)(done * kTileItems) * (float)(kSelRegs * 64) / (float)n_local;
-                    mine = (float)a > usable + 64.f;
+                    const float usable = 32.f * UG * (float)(done * kTileItems) * (float)(kSelRegs * 64) / (float)n_local;
+                    mine = (float)a > usable + 64.f * UG;
                 } else if (tid == 0) {
                     mine = __hip_atomic_load(blk_flag + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                 }
@@ -1101,14 +1168,15 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_b(
         }
         if (has_next) store_tile(buf ^ 1);
         __syncthreads();
-        tm_cur = tm_next;
+#pragma unroll
+        for (int g = 0; g < UG; ++g) tm_cur[g] = tm_next[g];
         buf ^= 1;
         t = tn; ++vi;
         if (stop) break;
     }
-    if (tid < kUsersPerBlock) {
-        const int qq = ub * kUsersPerBlock + tid;
-        if (qq < U) counts[(size_t)split * U + qq] = (int32_t)min(s_cnt[tid], (uint32_t)cap);
+    for (int k = tid; k < kUsersPerBlock; k += THREADS) {
+        const int qq = ub * kUsersPerBlock + k;
+        if (qq < U) counts[(size_t)split * U + qq] = (int32_t)min(s_cnt[k], (uint32_t)cap);
     }
     }   // segments
 }
@@ -1466,15 +1534,15 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
     // no item outside these 64 may belong to the exact top R (R = K, or the seed width when seeds are written)
     const int R = seed_out ? kSeedWidth : K;
     const uint32_t hi_r = __shfl((uint32_t)(ka >> 32), R - 1, kWave), hi_last = __shfl((uint32_t)(ka >> 32), 63, kWave);
-    if (n > 64) {
-        const float a_r = orderable_f32(hi_r), a_last = orderable_f32(hi_last);
-        const float m2 = 2.02f * filter_margin(unorm[q], __uint_as_float(*qmax_bits), c);
-        if (!(a_last < a_r - m2)) flag = true;
-    }
+    const float m2 = 2.02f * filter_margin(unorm[q], __uint_as_float(*qmax_bits), c);
+    // (hi_r == 0: fewer than R candidates -- all of them matter)
+    const float a_cut = hi_r ? orderable_f32(hi_r) - m2 : -INFINITY;
+    if (n > 64 && !(orderable_f32(hi_last) < a_cut)) flag = true;
     if (flag && lane == 0) overflow[ovf_per_user ? q : 0] = 1;
-    // exact scores of the candidates: the arithmetic of k_tau_seed / the fp32 listing pass
+    // exact scores of the candidates that can still belong to the top R (bf16 score within two margins of the R-th): the
+    // arithmetic of k_tau_seed / the fp32 listing pass
     uint64_t ke = 0ull;
-    if (ka) {
+    if (ka && key_score(ka) >= a_cut) {
         const int id = key_id(ka), it = id - item_offset;
         const float *ur = users_tab + (size_t)(user_ids ? user_ids[q] : q) * D, *ir = items + (size_t)it * D;
         float acc = 0.f;
@@ -2141,7 +2209,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             const size_t smem_b = StreamCfgB<D>::smem;
             MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass1b), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_b) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_b);
-            pass1b<<<geo.grid1, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev,
+            pass1b<<<geo.grid1, StreamGroupsB<D>::THREADS, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev,
                                                    mask_bits, item_offset, geo.ublocks, ws.tau, ws.lists, ws.counts, ws.cap,
                                                    repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
                                                    seeded ? ws.blk_flag : nullptr);

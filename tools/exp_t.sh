@@ -1,19 +1,9 @@
 #!/bin/bash
-export TMPDIR=/tmp; OUT=$PWD/gpurun_out/spmm; mkdir -p $OUT; ROOT=$PWD; : > $OUT/nb.txt
-for v in nb1 nb2 base; do
-  if [ $v = base ]; then unset MACR_HIP_LIB; else export MACR_HIP_LIB=$ROOT/macr_amd/csrc/_abl/libmacr_hip_$v.so; fi
-  echo "== $v" >> $OUT/nb.txt
-  python tools/spmm_lab.py yelp2018 30 >> $OUT/nb.txt 2>/dev/null
-  python tools/bench_lgcn.py 2>/dev/null | cut -c1-330 >> $OUT/nb.txt
-  (cd /tmp && timeout 300 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/f$v -o x -- python $ROOT/tools/spmm_lab.py yelp2018 10 > /dev/null 2>&1)
-  python - $v <<'PY' >> gpurun_out/spmm/nb.txt
-import csv,glob,collections,sys
-agg=collections.defaultdict(list)
-for f in glob.glob('gpurun_out/spmm/f%s/**/*counter_collection.csv'%sys.argv[1], recursive=True):
-    for r in csv.DictReader(open(f)):
-        if 'spmm_row' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
-print({k: round(sum(v)/len(v),1) for k,v in agg.items()})
-PY
-  rm -rf $OUT/f$v
-done
-cat $OUT/nb.txt
+# scratch: eval kernels of the bench under a filter
+f=${1:-bf16}
+MACR_EVAL_FILTER=$f python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$f abl=$MACR_ABL', round(r['eval_users_per_s']/1e6,2), 'M users/s', r['eval_ms_per_pass'], r['eval_ms_unseeded'])
+k=r['roofline_eval']['kernels_us']; print({a:round(b,1) for a,b in k.items() if 'stream' in a or 'select' in a})
+k=r['roofline_eval']['seeded']['kernels_us']; print({a:round(b,1) for a,b in k.items() if 'stream' in a or 'select' in a})"
