@@ -46,6 +46,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -194,21 +195,28 @@ def bench_config4(args, rank, world, dev):
         def run_eval():
             query_rows()
             return ev.test_mf(ops.SCORE_RUBI_BOTH, Pq, None, model.Q, [20], model.w, model.wu, c)
-        ret = run_eval(); ret = run_eval()
-        times = []
-        for r_ in range(max(2, min(args.eval_reps, 5))):
-            run_steps(2, 2 * r_)
-            barrier(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ret = run_eval()
-            torch.cuda.synchronize(); barrier()
-            times.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))
-        t_ev = float(np.median(times))
+        def timed(filt):
+            ev.filter = filt
+            ret = run_eval(); ret = run_eval()
+            times = []
+            for r_ in range(max(2, min(args.eval_reps, 5))):
+                run_steps(2, 2 * r_)
+                barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ret = run_eval()
+                torch.cuda.synchronize(); barrier()
+                times.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))
+            return float(np.median(times)), ret
+        # fp32 products throughout (priced against the fp32 MFMA peak), then the evaluator's default: the bf16 candidate
+        # filter with fp32 re-scoring -- the same ranking, bit for bit
+        t_f32, _ = timed("f32")
+        t_ev, ret = timed(os.environ.get("MACR_EVAL_FILTER", "bf16").lower())
         flops_rank = 2.0 * U * (i_hi - i_lo) * d
-        eval_out = {"eval_users_per_s": U / t_ev, "eval_ms_per_pass": 1e3 * t_ev, "eval_users": U,
+        eval_out = {"eval_users_per_s": U / t_ev, "eval_ms_per_pass": 1e3 * t_ev, "eval_users": U, "eval_filter": ev.filter,
                     "eval_metrics": {k: float(v[0]) for k, v in ret.items()},
-                    "roofline_eval": {"bound": "mfma", "flops_per_rank": flops_rank, "achieved": flops_rank / t_ev / 1e12,
-                                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_rank / t_ev / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "roofline_eval": {"filter": "f32", "bound": "mfma", "flops_per_rank": flops_rank, "eval_users_per_s": U / t_f32,
+                                      "achieved": flops_rank / t_f32 / 1e12,
+                                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_rank / t_f32 / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                       "note": "whole evaluation incl. the query-row exchange, the all-gather and the metrics, per rank"}}
     # ------------------------------------------------------------- CPU baseline (N = 1): the oracle on a 1/64 row sample
     cpu = None
@@ -433,94 +441,128 @@ def main():
     users, mask_lists, gt_lists = synth.eval_problem(cfg, seed=777)       # same on every rank
     Ks = [20]
     eval_users_per_s = ev_elapsed = ev_unseeded_ms = ev_modes = None
-    ret, roofline_eval = {}, None
+    ret, roofline_eval, roofline_eval_bf16 = {}, None, None
     if not args.no_eval:
         def one_model():
             if world > 1:      # replicas trained on different batches: evaluate ONE model (rank 0's), item-sharded
                 for t in (state.P, state.Q, state.w, state.wu):
                     torch.distributed.broadcast(t, 0)
-        one_model()
-        ev = Evaluator(mask_lists, gt_lists, cfg["n_items"], dev)
-        uid = torch.from_numpy(users).to(dev)
-
-        def run_eval():
-            return ev.test_mf(ops.SCORE_RUBI_BOTH, state.P, uid, state.Q, Ks, state.w, state.wu, cfg["c"])
-        ret = run_eval()                 # first evaluation: thresholds from a sampling pass (no previous ranking to seed from)
-        # a training run evaluates hundreds of times: let the evaluator's seeding policy see a few evaluations of THIS model
-        # (tables moving as below) before the clock starts -- it backs off from seeds that keep going stale
-        for r_ in range(args.eval_settle):
-            if args.eval_train_steps > 0:
-                run_steps(args.eval_train_steps, args.eval_train_steps * r_)
-                one_model()
-            ret = run_eval()
-            torch.cuda.synchronize()
-        # Timed evaluations: as in a training run, the tables MOVE between two evaluations (20 untimed training steps
-        # here), and an evaluation seeds its thresholds with the ids the previous one returned (Evaluator.rank_local).
-        ev_elapsed, ev_modes = 0.0, []
-        for r_ in range(args.eval_reps):
-            if args.eval_train_steps > 0:
-                run_steps(args.eval_train_steps, args.eval_train_steps * r_)
-                one_model()
-            barrier(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ret = run_eval()
-            torch.cuda.synchronize(); barrier()
-            ev_elapsed += sharding.max_over_ranks(time.perf_counter() - t0, dev)
-            st_ = ev._stats.tolist()
-            ev_modes.append({"seeded": bool(ev._last_seeded), "query_blocks_relisted": st_[0], "exact_fallback": st_[1]})
-        eval_users_per_s = len(users) * args.eval_reps / ev_elapsed
-        # the same evaluation without seeds (what a first evaluation costs: sampling pass + k_tau instead of k_tau_seed),
-        # also a graph replay
-        ev.use_seeds = False
-        run_eval(); torch.cuda.synchronize()
-        t0 = time.perf_counter(); run_eval(); torch.cuda.synchronize()
-        ev_unseeded_ms = 1e3 * (time.perf_counter() - t0)
-        if args.eval_train_steps > 0:
-            run_steps(args.eval_train_steps, 0)
+        def eval_suite(filt):
+            """the evaluator measurements under one candidate filter of the listing pass (Evaluator.filter): timed
+            evaluations with training in between, the unseeded time, per-kernel events of a sampled and a seeded ranking"""
             one_model()
-        # per-kernel events need the launches themselves, not the graph replay.  The SAMPLED sequence (what a first
-        # evaluation runs, and what the policy falls back to) is the one `roofline_eval` prices; a seeded attempt on
-        # the same tables is reported beside it with what happened to it (roofline_eval.seeded).
-        ev.use_graph = False
-        ops.timing_begin()
-        run_eval()
-        emarks = ops.timing_end()
-        ev.use_seeds = True
-        ev._seed_skip = 0
-        ops.timing_begin()
-        run_eval()
-        smarks = ops.timing_end()
-        seeded_run = {"seeded": bool(ev._last_seeded), "query_blocks_relisted": ev._stats.tolist()[0],
-                      "kernels_us": {}}
-        for name, ms in smarks:
-            seeded_run["kernels_us"][name] = seeded_run["kernels_us"].get(name, 0.0) + 1e3 * max(ms - 1e-3 * event_overhead_us, 0.0)
-        ev.use_graph = True
-        ev_kernel_mode = {"seeded": False}
-        ek = {}
-        for name, ms in emarks:
-            ek[name] = ek.get(name, 0.0) + max(ms - 1e-3 * event_overhead_us, 0.0)
-        lo, hi = sharding.item_shard_range(cfg["n_items"], rank, world)
-        flops = 2.0 * len(users) * (hi - lo) * d
-        # The ranking = sample pass + tau + listing pass + select (+ the fallback launch that returns at once):
-        # `achieved` counts the catalogue's U*N*d multiply-adds ONCE over the time of all of them (the sample pass
-        # re-multiplies 1/8 of the tiles; that is overhead, not work).  "stream" is the listing pass alone.
-        rank_kernels = ("score_sample", "tau", "tau_seed", "score_stream", "select", "repair_plan", "score_sample2", "tau2",
-                        "score_stream2", "select2", "score_topk")
-        st_us = 1e3 * sum(ek.get(k, 0.0) for k in rank_kernels)
-        stream_us = 1e3 * ek.get("score_stream", float("nan"))
-        roofline_eval = {"kernel": "+".join(k for k in rank_kernels if k in ek), "bound": "mfma",
-                         "achieved": flops / (st_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "avg_us": st_us, "flops": flops, "traffic": pmc.get(args.workload, {}).get("score_stream"),
-                         "stream": {"avg_us": stream_us, "achieved": flops / (stream_us * 1e-6) / 1e12,
-                                    "frac": flops / (stream_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS},
-                         "kernels_us": {k: 1e3 * v for k, v in ek.items()}, "mode": ev_kernel_mode}
-        roofline_eval["frac"] = roofline_eval["achieved"] / MFMA_F32_PEAK_TFLOPS
-        s_us = sum(seeded_run["kernels_us"].get(k, 0.0) for k in rank_kernels)
-        seeded_run.update({"avg_us": s_us, "frac": flops / (s_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                           "note": "one seeded ranking of the same tables (seeds = best candidates of the previous evaluation, "
-                                   "--eval-train-steps older); query_blocks_relisted > 0: the seeds were stale and the repair "
-                                   "round ran"})
-        roofline_eval["seeded"] = seeded_run
+            ev = Evaluator(mask_lists, gt_lists, cfg["n_items"], dev)
+            ev.filter = filt
+            uid = torch.from_numpy(users).to(dev)
+
+            def run_eval():
+                return ev.test_mf(ops.SCORE_RUBI_BOTH, state.P, uid, state.Q, Ks, state.w, state.wu, cfg["c"])
+            ret = run_eval()                 # first evaluation: thresholds from a sampling pass (no previous ranking to seed from)
+            # a training run evaluates hundreds of times: let the evaluator's seeding policy see a few evaluations of THIS model
+            # (tables moving as below) before the clock starts -- it backs off from seeds that keep going stale
+            for r_ in range(args.eval_settle):
+                if args.eval_train_steps > 0:
+                    run_steps(args.eval_train_steps, args.eval_train_steps * r_)
+                    one_model()
+                ret = run_eval()
+                torch.cuda.synchronize()
+            # Timed evaluations: as in a training run, the tables MOVE between two evaluations (20 untimed training steps
+            # here), and an evaluation seeds its thresholds with the ids the previous one returned (Evaluator.rank_local).
+            ev_elapsed, ev_modes = 0.0, []
+            for r_ in range(args.eval_reps):
+                if args.eval_train_steps > 0:
+                    run_steps(args.eval_train_steps, args.eval_train_steps * r_)
+                    one_model()
+                barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ret = run_eval()
+                torch.cuda.synchronize(); barrier()
+                ev_elapsed += sharding.max_over_ranks(time.perf_counter() - t0, dev)
+                st_ = ev._stats.tolist()
+                ev_modes.append({"seeded": bool(ev._last_seeded), "query_blocks_relisted": st_[0], "exact_fallback": st_[1]})
+            eval_users_per_s = len(users) * args.eval_reps / ev_elapsed
+            # the same evaluation without seeds (what a first evaluation costs: sampling pass + k_tau instead of k_tau_seed),
+            # also a graph replay
+            ev.use_seeds = False
+            run_eval(); torch.cuda.synchronize()
+            t0 = time.perf_counter(); run_eval(); torch.cuda.synchronize()
+            ev_unseeded_ms = 1e3 * (time.perf_counter() - t0)
+            if args.eval_train_steps > 0:
+                run_steps(args.eval_train_steps, 0)
+                one_model()
+            # per-kernel events need the launches themselves, not the graph replay.  The SAMPLED sequence (what a first
+            # evaluation runs, and what the policy falls back to) is the one `roofline_eval` prices; a seeded attempt on
+            # the same tables is reported beside it with what happened to it (roofline_eval.seeded).
+            ev.use_graph = False
+            ops.timing_begin()
+            run_eval()
+            emarks = ops.timing_end()
+            ev.use_seeds = True
+            ev._seed_skip = 0
+            ops.timing_begin()
+            run_eval()
+            smarks = ops.timing_end()
+            seeded_run = {"seeded": bool(ev._last_seeded), "query_blocks_relisted": ev._stats.tolist()[0],
+                          "kernels_us": {}}
+            for name, ms in smarks:
+                seeded_run["kernels_us"][name] = seeded_run["kernels_us"].get(name, 0.0) + 1e3 * max(ms - 1e-3 * event_overhead_us, 0.0)
+            ev.use_graph = True
+            ev_kernel_mode = {"seeded": False}
+            ek = {}
+            for name, ms in emarks:
+                ek[name] = ek.get(name, 0.0) + max(ms - 1e-3 * event_overhead_us, 0.0)
+            lo, hi = sharding.item_shard_range(cfg["n_items"], rank, world)
+            flops = 2.0 * len(users) * (hi - lo) * d
+            # The ranking = sample pass + tau + listing pass + select (+ the fallback launch that returns at once):
+            # `achieved` counts the catalogue's U*N*d multiply-adds ONCE over the time of all of them (the sample pass
+            # re-multiplies 1/8 of the tiles; that is overhead, not work).  "stream" is the listing pass alone.
+            rank_kernels = ("score_sample", "tau", "tau_seed", "bf16_prep", "score_stream", "score_stream_b", "select", "select_b",
+                            "repair_plan", "score_sample2", "tau2", "score_stream2", "select2", "score_topk")
+            st_us = 1e3 * sum(ek.get(k, 0.0) for k in rank_kernels)
+            stream_us = 1e3 * ek.get("score_stream_b" if filt == "bf16" else "score_stream", float("nan"))
+            roofline_eval = {"kernel": "+".join(k for k in rank_kernels if k in ek), "bound": "mfma",
+                             "achieved": flops / (st_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "avg_us": st_us, "flops": flops, "traffic": pmc.get(args.workload, {}).get("score_stream"),
+                             "stream": {"avg_us": stream_us, "achieved": flops / (stream_us * 1e-6) / 1e12,
+                                        "frac": flops / (stream_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+                             "kernels_us": {k: 1e3 * v for k, v in ek.items()}, "mode": ev_kernel_mode}
+            roofline_eval["frac"] = roofline_eval["achieved"] / MFMA_F32_PEAK_TFLOPS
+            s_us = sum(seeded_run["kernels_us"].get(k, 0.0) for k in rank_kernels)
+            seeded_run.update({"avg_us": s_us, "frac": flops / (s_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                               "note": "one seeded ranking of the same tables (seeds = best candidates of the previous evaluation, "
+                                       "--eval-train-steps older); query_blocks_relisted > 0: the seeds were stale and the repair "
+                                       "round ran"})
+            roofline_eval["seeded"] = seeded_run
+
+            return {"ret": ret, "eval_users_per_s": eval_users_per_s, "ev_elapsed": ev_elapsed, "ev_unseeded_ms": ev_unseeded_ms,
+                    "ev_modes": ev_modes, "roofline_eval": roofline_eval}
+
+        # "f32": the (U, N) product on the fp32 matrix cores -- `roofline_eval`, priced against the fp32 MFMA peak as in
+        # the earlier rounds.  "bf16": the Evaluator's default, a bf16 candidate filter with fp32 re-scoring (the same
+        # ranking bit for bit, tests/): the headline `eval_users_per_s`.
+        suite_f32 = eval_suite("f32")
+        suite = eval_suite("bf16") if os.environ.get("MACR_EVAL_FILTER", "bf16").lower() == "bf16" else suite_f32
+        ret, eval_users_per_s, ev_elapsed = suite["ret"], suite["eval_users_per_s"], suite["ev_elapsed"]
+        ev_unseeded_ms, ev_modes = suite["ev_unseeded_ms"], suite["ev_modes"]
+        roofline_eval = suite_f32["roofline_eval"]
+        roofline_eval["filter"] = "f32"
+        roofline_eval["eval_users_per_s"] = suite_f32["eval_users_per_s"]
+        roofline_eval["eval_ms_unseeded"] = suite_f32["ev_unseeded_ms"]
+        roofline_eval_bf16 = None
+        if suite is not suite_f32:
+            rb = suite["roofline_eval"]
+            # what the bf16 matrix cores execute: three products per fp32 multiply-add (hi*hi + hi*lo + lo*hi)
+            sb = rb["stream"]["avg_us"]
+            roofline_eval_bf16 = {"filter": "bf16", "bound": "mfma-bf16", "kernel": rb["kernel"], "avg_us": rb["avg_us"],
+                                  "kernels_us": rb["kernels_us"], "seeded": rb["seeded"], "mode": rb["mode"],
+                                  "stream": {"avg_us": sb, "executed_flops": 3.0 * rb["flops"],
+                                             "achieved": 3.0 * rb["flops"] / (sb * 1e-6) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                             "unit": "TFLOP/s", "frac": 3.0 * rb["flops"] / (sb * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+                                  "speedup_vs_f32_filter": suite["eval_users_per_s"] / suite_f32["eval_users_per_s"],
+                                  "note": "same ranking as the f32 filter, bit for bit: bf16 products only pick candidates, "
+                                          "the best 64 per query are re-scored in fp32 (DESIGN.md, ranking note)"}
+            for key in ("frac",):
+                rb["seeded"].pop(key, None)
 
     # ------------------------------------------------------------- CPU baseline: the oracle ("port") on the host cores
     cpu = None
@@ -588,7 +630,7 @@ def main():
                               "max_ms_per_step": 1e3 * max(regions) / args.steps},
             "step_kernel_us": step_kernel_us, "event_overhead_us_per_launch": event_overhead_us, "kernels": kern_avg,
             "roofline": roofline, "roofline_step": roofline_step, "roofline_aux": aux, "end_to_end": end_to_end,
-            "roofline_eval": roofline_eval, "cpu_baseline": cpu,
+            "roofline_eval": roofline_eval, "roofline_eval_bf16": roofline_eval_bf16, "cpu_baseline": cpu,
             "last_losses": [float(x) for x in losses[(args.warmup + args.steps - 1) % n_batches]],
         }
         print(json.dumps(out))

@@ -32,6 +32,10 @@ class Evaluator(object):
         self.max_queries_per_pass = 131072       # bounds the ranking workspace (~1.5 GB of candidate lists)
         self.use_graph = os.environ.get("MACR_EVAL_GRAPH", "1") != "0"    # replay the evaluation as one HIP graph (_means)
         self.use_seeds = os.environ.get("MACR_EVAL_SEEDS", "1") != "0"    # thresholds from the previous top K (rank_local)
+        # candidate filter of the listing pass (include/macr_hip.h MACR_EVAL_FILTER_*): "bf16" = two-term bf16 products on
+        # the bf16 matrix cores + fp32 re-scoring of the best candidates, "f32" = fp32 products throughout.  The ranking
+        # is the fp32 ranking bit for bit either way; MACR_EVAL_FILTER in the environment overrides the default.
+        self.filter = os.environ.get("MACR_EVAL_FILTER", "bf16").lower()
         self._graphs = {}
         self._graph_misses = 0
         # seeding policy: thresholds come from the previous ranking unless that went badly last time
@@ -71,6 +75,7 @@ class Evaluator(object):
         if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH):
             sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199,:201
         U = self.n_queries
+        ops.set_eval_filter(self.filter)                          # (process-wide switch, read when the launches are issued)
         if U <= self.max_queries_per_pass:
             # Seeds: the ids this shard returned last time (same queries, tables that moved by a few training steps).
             # Their exact current scores bound every query's K-th best score from below far more tightly than a
@@ -220,7 +225,7 @@ class Evaluator(object):
     def _means_launch(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, world, seeded):
         if not self.use_graph:
             return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
-        key = (flavour, kind, seeded, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
+        key = (flavour, self.filter, kind, seeded, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
                Ks, None if w is None else w.data_ptr(), None if wu is None else wu.data_ptr(),
                torch.cuda.current_stream().cuda_stream, world)
         entry = self._graphs.get(key)

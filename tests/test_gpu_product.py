@@ -24,9 +24,10 @@ def ops():
 
 
 @pytest.fixture(params=["f32", "bf16"])
-def eval_filter(request, ops):
+def eval_filter(request, ops, monkeypatch):
     """run the test once per candidate filter of the listing pass (include/macr_hip.h MACR_EVAL_FILTER_*): the ranking
     must be the fp32 ranking bit for bit either way"""
+    monkeypatch.setenv("MACR_EVAL_FILTER", request.param)       # what an Evaluator created by the test picks up
     ops.set_eval_filter(request.param)
     yield request.param
     ops.set_eval_filter("env")
