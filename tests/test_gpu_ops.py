@@ -957,3 +957,32 @@ def test_large_batch_indexed_adam_equals_segment_reduce(ops, d, kind, hot, monke
         for st in states:
             assert not st.tP.any() and not st.tQ.any() and not st.gP.any() and not st.gQ.any()
     monkeypatch.delenv("MACR_SEG_UNFUSED", raising=False)
+
+
+def test_bf16_filter_hands_crowded_tops_to_the_fp32_round(ops):
+    """Two hundred near-copies of one popular item: for every user the best ~200 scores differ by less than the bf16
+    filter's error bound, so its selection cannot tell which 64 candidates hold the exact top 20 -- it must say so (the
+    query blocks are listed again by the fp32 kernels: stats[0] > 0) and the ranking must still be the oracle's, bit for
+    bit, ties and near-ties included.  The fp32 filter ranks the same input in one round."""
+    rs = np.random.RandomState(91)
+    U, N, d, K = 300, 6000, 64, 20
+    P = (rs.standard_normal((U, d)) * 0.3 + 0.4).astype(np.float32)              # users share a direction
+    Q = (rs.standard_normal((N, d)) * 0.3).astype(np.float32)
+    pop = (np.ones(d) * 0.5).astype(np.float32)
+    where = rs.choice(N, 200, replace=False)
+    Q[where] = pop + (rs.standard_normal((200, d)) * 2e-7).astype(np.float32)    # 200 items within ~1e-6 of each other
+    mask = random_mask(rs, U, N, 8)
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    wv, wi, _ = oracle.score_topk(oracle.SCORE_NORMAL, P, Q, K, mask=oracle.csr_from_lists(mask))
+    assert np.isin(wi, where).mean() > 0.95                                      # the crowd is the top
+    stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    try:
+        for filt, relisted in (("f32", False), ("bf16", True)):
+            ops.set_eval_filter(filt)
+            v, ix = ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(Q), K, mask=mcsr, stats=stats)
+            val, idx, _ = ops.topk_merge(v, ix)
+            assert np.array_equal(idx.cpu().numpy(), wi), filt
+            assert np.array_equal(val.cpu().numpy().view(np.uint32), wv.view(np.uint32)), filt
+            assert (stats.cpu().numpy()[0] > 0) == relisted, (filt, stats.cpu().numpy())
+    finally:
+        ops.set_eval_filter("env")
