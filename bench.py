@@ -10,8 +10,13 @@ synthetic (u, i+, i-) triples that already live in HBM.  Default workload =
 BASELINE.json configs[1]: Gowalla shapes, MACR-MF `rubibceboth`, d=64, B=4096,
 c=40 (the other configs are parity-test cases, selectable with --workload).
 `value` = training interactions/s of the whole job; the evaluator (full
-catalogue, train-masked, top-20, metrics) is timed in the same run and reported
-as `eval_users_per_s` with its own MFMA roofline.
+catalogue, train-masked, top-20, metrics) is timed in the same run, under both
+candidate filters of its listing pass, from the same model state:
+`eval_users_per_s` = the evaluator as the CLIs run it (bf16 candidate filter +
+fp32 re-scoring: the fp32 ranking bit for bit), `roofline_eval` = the same
+evaluations with fp32 products throughout, priced against the fp32 MFMA peak
+(`roofline_eval.eval_users_per_s` is that configuration's rate),
+`roofline_eval_bf16` = what the bf16 matrix cores execute in the default one.
 
 Multi-GPU: the training step of these configs fits one GPU and the
 (B,B) loss couples every pair of a batch, so N GPUs run N independent replicas
@@ -540,14 +545,27 @@ def main():
         # "f32": the (U, N) product on the fp32 matrix cores -- `roofline_eval`, priced against the fp32 MFMA peak as in
         # the earlier rounds.  "bf16": the Evaluator's default, a bf16 candidate filter with fp32 re-scoring (the same
         # ranking bit for bit, tests/): the headline `eval_users_per_s`.
+        # Both suites start from the SAME model and train it through the same batches between their evaluations (the
+        # parameters and optimizer slots are put back in place -- captured graphs keep their pointers): how far a model has
+        # come decides how often seeded thresholds go stale, and the second suite must not meet an older model.
+        snap_names = ("P", "Q", "w", "wu", "mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu", "adam_pow")
+        state.flush()
+        snapshot = {n_: getattr(state, n_).clone() for n_ in snap_names}
         suite_f32 = eval_suite("f32")
-        suite = eval_suite("bf16") if os.environ.get("MACR_EVAL_FILTER", "bf16").lower() == "bf16" else suite_f32
+        suite = suite_f32
+        if os.environ.get("MACR_EVAL_FILTER", "bf16").lower() == "bf16":
+            state.flush()
+            for n_, t_ in snapshot.items():
+                getattr(state, n_).copy_(t_)
+            suite = eval_suite("bf16")
+        del snapshot
         ret, eval_users_per_s, ev_elapsed = suite["ret"], suite["eval_users_per_s"], suite["ev_elapsed"]
         ev_unseeded_ms, ev_modes = suite["ev_unseeded_ms"], suite["ev_modes"]
         roofline_eval = suite_f32["roofline_eval"]
         roofline_eval["filter"] = "f32"
         roofline_eval["eval_users_per_s"] = suite_f32["eval_users_per_s"]
         roofline_eval["eval_ms_unseeded"] = suite_f32["ev_unseeded_ms"]
+        roofline_eval["eval_modes"] = suite_f32["ev_modes"]
         roofline_eval_bf16 = None
         if suite is not suite_f32:
             rb = suite["roofline_eval"]

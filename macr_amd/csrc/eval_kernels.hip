@@ -919,7 +919,10 @@ __global__ __launch_bounds__(256) void k_bf16_prep(int U, int n_local, const flo
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-        if (m > 0.f) atomicMax(qmax_bits, __float_as_uint(m));
+        // (most blocks find the running maximum at or above theirs and skip the atomic: ~1700 of them on one address
+        // were a third of this kernel's time)
+        if (m > __uint_as_float(__hip_atomic_load(qmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+            atomicMax(qmax_bits, __float_as_uint(m));
     }
 }
 
@@ -1503,9 +1506,57 @@ __device__ __forceinline__ uint64_t gather_top64(int q, int lane, int U, int n_s
     return wave_sort_desc(k1);                                      // lane i: the (i+1)-th best candidate by bf16 score (0 = none)
 }
 
+// exact fp32 score of (query q, item id): the k-ascending fmaf chain and the epilogue of every other kernel here
+template <int D, int KIND>
+__device__ __forceinline__ uint64_t exact_key(int q, int id, const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
+                                              const float *__restrict__ items, const float *__restrict__ sig_u,
+                                              const float *__restrict__ sig_i, float c, int item_offset) {
+    const int it = id - item_offset;
+    const float *ur = users_tab + (size_t)(user_ids ? user_ids[q] : q) * D, *ir = items + (size_t)it * D;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < D / 4; ++k4) {
+        const float4 a = ld4(ur + 4 * k4), b = ld4(ir + 4 * k4);
+        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+    }
+    float v = acc;
+    if (score_uses_sig_i(KIND)) v = score_epilogue<KIND>(v, c, sig_i[it], score_uses_sig_u(KIND) ? sig_u[q] : 1.0f);
+    return v == v ? make_key(v, id) : 0ull;                   // (a NaN score is no candidate: the fp32 listing test fails on it too)
+}
+
+// A query whose 64 best bf16 scores do not settle the top (k_select_b): every listed candidate gets its exact key, in
+// place; the plain selection (select_user) then ranks the lists as if the fp32 listing pass had written them.
+template <int NREG, int D, int KIND>
+__device__ __forceinline__ void rescore_lists(int q, int lane, int U, int n_splits, int cap, int n, int incl, uint64_t *lists,
+                                              const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
+                                              const float *__restrict__ items, const float *__restrict__ sig_u,
+                                              const float *__restrict__ sig_i, float c, int item_offset) {
+    size_t rel[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) rel[j] = (size_t)q * cap + (j * 64 + lane);
+    for (int s = 1; s < n_splits; ++s) {
+        const int off = __builtin_amdgcn_readlane(incl, s - 1);
+        if (off >= n) break;
+        const size_t base = ((size_t)s * U + q) * cap - off;
+#pragma unroll
+        for (int j = 0; j < NREG; ++j)
+            if (j * 64 + lane >= off) rel[j] = base + (j * 64 + lane);
+    }
+    for (int j = 0; j < NREG; ++j) {
+        if (j * 64 + lane < n) {
+            const uint64_t k = lists[rel[j]];
+            lists[rel[j]] = k ? exact_key<D, KIND>(q, key_id(k), users_tab, user_ids, items, sig_u, sig_i, c, item_offset) : 0ull;
+        }
+    }
+    // the selection reads these words again (through a pointer it was promised nobody writes): the stores first, stale
+    // L1 lines gone, and no load of the compiler's moved above this point
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    asm volatile("" ::: "memory");
+}
+
 template <int D, int KIND>
 __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local, int n_splits, int n_out, int K, int cap,
-                                                             const uint64_t *__restrict__ lists, const int32_t *__restrict__ counts,
+                                                             uint64_t *lists, const int32_t *__restrict__ counts,
                                                              int32_t *overflow, int ovf_per_user, const int32_t *__restrict__ skip_blk,
                                                              const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
                                                              const float *__restrict__ items, const float *__restrict__ sig_u,
@@ -1537,24 +1588,26 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
     const float m2 = 2.02f * filter_margin(unorm[q], __uint_as_float(*qmax_bits), c);
     // (hi_r == 0: fewer than R candidates -- all of them matter)
     const float a_cut = hi_r ? orderable_f32(hi_r) - m2 : -INFINITY;
-    if (n > 64 && !(orderable_f32(hi_last) < a_cut)) flag = true;
     if (flag && lane == 0) overflow[ovf_per_user ? q : 0] = 1;
+    if (n > 64 && !(orderable_f32(hi_last) < a_cut)) {
+        // more than 64 candidates inside two margins of the R-th (a flat top: scores that differ in the fifth digit):
+        // every listed candidate is scored exactly and the plain selection ranks them -- a few queries per evaluation
+        if (n <= 256) {
+            rescore_lists<4, D, KIND>(q, lane, U, n_splits, cap, n, incl, lists, users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
+            select_user<4>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+        } else if (n <= 512) {
+            rescore_lists<8, D, KIND>(q, lane, U, n_splits, cap, n, incl, lists, users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
+            select_user<8>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+        } else {
+            rescore_lists<kSelRegs, D, KIND>(q, lane, U, n_splits, cap, n, incl, lists, users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
+            select_user<kSelRegs>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+        }
+        return;
+    }
     // exact scores of the candidates that can still belong to the top R (bf16 score within two margins of the R-th): the
     // arithmetic of k_tau_seed / the fp32 listing pass
     uint64_t ke = 0ull;
-    if (ka && key_score(ka) >= a_cut) {
-        const int id = key_id(ka), it = id - item_offset;
-        const float *ur = users_tab + (size_t)(user_ids ? user_ids[q] : q) * D, *ir = items + (size_t)it * D;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int k4 = 0; k4 < D / 4; ++k4) {
-            const float4 a = ld4(ur + 4 * k4), b = ld4(ir + 4 * k4);
-            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
-        }
-        float v = acc;
-        if (score_uses_sig_i(KIND)) v = score_epilogue<KIND>(v, c, sig_i[it], score_uses_sig_u(KIND) ? sig_u[q] : 1.0f);
-        if (v == v) ke = make_key(v, id);                     // (a NaN score is no candidate: the fp32 listing test fails on it too)
-    }
+    if (ka && key_score(ka) >= a_cut) ke = exact_key<D, KIND>(q, key_id(ka), users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
     ke = wave_sort_desc(ke);
     if (lane < K) {
         out_val[(size_t)q * K + lane] = ke ? key_score(ke) : -INFINITY;

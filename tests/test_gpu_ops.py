@@ -959,11 +959,11 @@ def test_large_batch_indexed_adam_equals_segment_reduce(ops, d, kind, hot, monke
     monkeypatch.delenv("MACR_SEG_UNFUSED", raising=False)
 
 
-def test_bf16_filter_hands_crowded_tops_to_the_fp32_round(ops):
+def test_bf16_filter_scores_a_crowded_top_exactly(ops):
     """Two hundred near-copies of one popular item: for every user the best ~200 scores differ by less than the bf16
-    filter's error bound, so its selection cannot tell which 64 candidates hold the exact top 20 -- it must say so (the
-    query blocks are listed again by the fp32 kernels: stats[0] > 0) and the ranking must still be the oracle's, bit for
-    bit, ties and near-ties included.  The fp32 filter ranks the same input in one round."""
+    filter's error bound, so its 64 best candidates by bf16 score do not settle the exact top 20 -- the selection must
+    notice (more than 64 candidates inside two margins of the K-th) and score every listed candidate in fp32 instead.
+    The ranking is the oracle's, bit for bit, near-ties included, in one round under either filter."""
     rs = np.random.RandomState(91)
     U, N, d, K = 300, 6000, 64, 20
     P = (rs.standard_normal((U, d)) * 0.3 + 0.4).astype(np.float32)              # users share a direction
@@ -976,13 +976,15 @@ def test_bf16_filter_hands_crowded_tops_to_the_fp32_round(ops):
     wv, wi, _ = oracle.score_topk(oracle.SCORE_NORMAL, P, Q, K, mask=oracle.csr_from_lists(mask))
     assert np.isin(wi, where).mean() > 0.95                                      # the crowd is the top
     stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    seeds = torch.full((U, ops.SEED_WIDTH), -1, dtype=torch.int32, device="cuda")
     try:
-        for filt, relisted in (("f32", False), ("bf16", True)):
+        for filt in ("f32", "bf16"):
             ops.set_eval_filter(filt)
-            v, ix = ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(Q), K, mask=mcsr, stats=stats)
-            val, idx, _ = ops.topk_merge(v, ix)
-            assert np.array_equal(idx.cpu().numpy(), wi), filt
-            assert np.array_equal(val.cpu().numpy().view(np.uint32), wv.view(np.uint32)), filt
-            assert (stats.cpu().numpy()[0] > 0) == relisted, (filt, stats.cpu().numpy())
+            for seed in (None, seeds):                                           # sampled thresholds, then seeded ones
+                v, ix = ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(Q), K, mask=mcsr, stats=stats, seed=seed, seed_out=seeds)
+                val, idx, _ = ops.topk_merge(v, ix)
+                assert np.array_equal(idx.cpu().numpy(), wi), filt
+                assert np.array_equal(val.cpu().numpy().view(np.uint32), wv.view(np.uint32)), filt
+                assert stats.cpu().numpy().tolist() == [0, 0], (filt, stats.cpu().numpy())
     finally:
         ops.set_eval_filter("env")

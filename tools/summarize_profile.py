@@ -20,7 +20,7 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def short(name):
-    m = re.search(r"macr::k_([a-z_]+)", name)
+    m = re.search(r"macr::k_([a-z0-9_]+)", name)
     if not m:
         return None
     k = m.group(1)
