@@ -1184,6 +1184,149 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
     }   // segments
 }
 
+// The sampling pass of k_score_stream (MODE = max) on the bf16 copies: per user and class the largest score_bf16 among
+// the sampled unmasked items.  K classes with maxima >= t hold K distinct items whose fp32 scores are >= t - margin_u:
+// k_tau takes the K-th largest maximum and subtracts the margin (its `unorm` argument), which makes tau a valid fp32
+// threshold again; the listing pass then works as after an fp32 sampling pass.
+template <int D, int KIND>
+__global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_b(
+    int U, int n_local, const uint4 *__restrict__ users_bf, const uint4 *__restrict__ items_bf,
+    const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val, const float *__restrict__ c_dev,
+    const uint32_t *__restrict__ mask_bits, int ublocks, float *__restrict__ maxima, int sample_log2) {
+    using C = StreamCfgB<D>;
+    constexpr int LDU = (C::UNITS + 511) / 512;
+    const float c = c_dev ? *c_dev : c_val;
+    constexpr int RSB = C::RSB, NS = C::NS;
+    const int kStep = 1 << sample_log2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __bf16 *s_a = reinterpret_cast<__bf16 *>(smem);                                   // [2][32][RSB]
+    float *s_sig = reinterpret_cast<float *>(smem + (size_t)2 * kTileItems * RSB * 2);  // [2][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int uslot = wid * 32 + col;
+    const int tiles_total = (n_local + kTileItems - 1) / kTileItems;
+    const int T = (tiles_total + kStep - 1) / kStep;          // windows = virtual tiles per user block
+    const long long G = gridDim.x, b = blockIdx.x;
+    int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream
+    S = S < 1 ? 1 : S;
+    for (;; ++S) {
+        int x = S, y = T;
+        while (y) { const int r = x % y; x = y; y = r; }
+        if (x == 1) break;
+    }
+    auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T) * kStep; };
+    const long long W = (long long)ublocks * T;
+    const long long w_end = W * (b + 1) / G;
+    for (long long w = W * b / G; w < w_end;) {
+    const int ub = (int)(w / T), i0 = (int)(w - (long long)ub * T);
+    const int i1 = (int)min((long long)T, i0 + (w_end - w));
+    w += i1 - i0;
+    long long first = (long long)ub * T * G / W;
+    while (W * (first + 1) / G <= (long long)ub * T) ++first;
+    while (W * first / G > (long long)ub * T) --first;
+    const int split = (int)(b - first);
+    const int q = ub * kUsersPerBlock + uslot;
+    const bool q_ok = q < U;
+
+    bf16x8 bhi[NS], blo[NS];
+    {
+        const uint4 *urow = users_bf + (size_t)(q_ok ? q : 0) * (2 * D / 8);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            uint4 v = urow[2 * sI + h], l = urow[D / 8 + 2 * sI + h];
+            if (!q_ok) { v = make_uint4(0u, 0u, 0u, 0u); l = v; }
+            bhi[sI] = *reinterpret_cast<bf16x8 *>(&v);
+            blo[sI] = *reinterpret_cast<bf16x8 *>(&l);
+        }
+    }
+    const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
+
+    int vi = i0, t = visit(i0);
+    uint4 stg[LDU];
+    float sg = 0.f;
+    uint32_t tm_next = 0u;
+    // item j of the virtual tile of window `tile >> s` = every kStep-th item of the window, phase = window index mod kStep
+    auto sampled_item = [&](int tile, int row) { return min(tile * kTileItems + kStep * row + ((tile >> sample_log2) & (kStep - 1)), n_local - 1); };
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int k = 0; k < LDU; ++k) {
+            const int e = tid + 512 * k, row = (e / (2 * D / 8)) & (kTileItems - 1), c8 = e % (2 * D / 8);
+            stg[k] = items_bf[(size_t)sampled_item(tile, row) * (2 * D / 8) + c8];
+        }
+        if (score_uses_sig_i(KIND)) sg = sig_i[sampled_item(tile, tid & (kTileItems - 1))];
+        tm_next = (mask_bits && q_ok) ? mask_bits[((size_t)tiles_total + (tile >> sample_log2)) * U + q] : 0u;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < LDU; ++k) {
+            asm volatile("" : "+v"(stg[k].x), "+v"(stg[k].y), "+v"(stg[k].z), "+v"(stg[k].w));
+            const int e = tid + 512 * k, row = e / (2 * D / 8), c8 = e % (2 * D / 8);
+            if (row < kTileItems)
+                *reinterpret_cast<uint4 *>(s_a + ((size_t)buf * kTileItems + row) * RSB + 8 * c8) = stg[k];
+        }
+        if (score_uses_sig_i(KIND)) {
+            asm volatile("" : "+v"(sg));
+            if (tid < kTileItems) s_sig[buf * kTileItems + tid] = sg;
+        }
+    };
+
+    float cmax[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cmax[r] = -INFINITY;
+    int buf = 0;
+    if (vi < i1) { load_tile(t); store_tile(0); }
+    uint32_t tm_cur = tm_next;
+    __syncthreads();
+    const float kNone = __builtin_nanf("");
+    while (vi < i1) {
+        const bool has_next = vi + 1 < i1;
+        const int tn = has_next ? visit(vi + 1) : t;
+        if (has_next) load_tile(tn);
+
+        uint32_t tmask = tm_cur;
+        const int valid = (n_local - t * kTileItems - ((t >> sample_log2) & (kStep - 1)) + kStep - 1) >> sample_log2;   // < 32 only in the last window
+        if (valid < kTileItems) tmask |= valid > 0 ? ~0u << valid : ~0u;
+
+        const __bf16 *ua = s_a + ((size_t)buf * kTileItems + col) * RSB + 8 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = ((tmask >> ((r & 3) + 8 * (r >> 2) + 4 * h)) & 1u) ? kNone : 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(ua + 16 * sI);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(ua + D + 16 * sI);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhi[sI], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blo[sI], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhi[sI], acc, 0, 0, 0);
+        }
+        float sgi[16];
+        if (score_uses_sig_i(KIND)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(sgi + 4 * g) = *reinterpret_cast<const float4 *>(s_sig + buf * kTileItems + 8 * g + 4 * h);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+            if (score_uses_sig_i(KIND)) v = score_epilogue<KIND>(v, c, sgi[r], su);
+            cmax[r] = fmaxf(cmax[r], v);                      // (fmaxf drops the NaN of a masked item)
+        }
+        if (has_next) store_tile(buf ^ 1);
+        __syncthreads();
+        tm_cur = tm_next;
+        buf ^= 1;
+        t = tn; ++vi;
+    }
+    if (q_ok) {
+        float *o = maxima + ((size_t)split * U + q) * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)       // slots (r&3)+8(r>>2)+4h: four runs of four consecutive floats
+            *reinterpret_cast<float4 *>(o + 8 * g + 4 * h) = make_float4(cmax[4 * g], cmax[4 * g + 1], cmax[4 * g + 2], cmax[4 * g + 3]);
+    }
+    }   // segments
+}
+
 constexpr int kSeedWidth = MACR_SEED_WIDTH;
 static_assert(kSeedWidth == 32, "one 32-lane half per user");
 template <int D, int KIND>
@@ -1254,7 +1397,9 @@ constexpr int kSelWaves = 4;
 // COMPILE-TIME register count (no per-register guards) and the count is dispatched outside.
 template <int NREG, bool REPAIR = false>
 __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int K, const float *__restrict__ maxima,
-                                                        const int32_t *__restrict__ blk_flag, float *__restrict__ tau) {
+                                                        const int32_t *__restrict__ blk_flag, float *__restrict__ tau,
+                                                        const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
+                                                        float c_val, const float *__restrict__ c_dev) {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x * kSelWaves + wid;
     if (q >= U) return;
@@ -1301,6 +1446,8 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int
         }
         t_out = orderable_f32(prefix);                            // (all 32 bits decided when equal maxima remain)
     }
+    // maxima of bf16 scores (k_score_sample_b): K items score >= t_out - margin in fp32
+    if (unorm) t_out -= 1.01f * filter_margin(unorm[q], __uint_as_float(*qmax_bits), c_dev ? *c_dev : c_val);
     if (lane == 0) tau[q] = REPAIR ? fmaxf(tau[q], t_out) : t_out;
 }
 
@@ -2135,14 +2282,16 @@ extern "C" int macr_score_topk_splits(int U, int n_local, int d) {
 namespace macr {
 template <bool REPAIR>
 static void launch_k_tau(int tau_regs, int blocks, hipStream_t st, int U, int slots0, int K, const float *maxima,
-                         const int32_t *blk_flag, float *tau) {
+                         const int32_t *blk_flag, float *tau, const float *unorm = nullptr, const uint32_t *qmax_bits = nullptr,
+                         float c = 0.f, const float *c_dev = nullptr) {
     const int th = 64 * kSelWaves;
-    if (tau_regs <= 1) k_tau<1, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
-    else if (tau_regs <= 2) k_tau<2, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
-    else if (tau_regs <= 4) k_tau<4, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
-    else if (tau_regs <= 8) k_tau<8, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
-    else if (tau_regs <= 16) k_tau<16, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
-    else k_tau<32, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau);
+    // (unorm != NULL: the maxima are bf16 scores, tau = K-th largest - the filter's margin)
+    if (tau_regs <= 1) k_tau<1, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
+    else if (tau_regs <= 2) k_tau<2, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
+    else if (tau_regs <= 4) k_tau<4, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
+    else if (tau_regs <= 8) k_tau<8, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
+    else if (tau_regs <= 16) k_tau<16, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
+    else k_tau<32, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
 }
 }  // namespace macr
 
@@ -2233,7 +2382,24 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             else launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau);
         };
         const bool seeded = !list_all && seed_idx;
-        if (seeded) {
+        uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws.overflow + 8);
+        if (filter_bf16) {
+            // operand copies (two bf16 per value), |u| per query, max |q|: for the sampling and the listing pass
+            k_bf16_prep<D><<<(unsigned)(((size_t)n_local + U + 256 / (D / 8) - 1) / (256 / (D / 8))), 256, 0, st>>>(
+                U, n_local, users_tab, user_ids, items, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits);
+            MACR_CHECK_LAUNCH("bf16_prep", st);
+        }
+        if (filter_bf16 && !seeded) {
+            auto pass0b = k_score_sample_b<D, KIND>;
+            const size_t smem_b = StreamCfgB<D>::smem;
+            MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass0b), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)smem_b) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_b);
+            pass0b<<<geo.grid0, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, sig_u, sig_i, c, c_dev, mask_bits,
+                                                  geo.ublocks, ws.maxima, sample_log2(n_local));
+            MACR_CHECK_LAUNCH("score_sample_b", st);
+            launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev);
+            MACR_CHECK_LAUNCH("tau", st);
+        } else if (seeded) {
             // thresholds from the exact scores of the caller's seed items (its previous top K): no sampling pass, no k_tau
             k_tau_seed<D, KIND><<<(U + 7) / 8, 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
                                                                mask_bits, item_offset, K, seed_idx, ws.tau);
@@ -2252,12 +2418,8 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         // threshold their cut lists imply (k_repair_plan); only a second overflow arms the exact fallback kernel.
         const bool repair = !list_all;
         if (filter_bf16) {
-            // bf16-filtered first round (k_score_stream_b): operand copies, listing on the bf16 matrix cores, then the
-            // selection re-scores its 64 best candidates in fp32
-            uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws.overflow + 8);
-            k_bf16_prep<D><<<(unsigned)(((size_t)n_local + U + 256 / (D / 8) - 1) / (256 / (D / 8))), 256, 0, st>>>(
-                U, n_local, users_tab, user_ids, items, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits);
-            MACR_CHECK_LAUNCH("bf16_prep", st);
+            // bf16-filtered first round (k_score_stream_b): listing on the bf16 matrix cores, then the selection re-scores
+            // its best candidates in fp32
             auto pass1b = k_score_stream_b<D, KIND>;
             const size_t smem_b = StreamCfgB<D>::smem;
             MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass1b), hipFuncAttributeMaxDynamicSharedMemorySize,
