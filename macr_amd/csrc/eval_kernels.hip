@@ -957,14 +957,14 @@ __device__ __forceinline__ float filter_y(float sig) {
 template <int D>
 struct StreamGroupsB { static constexpr int UG = 1, NW = kUsersPerBlock / (32 * UG), THREADS = 64 * NW; };
 
-template <int D, int KIND>
+template <int D, int KIND, bool REPAIR = false>
 __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_score_stream_b(
     int U, int n_local, const uint4 *__restrict__ users_bf, const uint4 *__restrict__ items_bf,
     const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
     const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val, const float *__restrict__ c_dev,
     const uint32_t *__restrict__ mask_bits, int item_offset, int ublocks, const float *__restrict__ tau,
     uint64_t *__restrict__ lists, int32_t *__restrict__ counts, int cap, int32_t *overflow, int ovf_per_user,
-    int32_t *blk_flag) {
+    int32_t *blk_flag, const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev) {
     using C = StreamCfgB<D>;
     constexpr int UG = StreamGroupsB<D>::UG, THREADS = StreamGroupsB<D>::THREADS;
     constexpr int LDU = (C::UNITS + THREADS - 1) / THREADS;
@@ -981,7 +981,17 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
     const int T = (n_local + kTileItems - 1) / kTileItems;
-    const long long G = gridDim.x, b = blockIdx.x;
+    // repair round (REPAIR; k_score_stream): only the *n_ub_dev user blocks of ub_map, by part of the grid
+    int n_ub = ublocks;
+    long long G = gridDim.x;
+    const long long b = blockIdx.x;
+    if (REPAIR) {
+        n_ub = *n_ub_dev;
+        if (n_ub == 0) return;
+        G = (long long)n_ub * G / ublocks;
+        if (G < 1) G = 1;
+        if (b >= G) return;
+    }
     int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream (scattered tile ranges)
     S = S < 1 ? 1 : S;
     for (;; ++S) {
@@ -992,16 +1002,17 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
     auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T); };
     auto visit_after = [&](int tile) { const int n = tile + S; return n >= T ? n - T : n; };     // visit(i + 1) from visit(i)
     const float qmax = __uint_as_float(*qmax_bits);
-    const long long W = (long long)ublocks * T;
+    const long long W = (long long)n_ub * T;
     const long long w_end = W * (b + 1) / G;
     for (long long w = W * b / G; w < w_end;) {
-    const int ub = (int)(w / T), i0 = (int)(w - (long long)ub * T);
+    const int ubv = (int)(w / T), i0 = (int)(w - (long long)ubv * T);
     const int i1 = (int)min((long long)T, i0 + (w_end - w));
     w += i1 - i0;
-    long long first = (long long)ub * T * G / W;
-    while (W * (first + 1) / G <= (long long)ub * T) ++first;
-    while (W * first / G > (long long)ub * T) --first;
+    long long first = (long long)ubv * T * G / W;
+    while (W * (first + 1) / G <= (long long)ubv * T) ++first;
+    while (W * first / G > (long long)ubv * T) --first;
     const int split = (int)(b - first);
+    const int ub = REPAIR ? ub_map[ubv] : ubv;
 
     for (int k = tid; k < kUsersPerBlock; k += THREADS) s_cnt[k] = 0u;
     // per user group g: users (wid * UG + g) * 32 + col
@@ -1188,11 +1199,12 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
 // the sampled unmasked items.  K classes with maxima >= t hold K distinct items whose fp32 scores are >= t - margin_u:
 // k_tau takes the K-th largest maximum and subtracts the margin (its `unorm` argument), which makes tau a valid fp32
 // threshold again; the listing pass then works as after an fp32 sampling pass.
-template <int D, int KIND>
+template <int D, int KIND, bool REPAIR = false>
 __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_b(
     int U, int n_local, const uint4 *__restrict__ users_bf, const uint4 *__restrict__ items_bf,
     const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val, const float *__restrict__ c_dev,
-    const uint32_t *__restrict__ mask_bits, int ublocks, float *__restrict__ maxima, int sample_log2) {
+    const uint32_t *__restrict__ mask_bits, int ublocks, float *__restrict__ maxima, int sample_log2,
+    const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev) {
     using C = StreamCfgB<D>;
     constexpr int LDU = (C::UNITS + 511) / 512;
     const float c = c_dev ? *c_dev : c_val;
@@ -1207,7 +1219,16 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_b(
     const int uslot = wid * 32 + col;
     const int tiles_total = (n_local + kTileItems - 1) / kTileItems;
     const int T = (tiles_total + kStep - 1) / kStep;          // windows = virtual tiles per user block
-    const long long G = gridDim.x, b = blockIdx.x;
+    int n_ub = ublocks;                                       // (repair round: see k_score_stream)
+    long long G = gridDim.x;
+    const long long b = blockIdx.x;
+    if (REPAIR) {
+        n_ub = *n_ub_dev;
+        if (n_ub == 0) return;
+        G = (long long)n_ub * G / ublocks;
+        if (G < 1) G = 1;
+        if (b >= G) return;
+    }
     int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream
     S = S < 1 ? 1 : S;
     for (;; ++S) {
@@ -1216,16 +1237,17 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_b(
         if (x == 1) break;
     }
     auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T) * kStep; };
-    const long long W = (long long)ublocks * T;
+    const long long W = (long long)n_ub * T;
     const long long w_end = W * (b + 1) / G;
     for (long long w = W * b / G; w < w_end;) {
-    const int ub = (int)(w / T), i0 = (int)(w - (long long)ub * T);
+    const int ubv = (int)(w / T), i0 = (int)(w - (long long)ubv * T);
     const int i1 = (int)min((long long)T, i0 + (w_end - w));
     w += i1 - i0;
-    long long first = (long long)ub * T * G / W;
-    while (W * (first + 1) / G <= (long long)ub * T) ++first;
-    while (W * first / G > (long long)ub * T) --first;
+    long long first = (long long)ubv * T * G / W;
+    while (W * (first + 1) / G <= (long long)ubv * T) ++first;
+    while (W * first / G > (long long)ubv * T) --first;
     const int split = (int)(b - first);
+    const int ub = REPAIR ? ub_map[ubv] : ubv;
     const int q = ub * kUsersPerBlock + uslot;
     const bool q_ok = q < U;
 
@@ -1701,10 +1723,11 @@ __device__ __forceinline__ void rescore_lists(int q, int lane, int U, int n_spli
     asm volatile("" ::: "memory");
 }
 
-template <int D, int KIND>
+template <int D, int KIND, bool REPAIR = false>
 __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local, int n_splits, int n_out, int K, int cap,
                                                              uint64_t *lists, const int32_t *__restrict__ counts,
-                                                             int32_t *overflow, int ovf_per_user, const int32_t *__restrict__ skip_blk,
+                                                             int32_t *overflow, int ovf_per_user, const int32_t *__restrict__ run_if,
+                                                             const int32_t *__restrict__ skip_blk,
                                                              const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
                                                              const float *__restrict__ items, const float *__restrict__ sig_u,
                                                              const float *__restrict__ sig_i, float c_val, const float *__restrict__ c_dev,
@@ -1713,7 +1736,10 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
                                                              float *__restrict__ out_val, int32_t *__restrict__ out_idx,
                                                              int32_t *__restrict__ seed_out) {
     __shared__ uint64_t s_top[kSelWaves][64];
-    if (skip_blk && skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] != 0) return;
+    // first selection: not the user blocks the listing pass gave up on; second one (REPAIR): only after a repair round,
+    // and only the user blocks that were listed again (k_select)
+    if (REPAIR && *run_if == 0) return;
+    if (skip_blk && (skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] != 0) != REPAIR) return;
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x * kSelWaves + wid;
     if (q >= U) return;
@@ -2395,7 +2421,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass0b), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_b) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_b);
             pass0b<<<geo.grid0, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, sig_u, sig_i, c, c_dev, mask_bits,
-                                                  geo.ublocks, ws.maxima, sample_log2(n_local));
+                                                  geo.ublocks, ws.maxima, sample_log2(n_local), nullptr, nullptr);
             MACR_CHECK_LAUNCH("score_sample_b", st);
             launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev);
             MACR_CHECK_LAUNCH("tau", st);
@@ -2427,10 +2453,10 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             pass1b<<<geo.grid1, StreamGroupsB<D>::THREADS, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev,
                                                    mask_bits, item_offset, geo.ublocks, ws.tau, ws.lists, ws.counts, ws.cap,
                                                    repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
-                                                   seeded ? ws.blk_flag : nullptr);
+                                                   seeded ? ws.blk_flag : nullptr, nullptr, nullptr);
             MACR_CHECK_LAUNCH("score_stream_b", st);
             k_select_b<D, KIND><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts,
-                                                                      repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
+                                                                      repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, nullptr,
                                                                       seeded ? ws.blk_flag : nullptr, users_tab, user_ids, items,
                                                                       sig_u, sig_i, c, c_dev, item_offset, ws.unorm, qmax_bits,
                                                                       out_val, out_idx, seed_out);
@@ -2450,6 +2476,33 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             k_repair_plan<<<geo.ublocks, kUsersPerBlock, 0, st>>>(U, K, geo.slots1, ws.user_ovf, out_val, ws.tau, ws.counts,
                                                                  ws.ub_map, ws.blk_flag, ws.overflow + 1);
             MACR_CHECK_LAUNCH("repair_plan", st);
+            if (filter_bf16) {
+                // the repair round on the bf16 copies too: sampling pass for the re-listed user blocks when the thresholds
+                // came from seeds, listing, selection with fp32 re-scoring
+                auto pass0rb = k_score_sample_b<D, KIND, true>;
+                auto pass1rb = k_score_stream_b<D, KIND, true>;
+                const size_t smem_b = StreamCfgB<D>::smem;
+                hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass0rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
+                if (eb == hipSuccess) eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
+                MACR_REQUIRE(eb == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_b);
+                if (seeded) {
+                    pass0rb<<<geo.grid0, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, sig_u, sig_i, c, c_dev, mask_bits,
+                                                           geo.ublocks, ws.maxima, sample_log2(n_local), ws.ub_map, ws.overflow + 1);
+                    MACR_CHECK_LAUNCH("score_sample2", st);
+                    launch_k_tau<true>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau, ws.unorm, qmax_bits, c, c_dev);
+                    MACR_CHECK_LAUNCH("tau2", st);
+                }
+                pass1rb<<<geo.grid1, StreamGroupsB<D>::THREADS, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u,
+                                                                            sig_i, c, c_dev, mask_bits, item_offset, geo.ublocks, ws.tau,
+                                                                            ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
+                                                                            ws.ub_map, ws.overflow + 1);
+                MACR_CHECK_LAUNCH("score_stream2", st);
+                k_select_b<D, KIND, true><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, n_splits, K, ws.cap, ws.lists,
+                                                                                ws.counts, ws.overflow, 0, ws.overflow + 1, ws.blk_flag,
+                                                                                users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
+                                                                                item_offset, ws.unorm, qmax_bits, out_val, out_idx, seed_out);
+                MACR_CHECK_LAUNCH("select2", st);
+            } else {
             if (seeded) {
                 pass0r<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits,
                                                      item_offset, geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
@@ -2465,6 +2518,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             k_select<true><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow, 0,
                                                            ws.overflow + 1, ws.blk_flag, out_val, out_idx, seed_out);
             MACR_CHECK_LAUNCH("select2", st);
+            }
         }
     });
     // Fallback, armed by the overflow flag on the device (its blocks return at once otherwise): the running
