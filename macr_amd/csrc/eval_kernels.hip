@@ -429,6 +429,37 @@ inline size_t score_topk_smem_bytes() {
 // A operand in LDS as [item][h][t] (k = 2t+h), row stride D+4: a lane's whole k-row is contiguous
 // (ds_read_b128) and 16 lanes x 16 B cover all 64 banks once.
 // ----------------------------------------------------------------------------
+// ---- repair round: where the re-listed query blocks keep their lists ---------------------------------------------------
+// A query block spreads over as many blocks of the grid as it has result slots, and the workspace has slots_full of them
+// per user: listed again alone, a query block would keep ~1/slots_full of the grid busy for a whole pass.  The lists of
+// everybody else are dead by then (the first selection has read them), so the n_ub re-listed query blocks take the whole
+// buffer: compact user index (position in ub_map) * 256 + slot, stride n_ub * 256, and slots_full * U / (n_ub * 256)
+// (<= 64) slots each -- one re-listed query block of the Gowalla shape runs on 63 blocks of the grid instead of 8.
+// k_repair_plan stores position + 1 in blk_flag and clears the counts of that layout.
+struct RepairLayout { bool compact; int slots, stride; };
+__device__ __forceinline__ RepairLayout repair_layout(int slots_full, int U, int n_ub) {
+    RepairLayout r;
+    long long sl = (long long)slots_full * U / ((long long)n_ub * kUsersPerBlock);
+    if (sl > 64) sl = 64;
+    r.compact = sl > slots_full;
+    r.slots = r.compact ? (int)sl : slots_full;
+    r.stride = r.compact ? n_ub * kUsersPerBlock : U;
+    return r;
+}
+// blocks of the grid a repair round uses for n_ub query blocks of T visits each
+__device__ __forceinline__ long long repair_grid(const RepairLayout &r, long long grid, int ublocks, int n_ub, int T) {
+    long long G;
+    if (r.compact) {
+        long long chunk = (T + r.slots - 2) / (r.slots - 1);          // a query block then overlaps <= slots ranges
+        if (chunk < 8) chunk = 8;
+        G = (long long)n_ub * T / chunk;
+        if (G > grid) G = grid;
+    } else {
+        G = (long long)n_ub * grid / ublocks;                        // ranges as long as in the full launch
+    }
+    return G < 1 ? 1 : G;
+}
+
 constexpr int kModeMax = 0, kModeList = 1;
 // Pass 0 is a SAMPLE of the catalogue: one "virtual tile" per window of 2^s consecutive tiles, made of every 2^s-th
 // item of the window (items w*32*2^s + 2^s*j + phase, j = 0..31, phase = w % 2^s) -- a 1/2^s sample spread evenly
@@ -516,7 +547,8 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     const uint32_t *__restrict__ mask_bits, int item_offset,
     int ublocks, const float *__restrict__ tau, float *__restrict__ maxima, uint64_t *__restrict__ lists,
     int32_t *__restrict__ counts, int cap, int32_t *overflow, int ovf_per_user, int sample_log2,
-    const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev, int32_t *blk_flag, SweepArgs sw) {
+    const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev, int32_t *blk_flag, SweepArgs sw,
+    int slots_full) {
     using C = StreamCfg<D>;
     // Seeded first round (blk_flag != NULL): "these seeds are stale" is decided early.  2, 8 and 32 tiles into a user
     // block's range every wave compares what its 32 users have listed with what a usable threshold lists (a projected
@@ -551,11 +583,12 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     int n_ub = ublocks;
     long long G = gridDim.x;
     const long long b = blockIdx.x;
+    RepairLayout rl = {false, 0, U};
     if (REPAIR) {                                  // (an instantiation of its own: the profiler tells the rounds apart)
         n_ub = *n_ub_dev;
         if (n_ub == 0) return;
-        G = (long long)n_ub * G / ublocks;
-        if (G < 1) G = 1;
+        if (MODE == kModeList) rl = repair_layout(slots_full, U, n_ub);       // (the sampling pass keeps the layout of its maxima)
+        G = repair_grid(rl, G, ublocks, n_ub, T);
         if (b >= G) return;
     }
     // A block's range [i0, i1) of VISITED tiles is not a contiguous stretch of the catalogue: visit i is tile (i * S) mod T,
@@ -603,7 +636,9 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
     // listing test: score >= tau_s (NaN = never: padding users, poisoned scores)
     float tau_s = (MODE == kModeList && NC == 1 && q_ok) ? tau[q] : __builtin_nanf("");       // +inf once her list is full
-    uint64_t *my_list = lists + ((size_t)split * U + (q_ok ? q : 0)) * cap;
+    // (repair round, compact layout: the lists are indexed by the query block's position among the re-listed ones)
+    const int ql = (REPAIR && rl.compact) ? ubv * kUsersPerBlock + uslot : (q_ok ? q : 0);
+    uint64_t *my_list = lists + ((size_t)split * rl.stride + ql) * cap;
     float tau_g[NC], c_g[NC];                 // sweep: per-c threshold and constant (NC > 1)
     if (NC > 1) {
 #pragma unroll
@@ -814,7 +849,8 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
     } else if (tid < kUsersPerBlock) {
         const int qq = ub * kUsersPerBlock + tid;
         if (NC == 1) {
-            if (qq < U) counts[(size_t)split * U + qq] = (int32_t)min(s_cnt[tid], (uint32_t)cap);
+            const int ql2 = (REPAIR && rl.compact) ? ubv * kUsersPerBlock + tid : qq;
+            if (qq < U) counts[(size_t)split * rl.stride + ql2] = (int32_t)min(s_cnt[tid], (uint32_t)cap);
         } else {
 #pragma unroll
             for (int g = 0; g < NC; ++g)
@@ -964,7 +1000,7 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
     const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c_val, const float *__restrict__ c_dev,
     const uint32_t *__restrict__ mask_bits, int item_offset, int ublocks, const float *__restrict__ tau,
     uint64_t *__restrict__ lists, int32_t *__restrict__ counts, int cap, int32_t *overflow, int ovf_per_user,
-    int32_t *blk_flag, const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev) {
+    int32_t *blk_flag, const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev, int slots_full) {
     using C = StreamCfgB<D>;
     constexpr int UG = StreamGroupsB<D>::UG, THREADS = StreamGroupsB<D>::THREADS;
     constexpr int LDU = (C::UNITS + THREADS - 1) / THREADS;
@@ -985,11 +1021,12 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
     int n_ub = ublocks;
     long long G = gridDim.x;
     const long long b = blockIdx.x;
+    RepairLayout rl = {false, 0, U};
     if (REPAIR) {
         n_ub = *n_ub_dev;
         if (n_ub == 0) return;
-        G = (long long)n_ub * G / ublocks;
-        if (G < 1) G = 1;
+        rl = repair_layout(slots_full, U, n_ub);
+        G = repair_grid(rl, G, ublocks, n_ub, T);
         if (b >= G) return;
     }
     int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream (scattered tile ranges)
@@ -1046,7 +1083,7 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
         else if (KIND == MACR_SCORE_DIRECT_MINUS) { fx[g] = c; }
         else if (KIND == MACR_SCORE_DIRECT_MINUS_BOTH) { fx[g] = c * su[g]; }
         if (KIND == MACR_SCORE_RUBI_BOTH) wave_slow = wave_slow || __any(q_ok[g] && !(su[g] > 1e-30f));
-        my_list[g] = lists + ((size_t)split * U + (q_ok[g] ? q[g] : 0)) * cap;
+        my_list[g] = lists + ((size_t)split * rl.stride + ((REPAIR && rl.compact) ? ubv * kUsersPerBlock + uslot[g] : (q_ok[g] ? q[g] : 0))) * cap;
     }
 
     int vi = i0, t = visit(i0);
@@ -1190,7 +1227,8 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
     }
     for (int k = tid; k < kUsersPerBlock; k += THREADS) {
         const int qq = ub * kUsersPerBlock + k;
-        if (qq < U) counts[(size_t)split * U + qq] = (int32_t)min(s_cnt[k], (uint32_t)cap);
+        const int ql2 = (REPAIR && rl.compact) ? ubv * kUsersPerBlock + k : qq;
+        if (qq < U) counts[(size_t)split * rl.stride + ql2] = (int32_t)min(s_cnt[k], (uint32_t)cap);
     }
     }   // segments
 }
@@ -1225,7 +1263,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_b(
     if (REPAIR) {
         n_ub = *n_ub_dev;
         if (n_ub == 0) return;
-        G = (long long)n_ub * G / ublocks;
+        G = (long long)n_ub * G / ublocks;                     // (the maxima keep their layout: ranges as long as in the full launch)
         if (G < 1) G = 1;
         if (b >= G) return;
     }
@@ -1485,7 +1523,8 @@ template <int NREG>
 __device__ __forceinline__ void select_user(int q, int lane, int U, int n_splits, int n_out, int K, int cap, int n, int incl,
                                             const uint64_t *__restrict__ lists, uint64_t *s_top,
                                             float *__restrict__ out_val, int32_t *__restrict__ out_idx,
-                                            int32_t *__restrict__ seed_out) {
+                                            int32_t *__restrict__ seed_out, int ql, int Ul) {
+    // (ql, Ul): the query's index and the stride in the LISTS -- (q, U) except in the compact layout of a repair round
     // with seed_out the best kSeedWidth (>= K) candidates are ranked: the first K are the result, all of them the seeds
     // of the caller's next ranking (macr_score_topk seed_idx)
     const int Ksel = seed_out ? kSeedWidth : K;
@@ -1493,11 +1532,11 @@ __device__ __forceinline__ void select_user(int q, int lane, int U, int n_splits
     // first (uniform loop over the splits), then all loads are issued back to back
     size_t rel[NREG];
 #pragma unroll
-    for (int j = 0; j < NREG; ++j) rel[j] = (size_t)q * cap + (j * 64 + lane);
+    for (int j = 0; j < NREG; ++j) rel[j] = (size_t)ql * cap + (j * 64 + lane);
     for (int s = 1; s < n_splits; ++s) {
         const int off = __builtin_amdgcn_readlane(incl, s - 1);                // exclusive prefix of split s
         if (off >= n) break;
-        const size_t base = ((size_t)s * U + q) * cap - off;
+        const size_t base = ((size_t)s * Ul + ql) * cap - off;
 #pragma unroll
         for (int j = 0; j < NREG; ++j)
             if (j * 64 + lane >= off) rel[j] = base + (j * 64 + lane);
@@ -1581,7 +1620,8 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
     if (REPAIR && *run_if == 0) return;               // second selection: only after a repair round
     // ... and only for the user blocks that were listed again (skip_blk = blk_flag: 1 = in the repair round); the other
     // users' results stand -- after a bf16-filtered first round their lists hold bf16 scores, not ranking material
-    if (REPAIR && skip_blk && skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] == 0) return;
+    const int blk_pos = skip_blk ? skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] : 0;       // repair round: position + 1 in ub_map
+    if (REPAIR && skip_blk && blk_pos == 0) return;
     // first selection: a user block the listing pass gave up on (stale seeds) is ranked after the repair round only
     if (!REPAIR && skip_blk && skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] != 0) return;
     // wave-uniform values are made so explicitly (readfirstlane): the selection state then lives in SGPRs
@@ -1589,7 +1629,13 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
     const int q = blockIdx.x * kSelWaves + wid;
     if (q >= U) return;
     // list lengths of all splits at once (lane s <-> split s), exclusive prefix = offsets in the gathered order
-    const int my_c = lane < n_splits ? counts[(size_t)lane * U + q] : 0;
+    // where this query's lists are (repair_layout): as everywhere, or the compact layout of the re-listed query blocks
+    int ql = q, Ul = U, nsl = n_splits;
+    if (REPAIR && skip_blk) {
+        const RepairLayout rl = repair_layout(n_splits, U, *run_if);
+        if (rl.compact) { ql = (blk_pos - 1) * kUsersPerBlock + q % kUsersPerBlock; Ul = rl.stride; nsl = rl.slots; }
+    }
+    const int my_c = lane < nsl ? counts[(size_t)lane * Ul + ql] : 0;
     int incl = my_c;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, kWave); if (lane >= m) incl += o; }
@@ -1598,9 +1644,9 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
     if (n_all > kSelRegs * 64 && lane == 0) overflow[ovf_per_user ? q : 0] = 1;
     // the common case (a few hundred candidates) runs the 4-keys-per-lane instance: these kernels are bound by the
     // CU's scalar unit and by registers, both proportional to the register count
-    if (n <= 256) select_user<4>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
-    else if (n <= 512) select_user<8>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
-    else select_user<kSelRegs>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+    if (n <= 256) select_user<4>(q, lane, U, nsl, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out, ql, Ul);
+    else if (n <= 512) select_user<8>(q, lane, U, nsl, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out, ql, Ul);
+    else select_user<kSelRegs>(q, lane, U, nsl, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out, ql, Ul);
 }
 
 
@@ -1696,17 +1742,17 @@ __device__ __forceinline__ uint64_t exact_key(int q, int id, const float *__rest
 // A query whose 64 best bf16 scores do not settle the top (k_select_b): every listed candidate gets its exact key, in
 // place; the plain selection (select_user) then ranks the lists as if the fp32 listing pass had written them.
 template <int NREG, int D, int KIND>
-__device__ __forceinline__ void rescore_lists(int q, int lane, int U, int n_splits, int cap, int n, int incl, uint64_t *lists,
+__device__ __forceinline__ void rescore_lists(int q, int ql, int lane, int U, int n_splits, int cap, int n, int incl, uint64_t *lists,
                                               const float *__restrict__ users_tab, const int32_t *__restrict__ user_ids,
                                               const float *__restrict__ items, const float *__restrict__ sig_u,
                                               const float *__restrict__ sig_i, float c, int item_offset) {
     size_t rel[NREG];
 #pragma unroll
-    for (int j = 0; j < NREG; ++j) rel[j] = (size_t)q * cap + (j * 64 + lane);
+    for (int j = 0; j < NREG; ++j) rel[j] = (size_t)ql * cap + (j * 64 + lane);     // (ql, U: index and stride in the lists)
     for (int s = 1; s < n_splits; ++s) {
         const int off = __builtin_amdgcn_readlane(incl, s - 1);
         if (off >= n) break;
-        const size_t base = ((size_t)s * U + q) * cap - off;
+        const size_t base = ((size_t)s * U + ql) * cap - off;
 #pragma unroll
         for (int j = 0; j < NREG; ++j)
             if (j * 64 + lane >= off) rel[j] = base + (j * 64 + lane);
@@ -1739,12 +1785,18 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
     // first selection: not the user blocks the listing pass gave up on; second one (REPAIR): only after a repair round,
     // and only the user blocks that were listed again (k_select)
     if (REPAIR && *run_if == 0) return;
-    if (skip_blk && (skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] != 0) != REPAIR) return;
+    const int blk_pos = skip_blk ? skip_blk[(blockIdx.x * kSelWaves) / kUsersPerBlock] : 0;       // repair round: position + 1 in ub_map
+    if (skip_blk && (blk_pos != 0) != REPAIR) return;
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x * kSelWaves + wid;
     if (q >= U) return;
     const float c = c_dev ? *c_dev : c_val;
-    const int my_c = lane < n_splits ? counts[(size_t)lane * U + q] : 0;
+    int ql = q, Ul = U, nsl = n_splits;               // where this query's lists are (repair_layout)
+    if (REPAIR && skip_blk) {
+        const RepairLayout rl = repair_layout(n_splits, U, *run_if);
+        if (rl.compact) { ql = (blk_pos - 1) * kUsersPerBlock + q % kUsersPerBlock; Ul = rl.stride; nsl = rl.slots; }
+    }
+    const int my_c = lane < nsl ? counts[(size_t)lane * Ul + ql] : 0;
     int incl = my_c;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, kWave); if (lane >= m) incl += o; }
@@ -1752,9 +1804,9 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
     const int n = n_all < kSelRegs * 64 ? n_all : kSelRegs * 64;
     bool flag = n_all > kSelRegs * 64;
     uint64_t ka;
-    if (n <= 256) ka = gather_top64<4>(q, lane, U, n_splits, cap, n, incl, lists, s_top[wid]);
-    else if (n <= 512) ka = gather_top64<8>(q, lane, U, n_splits, cap, n, incl, lists, s_top[wid]);
-    else ka = gather_top64<kSelRegs>(q, lane, U, n_splits, cap, n, incl, lists, s_top[wid]);
+    if (n <= 256) ka = gather_top64<4>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid]);
+    else if (n <= 512) ka = gather_top64<8>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid]);
+    else ka = gather_top64<kSelRegs>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid]);
     // no item outside these 64 may belong to the exact top R (R = K, or the seed width when seeds are written)
     const int R = seed_out ? kSeedWidth : K;
     const uint32_t hi_r = __shfl((uint32_t)(ka >> 32), R - 1, kWave), hi_last = __shfl((uint32_t)(ka >> 32), 63, kWave);
@@ -1766,14 +1818,14 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
         // more than 64 candidates inside two margins of the R-th (a flat top: scores that differ in the fifth digit):
         // every listed candidate is scored exactly and the plain selection ranks them -- a few queries per evaluation
         if (n <= 256) {
-            rescore_lists<4, D, KIND>(q, lane, U, n_splits, cap, n, incl, lists, users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
-            select_user<4>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+            rescore_lists<4, D, KIND>(q, ql, lane, Ul, nsl, cap, n, incl, lists, users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
+            select_user<4>(q, lane, U, nsl, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out, ql, Ul);
         } else if (n <= 512) {
-            rescore_lists<8, D, KIND>(q, lane, U, n_splits, cap, n, incl, lists, users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
-            select_user<8>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+            rescore_lists<8, D, KIND>(q, ql, lane, Ul, nsl, cap, n, incl, lists, users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
+            select_user<8>(q, lane, U, nsl, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out, ql, Ul);
         } else {
-            rescore_lists<kSelRegs, D, KIND>(q, lane, U, n_splits, cap, n, incl, lists, users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
-            select_user<kSelRegs>(q, lane, U, n_splits, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out);
+            rescore_lists<kSelRegs, D, KIND>(q, ql, lane, Ul, nsl, cap, n, incl, lists, users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
+            select_user<kSelRegs>(q, lane, U, nsl, n_out, K, cap, n, incl, lists, s_top[wid], out_val, out_idx, seed_out, ql, Ul);
         }
         return;
     }
@@ -1810,15 +1862,31 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
 __global__ __launch_bounds__(kUsersPerBlock) void k_repair_plan(int U, int K, int n_slots, const int32_t *__restrict__ user_ovf,
                                                                 const float *__restrict__ out_val, float *__restrict__ tau,
                                                                 int32_t *__restrict__ counts, int32_t *__restrict__ ub_map,
-                                                                int32_t *__restrict__ blk_flag, int32_t *n_ub) {
+                                                                int32_t *__restrict__ blk_flag, int32_t *n_ub, int32_t *n_done) {
     const int ub = blockIdx.x, q = ub * kUsersPerBlock + threadIdx.x;
     const bool stopped = blk_flag[ub] != 0;               // the listing pass gave up on this user block (stale seeds)
     const bool f = q < U && (user_ovf[q] != 0 || stopped);
     if (f && !stopped) tau[q] = fmaxf(tau[q], out_val[(size_t)q * K + (K - 1)]);      // (a stopped block was not ranked)
-    if (!__syncthreads_or(f)) return;
-    if (q < U)
-        for (int sl = 0; sl < n_slots; ++sl) counts[(size_t)sl * U + q] = 0;
-    if (threadIdx.x == 0) { ub_map[atomicAdd(n_ub, 1)] = ub; blk_flag[ub] = 1; }
+    const bool any = __syncthreads_or(f) != 0;
+    if (any) {
+        if (q < U)
+            for (int sl = 0; sl < n_slots; ++sl) counts[(size_t)sl * U + q] = 0;
+        // blk_flag: position among the re-listed query blocks + 1 (the compact list layout of the repair round, repair_layout)
+        if (threadIdx.x == 0) { const int pos = atomicAdd(n_ub, 1); ub_map[pos] = ub; blk_flag[ub] = pos + 1; }
+    }
+    // the last block to get here knows how many query blocks are listed again: if they take the compact layout, its
+    // counts (which overlay other queries' counts, all read by now) start at zero
+    __shared__ int s_last;
+    __threadfence();
+    if (threadIdx.x == 0) s_last = atomicAdd(n_done, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    const int n = __hip_atomic_load(n_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == 0) return;
+    const RepairLayout rl = repair_layout(n_slots, U, n);
+    if (!rl.compact) return;
+    const size_t words = (size_t)rl.slots * rl.stride;
+    for (size_t k = threadIdx.x; k < words; k += kUsersPerBlock) counts[k] = 0;
 }
 
 // ----------------------------------------------------------------------------
@@ -2435,7 +2503,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             // unmasked item and the selection kernel ranks them -- no sampling pass, no k_tau)
             pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
                                                 geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, 0,
-                                                sample_log2(n_local), nullptr, nullptr, nullptr, SweepArgs{});
+                                                sample_log2(n_local), nullptr, nullptr, nullptr, SweepArgs{}, 0);
             MACR_CHECK_LAUNCH("score_sample", st);
             launch_tau(false);
             MACR_CHECK_LAUNCH("tau", st);
@@ -2453,7 +2521,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             pass1b<<<geo.grid1, StreamGroupsB<D>::THREADS, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev,
                                                    mask_bits, item_offset, geo.ublocks, ws.tau, ws.lists, ws.counts, ws.cap,
                                                    repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
-                                                   seeded ? ws.blk_flag : nullptr, nullptr, nullptr);
+                                                   seeded ? ws.blk_flag : nullptr, nullptr, nullptr, 0);
             MACR_CHECK_LAUNCH("score_stream_b", st);
             k_select_b<D, KIND><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts,
                                                                       repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, nullptr,
@@ -2465,7 +2533,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
                                             geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
                                             repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, 0, nullptr, nullptr,
-                                            seeded ? ws.blk_flag : nullptr, SweepArgs{});
+                                            seeded ? ws.blk_flag : nullptr, SweepArgs{}, 0);
         MACR_CHECK_LAUNCH("score_stream", st);
         k_select<false><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts,
                                                               repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, nullptr,
@@ -2474,7 +2542,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         }
         if (repair) {
             k_repair_plan<<<geo.ublocks, kUsersPerBlock, 0, st>>>(U, K, geo.slots1, ws.user_ovf, out_val, ws.tau, ws.counts,
-                                                                 ws.ub_map, ws.blk_flag, ws.overflow + 1);
+                                                                 ws.ub_map, ws.blk_flag, ws.overflow + 1, ws.overflow + 2);
             MACR_CHECK_LAUNCH("repair_plan", st);
             if (filter_bf16) {
                 // the repair round on the bf16 copies too: sampling pass for the re-listed user blocks when the thresholds
@@ -2495,7 +2563,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
                 pass1rb<<<geo.grid1, StreamGroupsB<D>::THREADS, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u,
                                                                             sig_i, c, c_dev, mask_bits, item_offset, geo.ublocks, ws.tau,
                                                                             ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
-                                                                            ws.ub_map, ws.overflow + 1);
+                                                                            ws.ub_map, ws.overflow + 1, geo.slots1);
                 MACR_CHECK_LAUNCH("score_stream2", st);
                 k_select_b<D, KIND, true><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, n_splits, K, ws.cap, ws.lists,
                                                                                 ws.counts, ws.overflow, 0, ws.overflow + 1, ws.blk_flag,
@@ -2506,14 +2574,14 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             if (seeded) {
                 pass0r<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits,
                                                      item_offset, geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap,
-                                                     ws.overflow, 0, sample_log2(n_local), ws.ub_map, ws.overflow + 1, nullptr, SweepArgs{});
+                                                     ws.overflow, 0, sample_log2(n_local), ws.ub_map, ws.overflow + 1, nullptr, SweepArgs{}, 0);
                 MACR_CHECK_LAUNCH("score_sample2", st);
                 launch_tau(true);
                 MACR_CHECK_LAUNCH("tau2", st);
             }
             pass1r<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
                                                  geo.ublocks, ws.tau, ws.maxima, ws.lists, ws.counts, ws.cap, ws.overflow, 0, 0,
-                                                 ws.ub_map, ws.overflow + 1, nullptr, SweepArgs{});
+                                                 ws.ub_map, ws.overflow + 1, nullptr, SweepArgs{}, geo.slots1);
             MACR_CHECK_LAUNCH("score_stream2", st);
             k_select<true><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts, ws.overflow, 0,
                                                            ws.overflow + 1, ws.blk_flag, out_val, out_idx, seed_out);
@@ -2594,7 +2662,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
             if (list_all) continue;
             pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev + g, mask_bits_in,
                                                 item_offset, geo.ublocks, ws[g].tau, ws[g].maxima, ws[g].lists, ws[g].counts,
-                                                ws[g].cap, ws[g].overflow, 0, sample_log2(n_local), nullptr, nullptr, nullptr, SweepArgs{});
+                                                ws[g].cap, ws[g].overflow, 0, sample_log2(n_local), nullptr, nullptr, nullptr, SweepArgs{}, 0);
             MACR_CHECK_LAUNCH("score_sample", st);
             const int tau_regs = (geo.slots0 * 32 + 63) / 64;
             launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws[g].maxima, nullptr, ws[g].tau);
@@ -2603,7 +2671,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
         // ONE listing pass for all n_c values
         pass1<<<geo.grid1, 512, smem1, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev, mask_bits_in,
                                              item_offset, geo.ublocks, ws[0].tau, ws[0].maxima, ws[0].lists, ws[0].counts,
-                                             ws[0].cap, ws[0].overflow, 0, sample_log2(n_local), nullptr, nullptr, nullptr, sw);
+                                             ws[0].cap, ws[0].overflow, 0, sample_log2(n_local), nullptr, nullptr, nullptr, sw, 0);
         MACR_CHECK_LAUNCH("score_stream", st);
         for (int g = 0; g < n_c; ++g) {
             k_select<false><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, 1, K, ws[g].cap, ws[g].lists, ws[g].counts, ws[g].overflow,

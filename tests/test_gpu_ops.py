@@ -988,3 +988,37 @@ def test_bf16_filter_scores_a_crowded_top_exactly(ops):
                 assert stats.cpu().numpy().tolist() == [0, 0], (filt, stats.cpu().numpy())
     finally:
         ops.set_eval_filter("env")
+
+
+@pytest.mark.parametrize("bad_blocks", [(0,), (1, 3), (0, 1, 2, 3, 4)])
+def test_repair_round_of_a_few_query_blocks(ops, eval_filter, bad_blocks):
+    """Seeds that are useless for SOME blocks of 256 queries (random item ids) and fresh for the others: the repair round
+    lists the bad blocks again -- in the compact list layout when they are few (their lists take the whole buffer, more
+    result slots per query block, more of the grid) -- and must return the oracle's ranking for everybody, the untouched
+    blocks included; stats[0] = the number of re-listed blocks."""
+    rs = np.random.RandomState(123)
+    U, N, d, K = 5 * 256 - 40, 9000, 64, 20
+    P = (rs.standard_normal((U, d)) * 0.5).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.5).astype(np.float32)
+    Q += (rs.standard_normal(N).astype(np.float32) * 0.5)[:, None] * np.sign(P.mean(0, keepdims=True))
+    mask = random_mask(rs, U, N, 10)
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    wv, wi, _ = oracle.score_topk(oracle.SCORE_NORMAL, P, Q, K, mask=oracle.csr_from_lists(mask))
+    seeds = torch.full((U, ops.SEED_WIDTH), -1, dtype=torch.int32, device="cuda")
+    stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(Q), K, mask=mcsr, seed_out=seeds)
+    bad = seeds.clone()
+    for b in bad_blocks:      # the lowest-scoring items as seeds: thresholds far too loose, lists overflow
+        lo, hi = b * 256, min(U, (b + 1) * 256)
+        worst = np.argsort((P[lo:hi] @ Q.T), axis=1)[:, :ops.SEED_WIDTH].astype(np.int32)
+        bad[lo:hi] = dev(worst)
+    v, ix = ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(Q), K, mask=mcsr, seed=bad, seed_out=bad, stats=stats)
+    val, idx, _ = ops.topk_merge(v, ix)
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    assert np.array_equal(val.cpu().numpy().view(np.uint32), wv.view(np.uint32))
+    assert stats.cpu().numpy().tolist() == [len(bad_blocks), 0]
+    # ... and the seeds it left are good again: a ranking from them needs no repair
+    v, ix = ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(Q), K, mask=mcsr, seed=bad, seed_out=bad, stats=stats)
+    val, idx, _ = ops.topk_merge(v, ix)
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    assert stats.cpu().numpy().tolist() == [0, 0]
