@@ -25,8 +25,8 @@ ops.timing_begin(); ev.test_mf(ops.SCORE_RUBI_BOTH, P, uid, Q, [20], w, wu, 40.0
 marks = {}
 for n, ms in ops.timing_end():
     marks[n] = marks.get(n, 0.0) + ms * 1e3
-stream = marks.get("score_stream", float("nan"))
+stream = marks.get("score_stream_b", marks.get("score_stream", float("nan")))      # bf16 candidate filter (default) / fp32
 print(json.dumps({"workload": "configs[4] shard: %d query users x %d items, d=%d, K=20, c=40" % (len(users), cfg["n_items"], d),
                   "eval_ms": dt * 1e3, "users_per_s": len(users) / dt, "flops": fl, "achieved_tflops": fl / dt / 1e12,
                   "frac_of_fp32_mfma_peak": fl / dt / 157.3e12, "listing_pass_us": stream,
-                  "listing_pass_frac": fl / (stream * 1e-6) / 157.3e12, "kernels_us": {k: round(v, 1) for k, v in marks.items()}}))
+                  "filter": ev.filter, "listing_pass_frac_of_fp32_mfma_peak": fl / (stream * 1e-6) / 157.3e12, "kernels_us": {k: round(v, 1) for k, v in marks.items()}}))
