@@ -893,8 +893,8 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 //   * the pass lists every item with score_bf16 >= tau_u - margin_u (tau_u a valid fp32 threshold: >= K unmasked items
 //     score >= tau_u), i.e. every item whose fp32 score is >= tau_u;
 //   * k_select_b takes the 64 best listed items by bf16 score, checks that the 64th lies more than 2 margin_u below the
-//     K-th (32nd with seeds) -- then no item outside the 64 can belong to the exact top K -- computes the fp32 score of
-//     those 64 with the k-ascending fmaf chain and the exact epilogue of every other kernel here, and ranks them.
+//     K-th -- then no item outside the 64 can belong to the exact top K -- computes the fp32 score of those within
+//     2 margin_u of the K-th with the k-ascending fmaf chain and the exact epilogue of every other kernel here, and ranks them.
 //     A user for whom the check fails (dozens of scores inside a margin) is flagged like a user whose list overflowed:
 //     the repair round lists her user block again with the fp32 kernels.
 // The result is the fp32 ranking, bit for bit; tests compare both filters with the oracle.
@@ -1807,8 +1807,8 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
     if (n <= 256) ka = gather_top64<4>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid]);
     else if (n <= 512) ka = gather_top64<8>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid]);
     else ka = gather_top64<kSelRegs>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid]);
-    // no item outside these 64 may belong to the exact top R (R = K, or the seed width when seeds are written)
-    const int R = seed_out ? kSeedWidth : K;
+    // no item outside these 64 may belong to the exact top K
+    const int R = K;
     const uint32_t hi_r = __shfl((uint32_t)(ka >> 32), R - 1, kWave), hi_last = __shfl((uint32_t)(ka >> 32), 63, kWave);
     const float m2 = 2.02f * filter_margin(unorm[q], __uint_as_float(*qmax_bits), c);
     // (hi_r == 0: fewer than R candidates -- all of them matter)
@@ -1829,9 +1829,11 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
         }
         return;
     }
-    // exact scores of the candidates that can still belong to the top R (bf16 score within two margins of the R-th): the
-    // arithmetic of k_tau_seed / the fp32 listing pass
-    uint64_t ke = 0ull;
+    // exact scores of the candidates that can still belong to the top K (bf16 score within two margins of the K-th): the
+    // arithmetic of k_tau_seed / the fp32 listing pass.  The others keep their bf16 key: each of them lies below every one
+    // of the exact top K (its bf16 score + margin < K-th bf16 score - margin <= the K-th best exact score), so the first K
+    // of the sorted keys are the exact ranking, and what follows only serves as seeds (any good candidates do).
+    uint64_t ke = ka;
     if (ka && key_score(ka) >= a_cut) ke = exact_key<D, KIND>(q, key_id(ka), users_tab, user_ids, items, sig_u, sig_i, c, item_offset);
     ke = wave_sort_desc(ke);
     if (lane < K) {
