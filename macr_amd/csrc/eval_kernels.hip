@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
 // score, the margin check, their exact fp32 scores, the ranking.  One wave per user.
 template <int NREG>
 __device__ __forceinline__ uint64_t gather_top64(int q, int lane, int U, int n_splits, int cap, int n, int incl,
-                                                 const uint64_t *__restrict__ lists, uint64_t *s_top) {
+                                                 const uint64_t *__restrict__ lists, uint64_t *s_top, bool sorted = true) {
     size_t rel[NREG];
 #pragma unroll
     for (int j = 0; j < NREG; ++j) rel[j] = (size_t)q * cap + (j * 64 + lane);
@@ -1718,7 +1718,7 @@ __device__ __forceinline__ uint64_t gather_top64(int q, int lane, int U, int n_s
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint64_t k1 = lane < base ? s_top[lane] : 0ull;
-    return wave_sort_desc(k1);                                      // lane i: the (i+1)-th best candidate by bf16 score (0 = none)
+    return sorted ? wave_sort_desc(k1) : k1;                        // sorted: lane i = the (i+1)-th best candidate by bf16 score (0 = none)
 }
 
 // exact fp32 score of (query q, item id): the k-ascending fmaf chain and the epilogue of every other kernel here
@@ -1804,6 +1804,24 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
     const int n = n_all < kSelRegs * 64 ? n_all : kSelRegs * 64;
     bool flag = n_all > kSelRegs * 64;
     uint64_t ka;
+    if (n <= 64) {
+        // at most 64 candidates (the usual case with seeded thresholds): all of them are scored exactly and sorted once
+        // -- the bf16 order (a 64-lane bitonic sort) and the margin test would cost more than the extra fp32 scores
+        ka = gather_top64<4>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid], false);
+        if (flag && lane == 0) overflow[ovf_per_user ? q : 0] = 1;
+        uint64_t ke = ka ? exact_key<D, KIND>(q, key_id(ka), users_tab, user_ids, items, sig_u, sig_i, c, item_offset) : 0ull;
+        ke = wave_sort_desc(ke);
+        if (lane < K) {
+            out_val[(size_t)q * K + lane] = ke ? key_score(ke) : -INFINITY;
+            out_idx[(size_t)q * K + lane] = ke ? key_id(ke) : -1;
+            for (int s = 1; s < n_out; ++s) {
+                out_val[((size_t)s * U + q) * K + lane] = -INFINITY;
+                out_idx[((size_t)s * U + q) * K + lane] = -1;
+            }
+        }
+        if (seed_out && lane < kSeedWidth) seed_out[(size_t)q * kSeedWidth + lane] = ke ? key_id(ke) : -1;
+        return;
+    }
     if (n <= 256) ka = gather_top64<4>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid]);
     else if (n <= 512) ka = gather_top64<8>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid]);
     else ka = gather_top64<kSelRegs>(ql, lane, Ul, nsl, cap, n, incl, lists, s_top[wid]);
