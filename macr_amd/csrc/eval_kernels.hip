@@ -916,47 +916,61 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {          // round t
 
 // Rows of the item table (shard) and the query users' rows -> bf16 copies; |u| per query user; max |q| over the items
 // (atomicMax on the float's bits: norms are >= 0).  One 8-lane group per 64 columns... one lane converts 8 columns.
+constexpr int kPrepTrips = 8;
 template <int D>
 __global__ __launch_bounds__(256) void k_bf16_prep(int U, int n_local, const float *__restrict__ users_tab,
                                                    const int32_t *__restrict__ user_ids, const float *__restrict__ items,
                                                    uint4 *__restrict__ users_bf, uint4 *__restrict__ items_bf,
                                                    float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
-    constexpr int LPRB = D / 8, RPB = 256 / LPRB;            // lanes per row, rows per block
+    constexpr int LPRB = D / 8, RPB = 256 / LPRB;            // lanes per row, rows per block and trip
     __shared__ float s_max[4];
     const int sub = threadIdx.x % LPRB, slot = threadIdx.x / LPRB;
-    const long long row = (long long)blockIdx.x * RPB + slot;
-    const bool is_item = row < n_local;
-    const long long q = row - n_local;
-    float sq = 0.f;
-    if (is_item || q < U) {
-        const float *src = is_item ? items + (size_t)row * D : users_tab + (size_t)(user_ids ? user_ids[q] : q) * D;
-        const float4 a = ld4(src + 8 * sub), b = ld4(src + 8 * sub + 4);
-        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        uint32_t hi[8], lo[8];
+    // kPrepTrips rows per lane group, all loads first: an eighth of the blocks -- and of the atomics on the one maximum,
+    // which were most of this kernel's time with a block per 32 rows
+    float4 a[kPrepTrips], b[kPrepTrips];
+    const float *src[kPrepTrips];
+    long long row[kPrepTrips];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            hi[k] = bf16_rne_bits(x[k]);
-            lo[k] = bf16_rne_bits(x[k] - __uint_as_float(hi[k] << 16));       // (x - hi is exact in fp32)
-        }
-        // row layout: hi[D] then lo[D]
-        uint4 *dst = is_item ? items_bf + (size_t)row * 2 * LPRB : users_bf + (size_t)q * 2 * LPRB;
-        dst[sub] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
-        dst[LPRB + sub] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
-        sq = dot4(a, a) + dot4(b, b);
+    for (int t = 0; t < kPrepTrips; ++t) {
+        row[t] = ((long long)blockIdx.x * kPrepTrips + t) * RPB + slot;
+        const bool is_item = row[t] < n_local;
+        const long long q = row[t] - n_local;
+        src[t] = is_item ? items + (size_t)row[t] * D : users_tab + (size_t)((q < U) ? (user_ids ? user_ids[q] : q) : 0) * D;
     }
-    sq = group_sum<LPRB>(sq);
-    float nrm = sqrtf(sq) * 1.0001f;                          // (rounded up: the margin must not be short)
-    if (!(nrm == nrm)) nrm = INFINITY;                        // a NaN row: margin +inf, everything of that user is listed / re-scored
-    if (!is_item && q < U && sub == 0) unorm[q] = nrm;
-    float m = is_item ? nrm : 0.f;
+#pragma unroll
+    for (int t = 0; t < kPrepTrips; ++t) { a[t] = ld4(src[t] + 8 * sub); b[t] = ld4(src[t] + 8 * sub + 4); }
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < kPrepTrips; ++t) {
+        const bool is_item = row[t] < n_local;
+        const long long q = row[t] - n_local;
+        float sq = 0.f;
+        if (is_item || q < U) {
+            const float x[8] = {a[t].x, a[t].y, a[t].z, a[t].w, b[t].x, b[t].y, b[t].z, b[t].w};
+            uint32_t hi[8], lo[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                hi[k] = bf16_rne_bits(x[k]);
+                lo[k] = bf16_rne_bits(x[k] - __uint_as_float(hi[k] << 16));       // (x - hi is exact in fp32)
+            }
+            // row layout: hi[D] then lo[D]
+            uint4 *dst = is_item ? items_bf + (size_t)row[t] * 2 * LPRB : users_bf + (size_t)q * 2 * LPRB;
+            dst[sub] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+            dst[LPRB + sub] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+            sq = dot4(a[t], a[t]) + dot4(b[t], b[t]);
+        }
+        sq = group_sum<LPRB>(sq);
+        float nrm = sqrtf(sq) * 1.0001f;                      // (rounded up: the margin must not be short)
+        if (!(nrm == nrm)) nrm = INFINITY;                    // a NaN row: margin +inf, everything of that user is listed / re-scored
+        if (!is_item && q < U && sub == 0) unorm[q] = nrm;
+        if (is_item) m = fmaxf(m, nrm);
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-        // (most blocks find the running maximum at or above theirs and skip the atomic: ~1700 of them on one address
-        // were a third of this kernel's time)
         if (m > __uint_as_float(__hip_atomic_load(qmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
             atomicMax(qmax_bits, __float_as_uint(m));
     }
@@ -2499,7 +2513,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws.overflow + 8);
         if (filter_bf16) {
             // operand copies (two bf16 per value), |u| per query, max |q|: for the sampling and the listing pass
-            k_bf16_prep<D><<<(unsigned)(((size_t)n_local + U + 256 / (D / 8) - 1) / (256 / (D / 8))), 256, 0, st>>>(
+            k_bf16_prep<D><<<(unsigned)(((size_t)n_local + U + kPrepTrips * (256 / (D / 8)) - 1) / (kPrepTrips * (256 / (D / 8)))), 256, 0, st>>>(
                 U, n_local, users_tab, user_ids, items, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits);
             MACR_CHECK_LAUNCH("bf16_prep", st);
         }
