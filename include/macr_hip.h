@@ -320,23 +320,26 @@ int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, con
  *              by ascending id, unused slots (-inf, -1).  Feed to macr_topk_merge
  *              (with the other shards' lists on several GPUs).
  *   workspace (dev) >= macr_score_topk_workspace_bytes(U, n_local, d) bytes, 256-B
- *              aligned: per-query thresholds, the (item tile, query) mask bitmap and the
- *              per-(split,query) candidate lists of the fixed-threshold stream (512 or
- *              1024 keys of 8 bytes each).  Contents need not be initialised or preserved.
+ *              aligned: per-query thresholds, the (item tile, query) mask bitmap, the
+ *              per-(slot,query) candidate lists of the fixed-threshold stream (512 or
+ *              1024 keys of 8 bytes each) and the two-term bf16 copies of the operands (as
+ *              many bytes as the fp32 rows: the bf16 candidate filter, below).  Contents
+ *              need not be initialised or preserved.
  * Score: NORMAL e_u.e_i ; RUBI_BOTH ((e_u.e_i - c) * sig_i) * sig_u ; RUBI,
  * DIRECT_MINUS, DIRECT_MINUS_BOTH as listed at the MACR_SCORE_* constants (every
  * operation rounds on its own, in the order of the reference's expression), the dot
  * product being a k-ascending fp32 fma chain (gfx950 fp32 MFMA arithmetic).
  * sig_i is needed by every kind but NORMAL, sig_u by RUBI_BOTH and DIRECT_MINUS_BOTH.
  * d in {32,64,128,256}; 1 <= K <= MACR_MAX_TOPK.
- * Launches (without seeds): a sampling pass over every 8th item tile (per-query lower bound tau of
+ * Launches (without seeds): a sampling pass over every 8th item (per-query lower bound tau of
  * the K-th best score), the listing pass over all tiles (items scoring >= tau go to
  * per-query candidate lists), a selection kernel (exact top K of each list); then the
  * REPAIR round for queries whose list overflowed (threshold too loose): their K-th listed
  * score becomes their threshold and the listing pass + selection run again for the blocks
- * of 128 queries that hold them (three launches that return at once when nothing
- * overflowed); and a fallback launch of the running-top-K kernel whose blocks return at
- * once unless a list overflowed again (exact for any input).  With seeds: one kernel
+ * of 256 queries that hold them, which then share the whole list buffer (launches that
+ * return at once when nothing overflowed); and a fallback launch of the running-top-K
+ * kernel whose blocks return at once unless a list overflowed again (exact for any input).
+ * With seeds: one kernel
  * (k_tau_seed) instead of the sampling pass and its selection, and a listing pass that gives a
  * block of queries up to the repair round as soon as its lists grow faster than a usable
  * threshold allows (stale seeds).  No host synchronisation.
@@ -350,10 +353,10 @@ size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
  *   MACR_EVAL_FILTER_F32   the (U, N) product on the fp32 matrix cores; a listed score is the final score.
  *   MACR_EVAL_FILTER_BF16  the product on two-term bf16 splits of the operands (hi*hi + hi*lo + lo*hi: 5x fewer
  *                          matrix-core cycles), every score compared with the query's threshold LESS a rigorous bound of
- *                          the error (1e-4 |u| max|q| + roundings); the
- *                          selection re-computes the fp32 score of each query's 64 best candidates and ranks those,
- *                          after checking that nothing else can belong to the top K; a query that fails the check goes
- *                          through the fp32 repair round.
+ *                          the error (1e-4 |u| max|q| + roundings), in the sampling pass, the listing pass and the
+ *                          repair round; the selection takes each query's 64 best candidates by bf16 score, checks that
+ *                          nothing else can belong to the top K, re-computes the fp32 score of those that can and ranks
+ *                          them; a query that fails the check has all its listed candidates re-scored in fp32.
  *   MACR_EVAL_FILTER_ENV   (default) follow MACR_EVAL_FILTER=f32|bf16 in the environment, f32 when unset.
  * Process-wide; not meant to be flipped while rankings are in flight on other threads. */
 #define MACR_EVAL_FILTER_ENV  0
