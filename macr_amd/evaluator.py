@@ -285,7 +285,11 @@ class Evaluator(object):
         in a device array the kernels read at run time); item-sharded runs evaluate c by c."""
         from . import _lib
         cs = [float(c) for c in cs]
-        if sharding.world()[1] > 1 or kind == ops.SCORE_NORMAL or self.n_queries > self.max_queries_per_pass:
+        # The shared-listing-pass kernel multiplies in fp32 only.  With the bf16 candidate filter one value at a time is as
+        # fast or faster on larger catalogues (tools/bench_sweep.py, per value: Gowalla shape 0.43 ms against 0.48 for the
+        # four-c sweep; ML-10M shape 0.22 against 0.20): those go c by c through the seeded, graph-replayed evaluation.
+        one_by_one = self.filter == "bf16" and items_tab.shape[0] >= 16384
+        if one_by_one or sharding.world()[1] > 1 or kind == ops.SCORE_NORMAL or self.n_queries > self.max_queries_per_pass:
             return torch.stack([self._means(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c).clone() for c in cs])
         outs = []
         for a in range(0, len(cs), _lib.MAX_SWEEP):
