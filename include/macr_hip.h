@@ -385,7 +385,9 @@ int macr_score_topk(int score_kind, int U, int n_local, int d,
  *              macr_score_topk writes them (one list per value: n_splits = 1)
  *   workspace >= macr_score_topk_sweep_workspace_bytes(U, n_local, d, n_c), 256-B aligned
  * score_kind: any kind that uses c (not MACR_SCORE_NORMAL).  Results per value are
- * identical to macr_score_topk with that c.
+ * identical to macr_score_topk with that c.  Follows the candidate filter (macr_set_eval_filter):
+ * with the bf16 filter the shared listing pass, the sampling passes and the selections are the
+ * bf16 kernels.
  * -------------------------------------------------------------------------*/
 #define MACR_MAX_SWEEP 4
 size_t macr_score_topk_sweep_workspace_bytes(int U, int n_local, int d, int n_c);

@@ -1247,6 +1247,190 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
     }   // segments
 }
 
+// The listing pass of k_score_stream_b for up to kMaxSweep values of c at once (macr_score_topk_sweep under the bf16
+// filter): one staging of the item tiles, one set of MFMAs and one barrier per tile serve every value; per (score, c)
+// there remain the test on the raw product and, for the hits, the epilogue and the append into that c's lists.
+template <int D, int KIND>
+__global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_bs(
+    int U, int n_local, const uint4 *__restrict__ users_bf, const uint4 *__restrict__ items_bf,
+    const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
+    const float *__restrict__ sig_u, const float *__restrict__ sig_i, const float *__restrict__ c_dev,
+    const uint32_t *__restrict__ mask_bits, int item_offset, int ublocks, int cap, SweepArgs sw) {
+    using C = StreamCfgB<D>;
+    constexpr int NC = kMaxSweep, LDU = (C::UNITS + 511) / 512;
+    constexpr int RSB = C::RSB, NS = C::NS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __bf16 *s_a = reinterpret_cast<__bf16 *>(smem);                                   // [2][32][RSB]
+    float *s_sig = reinterpret_cast<float *>(smem + (size_t)2 * kTileItems * RSB * 2);  // [2][32]
+    float *s_y = s_sig + 2 * kTileItems;                                               // [2][32]  filter_y(sig_i)
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_y + 2 * kTileItems);            // [NC][256]
+    int *s_slow = reinterpret_cast<int *>(s_cnt + NC * kUsersPerBlock);               // [2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int uslot = wid * 32 + col;
+    const int T = (n_local + kTileItems - 1) / kTileItems;
+    const long long G = gridDim.x, b = blockIdx.x;
+    int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream
+    S = S < 1 ? 1 : S;
+    for (;; ++S) {
+        int x = S, y = T;
+        while (y) { const int r = x % y; x = y; y = r; }
+        if (x == 1) break;
+    }
+    auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T); };
+    auto visit_after = [&](int tile) { const int n = tile + S; return n >= T ? n - T : n; };
+    const float qmax = __uint_as_float(*qmax_bits);
+    const long long W = (long long)ublocks * T;
+    const long long w_end = W * (b + 1) / G;
+    for (long long w = W * b / G; w < w_end;) {
+    const int ub = (int)(w / T), i0 = (int)(w - (long long)ub * T);
+    const int i1 = (int)min((long long)T, i0 + (w_end - w));
+    w += i1 - i0;
+    long long first = (long long)ub * T * G / W;
+    while (W * (first + 1) / G <= (long long)ub * T) ++first;
+    while (W * first / G > (long long)ub * T) --first;
+    const int split = (int)(b - first);
+    const int q = ub * kUsersPerBlock + uslot;
+    const bool q_ok = q < U;
+
+    for (int k = tid; k < NC * kUsersPerBlock; k += 512) s_cnt[k] = 0u;
+    bf16x8 bhi[NS], blo[NS];
+    {
+        const uint4 *urow = users_bf + (size_t)(q_ok ? q : 0) * (2 * D / 8);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            uint4 v = urow[2 * sI + h], l = urow[D / 8 + 2 * sI + h];
+            if (!q_ok) { v = make_uint4(0u, 0u, 0u, 0u); l = v; }
+            bhi[sI] = *reinterpret_cast<bf16x8 *>(&v);
+            blo[sI] = *reinterpret_cast<bf16x8 *>(&l);
+        }
+    }
+    const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
+    const bool wave_slow = KIND == MACR_SCORE_RUBI_BOTH && __any(q_ok && !(su > 1e-30f));
+    const float un = q_ok ? unorm[q] : 0.f;
+    // per value of c: threshold less the margin, and the test on the raw product (filter_y): acc >= fma(fx, Y_i, fz)
+    float c_g[NC], tau_g[NC], fx[NC], fz[NC];
+#pragma unroll
+    for (int g = 0; g < NC; ++g) {
+        c_g[g] = g < sw.n_c ? c_dev[g] : 0.f;
+        tau_g[g] = (g < sw.n_c && q_ok) ? sw.tau[g][q] - 1.01f * filter_margin(un, qmax, c_g[g]) : __builtin_nanf("");
+        fx[g] = 0.f; fz[g] = tau_g[g];
+        if (KIND == MACR_SCORE_RUBI_BOTH) { fx[g] = tau_g[g] / su; fz[g] = c_g[g]; }
+        else if (KIND == MACR_SCORE_RUBI) { fx[g] = tau_g[g]; fz[g] = c_g[g]; }
+        else if (KIND == MACR_SCORE_DIRECT_MINUS) { fx[g] = c_g[g]; }
+        else if (KIND == MACR_SCORE_DIRECT_MINUS_BOTH) { fx[g] = c_g[g] * su; }
+    }
+
+    int vi = i0, t = visit(i0);
+    uint4 stg[LDU];
+    float sg = 0.f;
+    uint32_t tm_next = 0u;
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int k = 0; k < LDU; ++k) {
+            const int e = tid + 512 * k, row = (e / (2 * D / 8)) & (kTileItems - 1), c8 = e % (2 * D / 8);
+            const int it = min(tile * kTileItems + row, n_local - 1);
+            stg[k] = items_bf[(size_t)it * (2 * D / 8) + c8];
+        }
+        sg = sig_i[min(tile * kTileItems + (tid & (kTileItems - 1)), n_local - 1)];
+        tm_next = (mask_bits && q_ok) ? mask_bits[(size_t)tile * U + q] : 0u;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < LDU; ++k) {
+            asm volatile("" : "+v"(stg[k].x), "+v"(stg[k].y), "+v"(stg[k].z), "+v"(stg[k].w));
+            const int e = tid + 512 * k, row = e / (2 * D / 8), c8 = e % (2 * D / 8);
+            if (row < kTileItems)
+                *reinterpret_cast<uint4 *>(s_a + ((size_t)buf * kTileItems + row) * RSB + 8 * c8) = stg[k];
+        }
+        asm volatile("" : "+v"(sg));
+        if (tid < 64) {
+            const bool tiny = !(sg > 1e-30f);
+            if (tid < kTileItems) { s_sig[buf * kTileItems + tid] = sg; s_y[buf * kTileItems + tid] = filter_y<KIND>(sg); }
+            const bool any_tiny = __any(tiny);
+            if (tid == 0) s_slow[buf] = any_tiny ? 1 : 0;
+        }
+    };
+
+    int buf = 0;
+    if (vi < i1) { load_tile(t); store_tile(0); }
+    uint32_t tm_cur = tm_next;
+    __syncthreads();
+    while (vi < i1) {
+        const bool has_next = vi + 1 < i1;
+        const int tn = has_next ? visit_after(t) : t;
+        if (has_next) load_tile(tn);
+
+        const int gid0 = t * kTileItems + item_offset;
+        const int valid = n_local - t * kTileItems;
+        const uint32_t tmask = tm_cur | (valid < kTileItems ? (valid > 0 ? ~0u << valid : ~0u) : 0u);
+
+        const __bf16 *ua = s_a + ((size_t)buf * kTileItems + col) * RSB + 8 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(ua + 16 * sI);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(ua + D + 16 * sI);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhi[sI], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blo[sI], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhi[sI], acc, 0, 0, 0);
+        }
+        const bool slow = wave_slow || s_slow[buf] != 0;      // wave-uniform, practically never
+        float yi[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<float4 *>(yi + 4 * k) = *reinterpret_cast<const float4 *>(s_y + buf * kTileItems + 8 * k + 4 * h);
+#pragma unroll
+        for (int g = 0; g < NC; ++g) {
+            if (g >= sw.n_c) break;                           // wave-uniform
+            uint32_t hit = 0u;
+            if (!slow) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hit |= __ballot(acc[r] >= fmaf(fx[g], yi[r], fz[g])) ? 1u << r : 0u;
+            } else {
+                hit = 0xffffu;
+            }
+            if (hit) {
+                uint64_t *lst = sw.lists[g] + ((size_t)split * U + (q_ok ? q : 0)) * cap;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (!((hit >> r) & 1u)) continue;         // wave-uniform
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    bool pass = slow || acc[r] >= fmaf(fx[g], yi[r], fz[g]);
+                    pass = pass && ((tmask >> row) & 1u) == 0u;
+                    if (pass) {
+                        const float v = score_epilogue<KIND>(acc[r], c_g[g], s_sig[buf * kTileItems + row], su);
+                        if (v >= tau_g[g]) {
+                            const uint32_t pos = atomicAdd(&s_cnt[g * kUsersPerBlock + uslot], 1u);
+                            if (pos < (uint32_t)cap) lst[pos] = make_key(v, gid0 + row);
+                            else {                            // full: that c's fallback kernel ranks; stop listing for her
+                                *sw.overflow[g] = 1;
+                                tau_g[g] = INFINITY; fz[g] = INFINITY;
+                                if (KIND == MACR_SCORE_RUBI_BOTH || KIND == MACR_SCORE_RUBI) fx[g] = INFINITY;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (has_next) store_tile(buf ^ 1);
+        __syncthreads();
+        tm_cur = tm_next;
+        buf ^= 1;
+        t = tn; ++vi;
+    }
+    for (int k = tid; k < kUsersPerBlock; k += 512) {
+        const int qq = ub * kUsersPerBlock + k;
+#pragma unroll
+        for (int g = 0; g < NC; ++g)
+            if (g < sw.n_c && qq < U) sw.counts[g][(size_t)split * U + qq] = (int32_t)min(s_cnt[g * kUsersPerBlock + k], (uint32_t)cap);
+    }
+    }   // segments
+}
+
 // The sampling pass of k_score_stream (MODE = max) on the bf16 copies: per user and class the largest score_bf16 among
 // the sampled unmasked items.  K classes with maxima >= t hold K distinct items whose fp32 scores are >= t - margin_u:
 // k_tau takes the K-th largest maximum and subtracts the margin (its `unorm` argument), which makes tau a valid fp32
@@ -2644,7 +2828,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
 extern "C" size_t macr_score_topk_sweep_workspace_bytes(int U, int n_local, int d, int n_c) {
     if (U <= 0 || n_local <= 0 || !dim_supported(d) || n_c < 1 || n_c > kMaxSweep) return 0;
     const StreamGeo geo = stream_geo(U, n_local, d);
-    return (size_t)n_c * align_up(carve_topk_ws(nullptr, U, n_local, geo).bytes, 256);
+    return (size_t)n_c * align_up(carve_topk_ws(nullptr, U, n_local, geo, d).bytes, 256);
 }
 
 extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, const float *users_tab,
@@ -2663,7 +2847,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
     MACR_REQUIRE(mask_bits_in || !mask_ptr, MACR_E_INVALID, "score_topk_sweep: pass the mask bitmap (macr_mask_bits_build) with the mask");
     MACR_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID, "score_topk_sweep: workspace");
     const StreamGeo geo = stream_geo(U, n_local, d);
-    const size_t one = align_up(carve_topk_ws(nullptr, U, n_local, geo).bytes, 256);
+    const size_t one = align_up(carve_topk_ws(nullptr, U, n_local, geo, d).bytes, 256);
     MACR_REQUIRE(workspace_bytes >= one * n_c, MACR_E_WORKSPACE, "score_topk_sweep: workspace %zu < %zu bytes", workspace_bytes, one * n_c);
     static const bool force_fallback = getenv("MACR_TOPK_FALLBACK") && getenv("MACR_TOPK_FALLBACK")[0] == '1';
     hipStream_t st = as_stream(stream);
@@ -2673,7 +2857,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
     SweepArgs sw;
     sw.n_c = n_c;
     for (int g = 0; g < kMaxSweep; ++g) {
-        ws[g] = carve_topk_ws(static_cast<char *>(workspace) + (size_t)(g < n_c ? g : 0) * one, U, n_local, geo);
+        ws[g] = carve_topk_ws(static_cast<char *>(workspace) + (size_t)(g < n_c ? g : 0) * one, U, n_local, geo, d);
         sw.tau[g] = ws[g].tau; sw.lists[g] = ws[g].lists; sw.counts[g] = ws[g].counts; sw.overflow[g] = ws[g].overflow;
     }
     MACR_DISPATCH_DK(d, score_kind, {
@@ -2684,6 +2868,15 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
         MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk_sweep: cannot reserve %zu B of LDS: %s", smem1, hipGetErrorString(e));
+        const bool filter_bf16 = !list_all && eval_filter_bf16();
+        uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws[0].overflow + 8);      // (value 0's workspace holds the operand copies)
+        const size_t smem_b = StreamCfgB<D>::smem, smem_bs = StreamCfgB<D>::smem + (size_t)(kMaxSweep - 1) * kUsersPerBlock * 4;
+        if (filter_bf16) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_sample_b<D, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_stream_bs<D, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bs);
+            MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk_sweep: cannot reserve %zu B of LDS: %s", smem_bs, hipGetErrorString(e));
+        }
         for (int g = 0; g < n_c; ++g) {           // per c: workspace head, sampling pass, threshold
             const size_t n_zero = ws[g].header_bytes / 4;
             const size_t n_tau = (reinterpret_cast<char *>(ws[g].maxima) - reinterpret_cast<char *>(ws[g].tau)) / 4;
@@ -2694,6 +2887,20 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
                                                          n_zero, n_tau, 0xff800000u, list_all ? 1 : 0, n_max);
             MACR_CHECK_LAUNCH("ws_init", st);
             if (list_all) continue;
+            if (filter_bf16) {
+                if (g == 0) {
+                    k_bf16_prep<D><<<(unsigned)(((size_t)n_local + U + kPrepTrips * (256 / (D / 8)) - 1) / (kPrepTrips * (256 / (D / 8)))), 256, 0, st>>>(
+                        U, n_local, users_tab, user_ids, items, ws[0].users_bf, ws[0].items_bf, ws[0].unorm, qmax_bits);
+                    MACR_CHECK_LAUNCH("bf16_prep", st);
+                }
+                k_score_sample_b<D, KIND><<<geo.grid0, 512, smem_b, st>>>(U, n_local, ws[0].users_bf, ws[0].items_bf, sig_u, sig_i, 0.f, c_dev + g,
+                                                                         mask_bits_in, geo.ublocks, ws[g].maxima, sample_log2(n_local), nullptr, nullptr);
+                MACR_CHECK_LAUNCH("score_sample_b", st);
+                launch_k_tau<false>((geo.slots0 * 32 + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws[g].maxima, nullptr, ws[g].tau, ws[0].unorm,
+                                    qmax_bits, 0.f, c_dev + g);
+                MACR_CHECK_LAUNCH("tau", st);
+                continue;
+            }
             pass0<<<geo.grid0, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev + g, mask_bits_in,
                                                 item_offset, geo.ublocks, ws[g].tau, ws[g].maxima, ws[g].lists, ws[g].counts,
                                                 ws[g].cap, ws[g].overflow, 0, sample_log2(n_local), nullptr, nullptr, nullptr, SweepArgs{}, 0);
@@ -2703,6 +2910,18 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
             MACR_CHECK_LAUNCH("tau", st);
         }
         // ONE listing pass for all n_c values
+        if (filter_bf16) {
+            k_score_stream_bs<D, KIND><<<geo.grid1, 512, smem_bs, st>>>(U, n_local, ws[0].users_bf, ws[0].items_bf, ws[0].unorm, qmax_bits, sig_u,
+                                                                       sig_i, c_dev, mask_bits_in, item_offset, geo.ublocks, ws[0].cap, sw);
+            MACR_CHECK_LAUNCH("score_stream_b", st);
+            for (int g = 0; g < n_c; ++g) {
+                k_select_b<D, KIND><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, 1, K, ws[g].cap, ws[g].lists, ws[g].counts,
+                                                                          ws[g].overflow, 0, nullptr, nullptr, users_tab, user_ids, items, sig_u,
+                                                                          sig_i, 0.f, c_dev + g, item_offset, ws[0].unorm, qmax_bits,
+                                                                          out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K, nullptr);
+                MACR_CHECK_LAUNCH("select_b", st);
+            }
+        } else {
         pass1<<<geo.grid1, 512, smem1, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev, mask_bits_in,
                                              item_offset, geo.ublocks, ws[0].tau, ws[0].maxima, ws[0].lists, ws[0].counts,
                                              ws[0].cap, ws[0].overflow, 0, sample_log2(n_local), nullptr, nullptr, nullptr, sw, 0);
@@ -2711,6 +2930,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
             k_select<false><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, geo.slots1, 1, K, ws[g].cap, ws[g].lists, ws[g].counts, ws[g].overflow,
                                                            0, nullptr, nullptr, out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K, nullptr);
             MACR_CHECK_LAUNCH("select", st);
+        }
         }
     });
     // per-c fallback, armed by that c's overflow flag

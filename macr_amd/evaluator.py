@@ -288,7 +288,7 @@ class Evaluator(object):
         # The shared-listing-pass kernel multiplies in fp32 only.  With the bf16 candidate filter one value at a time is as
         # fast or faster on larger catalogues (tools/bench_sweep.py, per value: Gowalla shape 0.43 ms against 0.48 for the
         # four-c sweep; ML-10M shape 0.22 against 0.20): those go c by c through the seeded, graph-replayed evaluation.
-        one_by_one = self.filter == "bf16" and items_tab.shape[0] >= 16384
+        one_by_one = os.environ.get("MACR_SWEEP_ONE_BY_ONE", "0") == "1"
         if one_by_one or sharding.world()[1] > 1 or kind == ops.SCORE_NORMAL or self.n_queries > self.max_queries_per_pass:
             return torch.stack([self._means(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c).clone() for c in cs])
         outs = []

@@ -610,7 +610,7 @@ def test_any_embed_size_runs_zero_padded_and_exact(ops, d):
 
 
 @pytest.mark.parametrize("kind_name", ["SCORE_RUBI_BOTH", "SCORE_RUBI", "SCORE_DIRECT_MINUS_BOTH"])
-def test_shared_listing_pass_sweep_equals_single_c(ops, kind_name):
+def test_shared_listing_pass_sweep_equals_single_c(ops, kind_name, eval_filter):
     """f1: macr_score_topk_sweep ranks up to four values of c with ONE listing pass; every value must give exactly the
     lists macr_score_topk gives for that c (ids and score bits), and Evaluator.test_mf_sweep the metrics of separate
     test_mf calls -- 7 values: a group of four and a group of three."""
