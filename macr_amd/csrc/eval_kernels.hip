@@ -918,10 +918,10 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {          // round t
 // (atomicMax on the float's bits: norms are >= 0).  One 8-lane group per 64 columns... one lane converts 8 columns.
 constexpr int kPrepTrips = 8;
 template <int D>
-__global__ __launch_bounds__(256) void k_bf16_prep(int U, int n_local, const float *__restrict__ users_tab,
-                                                   const int32_t *__restrict__ user_ids, const float *__restrict__ items,
-                                                   uint4 *__restrict__ users_bf, uint4 *__restrict__ items_bf,
-                                                   float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
+__device__ __forceinline__ void bf16_prep_block(int blk, int U, int n_local, const float *__restrict__ users_tab,
+                                                const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                                uint4 *__restrict__ users_bf, uint4 *__restrict__ items_bf,
+                                                float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
     constexpr int LPRB = D / 8, RPB = 256 / LPRB;            // lanes per row, rows per block and trip
     __shared__ float s_max[4];
     const int sub = threadIdx.x % LPRB, slot = threadIdx.x / LPRB;
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void k_bf16_prep(int U, int n_local, const flo
     long long row[kPrepTrips];
 #pragma unroll
     for (int t = 0; t < kPrepTrips; ++t) {
-        row[t] = ((long long)blockIdx.x * kPrepTrips + t) * RPB + slot;
+        row[t] = ((long long)blk * kPrepTrips + t) * RPB + slot;
         const bool is_item = row[t] < n_local;
         const long long q = row[t] - n_local;
         src[t] = is_item ? items + (size_t)row[t] * D : users_tab + (size_t)((q < U) ? (user_ids ? user_ids[q] : q) : 0) * D;
@@ -974,6 +974,18 @@ __global__ __launch_bounds__(256) void k_bf16_prep(int U, int n_local, const flo
         if (m > __uint_as_float(__hip_atomic_load(qmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
             atomicMax(qmax_bits, __float_as_uint(m));
     }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_bf16_prep(int U, int n_local, const float *__restrict__ users_tab,
+                                                   const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                                   uint4 *__restrict__ users_bf, uint4 *__restrict__ items_bf,
+                                                   float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
+    bf16_prep_block<D>(blockIdx.x, U, n_local, users_tab, user_ids, items, users_bf, items_bf, unorm, qmax_bits);
+}
+static inline unsigned bf16_prep_blocks(int U, int n_local, int d) {
+    const size_t rows_per_block = (size_t)kPrepTrips * (256 / (d / 8));
+    return (unsigned)(((size_t)n_local + U + rows_per_block - 1) / rows_per_block);
 }
 
 template <int D>
@@ -1588,14 +1600,14 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_b(
 constexpr int kSeedWidth = MACR_SEED_WIDTH;
 static_assert(kSeedWidth == 32, "one 32-lane half per user");
 template <int D, int KIND>
-__global__ __launch_bounds__(256) void k_tau_seed(int U, int n_local, const float *__restrict__ users_tab,
-                                                  const int32_t *__restrict__ user_ids, const float *__restrict__ items,
-                                                  const float *__restrict__ sig_u, const float *__restrict__ sig_i,
-                                                  float c_val, const float *__restrict__ c_dev,
-                                                  const uint32_t *__restrict__ mask_bits, int item_offset, int K,
-                                                  const int32_t *__restrict__ seed, float *__restrict__ tau) {
+__device__ __forceinline__ void tau_seed_block(int blk, int U, int n_local, const float *__restrict__ users_tab,
+                                               const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                               const float *__restrict__ sig_u, const float *__restrict__ sig_i,
+                                               float c_val, const float *__restrict__ c_dev,
+                                               const uint32_t *__restrict__ mask_bits, int item_offset, int K,
+                                               const int32_t *__restrict__ seed, float *__restrict__ tau) {
     const float c = c_dev ? *c_dev : c_val;
-    const int q = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    const int q = blk * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     if (q >= U) return;                                   // whole 32-lane halves leave together
     const int it = seed[(size_t)q * kSeedWidth + l] - item_offset;
     bool ok = it >= 0 && it < n_local;
@@ -1640,6 +1652,34 @@ __global__ __launch_bounds__(256) void k_tau_seed(int U, int n_local, const floa
     const uint32_t ot = f32_orderable(t);
     t = orderable_f32(ot > 0x007fffffu + 2u ? ot - 2u : 0x007fffffu);       // (0x007fffff is -inf in that order)
     if (l == 0) tau[q] = (__popcll(good) >= K && kth) ? t : -INFINITY;
+}
+
+template <int D, int KIND>
+__global__ __launch_bounds__(256) void k_tau_seed(int U, int n_local, const float *__restrict__ users_tab,
+                                                  const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                                  const float *__restrict__ sig_u, const float *__restrict__ sig_i,
+                                                  float c_val, const float *__restrict__ c_dev,
+                                                  const uint32_t *__restrict__ mask_bits, int item_offset, int K,
+                                                  const int32_t *__restrict__ seed, float *__restrict__ tau) {
+    tau_seed_block<D, KIND>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_val, c_dev, mask_bits, item_offset, K, seed, tau);
+}
+
+// Seeded ranking under the bf16 filter: the operand copies and the seeded thresholds do not depend on each other -- two
+// short, latency-bound kernels -- and go out as ONE launch (blocks [0, n_prep) convert, the others score seeds).
+template <int D, int KIND>
+__global__ __launch_bounds__(256) void k_prep_tau_seed(int n_prep, int U, int n_local, const float *__restrict__ users_tab,
+                                                       const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                                       uint4 *__restrict__ users_bf, uint4 *__restrict__ items_bf,
+                                                       float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits,
+                                                       const float *__restrict__ sig_u, const float *__restrict__ sig_i,
+                                                       float c_val, const float *__restrict__ c_dev,
+                                                       const uint32_t *__restrict__ mask_bits, int item_offset, int K,
+                                                       const int32_t *__restrict__ seed, float *__restrict__ tau) {
+    if ((int)blockIdx.x < n_prep)
+        bf16_prep_block<D>(blockIdx.x, U, n_local, users_tab, user_ids, items, users_bf, items_bf, unorm, qmax_bits);
+    else
+        tau_seed_block<D, KIND>(blockIdx.x - n_prep, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_val, c_dev, mask_bits,
+                                item_offset, K, seed, tau);
 }
 
 // ----------------------------------------------------------------------------
@@ -2695,10 +2735,16 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         };
         const bool seeded = !list_all && seed_idx;
         uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws.overflow + 8);
-        if (filter_bf16) {
-            // operand copies (two bf16 per value), |u| per query, max |q|: for the sampling and the listing pass
-            k_bf16_prep<D><<<(unsigned)(((size_t)n_local + U + kPrepTrips * (256 / (D / 8)) - 1) / (kPrepTrips * (256 / (D / 8)))), 256, 0, st>>>(
-                U, n_local, users_tab, user_ids, items, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits);
+        if (filter_bf16 && seeded) {
+            // operand copies (two bf16 per value), |u| per query, max |q| -- and, in the same launch, the seeded thresholds
+            const unsigned n_prep = bf16_prep_blocks(U, n_local, D);
+            k_prep_tau_seed<D, KIND><<<n_prep + (U + 7) / 8, 256, 0, st>>>((int)n_prep, U, n_local, users_tab, user_ids, items, ws.users_bf,
+                                                                           ws.items_bf, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev, mask_bits,
+                                                                           item_offset, K, seed_idx, ws.tau);
+            MACR_CHECK_LAUNCH("bf16_prep+tau_seed", st);
+        } else if (filter_bf16) {
+            k_bf16_prep<D><<<bf16_prep_blocks(U, n_local, D), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, ws.users_bf, ws.items_bf,
+                                                                            ws.unorm, qmax_bits);
             MACR_CHECK_LAUNCH("bf16_prep", st);
         }
         if (filter_bf16 && !seeded) {
@@ -2711,6 +2757,8 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             MACR_CHECK_LAUNCH("score_sample_b", st);
             launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev);
             MACR_CHECK_LAUNCH("tau", st);
+        } else if (seeded && filter_bf16) {
+            // (thresholds: in the launch above)
         } else if (seeded) {
             // thresholds from the exact scores of the caller's seed items (its previous top K): no sampling pass, no k_tau
             k_tau_seed<D, KIND><<<(U + 7) / 8, 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
@@ -2889,7 +2937,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
             if (list_all) continue;
             if (filter_bf16) {
                 if (g == 0) {
-                    k_bf16_prep<D><<<(unsigned)(((size_t)n_local + U + kPrepTrips * (256 / (D / 8)) - 1) / (kPrepTrips * (256 / (D / 8)))), 256, 0, st>>>(
+                    k_bf16_prep<D><<<bf16_prep_blocks(U, n_local, D), 256, 0, st>>>(
                         U, n_local, users_tab, user_ids, items, ws[0].users_bf, ws[0].items_bf, ws[0].unorm, qmax_bits);
                     MACR_CHECK_LAUNCH("bf16_prep", st);
                 }
