@@ -52,6 +52,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense (MI355X_MICROARCH.md)
+N_BATCHES = 256                # pre-generated sampler batches every leg of the default workloads cycles through
 
 
 def parse():
@@ -122,7 +123,7 @@ def bench_config4(args, rank, world, dev):
     model = sharded_train.RowShardedMF(None, None, w, wu, sharded_train.HipBackend(ops.LOSS_RUBIBCEBOTH, d, hyper, dev),
                                        rank=rank, world=world,
                                        shards=(xavier_rows(u_hi - u_lo, n_users), xavier_rows(i_hi - i_lo, n_items), n_users, n_items))
-    n_batches = min(args.steps + args.warmup, 32)
+    n_batches = 32                  # (independent of --steps: same batches, same model, whatever the call)
     batches = synth.train_batches(n_batches, n_users, n_items, B, gen_all, dev)
 
     def barrier():
@@ -308,7 +309,10 @@ def main():
     wu = synth.xavier_table(d, 1, gen, dev).reshape(-1)
     hyper = ops.make_hyper(cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
     state = ops.MFState(P, Q, w, wu, hyper, B)
-    n_batches = min(args.steps + args.warmup, 256)
+    # The batch pool does NOT depend on --steps / --warmup: the evaluator leg trains the model through it between its
+    # timed evaluations, and `--steps 20` must evaluate the same model as `--steps 200` (round 3: 25 batches in the
+    # driver's call, 220 in the README's -- every seeded evaluation of the 25-batch model was repaired).
+    n_batches = N_BATCHES
     batches = synth.train_batches(n_batches, cfg["n_users"], cfg["n_items"], B, gen, dev, zipf=args.pos == "zipf",
                                   sort_by_pos=args.presorted)
     loss_log = torch.zeros((n_batches, 3), dtype=torch.float32, device=dev)
@@ -582,6 +586,21 @@ def main():
             for key in ("frac",):
                 rb["seeded"].pop(key, None)
 
+    # both filters side by side, in one short object near the top of the line
+    eval_summary = None
+    if not args.no_eval:
+        def _row(su):
+            modes = su["ev_modes"]
+            return {"users_per_s": su["eval_users_per_s"], "ms_per_eval": 1e3 * su["ev_elapsed"] / args.eval_reps,
+                    "ms_unseeded": su["ev_unseeded_ms"], "evaluations": len(modes),
+                    "seeded": sum(1 for m in modes if m["seeded"]),
+                    "repaired": sum(1 for m in modes if m["query_blocks_relisted"] > 0 or m["exact_fallback"]),
+                    "query_blocks_relisted": sum(m["query_blocks_relisted"] for m in modes)}
+        eval_summary = {"default_filter": "bf16" if suite is not suite_f32 else "f32", "f32": _row(suite_f32),
+                        "bf16": _row(suite) if suite is not suite_f32 else None,
+                        "train_steps_between_evaluations": args.eval_train_steps, "batch_pool": n_batches,
+                        "roofline_eval_frac_f32_sampled": roofline_eval["frac"]}
+
     # ------------------------------------------------------------- CPU baseline: the oracle ("port") on the host cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -630,6 +649,7 @@ def main():
                        "parallelism": "replicas x%d (train) / item-sharded x%d + RCCL all-gather (eval)" % (world, world),
                        "global_batch": B * world},
             "eval_users_per_s": eval_users_per_s,
+            "eval": eval_summary,
             "sharded_figure": {"name": "eval_users_per_s", "value": eval_users_per_s, "scaling": "strong",
                                "note": "`value` counts N independent training replicas (these configs' step fits one GPU: "
                                        "replicas only, SURVEY.md 8e); the path of this workload that SHARDS over the ranks is the "

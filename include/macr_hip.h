@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     7
+#define MACR_ABI_VERSION     8
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -353,7 +353,8 @@ size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
  *   MACR_EVAL_FILTER_F32   the (U, N) product on the fp32 matrix cores; a listed score is the final score.
  *   MACR_EVAL_FILTER_BF16  the product on two-term bf16 splits of the operands (hi*hi + hi*lo + lo*hi: 5x fewer
  *                          matrix-core cycles), every score compared with the query's threshold LESS a rigorous bound of
- *                          the error (1e-4 |u| max|q| + roundings), in the sampling pass, the listing pass and the
+ *                          the error ((3.2 * 2^-16 + 8 d * 2^-24) |u| max|q| + roundings: 7.9e-5 at d = 64, 1.71e-4 at
+ *                          d = 256), in the sampling pass, the listing pass and the
  *                          repair round; the selection takes each query's 64 best candidates by bf16 score, checks that
  *                          nothing else can belong to the top K, re-computes the fp32 score of those that can and ranks
  *                          them; a query that fails the check has all its listed candidates re-scored in fp32.
@@ -397,6 +398,16 @@ int macr_score_topk_sweep(int score_kind, int U, int n_local, int d,
                           const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
                           int item_offset, int K, float *out_val, int32_t *out_idx,
                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* TEST-ONLY: the invariant the bf16 candidate filter rests on, made observable.  Writes, for U query rows and N item
+ * rows (dev, fp32 [U][d] / [N][d]), the RAW product the bf16 kernels compute -- two-term bf16 splits, hi*hi + hi*lo +
+ * lo*hi on v_mfma_f32_32x32x16_bf16 in the listing pass's instruction order -- to prod (dev) fp32[U][N], and to margin
+ * (dev) fp32[U] the error margin the filter grants each query at this c (what it subtracts from her threshold).
+ * tests/ assert |prod - fp32 fmaf chain| <= margin element-wise on adversarial operands for every d; no product code
+ * calls this.  (The reference scores in fp32: macr_mf/model.py:199.) */
+size_t macr_test_bf16_products_workspace_bytes(int d, int U, int N);
+int macr_test_bf16_products(int d, int U, int N, const float *users, const float *items, float c,
+                            float *prod, float *margin, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The train-item mask as the ranking kernels read it: mask_bits[tile][query] has bit (i % 32)
  * set when the query masks item 32*tile + i of the shard.  The mask of an evaluator never

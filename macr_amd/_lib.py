@@ -16,7 +16,7 @@ STEP_DEFER, STEP_PENDING, STEP_LOSS_ONLY, STEP_DENSE_LAYERS = 1, 2, 4, 8
 SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINUS_BOTH = 0, 1, 2, 3, 4
 MAX_TOPK = 32
 MAX_SWEEP = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class MacrError(RuntimeError):
@@ -66,6 +66,8 @@ SIGNATURES = {
     "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "macr_score_topk_sweep_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "macr_score_topk_sweep": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _z, _p]),
+    "macr_test_bf16_products_workspace_bytes": (_z, [_i, _i, _i]),
+    "macr_test_bf16_products": (_i, [_i, _i, _i, _p, _p, _f, _p, _p, _p, _z, _p]),
     "macr_mask_bits_bytes": (_z, [_i, _i]),
     "macr_mask_bits_build": (_i, [_i, _i, _p, _p, _i, _p, _p]),
     "macr_score_matrix": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),

@@ -885,7 +885,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 //   * every operand as TWO bf16 numbers, x ~ hi + lo (hi = bf16(x), lo = bf16(x - hi), round to nearest even:
 //     |x - hi - lo| <= 2^-16 |x|; k_bf16_prep), the product as hi*hi + hi*lo + lo*hi on the bf16 matrix cores (products
 //     exact, fp32 accumulation): 3 MFMAs of 32 cycles per 16 k instead of 8 of 64 -- 5.3x fewer matrix-core cycles --
-//     and |s_bf16 - s_fp32| <= (3.1 * 2^-16 + 6 d 2^-24) sum_k |u_k q_k| <= kFilterRel * |u| * max_i |q_i|  (Cauchy-Schwarz).
+//     and |s_bf16 - s_fp32| <= filter_rel(d) * sum_k |u_k q_k| <= filter_rel(d) * |u| * max_i |q_i|  (Cauchy-Schwarz; filter_rel below).
 //     (One bf16 per operand -- 16x -- was built first: its bound, 2^-7 |u| max|q|, is wider than the gap between a user's
 //     K-th and 64th best score whenever a few popular items have long rows, and most users failed the check below.)
 //     every epilogue (common.hpp score_epilogue) is 1-Lipschitz in s (sigmoids <= 1) and adds <= 3 roundings of values
@@ -900,12 +900,21 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 // The result is the fp32 ranking, bit for bit; tests compare both filters with the oracle.
 // ============================================================================
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-constexpr float kFilterRel = 1.0e-4f;        // > 3.1 * 2^-16 + 6 * 256 * 2^-24
+// Relative term of the margin, per embedding width d (a bound of |s_bf16 - s_fp32| / sum_k |u_k q_k|):
+//   3.2 * 2^-16   the three dropped terms of the split product, lo*lo + r_u*q + u*r_q  (|lo| <= 2^-8 |x|, |r| <= 2^-16 |x|;
+//                 3 * 2^-16 plus their second-order terms)
+//   8 d * 2^-24   the accumulation: 3d exact bf16 products added into an fp32 accumulator over 3d/16 MFMAs -- <= 2^-23 per
+//                 added term relative to the running sum of magnitudes whether the matrix core rounds to nearest or
+//                 truncates the aligned addends (6 d 2^-24), the 17-term alignment of one instruction (< d 2^-24) -- and the
+//                 fp32 fmaf chain of the exact score itself (d 2^-24).
+// d = 32: 6.4e-5, 64: 7.9e-5, 128: 1.10e-4, 256: 1.71e-4.  tests/test_gpu_ops.py measures the element-wise error of the
+// very MFMA sequence of the listing pass on adversarial operands (macr_test_bf16_products) against this margin.
+__host__ __device__ constexpr float filter_rel(int d) { return 3.2f / 65536.f + 8.f * (float)d / 16777216.f; }
 constexpr float kFilterAbs = 1.0e-6f;        // > 2^-20: roundings of the epilogue / of the test on the raw product, relative to |u| max|q| + |c|
 
-__device__ __forceinline__ float filter_margin(float unorm, float qmax, float c) {
+__device__ __forceinline__ float filter_margin(int d, float unorm, float qmax, float c) {
     const float b = unorm * qmax * 1.0001f;
-    return kFilterRel * b + kFilterAbs * (b + fabsf(c)) + 1e-37f;
+    return filter_rel(d) * b + kFilterAbs * (b + fabsf(c)) + 1e-37f;
 }
 
 __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {          // round to nearest even; NaN stays NaN
@@ -986,6 +995,41 @@ __global__ __launch_bounds__(256) void k_bf16_prep(int U, int n_local, const flo
 static inline unsigned bf16_prep_blocks(int U, int n_local, int d) {
     const size_t rows_per_block = (size_t)kPrepTrips * (256 / (d / 8));
     return (unsigned)(((size_t)n_local + U + rows_per_block - 1) / rows_per_block);
+}
+
+// Test-only (macr_test_bf16_products): the RAW product of the bf16 kernels for a whole (U, N) block -- the three MFMAs
+// per 16 k of k_score_stream_b / k_score_sample_b / k_score_stream_bs in their order, on the operand copies k_bf16_prep
+// wrote -- and the margin the filter would grant each query.  One wave per 32 x 32 tile.
+template <int D>
+__global__ __launch_bounds__(64) void k_test_bf16_products(int U, int N, const uint4 *__restrict__ users_bf,
+                                                           const uint4 *__restrict__ items_bf, const float *__restrict__ unorm,
+                                                           const uint32_t *__restrict__ qmax_bits, float c,
+                                                           float *__restrict__ prod, float *__restrict__ margin) {
+    const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+    const int item = min((int)blockIdx.x * 32 + col, N - 1), user = min((int)blockIdx.y * 32 + col, U - 1);
+    const uint4 *irow = items_bf + (size_t)item * (2 * D / 8), *urow = users_bf + (size_t)user * (2 * D / 8);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int sI = 0; sI < D / 16; ++sI) {
+        uint4 v;
+        v = irow[2 * sI + h];          const bf16x8 ah = *reinterpret_cast<bf16x8 *>(&v);
+        v = irow[D / 8 + 2 * sI + h];  const bf16x8 al = *reinterpret_cast<bf16x8 *>(&v);
+        v = urow[2 * sI + h];          const bf16x8 bh = *reinterpret_cast<bf16x8 *>(&v);
+        v = urow[D / 8 + 2 * sI + h];  const bf16x8 bl = *reinterpret_cast<bf16x8 *>(&v);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+    const int u = (int)blockIdx.y * 32 + col;
+    if (u >= U) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int it = (int)blockIdx.x * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (it < N) prod[(size_t)u * N + it] = acc[r];
+    }
+    if (blockIdx.x == 0 && h == 0) margin[u] = filter_margin(D, unorm[u], __uint_as_float(*qmax_bits), c);
 }
 
 template <int D>
@@ -1101,7 +1145,7 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
         su[g] = (score_uses_sig_u(KIND) && q_ok[g]) ? sig_u[q[g]] : 1.0f;
         // listing test: score_bf16 >= tau - margin (NaN = never: padding users)
         tau_s[g] = __builtin_nanf("");
-        if (q_ok[g]) tau_s[g] = tau[q[g]] - 1.01f * filter_margin(unorm[q[g]], qmax, c);
+        if (q_ok[g]) tau_s[g] = tau[q[g]] - 1.01f * filter_margin(D, unorm[q[g]], qmax, c);
         // the test on the raw product (filter_y): acc >= fma(fx, Y_i, fz)
         fx[g] = 0.f; fz[g] = tau_s[g];
         if (KIND == MACR_SCORE_RUBI_BOTH) { fx[g] = tau_s[g] / su[g]; fz[g] = c; }
@@ -1326,7 +1370,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_bs(
 #pragma unroll
     for (int g = 0; g < NC; ++g) {
         c_g[g] = g < sw.n_c ? c_dev[g] : 0.f;
-        tau_g[g] = (g < sw.n_c && q_ok) ? sw.tau[g][q] - 1.01f * filter_margin(un, qmax, c_g[g]) : __builtin_nanf("");
+        tau_g[g] = (g < sw.n_c && q_ok) ? sw.tau[g][q] - 1.01f * filter_margin(D, un, qmax, c_g[g]) : __builtin_nanf("");
         fx[g] = 0.f; fz[g] = tau_g[g];
         if (KIND == MACR_SCORE_RUBI_BOTH) { fx[g] = tau_g[g] / su; fz[g] = c_g[g]; }
         else if (KIND == MACR_SCORE_RUBI) { fx[g] = tau_g[g]; fz[g] = c_g[g]; }
@@ -1697,7 +1741,7 @@ template <int NREG, bool REPAIR = false>
 __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int K, const float *__restrict__ maxima,
                                                         const int32_t *__restrict__ blk_flag, float *__restrict__ tau,
                                                         const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
-                                                        float c_val, const float *__restrict__ c_dev) {
+                                                        float c_val, const float *__restrict__ c_dev, int d_filter) {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x * kSelWaves + wid;
     if (q >= U) return;
@@ -1745,7 +1789,7 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int
         t_out = orderable_f32(prefix);                            // (all 32 bits decided when equal maxima remain)
     }
     // maxima of bf16 scores (k_score_sample_b): K items score >= t_out - margin in fp32
-    if (unorm) t_out -= 1.01f * filter_margin(unorm[q], __uint_as_float(*qmax_bits), c_dev ? *c_dev : c_val);
+    if (unorm) t_out -= 1.01f * filter_margin(d_filter, unorm[q], __uint_as_float(*qmax_bits), c_dev ? *c_dev : c_val);
     if (lane == 0) tau[q] = REPAIR ? fmaxf(tau[q], t_out) : t_out;
 }
 
@@ -2066,7 +2110,7 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
     // no item outside these 64 may belong to the exact top K
     const int R = K;
     const uint32_t hi_r = __shfl((uint32_t)(ka >> 32), R - 1, kWave), hi_last = __shfl((uint32_t)(ka >> 32), 63, kWave);
-    const float m2 = 2.02f * filter_margin(unorm[q], __uint_as_float(*qmax_bits), c);
+    const float m2 = 2.02f * filter_margin(D, unorm[q], __uint_as_float(*qmax_bits), c);
     // (hi_r == 0: fewer than R candidates -- all of them matter)
     const float a_cut = hi_r ? orderable_f32(hi_r) - m2 : -INFINITY;
     if (flag && lane == 0) overflow[ovf_per_user ? q : 0] = 1;
@@ -2635,15 +2679,15 @@ namespace macr {
 template <bool REPAIR>
 static void launch_k_tau(int tau_regs, int blocks, hipStream_t st, int U, int slots0, int K, const float *maxima,
                          const int32_t *blk_flag, float *tau, const float *unorm = nullptr, const uint32_t *qmax_bits = nullptr,
-                         float c = 0.f, const float *c_dev = nullptr) {
+                         float c = 0.f, const float *c_dev = nullptr, int d_filter = 0) {
     const int th = 64 * kSelWaves;
     // (unorm != NULL: the maxima are bf16 scores, tau = K-th largest - the filter's margin)
-    if (tau_regs <= 1) k_tau<1, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
-    else if (tau_regs <= 2) k_tau<2, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
-    else if (tau_regs <= 4) k_tau<4, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
-    else if (tau_regs <= 8) k_tau<8, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
-    else if (tau_regs <= 16) k_tau<16, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
-    else k_tau<32, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev);
+    if (tau_regs <= 1) k_tau<1, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
+    else if (tau_regs <= 2) k_tau<2, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
+    else if (tau_regs <= 4) k_tau<4, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
+    else if (tau_regs <= 8) k_tau<8, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
+    else if (tau_regs <= 16) k_tau<16, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
+    else k_tau<32, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
 }
 }  // namespace macr
 
@@ -2755,7 +2799,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             pass0b<<<geo.grid0, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, sig_u, sig_i, c, c_dev, mask_bits,
                                                   geo.ublocks, ws.maxima, sample_log2(n_local), nullptr, nullptr);
             MACR_CHECK_LAUNCH("score_sample_b", st);
-            launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev);
+            launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev, D);
             MACR_CHECK_LAUNCH("tau", st);
         } else if (seeded && filter_bf16) {
             // (thresholds: in the launch above)
@@ -2823,7 +2867,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
                     pass0rb<<<geo.grid0, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, sig_u, sig_i, c, c_dev, mask_bits,
                                                            geo.ublocks, ws.maxima, sample_log2(n_local), ws.ub_map, ws.overflow + 1);
                     MACR_CHECK_LAUNCH("score_sample2", st);
-                    launch_k_tau<true>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau, ws.unorm, qmax_bits, c, c_dev);
+                    launch_k_tau<true>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau, ws.unorm, qmax_bits, c, c_dev, D);
                     MACR_CHECK_LAUNCH("tau2", st);
                 }
                 pass1rb<<<geo.grid1, StreamGroupsB<D>::THREADS, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u,
@@ -2945,7 +2989,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
                                                                          mask_bits_in, geo.ublocks, ws[g].maxima, sample_log2(n_local), nullptr, nullptr);
                 MACR_CHECK_LAUNCH("score_sample_b", st);
                 launch_k_tau<false>((geo.slots0 * 32 + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws[g].maxima, nullptr, ws[g].tau, ws[0].unorm,
-                                    qmax_bits, 0.f, c_dev + g);
+                                    qmax_bits, 0.f, c_dev + g, D);
                 MACR_CHECK_LAUNCH("tau", st);
                 continue;
             }
@@ -3010,6 +3054,35 @@ extern "C" int macr_score_matrix(int score_kind, int U, int n_local, int d, cons
     MACR_DISPATCH_DK(d, score_kind, (k_score_matrix<D, KIND><<<grid, 256, 0, st>>>(
                                         U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, out_scores)));
     MACR_CHECK_LAUNCH("score_matrix", st);
+    return MACR_OK;
+}
+
+extern "C" size_t macr_test_bf16_products_workspace_bytes(int d, int U, int N) {
+    if (!dim_supported(d) || U <= 0 || N <= 0) return 0;
+    return align_up((size_t)U * 4 * d, 256) + align_up((size_t)N * 4 * d, 256) + align_up((size_t)U * 4, 256) + 256;
+}
+
+extern "C" int macr_test_bf16_products(int d, int U, int N, const float *users, const float *items, float c, float *prod,
+                                       float *margin, void *workspace, size_t workspace_bytes, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(U > 0 && N > 0, MACR_E_INVALID, "test_bf16_products: U=%d N=%d", U, N);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "test_bf16_products: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(users && items && prod && margin && workspace, MACR_E_INVALID, "test_bf16_products: null pointer");
+    MACR_REQUIRE(workspace_bytes >= macr_test_bf16_products_workspace_bytes(d, U, N), MACR_E_WORKSPACE,
+                 "test_bf16_products: workspace %zu < %zu", workspace_bytes, macr_test_bf16_products_workspace_bytes(d, U, N));
+    unsigned char *p = static_cast<unsigned char *>(workspace);
+    uint4 *users_bf = reinterpret_cast<uint4 *>(p);  p += align_up((size_t)U * 4 * d, 256);
+    uint4 *items_bf = reinterpret_cast<uint4 *>(p);  p += align_up((size_t)N * 4 * d, 256);
+    float *unorm = reinterpret_cast<float *>(p);     p += align_up((size_t)U * 4, 256);
+    uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(p);
+    fill_words(qmax_bits, 1, 0u, st);
+    dim3 grid((N + 31) / 32, (U + 31) / 32);
+    MACR_DISPATCH_LPR(d, {
+        constexpr int D = 4 * LPR;
+        k_bf16_prep<D><<<bf16_prep_blocks(U, N, D), 256, 0, st>>>(U, N, users, nullptr, items, users_bf, items_bf, unorm, qmax_bits);
+        k_test_bf16_products<D><<<grid, 64, 0, st>>>(U, N, users_bf, items_bf, unorm, qmax_bits, c, prod, margin);
+    });
+    MACR_CHECK_LAUNCH("test_bf16_products", st);
     return MACR_OK;
 }
 

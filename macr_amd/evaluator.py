@@ -35,7 +35,8 @@ class Evaluator(object):
         # candidate filter of the listing pass (include/macr_hip.h MACR_EVAL_FILTER_*): "bf16" = two-term bf16 products on
         # the bf16 matrix cores + fp32 re-scoring of the best candidates, "f32" = fp32 products throughout.  The ranking
         # is the fp32 ranking bit for bit either way; MACR_EVAL_FILTER in the environment overrides the default.
-        self.filter = os.environ.get("MACR_EVAL_FILTER", "bf16").lower()
+        self.filter = os.environ.get("MACR_EVAL_FILTER", "bf16").strip().lower()
+        ops.eval_filter_code(self.filter)         # a typo in the environment is refused here, by name
         self._graphs = {}
         self._graph_misses = 0
         # seeding policy: thresholds come from the previous ranking unless that went badly last time
@@ -274,6 +275,7 @@ class Evaluator(object):
 
     # ------------------------------------------------------------------ c sweep (tuners)
     def _sweep_direct(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c_dev):
+        ops.set_eval_filter(self.filter)          # (process-wide switch, read when the launches are issued)
         sig_i = ops.branch_sigmoid(items_tab, w)
         sig_u = ops.branch_sigmoid(users_tab, wu, user_ids) if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH) else None
         vals, idx = ops.score_topk_sweep(kind, users_tab, user_ids, items_tab, max(Ks), sig_u, sig_i, c_dev, self.mask, 0)
@@ -285,9 +287,9 @@ class Evaluator(object):
         in a device array the kernels read at run time); item-sharded runs evaluate c by c."""
         from . import _lib
         cs = [float(c) for c in cs]
-        # The shared-listing-pass kernel multiplies in fp32 only.  With the bf16 candidate filter one value at a time is as
-        # fast or faster on larger catalogues (tools/bench_sweep.py, per value: Gowalla shape 0.43 ms against 0.48 for the
-        # four-c sweep; ML-10M shape 0.22 against 0.20): those go c by c through the seeded, graph-replayed evaluation.
+        # The shared-listing-pass kernels follow the candidate filter (k_score_stream_bs under "bf16": 0.31 ms per value
+        # on the Gowalla shape against 0.43 one evaluation at a time, tools/bench_sweep.py).  MACR_SWEEP_ONE_BY_ONE=1
+        # sends every value through the seeded, graph-replayed single evaluation instead (A/B switch).
         one_by_one = os.environ.get("MACR_SWEEP_ONE_BY_ONE", "0") == "1"
         if one_by_one or sharding.world()[1] > 1 or kind == ops.SCORE_NORMAL or self.n_queries > self.max_queries_per_pass:
             return torch.stack([self._means(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c).clone() for c in cs])
@@ -303,7 +305,7 @@ class Evaluator(object):
             if not self.use_graph:
                 outs.append(self._sweep_direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c_dev).clone())
                 continue
-            key = ("sweep", n, flavour, kind, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(),
+            key = ("sweep", n, flavour, self.filter, kind, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(),
                    items_tab.data_ptr(), Ks, w.data_ptr(), None if wu is None else wu.data_ptr(),
                    torch.cuda.current_stream().cuda_stream)
             entry = self._graphs.get(key)

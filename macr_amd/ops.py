@@ -162,12 +162,39 @@ def score_topk_splits(U, n_local, d):
 EVAL_FILTER_ENV, EVAL_FILTER_F32, EVAL_FILTER_BF16 = 0, 1, 2
 
 
+_FILTER_NAMES = {"env": EVAL_FILTER_ENV, "f32": EVAL_FILTER_F32, "bf16": EVAL_FILTER_BF16}
+
+
+def eval_filter_code(mode):
+    """"env" | "f32" | "bf16" (any case) or 0..2 -> MACR_EVAL_FILTER_*; anything else is refused by name (a typo in
+    MACR_EVAL_FILTER must not surface as a bare ValueError inside the first evaluation)."""
+    if isinstance(mode, str) and mode.strip().lower() in _FILTER_NAMES:
+        return _FILTER_NAMES[mode.strip().lower()]
+    if isinstance(mode, int) and not isinstance(mode, bool) and mode in _FILTER_NAMES.values():
+        return mode
+    raise MacrError(_lib.E_INVALID, "eval filter %r: accepted values are 'env', 'f32', 'bf16' (or 0, 1, 2)" % (mode,))
+
+
 def set_eval_filter(mode):
     """How macr_score_topk's listing pass forms its candidate lists (include/macr_hip.h MACR_EVAL_FILTER_*): "f32", "bf16"
     (bf16 matrix cores + fp32 re-scoring of the best candidates: the same ranking, bit for bit) or "env" (default:
     MACR_EVAL_FILTER in the environment, f32 when unset)."""
-    mode = {"env": EVAL_FILTER_ENV, "f32": EVAL_FILTER_F32, "bf16": EVAL_FILTER_BF16}.get(mode, mode)
-    check(_lib.lib().macr_set_eval_filter(int(mode)))
+    check(_lib.lib().macr_set_eval_filter(eval_filter_code(mode)))
+
+
+def test_bf16_products(users, items, c=0.0):
+    """TEST-ONLY (macr_test_bf16_products): the raw product of the bf16 filter's kernels for every (user row, item row)
+    pair and the margin the filter grants each user row -> ((U, N) fp32, (U,) fp32)."""
+    _require_f32(users=users, items=items)
+    U, d = users.shape
+    N = items.shape[0]
+    L = _lib.lib()
+    ws = torch.empty(L.macr_test_bf16_products_workspace_bytes(d, U, N), dtype=torch.uint8, device=items.device)
+    prod = torch.empty((U, N), dtype=_f32, device=items.device)
+    margin = torch.empty(U, dtype=_f32, device=items.device)
+    check(L.macr_test_bf16_products(d, U, N, _ptr(users, _f32), _ptr(items, _f32), float(c), _ptr(prod), _ptr(margin),
+                                    _ptr(ws), ws.numel(), _stream()))
+    return prod, margin
 
 
 SEED_WIDTH = 32          # MACR_SEED_WIDTH

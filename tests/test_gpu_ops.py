@@ -959,13 +959,14 @@ def test_large_batch_indexed_adam_equals_segment_reduce(ops, d, kind, hot, monke
     monkeypatch.delenv("MACR_SEG_UNFUSED", raising=False)
 
 
-def test_bf16_filter_scores_a_crowded_top_exactly(ops):
+@pytest.mark.parametrize("d", [64, 256])
+def test_bf16_filter_scores_a_crowded_top_exactly(ops, d):
     """Two hundred near-copies of one popular item: for every user the best ~200 scores differ by less than the bf16
     filter's error bound, so its 64 best candidates by bf16 score do not settle the exact top 20 -- the selection must
     notice (more than 64 candidates inside two margins of the K-th) and score every listed candidate in fp32 instead.
     The ranking is the oracle's, bit for bit, near-ties included, in one round under either filter."""
     rs = np.random.RandomState(91)
-    U, N, d, K = 300, 6000, 64, 20
+    U, N, K = 300, 6000, 20
     P = (rs.standard_normal((U, d)) * 0.3 + 0.4).astype(np.float32)              # users share a direction
     Q = (rs.standard_normal((N, d)) * 0.3).astype(np.float32)
     pop = (np.ones(d) * 0.5).astype(np.float32)
@@ -1022,3 +1023,92 @@ def test_repair_round_of_a_few_query_blocks(ops, eval_filter, bad_blocks):
     val, idx, _ = ops.topk_merge(v, ix)
     assert np.array_equal(idx.cpu().numpy(), wi)
     assert stats.cpu().numpy().tolist() == [0, 0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The invariant the bf16 candidate filter rests on: |raw product of the bf16 kernels - fp32 fmaf chain| <= the margin the
+# filter subtracts from a query's threshold, element-wise (eval_kernels.hip filter_rel / filter_margin).  Random data never
+# attains a worst-case bound, so the operands here are built to: same-sign products (sum_k |u_k q_k| = |s|), u parallel to
+# q (Cauchy-Schwarz tight), split residuals at their maximum, magnitudes over 24 binades in one row, one dominant term,
+# values on bf16 rounding ties.  macr_test_bf16_products runs the listing pass's own MFMA sequence.
+# ---------------------------------------------------------------------------------------------------------------------
+def _with_low_bits(x, low):
+    """fp32 array whose low 16 mantissa bits are `low` (what the two bf16 roundings see)"""
+    b = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return ((b & np.uint32(0xffff0000)) | np.asarray(low, dtype=np.uint32)).view(np.float32)
+
+
+def adversarial_operands(case, U, N, d, rs):
+    ties = np.array([0x8000, 0x7f80, 0x807f, 0x7fff, 0x8080, 0xff80, 0x0080, 0x7f7f, 0x80ff, 0xffff], dtype=np.uint32)
+    if case == "same_sign":                      # every product positive: no cancellation anywhere in the accumulation
+        P = rs.uniform(0.5, 1.0, (U, d)); Q = rs.uniform(0.5, 1.0, (N, d))
+    elif case == "aligned":                      # items are (scaled) copies of the users: |u . q| = |u| |q|
+        P = rs.standard_normal((U, d))
+        Q = P[rs.randint(0, U, N)] * rs.uniform(0.9, 1.0, (N, 1)) * rs.choice([-1.0, 1.0], (N, 1))
+    elif case == "worst_residual":               # same sign, parallel, every mantissa with its low 16 bits on a tie / just off it
+        P = _with_low_bits(rs.uniform(1.0, 2.0, (U, d)), ties[rs.randint(0, len(ties), (U, d))])
+        Q = _with_low_bits(rs.uniform(1.0, 2.0, (N, d)), ties[rs.randint(0, len(ties), (N, d))])
+    elif case == "binades":                      # magnitudes 2^-20 .. 2^4 inside one row, random signs
+        P = np.ldexp(rs.uniform(1.0, 2.0, (U, d)), rs.randint(-20, 5, (U, d))) * rs.choice([-1.0, 1.0], (U, d))
+        Q = np.ldexp(rs.uniform(1.0, 2.0, (N, d)), rs.randint(-20, 5, (N, d))) * rs.choice([-1.0, 1.0], (N, d))
+    elif case == "binades_same_sign":
+        P = np.ldexp(rs.uniform(1.0, 2.0, (U, d)), rs.randint(-20, 5, (U, d)))
+        Q = np.ldexp(rs.uniform(1.0, 2.0, (N, d)), rs.randint(-20, 5, (N, d)))
+    elif case == "dominant":                     # one term carries the product, the others sit 2^-12 .. 2^-24 below it
+        P = rs.standard_normal((U, d)) * 2.0 ** -12; Q = rs.standard_normal((N, d)) * 2.0 ** -12
+        k = rs.randint(0, d, U); P[np.arange(U), k] = rs.uniform(1.0, 2.0, U) * 64.0
+        Q[np.arange(N), rs.randint(0, d, N)] = rs.uniform(1.0, 2.0, N) * 64.0
+        Q[: N // 2, :] = np.abs(Q[: N // 2, :]); Q[np.arange(N // 2), k[rs.randint(0, U, N // 2)]] = 100.0
+    elif case == "ties":                         # every value exactly half way between two bf16 numbers (both roundings tie)
+        P = _with_low_bits(rs.standard_normal((U, d)), 0x8000); Q = _with_low_bits(rs.standard_normal((N, d)), 0x8000)
+    elif case == "lo_ties":                      # hi exact-ish, the SECOND rounding on a tie
+        P = _with_low_bits(rs.standard_normal((U, d)), 0x0080); Q = _with_low_bits(rs.standard_normal((N, d)), 0x7f80)
+    elif case == "big_plus_small":               # 2^24 + sixteen terms below half an ulp of it: how the accumulator rounds
+        P = np.ones((U, d)); Q = np.full((N, d), 1.0 + 2.0 ** -7)
+        P[:, 0] = 4096.0; Q[:, 0] = 4096.0
+        Q[N // 2:, 1:] *= -1.0
+    elif case == "gaussian":
+        P = rs.standard_normal((U, d)) * 0.3; Q = rs.standard_normal((N, d)) * 0.3
+    else:
+        raise ValueError(case)
+    return np.ascontiguousarray(P, dtype=np.float32), np.ascontiguousarray(Q, dtype=np.float32)
+
+
+BF16_CASES = ["same_sign", "aligned", "worst_residual", "binades", "binades_same_sign", "dominant", "ties", "lo_ties",
+              "big_plus_small", "gaussian"]
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_bf16_filter_margin_bounds_the_product_error(ops, case, d, record_property):
+    rs = np.random.RandomState(1000 + d + 7 * BF16_CASES.index(case))
+    U, N = 96 + 5, 480 + 3                       # ragged against the 32 x 32 tiles
+    P, Q = adversarial_operands(case, U, N, d, rs)
+    want = oracle.score_matrix(oracle.SCORE_NORMAL, P, Q)                 # the k-ascending fp32 fmaf chain of every kernel
+    for c in (0.0, 40.0):
+        prod, margin = ops.test_bf16_products(dev(P), dev(Q), c)
+        prod, margin = prod.cpu().numpy(), margin.cpu().numpy()
+        assert np.isfinite(prod).all() and np.isfinite(margin).all() and (margin > 0).all()
+        err = np.abs(prod.astype(np.float64) - want.astype(np.float64))
+        worst = (err / margin[:, None].astype(np.float64)).max()
+        assert (err <= margin[:, None]).all(), "case %s d=%d c=%g: error reaches %.3f of the margin" % (case, d, c, worst)
+        if c == 0.0:
+            # how much of the RELATIVE term the error uses where the norm bound is tight (reported, and kept below 1)
+            un = np.sqrt((P.astype(np.float64) ** 2).sum(1)); qn = np.sqrt((Q.astype(np.float64) ** 2).sum(1))
+            rel_used = (err / (un[:, None] * qn.max())).max() / (3.2 / 65536 + 8.0 * d / 16777216)
+            record_property("rel_used", float(rel_used))
+            print("bf16 bound %-18s d=%3d: max err/margin %.3f, of the relative term %.3f" % (case, d, worst, rel_used))
+            assert rel_used <= 1.0
+    # the margin is not vacuous either: it stays within a small factor of the documented constant times |u| max|q|
+    lim = (3.2 / 65536 + 8.0 * d / 16777216 + 1.2e-6) * 1.001 * un * qn.max() * 1.0003 + 1e-6 * 40.0 + 1e-30
+    assert (margin <= lim * 1.01).all()
+
+
+def test_bf16_filter_margin_constant_covers_its_stated_bound():
+    """filter_rel(d) >= 3.2 * 2^-16 + 6 d * 2^-24 for every supported d (round 3 shipped 1e-4 < 1.39e-4 at d = 256); the
+    header's prose quotes the same numbers."""
+    src = open(os.path.join(REPO, "macr_amd", "csrc", "eval_kernels.hip")).read()
+    assert "return 3.2f / 65536.f + 8.f * (float)d / 16777216.f;" in src
+    assert "kFilterRel" not in src
+    for d in (32, 64, 128, 256):
+        assert 3.2 / 65536 + 8.0 * d / 16777216 >= 3.2 / 65536 + 6.0 * d / 16777216 + d / 16777216
