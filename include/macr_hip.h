@@ -218,14 +218,20 @@ int macr_sample_triples_many(uint64_t seed, uint64_t step0, int n_steps, int B, 
  * wavefront serialises a hub; the piece of a hub row that finishes last sums the
  * partial rows in fixed order (deterministic whichever piece that is).
  *   rowptr_host (HOST) int32[N+1]
- *   plan_host   (HOST) >= macr_spmm_plan_bytes(N, rowptr_host) bytes, written by
+ *   col_host / val_host (HOST, both or neither) int32 / fp32 [nnz]: with them the plan also carries the ENTRY STREAM of
+ *               the dense layers -- the matrix once more in row order, every row followed by an end marker that makes
+ *               the wave gather the row's running sum, cut into chunks of a few hundred entries (k_spmm_stream:
+ *               no per-row descriptor, no per-row launch; rows above 512 entries in pieces of 255).  The device copy
+ *               must be 64-byte aligned.  Without them every layer runs the one-wavefront-per-row kernel.
+ *   plan_host   (HOST) >= macr_spmm_plan_bytes(...) bytes, written by
  *               macr_spmm_plan_build; the caller uploads a copy to the device and
  *               passes BOTH pointers (device copy for the kernels, host copy for the
  *               launch geometry) to the LightGCN entry points.  Passing NULL for both
  *               selects the plain one-wavefront-per-row kernel.
  * -------------------------------------------------------------------------*/
-size_t macr_spmm_plan_bytes(int N, const int32_t *rowptr_host);
-int    macr_spmm_plan_build(int N, const int32_t *rowptr_host, void *plan_host, size_t plan_bytes);
+size_t macr_spmm_plan_bytes(int N, const int32_t *rowptr_host, const int32_t *col_host, const float *val_host);
+int    macr_spmm_plan_build(int N, const int32_t *rowptr_host, const int32_t *col_host, const float *val_host,
+                            void *plan_host, size_t plan_bytes);
 size_t macr_lgcn_work_floats(int N, int d, const void *plan_host);   /* size of `work` below, in floats */
 
 /* ---------------------------------------------------------------------------

@@ -52,8 +52,8 @@ SIGNATURES = {
     "macr_shard_apply": (_i, [_i] * 7 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), _p, _z, _p]),
     "macr_sample_triples": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _i, _p, _i, _p, _p, _p, _p]),
     "macr_sample_triples_many": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
-    "macr_spmm_plan_bytes": (_z, [_i, _p]),
-    "macr_spmm_plan_build": (_i, [_i, _p, _p, _z]),
+    "macr_spmm_plan_bytes": (_z, [_i, _p, _p, _p]),
+    "macr_spmm_plan_build": (_i, [_i, _p, _p, _p, _p, _z]),
     "macr_lgcn_work_floats": (_z, [_i, _i, _p]),
     "macr_lgcn_propagate": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "macr_lgcn_train_workspace_bytes": (_z, [_i, _i, _i, _p]),

@@ -12,6 +12,7 @@
 // 8-bit digits; a wave ranks 64 keys at a time with ballots (no LDS atomics in the ranking step); every pass is
 // stable, so equal rows keep their batch order and the summation order of a row is the same in every run.
 #pragma once
+#include <algorithm>
 #include "common.hpp"
 
 namespace macr {
@@ -250,9 +251,17 @@ static inline int sort_tile_for(int n) {
     return n <= kSortSmallMax ? kSortTileSmall : n <= kSortMidMax ? kSortTileMid : kSortTile;
 }
 constexpr int kSortMaxPasses = 4;
+// Words of tile counts + digit totals a sort of UP TO n pairs may need: monotone in n although the tile size is not
+// (n = 2^17 sorts in 64 tiles of 2048 keys, n = 2^17 + 1 in 17 of 8192), so a workspace sized for a batch capacity
+// serves every smaller batch (a MACR_SORT_TILE override counts as the small tile: the largest count).
 static inline size_t sort_hist_words(int n) {
-    const int t = sort_tile_for(n);
-    return (size_t)kRadix * ((n + t - 1) / t) + (size_t)kSortMaxPasses * kRadix;      // tile counts + digit totals per pass
+    size_t tiles = 0;
+    const int small_n = n < kSortSmallMax ? n : kSortSmallMax, mid_n = n < kSortMidMax ? n : kSortMidMax;
+    tiles = (size_t)(small_n + kSortTileSmall - 1) / kSortTileSmall;
+    if (n > kSortSmallMax) tiles = std::max(tiles, (size_t)(mid_n + kSortTileMid - 1) / kSortTileMid);
+    if (n > kSortMidMax) tiles = std::max(tiles, (size_t)((size_t)n + kSortTile - 1) / kSortTile);
+    if (getenv("MACR_SORT_TILE")) tiles = std::max(tiles, ((size_t)n + kSortTileSmall - 1) / kSortTileSmall);
+    return (size_t)kRadix * tiles + (size_t)kSortMaxPasses * kRadix;
 }
 
 template <int TILE>

@@ -136,6 +136,21 @@ __device__ __forceinline__ float ld_elem(const float *__restrict__ X, int c, int
     const uint32_t off = ((uint32_t)c * (uint32_t)D + (uint32_t)k) * 4u;
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(X) + off);
 }
+#ifdef MACR_ABL_SPMM_LDS                                          // timing probe (wrong results): gathers from LDS rows
+__shared__ float abl_lds[128 * 64];
+template <int D>
+__device__ __forceinline__ float ld_elem_lds(int c, int k) { return abl_lds[(c & 127) * 64 + (k & 63)]; }
+#endif
+
+// the same with the row index in a VGPR (wave-uniform all the same: it came out of LDS) and the lane's byte offset given
+template <int D>
+__device__ __forceinline__ float ld_elem_v(const float *__restrict__ X, int c, uint32_t lane_bytes) {
+#ifdef MACR_ABL_SPMM_ROWMASK
+    c &= MACR_ABL_SPMM_ROWMASK;
+#endif
+    const uint32_t off = (uint32_t)c * (uint32_t)(D * 4) + lane_bytes;     // (an end marker's bit 31 leaves with the overflow)
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(X) + off);
+}
 
 __device__ __forceinline__ bool row_flag(const int32_t *cnt, int r) { return cnt[r] != 0; }
 
@@ -188,7 +203,12 @@ __device__ __forceinline__ void gather_batches(const int32_t *__restrict__ col, 
         } else {
             w[k] = wgt(k);                                       // wave-uniform
 #pragma unroll
-            for (int v = 0; v < G::NV; ++v) x[k][v] = ld_elem<D>(X, c[k], lane + 64 * v);
+            for (int v = 0; v < G::NV; ++v) {
+#ifdef MACR_ABL_SPMM_LDS
+                if (MACR_ABL_SPMM_LDS == 1 || (k & 1)) { x[k][v] = ld_elem_lds<D>(c[k], lane + 64 * v); continue; }
+#endif
+                x[k][v] = ld_elem<D>(X, c[k], lane + 64 * v);
+            }
         }
     }
 #pragma unroll
@@ -492,6 +512,289 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
     }
 }
 
+// =====================================================================================================================
+// STREAM kernel (round 4): the dense layers.
+//
+// What the layer's time was made of (round 4 measurements, tools/spmm_bench.hip): with every gather served from LDS the
+// layer still took 48 of its 51 us, with the gathers AND their index loads compiled out 14 -- the kernel was never short
+// of gather bandwidth, it was a sum of chains: per wave  launch -> descriptor (cold) -> column/weight window (cold,
+// scalar) -> gathers -> next window ... with nothing in flight while the next indices travel, 70 000 times.  Occupancy
+// is at the hardware's 32 waves per CU, so the only levers are fewer, fatter work items and shorter chains:
+//   * a work item is a CHUNK of a plan-owned entry stream (pcw: the matrix in row order as (column, weight) pairs, a few
+//     hundred entries, whole rows only -- rows above kStreamHub entries are cut into pieces that are chunks of their
+//     own); the wave walks it in rounds of 32 entries: 32 gathers in flight, 32 fmas;
+//   * rows end INSIDE the stream: after a row's neighbours comes one more entry {row | bit 31, 0} whose gather reads the
+//     row's S_in instead of X, always as the LAST entry of a group of 8 (padding in front of it) -- the wave then holds
+//     (S_in + A X)[row] and stores; no descriptor, no row pointer, no per-row launch, one uniform branch per 8 entries;
+//   * the stream does not touch the scalar caches (see the kernel): asynchronous LDS-DMA fills, broadcast LDS reads;
+//   * rows without neighbours never enter the stream: each chunk takes its share of a list of them.
+// =====================================================================================================================
+struct StreamHeader {             // all int32; follows the row plan at PlanHeader.reserved (in int32 units)
+    int32_t magic, n_chunks, n_sb, n_empty, n_slots, n_groups, n_split, n_entries;
+};
+constexpr int32_t kStreamMagic = 0x4d535452;   // "MSTR"
+constexpr int kStreamHub = 512;   // rows with more neighbours are cut into pieces
+constexpr int kStreamPiece = 256; // entries per piece (255 neighbours + its end marker)
+// layout after the header: chunk_desc[n_chunks] = {first sub-batch (32 entries), end, first empty row | count << 24, slot or -1}, empties[n_empty],
+// slot_group[n_slots], group_slot0[n_groups+1], group_split[n_groups], split_group0[n_split+1],
+// split_row[n_split], then (64-byte aligned) pcw[n_entries + 128] = {column | bit 31 for an end marker, weight bits (marker: 0 row, 1 piece)}
+struct StreamView {
+    const int4 *chunk_desc;
+    const int32_t *empties;
+    const int32_t *slot_group, *group_slot0, *group_split, *split_group0, *split_row;
+    const int2 *pcw;
+};
+// plan: the start of the whole plan buffer (host or device copy), off: PlanHeader.reserved.  The arrays sit at offsets
+// that are multiples of 64 bytes from the START of the buffer (the device copy is allocated 256-byte aligned).
+__host__ __device__ inline StreamView view_stream(const void *plan, int32_t off, const StreamHeader &h) {
+    const int32_t *base = reinterpret_cast<const int32_t *>(plan);
+    size_t o = (size_t)off + sizeof(StreamHeader) / 4;
+    o = (o + 3) / 4 * 4;                                           // chunk descriptors 16-byte aligned
+    auto take = [&](size_t n) { const int32_t *p = base + o; o += n; return p; };
+    StreamView v;
+    v.chunk_desc = reinterpret_cast<const int4 *>(take(4 * (size_t)h.n_chunks));
+    v.empties = take(h.n_empty);
+    v.slot_group = take(h.n_slots);
+    v.group_slot0 = take(h.n_groups + 1);
+    v.group_split = take(h.n_groups);
+    v.split_group0 = take(h.n_split + 1);
+    v.split_row = take(h.n_split);
+    o = (o + 15) / 16 * 16;
+    v.pcw = reinterpret_cast<const int2 *>(take(2 * ((size_t)h.n_entries + 128)));
+    return v;
+}
+
+
+// An end marker's gather must not cost a select per entry: it reads S_in through X's base register with s_in_bytes added
+// to its offset, where S_in = X + s_in_bytes -- 0 for the first layer (S_in is X), N rows for the others, whose buffers
+// the launcher keeps as pairs [X | S_in].  Only a group's last entry can be a marker (bit 31 of its index).
+// The kernel takes ONE struct: what the rounds need (hot) is read from the argument as usual and lives in SGPRs; what only a
+// flush or the hub reduction needs (cold) is fetched from the kernel-argument segment on the spot -- otherwise the compiler
+// keeps all of it in scalar registers for the whole kernel and spills the operands of the rounds.
+struct StreamHub { const int32_t *plan; int32_t off; int32_t pad; int32_t *arrivals; float *slab; };
+struct StreamFuse { int32_t *cnt; float *T, *m, *v; const StepScalars *scal; float *dE; double *emb; };
+struct StreamArgs {
+    // hot
+    const int4 *chunk_desc; const int32_t *empties; const int2 *pcw; uint32_t s_in_bytes; uint32_t pad0;
+    const float *X;               // end markers gather S_in through X too:
+    const float *S_in;            // S_in == X + s_in_bytes (the launcher lays the layer buffers out that way, or passes X itself)
+    int n_chunks; float scale;
+    // cold
+    float *Y; float *S_out;
+    float b1, b2, eps, coef;
+    StreamHub hub; StreamFuse fz;
+};
+
+// One row's result: Y = A X, S_out = (S_in + A X) * scale -- or, FUSE, the optimizer on T[r] (see AdamFuse).
+template <int D, bool FUSE>
+__device__ __forceinline__ void stream_row_out(int r, const float (&acc)[RowGeom<D>::NV], const float (&s)[RowGeom<D>::NV],
+                                               int lane, float scale) {
+    constexpr int NV = RowGeom<D>::NV;
+    const auto *ka = (const __attribute__((address_space(4))) StreamArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    if (FUSE) {
+        int32_t *cnt = ka->fz.cnt;
+        float *fT = ka->fz.T, *fm = ka->fz.m, *fv = ka->fz.v, *fdE = ka->fz.dE;
+        const int c = cnt[r];                                    // references of the batch to this row (wave-uniform)
+        const float lr_t = ka->fz.scal->lr_t;
+        const float b1 = ka->b1, b2 = ka->b2, eps = ka->eps, coef = ka->coef;
+        float th[NV], m[NV], vv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const size_t o = (size_t)r * D + lane + 64 * v;
+            th[v] = fT[o]; m[v] = fm[o]; vv[v] = fv[o];
+        }
+        float sq = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const size_t o = (size_t)r * D + lane + 64 * v;
+            float g = (s[v] + acc[v]) * scale;
+            if (c) { g = fmaf(coef * (float)c, th[v], g); sq = fmaf(th[v], th[v], sq); fdE[o] = 0.f; }
+            adam1(th[v], m[v], vv[v], g, lr_t, b1, b2, eps);
+            fT[o] = th[v]; fm[o] = m[v]; fv[o] = vv[v];
+        }
+        if (c) {                                                 // wave-uniform
+            sq = wave_sum(sq);
+            if (lane == 0) {
+                atomicAdd(ka->fz.emb + (r & 2047), (double)c * (double)sq);
+                cnt[r] = 0;
+            }
+        }
+        return;
+    }
+    float *Y = ka->Y, *S_out = ka->S_out;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const size_t o = (size_t)r * D + lane + 64 * v;
+        if (Y) Y[o] = acc[v];
+        if (S_out) S_out[o] = (s[v] + acc[v]) * scale;
+    }
+}
+
+template <int D, bool FUSE>
+__global__ __launch_bounds__(256) void k_spmm_stream(const StreamArgs A) {
+    const int4 *__restrict__ chunk_desc = A.chunk_desc;
+    const int32_t *__restrict__ empties = A.empties;
+    const int2 *__restrict__ pcw = A.pcw;
+    const float *__restrict__ X = A.X;
+    const float *S_in = A.S_in;                                  // (the rounds find it behind X: see StreamArgs)
+    struct { int n_chunks; float scale; } P = {A.n_chunks, A.scale};
+    using G = RowGeom<D>;
+    constexpr int NV = G::NV;
+    constexpr int NE = 32 / NV;                                  // entries per round of gathers (32 row registers)
+    static_assert(!G::kHalf, "d = 32 runs the row kernel");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wid);
+    if (w >= P.n_chunks) return;
+    const int4 cd = chunk_desc[w];                               // {first sub-batch, end, first empty row | n << 24, slot or -1}
+    const int sb0 = cd.x, sb1 = cd.y;
+    // The index stream travels through LDS.  (Round 4 measured what the scalar path costs: with the gathers compiled out
+    // the kernel took as long as with them -- 27 MB of (index, weight) pairs through the scalar data caches, one 64-byte
+    // line per miss and a handful of misses in flight per cache, is ~50 us whatever else happens; with the scalar loads
+    // compiled out it took 36.)  A window of 128 entries = 1 KB is ONE LDS-DMA instruction (16 bytes per lane, no
+    // registers, asynchronous); three windows per wave form a ring, filled two windows ahead; the rounds read the pairs
+    // back as broadcasts (ds_read_b128: two entries per instruction).
+    constexpr int kWin = 128, kRing = 3;
+    __shared__ int4 ring[4][kRing][kWin / 2];                    // [wave][slot][pair of entries]
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    const int n_rounds = (sb1 - sb0) * (32 / NE);
+    const int n_win = (sb1 - sb0 + 3) / 4;
+    auto fill = [&](int j) {                                     // window j of the chunk -> ring slot j % kRing (no wait)
+        const char *src = reinterpret_cast<const char *>(pcw) + ((size_t)sb0 * 32 + (size_t)j * kWin) * 8 + lane * 16;
+        __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)&ring[wid][j % kRing][0], 16, 0, 0);
+    };
+    if (n_win > 0) fill(0);
+    if (n_win > 1) fill(1);
+    const float zero[NV] = {};
+    // rows without neighbours: A X = 0
+    for (int k = cd.z & 0xffffff, k1 = k + ((uint32_t)cd.z >> 24); k < k1; ++k) {
+        const int r = empties[k];
+        float s[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) s[v] = S_in[(size_t)r * D + lane + 64 * v];
+        stream_row_out<D, FUSE>(r, zero, s, lane, P.scale);
+    }
+    float acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+    constexpr int NG = NE / 8;                                   // groups of 8 entries per round: a row can only end at a group's last entry
+    constexpr int RPW = kWin / NE;                               // rounds per window
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    for (int k = 0; k < n_rounds; ++k) {                         // wave-uniform
+        if (k % RPW == 0) {
+            // a new window: it was asked for two windows ago.  Every gather issued since has been waited for, so this wait
+            // is for the fills alone; then the slot of the window before is free for the window after next.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (k / RPW + 2 < n_win) fill(k / RPW + 2);
+        }
+        const int4 *win = &ring[wid][(k / RPW) % kRing][(k % RPW) * (NE / 2)];
+        float x[NE][NV], wgt[NE];
+        int cend[NG];
+#pragma unroll
+        for (int e = 0; e < NE; e += 2) {
+            const int4 q = win[e / 2];                           // broadcast: every lane reads the same two entries
+            wgt[e] = __int_as_float(q.y); wgt[e + 1] = __int_as_float(q.w);
+            const int c0 = q.x, c1 = q.z;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) x[e][v] = ld_elem_v<D>(X, c0, lane4 + 256u * v);
+            // a group's last entry may be an end marker (bit 31): it gathers S_in, which sits s_in_bytes behind X
+            uint32_t extra = 0u;
+            if ((e + 1) % 8 == 7) { cend[(e + 1) / 8] = c1; extra = (uint32_t)(c1 >> 31) & A.s_in_bytes; }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) x[e + 1][v] = ld_elem_v<D>(X, c1, lane4 + 256u * v + extra);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int e = 8 * g; e < 8 * g + 7; ++e) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] = fmaf(wgt[e], x[e][v], acc[v]);
+            }
+            const int c7 = __builtin_amdgcn_readfirstlane(cend[g]);
+            if (c7 >= 0) {                                       // wave-uniform: the usual case, an entry like the others
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] = fmaf(wgt[8 * g + 7], x[8 * g + 7][v], acc[v]);
+            } else if (__builtin_amdgcn_readfirstlane(__float_as_int(wgt[8 * g + 7])) == 0) {   // the row's end marker: x = S_in of the row
+                stream_row_out<D, FUSE>(c7 & 0x7fffffff, acc, x[8 * g + 7], lane, P.scale);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+            }                                                    // (weight bits 1: the end of a piece, always its chunk's last entry)
+        }
+    }
+    const int slot = cd.w;                                       // >= 0: the chunk is a piece of a hub row, this is its slot
+    if (slot < 0) return;
+    // A piece of a hub row (see k_spmm_row): partial rows travel write-through, whoever arrives last sums them in slot
+    // order -- the pieces of a group, then the groups of the row -- and finishes the row.
+    const auto *ka = (const __attribute__((address_space(4))) StreamArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const StreamHub hub = {ka->hub.plan, ka->hub.off, 0, ka->hub.arrivals, ka->hub.slab};
+    StreamHeader sh;
+    {
+        const int32_t *hp = hub.plan + hub.off;
+        sh.magic = hp[0]; sh.n_chunks = hp[1]; sh.n_sb = hp[2]; sh.n_empty = hp[3]; sh.n_slots = hp[4]; sh.n_groups = hp[5];
+        sh.n_split = hp[6]; sh.n_entries = hp[7];
+    }
+    const StreamView sv = view_stream(hub.plan, hub.off, sh);
+    float *slab = hub.slab;
+    int32_t *arrivals = hub.arrivals;
+    auto publish = [&](int at) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            __hip_atomic_store(slab + (size_t)at * D + lane + 64 * v, acc[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto last_of = [&](int counter, int expected) {
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(arrivals + counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != expected - 1) return false;
+        if (lane == 0) __hip_atomic_store(arrivals + counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    };
+    auto sum_range = [&](int p0, int p1) {
+        float p[kGroup][NV];
+#pragma unroll
+        for (int q = 0; q < kGroup; ++q) {
+            const int sq = p0 + q < p1 ? p0 + q : p1 - 1;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                p[q][v] = __hip_atomic_load(slab + (size_t)sq * D + lane + 64 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+#pragma unroll
+        for (int q = 0; q < kGroup; ++q) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += p0 + q < p1 ? p[q][v] : 0.f;
+        }
+    };
+    const int g = sv.slot_group[slot];
+    const int s0 = sv.group_slot0[g], s1 = sv.group_slot0[g + 1];
+    const int k = sv.group_split[g];
+    const int g0 = sv.split_group0[k], g1 = sv.split_group0[k + 1];
+    if (s1 - s0 > 1) {
+        publish(slot);
+        if (!last_of(g, s1 - s0)) return;
+        sum_range(s0, s1);
+    }
+    if (g1 - g0 > 1) {
+        publish(sh.n_slots + g);
+        if (!last_of(sh.n_groups + k, g1 - g0)) return;
+        for (int q0 = g0; q0 < g1; q0 += kGroup) {
+            float part[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) part[v] = q0 == g0 ? 0.f : acc[v];
+            sum_range(sh.n_slots + q0, sh.n_slots + (q0 + kGroup < g1 ? q0 + kGroup : g1));
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += part[v];
+        }
+    }
+    const int r = sv.split_row[k];
+    float s[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s[v] = S_in[(size_t)r * D + lane + 64 * v];
+    stream_row_out<D, FUSE>(r, acc, s, lane, P.scale);
+}
+
 // out = in * scale   (n_layers == 0 degenerate case) -- float4 per lane
 __global__ void k_scale_copy(size_t n_vec, const float *__restrict__ in, float *__restrict__ out, float scale) {
     for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * blockDim.x) {
@@ -500,16 +803,29 @@ __global__ void k_scale_copy(size_t n_vec, const float *__restrict__ in, float *
     }
 }
 
-// work: [3*N*d] two alternating layer buffers and the running layer sum (the last layer writes E from it: no layer
-// updates its output in place), [n_slots*d] slab and [n_split] arrival counters (zero between calls) when a plan is given.
+// what the hub reduction needs behind the three layer buffers: partial rows of pieces and groups + arrival counters, for
+// whichever of the plan's two schedules (row items / entry stream) has more of them
+static void plan_extras(const void *plan_host, size_t &slab_rows, size_t &counters) {
+    const PlanHeader *h = static_cast<const PlanHeader *>(plan_host);
+    slab_rows = (size_t)h->n_slots + h->n_groups;
+    counters = (size_t)h->n_groups + h->n_split;
+    if (h->reserved > 0) {
+        const StreamHeader *sh = reinterpret_cast<const StreamHeader *>(static_cast<const int32_t *>(plan_host) + h->reserved);
+        slab_rows = std::max(slab_rows, (size_t)sh->n_slots + sh->n_groups);
+        counters = std::max(counters, (size_t)sh->n_groups + sh->n_split);
+    }
+}
+
+// work: [4*N*d] two pairs [layer output | running layer sum] used alternately (no layer updates its input in place), [n_slots*d] slab and [n_split] arrival counters (zero between calls) when a plan is given.
 // sp (may be NULL) with mode kSparseOut: only the flagged rows of E are wanted (computed in the last layer);
 // with mode kSparseIn: E0 is row-sparse, only its flagged rows are non-zero (and only they are read).
 int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col, const float *val,
                      const void *plan_dev, const void *plan_host_header, const float *E0, float *E, float *work,
                      hipStream_t st, const SparseCtx *sp, int sparse_mode, const AdamFuse *fuse) {
     const size_t nd = (size_t)N * d;
-    float *bufA = work, *bufB = work + nd;            // alternating layer outputs
-    float *sum = work + 2 * nd;                       // E0 + A E0 + ... up to the layer before the last
+    // layer buffers as PAIRS [X | S]: layer l reads (X, S_in) from one pair -- or E0 for both -- and writes (Y, S_out)
+    // into the other, so that S_in == X + nd wherever it is not X itself (k_spmm_stream gathers S_in through X)
+    float *pairX[2] = {work, work + 2 * nd}, *pairS[2] = {work + nd, work + 3 * nd};
     const float inv = 1.0f / (float)(n_layers + 1);
     if (n_layers == 0) {
         k_scale_copy<<<1024, 256, 0, st>>>(nd / 4, E0, E, 1.0f);
@@ -526,15 +842,26 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
         a.n_items = ph.n_items; a.n_slots = ph.n_slots;
         a.items = pv.item; a.slot_group = pv.slot_group; a.group_slot0 = pv.group_slot0; a.group_split = pv.group_split;
         a.split_group0 = pv.split_group0; a.n_groups = ph.n_groups;
-        a.slab = work + 3 * nd;
-        a.arrivals = reinterpret_cast<int32_t *>(a.slab + ((size_t)ph.n_slots + ph.n_groups) * d);
+        a.slab = work + 4 * nd;
+        size_t slab_rows, counters;
+        plan_extras(plan_host_header, slab_rows, counters);
+        a.arrivals = reinterpret_cast<int32_t *>(a.slab + slab_rows * d);
+    }
+    // the entry stream (k_spmm_stream) runs the dense layers of d >= 64 when the plan carries one
+    const bool have_stream = plan_dev && ph.reserved > 0 && d >= 64;
+    StreamHeader sh = {};
+    StreamView sv = {};
+    if (have_stream) {
+        sh = *reinterpret_cast<const StreamHeader *>(static_cast<const int32_t *>(plan_host_header) + ph.reserved);
+        sv = view_stream(plan_dev, ph.reserved, sh);
     }
     const int n_waves = plan_dev ? ph.n_items : N;
     const float *X = E0;
     const float *S_in = E0;
     for (int l = 0; l < n_layers; ++l) {
         const bool last = (l == n_layers - 1);
-        float *Y = last ? nullptr : ((l & 1) ? bufB : bufA);
+        float *Y = last ? nullptr : pairX[l & 1];
+        float *sum = pairS[l & 1];
         const float scale = last ? inv : 1.0f;        // running sum lives in E; first layer reads E0 as S_in
         const int mode = !sp ? kDense
                          : (sparse_mode == kSparseOut && last) ? kSparseOut
@@ -546,6 +873,37 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
         const int waves = mode == kSparseOut ? (plan_dev ? ph.n_slots : 0) + 3 * sp->B : n_waves;
         const int grid = (waves + 3) / 4;
         const char *name = mode == kSparseOut ? "spmm_csr_rows" : mode == kSparseIn ? "spmm_csr_sparse" : fused ? "spmm_csr+adam" : "spmm_csr";
+        // (the fused layer stays with the row kernel: there the optimizer's operands travel with the row's first gathers,
+        // in the stream kernel they would be a dependent trip per row end -- measured 67 against 62 us)
+        static const bool stream_fused = getenv("MACR_SPMM_STREAM_FUSED") && atoi(getenv("MACR_SPMM_STREAM_FUSED")) != 0;
+        if (have_stream && mode == kDense && (!fused || stream_fused) && sh.magic == kStreamMagic && (a.S_in == a.X || a.S_in == a.X + nd) &&
+            2 * nd * 4 < ((size_t)1 << 32)) {
+            StreamArgs sa = {};
+            sa.chunk_desc = sv.chunk_desc; sa.empties = sv.empties; sa.pcw = sv.pcw;
+            sa.s_in_bytes = a.S_in == a.X ? 0u : (uint32_t)(nd * 4);    // (S_in is X itself, or sits N rows behind it: the pair layout)
+            sa.X = a.X; sa.S_in = a.S_in; sa.n_chunks = sh.n_chunks; sa.scale = scale;
+            sa.Y = a.Y; sa.S_out = a.S_out; sa.b1 = af.b1; sa.b2 = af.b2; sa.eps = af.eps; sa.coef = af.coef;
+            sa.hub = StreamHub{static_cast<const int32_t *>(plan_dev), ph.reserved, 0, a.arrivals, a.slab};
+            sa.fz = StreamFuse{fused ? sp->cnt : nullptr, af.T, af.m, af.v, af.scal, af.dE, af.emb_acc};
+            const int sgrid = (sh.n_chunks + 3) / 4;
+#define MACR_STREAM_ARGS sa
+#define MACR_STREAM_ROW(D_)                                                                       \
+    do {                                                                                          \
+        if (fused) k_spmm_stream<D_, true><<<sgrid, 256, 0, st>>>(MACR_STREAM_ARGS);              \
+        else k_spmm_stream<D_, false><<<sgrid, 256, 0, st>>>(MACR_STREAM_ARGS);                   \
+    } while (0)
+            switch (d) {
+                case 64: MACR_STREAM_ROW(64); break;
+                case 128: MACR_STREAM_ROW(128); break;
+                case 256: MACR_STREAM_ROW(256); break;
+            }
+#undef MACR_STREAM_ROW
+#undef MACR_STREAM_ARGS
+            MACR_CHECK_LAUNCH(fused ? "spmm_stream+adam" : "spmm_stream", st);
+            X = Y;
+            S_in = sum;
+            continue;
+        }
         const SpmmScalars ps = {a.N, a.n_items, a.n_slots, a.n_groups, a.scale, a.sp.B, a.sp.n_users, a.sp.chunk, a.sp.count,
                                 af.b1, af.b2, af.eps, af.coef};
 #define MACR_SPMM_ARGS ps, a.rowptr, a.col, a.val, a.items, a.slot_group, a.group_slot0, a.group_split, a.split_group0, \
@@ -625,32 +983,146 @@ static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) 
     out.insert(out.end(), split_row.begin(), split_row.end());
 }
 
+
+// The entry stream of k_spmm_stream (see there).  Appends the stream section (64-byte aligned) to `out`, the row plan.
+static int stream_target() {
+    static const int t = getenv("MACR_SPMM_T") && atoi(getenv("MACR_SPMM_T")) >= 32 ? atoi(getenv("MACR_SPMM_T")) : 256;
+    return t;
+}
+static void build_stream(int N, const int32_t *rowptr, const int32_t *col, const float *val, std::vector<int32_t> &out) {
+    std::vector<int32_t> pc, prow, chunk_slot, empties, slot_group, group_slot0, group_split, split_group0, split_row;
+    std::vector<float> pv;
+    const int T = stream_target();
+    pc.reserve((size_t)rowptr[N] + 8 * (size_t)N); pv.reserve(pc.capacity());
+    // an entry; rows end only at the last entry of a group of 8 (prow: one int per group)
+    auto emit = [&](int32_t c, float w) {
+        if ((pc.size() & 7) == 0) prow.push_back(-1);
+        pc.push_back(c); pv.push_back(w);
+    };
+    // the end marker of row r (mark >= 0) or of a piece (mark == -2): padded up to a group's last entry.  The padding
+    // gathers row `r` with weight 0 (a row the marker reads anyway).
+    auto emit_end = [&](int32_t r, int32_t mark) {
+        while ((pc.size() & 7) != 7) emit(r, 0.f);
+        emit(r, 0.f);
+        prow.back() = mark;
+    };
+    auto pad32 = [&]() { while (pc.size() & 31) emit(0, 0.f); };
+    int cost = 0;
+    bool open = false;
+    std::vector<int32_t> chunk_start;
+    auto close_chunk = [&](int slot) {
+        if (!open) return;
+        pad32();
+        chunk_slot.push_back(slot);
+        open = false; cost = 0;
+    };
+    auto open_chunk = [&]() { if (!open) { chunk_start.push_back((int32_t)(pc.size() / 32)); open = true; } };
+    int n_slots = 0;
+    for (int r = 0; r < N; ++r) {
+        const int beg = rowptr[r], end = rowptr[r + 1], deg = end - beg;
+        if (deg == 0) { empties.push_back(r); continue; }
+        if (deg <= kStreamHub) {
+            const int slots = (deg + 1 + 7) / 8 * 8;
+            if (open && cost > 0 && cost + slots > T + T / 4) close_chunk(-1);
+            open_chunk();
+            for (int e = beg; e < end; ++e) emit(col[e], val[e]);
+            emit_end(r, r);                                  // gathers S_in[r]
+            cost += slots + 4;
+            if (cost >= T) close_chunk(-1);
+        } else {
+            close_chunk(-1);
+            split_group0.push_back((int32_t)group_split.size());
+            int in_group = kGroup;
+            for (int b = beg; b < end; b += kStreamPiece - 1) {
+                if (in_group == kGroup) {
+                    group_slot0.push_back(n_slots);
+                    group_split.push_back((int32_t)split_row.size());
+                    in_group = 0;
+                }
+                slot_group.push_back((int32_t)group_split.size() - 1);
+                open_chunk();
+                const int pe = b + kStreamPiece - 1 < end ? b + kStreamPiece - 1 : end;
+                for (int e = b; e < pe; ++e) emit(col[e], val[e]);
+                emit_end(r, -2);
+                close_chunk(n_slots++);
+                ++in_group;
+            }
+            split_row.push_back(r);
+        }
+    }
+    close_chunk(-1);
+    group_slot0.push_back(n_slots);
+    split_group0.push_back((int32_t)group_split.size());
+    const int n_chunks = (int)chunk_start.size();
+    // chunk_sb[k] = start of chunk k, chunk_sb[n_chunks] = end: chunks are contiguous, so ends = next starts
+    std::vector<int32_t> sbv(chunk_start);
+    sbv.push_back((int32_t)(pc.size() / 32));
+    std::vector<int32_t> chunk_empty(n_chunks + 1);
+    for (int k = 0; k <= n_chunks; ++k) chunk_empty[k] = (int32_t)((long long)empties.size() * k / (n_chunks ? n_chunks : 1));
+    if (n_chunks == 0) chunk_empty[0] = 0;
+    StreamHeader h = {};
+    h.magic = kStreamMagic; h.n_chunks = n_chunks; h.n_sb = (int32_t)(pc.size() / 32); h.n_empty = (int32_t)empties.size();
+    h.n_slots = n_slots; h.n_groups = (int32_t)group_split.size(); h.n_split = (int32_t)split_row.size();
+    h.n_entries = (int32_t)pc.size();
+    while ((out.size() * 4) % 64) out.push_back(0);
+    reinterpret_cast<PlanHeader *>(out.data())->reserved = (int32_t)out.size();
+    out.insert(out.end(), reinterpret_cast<int32_t *>(&h), reinterpret_cast<int32_t *>(&h) + sizeof(h) / 4);
+    while (out.size() % 4) out.push_back(0);
+    for (int k = 0; k < n_chunks; ++k) {
+        const int32_t ne = chunk_empty[k + 1] - chunk_empty[k];
+        out.push_back(sbv[k]); out.push_back(sbv[k + 1]); out.push_back(chunk_empty[k] | (ne << 24)); out.push_back(chunk_slot[k]);
+    }
+    out.insert(out.end(), empties.begin(), empties.end());
+    out.insert(out.end(), slot_group.begin(), slot_group.end());
+    out.insert(out.end(), group_slot0.begin(), group_slot0.end());
+    out.insert(out.end(), group_split.begin(), group_split.end());
+    out.insert(out.end(), split_group0.begin(), split_group0.end());
+    out.insert(out.end(), split_row.begin(), split_row.end());
+    while ((out.size() * 4) % 64) out.push_back(0);          // pcw 64-byte aligned RELATIVE to the plan's start (the device copy is allocated aligned)
+    for (size_t e = 0; e < pc.size(); ++e) {
+        int32_t c = pc[e], wb;
+        memcpy(&wb, &pv[e], 4);
+        const int32_t mark = (e & 7) == 7 ? prow[e / 8] : -1;
+        if (mark != -1) { c |= (int32_t)0x80000000; wb = mark >= 0 ? 0 : 1; }
+        out.push_back(c); out.push_back(wb);
+    }
+    out.insert(out.end(), 256, 0);                           // (a window's fill may read up to 127 entries past the last chunk)
+}
+
 }  // namespace macr
 
 using namespace macr;
 
 // ---- plan (host) ----------------------------------------------------------------
-extern "C" size_t macr_spmm_plan_bytes(int N, const int32_t *rowptr_host) {
+static void build_whole_plan(int N, const int32_t *rowptr, const int32_t *col, const float *val, std::vector<int32_t> &v) {
+    build_plan(N, rowptr, v);
+    if (col && val && !(getenv("MACR_SPMM_STREAM") && atoi(getenv("MACR_SPMM_STREAM")) == 0)) build_stream(N, rowptr, col, val, v);
+}
+
+extern "C" size_t macr_spmm_plan_bytes(int N, const int32_t *rowptr_host, const int32_t *col_host, const float *val_host) {
     if (N <= 0 || !rowptr_host) return 0;
     std::vector<int32_t> v;
-    build_plan(N, rowptr_host, v);
+    build_whole_plan(N, rowptr_host, col_host, val_host, v);
     return v.size() * 4;
 }
 
-extern "C" int macr_spmm_plan_build(int N, const int32_t *rowptr_host, void *plan_host, size_t plan_bytes) {
+extern "C" int macr_spmm_plan_build(int N, const int32_t *rowptr_host, const int32_t *col_host, const float *val_host,
+                                    void *plan_host, size_t plan_bytes) {
     MACR_REQUIRE(N > 0 && rowptr_host && plan_host, MACR_E_INVALID, "spmm_plan_build: bad arguments");
+    MACR_REQUIRE((col_host == nullptr) == (val_host == nullptr), MACR_E_INVALID, "spmm_plan_build: col and val go together");
     std::vector<int32_t> v;
-    build_plan(N, rowptr_host, v);
+    build_whole_plan(N, rowptr_host, col_host, val_host, v);
     MACR_REQUIRE(plan_bytes >= v.size() * 4, MACR_E_WORKSPACE, "spmm_plan_build: buffer %zu < %zu bytes", plan_bytes, v.size() * 4);
     memcpy(plan_host, v.data(), v.size() * 4);
     return MACR_OK;
 }
 
 extern "C" size_t macr_lgcn_work_floats(int N, int d, const void *plan_host) {
-    size_t n = (size_t)3 * N * d;
+    size_t n = (size_t)4 * N * d;
     if (plan_host) {
-        const PlanHeader *h = static_cast<const PlanHeader *>(plan_host);
-        n += ((size_t)h->n_slots + h->n_groups) * d + (size_t)h->n_groups + h->n_split + 64;   // slab, arrival counters
+        size_t slab_rows, counters;
+        plan_extras(plan_host, slab_rows, counters);
+        n += slab_rows * d + counters + 64;
     }
     return n;
 }

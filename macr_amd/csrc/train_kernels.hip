@@ -1721,7 +1721,6 @@ namespace macr {
 struct PlanHeaderLite { int32_t magic, n_items, n_split, n_slots, N, chunk, n_groups, reserved; };   // = spmm_kernels.hip PlanHeader
 struct LgcnWs { float *E, *dE, *G, *work; int32_t *cnt; double *emb_acc; PairWs pair; size_t bytes; };
 static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, const PlanHeaderLite *ph) {
-    const size_t n_slots = ph ? (size_t)ph->n_slots + ph->n_groups : 0, n_split = ph ? (size_t)ph->n_groups + ph->n_split : 0;
     LgcnWs w;
     char *p = static_cast<char *>(base);
     const size_t nd = align_up((size_t)N * d * 4, 256);
@@ -1731,7 +1730,7 @@ static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, const PlanHeaderLit
     w.dE = static_cast<float *>(take(nd));
     w.G = static_cast<float *>(take(nd));
     // layer buffers, partial rows of the hub pieces, their arrival counters (= macr_lgcn_work_floats; zero between steps)
-    w.work = static_cast<float *>(take(3 * nd + align_up(((size_t)n_slots * d + n_split + 64) * 4, 256)));
+    w.work = static_cast<float *>(take(align_up(macr_lgcn_work_floats(N, d, ph) * 4, 256)));
     w.cnt = static_cast<int32_t *>(take(align_up((size_t)N * 4, 256)));    // references of the current batch per row (zero between steps)
     w.emb_acc = static_cast<double *>(take(kEmbSlots * 8));                 // emb_loss partial sums (zero between steps)
     w.pair = carve_pair_ws(p ? p + off : nullptr, B, d);

@@ -54,17 +54,22 @@ class CSR(object):
         self.plan_host = self.plan_dev = None          # SpMM plan (adjacency matrices only)
 
     def build_spmm_plan(self):
-        """Static row-split schedule for the SpMM kernels (macr_spmm_plan_build); built once per graph."""
+        """Static schedule of the SpMM kernels (macr_spmm_plan_build): the row items with the hub rows cut into pieces
+        and, when the matrix has values, the entry stream of the dense layers; built once per graph."""
         import numpy as np
         rowptr = np.ascontiguousarray(self.ptr.cpu().numpy(), dtype=np.int32)
         N = len(rowptr) - 1
+        col = val = None
+        if self.val is not None:
+            col = np.ascontiguousarray(self.idx.cpu().numpy(), dtype=np.int32)
+            val = np.ascontiguousarray(self.val.cpu().numpy(), dtype=np.float32)
+        hp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
         L = _lib.lib()
-        nbytes = L.macr_spmm_plan_bytes(N, rowptr.ctypes.data_as(ctypes.c_void_p))
+        nbytes = L.macr_spmm_plan_bytes(N, hp(rowptr), hp(col), hp(val))
         host = np.zeros((nbytes + 3) // 4, np.int32)
-        check(L.macr_spmm_plan_build(N, rowptr.ctypes.data_as(ctypes.c_void_p), host.ctypes.data_as(ctypes.c_void_p),
-                                     host.nbytes))
-        self.plan_host = host                            # keep alive: the launcher reads its header
-        self.plan_dev = torch.from_numpy(host).to(self.ptr.device)
+        check(L.macr_spmm_plan_build(N, hp(rowptr), hp(col), hp(val), hp(host), host.nbytes))
+        self.plan_host = host                            # keep alive: the launcher reads its headers
+        self.plan_dev = torch.from_numpy(host).to(self.ptr.device)      # (torch allocations are 256-byte aligned)
         return self
 
     def mask_bits(self, U, n_local, item_offset):

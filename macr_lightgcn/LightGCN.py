@@ -160,18 +160,18 @@ def main(sweep=False):
     cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch, best_c_hr = 0., 0, 0, 0, 0, 0.
     resumed = None                                   # the bookkeeping of the interrupted run (saved next to its weights)
     if args.resume == 1:
-        epochs = _saved_epochs(weights_save_path)
-        if epochs:
-            model.load_state_dict(torch.load(weights_save_path + '/weights_{}-{}.pt'.format(args.saveID, epochs[-1]),
-                                             map_location=model.device))
-            start_epoch = epochs[-1] + 1
-            say('resumed from epoch %d' % epochs[-1])
-            side = weights_save_path + '/train_state_{}-{}.pt'.format(args.saveID, epochs[-1])
-            if os.path.exists(side):
-                resumed = torch.load(side, weights_only=False)
+        from macr_amd import train_state
+
+        def latest():
+            epochs = _saved_epochs(weights_save_path)
+            return (epochs[-1], weights_save_path + '/weights_{}-{}.pt'.format(args.saveID, epochs[-1])) if epochs else None
+        last, resumed = train_state.resume(model, latest,
+                                           lambda e: weights_save_path + '/train_state_{}-{}.json'.format(args.saveID, e))
+        if last is not None:
+            start_epoch = last + 1
+            say('resumed from epoch %d' % last)
+            if resumed:
                 cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch, best_c_hr = resumed['bests']
-                random.setstate(resumed['py_random'])
-                np.random.set_state(resumed['np_random'])
 
     n_batch = data_generator.n_train // args.batch_size + 1
     loss_log = torch.zeros((n_batch, 3), dtype=torch.float32, device=model.device)
@@ -252,11 +252,12 @@ def main(sweep=False):
             os.makedirs(weights_save_path, exist_ok=True)      # tf.train.Saver created this level itself
             torch.save(model.state_dict(), weights_save_path + '/weights_{}-{}.pt'.format(args.saveID, epoch))
             # what --resume 1 needs besides the model: best-so-far / early-stopping state and where the samplers stand
-            torch.save({'bests': (cur_best_pre_0, stopping_step, best_epoch, best_hr_norm, best_c_epoch, best_c_hr),
-                        'py_random': random.getstate(), 'np_random': np.random.get_state(),
-                        'sampler_step': device_sampler.step if device_sampler is not None else 0,
-                        'test_sampler_step': test_sampler.step if test_sampler is not None else 0},
-                       weights_save_path + '/train_state_{}-{}.pt'.format(args.saveID, epoch))
+            from macr_amd import train_state
+            train_state.save(weights_save_path + '/train_state_{}-{}.json'.format(args.saveID, epoch),
+                             {'bests': [float(cur_best_pre_0), int(stopping_step), int(best_epoch), float(best_hr_norm),
+                                        int(best_c_epoch), float(best_c_hr)],
+                              'sampler_step': int(device_sampler.step) if device_sampler is not None else 0,
+                              'test_sampler_step': int(test_sampler.step) if test_sampler is not None else 0})
             print('save the weights in path: ', weights_save_path)
         if should_stop and args.early_stop == 1:
             if main_rank:

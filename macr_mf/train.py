@@ -187,18 +187,18 @@ def main(sweep=False):
     start_epoch = 0
     resumed = None                                   # the bookkeeping of the interrupted run (saved next to its checkpoint)
     if args.resume == 1:
-        epochs = _saved_epochs()
-        if epochs:
-            model.load_state_dict(torch.load(_ckpt_dir() + '{}_ckpt.pt'.format(epochs[-1]), map_location=model.device))
-            start_epoch = epochs[-1] + 1
-            say('resumed from epoch %d' % epochs[-1])
-            side = _ckpt_dir() + '{}_train_state.pt'.format(epochs[-1])
-            if os.path.exists(side):
-                resumed = torch.load(side, weights_only=False)
+        from macr_amd import train_state
+
+        def latest():
+            epochs = _saved_epochs()
+            return (epochs[-1], _ckpt_dir() + '{}_ckpt.pt'.format(epochs[-1])) if epochs else None
+        last, resumed = train_state.resume(model, latest, lambda e: _ckpt_dir() + '{}_train_state.json'.format(e))
+        if last is not None:
+            start_epoch = last + 1
+            say('resumed from epoch %d' % last)
+            if resumed:
                 config.update(resumed['config'])
                 stopping_step = resumed['stopping_step']
-                random.setstate(resumed['py_random'])
-                np.random.set_state(resumed['np_random'])
     n_batch = data.n_train // args.batch_size + 1
     loss_log = torch.zeros((n_batch, 3), dtype=torch.float32, device=model.device)
     device_sampler = None
@@ -263,10 +263,11 @@ def main(sweep=False):
             os.makedirs(_ckpt_dir(), exist_ok=True)
             torch.save(model.state_dict(), _ckpt_dir() + '{}_ckpt.pt'.format(epoch))
             # what --resume 1 needs besides the model: best-so-far / early-stopping state and where the samplers stand
-            torch.save({'config': {k: v for k, v in config.items() if k.startswith('best_')}, 'stopping_step': stopping_step,
-                        'py_random': random.getstate(), 'np_random': np.random.get_state(),
-                        'sampler_step': device_sampler.step if device_sampler is not None else 0},
-                       _ckpt_dir() + '{}_train_state.pt'.format(epoch))
+            from macr_amd import train_state
+            train_state.save(_ckpt_dir() + '{}_train_state.json'.format(epoch),
+                             {'config': {k: (v.item() if hasattr(v, 'item') else v) for k, v in config.items() if k.startswith('best_')},
+                              'stopping_step': int(stopping_step),
+                              'sampler_step': int(device_sampler.step) if device_sampler is not None else 0})
         if should_stop and args.early_stop == 1:
             say("{} dataset best epoch{}: hr:{} ndcg:{} recall:{} precision:{}".format(
                 args.dataset, config['best_epoch'], config['best_hr'], config['best_ndcg'], config['best_recall'],

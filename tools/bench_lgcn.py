@@ -38,9 +38,10 @@ agg = {}
 for name, ms in ops.timing_end(512):
     a = agg.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += ms
 bytes_layer = nnz * 8 + (N + 1) * 4 + 2 * N * d * 4
+dense = "spmm_stream" if "spmm_stream" in agg else "spmm_csr"
 out = {"N": N, "nnz": nnz, "us_per_step": dt * 1e6, "interactions_per_s": B / dt,
        "kernels_us": {k: round(1e3 * v[1] / v[0], 1) for k, v in agg.items()},
        "launches_per_step": {k: v[0] / 10 for k, v in agg.items()},
        "spmm_algorithmic_MB": bytes_layer / 1e6,
-       "spmm_GBps": bytes_layer / (1e-3 * agg["spmm_csr"][1] / agg["spmm_csr"][0]) / 1e9}
+       "spmm_GBps": bytes_layer / (1e-3 * agg[dense][1] / agg[dense][0]) / 1e9}
 print(json.dumps(out))
