@@ -55,8 +55,11 @@ extern "C" {
 #define MACR_SCORE_DIRECT_MINUS_BOTH 4  /* direct_minus_ratings_both model.py:201 ; LightGCN.py:510  y - ((c * sig_i) * sig_u) */
 
 /* largest K the top-K kernels are built for (the reference uses 20; parser default max 30) */
-#define MACR_MAX_TOPK 32
-#define MACR_MAX_TOPK_SCORES 128   /* macr_topk_scores only (c_top_k_array_index of the reference has no bound) */
+#define MACR_MAX_TOPK 128          /* macr_score_topk, macr_topk_merge, macr_topk_scores, the metrics (--Ks of the reference: any list) */
+#define MACR_MAX_TOPK_FUSED 32     /* up to here macr_score_topk is the fused ranking (thresholds, candidate lists, seeds); above,
+                                      blocks of dense score rows + streaming selection -- same results, no seeds; the c sweep
+                                      (macr_score_topk_sweep) stays at K <= 32 */
+#define MACR_MAX_TOPK_SCORES 128   /* = MACR_MAX_TOPK (c_top_k_array_index of the reference has no bound) */
 #define MACR_SEED_WIDTH 32       /* threshold seeds per query of macr_score_topk (seed_idx / seed_out) */
 
 int         macr_abi_version(void);

@@ -14,7 +14,8 @@ OK, E_INVALID, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH = 0, -1, -2, -3, -4
 LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, LOSS_RUBIBCE = 0, 1, 2
 STEP_DEFER, STEP_PENDING, STEP_LOSS_ONLY, STEP_DENSE_LAYERS = 1, 2, 4, 8
 SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINUS_BOTH = 0, 1, 2, 3, 4
-MAX_TOPK = 32
+MAX_TOPK = 128
+MAX_TOPK_FUSED = 32
 MAX_SWEEP = 4
 ABI_VERSION = 8
 

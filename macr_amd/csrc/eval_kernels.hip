@@ -17,6 +17,8 @@
 // sorting 64-bit keys (orderable(score) << 32 | ~id).
 #include "common.hpp"
 
+#include <algorithm>
+
 #include <type_traits>
 
 namespace macr {
@@ -2343,33 +2345,10 @@ __device__ __forceinline__ uint64_t keep_best_wide(uint64_t *keys, int n, int K)
     return kth;
 }
 
-__global__ __launch_bounds__(256) void k_topk_scores_wide(const float *__restrict__ scores, int cols, int rows, int K,
-                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
-    __shared__ uint64_t s_keys[4][kWideCap];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wid;
-    if (row >= rows) return;
-    const float *src = scores + (size_t)row * cols;
-    uint64_t *keys = s_keys[wid];
-    int cnt = 0;
-    uint64_t thr_key = 0ull;                        // admission: key > thr_key
-    for (int base = 0; base < cols; base += kWave) {
-        const int cidx = base + lane;
-        const uint64_t key = cidx < cols ? make_key(src[cidx], cidx) : 0ull;
-        bool cand = key > thr_key;
-        uint64_t bal = __ballot(cand);
-        if (bal == 0ull) continue;
-        if (cnt + __popcll(bal) > kWideCap) {
-            const uint64_t kth = keep_best_wide(keys, cnt, K);
-            if (kth) { thr_key = kth; cnt = K; }
-            cand = key > thr_key;
-            bal = __ballot(cand);
-        }
-        if (cand) keys[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = key;
-        cnt += __popcll(bal);
-    }
-    if (keep_best_wide(keys, cnt, K)) cnt = K;
-    // order the cnt <= K <= 128 survivors: rank = number of larger keys
+// the final K (cnt <= K <= 128 keys at the front of `keys`) in order: rank = number of larger keys
+__device__ __forceinline__ void emit_wide(const uint64_t *keys, int cnt, int K, int32_t *__restrict__ idx_row,
+                                          float *__restrict__ val_row, int id_offset) {
+    const int lane = threadIdx.x & 63;
     uint64_t mine[2]; int rank[2] = {0, 0};
 #pragma unroll
     for (int h = 0; h < 2; ++h) mine[h] = h * 64 + lane < cnt ? keys[h * 64 + lane] : 0ull;
@@ -2381,12 +2360,90 @@ __global__ __launch_bounds__(256) void k_topk_scores_wide(const float *__restric
 #pragma unroll
     for (int h = 0; h < 2; ++h)
         if (mine[h]) {
-            out_idx[(size_t)row * K + rank[h]] = key_id(mine[h]);
-            if (out_val) out_val[(size_t)row * K + rank[h]] = key_score(mine[h]);
+            idx_row[rank[h]] = key_id(mine[h]) + id_offset;
+            if (val_row) val_row[rank[h]] = key_score(mine[h]);
         }
-    for (int e = cnt + lane; e < K; e += kWave) {          // fewer than K columns
-        out_idx[(size_t)row * K + e] = -1;
-        if (out_val) out_val[(size_t)row * K + e] = -INFINITY;
+    for (int e = cnt + lane; e < K; e += kWave) {          // fewer than K candidates
+        idx_row[e] = -1;
+        if (val_row) val_row[e] = -INFINITY;
+    }
+}
+// one round of admission: `key` per lane (0 = none) against the running threshold; the buffer is compacted to its best K
+// when it could overflow
+__device__ __forceinline__ void admit_wide(uint64_t *keys, int &cnt, uint64_t &thr_key, uint64_t key, int K) {
+    const int lane = threadIdx.x & 63;
+    bool cand = key > thr_key;
+    uint64_t bal = __ballot(cand);
+    if (bal == 0ull) return;
+    if (cnt + __popcll(bal) > kWideCap) {
+        const uint64_t kth = keep_best_wide(keys, cnt, K);
+        if (kth) { thr_key = kth; cnt = K; }
+        cand = key > thr_key;
+        bal = __ballot(cand);
+    }
+    if (cand) keys[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+    cnt += __popcll(bal);
+}
+
+// mask_bits (may be NULL): the (item tile, query) bitmap of macr_mask_bits_build with `mask_stride` queries; row r of the
+// matrix is query q0 + r; a masked column is no candidate at all (as in the fused ranking).  Ids leave as column + id_offset.
+__global__ __launch_bounds__(256) void k_topk_scores_wide(const float *__restrict__ scores, int cols, int rows, int K,
+                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                                          const uint32_t *__restrict__ mask_bits, int mask_stride, int q0,
+                                                          int id_offset) {
+    __shared__ uint64_t s_keys[4][kWideCap];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= rows) return;
+    const float *src = scores + (size_t)row * cols;
+    uint64_t *keys = s_keys[wid];
+    int cnt = 0;
+    uint64_t thr_key = 0ull;                        // admission: key > thr_key
+    for (int base = 0; base < cols; base += kWave) {
+        const int cidx = base + lane;
+        uint64_t key = cidx < cols ? make_key(src[cidx], cidx) : 0ull;
+        if (mask_bits && cidx < cols && ((mask_bits[(size_t)(cidx >> 5) * mask_stride + q0 + row] >> (cidx & 31)) & 1u)) key = 0ull;
+        admit_wide(keys, cnt, thr_key, key, K);
+    }
+    if (keep_best_wide(keys, cnt, K)) cnt = K;
+    emit_wide(keys, cnt, K, out_idx + (size_t)row * K, out_val ? out_val + (size_t)row * K : nullptr, id_offset);
+}
+
+// k_topk_merge for MACR_MAX_TOPK_FUSED < K <= MACR_MAX_TOPK: the W*K entries stream through the same 256-key buffer.
+__global__ __launch_bounds__(256) void k_topk_merge_wide(int W, int U, int K, const float *__restrict__ vals,
+                                                         const int32_t *__restrict__ idxs,
+                                                         const int32_t *__restrict__ fill_ptr,
+                                                         const int32_t *__restrict__ fill_idx,
+                                                         float *__restrict__ out_val, int32_t *__restrict__ out_idx,
+                                                         int32_t *__restrict__ out_cnt) {
+    __shared__ uint64_t s_keys[4][kWideCap];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wid;
+    if (q >= U) return;
+    uint64_t *keys = s_keys[wid];
+    int cnt = 0;
+    uint64_t thr_key = 0ull;
+    for (int s = 0; s < W; ++s) {
+        for (int base = 0; base < K; base += kWave) {
+            const int k = base + lane;
+            uint64_t key = 0ull;
+            if (k < K) {
+                const size_t o = ((size_t)s * U + q) * K + k;
+                const int32_t id = idxs[o];
+                if (id >= 0) key = make_key(vals[o], id);
+            }
+            admit_wide(keys, cnt, thr_key, key, K);
+        }
+    }
+    if (keep_best_wide(keys, cnt, K)) cnt = K;
+    emit_wide(keys, cnt, K, out_idx + (size_t)q * K, out_val + (size_t)q * K, 0);
+    if (lane == 0) {
+        if (out_cnt) out_cnt[q] = cnt;
+        if (fill_ptr && cnt < K)       // complete with the masked ids, ascending (score -inf)
+            for (int e = fill_ptr[q]; e < fill_ptr[q + 1] && cnt < K; ++e, ++cnt) {
+                out_idx[(size_t)q * K + cnt] = fill_idx[e];
+                out_val[(size_t)q * K + cnt] = -INFINITY;
+            }
     }
 }
 
@@ -2493,7 +2550,7 @@ __global__ void k_metrics_foldout(int U, int K, const int32_t *__restrict__ rank
 
 // macr_mf/train.py:32-117 in float64: per query {precision, recall, ndcg, hit} x Ks.
 struct KsArg { int32_t k[8]; int n; };
-// One wave per query: lane i owns rank position i (Kmax <= 32), so the membership searches and the log2 terms of a
+// One wave per query: lane i owns rank positions i and 64 + i (Kmax <= 128), so the membership searches and the log2 terms of a
 // query run side by side; sums are fixed-shape shuffle trees (deterministic).
 __global__ __launch_bounds__(256) void k_metrics_mf(int U, int Kmax, const int32_t *__restrict__ rankings,
                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ gt_ptr,
@@ -2504,17 +2561,28 @@ __global__ __launch_bounds__(256) void k_metrics_mf(int U, int Kmax, const int32
     const int32_t *truth = gt_idx + gt_ptr[u];
     const int truth_len = gt_ptr[u + 1] - gt_ptr[u];
     const int len = cnt ? cnt[u] : Kmax;
-    const int item = lane < Kmax ? rankings[(size_t)u * Kmax + lane] : -1;
-    const bool hit = item >= 0 && in_sorted(truth, truth_len, item);
-    const double term = 1.0 / log2((double)(lane + 2));          // DCG discount of position `lane`
+    // lane l owns rank positions l and 64 + l (Kmax <= 128)
+    bool hit[2]; double term[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pos = lane + 64 * h;
+        const int item = pos < Kmax ? rankings[(size_t)u * Kmax + pos] : -1;
+        hit[h] = item >= 0 && in_sorted(truth, truth_len, item);
+        term[h] = 1.0 / log2((double)(pos + 2));                  // DCG discount of position `pos`
+    }
     for (int qk = 0; qk < Ks.n; ++qk) {
         const int K = Ks.k[qk];
         const int m = len < K ? len : K;
         const int lim = truth_len < K ? truth_len : K;
-        const bool mine = hit && lane < m;
-        const double hits = (double)__popcll(__ballot(mine));
-        const double dcg = wave_sum_d(mine ? term : 0.0);
-        const double dcg_max = wave_sum_d(lane < lim ? term : 0.0);
+        double hits = 0.0, dcg = 0.0, dcg_max = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                             // (positions 0..63 first, as before; then 64..127)
+            const int pos = lane + 64 * h;
+            const bool mine = hit[h] && pos < m;
+            hits += (double)__popcll(__ballot(mine));
+            dcg += wave_sum_d(mine ? term[h] : 0.0);
+            dcg_max += wave_sum_d(pos < lim ? term[h] : 0.0);
+        }
         if (lane == 0) {
             double *o = out + ((size_t)u * 4) * Ks.n;
             o[0 * Ks.n + qk] = m > 0 ? hits / m : NAN;
@@ -2595,7 +2663,7 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
 struct TopkWs {
     float *tau, *maxima; int32_t *counts; int32_t *overflow, *user_ovf, *ub_map, *blk_flag; uint32_t *shared_thr, *mask_bits; uint64_t *lists;
     uint4 *users_bf, *items_bf; float *unorm;        // bf16 filter: operand copies, |u| per query user (max |q|: overflow[8], zeroed per call)
-    int cap; size_t header_bytes, maxima_bytes, mask_bytes, bytes;
+    int cap; size_t header_bytes, maxima_bytes, mask_bytes, lists_bytes, bytes;
 };
 static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g, int d = 0) {
     TopkWs w;
@@ -2617,7 +2685,9 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g, 
     w.maxima = static_cast<float *>(take(w.maxima_bytes));
     w.mask_bytes = (size_t)(n_tiles(n_local) + n_windows(n_local)) * U * 4;
     w.mask_bits = static_cast<uint32_t *>(take(w.mask_bytes));
-    w.lists = static_cast<uint64_t *>(take((size_t)g.slots1 * U * w.cap * 8));
+    // (the wide ranking, K > MACR_MAX_TOPK_FUSED, keeps a block of dense score rows here: room for at least min(U, 32) of them)
+    w.lists_bytes = std::max((size_t)g.slots1 * U * w.cap * 8, (size_t)(U < 32 ? U : 32) * n_local * 4);
+    w.lists = static_cast<uint64_t *>(take(w.lists_bytes));
     w.users_bf = static_cast<uint4 *>(take((size_t)U * d * 4));          // (hi[d], lo[d]) bf16 per row
     w.items_bf = static_cast<uint4 *>(take((size_t)n_local * d * 4));
     w.unorm = static_cast<float *>(take((size_t)U * 4));
@@ -2760,6 +2830,34 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
                                                  sample_log2(n_local));
         MACR_CHECK_LAUNCH("mask_bits", st);
         mask_bits = ws.mask_bits;
+    }
+    if (K > MACR_MAX_TOPK_FUSED) {
+        // The wide ranking (--Ks up to 128: macr_mf/parse.py:31, utility/parser.py:63 take any list): thresholds at rank ~8K
+        // and 1024-candidate lists are built for K <= 32, so larger K take the reference's own route -- a block of dense
+        // score rows (the fp32 MFMA chain and epilogue of every other kernel here: the same bits), masked columns are no
+        // candidates, the best K per row by the streaming selection of macr_topk_scores -- block by block through the list
+        // buffer.  Same result contract: (score, global id) pairs in out[0], the other splits empty; seeds are not used.
+        const size_t row_bytes = (size_t)n_local * 4;
+        const int rows = (int)std::min<size_t>((size_t)U, ws.lists_bytes / row_bytes);
+        MACR_REQUIRE(rows >= 1, MACR_E_WORKSPACE, "score_topk: K=%d needs %zu B of list buffer per query, have %zu", K, row_bytes, ws.lists_bytes);
+        float *scores = reinterpret_cast<float *>(ws.lists);
+        for (int q0 = 0; q0 < U; q0 += rows) {
+            const int nq = std::min(rows, U - q0);
+            dim3 grid((n_local + 127) / 128, (nq + 31) / 32);
+            MACR_DISPATCH_DK(d, score_kind, (k_score_matrix<D, KIND><<<grid, 256, 0, st>>>(
+                                                nq, n_local, user_ids ? users_tab : users_tab + (size_t)q0 * d, user_ids ? user_ids + q0 : nullptr,
+                                                items, sig_u ? sig_u + q0 : nullptr, sig_i, c, c_dev, scores)));
+            MACR_CHECK_LAUNCH("score_matrix", st);
+            k_topk_scores_wide<<<(nq + 3) / 4, 256, 0, st>>>(scores, n_local, nq, K, out_idx + (size_t)q0 * K, out_val + (size_t)q0 * K,
+                                                             mask_bits, U, q0, item_offset);
+            MACR_CHECK_LAUNCH("topk_scores", st);
+        }
+        if (n_splits > 1) {
+            fill_words(out_val + (size_t)U * K, (size_t)(n_splits - 1) * U * K, 0xff800000u, st);
+            fill_words(out_idx + (size_t)U * K, (size_t)(n_splits - 1) * U * K, 0xffffffffu, st);
+        }
+        if (stats) fill_words(stats, 2, 0u, st);
+        return MACR_OK;
     }
     MACR_DISPATCH_DK(d, score_kind, {
         auto pass0 = k_score_stream<D, KIND, kModeMax>;
@@ -2933,7 +3031,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
     MACR_REQUIRE(n_c >= 1 && n_c <= kMaxSweep, MACR_E_UNSUPPORTED, "score_topk_sweep: n_c=%d outside [1,%d]", n_c, kMaxSweep);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk_sweep: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk_sweep: d=%d not in {32,64,128,256}", d);
-    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "score_topk_sweep: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
+    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK_FUSED, MACR_E_UNSUPPORTED, "score_topk_sweep: K=%d outside [1,%d] (larger K: macr_score_topk per value)", K, MACR_MAX_TOPK_FUSED);
     MACR_REQUIRE(users_tab && items && out_val && out_idx && c_dev && sig_i && (!score_uses_sig_u(score_kind) || sig_u),
                  MACR_E_INVALID, "score_topk_sweep: null pointer");
     MACR_REQUIRE(mask_bits_in || !mask_ptr, MACR_E_INVALID, "score_topk_sweep: pass the mask bitmap (macr_mask_bits_build) with the mask");
@@ -3092,8 +3190,8 @@ extern "C" int macr_topk_scores(const float *scores, int cols, int rows, int K, 
     MACR_REQUIRE(scores && out_idx, MACR_E_INVALID, "topk_scores: null pointer");
     MACR_REQUIRE(cols > 0 && rows > 0, MACR_E_INVALID, "topk_scores: cols=%d rows=%d", cols, rows);
     MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK_SCORES, MACR_E_UNSUPPORTED, "topk_scores: K=%d outside [1,%d]", K, MACR_MAX_TOPK_SCORES);
-    if (K <= MACR_MAX_TOPK) k_topk_scores<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val);
-    else k_topk_scores_wide<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val);
+    if (K <= MACR_MAX_TOPK_FUSED) k_topk_scores<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val);
+    else k_topk_scores_wide<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val, nullptr, 0, 0, 0);
     MACR_CHECK_LAUNCH("topk_scores", st);
     return MACR_OK;
 }
@@ -3105,8 +3203,8 @@ extern "C" int macr_topk_merge(int W, int U, int K, const float *vals, const int
     MACR_REQUIRE(W >= 1 && U > 0, MACR_E_INVALID, "topk_merge: W=%d U=%d", W, U);
     MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "topk_merge: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
     MACR_REQUIRE(vals && idxs && out_val && out_idx, MACR_E_INVALID, "topk_merge: null pointer");
-    k_topk_merge<<<(U + 3) / 4, 256, 0, st>>>(W, U, K, vals, idxs, fill_mask_ptr, fill_mask_idx,
-                                                             out_val, out_idx, out_cnt);
+    if (K <= MACR_MAX_TOPK_FUSED) k_topk_merge<<<(U + 3) / 4, 256, 0, st>>>(W, U, K, vals, idxs, fill_mask_ptr, fill_mask_idx, out_val, out_idx, out_cnt);
+    else k_topk_merge_wide<<<(U + 3) / 4, 256, 0, st>>>(W, U, K, vals, idxs, fill_mask_ptr, fill_mask_idx, out_val, out_idx, out_cnt);
     MACR_CHECK_LAUNCH("topk_merge", st);
     return MACR_OK;
 }
@@ -3138,7 +3236,7 @@ extern "C" int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const i
                                double *out, void *stream) {
     hipStream_t st = as_stream(stream);
     MACR_REQUIRE(U > 0 && Kmax >= 1, MACR_E_INVALID, "metrics_mf: U=%d Kmax=%d", U, Kmax);
-    MACR_REQUIRE(Kmax <= 64, MACR_E_UNSUPPORTED, "metrics_mf: Kmax=%d > 64", Kmax);
+    MACR_REQUIRE(Kmax <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "metrics_mf: Kmax=%d > %d", Kmax, MACR_MAX_TOPK);
     MACR_REQUIRE(rankings && gt_ptr && gt_idx && Ks && out, MACR_E_INVALID, "metrics_mf: null pointer");
     MACR_REQUIRE(nK >= 1 && nK <= 8, MACR_E_UNSUPPORTED, "metrics_mf: nK=%d outside [1,8]", nK);
     KsArg ka;

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import ops, sharding
+from . import _lib as _lib_consts
 
 
 class Evaluator(object):
@@ -84,7 +85,8 @@ class Evaluator(object):
             # Seeds the tables have moved away from (early epochs) cost a repair round, so the evaluator watches how
             # many query blocks were listed twice (_seed_feedback) and goes back to the sampling pass for a while.
             seeds = self.__dict__.setdefault("_seeds", {})
-            use = self.use_seeds and ws == 1 and self._shape_uses_seeds(hi - lo, items_tab.shape[1])
+            use = (self.use_seeds and ws == 1 and K <= _lib_consts.MAX_TOPK_FUSED       # (the wide ranking takes no seeds)
+                   and self._shape_uses_seeds(hi - lo, items_tab.shape[1]))
             seed = seeds.get((K, lo, hi)) if use else None
             seeded = self._ranked_seeded = seed is not None and self._seeded_now
             if use and seed is None:
@@ -291,7 +293,8 @@ class Evaluator(object):
         # on the Gowalla shape against 0.43 one evaluation at a time, tools/bench_sweep.py).  MACR_SWEEP_ONE_BY_ONE=1
         # sends every value through the seeded, graph-replayed single evaluation instead (A/B switch).
         one_by_one = os.environ.get("MACR_SWEEP_ONE_BY_ONE", "0") == "1"
-        if one_by_one or sharding.world()[1] > 1 or kind == ops.SCORE_NORMAL or self.n_queries > self.max_queries_per_pass:
+        if (one_by_one or sharding.world()[1] > 1 or kind == ops.SCORE_NORMAL or self.n_queries > self.max_queries_per_pass
+                or max(Ks) > _lib.MAX_TOPK_FUSED):           # (the shared-listing-pass kernels rank K <= 32)
             return torch.stack([self._means(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c).clone() for c in cs])
         outs = []
         for a in range(0, len(cs), _lib.MAX_SWEEP):

@@ -27,7 +27,7 @@ _FLAGS = [
     ("node_dropout_flag", int, 0, "0 (node dropout is out of scope)"),
     ("node_dropout", None, '[0.1]', "(compat)"),
     ("mess_dropout", None, '[0.1]', "(compat)"),
-    ("Ks", None, '[1,5,10,15,20,30]', "top-K cut-offs, python list literal (max 32 on the HIP path)"),
+    ("Ks", None, '[1,5,10,15,20,30]', "top-K cut-offs, python list literal (up to 128)"),
     ("save_flag", int, 1, "1: save a checkpoint at every evaluation"),
     ("test_flag", None, 'part', "(compat)"),
     ("saveID", None, '', "suffix of the checkpoint files"),

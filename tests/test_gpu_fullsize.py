@@ -79,6 +79,51 @@ def test_fullsize_eval(ops, workload, eval_filter):
         assert torch.equal(again[1], idx)
 
 
+@pytest.mark.parametrize("K", [50, 100])
+def test_fullsize_eval_wide_K(ops, K):
+    """--Ks beyond 32 at the Gowalla shape (15 424 query users x 40 981 items): the wide ranking against the oracle on every
+    97th user, sortedness / mask / item-shard invariance on all of them"""
+    from macr_amd import synth
+    from macr_amd.evaluator import Evaluator
+    cfg = synth.WORKLOADS["gowalla"]
+    d = cfg["d"]
+    rs = np.random.RandomState(2)
+    P = (rs.standard_normal((cfg["n_users"], d)) * 0.3).astype(np.float32)
+    Q = (rs.standard_normal((cfg["n_items"], d)) * 0.3).astype(np.float32)
+    Q[:, 0] += np.sort(rs.standard_normal(cfg["n_items"]))[::-1].astype(np.float32)
+    P[:, 0] = np.abs(P[:, 0])
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    users, mask, gt = synth.eval_problem(cfg, seed=3)
+    ev = Evaluator(mask, gt, cfg["n_items"], torch.device("cuda"))
+    uid, Pd, Qd, wd, wud = dev(users), dev(P), dev(Q), dev(w), dev(wu)
+    val, idx, cnt = ev.rank(1, Pd, uid, Qd, K, wd, wud, 40.0)
+    sel = np.arange(0, len(users), 97)
+    sig_i = ops.branch_sigmoid(Qd, wd).cpu().numpy()
+    sig_u = ops.branch_sigmoid(Pd, wud, uid).cpu().numpy()
+    sub = oracle.csr_from_lists([mask[q] for q in sel])
+    wv, wi, wc = oracle.score_topk(1, P[users[sel]], Q, K, sig_u[sel], sig_i, 40.0, sub)
+    assert np.array_equal(idx.cpu().numpy()[sel], wi)
+    assert np.array_equal(val.cpu().numpy()[sel].view(np.uint32), wv.view(np.uint32))
+    v = val.cpu().numpy(); ix = idx.cpu().numpy()
+    assert np.all(v[:, :-1] >= v[:, 1:])
+    ties = v[:, :-1] == v[:, 1:]
+    assert np.all(ix[:, :-1][ties] < ix[:, 1:][ties])
+    for q in range(0, len(users), 501):
+        assert not set(ix[q]) & set(mask[q])
+    # two item shards, merged
+    half = cfg["n_items"] // 2
+    sig_ud, sig_id = dev(sig_u), dev(sig_i)
+    parts = []
+    for a, b in ((0, half), (half, cfg["n_items"])):
+        pv, pi = ops.score_topk(1, Pd, uid, Qd[a:b], K, sig_ud, sig_id[a:b].contiguous(), 40.0, ev.mask, a, 1)
+        lv, li, _ = ops.topk_merge(pv, pi)
+        parts.append((lv, li))
+    mv, mi, _ = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(mi, idx) and torch.equal(mv, val)
+    ret = ev.test_mf(1, Pd, uid, Qd, [20, K], wd, wud, 40.0)
+    assert 0.0 <= ret["recall"][0] <= ret["recall"][1] <= 1.0
+
+
 @pytest.mark.parametrize("workload,kind", [("ml10m", 1), ("gowalla", 1), ("gowalla", 0)])
 def test_fullsize_train_step(ops, workload, kind):
     """configs[1]/[2]: B=4096 / 8192 on the real table shapes, one step against the oracle."""

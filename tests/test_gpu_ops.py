@@ -1112,3 +1112,115 @@ def test_bf16_filter_margin_constant_covers_its_stated_bound():
     assert "kFilterRel" not in src
     for d in (32, 64, 128, 256):
         assert 3.2 / 65536 + 8.0 * d / 16777216 >= 3.2 / 65536 + 6.0 * d / 16777216 + d / 16777216
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --Ks beyond 32 (macr_mf/parse.py:31, utility/parser.py:63 take any list; evaluate_foldout.h:115 any rank_len): the wide
+# ranking of macr_score_topk / macr_topk_merge / the metrics, K <= 128 -- dense score rows in blocks + streaming selection
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", [oracle.SCORE_NORMAL, oracle.SCORE_RUBI_BOTH, oracle.SCORE_DIRECT_MINUS])
+@pytest.mark.parametrize("U,N,d,K,splits,off", [
+    (300, 3000, 64, 50, 1, 0), (257, 2085, 64, 100, 3, 0), (40, 744, 64, 128, 0, 0), (5, 60, 64, 100, 1, 0),
+    (64, 1000, 32, 33, 2, 0), (100, 900, 128, 64, 4, 0), (70, 500, 256, 100, 1, 0), (300, 1000, 64, 50, 2, 5000)])
+def test_score_topk_wide_bit_exact(ops, kind, U, N, d, K, splits, off, eval_filter):
+    rs = np.random.RandomState(U + N + d + K)
+    n_users = U + 50
+    P = (rs.standard_normal((n_users, d)) * 0.5).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.5).astype(np.float32)
+    Q += (rs.standard_normal(N).astype(np.float32) * 0.5)[:, None] * np.sign(P.mean(0, keepdims=True))
+    w = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    wu = (rs.standard_normal(d) * 0.3).astype(np.float32)
+    user_ids = rs.permutation(n_users)[:U].astype(np.int32)
+    mask_lists = random_mask(rs, U, N, 12, heavy=(0, U - 1) if N > 100 else ())
+    mask_lists = [[x + off for x in row] for row in mask_lists]
+    mptr, midx = oracle.csr_from_lists(mask_lists)
+    c = 3.0
+    sig_i_hip = ops.branch_sigmoid(dev(Q), dev(w))
+    sig_u_hip = ops.branch_sigmoid(dev(P), dev(wu), dev(user_ids))
+    sig_i, sig_u = sig_i_hip.cpu().numpy(), sig_u_hip.cpu().numpy()
+    want_v, want_i, want_c = oracle.score_topk(kind, P[user_ids], Q, K, sig_u, sig_i, c, (mptr, midx), off)
+    mask = ops.CSR(dev(mptr), dev(midx if len(midx) else np.zeros(1, np.int32)))
+    vals, idx = ops.score_topk(kind, dev(P), dev(user_ids), dev(Q), K, sig_u_hip, sig_i_hip, c, mask, off, splits)
+    gv, gi, gc = ops.topk_merge(vals, idx)
+    assert np.array_equal(gi.cpu().numpy(), want_i)
+    assert np.array_equal(gc.cpu().numpy(), want_c)
+    assert np.array_equal(gv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))      # bit for bit
+    fv, fi, fc = ops.topk_merge(vals, idx, fill_mask=mask)
+    ov, oi, oc = oracle.score_topk(kind, P[user_ids], Q, K, sig_u, sig_i, c, (mptr, midx), off, fill_masked=True)
+    assert np.array_equal(fi.cpu().numpy(), oi)
+    # item shards of the wide ranking merge to the unsharded result (what the ranks exchange: K pairs per query and shard)
+    cut = [0, N // 3, N // 3 + 1, N]
+    parts_v, parts_i = [], []
+    for a, b in zip(cut[:-1], cut[1:]):
+        v, ix = ops.score_topk(kind, dev(P), dev(user_ids), dev(Q[a:b]), K, sig_u_hip, sig_i_hip[a:b].contiguous(), c, mask, off + a, 1)
+        lv, li, _ = ops.topk_merge(v, ix)
+        parts_v.append(lv); parts_i.append(li)
+    mv, mi, mc = ops.topk_merge(torch.stack(parts_v), torch.stack(parts_i))
+    assert np.array_equal(mi.cpu().numpy(), want_i) and np.array_equal(mc.cpu().numpy(), want_c)
+    assert np.array_equal(mv.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+
+
+@pytest.mark.parametrize("K,W", [(50, 3), (100, 8), (128, 2), (33, 64)])
+def test_topk_merge_wide_matches_oracle(ops, K, W):
+    rs = np.random.RandomState(K + W)
+    U = 37
+    vals = np.sort(np.round(rs.standard_normal((W, U, K)).astype(np.float32) * 4) / 4 + np.float32(0), axis=2)[:, :, ::-1].copy()   # ties across lists (no -0.0)
+    idxs = np.empty((W, U, K), np.int32)
+    for q in range(U):
+        ids = rs.permutation(W * K * 2)[: W * K].astype(np.int32).reshape(W, K)
+        idxs[:, q, :] = ids
+    short = rs.rand(W, U) < 0.3                                  # some lists hold fewer than K candidates
+    for s_ in range(W):
+        for q in range(U):
+            if short[s_, q]:
+                n = rs.randint(0, K)
+                idxs[s_, q, n:] = -1; vals[s_, q, n:] = -np.inf
+    # lists must be sorted by (score desc, id asc) where scores tie: re-sort each
+    for s_ in range(W):
+        for q in range(U):
+            order = np.lexsort((idxs[s_, q], -vals[s_, q]))
+            keep = idxs[s_, q][order] >= 0
+            order = np.concatenate([order[keep], order[~keep]])
+            vals[s_, q] = vals[s_, q][order]; idxs[s_, q] = idxs[s_, q][order]
+    wv, wi, wc = oracle.topk_merge(vals, idxs)
+    gv, gi, gc = ops.topk_merge(dev(vals), dev(idxs))
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gc.cpu().numpy(), wc)
+    assert np.array_equal(gv.cpu().numpy().view(np.uint32), wv.view(np.uint32))
+
+
+def test_metrics_and_evaluator_with_wide_Ks(ops, eval_filter):
+    """Ks = [20, 50, 100] through both evaluator flavours and the c sweep against the oracle's metrics"""
+    from macr_amd.evaluator import Evaluator
+    rs = np.random.RandomState(77)
+    n_users, N, d = 900, 2500, 64
+    P = (rs.standard_normal((n_users, d)) * 0.4).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.4 + rs.standard_normal((N, 1)) * 0.3).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    users = np.sort(rs.choice(n_users, 500, replace=False)).astype(np.int32)
+    mask = random_mask(rs, len(users), N, 15)
+    gt = [sorted(rs.choice(N, rs.randint(1, 30), replace=False).tolist()) for _ in users]
+    Ks, c, kind = [20, 50, 100], 40.0, oracle.SCORE_RUBI_BOTH
+    ev = Evaluator(mask, gt, N, torch.device("cuda"))
+    uid, Pd, Qd, wd, wud = dev(users), dev(P), dev(Q), dev(w), dev(wu)
+    sig_i = ops.branch_sigmoid(Qd, wd).cpu().numpy()
+    sig_u = ops.branch_sigmoid(Pd, wud, uid).cpu().numpy()
+    mcsr, gcsr = oracle.csr_from_lists(mask), oracle.csr_from_lists(gt)
+    for rep in range(2):                                         # second call: the graph replay
+        _, oi, oc = oracle.score_topk(kind, P[users], Q, max(Ks), sig_u, sig_i, c, mcsr)
+        got = ev.test_mf(kind, Pd, uid, Qd, Ks, wd, wud, c)
+        want = oracle.metrics_mf(oi, oc, gcsr, Ks).mean(0)
+        for row, k in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
+            np.testing.assert_allclose(got[k], want[row], rtol=1e-12, err_msg=k)
+        got = ev.test_lgcn(kind, Pd, uid, Qd, Ks, wd, wud, c)
+        _, oi, _ = oracle.score_topk(kind, P[users], Q, max(Ks), sig_u, sig_i, c, mcsr, fill_masked=True)
+        res = oracle.metrics_foldout(oi, gcsr)
+        K = max(Ks)
+        res[:, 2 * K:3 * K] = (res[:, K:2 * K] != 0)
+        fin = res.astype(np.float64).mean(0).reshape(5, K)[:, np.asarray(sorted(Ks)) - 1]
+        np.testing.assert_allclose(got["hr"], fin[2], rtol=1e-6)
+        np.testing.assert_allclose(got["ndcg"], fin[3], rtol=1e-6)
+    sweep = ev.test_mf_sweep(kind, Pd, uid, Qd, Ks, wd, wud, [0.0, 20.0, 40.0])
+    for cc, res_c in zip([0.0, 20.0, 40.0], sweep):
+        _, oi, oc = oracle.score_topk(kind, P[users], Q, max(Ks), sig_u, sig_i, cc, mcsr)
+        want = oracle.metrics_mf(oi, oc, gcsr, Ks).mean(0)
+        np.testing.assert_allclose(res_c["recall"], want[1], rtol=1e-12)

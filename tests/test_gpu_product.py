@@ -274,6 +274,25 @@ def test_lightgcn_cli_addressa(tmp_path):
     assert not [f for f in os.listdir(os.path.join(REPO, "data", "addressa")) if f.endswith(".npz")]
 
 
+def test_clis_take_Ks_beyond_32(tmp_path):
+    """--Ks "[20,50,100]" (the reference takes any list: macr_mf/parse.py:31, utility/parser.py:63) through both CLIs"""
+    os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
+    out = _run_cli([os.path.join(REPO, "macr_mf", "train.py"), "--dataset", "addressa", "--batch_size", "1024",
+                    "--cuda", "0", "--saveID", "k", "--log_interval", "2", "--lr", "0.001", "--epoch", "2",
+                    "--train", "rubibceboth", "--test", "rubi", "--c", "40", "--Ks", "[20,50,100]", "--save_flag", "0"],
+                   str(tmp_path))
+    ev = [l for l in out.splitlines() if "hit=[" in l][-1]
+    hits = [float(x) for x in ev.split("hit=[")[1].split("]")[0].split(",")]        # (the log shows the first and the last K: train.py:532)
+    assert len(hits) == 2 and 0.0 < hits[0] < hits[1] <= 1.0, ev
+    out = _run_cli([os.path.join(REPO, "macr_lightgcn", "LightGCN.py"), "--data_path", os.path.join(REPO, "data") + "/",
+                    "--dataset", "addressa", "--verbose", "1", "--layer_size", "[64,64]", "--Ks", "[20,50,100]", "--loss",
+                    "bceboth", "--test", "rubiboth", "--c", "40", "--epoch", "2", "--lr", "0.001", "--batch_size", "1024",
+                    "--gpu_id", "0", "--log_interval", "2", "--weights_path", str(tmp_path) + "/"], str(tmp_path))
+    ev = [l for l in out.splitlines() if "hit=[" in l][-1]
+    hits = [float(x) for x in ev.split("hit=[")[1].split("]")[0].replace(",", " ").split()]
+    assert len(hits) in (2, 3) and 0.0 < hits[0] < hits[-1] <= 1.0, ev
+
+
 def test_bench_two_ranks_share_one_gpu(tmp_path):
     """bench.py's N>1 path (replica training, rank-0 broadcast, item-sharded evaluation, all-gather, merge) with
     two ranks on ONE GPU through the gloo test rig; the single-rank run is the reference for the eval metrics."""
