@@ -533,7 +533,7 @@ struct StreamHeader {             // all int32; follows the row plan at PlanHead
     int32_t magic, n_chunks, n_sb, n_empty, n_slots, n_groups, n_split, n_entries;
 };
 constexpr int32_t kStreamMagic = 0x4d535452;   // "MSTR"
-constexpr int kStreamHub = 512;   // rows with more neighbours are cut into pieces
+constexpr int kStreamHubDefault = 512;   // rows with more neighbours are cut into pieces (MACR_SPMM_HUB at plan time)
 constexpr int kStreamPiece = 256; // entries per piece (255 neighbours + its end marker)
 // layout after the header: chunk_desc[n_chunks] = {first sub-batch (32 entries), end, first empty row | count << 24, slot or -1}, empties[n_empty],
 // slot_group[n_slots], group_slot0[n_groups+1], group_split[n_groups], split_group0[n_split+1],
@@ -936,11 +936,65 @@ static int plan_chunk() {
     return c;
 }
 
-static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) {
+// Eight ranges of source rows of equal entry mass over the rows longer than `hub` (see build_stream: XCD affinity).
+static void source_octants(int N, const int32_t *rowptr, const int32_t *col, int hub, int32_t (&bound)[kNumXcd + 1]) {
+    std::vector<int64_t> mass((size_t)N + 1, 0);
+    int64_t total = 0;
+    for (int r = 0; r < N; ++r)
+        if (rowptr[r + 1] - rowptr[r] > hub)
+            for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) { ++mass[col[e]]; ++total; }
+    bound[0] = 0;
+    int64_t run = 0; int x = 1;
+    for (int c = 0; c < N && x < kNumXcd; ++c) {
+        run += mass[c];
+        while (x < kNumXcd && run * kNumXcd >= total * x) bound[x++] = c + 1;
+    }
+    for (; x <= kNumXcd; ++x) bound[x] = N;
+    bound[kNumXcd] = N;
+}
+static bool plan_octants() {
+    static const bool on = !(getenv("MACR_SPMM_OCTANTS") && atoi(getenv("MACR_SPMM_OCTANTS")) == 0);
+    return on;
+}
+// `queues[x]`: what should run on XCD x (block j of a launch lands on XCD j % 8 and takes four consecutive work items);
+// `free_items`: what may run anywhere.  Returns the launch order: block j = four items of queue j % 8, the shortest queue
+// takes the next free item, an empty queue borrows from the fullest.
+static std::vector<int32_t> xcd_order(std::vector<int32_t> (&q)[kNumXcd], const std::vector<int32_t> &free_items) {
+    int turn = 0;
+    for (int32_t k : free_items) {
+        int best = turn;
+        for (int x = 0; x < kNumXcd; ++x) if (q[(turn + x) % kNumXcd].size() < q[best].size()) best = (turn + x) % kNumXcd;
+        q[best].push_back(k);
+        turn = (best + 1) % kNumXcd;
+    }
+    size_t total = 0, at[kNumXcd] = {};
+    for (int x = 0; x < kNumXcd; ++x) total += q[x].size();
+    std::vector<int32_t> order;
+    order.reserve(total);
+    for (int blk = 0; order.size() < total; ++blk) {
+        int x = blk % kNumXcd;
+        for (int i4 = 0; i4 < 4 && order.size() < total; ++i4) {
+            if (at[x] >= q[x].size()) {
+                int donor = -1;
+                for (int y = 0; y < kNumXcd; ++y)
+                    if (at[y] < q[y].size() && (donor < 0 || q[y].size() - at[y] > q[donor].size() - at[donor])) donor = y;
+                x = donor;
+            }
+            order.push_back(q[x][at[x]++]);
+        }
+    }
+    return order;
+}
+
+static void build_plan(int N, const int32_t *rowptr, const int32_t *col, std::vector<int32_t> &out) {
     struct Item { int32_t row, beg, end, slot; };
     std::vector<Item> items;
-    std::vector<int32_t> slot_group, group_slot0, group_split, split_group0, split_row;
+    std::vector<int32_t> slot_group, group_slot0, group_split, split_group0, split_row, piece_xcd;
     const int chunk = plan_chunk();
+    const bool octants = col && plan_octants();
+    int32_t bound[kNumXcd + 1] = {};
+    if (octants) source_octants(N, rowptr, col, chunk, bound);
+    auto octant_of = [&](int32_t c) { int x = 0; while (x + 1 < kNumXcd && c >= bound[x + 1]) ++x; return x; };
     int n_slots = 0;
     for (int r = 0; r < N; ++r) {
         const int beg = rowptr[r], end = rowptr[r + 1];
@@ -949,15 +1003,23 @@ static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) 
         } else {
             split_group0.push_back((int32_t)group_split.size());
             int in_group = kGroup;
-            for (int b = beg; b < end; b += chunk) {
+            for (int b = beg; b < end;) {
                 if (in_group == kGroup) {                       // a new group of this row
                     group_slot0.push_back(n_slots);
                     group_split.push_back((int32_t)split_row.size());
                     in_group = 0;
                 }
                 slot_group.push_back((int32_t)group_split.size() - 1);
-                items.push_back({r, b, b + chunk < end ? b + chunk : end, n_slots++});
+                int pe = b + chunk < end ? b + chunk : end;
+                int x = -1;
+                if (octants) {                                  // a piece stays inside one range of source rows
+                    x = octant_of(col[b]);
+                    while (pe > b + 1 && col[pe - 1] >= bound[x + 1]) --pe;
+                }
+                piece_xcd.push_back(x);
+                items.push_back({r, b, pe, n_slots++});
                 ++in_group;
+                b = pe;
             }
             split_row.push_back(r);
         }
@@ -971,6 +1033,14 @@ static void build_plan(int N, const int32_t *rowptr, std::vector<int32_t> &out) 
         if (pa) return false;
         return a.end - a.beg > b.end - b.beg;                   // then the longest rows
     });
+    if (octants && n_slots > 0) {
+        // the pieces (the first n_slots items, in slot order) in XCD order: piece w of the launch is wave w, block w / 4
+        std::vector<int32_t> q[kNumXcd], none;
+        for (int k = 0; k < n_slots; ++k) q[piece_xcd[items[k].slot]].push_back(k);
+        const std::vector<int32_t> order = xcd_order(q, none);
+        std::vector<Item> pieces(items.begin(), items.begin() + n_slots);
+        for (int k = 0; k < n_slots; ++k) items[k] = pieces[order[k]];
+    }
     PlanHeader h = {};
     h.magic = kPlanMagic; h.n_items = (int32_t)items.size(); h.n_split = (int32_t)split_row.size(); h.n_slots = n_slots; h.N = N;
     h.chunk = chunk; h.n_groups = (int32_t)group_split.size();
@@ -989,7 +1059,12 @@ static int stream_target() {
     static const int t = getenv("MACR_SPMM_T") && atoi(getenv("MACR_SPMM_T")) >= 32 ? atoi(getenv("MACR_SPMM_T")) : 256;
     return t;
 }
+static int stream_hub() {
+    static const int t = getenv("MACR_SPMM_HUB") && atoi(getenv("MACR_SPMM_HUB")) >= 32 ? atoi(getenv("MACR_SPMM_HUB")) : kStreamHubDefault;
+    return t;
+}
 static void build_stream(int N, const int32_t *rowptr, const int32_t *col, const float *val, std::vector<int32_t> &out) {
+    const int kStreamHub = stream_hub();
     std::vector<int32_t> pc, prow, chunk_slot, empties, slot_group, group_slot0, group_split, split_group0, split_row;
     std::vector<float> pv;
     const int T = stream_target();
@@ -1018,6 +1093,17 @@ static void build_stream(int N, const int32_t *rowptr, const int32_t *col, const
     };
     auto open_chunk = [&]() { if (!open) { chunk_start.push_back((int32_t)(pc.size() / 32)); open = true; } };
     int n_slots = 0;
+    // XCD affinity of the hub rows' pieces.  A hub row walks its neighbours in ascending order, so a piece covers a RANGE of
+    // source rows; block b of a launch runs on XCD b % 8, each with an L2 of its own (4 MB).  The source rows of all hub
+    // entries are cut into eight ranges of equal entry mass, a hub row is cut at the range boundaries first, and the
+    // chunk order below puts the pieces of range x into blocks that land on XCD x: that L2 then serves one eighth of the
+    // source rows (~1 MB of an 8 MB user table) instead of all of them.  Placement is the driver's habit, not a promise:
+    // results do not depend on it, only the L2 hit rate does.  MACR_SPMM_OCTANTS=0 keeps stream order.
+    const bool octants = plan_octants();
+    int32_t bound[kNumXcd + 1];
+    source_octants(N, rowptr, col, kStreamHub, bound);
+    std::vector<int32_t> chunk_xcd;                               // per chunk: the XCD its block should land on, -1 any
+    auto octant_of = [&](int32_t c) { int x = 0; while (x + 1 < kNumXcd && c >= bound[x + 1]) ++x; return x; };
     for (int r = 0; r < N; ++r) {
         const int beg = rowptr[r], end = rowptr[r + 1], deg = end - beg;
         if (deg == 0) { empties.push_back(r); continue; }
@@ -1033,7 +1119,7 @@ static void build_stream(int N, const int32_t *rowptr, const int32_t *col, const
             close_chunk(-1);
             split_group0.push_back((int32_t)group_split.size());
             int in_group = kGroup;
-            for (int b = beg; b < end; b += kStreamPiece - 1) {
+            for (int b = beg; b < end;) {
                 if (in_group == kGroup) {
                     group_slot0.push_back(n_slots);
                     group_split.push_back((int32_t)split_row.size());
@@ -1041,11 +1127,17 @@ static void build_stream(int N, const int32_t *rowptr, const int32_t *col, const
                 }
                 slot_group.push_back((int32_t)group_split.size() - 1);
                 open_chunk();
-                const int pe = b + kStreamPiece - 1 < end ? b + kStreamPiece - 1 : end;
+                int pe = b + kStreamPiece - 1 < end ? b + kStreamPiece - 1 : end;
+                const int x = octant_of(col[b]);
+                if (octants)                                      // a piece stays inside one source range
+                    while (pe > b + 1 && col[pe - 1] >= bound[x + 1]) --pe;
                 for (int e = b; e < pe; ++e) emit(col[e], val[e]);
                 emit_end(r, -2);
                 close_chunk(n_slots++);
+                chunk_xcd.resize(chunk_slot.size(), -1);
+                chunk_xcd.back() = octants ? x : -1;
                 ++in_group;
+                b = pe;
             }
             split_row.push_back(r);
         }
@@ -1054,9 +1146,18 @@ static void build_stream(int N, const int32_t *rowptr, const int32_t *col, const
     group_slot0.push_back(n_slots);
     split_group0.push_back((int32_t)group_split.size());
     const int n_chunks = (int)chunk_start.size();
+    chunk_xcd.resize(n_chunks, -1);
     // chunk_sb[k] = start of chunk k, chunk_sb[n_chunks] = end: chunks are contiguous, so ends = next starts
     std::vector<int32_t> sbv(chunk_start);
     sbv.push_back((int32_t)(pc.size() / 32));
+    // the order the chunks are launched in (their descriptors; the stream itself stays in row order): eight queues, one per
+    // XCD, the pinned pieces first, the other chunks dealt round; block j takes four chunks of queue j % 8
+    std::vector<int32_t> order;
+    {
+        std::vector<int32_t> q[kNumXcd], free_chunks;
+        for (int k = 0; k < n_chunks; ++k) (chunk_xcd[k] >= 0 ? q[chunk_xcd[k]] : free_chunks).push_back(k);
+        order = xcd_order(q, free_chunks);
+    }
     std::vector<int32_t> chunk_empty(n_chunks + 1);
     for (int k = 0; k <= n_chunks; ++k) chunk_empty[k] = (int32_t)((long long)empties.size() * k / (n_chunks ? n_chunks : 1));
     if (n_chunks == 0) chunk_empty[0] = 0;
@@ -1068,9 +1169,10 @@ static void build_stream(int N, const int32_t *rowptr, const int32_t *col, const
     reinterpret_cast<PlanHeader *>(out.data())->reserved = (int32_t)out.size();
     out.insert(out.end(), reinterpret_cast<int32_t *>(&h), reinterpret_cast<int32_t *>(&h) + sizeof(h) / 4);
     while (out.size() % 4) out.push_back(0);
-    for (int k = 0; k < n_chunks; ++k) {
-        const int32_t ne = chunk_empty[k + 1] - chunk_empty[k];
-        out.push_back(sbv[k]); out.push_back(sbv[k + 1]); out.push_back(chunk_empty[k] | (ne << 24)); out.push_back(chunk_slot[k]);
+    for (int pos = 0; pos < n_chunks; ++pos) {
+        const int k = order[pos];
+        const int32_t ne = chunk_empty[pos + 1] - chunk_empty[pos];
+        out.push_back(sbv[k]); out.push_back(sbv[k + 1]); out.push_back(chunk_empty[pos] | (ne << 24)); out.push_back(chunk_slot[k]);
     }
     out.insert(out.end(), empties.begin(), empties.end());
     out.insert(out.end(), slot_group.begin(), slot_group.end());
@@ -1095,8 +1197,11 @@ using namespace macr;
 
 // ---- plan (host) ----------------------------------------------------------------
 static void build_whole_plan(int N, const int32_t *rowptr, const int32_t *col, const float *val, std::vector<int32_t> &v) {
-    build_plan(N, rowptr, v);
-    if (col && val && !(getenv("MACR_SPMM_STREAM") && atoi(getenv("MACR_SPMM_STREAM")) == 0)) build_stream(N, rowptr, col, val, v);
+    build_plan(N, rowptr, col, v);
+    // The entry stream is an option (MACR_SPMM_STREAM=1 at plan time): with the XCD-affine piece order both kernels sit at
+    // the same level (stand-alone dense layer at the Yelp2018 shape: row kernel 42.7 us, stream kernel 46.3; LightGCN step
+    // 205-209 us either way), and the row kernel needs no second copy of the matrix.
+    if (col && val && getenv("MACR_SPMM_STREAM") && atoi(getenv("MACR_SPMM_STREAM")) != 0) build_stream(N, rowptr, col, val, v);
 }
 
 extern "C" size_t macr_spmm_plan_bytes(int N, const int32_t *rowptr_host, const int32_t *col_host, const float *val_host) {
