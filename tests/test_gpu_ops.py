@@ -405,6 +405,42 @@ def test_lgcn_propagate_matches_oracle(ops, d, L):
     np.testing.assert_allclose(got2, want, rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("octants", ["1", "0"])
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_lgcn_propagate_entry_stream_and_piece_orders(ops, d, octants, monkeypatch):
+    """The optional entry-stream kernel of the dense layers (MACR_SPMM_STREAM=1 at plan time: chunks of a plan-owned
+    (column, weight) stream, rows ending inside it) and both orders of the hub pieces (MACR_SPMM_OCTANTS: cut at the
+    boundaries of eight source-row ranges and placed XCD by XCD, or in slot order) give the oracle's propagation; a graph
+    with several hub rows, rows without neighbours and a row-count that is no multiple of anything."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(17 + d)
+    n_users, n_items = 1900, 517
+    R = (rs.rand(n_users, n_items) < 0.02).astype(np.float32)
+    R[:, :5] = (rs.rand(n_users, 5) < 0.7)                # five hub items with > 1000 neighbours each
+    R[:3, :] = 0; R[:, 40:47] = 0                         # users and items without neighbours
+    A = sp.bmat([[None, sp.csr_matrix(R)], [sp.csr_matrix(R.T), None]]).tocsr()
+    deg = np.asarray(A.sum(1)).ravel()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5).astype(np.float32)
+    dinv[np.isinf(dinv)] = 0
+    A = (sp.diags(dinv) @ A @ sp.diags(dinv)).tocsr().astype(np.float32)
+    A.sort_indices()
+    E0 = rs.standard_normal((n_users + n_items, d)).astype(np.float32)
+    monkeypatch.setenv("MACR_SPMM_OCTANTS", octants)
+    for stream in ("0", "1"):
+        monkeypatch.setenv("MACR_SPMM_STREAM", stream)
+        adj = ops.CSR.from_scipy(A, "cuda")
+        assert adj.plan_host[2] >= 5                      # header: n_split
+        assert (adj.plan_host[7] > 0) == (stream == "1")  # header: offset of the stream section
+        for L in (1, 2, 3):
+            want = oracle.lgcn_propagate(A.indptr, A.indices, A.data, E0, L)
+            ops.timing_begin()
+            got = ops.lgcn_propagate(adj, dev(E0), L).cpu().numpy()
+            names = {n for n, _ in ops.timing_end(16)}
+            assert ("spmm_stream" in names) == (stream == "1"), names
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize("kind", [oracle.LOSS_NORMALBCE, oracle.LOSS_RUBIBCEBOTH])
 @pytest.mark.parametrize("d,B", [(64, 256), (128, 100)])
 def test_lgcn_train_step_matches_oracle(ops, kind, d, B):
