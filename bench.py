@@ -100,7 +100,7 @@ def algorithmic_bytes(kernel, cfg, B):
 
 def bench_config4(args, rank, world, dev):
     """BASELINE configs[4]: synthetic 10 M users x 1 M items, d = 128, B = 8192, `rubibceboth`, ONE model whose rows are
-    range-sharded over the ranks (macr_amd/sharded_train.py: three batch-sized collectives per step, dense Adam on the
+    sharded over the ranks, row r on rank r % W (macr_amd/sharded_train.py: three batch-sized collectives per step, dense Adam on the
     rank's shard) and whose evaluation is item-sharded (one all-gather of per-shard top-K).  `value` = interactions/s of
     that one model = B * steps / time: the work is fixed, more ranks divide it -- strong scaling.  At --gpus 1 the whole
     22.5 GB of tables, Adam slots and gradient scratch sit on the one GPU (the > 2^32-byte case of every kernel)."""
@@ -109,8 +109,8 @@ def bench_config4(args, rank, world, dev):
     from macr_amd.evaluator import Evaluator
     n_users, n_items, d, B = args.c4_users, args.c4_items, 128, 8192
     lr, regs, alpha, beta, c = 1e-3, 1e-5, 1e-3, 1e-3, 40.0
-    u_lo, u_hi = sharded_train.row_range(n_users, rank, world)
-    i_lo, i_hi = sharded_train.row_range(n_items, rank, world)
+    own_u = sharded_train.Owned(n_users, rank, world)         # interleaved: row r on rank r % world
+    own_i = sharded_train.Owned(n_items, rank, world)
     gen = torch.Generator(device=dev).manual_seed(4000 + rank)
 
     def xavier_rows(rows_local, rows_global):
@@ -122,7 +122,7 @@ def bench_config4(args, rank, world, dev):
     hyper = ops.make_hyper(lr, regs, alpha, beta, B)
     model = sharded_train.RowShardedMF(None, None, w, wu, sharded_train.HipBackend(ops.LOSS_RUBIBCEBOTH, d, hyper, dev),
                                        rank=rank, world=world,
-                                       shards=(xavier_rows(u_hi - u_lo, n_users), xavier_rows(i_hi - i_lo, n_items), n_users, n_items))
+                                       shards=(xavier_rows(own_u.n, n_users), xavier_rows(own_i.n, n_items), n_users, n_items))
     n_batches = 32                  # (independent of --steps: same batches, same model, whatever the call)
     batches = synth.train_batches(n_batches, n_users, n_items, B, gen_all, dev)
 
@@ -167,7 +167,7 @@ def bench_config4(args, rank, world, dev):
     for name, ms in marks:
         e = ku.setdefault(name, [0, 0.0]); e[0] += 1; e[1] += ms
     kern = {n_: {"launches_per_step": c_ / n_prof, "event_us": 1e3 * t / c_} for n_, (c_, t) in ku.items()}
-    rows_local = (u_hi - u_lo) + (i_hi - i_lo)
+    rows_local = own_u.n + own_i.n
     adam_bytes = 24.0 * d * rows_local
     adam_us = kern.get("adam_dense", {}).get("event_us")
     roofline = None
@@ -187,14 +187,14 @@ def bench_config4(args, rank, world, dev):
         mask_lists = synth.interaction_lists(U, n_items, 30.0, seed=778)
         gt_lists = [sorted(set(rs.randint(0, n_items, 50).tolist()) - set(m)) for m in mask_lists]
         ev = Evaluator(mask_lists, gt_lists, n_items, dev)
-        ev.local_items_range = (i_lo, i_hi)
+        ev.set_local_items(own_i)
         ud = torch.from_numpy(users).to(dev)
         Pq = torch.zeros((U, d), dtype=torch.float32, device=dev)       # the query users' rows: every rank adds the ones it owns
 
         def query_rows():
-            own = (ud >= u_lo) & (ud < u_hi)
+            own, loc = own_u.local_of(ud)
             Pq.zero_()
-            Pq[own] = model.P[ud[own] - u_lo]
+            Pq[own] = model.P[loc[own]]
             if world > 1:
                 torch.distributed.all_reduce(Pq)
 
@@ -217,7 +217,7 @@ def bench_config4(args, rank, world, dev):
         # filter with fp32 re-scoring -- the same ranking, bit for bit
         t_f32, _ = timed("f32")
         t_ev, ret = timed(os.environ.get("MACR_EVAL_FILTER", "bf16").lower())
-        flops_rank = 2.0 * U * (i_hi - i_lo) * d
+        flops_rank = 2.0 * U * own_i.n * d
         eval_out = {"eval_users_per_s": U / t_ev, "eval_ms_per_pass": 1e3 * t_ev, "eval_users": U, "eval_filter": ev.filter,
                     "eval_metrics": {k: float(v[0]) for k, v in ret.items()},
                     "roofline_eval": {"filter": "f32", "bound": "mfma", "flops_per_rank": flops_rank, "eval_users_per_s": U / t_f32,
@@ -249,7 +249,7 @@ def bench_config4(args, rank, world, dev):
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[4]: synthetic %d users x %d items, MACR-MF rubibceboth d=%d batch=%d c=%g; ONE model, "
-                                      "rows range-sharded over %d rank(s) (training), item-sharded evaluation of %d query users"
+                                      "rows sharded over %d rank(s), row r on rank r %% W (training), item-sharded evaluation of %d query users"
                                       % (n_users, n_items, d, B, c, world, args.c4_eval_users),
                           "parallelism": "row-sharded x%d: all-reduce of the batch's 3B rows (%.1f MB) + all-reduce of the (B,B) "
                                          "partials + broadcast of the branch-vector partials per step; evaluation: all-reduce of "

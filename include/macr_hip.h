@@ -157,26 +157,29 @@ int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int n_items,
  * gradient scratch are range-sharded over W ranks (new: the reference keeps each table
  * in one tf.Variable, macr_mf/model.py:112-113; BASELINE configs[4] = 10 M x 1 M rows,
  * d = 128 on 8 GPUs, where the dense Adam pass alone streams 33.8 GB per step).
- * Same arithmetic as macr_mf_train_step (loss kinds RUBIBCEBOTH, RUBIBCE); the three
+ * Same arithmetic as macr_mf_train_step (all loss kinds; NORMALBCE has no (B,B) term and no branch vectors:
+ * macr_shard_forward only prepares indices, macr_shard_bxb is not called, *branch_bytes comes back 0); the three
  * exchanges between the calls are the host's (torch.distributed / RCCL over xGMI,
  * macr_amd/sharded_train.py):
- *   macr_shard_gather    rows3[3][B][d] = the batch rows THIS rank owns, zero elsewhere
- *                        (users [u_lo,u_hi) of P, items [i_lo,i_hi) of Q)      -> all-reduce(sum) rows3
+ *   macr_shard_gather    rows3[3][B][d] = the batch rows THIS rank owns, zero elsewhere      -> all-reduce(sum) rows3
+ *                        Ownership of a table: local row l is global row lo + l * stride, l < n_loc (stride 1 = a
+ *                        contiguous range; stride = W, lo = rank = interleaved: hot low ids spread over the ranks)
  *   macr_shard_forward   dots and branch factors of the whole batch (every rank, from rows3)
  *   macr_shard_bxb       this rank's row blocks of the (B,B) term into zeroed partials; *partials /
  *                        *partial_bytes = the fp32 region to sum over the ranks   -> all-reduce(sum)
  *   macr_shard_backward  losses[3] and the gradient rows of the whole batch (staging buffer inside
  *                        the workspace); *branch_grads / *branch_bytes = partial rows of dw, dw_user
  *                        (replicated work; broadcast rank 0's so w, w_user stay bit-identical)
- *   macr_shard_apply     references to this rank's rows are radix-sorted by row, one owner per row
- *                        sums them into gP/gQ (local shards), dense Adam over the local shards
- *                        and over w, w_user
+ *   macr_shard_apply     references to this rank's rows are radix-sorted by row; the dense Adam pass over the
+ *                        local shards sums each row's staged gradient rows itself (rows with more than 16
+ *                        references through gP/gQ), and updates w, w_user
  * All five take the SAME workspace (>= macr_shard_workspace_bytes(B, d), 256-B aligned,
  * contents preserved between the calls of one step); adam_pow as in macr_mf_train_step.
  * -------------------------------------------------------------------------*/
 size_t macr_shard_workspace_bytes(int B, int d);
-int macr_shard_gather(int B, int d, const float *P_loc, int u_lo, int u_hi, const float *Q_loc, int i_lo, int i_hi,
-                      const int32_t *u, const int32_t *i, const int32_t *j, float *rows3, void *stream);
+int macr_shard_gather(int B, int d, const float *P_loc, int u_lo, int u_stride, int n_users_loc, const float *Q_loc,
+                      int i_lo, int i_stride, int n_items_loc, const int32_t *u, const int32_t *i, const int32_t *j,
+                      float *rows3, void *stream);
 int macr_shard_forward(int loss_kind, int B, int d, const float *rows3, const float *w, const float *wu,
                        void *workspace, size_t workspace_bytes, void *stream);
 int macr_shard_bxb(int B, int d, int rank, int world, void **partials, size_t *partial_bytes,
@@ -184,8 +187,8 @@ int macr_shard_bxb(int B, int d, int rank, int world, void **partials, size_t *p
 int macr_shard_backward(int loss_kind, int B, int d, const float *rows3, const float *w, const float *wu,
                         float *adam_pow, const macr_hyper *hp, float *losses, void **branch_grads,
                         size_t *branch_bytes, void *workspace, size_t workspace_bytes, void *stream);
-int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int i_lo,
-                     const int32_t *u, const int32_t *i, const int32_t *j,
+int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int u_stride, int i_lo,
+                     int i_stride, const int32_t *u, const int32_t *i, const int32_t *j,
                      float *P_loc, float *Q_loc, float *w, float *wu,
                      float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu, float *vwu,
                      float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ, const macr_hyper *hp,

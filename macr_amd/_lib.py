@@ -46,11 +46,11 @@ SIGNATURES = {
     "macr_mf_train_step": (_i, [_i] * 5 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [_p, ctypes.POINTER(Hyper), _p, _i, _p, _z, _p]),
     "macr_mf_train_flush": (_i, [_i] * 5 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), _p, _z, _p]),
     "macr_shard_workspace_bytes": (_z, [_i, _i]),
-    "macr_shard_gather": (_i, [_i, _i, _p, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "macr_shard_gather": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "macr_shard_forward": (_i, [_i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "macr_shard_bxb": (_i, [_i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "macr_shard_backward": (_i, [_i, _i, _i, _p, _p, _p, _p, ctypes.POINTER(Hyper), _p, _p, _p, _p, _z, _p]),
-    "macr_shard_apply": (_i, [_i] * 7 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), _p, _z, _p]),
+    "macr_shard_apply": (_i, [_i] * 9 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), _p, _z, _p]),
     "macr_sample_triples": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _i, _p, _i, _p, _p, _p, _p]),
     "macr_sample_triples_many": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "macr_spmm_plan_bytes": (_z, [_i, _p, _p, _p]),

@@ -1550,8 +1550,17 @@ extern "C" int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int
 // points are the device half.  Results equal the single-GPU step up to summation order.
 // ============================================================================
 namespace macr {
-__global__ __launch_bounds__(256) void k_rows_gather_owned(int B, int lpr, const float *__restrict__ P, int u_lo, int u_hi,
-                                                           const float *__restrict__ Q, int i_lo, int i_hi,
+// Ownership of a table's rows: rank-local row l is global row lo + l * stride, l < n_loc (stride 1: a contiguous range;
+// stride = number of ranks, lo = rank: interleaved -- the hot low item ids and the Adam pass spread evenly).
+struct Owned { int lo, stride, n_loc; };
+__device__ __forceinline__ int owned_local(const Owned o, int row) {      // local index, or -1 when another rank owns the row
+    const int rel = row - o.lo;
+    if (rel < 0) return -1;
+    const int l = o.stride == 1 ? rel : rel / o.stride;
+    return (l < o.n_loc && l * o.stride == rel) ? l : -1;
+}
+__global__ __launch_bounds__(256) void k_rows_gather_owned(int B, int lpr, const float *__restrict__ P, const Owned ou,
+                                                           const float *__restrict__ Q, const Owned oi,
                                                            const int32_t *__restrict__ u, const int32_t *__restrict__ i,
                                                            const int32_t *__restrict__ j, float *__restrict__ rows3) {
     const long long n4 = 3LL * B * lpr;
@@ -1559,9 +1568,9 @@ __global__ __launch_bounds__(256) void k_rows_gather_owned(int B, int lpr, const
         const long long ref = g / lpr;
         const int sub = (int)(g % lpr), role = (int)(ref / B), t = (int)(ref % B);
         const int row = role == 0 ? u[t] : role == 1 ? i[t] : j[t];
-        const int lo = role == 0 ? u_lo : i_lo, hi = role == 0 ? u_hi : i_hi;
+        const int l = owned_local(role == 0 ? ou : oi, row);
         float4 v = make_float4(0, 0, 0, 0);
-        if (row >= lo && row < hi) v = ld4((role == 0 ? P : Q) + ((size_t)(row - lo) * lpr + sub) * 4);
+        if (l >= 0) v = ld4((role == 0 ? P : Q) + ((size_t)l * lpr + sub) * 4);
         st4(rows3 + (size_t)g * 4, v);
     }
 }
@@ -1569,15 +1578,17 @@ __global__ __launch_bounds__(256) void k_iota3(int B, int32_t *__restrict__ a) {
     for (int t = blockIdx.x * 256 + threadIdx.x; t < B; t += gridDim.x * 256) { a[t] = t; a[B + t] = t; a[2 * (size_t)B + t] = B + t; }
 }
 // sort keys of the references to THIS rank's rows (others: key_end, which k_seg_reduce ignores); value = staging row
-__global__ __launch_bounds__(256) void k_shard_keys(int B, int u_lo, int n_u, int i_lo, int n_i, const int32_t *__restrict__ u,
+__global__ __launch_bounds__(256) void k_shard_keys(int B, const Owned ou, const Owned oi, const int32_t *__restrict__ u,
                                                     const int32_t *__restrict__ i, const int32_t *__restrict__ j,
-                                                    uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
-    const uint32_t none = (uint32_t)(n_u + n_i);
+                                                    uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                    uint32_t *__restrict__ n_work) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_work = 0u;           // work list of k_seg_scan, empty again
+    const uint32_t none = (uint32_t)(ou.n_loc + oi.n_loc);
     for (int t = blockIdx.x * 256 + threadIdx.x; t < B; t += gridDim.x * 256) {
-        const int ru = u[t] - u_lo, ri = i[t] - i_lo, rj = j[t] - i_lo;
-        key[t] = (ru >= 0 && ru < n_u) ? (uint32_t)ru : none;                         val[t] = (uint32_t)t;
-        key[B + t] = (ri >= 0 && ri < n_i) ? (uint32_t)(n_u + ri) : none;             val[B + t] = (uint32_t)(B + t);
-        key[2 * (size_t)B + t] = (rj >= 0 && rj < n_i) ? (uint32_t)(n_u + rj) : none; val[2 * (size_t)B + t] = (uint32_t)(2 * (size_t)B + t);
+        const int ru = owned_local(ou, u[t]), ri = owned_local(oi, i[t]), rj = owned_local(oi, j[t]);
+        key[t] = ru >= 0 ? (uint32_t)ru : none;                                   val[t] = (uint32_t)t;
+        key[B + t] = ri >= 0 ? (uint32_t)(ou.n_loc + ri) : none;                  val[B + t] = (uint32_t)(B + t);
+        key[2 * (size_t)B + t] = rj >= 0 ? (uint32_t)(ou.n_loc + rj) : none;      val[2 * (size_t)B + t] = (uint32_t)(2 * (size_t)B + t);
     }
 }
 struct ShardWs { PairWs pair; int32_t *iota; size_t bytes; };
@@ -1604,23 +1615,25 @@ extern "C" size_t macr_shard_workspace_bytes(int B, int d) {
     return carve_shard_ws(nullptr, B, d).bytes;
 }
 
-extern "C" int macr_shard_gather(int B, int d, const float *P_loc, int u_lo, int u_hi, const float *Q_loc, int i_lo, int i_hi,
-                                 const int32_t *u, const int32_t *i, const int32_t *j, float *rows3, void *stream) {
-    MACR_REQUIRE(B > 0 && dim_supported(d) && P_loc && Q_loc && u && i && j && rows3 && u_lo <= u_hi && i_lo <= i_hi,
-                 MACR_E_INVALID, "shard_gather: bad argument");
-    k_rows_gather_owned<<<grid_for(3LL * B * (d / 4)), 256, 0, as_stream(stream)>>>(B, d / 4, P_loc, u_lo, u_hi, Q_loc, i_lo, i_hi,
-                                                                                 u, i, j, rows3);
+extern "C" int macr_shard_gather(int B, int d, const float *P_loc, int u_lo, int u_stride, int n_users_loc, const float *Q_loc,
+                                 int i_lo, int i_stride, int n_items_loc, const int32_t *u, const int32_t *i, const int32_t *j,
+                                 float *rows3, void *stream) {
+    MACR_REQUIRE(B > 0 && dim_supported(d) && P_loc && Q_loc && u && i && j && rows3 && u_lo >= 0 && i_lo >= 0 && u_stride >= 1 &&
+                     i_stride >= 1 && n_users_loc >= 0 && n_items_loc >= 0, MACR_E_INVALID, "shard_gather: bad argument");
+    const Owned ou = {u_lo, u_stride, n_users_loc}, oi = {i_lo, i_stride, n_items_loc};
+    k_rows_gather_owned<<<grid_for(3LL * B * (d / 4)), 256, 0, as_stream(stream)>>>(B, d / 4, P_loc, ou, Q_loc, oi, u, i, j, rows3);
     MACR_CHECK_LAUNCH("shard_gather", as_stream(stream));
     return MACR_OK;
 }
 
 extern "C" int macr_shard_forward(int loss_kind, int B, int d, const float *rows3, const float *w, const float *wu,
                                   void *workspace, size_t workspace_bytes, void *stream) {
-    MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE, MACR_E_UNSUPPORTED,
-                 "shard_forward: loss_kind=%d (the (B,B) losses only)", loss_kind);
+    MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE || loss_kind == MACR_LOSS_NORMALBCE,
+                 MACR_E_INVALID, "shard_forward: loss_kind=%d", loss_kind);
     MACR_REQUIRE(rows3 && w && wu, MACR_E_INVALID, "shard_forward: null pointer");
     MACR_SHARD_COMMON("shard_forward");
     k_iota3<<<grid_for(B), 256, 0, st>>>(B, sw.iota);
+    if (loss_kind == MACR_LOSS_NORMALBCE) { MACR_CHECK_LAUNCH("iota", st); return MACR_OK; }   // (forward and backward are one kernel: macr_shard_backward)
     PendingAdam none = {};
     const int user_branch = loss_kind == MACR_LOSS_RUBIBCEBOTH;
     const float *Isrc = rows3 + (size_t)B * d;
@@ -1662,8 +1675,8 @@ extern "C" int macr_shard_bxb(int B, int d, int rank, int world, void **partials
 extern "C" int macr_shard_backward(int loss_kind, int B, int d, const float *rows3, const float *w, const float *wu,
                                    float *adam_pow, const macr_hyper *hp, float *losses, void **branch_grads,
                                    size_t *branch_bytes, void *workspace, size_t workspace_bytes, void *stream) {
-    MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE, MACR_E_UNSUPPORTED,
-                 "shard_backward: loss_kind=%d", loss_kind);
+    MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE || loss_kind == MACR_LOSS_NORMALBCE,
+                 MACR_E_INVALID, "shard_backward: loss_kind=%d", loss_kind);
     MACR_REQUIRE(rows3 && w && wu && adam_pow && losses, MACR_E_INVALID, "shard_backward: null pointer");
     if (int e = validate_hyper(hp, "shard_backward")) return e;
     MACR_SHARD_COMMON("shard_backward");
@@ -1674,6 +1687,20 @@ extern "C" int macr_shard_backward(int loss_kind, int B, int d, const float *row
     L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
     const float coef = hp->decay / (float)hp->batch_size_cfg;
     const float *Isrc = rows3 + (size_t)B * d;
+    if (loss_kind == MACR_LOSS_NORMALBCE) {
+        // macr_mf/model.py:277-287: no (B,B) term, no branch vectors -- per-pair forward and backward in one kernel, gradient
+        // rows of the whole batch into the staging buffer (replicated work, a few MB), then the loss sums
+        MACR_DISPATCH_LPR(d, (k_pair_normal_stage<LPR><<<ws.nblk_bwd, 256, 0, st>>>(
+                                 B, sw.iota, sw.iota + B, sw.iota + 2 * (size_t)B, rows3, Isrc, ws.stage, ws.part, coef, 1, adam_pow,
+                                 adam_pow, ws.scal, hp->lr, hp->beta1, hp->beta2)));
+        MACR_CHECK_LAUNCH("pair_normal", st);
+        L.n_part = ws.nblk_bwd; L.lpart = nullptr; L.n_lpart = 0;
+        k_finalize_losses<<<1, 64, 0, st>>>(L);
+        MACR_CHECK_LAUNCH("finalize_losses", st);
+        if (branch_grads) *branch_grads = nullptr;
+        if (branch_bytes) *branch_bytes = 0;
+        return MACR_OK;
+    }
     MACR_DISPATCH_LPR(d, (k_pair_bwd_stage<LPR><<<ws.nblk_bwd + 1, 256, 0, st>>>(
                              B, ws.Bp, ws.nrb, ws.ncb, sw.iota, sw.iota + B, sw.iota + 2 * (size_t)B, rows3, Isrc, w, wu, ws.fwd,
                              ws.rowpart, ws.colpart, ws.stage, ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal, hp->lr,
@@ -1685,32 +1712,55 @@ extern "C" int macr_shard_backward(int loss_kind, int B, int d, const float *row
 }
 
 /* this rank's rows: sort the references to them, one owner per row sums its staging rows, dense Adam over the shard */
-extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int i_lo,
-                                const int32_t *u, const int32_t *i, const int32_t *j, float *P, float *Q, float *w, float *wu,
-                                float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu, float *vwu,
+extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int u_stride, int i_lo,
+                                int i_stride, const int32_t *u, const int32_t *i, const int32_t *j, float *P, float *Q, float *w,
+                                float *wu, float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu, float *vwu,
                                 float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ, const macr_hyper *hp,
                                 void *workspace, size_t workspace_bytes, void *stream) {
-    MACR_REQUIRE(n_users_loc >= 0 && n_items_loc >= 0 && u && i && j && P && Q && w && wu && mP && vP && mQ && vQ && mw && vw &&
-                     mwu && vwu && gP && gQ && touchedP && touchedQ, MACR_E_INVALID, "shard_apply: bad argument");
+    MACR_REQUIRE(n_users_loc >= 0 && n_items_loc >= 0 && u_stride >= 1 && i_stride >= 1 && u && i && j && P && Q && w && wu && mP &&
+                     vP && mQ && vQ && mw && vw && mwu && vwu && gP && gQ && touchedP && touchedQ, MACR_E_INVALID,
+                 "shard_apply: bad argument");
     if (int e = validate_hyper(hp, "shard_apply")) return e;
     MACR_SHARD_COMMON("shard_apply");
     const int n = 3 * B;
-    k_shard_keys<<<grid_for(B), 256, 0, st>>>(B, u_lo, n_users_loc, i_lo, n_items_loc, u, i, j, ws.ska, ws.sva);
+    const Owned ou = {u_lo, u_stride, n_users_loc}, oi = {i_lo, i_stride, n_items_loc};
+    k_shard_keys<<<grid_for(B), 256, 0, st>>>(B, ou, oi, u, i, j, ws.ska, ws.sva, ws.n_work);
     const int flip = launch_radix_sort(ws.ska, ws.sva, ws.skb, ws.svb, n, (uint32_t)(n_users_loc + n_items_loc), ws.ghist, st);
     MACR_CHECK_LAUNCH("ref_sort", st);
     const uint32_t *sk = flip ? ws.skb : ws.ska, *sv = flip ? ws.svb : ws.sva;
-    MACR_DISPATCH_LPR(d, (k_seg_reduce<LPR><<<(n + 256 / LPR - 1) / (256 / LPR), 256, 0, st>>>(
-                             n, n_users_loc, (uint32_t)(n_users_loc + n_items_loc), sk, sv, ws.stage, gP, gQ, touchedP, touchedQ)));
-    MACR_CHECK_LAUNCH("seg_reduce", st);
+    // The step completes here, so nothing needs a row's gradient as a row in memory: k_seg_scan finds each row's first
+    // reference and names its run in the row's flag, the Adam pass sums the <= 16 staged rows itself (adam_block INDEXED;
+    // longer runs -- the hot items -- go through gP/gQ by k_seg_sum).  MACR_SEG_UNFUSED=1: the segment reduce writes
+    // every row, as before (A/B measurements, tests).
+    const char *unfused = getenv("MACR_SEG_UNFUSED");
+    const bool indexed = (size_t)n <= kRefMaxRefs && !(unfused && unfused[0] == '1');
+    if (indexed) {
+        uint32_t *work = flip ? ws.ska : ws.skb;                       // the buffer the sort no longer needs
+        k_seg_scan<<<(n + 255) / 256, 256, 0, st>>>(n, n_users_loc, (uint32_t)(n_users_loc + n_items_loc), sk, touchedP, touchedQ, work, ws.n_work);
+        MACR_CHECK_LAUNCH("seg_index", st);
+        MACR_DISPATCH_LPR(d, (k_seg_sum<LPR><<<1024, 256, 0, st>>>(work, ws.n_work, n_users_loc, sk, sv, ws.stage, gP, gQ)));
+        MACR_CHECK_LAUNCH("seg_sum", st);
+    } else {
+        MACR_DISPATCH_LPR(d, (k_seg_reduce<LPR><<<(n + 256 / LPR - 1) / (256 / LPR), 256, 0, st>>>(
+                                 n, n_users_loc, (uint32_t)(n_users_loc + n_items_loc), sk, sv, ws.stage, gP, gQ, touchedP, touchedQ)));
+        MACR_CHECK_LAUNCH("seg_reduce", st);
+    }
     AdamArgs a;
     long long nb = 0;
     a.n_seg = 0; a.lpr = d / 4; a.lpr_shift = d == 32 ? 3 : d == 64 ? 4 : d == 128 ? 5 : 6;
     a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
     if (n_users_loc) add_seg(a, P, mP, vP, gP, touchedP, n_users_loc, nb);
     if (n_items_loc) add_seg(a, Q, mQ, vQ, gQ, touchedQ, n_items_loc, nb);
-    add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
+    const int n_tab = a.n_seg;
+    if (loss_kind != MACR_LOSS_NORMALBCE) add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
     if (loss_kind == MACR_LOSS_RUBIBCEBOTH) add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
     LossArgs L; L.losses = nullptr;
+    if (indexed) {
+        for (int k = 0; k < n_tab; ++k) { a.seg[k].sv = sv; a.seg[k].stage = ws.stage; }
+        k_adam_dense<true><<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
+        MACR_CHECK_LAUNCH("adam_indexed", st);
+        return MACR_OK;
+    }
     k_adam_dense<false><<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;

@@ -53,9 +53,30 @@ class Evaluator(object):
         # (lo, hi): the `items_tab` the methods below receive is ALREADY this rank's shard, rows [lo, hi) of a catalogue
         # whose full table exists nowhere (row-sharded training, BASELINE configs[4]); None: a replicated full table
         self.local_items_range = None
+        # the same for a STRIDED shard (set_local_items): local row l is item lo + l * stride
+        self._local_own = None
+        self._mask_lists = mask_lists
+
+    def set_local_items(self, own):
+        """`items_tab` is this rank's shard of an item table sharded like the training state (sharded_train.Owned: local
+        row l = item own.lo + l * own.stride).  A contiguous shard is an item offset; an interleaved one is ranked in LOCAL
+        ids against the owned part of every query's train list and its ids are mapped back before the shards meet."""
+        if own.stride == 1:
+            self.local_items_range = (own.lo, own.lo + own.n)
+            self._local_own = None
+            return
+        self.local_items_range = None
+        self._local_own = own
+        local_lists = [[(g - own.lo) // own.stride for g in row if g >= own.lo and (g - own.lo) % own.stride == 0
+                        and (g - own.lo) // own.stride < own.n] for row in self._mask_lists]
+        self._mask_local = ops.CSR.from_lists(local_lists, self.device)
+        self.__dict__.pop("_seeds", None)
 
     def _shard(self, items_tab):
         """(lo, hi, this rank's rows of the item table)"""
+        if self._local_own is not None:
+            assert items_tab.shape[0] == self._local_own.n
+            return 0, self._local_own.n, items_tab
         if self.local_items_range is not None:
             lo, hi = self.local_items_range
             assert items_tab.shape[0] == hi - lo
@@ -92,7 +113,8 @@ class Evaluator(object):
             if use and seed is None:
                 seed = seeds[(K, lo, hi)] = torch.full((U, ops.SEED_WIDTH), -1, dtype=torch.int32, device=self.device)
             # the ranking leaves its best SEED_WIDTH candidates per query in `seed` (in place): the next ranking's seeds
-            vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, self.mask, lo,
+            mask = self._mask_local if self._local_own is not None else self.mask
+            vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, mask, lo,
                                        seed=seed if seeded else None, seed_out=seed, stats=self._stats)
         else:
             # the ranking workspace (candidate lists, mask bitmap) grows with the number of queries: rank them in
@@ -101,10 +123,14 @@ class Evaluator(object):
             for a in range(0, U, self.max_queries_per_pass):
                 b = min(U, a + self.max_queries_per_pass)
                 uid = user_ids[a:b] if user_ids is not None else torch.arange(a, b, dtype=torch.int32, device=self.device)
+                mask = self._mask_local if self._local_own is not None else self.mask
                 parts.append(ops.score_topk(kind, users_tab, uid, items_local, K, None if sig_u is None else sig_u[a:b],
-                                            sig_i, c, self.mask.row_range(a, b), lo))
+                                            sig_i, c, mask.row_range(a, b), lo))
             vals = torch.cat([p[0] for p in parts], dim=1)
             idx = torch.cat([p[1] for p in parts], dim=1)
+        if self._local_own is not None:           # local row -> item id (the order by id within the shard is the same either way)
+            own = self._local_own
+            idx = torch.where(idx >= 0, idx * own.stride + own.lo, idx)
         return vals, idx
 
     def _seed_feedback(self):
@@ -147,6 +173,8 @@ class Evaluator(object):
         return cache[key]
 
     def _has_seeds(self, K, n_items):
+        if self._local_own is not None:
+            return (K, 0, self._local_own.n) in self.__dict__.get("_seeds", {})
         if self.local_items_range is not None:
             return (K,) + tuple(self.local_items_range) in self.__dict__.get("_seeds", {})
         rank, ws = sharding.world()
@@ -264,7 +292,8 @@ class Evaluator(object):
             # (ranking workspace, mask bitmaps) alive for as long as they exist, whatever the caches do later
             keep = [users_tab, user_ids, items_tab, w, wu, c, ops._topk_ws_cache.get(items_tab.device)]
             keep.extend(self.__dict__.get("_seeds", {}).values())
-            for csr in [self.mask] + list(self.mask.__dict__.get("_row_ranges", {}).values()):
+            local = [] if self._local_own is None else [self._mask_local] + list(self._mask_local.__dict__.get("_row_ranges", {}).values())
+            for csr in [self.mask] + list(self.mask.__dict__.get("_row_ranges", {}).values()) + local:
                 keep.extend(csr.__dict__.get("_mask_bits", {}).values())
             entry = self._graphs[key] = (stages, out, keep)
         (ga, local, gathered, gb), out = entry[0], entry[1]

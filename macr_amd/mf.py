@@ -200,6 +200,144 @@ class BPRMF(object):
                 getattr(st, name).copy_(sd["opt%d.%s" % (kind, name)])
 
 
+class ShardedBPRMF(object):
+    """BPRMF whose embedding tables, Adam slots and gradient scratch are ROW-SHARDED over the ranks of the process group
+    (`--row_shard 1`; macr_amd/sharded_train.py): what the MF CLI needs of BPRMF, same names.  The reference keeps each table
+    in one tf.Variable (macr_mf/model.py:112-113); at BASELINE configs[4] sizes the TF-style dense Adam pass over every row
+    is what a step costs, and it divides by the number of ranks.  Every rank feeds the SAME batch (same sampler seed).
+    The initial tables are the ones BPRMF(seed) draws (the same host generator), so a sharded and an unsharded run start
+    from the same model."""
+    sharded = True
+    _TRAIN = BPRMF._TRAIN
+
+    def __init__(self, args, data_config, device=None, seed=12345, layout="interleaved"):
+        from . import sharded_train, sharding
+        self.n_users, self.n_items = data_config['n_users'], data_config['n_items']
+        self.decay, self.emb_dim, self.lr, self.batch_size = args.regs, args.embed_size, args.lr, args.batch_size
+        self.c, self.alpha, self.beta = args.c, args.alpha, args.beta
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.rank, self.world = sharding.world()
+        self.rubi_c = 0.0
+        gen = torch.Generator().manual_seed(seed)
+        d = self.emb_dim
+        dp = self.d_pad = ops.padded_dim(d)
+        cpu = torch.device("cpu")
+        self.own_u = sharded_train.Owned(self.n_users, self.rank, self.world, layout)
+        self.own_i = sharded_train.Owned(self.n_items, self.rank, self.world, layout)
+        # the draws of BPRMF.init_weights, in its order; only this rank's rows go to the device
+        P = self.own_u.take(xavier_uniform((self.n_users, d), gen, cpu)).to(self.device)
+        Q = self.own_i.take(xavier_uniform((self.n_items, d), gen, cpu)).to(self.device)
+        w = ops.pad_cols(xavier_uniform((d, 1), gen, cpu).reshape(-1), dp).to(self.device)
+        wu = ops.pad_cols(xavier_uniform((d, 1), gen, cpu).reshape(-1), dp).to(self.device)
+        self._hyper = ops.make_hyper(self.lr, self.decay, self.alpha, self.beta, self.batch_size)
+        self._init = (ops.pad_cols(P, dp), ops.pad_cols(Q, dp), w, wu)
+        self._layout = layout
+        self._models = {}
+        self._q = {}
+
+    def kind_of(self, train):
+        if train not in self._TRAIN:
+            raise NotImplementedError("--train %s is not on the MI355X hot path (normalbce | rubibce | rubibceboth)" % train)
+        return self._TRAIN[train][1]
+
+    def _model(self, kind):
+        from . import sharded_train
+        if kind not in self._models:
+            if self._models:
+                raise NotImplementedError("a row-sharded model trains with one loss kind per run")
+            P, Q, w, wu = self._init
+            self._models[kind] = sharded_train.RowShardedMF(
+                None, None, w, wu, sharded_train.HipBackend(kind, self.d_pad, self._hyper, self.device), rank=self.rank,
+                world=self.world, shards=(P, Q, self.n_users, self.n_items), layout=self._layout)
+        return self._models[kind]
+
+    def _any(self):
+        if not self._models:
+            self._model(ops.LOSS_RUBIBCEBOTH)
+        return next(iter(self._models.values()))
+
+    to_device_batch = BPRMF.to_device_batch
+
+    def update_c(self, sess, c):
+        self.rubi_c = float(c)
+
+    def train_step(self, kind, batch, losses=None, defer=False):
+        out = self._model(kind).step(batch[0], batch[1], batch[2])
+        if losses is not None:
+            losses.copy_(out)
+        return out
+
+    def sync(self):
+        pass
+
+    def parameters(self):
+        return []                                   # nothing is replicated but w, w_user, which are bit-identical by construction
+
+    @property
+    def user_embedding(self):
+        return self._any().P                        # THIS RANK'S rows (own_u)
+
+    @property
+    def item_embedding(self):
+        return self._any().Q                        # THIS RANK'S rows (own_i): the evaluator's item shard
+
+    @property
+    def w(self):
+        return self._any().w
+
+    @property
+    def w_user(self):
+        return self._any().wu
+
+    def query_rows(self, uid):
+        """(U, d) rows of the query users on every rank: each rank adds the rows it owns, one all-reduce (a persistent
+        buffer per query set: the evaluator replays a captured graph that reads it)"""
+        key = uid.data_ptr()
+        if key not in self._q:
+            self._q[key] = torch.zeros((uid.numel(), self.d_pad), dtype=torch.float32, device=self.device)
+        buf, m = self._q[key], self._any()
+        own, loc = self.own_u.local_of(uid.long())
+        buf.zero_()
+        buf[own] = m.P[loc[own]]
+        m._all_reduce(buf, "query_rows")
+        return buf
+
+    def _full(self, local, own):
+        m = self._any()
+        if self.world == 1:
+            return local.clone()
+        full = torch.zeros((own.n_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        full[own.global_ids(local.device)] = local
+        m._all_reduce(full, "full_table")
+        return full
+
+    def state_dict(self):
+        """The model as BPRMF saves it (full tables): COLLECTIVE -- every rank calls it, the main rank writes the file."""
+        sd = {"rubi_c": self.rubi_c}
+        for kind, m in self._models.items():
+            sd["user_embedding"], sd["item_embedding"] = self._full(m.P, self.own_u), self._full(m.Q, self.own_i)
+            sd["w"], sd["w_user"] = m.w, m.wu
+            for name, own in (("mP", self.own_u), ("vP", self.own_u), ("mQ", self.own_i), ("vQ", self.own_i)):
+                sd["opt%d.%s" % (kind, name)] = self._full(getattr(m, name), own)
+            for name in ("mw", "vw", "mwu", "vwu"):
+                sd["opt%d.%s" % (kind, name)] = getattr(m, name)
+            sd["opt%d.adam_pow" % kind] = m.backend.adam_pow
+            sd["row_shard_kind"] = kind
+        return sd
+
+    def load_state_dict(self, sd):
+        kind = int(sd["row_shard_kind"])
+        m = self._model(kind)
+        dev = self.device
+        m.P.copy_(self.own_u.take(sd["user_embedding"].to(dev))); m.Q.copy_(self.own_i.take(sd["item_embedding"].to(dev)))
+        m.w.copy_(sd["w"]); m.wu.copy_(sd["w_user"]); self.rubi_c = float(sd["rubi_c"])
+        for name, own in (("mP", self.own_u), ("vP", self.own_u), ("mQ", self.own_i), ("vQ", self.own_i)):
+            getattr(m, name).copy_(own.take(sd["opt%d.%s" % (kind, name)].to(dev)))
+        for name in ("mw", "vw", "mwu", "vwu"):
+            getattr(m, name).copy_(sd["opt%d.%s" % (kind, name)])
+        m.backend.adam_pow.copy_(sd["opt%d.adam_pow" % kind])
+
+
 class Session(object):
     """Stands where the reference has tf.Session: `run(fetches, feed_dict)` with the fetch handles of
     BPRMF / LightGCN.  Training fetch lists return [None, loss, mf_loss, reg_loss] as Python floats

@@ -2,8 +2,8 @@
 
 The reference keeps each embedding table in one tf.Variable (macr_mf/model.py:112-113).  At 10 M users x 1 M items,
 d = 128, TF-style dense Adam streams 24*d bytes of EVERY row per step -- 33.8 GB -- which is what a step costs; the
-batch itself is a few MB.  So the rows of P and Q (with their Adam slots and gradient scratch) are range-sharded over
-the ranks, one process per GPU, and a step exchanges only batch-sized data:
+batch itself is a few MB.  So the rows of P and Q (with their Adam slots and gradient scratch) are sharded over the ranks
+(interleaved: row r on rank r % W, see Owned), one process per GPU, and a step exchanges only batch-sized data:
 
     1. gather     each rank writes the batch rows it owns into a zero (3,B,d) buffer; ONE all-reduce(sum) makes the
                   batch's 3B rows resident everywhere (every row has exactly one owner)         3*B*d*4 bytes
@@ -17,7 +17,8 @@ the ranks, one process per GPU, and a step exchanges only batch-sized data:
                   bytes per step are divided by the number of ranks
 
 All three collectives are latency-class messages on xGMI (12.6 MB + 0.5 MB + 8 KB at B = 8192, d = 128).  The math is
-the single-GPU step's (macr_mf_train_step) up to summation order; `backend` is the device half (HIP: the macr_shard_*
+the single-GPU step's (macr_mf_train_step) up to summation order, for all three loss kinds (`normalbce` has no (B,B)
+term and no branch vectors: steps 2-4 are one kernel and there is ONE collective per step); `backend` is the device half (HIP: the macr_shard_*
 entry points of include/macr_hip.h; the CPU tests plug the oracle in its place)."""
 import ctypes
 
@@ -30,6 +31,37 @@ from . import sharding
 def row_range(n_rows, rank, world):
     """Contiguous, balanced [lo, hi) of the rows rank owns (same rule as the evaluator's item shards)."""
     return sharding.item_shard_range(n_rows, rank, world)
+
+
+class Owned(object):
+    """Which rows of a table a rank holds: local row l is global row lo + l * stride, l < n.
+    "interleaved" (default): row r lives on rank r % world -- item ids follow popularity in recommender data, so a
+    contiguous range puts every hot item (and its Adam traffic, its gradient references) on rank 0; interleaved, the hot
+    rows and the row counts spread evenly (they differ by at most one row).  "range": contiguous, balanced ranges."""
+
+    def __init__(self, n_rows, rank, world, layout="interleaved"):
+        self.n_rows, self.rank, self.world, self.layout = n_rows, rank, world, layout
+        if layout == "interleaved":
+            self.lo, self.stride = rank, world
+            self.n = (n_rows - rank + world - 1) // world if n_rows > rank else 0
+        elif layout == "range":
+            lo, hi = row_range(n_rows, rank, world)
+            self.lo, self.stride, self.n = lo, 1, hi - lo
+        else:
+            raise ValueError("layout must be 'interleaved' or 'range'")
+
+    def global_ids(self, device=None):
+        return torch.arange(self.n, dtype=torch.long, device=device) * self.stride + self.lo
+
+    def take(self, full):
+        """this rank's rows of a full table"""
+        return full[self.lo::self.stride][:self.n] if self.stride > 1 else full[self.lo:self.lo + self.n]
+
+    def local_of(self, ids):
+        """(mask of the ids this rank owns, their local indices) for an integer tensor / array of global row ids"""
+        rel = ids - self.lo
+        own = (rel >= 0) & (rel % self.stride == 0) & (rel // self.stride < self.n)
+        return own, rel // self.stride
 
 
 class HipBackend(object):
@@ -60,8 +92,9 @@ class HipBackend(object):
         B = u.numel()
         self._reserve(B)
         o, L = self.ops, self._lib.lib()
-        self._lib.check(L.macr_shard_gather(B, self.d, o._ptr(shard.P), shard.u_lo, shard.u_hi, o._ptr(shard.Q), shard.i_lo,
-                                            shard.i_hi, o._ptr(u), o._ptr(i), o._ptr(j), o._ptr(self.rows3), o._stream()))
+        ou, oi = shard.own_u, shard.own_i
+        self._lib.check(L.macr_shard_gather(B, self.d, o._ptr(shard.P), ou.lo, ou.stride, ou.n, o._ptr(shard.Q), oi.lo, oi.stride,
+                                            oi.n, o._ptr(u), o._ptr(i), o._ptr(j), o._ptr(self.rows3), o._stream()))
         return self.rows3
 
     def forward_and_bxb(self, shard, rows3, rank, world):
@@ -69,6 +102,8 @@ class HipBackend(object):
         B = rows3.shape[1]
         self._lib.check(L.macr_shard_forward(self.kind, B, self.d, o._ptr(rows3), o._ptr(shard.w), o._ptr(shard.wu),
                                              o._ptr(self.ws), self.ws.numel(), o._stream()))
+        if self.kind == self._lib.LOSS_NORMALBCE:
+            return None                                     # no (B,B) term (macr_mf/model.py:277-287): nothing to sum over the ranks
         ptr, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
         self._lib.check(L.macr_shard_bxb(B, self.d, rank, world, ctypes.byref(ptr), ctypes.byref(nbytes), o._ptr(self.ws),
                                          self.ws.numel(), o._stream()))
@@ -82,12 +117,15 @@ class HipBackend(object):
                                               o._ptr(self.adam_pow), ctypes.byref(self.hyper), o._ptr(self.losses),
                                               ctypes.byref(ptr), ctypes.byref(nbytes), o._ptr(self.ws), self.ws.numel(),
                                               o._stream()))
+        if not nbytes.value:
+            return self.losses, None                        # normalbce: no branch vectors
         return self.losses, self._view(ptr, nbytes)         # losses; branch-vector partial rows (broadcast from rank 0)
 
     def apply(self, shard, u, i, j):
         o, L = self.ops, self._lib.lib()
-        self._lib.check(L.macr_shard_apply(self.kind, u.numel(), self.d, shard.u_hi - shard.u_lo, shard.i_hi - shard.i_lo,
-                                           shard.u_lo, shard.i_lo, o._ptr(u), o._ptr(i), o._ptr(j),
+        ou, oi = shard.own_u, shard.own_i
+        self._lib.check(L.macr_shard_apply(self.kind, u.numel(), self.d, ou.n, oi.n, ou.lo, ou.stride, oi.lo, oi.stride,
+                                           o._ptr(u), o._ptr(i), o._ptr(j),
                                            o._ptr(shard.P), o._ptr(shard.Q), o._ptr(shard.w), o._ptr(shard.wu),
                                            o._ptr(shard.mP), o._ptr(shard.vP), o._ptr(shard.mQ), o._ptr(shard.vQ),
                                            o._ptr(shard.mw), o._ptr(shard.vw), o._ptr(shard.mwu), o._ptr(shard.vwu),
@@ -99,20 +137,20 @@ class RowShardedMF(object):
     """This rank's shard of the MF model + its optimizer state.  P_full / Q_full (any rank-identical source) are only
     sliced at construction; afterwards a rank holds rows [u_lo,u_hi) of P and [i_lo,i_hi) of Q, nothing else."""
 
-    def __init__(self, P_full, Q_full, w, wu, backend, rank=None, world=None, group=None, shards=None):
+    def __init__(self, P_full, Q_full, w, wu, backend, rank=None, world=None, group=None, shards=None, layout="interleaved"):
         """shards=(P_shard, Q_shard, n_users, n_items): this rank's rows directly (P_full / Q_full are ignored) -- for
-        tables whose full copy exists nowhere (10 M x 1 M rows, d = 128)."""
+        tables whose full copy exists nowhere (10 M x 1 M rows, d = 128).  layout: see Owned."""
         r, ws = sharding.world()
         self.rank, self.world, self.group = (r if rank is None else rank), (ws if world is None else world), group
         self.n_users, self.n_items = (shards[2], shards[3]) if shards else (P_full.shape[0], Q_full.shape[0])
-        self.u_lo, self.u_hi = row_range(self.n_users, self.rank, self.world)
-        self.i_lo, self.i_hi = row_range(self.n_items, self.rank, self.world)
+        self.own_u = Owned(self.n_users, self.rank, self.world, layout)
+        self.own_i = Owned(self.n_items, self.rank, self.world, layout)
         clone = lambda t: t.clone().contiguous()
         if shards:
             self.P, self.Q = shards[0].contiguous(), shards[1].contiguous()
-            assert self.P.shape[0] == self.u_hi - self.u_lo and self.Q.shape[0] == self.i_hi - self.i_lo
+            assert self.P.shape[0] == self.own_u.n and self.Q.shape[0] == self.own_i.n
         else:
-            self.P, self.Q = clone(P_full[self.u_lo:self.u_hi]), clone(Q_full[self.i_lo:self.i_hi])
+            self.P, self.Q = clone(self.own_u.take(P_full)), clone(self.own_i.take(Q_full))
         self.w, self.wu = clone(w.reshape(-1)), clone(wu.reshape(-1))
         self.collective_ms = None                   # bench: {"rows": [...], "partials": [...], "branch": [...]} event times
         z = torch.zeros_like
@@ -172,13 +210,11 @@ class RowShardedMF(object):
 
     def full_tables(self):
         """(P, Q) reassembled on every rank (tests / checkpoints; not on the training path)."""
-        def cat(local, n_rows):
+        def cat(local, own):
             if self.world == 1:
                 return local.clone()
-            d = local.shape[1]
-            full = torch.zeros((n_rows, d), dtype=local.dtype, device=local.device)
-            lo, _ = row_range(n_rows, self.rank, self.world)
-            full[lo:lo + local.shape[0]] = local
+            full = torch.zeros((own.n_rows, local.shape[1]), dtype=local.dtype, device=local.device)
+            full[own.global_ids(local.device)] = local
             self._all_reduce(full)
             return full
-        return cat(self.P, self.n_users), cat(self.Q, self.n_items)
+        return cat(self.P, self.own_u), cat(self.Q, self.own_i)

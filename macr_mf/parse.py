@@ -53,6 +53,8 @@ _FLAGS = [
     # additive
     ("seed", int, 12345, "[new] seed of python/numpy/torch RNGs (the reference hard-codes 12345)"),
     ("resume", int, 0, "[new] 1: load the newest checkpoint of this run's checkpoint directory and continue training"),
+    ("row_shard", int, 0, "[new] 1: ONE model whose table rows are sharded over the ranks of the process group (torchrun); "
+                          "0: every rank trains a replica"),
     ("sampler", str, "reference", "[new] reference: the reference's python `random` stream (host); device: GPU sampler"),
 ]
 

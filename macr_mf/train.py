@@ -51,8 +51,13 @@ def test(sess, model, test_users, batch_test_flag=False, model_type='o', valid_s
         mask, gt = data.eval_lists(test_users, valid_set)
         ev = _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
                                  torch.tensor(list(test_users), dtype=torch.int32, device=model.device))
+        if getattr(model, "sharded", False):         # --row_shard 1: the item table this rank holds IS its item shard
+            ev[0].set_local_items(model.own_i)
     evaluator, uid = ev
     model.sync()
+    if getattr(model, "sharded", False):
+        return evaluator.test_mf(_MODEL_TYPES[model_type], model.query_rows(uid), None, model.item_embedding, Ks,
+                                 model.w, model.w_user, model.rubi_c)
     return evaluator.test_mf(_MODEL_TYPES[model_type], model.user_embedding, uid, model.item_embedding, Ks,
                              model.w, model.w_user, model.rubi_c)
 
@@ -69,8 +74,13 @@ def test_sweep(sess, model, test_users, cs, model_type='rubi_both', valid_set="t
         mask, gt = data.eval_lists(test_users, valid_set)
         _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
                             torch.tensor(list(test_users), dtype=torch.int32, device=model.device))
+        if getattr(model, "sharded", False):
+            _evaluators[key][0].set_local_items(model.own_i)
     evaluator, uid = _evaluators[key]
     model.sync()
+    if getattr(model, "sharded", False):
+        return evaluator.test_mf_sweep(_MODEL_TYPES[model_type], model.query_rows(uid), None, model.item_embedding, Ks,
+                                       model.w, model.w_user, list(cs))
     return evaluator.test_mf_sweep(_MODEL_TYPES[model_type], model.user_embedding, uid, model.item_embedding, Ks,
                                    model.w, model.w_user, list(cs))
 
@@ -148,7 +158,11 @@ def main(sweep=False):
             logging.info(text)
 
     config = dict(n_users=data.n_users, n_items=data.n_items)
-    model = BPRMF(args, config, seed=seed)
+    if args.row_shard == 1:
+        from macr_amd.mf import ShardedBPRMF
+        model = ShardedBPRMF(args, config, seed=seed)
+    else:
+        model = BPRMF(args, config, seed=seed)
     if main_rank:
         print('MF model.')
     sess = Session(model)
@@ -259,9 +273,10 @@ def main(sweep=False):
 
         config, stopping_step, should_stop = early_stop(ret['hit_ratio'][0], ret['ndcg'][0], ret['recall'][0],
                                                         ret['precision'][0], epoch, config, stopping_step)
+        state = model.state_dict() if args.save_flag == 1 and (main_rank or getattr(model, "sharded", False)) else None   # (sharded: collective)
         if args.save_flag == 1 and main_rank:
             os.makedirs(_ckpt_dir(), exist_ok=True)
-            torch.save(model.state_dict(), _ckpt_dir() + '{}_ckpt.pt'.format(epoch))
+            torch.save(state, _ckpt_dir() + '{}_ckpt.pt'.format(epoch))
             # what --resume 1 needs besides the model: best-so-far / early-stopping state and where the samplers stand
             from macr_amd import train_state
             train_state.save(_ckpt_dir() + '{}_train_state.json'.format(epoch),

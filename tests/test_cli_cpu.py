@@ -20,7 +20,7 @@ def test_mf_flags_match_reference_defaults():
     for k, v in ref.items():
         assert k in ours, k
         assert ours[k] == v and type(ours[k]) is type(v), (k, ours[k], v)
-    assert set(ours) - set(ref) == {"seed", "sampler", "resume"}  # additive flags only
+    assert set(ours) - set(ref) == {"seed", "sampler", "resume", "row_shard"}  # additive flags only
 
 
 def test_lightgcn_flags_match_reference_defaults():

@@ -301,11 +301,17 @@ def test_mf_large_batch_staged_path_is_deterministic(ops):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("kind_name,B,d", [("LOSS_RUBIBCEBOTH", 777, 64), ("LOSS_RUBIBCE", 256, 32), ("LOSS_RUBIBCEBOTH", 2048, 128)])
-def test_row_shard_entry_points_world1(ops, kind_name, B, d):
+@pytest.mark.parametrize("unfused", [False, True])
+@pytest.mark.parametrize("kind_name,B,d", [("LOSS_RUBIBCEBOTH", 777, 64), ("LOSS_RUBIBCE", 256, 32), ("LOSS_RUBIBCEBOTH", 2048, 128),
+                                           ("LOSS_NORMALBCE", 1000, 64), ("LOSS_NORMALBCE", 300, 256)])
+def test_row_shard_entry_points_world1(ops, kind_name, B, d, unfused, monkeypatch):
     """The macr_shard_* device entry points (row-sharded training) on one rank owning everything: gather, forward,
     (B,B) row blocks, backward into the staging buffer, sorted segment reduce + Adam -- against the oracle step."""
     from macr_amd import sharded_train
+    if unfused:                                   # the segment reduce writes every gradient row (before round 4: always)
+        monkeypatch.setenv("MACR_SEG_UNFUSED", "1")
+    else:                                         # the Adam pass sums the staged rows itself (adam_block INDEXED)
+        monkeypatch.delenv("MACR_SEG_UNFUSED", raising=False)
     kind = getattr(ops, kind_name)
     n_users, n_items = 900, 350
     P, Q, w, wu, u, i, j = make_problem(B + d, n_users, n_items, d, B)
@@ -322,7 +328,10 @@ def test_row_shard_entry_points_world1(ops, kind_name, B, d):
             i = (rs.zipf(1.3, B) % n_items).astype(np.int32)
             j = rs.randint(0, n_items, B).astype(np.int32)
         want = oracle.mf_train_step(getattr(oracle, kind_name), u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, bs)
+        ops.timing_begin()
         got = model.step(dev(u), dev(i), dev(j)).cpu().numpy()
+        names = {n for n, _ in ops.timing_end(64)}
+        assert ("adam_indexed" in names) == (not unfused) and ("seg_reduce" in names) == unfused, names
         np.testing.assert_allclose(got, want, rtol=1e-5)
         if t == 0:
             np.testing.assert_allclose(model.mP.cpu().numpy() / 0.1, st.m[0] / 0.1, rtol=2e-4, atol=2e-6 * np.abs(st.m[0] / 0.1).max())
@@ -331,6 +340,38 @@ def test_row_shard_entry_points_world1(ops, kind_name, B, d):
         np.testing.assert_allclose(mine.cpu().numpy(), theirs, rtol=0, atol=2e-3 * lr * 3, err_msg=name)
     assert float(model.gP.abs().max()) == 0.0 and float(model.gQ.abs().max()) == 0.0
     assert int(model.tP.sum()) == 0 and int(model.tQ.sum()) == 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_evaluator_ranks_interleaved_item_shards(ops, world, eval_filter):
+    """The item shard of a row-sharded model is STRIDED (item g on rank g % W, sharded_train.Owned): every rank ranks its
+    rows in local ids against the owned part of the train lists, ids are mapped back, the shards merge to the unsharded
+    ranking bit for bit -- W ranks played one after the other on this GPU."""
+    from macr_amd import sharded_train
+    from macr_amd.evaluator import Evaluator
+    rs = np.random.RandomState(world)
+    n_users, N, d, K = 400, 3001, 64, 20
+    P = (rs.standard_normal((n_users, d)) * 0.5).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.5 + rs.standard_normal((N, 1)) * 0.4).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    users = np.sort(rs.choice(n_users, 300, replace=False)).astype(np.int32)
+    mask = random_mask(rs, len(users), N, 14, heavy=(0, 7))
+    gt = [sorted(rs.choice(N, 5, replace=False).tolist()) for _ in users]
+    Pq = dev(P[users])
+    whole = Evaluator(mask, gt, N, torch.device("cuda"))
+    wv, wi, wc = whole.rank(ops.SCORE_RUBI_BOTH, Pq, None, dev(Q), K, dev(w), dev(wu), 40.0)
+    parts_v, parts_i = [], []
+    for r in range(world):
+        own = sharded_train.Owned(N, r, world)
+        ev = Evaluator(mask, gt, N, torch.device("cuda"))
+        ev.set_local_items(own)
+        for rep in range(2):                                     # second call: seeded thresholds (local ids)
+            v, ix = ev.rank_local(ops.SCORE_RUBI_BOTH, Pq, None, dev(np.ascontiguousarray(Q[r::world])), K, dev(w), dev(wu), 40.0)
+        lv, li, _ = ops.topk_merge(v, ix)
+        assert bool(((li < 0) | (li % world == r)).all())
+        parts_v.append(lv); parts_i.append(li)
+    mv, mi, mc = ops.topk_merge(torch.stack(parts_v), torch.stack(parts_i))
+    assert torch.equal(mi, wi) and torch.equal(mv, wv) and torch.equal(mc, wc)
 
 
 def test_mf_deferred_mode_flushes_on_batch_size_change(ops):

@@ -498,6 +498,38 @@ def test_mf_cli_two_ranks_one_gpu(tmp_path):
     assert abs(h1 - h2) <= 0.02 * max(h1, 1e-3), (h1, h2)
 
 
+@pytest.mark.parametrize("train,test_", [("rubibceboth", "rubi"), ("normalbce", "normal")])
+def test_mf_cli_row_sharded_two_ranks_one_gpu(tmp_path, train, test_):
+    """--row_shard 1 under torch.distributed.run (gloo rig, both ranks on this GPU): ONE model, table rows interleaved over
+    the ranks, item-sharded evaluation of the strided shards, checkpoint of the reassembled tables -- same losses and
+    metrics as the unsharded single-process run from the same seed (same initial model, same batches)."""
+    os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
+    args_ = [os.path.join(REPO, "macr_mf", "train.py"), "--dataset", "addressa", "--batch_size", "1024", "--cuda", "0",
+             "--saveID", "rs", "--log_interval", "2", "--lr", "0.001", "--epoch", "2", "--train", train, "--test", test_,
+             "--c", "40", "--alpha", "1e-3", "--beta", "1e-3"]
+    one = _run_cli(args_, str(tmp_path))
+    ckpt = tmp_path / "mf_addressa_checkpoint/wd_1e-05_lr_0.001_rs/1_ckpt.pt"
+    ref_sd = torch.load(ckpt, map_location="cpu")
+    os.remove(ckpt)
+    env = dict(os.environ, MACR_DIST_BACKEND="gloo", PYTHONUNBUFFERED="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547"] + args_ + ["--row_shard", "1"],
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-3000:]
+    tag = "c:40.00" if test_ == "rubi" else "Epoch 1"
+    l1 = [l for l in one.splitlines() if l.startswith(tag) and "hit=[" in l]
+    l2 = [l for l in two.stdout.splitlines() if l.startswith(tag) and "hit=[" in l]
+    assert len(l1) == 1 and len(l2) == 1, two.stdout
+    loss1, loss2 = (float(l.split("train==[")[1].split("=")[0]) for l in (l1[0], l2[0]))
+    assert abs(loss1 - loss2) <= 1e-5 * abs(loss1), (loss1, loss2)
+    h1, h2 = (float(l.split("hit=[")[1].split(",")[0]) for l in (l1[0], l2[0]))
+    assert abs(h1 - h2) <= 0.02 * max(h1, 1e-3), (h1, h2)
+    sd = torch.load(ckpt, map_location="cpu")                              # written by rank 0 from the reassembled tables
+    for name in ("user_embedding", "item_embedding"):
+        assert sd[name].shape == ref_sd[name].shape
+        assert float((sd[name] - ref_sd[name]).abs().max()) <= 2e-3 * 1e-3 * 30, name
+
+
 def test_row_sharded_training_two_ranks_one_gpu(tmp_path):
     """configs[4]'s training path at test size: P, Q and their Adam state range-sharded over two ranks (gloo rig on one
     GPU), the macr_shard_* device entry points, three collectives per step; losses and the reassembled tables must

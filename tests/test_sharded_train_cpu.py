@@ -22,6 +22,25 @@ def test_row_ranges_partition_the_tables():
         assert prev == n
 
 
+def test_both_layouts_give_every_row_exactly_one_owner():
+    for layout in ("interleaved", "range"):
+        for n, w in ((13485, 2), (101, 3), (7, 8), (64, 8), (1, 3)):
+            seen = np.zeros(n, np.int64)
+            sizes = []
+            for r in range(w):
+                own = sharded_train.Owned(n, r, w, layout)
+                ids = own.global_ids().numpy()
+                assert len(ids) == own.n and (ids < n).all()
+                seen[ids] += 1
+                mask, loc = own.local_of(torch.arange(n))
+                assert np.array_equal(np.nonzero(mask.numpy())[0], ids) and np.array_equal(loc[mask].numpy(), np.arange(own.n))
+                assert torch.equal(own.take(torch.arange(n)), torch.from_numpy(ids))
+                sizes.append(own.n)
+            assert (seen == 1).all() and max(sizes) - min(sizes) <= 1
+    # interleaved: the hot low ids do not share a rank
+    assert [sharded_train.Owned(1000, r, 4).global_ids()[0].item() for r in range(4)] == [0, 1, 2, 3]
+
+
 def _vp(a):
     import ctypes
     return a.ctypes.data_as(ctypes.c_void_p)
@@ -40,11 +59,10 @@ class OracleBackend(object):
         B = len(u)
         rows3 = np.zeros((3, B, self.d), np.float32)
         P, Q = shard.P.numpy(), shard.Q.numpy()
-        for role, idx, tab, lo, hi in ((0, u, P, shard.u_lo, shard.u_hi), (1, i, Q, shard.i_lo, shard.i_hi),
-                                       (2, j, Q, shard.i_lo, shard.i_hi)):
-            idx = idx.numpy()
-            own = (idx >= lo) & (idx < hi)
-            rows3[role, own] = tab[idx[own] - lo]
+        for role, idx, tab, owner in ((0, u, P, shard.own_u), (1, i, Q, shard.own_i), (2, j, Q, shard.own_i)):
+            own, loc = owner.local_of(idx.long())
+            own, loc = own.numpy(), loc.numpy()
+            rows3[role, own] = tab[loc[own]]
         return torch.from_numpy(rows3)
 
     def forward_and_bxb(self, shard, rows3, rank, world):
@@ -60,23 +78,27 @@ class OracleBackend(object):
         self.stage = (deu, dei, dej)
         self.gw = np.stack([res["dw"], res["dwu"]])
         losses = torch.tensor([res["mf"] + reg, res["mf"], reg], dtype=torch.float32)
+        if self.kind == o.LOSS_NORMALBCE:
+            return losses, None                       # no branch vectors: nothing to broadcast
         return losses, torch.from_numpy(self.gw)
 
     def apply(self, shard, u, i, j):
         o = self.o
         lr_t = o.lib().orc_adam_lr_t(self.lr, self.power)
         gP, gQ = np.zeros_like(shard.P.numpy()), np.zeros_like(shard.Q.numpy())
-        for grad, idx, g, lo, hi in ((self.stage[0], u, gP, shard.u_lo, shard.u_hi), (self.stage[1], i, gQ, shard.i_lo, shard.i_hi),
-                                     (self.stage[2], j, gQ, shard.i_lo, shard.i_hi)):
-            idx = idx.numpy()
-            for t in range(len(idx)):                 # batch order, like orc_scatter_add_rows
-                if lo <= idx[t] < hi:
-                    g[idx[t] - lo] += grad[t]
+        for grad, idx, g, owner in ((self.stage[0], u, gP, shard.own_u), (self.stage[1], i, gQ, shard.own_i),
+                                    (self.stage[2], j, gQ, shard.own_i)):
+            own, loc = owner.local_of(idx.long())
+            own, loc = own.numpy(), loc.numpy()
+            for t in range(len(loc)):                 # batch order, like orc_scatter_add_rows
+                if own[t]:
+                    g[loc[t]] += grad[t]
         adam = lambda th, m, v, gr: o.lib().orc_adam_dense(th.numpy(), m.numpy(), v.numpy(), _vp(np.ascontiguousarray(gr)),
                                                            th.numel(), lr_t, 0.9, 0.999, 1e-8)
         adam(shard.P, shard.mP, shard.vP, gP)
         adam(shard.Q, shard.mQ, shard.vQ, gQ)
-        adam(shard.w, shard.mw, shard.vw, self.gw[0])
+        if self.kind != o.LOSS_NORMALBCE:
+            adam(shard.w, shard.mw, shard.vw, self.gw[0])
         if self.kind == o.LOSS_RUBIBCEBOTH:
             adam(shard.wu, shard.mwu, shard.vwu, self.gw[1])
         self.power *= np.asarray([0.9, 0.999], np.float32)
@@ -100,16 +122,16 @@ def _problem():
 HYP = dict(lr=1e-3, decay=1e-5, alpha=1e-2, beta=1e-3, bs=64)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, kind_name="rubibceboth", layout="interleaved"):
     import oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         P, Q, w, wu, batches = _problem()
-        kind = oracle.LOSS_RUBIBCEBOTH
+        kind = {"rubibceboth": oracle.LOSS_RUBIBCEBOTH, "rubibce": oracle.LOSS_RUBIBCE, "normalbce": oracle.LOSS_NORMALBCE}[kind_name]
         model = sharded_train.RowShardedMF(torch.from_numpy(P), torch.from_numpy(Q), torch.from_numpy(w), torch.from_numpy(wu),
-                                           OracleBackend(kind, P.shape[1], **HYP))
+                                           OracleBackend(kind, P.shape[1], **HYP), layout=layout)
         Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
         st = oracle.AdamState([P.shape, Q.shape, w.shape, wu.shape])
         ok = True
@@ -121,20 +143,33 @@ def _worker(rank, world, port, q):
         Pf, Qf = model.full_tables()
         ok = ok and np.array_equal(Pf.numpy(), Po) and np.array_equal(Qf.numpy(), Qo)
         ok = ok and np.array_equal(model.w.numpy(), wo) and np.array_equal(model.wu.numpy(), wuo)
-        ok = ok and model.P.shape[0] == sharded_train.row_range(P.shape[0], rank, world)[1] - sharded_train.row_range(P.shape[0], rank, world)[0]
+        ok = ok and model.P.shape[0] == sharded_train.Owned(P.shape[0], rank, world, layout).n
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
 
 
-def test_row_sharded_training_gloo_world2():
+def _run_world(world, kind_name, layout):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind_name, layout)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=60) for _ in procs)
+    res = sorted(q.get(timeout=90) for _ in procs)
     for p in procs:
         p.join(60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_row_sharded_training_gloo_world2():
+    _run_world(2, "rubibceboth", "interleaved")
+
+
+def test_row_sharded_training_gloo_world3_uneven_shards_normalbce():
+    """three ranks (301 and 77 rows: shards of unequal size), the loss without a (B,B) term: one collective per step"""
+    _run_world(3, "normalbce", "interleaved")
+
+
+def test_row_sharded_training_gloo_world3_ranges_rubibce():
+    _run_world(3, "rubibce", "range")
