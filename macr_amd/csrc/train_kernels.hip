@@ -160,17 +160,28 @@ __device__ __forceinline__ void adam_block(const AdamArgs &a, long long blk, flo
         gr[it] = make_float4(0, 0, 0, 0);
         if (INDEXED && (flag[it] >> kRefShift)) {
             const int len = flag[it] >> kRefShift;
-            const uint32_t *sv = sg.sv + (flag[it] & (int)(kRefMaxRefs - 1));
+            const uint32_t pos = (uint32_t)(flag[it] & (int)(kRefMaxRefs - 1));
             const float *src = sg.stage + 4 * (vi[it] & (a.lpr - 1));
             const size_t d = (size_t)4 * a.lpr;
             float4 acc = make_float4(0, 0, 0, 0);
             int k = 0;
-            for (; k + 4 <= len; k += 4) {
-                const uint32_t r0 = sv[k], r1 = sv[k + 1], r2 = sv[k + 2], r3 = sv[k + 3];
-                const float4 x0 = ld4(src + r0 * d), x1 = ld4(src + r1 * d), x2 = ld4(src + r2 * d), x3 = ld4(src + r3 * d);
-                acc = add4(add4(add4(add4(acc, x0), x1), x2), x3);
+            if (sg.sv) {                                         // staging rows in batch order: the list names them
+                const uint32_t *sv = sg.sv + pos;
+                for (; k + 4 <= len; k += 4) {
+                    const uint32_t r0 = sv[k], r1 = sv[k + 1], r2 = sv[k + 2], r3 = sv[k + 3];
+                    const float4 x0 = ld4(src + r0 * d), x1 = ld4(src + r1 * d), x2 = ld4(src + r2 * d), x3 = ld4(src + r3 * d);
+                    acc = add4(add4(add4(add4(acc, x0), x1), x2), x3);
+                }
+                for (; k < len; ++k) acc = add4(acc, ld4(src + sv[k] * d));
+            } else {                                             // staging rows in LIST order: `len` consecutive rows from `pos`
+                const float *run = src + (size_t)pos * d;
+                for (; k + 4 <= len; k += 4) {
+                    const float4 x0 = ld4(run + (size_t)k * d), x1 = ld4(run + (size_t)(k + 1) * d);
+                    const float4 x2 = ld4(run + (size_t)(k + 2) * d), x3 = ld4(run + (size_t)(k + 3) * d);
+                    acc = add4(add4(add4(add4(acc, x0), x1), x2), x3);
+                }
+                for (; k < len; ++k) acc = add4(acc, ld4(run + (size_t)k * d));
             }
-            for (; k < len; ++k) acc = add4(acc, ld4(src + sv[k] * d));
             gr[it] = acc;
             if ((vi[it] & (a.lpr - 1)) == 0) sg.touched[vi[it] >> a.lpr_shift] = 0;
         } else if (flag[it]) {               // implies vi < n_vec
@@ -840,7 +851,7 @@ __global__ __launch_bounds__(256) void k_pair_normal_stage(
     int B, const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
     const float *__restrict__ Usrc, const float *__restrict__ Isrc, float *__restrict__ stage,
     float *__restrict__ part, float coef, int reg_on_gathered, const float *__restrict__ adam_pow_in,
-    float *adam_pow_out, StepScalars *scal, float lr, float b1, float b2) {
+    float *adam_pow_out, StepScalars *scal, float lr, float b1, float b2, const uint32_t *__restrict__ place = nullptr) {
     constexpr int d = 4 * LPR, RPB = RowGroup<LPR>::kRowsPerBlock;
     __shared__ float red[16];
     RowGroup<LPR> g;
@@ -864,9 +875,13 @@ __global__ __launch_bounds__(256) void k_pair_normal_stage(
         const float sp = sigmoid_acc(p), sn = sigmoid_acc(n);
         if (g.sub == 0) bce += -logf(sp + eps) + -logf((1.0f - sn) + eps);
         const float dp = dneglog_sig(sp, eps) * invB, dn = dneglog_1msig(sn, eps) * invB;
-        st4(stage + ((size_t)t) * d + 4 * g.sub, fma4(coef, eu, fma4(dn, ej, scale4(dp, ei))));
-        st4(stage + ((size_t)B + t) * d + 4 * g.sub, fma4(coef, ei, scale4(dp, eu)));
-        st4(stage + (2 * (size_t)B + t) * d + 4 * g.sub, fma4(coef, ej, scale4(dn, eu)));
+        // place (may be NULL): where reference (role, t) stands in the list sorted by row -- its gradient row goes THERE,
+        // so that a row's references are consecutive staging rows for whoever sums them
+        const size_t o0 = place ? place[t] : (size_t)t, o1 = place ? place[(size_t)B + t] : (size_t)B + t;
+        const size_t o2 = place ? place[2 * (size_t)B + t] : 2 * (size_t)B + t;
+        st4(stage + o0 * d + 4 * g.sub, fma4(coef, eu, fma4(dn, ej, scale4(dp, ei))));
+        st4(stage + o1 * d + 4 * g.sub, fma4(coef, ei, scale4(dp, eu)));
+        st4(stage + o2 * d + 4 * g.sub, fma4(coef, ej, scale4(dn, eu)));
     }
     const float s0 = block_sum(sq, red);
     const float s3 = block_sum(bce, red);
@@ -884,7 +899,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
     const float *__restrict__ w, const float *__restrict__ wu, const float *__restrict__ fwd,
     const float *__restrict__ rowpart, const float *__restrict__ colpart, float *__restrict__ stage,
     float *__restrict__ wpart, float alpha, float beta, float coef, float *adam_pow, StepScalars *scal, float lr,
-    float b1, float b2, LossArgs L) {
+    float b1, float b2, LossArgs L, const uint32_t *__restrict__ place = nullptr) {
     constexpr int d = 4 * LPR, RPB = RowGroup<LPR>::kRowsPerBlock;
     __shared__ float4 s_w[2][256];
     const int nblk = gridDim.x - 1;
@@ -919,9 +934,11 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
         const float4 eu = ld4(Usrc + (size_t)ru * d + 4 * g.sub);
         const float4 ei = ld4(Isrc + (size_t)ri * d + 4 * g.sub);
         const float4 ej = ld4(Isrc + (size_t)rj * d + 4 * g.sub);
-        st4(stage + ((size_t)t) * d + 4 * g.sub, fma4(coef, eu, fma4(dsu, wu4, fma4(dn, ej, scale4(dp, ei)))));
-        st4(stage + ((size_t)B + t) * d + 4 * g.sub, fma4(coef, ei, fma4(dsi, w4, scale4(dp, eu))));
-        st4(stage + (2 * (size_t)B + t) * d + 4 * g.sub, fma4(coef, ej, fma4(dsj, w4, scale4(dn, eu))));
+        const size_t o0 = place ? place[t] : (size_t)t, o1 = place ? place[(size_t)B + t] : (size_t)B + t;
+        const size_t o2 = place ? place[2 * (size_t)B + t] : 2 * (size_t)B + t;       // (see k_pair_normal_stage)
+        st4(stage + o0 * d + 4 * g.sub, fma4(coef, eu, fma4(dsu, wu4, fma4(dn, ej, scale4(dp, ei)))));
+        st4(stage + o1 * d + 4 * g.sub, fma4(coef, ei, fma4(dsi, w4, scale4(dp, eu))));
+        st4(stage + o2 * d + 4 * g.sub, fma4(coef, ej, fma4(dsj, w4, scale4(dn, eu))));
         aw = fma4(dsi, ei, fma4(dsj, ej, aw));
         awu = fma4(dsu, eu, awu);
     }
@@ -1057,13 +1074,14 @@ __global__ __launch_bounds__(256) void k_seg_sum(const uint32_t *__restrict__ wo
         const float *src = stage + 4 * sub;
         float4 acc = make_float4(0, 0, 0, 0);
         uint32_t k = grp;
+        auto row_of = [&](uint32_t q) { return sv ? sv[q] : q; };       // (sv == NULL: the staging rows are in list order)
         for (; k + 3 * G < len; k += 4 * G) {
-            const uint32_t r0 = sv[p + k], r1 = sv[p + k + G], r2 = sv[p + k + 2 * G], r3 = sv[p + k + 3 * G];
+            const uint32_t r0 = row_of(p + k), r1 = row_of(p + k + G), r2 = row_of(p + k + 2 * G), r3 = row_of(p + k + 3 * G);
             const float4 x0 = ld4(src + (size_t)r0 * d), x1 = ld4(src + (size_t)r1 * d);
             const float4 x2 = ld4(src + (size_t)r2 * d), x3 = ld4(src + (size_t)r3 * d);
             acc = add4(add4(add4(add4(acc, x0), x1), x2), x3);
         }
-        for (; k < len; k += G) acc = add4(acc, ld4(src + (size_t)sv[p + k] * d));
+        for (; k < len; k += G) acc = add4(acc, ld4(src + (size_t)row_of(p + k) * d));
 #pragma unroll
         for (int m = LPR; m < kWave; m <<= 1) {
             acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
@@ -1292,25 +1310,44 @@ static BatchSort batch_sort_args(const PairWs &ws, int B, const int32_t *u, cons
 // staged path: sort the 3B references by row, then one owner per row sums its staging rows into gU/gI
 // sv_sorted != NULL: INDEX mode -- rows whose references lie in one chunk get a flag naming them instead of a sum
 // (*sv_sorted = the sorted list's values, for the indexed Adam pass that must follow)
+struct RefSort { const uint32_t *sk, *sv; uint32_t *free_key, *free_val; };
+static RefSort launch_ref_sort(int B, int n_urows, int n_irows, const int32_t *u, const int32_t *i, const int32_t *j,
+                               const PairWs &ws, hipStream_t st) {
+    const int n = 3 * B;
+    k_refs_init<<<(B + 255) / 256 < 2048 ? (B + 255) / 256 : 2048, 256, 0, st>>>(B, n_urows, u, i, j, ws.ska, ws.sva, ws.n_work);
+    const int flip = launch_radix_sort(ws.ska, ws.sva, ws.skb, ws.svb, n, (uint32_t)(n_urows + n_irows - 1), ws.ghist, st);
+    RefSort r;
+    r.sk = flip ? ws.skb : ws.ska; r.sv = flip ? ws.svb : ws.sva;
+    r.free_key = flip ? ws.ska : ws.skb; r.free_val = flip ? ws.sva : ws.svb;     // the buffers the sort no longer needs
+    return r;
+}
+// place[reference] = its position in the sorted list (the inverse of the list's values)
+__global__ __launch_bounds__(256) void k_ref_place(int n, const uint32_t *__restrict__ sv, uint32_t *__restrict__ place) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) place[sv[p]] = (uint32_t)p;
+}
+// INDEX mode behind a sort: flags that name each row's run, the long runs summed into gU/gI.  listed: the staging rows
+// are in list order (sv not needed to find them)
+static int launch_seg_index(int B, int d, int n_urows, int n_irows, const RefSort &r, bool listed, float *gU, float *gI,
+                            int32_t *tU, int32_t *tI, const PairWs &ws, hipStream_t st) {
+    const int n = 3 * B;
+    k_seg_scan<<<(n + 255) / 256, 256, 0, st>>>(n, n_urows, (uint32_t)(n_urows + n_irows), r.sk, tU, tI, r.free_key, ws.n_work);
+    MACR_CHECK_LAUNCH("seg_index", st);
+    MACR_DISPATCH_LPR(d, (k_seg_sum<LPR><<<1024, 256, 0, st>>>(r.free_key, ws.n_work, n_urows, r.sk, listed ? nullptr : r.sv, ws.stage, gU, gI)));
+    MACR_CHECK_LAUNCH("seg_sum", st);
+    return MACR_OK;
+}
 static int launch_ref_sort_reduce(int B, int d, int n_urows, int n_irows, const int32_t *u, const int32_t *i,
                                   const int32_t *j, float *gU, float *gI, int32_t *tU, int32_t *tI, const PairWs &ws,
                                   hipStream_t st, const uint32_t **sv_sorted = nullptr) {
     const int n = 3 * B;
-    k_refs_init<<<(B + 255) / 256 < 2048 ? (B + 255) / 256 : 2048, 256, 0, st>>>(B, n_urows, u, i, j, ws.ska, ws.sva, ws.n_work);
-    const int flip = launch_radix_sort(ws.ska, ws.sva, ws.skb, ws.svb, n, (uint32_t)(n_urows + n_irows - 1), ws.ghist, st);
+    const RefSort r = launch_ref_sort(B, n_urows, n_irows, u, i, j, ws, st);
     MACR_CHECK_LAUNCH("ref_sort", st);
-    const uint32_t *sk = flip ? ws.skb : ws.ska, *sv = flip ? ws.svb : ws.sva;
     if (sv_sorted) {
-        *sv_sorted = sv;
-        uint32_t *work = flip ? ws.ska : ws.skb;                       // the buffer the sort no longer needs
-        k_seg_scan<<<(n + 255) / 256, 256, 0, st>>>(n, n_urows, (uint32_t)(n_urows + n_irows), sk, tU, tI, work, ws.n_work);
-        MACR_CHECK_LAUNCH("seg_index", st);
-        MACR_DISPATCH_LPR(d, (k_seg_sum<LPR><<<1024, 256, 0, st>>>(work, ws.n_work, n_urows, sk, sv, ws.stage, gU, gI)));
-        MACR_CHECK_LAUNCH("seg_sum", st);
-        return MACR_OK;
+        *sv_sorted = r.sv;
+        return launch_seg_index(B, d, n_urows, n_irows, r, false, gU, gI, tU, tI, ws, st);
     }
     MACR_DISPATCH_LPR(d, (k_seg_reduce<LPR><<<(n + 256 / LPR - 1) / (256 / LPR), 256, 0, st>>>(
-                             n, n_urows, (uint32_t)(n_urows + n_irows), sk, sv, ws.stage, gU, gI, tU, tI)));
+                             n, n_urows, (uint32_t)(n_urows + n_irows), r.sk, r.sv, ws.stage, gU, gI, tU, tI)));
     MACR_CHECK_LAUNCH("seg_reduce", st);
     return MACR_OK;
 }
@@ -1336,12 +1373,27 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
         MACR_CHECK_LAUNCH("pair_normal", st);
         return MACR_OK;
     }
+    // Large batch whose Adam pass follows at once (sv_sorted): the references are sorted FIRST -- the order depends on the
+    // indices only -- and every gradient row is staged at its reference's position in the sorted list, so that the pass
+    // reads a row's <= 16 staging rows as one run (805 MB of scattered 256-byte reads at B = 2^20 became sequential) and
+    // needs no list to find them.  MACR_STAGE_LISTED=0: staging in batch order, found through the list (before round 4).
+    static const bool listed_ok = !(getenv("MACR_STAGE_LISTED") && atoi(getenv("MACR_STAGE_LISTED")) == 0);
+    const bool listed = ws.staged && sv_sorted && listed_ok && !loss_only;
+    RefSort rs = {};
+    if (listed) {
+        rs = launch_ref_sort(B, n_urows, n_irows, u, i, j, ws, st);
+        MACR_CHECK_LAUNCH("ref_sort", st);
+        k_ref_place<<<(3 * B + 255) / 256 < 4096 ? (3 * B + 255) / 256 : 4096, 256, 0, st>>>(3 * B, rs.sv, rs.free_val);
+        MACR_CHECK_LAUNCH("ref_place", st);
+        *sv_sorted = nullptr;                                    // (the indexed pass finds the rows by position)
+    }
     if (kind == MACR_LOSS_NORMALBCE) {
         if (ws.staged) {
             MACR_DISPATCH_LPR(d, (k_pair_normal_stage<LPR><<<ws.nblk_bwd, 256, 0, st>>>(
                                      B, u, i, j, Usrc, Isrc, ws.stage, ws.part, coef, reg_on_gathered, adam_pow, adam_pow,
-                                     ws.scal, hp->lr, hp->beta1, hp->beta2)));
+                                     ws.scal, hp->lr, hp->beta1, hp->beta2, listed ? rs.free_val : nullptr)));
             MACR_CHECK_LAUNCH("pair_normal", st);
+            if (listed) return launch_seg_index(B, d, n_urows, n_irows, rs, true, gU, gI, tU, tI, ws, st);
             return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st, sv_sorted);
         }
         k_batch_sort<<<(B + kBucketSpan - 1) / kBucketSpan, 256, 0, st>>>(sort);
@@ -1373,8 +1425,10 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
     if (ws.staged) {
         MACR_DISPATCH_LPR(d, (k_pair_bwd_stage<LPR><<<ws.nblk_bwd + 1, 256, 0, st>>>(
                                  B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, ws.stage,
-                                 ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal, hp->lr, hp->beta1, hp->beta2, L)));
+                                 ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal, hp->lr, hp->beta1, hp->beta2, L,
+                                 listed ? rs.free_val : nullptr)));
         MACR_CHECK_LAUNCH("pair_bwd", st);
+        if (listed) return launch_seg_index(B, d, n_urows, n_irows, rs, true, gU, gI, tU, tI, ws, st);
         return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st, sv_sorted);
     }
     MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd + 1, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, ws.perm, ws.us, ws.is, ws.js,
