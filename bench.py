@@ -169,11 +169,12 @@ def bench_config4(args, rank, world, dev):
     kern = {n_: {"launches_per_step": c_ / n_prof, "event_us": 1e3 * t / c_} for n_, (c_, t) in ku.items()}
     rows_local = own_u.n + own_i.n
     adam_bytes = 24.0 * d * rows_local
-    adam_us = kern.get("adam_dense", {}).get("event_us")
+    adam_name = "adam_indexed" if "adam_indexed" in kern else "adam_dense"    # (indexed: the pass sums the staged gradient rows itself)
+    adam_us = kern.get(adam_name, {}).get("event_us")
     roofline = None
     if adam_us:
         gbps = adam_bytes / (adam_us * 1e-6) / 1e9
-        roofline = {"kernel": "adam_dense", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"kernel": adam_name, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbps / HBM_PEAK_GBS, "traffic": None, "avg_us": adam_us, "algorithmic_bytes": adam_bytes,
                     "note": "TF-style dense Adam over this rank's %d rows (24*d bytes per row and step); event-timed, "
                             "includes ~3 us of event overhead" % rows_local}
