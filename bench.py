@@ -488,8 +488,7 @@ def main():
                 ret = run_eval()
                 torch.cuda.synchronize(); barrier()
                 ev_elapsed += sharding.max_over_ranks(time.perf_counter() - t0, dev)
-                st_ = ev._stats.tolist()
-                ev_modes.append({"seeded": bool(ev._last_seeded), "query_blocks_relisted": st_[0], "exact_fallback": st_[1]})
+                ev_modes.append(ev.last_eval_info())
             eval_users_per_s = len(users) * args.eval_reps / ev_elapsed
             # the same evaluation without seeds (what a first evaluation costs: sampling pass + k_tau instead of k_tau_seed),
             # also a graph replay
@@ -512,7 +511,7 @@ def main():
             ops.timing_begin()
             run_eval()
             smarks = ops.timing_end()
-            seeded_run = {"seeded": bool(ev._last_seeded), "query_blocks_relisted": ev._stats.tolist()[0],
+            seeded_run = {"seeded": ev.last_eval_info()["seeded"], "query_blocks_relisted": ev.last_eval_info()["query_blocks_relisted"],
                           "kernels_us": {}}
             for name, ms in smarks:
                 seeded_run["kernels_us"][name] = seeded_run["kernels_us"].get(name, 0.0) + 1e3 * max(ms - 1e-3 * event_overhead_us, 0.0)

@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     8
+#define MACR_ABI_VERSION     9
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -385,6 +385,20 @@ int macr_score_topk(int score_kind, int U, int n_local, int d,
                     float *out_val, int32_t *out_idx, int32_t *stats,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* The FIRST ROUND of macr_score_topk alone, for a caller that reads results back after every ranking anyway (each test()
+ * of macr_mf/train.py:162-311 / utility/batch_test.py:26-162 returns metrics to the host): same arguments, but neither the
+ * repair round nor the exact fallback kernel is launched -- in the common case those five launches find nothing to do.
+ * stats (required; device memory or device-visible host memory) receives {query blocks whose candidate lists overflowed
+ * or whose seeds were stale, 0}.  stats[0] == 0: out_val / out_idx / seed_out are exactly what macr_score_topk returns.
+ * Otherwise they are not the ranking and the caller runs macr_score_topk (without seed_idx) on the same inputs. */
+int macr_score_topk_first_round(int score_kind, int U, int n_local, int d,
+                    const float *users_tab, const int32_t *user_ids, const float *items,
+                    const float *sig_u, const float *sig_i, float c, const float *c_dev,
+                    const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
+                    int item_offset, int K, int n_splits, const int32_t *seed_idx, int32_t *seed_out,
+                    float *out_val, int32_t *out_idx, int32_t *stats,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------
  * The same ranking for SEVERAL values of c at once -- the c sweep of the tuners
  * (macr_mf/tune.py:545-578, macr_lightgcn/LightGCN_tune.py:852-870: test() once per
@@ -481,7 +495,9 @@ int macr_metrics_foldout(int U, int K, const int32_t *rankings,
 
 /* MF metrics (macr_mf/train.py:32-117, float64 like NumPy): out (dev) f64
  * [U*4*nK] = per query {precision, recall, ndcg, hit_ratio} x Ks.  cnt (dev,
- * may be NULL) int32[U] = length of each ranked list. */
+ * may be NULL) int32[U] = length of each ranked list; NULL: a list's length is its
+ * number of ids >= 0 (unused slots hold -1: what macr_topk_merge reports as its count),
+ * so the one sorted list per query that macr_score_topk leaves needs no merge first. */
 int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const int32_t *cnt,
                     const int32_t *gt_ptr, const int32_t *gt_idx,
                     const int32_t *Ks /*host*/, int nK, double *out, void *stream);
@@ -489,7 +505,7 @@ int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const int32_t *cnt
 /* Column means of a (rows, cols) matrix in float64 (deterministic tree):
  * the "/ n_test_users" accumulation of macr_mf/train.py:286-290 and the
  * np.mean(all_result, axis=0) of batch_test.py:151.  in_is_f32 selects input
- * type; out (dev) f64[cols]. */
+ * type; out f64[cols]: device memory or device-visible (pinned) host memory. */
 int macr_colmean(const void *in, int in_is_f32, int rows, int cols, double *out, void *stream);
 
 #ifdef __cplusplus

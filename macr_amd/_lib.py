@@ -17,7 +17,7 @@ SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINU
 MAX_TOPK = 128
 MAX_TOPK_FUSED = 32
 MAX_SWEEP = 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MacrError(RuntimeError):
@@ -65,6 +65,7 @@ SIGNATURES = {
     "macr_set_eval_filter": (_i, [_i]),
     "macr_score_topk_workspace_bytes": (_z, [_i, _i, _i]),
     "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "macr_score_topk_first_round": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "macr_score_topk_sweep_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "macr_score_topk_sweep": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _z, _p]),
     "macr_test_bf16_products_workspace_bytes": (_z, [_i, _i, _i]),

@@ -2166,7 +2166,8 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local,
 __global__ __launch_bounds__(kUsersPerBlock) void k_repair_plan(int U, int K, int n_slots, const int32_t *__restrict__ user_ovf,
                                                                 const float *__restrict__ out_val, float *__restrict__ tau,
                                                                 int32_t *__restrict__ counts, int32_t *__restrict__ ub_map,
-                                                                int32_t *__restrict__ blk_flag, int32_t *n_ub, int32_t *n_done) {
+                                                                int32_t *__restrict__ blk_flag, int32_t *n_ub, int32_t *n_done,
+                                                                int32_t *stats) {
     const int ub = blockIdx.x, q = ub * kUsersPerBlock + threadIdx.x;
     const bool stopped = blk_flag[ub] != 0;               // the listing pass gave up on this user block (stale seeds)
     const bool f = q < U && (user_ovf[q] != 0 || stopped);
@@ -2186,6 +2187,8 @@ __global__ __launch_bounds__(kUsersPerBlock) void k_repair_plan(int U, int K, in
     __syncthreads();
     if (!s_last) return;
     const int n = __hip_atomic_load(n_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (macr_score_topk_first_round: the caller learns here whether this round's result stands)
+    if (stats && threadIdx.x == 0) { stats[0] = n; stats[1] = 0; }
     if (n == 0) return;
     const RepairLayout rl = repair_layout(n_slots, U, n);
     if (!rl.compact) return;
@@ -2560,16 +2563,19 @@ __global__ __launch_bounds__(256) void k_metrics_mf(int U, int Kmax, const int32
     if (u >= U) return;
     const int32_t *truth = gt_idx + gt_ptr[u];
     const int truth_len = gt_ptr[u + 1] - gt_ptr[u];
-    const int len = cnt ? cnt[u] : Kmax;
     // lane l owns rank positions l and 64 + l (Kmax <= 128)
     bool hit[2]; double term[2];
+    int n_valid = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int pos = lane + 64 * h;
         const int item = pos < Kmax ? rankings[(size_t)u * Kmax + pos] : -1;
+        n_valid += __popcll(__ballot(item >= 0));
         hit[h] = item >= 0 && in_sorted(truth, truth_len, item);
         term[h] = 1.0 / log2((double)(pos + 2));                  // DCG discount of position `pos`
     }
+    // cnt == NULL: a list's length is its number of ids >= 0 -- what macr_topk_merge reports for it
+    const int len = cnt ? cnt[u] : n_valid;
     for (int qk = 0; qk < Ks.n; ++qk) {
         const int K = Ks.k[qk];
         const int m = len < K ? len : K;
@@ -2696,6 +2702,9 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g, 
 }
 }  // namespace macr
 
+// (tools/listing_bench.hip includes this file for its kernel templates and launch geometry alone: seconds to compile
+// instead of minutes)
+#ifndef MACR_EVAL_KERNELS_ONLY
 extern "C" size_t macr_score_topk_workspace_bytes(int U, int n_local, int d) {
     if (U <= 0 || n_local <= 0 || !dim_supported(d)) return 0;
     return carve_topk_ws(nullptr, U, n_local, stream_geo(U, n_local, d), d).bytes;
@@ -2779,13 +2788,14 @@ static void launch_k_tau(int tau_regs, int blocks, hipStream_t st, int U, int sl
 
 static inline bool score_kind_valid(int k) { return k >= MACR_SCORE_NORMAL && k <= MACR_SCORE_DIRECT_MINUS_BOTH; }
 
-extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const float *users_tab,
-                               const int32_t *user_ids, const float *items, const float *sig_u,
-                               const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
-                               const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, const int32_t *seed_idx,
-                               int32_t *seed_out, float *out_val, int32_t *out_idx, int32_t *stats, void *workspace,
-                               size_t workspace_bytes,
-                               void *stream) {
+// first_only (macr_score_topk_first_round): the first round alone -- no repair round, no fallback kernel; stats tell
+// whether its result stands.
+static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, int d, const float *users_tab,
+                           const int32_t *user_ids, const float *items, const float *sig_u,
+                           const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
+                           const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, const int32_t *seed_idx,
+                           int32_t *seed_out, float *out_val, int32_t *out_idx, int32_t *stats, void *workspace,
+                           size_t workspace_bytes, void *stream) {
     // MACR_TOPK_FALLBACK=1 in the environment runs the fallback kernel unconditionally (tests of that path)
     static const bool force_fallback = getenv("MACR_TOPK_FALLBACK") && getenv("MACR_TOPK_FALLBACK")[0] == '1';
     MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "score_topk: score_kind=%d", score_kind);
@@ -2950,9 +2960,12 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
         }
         if (repair) {
             k_repair_plan<<<geo.ublocks, kUsersPerBlock, 0, st>>>(U, K, geo.slots1, ws.user_ovf, out_val, ws.tau, ws.counts,
-                                                                 ws.ub_map, ws.blk_flag, ws.overflow + 1, ws.overflow + 2);
+                                                                 ws.ub_map, ws.blk_flag, ws.overflow + 1, ws.overflow + 2,
+                                                                 first_only ? stats : nullptr);
             MACR_CHECK_LAUNCH("repair_plan", st);
-            if (filter_bf16) {
+            if (first_only) {
+                // (stats[0] = query blocks whose lists overflowed or whose seeds were stale: their rows of out_* are not the ranking)
+            } else if (filter_bf16) {
                 // the repair round on the bf16 copies too: sampling pass for the re-listed user blocks when the thresholds
                 // came from seeds, listing, selection with fp32 re-scoring
                 auto pass0rb = k_score_sample_b<D, KIND, true>;
@@ -2997,6 +3010,12 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
             }
         }
     });
+    if (first_only && !list_all) return MACR_OK;
+    if (first_only) {
+        // a shard small enough to list everything cannot overflow a list: the first round is the ranking
+        fill_words(stats, 2, 0u, st);
+        return MACR_OK;
+    }
     // Fallback, armed by the overflow flag on the device (its blocks return at once otherwise): the running
     // top-K kernel is exact for any score order.
     const size_t smem_old = score_topk_smem_bytes();
@@ -3012,6 +3031,30 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
     });
     MACR_CHECK_LAUNCH("score_topk", st);
     return MACR_OK;
+}
+
+extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const float *users_tab,
+                               const int32_t *user_ids, const float *items, const float *sig_u,
+                               const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
+                               const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, const int32_t *seed_idx,
+                               int32_t *seed_out, float *out_val, int32_t *out_idx, int32_t *stats, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    return score_topk_impl(false, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
+                           mask_bits_in, item_offset, K, n_splits, seed_idx, seed_out, out_val, out_idx, stats, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" int macr_score_topk_first_round(int score_kind, int U, int n_local, int d, const float *users_tab,
+                                           const int32_t *user_ids, const float *items, const float *sig_u,
+                                           const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr,
+                                           const int32_t *mask_idx, const uint32_t *mask_bits_in, int item_offset, int K,
+                                           int n_splits, const int32_t *seed_idx, int32_t *seed_out, float *out_val,
+                                           int32_t *out_idx, int32_t *stats, void *workspace, size_t workspace_bytes,
+                                           void *stream) {
+    MACR_REQUIRE(stats, MACR_E_INVALID, "score_topk_first_round: stats is null (it says whether the result stands)");
+    return score_topk_impl(true, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
+                           mask_bits_in, item_offset, K, n_splits, seed_idx, seed_out, out_val, out_idx, stats, workspace,
+                           workspace_bytes, stream);
 }
 
 /* ---- c sweep -------------------------------------------------------------------------------------------------- */
@@ -3260,3 +3303,4 @@ extern "C" int macr_colmean(const void *in, int in_is_f32, int rows, int cols, d
     MACR_CHECK_LAUNCH("colmean", st);
     return MACR_OK;
 }
+#endif  // MACR_EVAL_KERNELS_ONLY

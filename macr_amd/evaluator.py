@@ -38,6 +38,15 @@ class Evaluator(object):
         # is the fp32 ranking bit for bit either way; MACR_EVAL_FILTER in the environment overrides the default.
         self.filter = os.environ.get("MACR_EVAL_FILTER", "bf16").strip().lower()
         ops.eval_filter_code(self.filter)         # a typo in the environment is refused here, by name
+        # One GPU, graph replays: an evaluation launches the FIRST ROUND of the ranking only and writes its means and the
+        # ranking's stats straight into pinned host memory; the host, which waits for the means anyway, sees whether a
+        # candidate list overflowed or the seeds were stale and, in that rare case, runs the complete sequence (repair
+        # round, fallback) from a sampled start.  Saves the launches that find nothing to do (~25 us of a 0.45 ms
+        # evaluation on the Gowalla shape) and both result copies.  MACR_EVAL_OPTIMISTIC=0: the complete sequence always.
+        self.optimistic = os.environ.get("MACR_EVAL_OPTIMISTIC", "1") != "0"
+        self._first_round_now = False
+        self._host_out = {}
+        self.fast_stats = {"fast": 0, "redone": 0}
         self._graphs = {}
         self._graph_misses = 0
         # seeding policy: thresholds come from the previous ranking unless that went badly last time
@@ -45,8 +54,10 @@ class Evaluator(object):
         self._seed_skip, self._seed_backoff = 0, 1
         self._stats = torch.zeros(2, dtype=torch.int32, device=device)          # macr_score_topk stats of the last ranking
         self._stats_host = torch.zeros(2, dtype=torch.int32)
+        self._stats_first = torch.zeros(2, dtype=torch.int32)          # written by the first-round ranking's own kernel
         if device.type == "cuda":
             self._stats_host = self._stats_host.pin_memory()
+            self._stats_first = self._stats_first.pin_memory()
         self._stats_evt = None
         self._last_seeded = False
         self.gt = ops.CSR.from_lists(gt_lists, device)
@@ -114,8 +125,10 @@ class Evaluator(object):
                 seed = seeds[(K, lo, hi)] = torch.full((U, ops.SEED_WIDTH), -1, dtype=torch.int32, device=self.device)
             # the ranking leaves its best SEED_WIDTH candidates per query in `seed` (in place): the next ranking's seeds
             mask = self._mask_local if self._local_own is not None else self.mask
+            first = self._first_round_now
             vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, mask, lo,
-                                       seed=seed if seeded else None, seed_out=seed, stats=self._stats)
+                                       seed=seed if seeded else None, seed_out=seed,
+                                       stats=self._stats_first if first else self._stats, first_round=first)
         else:
             # the ranking workspace (candidate lists, mask bitmap) grows with the number of queries: rank them in
             # chunks; every query is independent of the chunking
@@ -209,13 +222,17 @@ class Evaluator(object):
         m = self._means("mf", kind, users_tab, user_ids, items_tab, tuple(Ks), w, wu, c).cpu().numpy()
         return {'precision': m[0].copy(), 'recall': m[1].copy(), 'ndcg': m[2].copy(), 'hit_ratio': m[3].copy()}
 
-    def _finish(self, flavour, vals, idx, Ks):
-        """(W,U,K) lists (splits of one shard, or the gathered shards) -> column means of the per-user metrics"""
+    def _finish(self, flavour, vals, idx, Ks, out=None):
+        """(W,U,K) lists (splits of one shard, or the gathered shards) -> column means of the per-user metrics.
+        out: optional pinned host tensor the last kernel writes the means to."""
         if flavour == "mf":
+            if vals.shape[0] == 1:
+                # one sorted list per query: nothing to merge (the metrics kernel counts a list's ids itself)
+                return ops.colmean(ops.metrics_mf(idx[0], None, self.gt, list(Ks)), out=out)
             _, ix, cnt = ops.topk_merge(vals, idx)
-            return ops.colmean(ops.metrics_mf(ix, cnt, self.gt, list(Ks)))                  # (U,4,nK) float64 -> (4,nK)
+            return ops.colmean(ops.metrics_mf(ix, cnt, self.gt, list(Ks)), out=out)         # (U,4,nK) float64 -> (4,nK)
         _, ix, _ = ops.topk_merge(vals, idx, self.mask)                                      # -inf fill, batch_test.py:124-134
-        return ops.colmean(ops.metrics_foldout(ix, self.gt, hr_in_ap_slot=True))            # (U,5*max_top) fp32
+        return ops.colmean(ops.metrics_foldout(ix, self.gt, hr_in_ap_slot=True), out=out)   # (U,5*max_top) fp32
 
     def _direct(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
         vals, idx = self.rank_local(kind, users_tab, user_ids, items_tab, max(Ks), w, wu, c)
@@ -245,6 +262,10 @@ class Evaluator(object):
         the sequence is two graphs around the one collective (all-gather of the shards' top-K)."""
         c = self._c_scalar(c)
         world = sharding.world()[1]
+        if (self.optimistic and self.use_graph and world == 1 and self.device.type == "cuda"
+                and self.n_queries <= self.max_queries_per_pass and max(Ks) <= _lib_consts.MAX_TOPK_FUSED):
+            return self._means_optimistic(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
+        self._last_info = None
         # (no seeds yet for this K and shard: the first ranking samples, and leaves them)
         seeded = self._seed_feedback() and self.n_queries <= self.max_queries_per_pass and self._has_seeds(max(Ks), items_tab.shape[0])
         self._seeded_now = seeded        # the warm-up run of a capture creates the seeds: the capture itself must not pick them up
@@ -253,10 +274,56 @@ class Evaluator(object):
         finally:
             self._stats_readback(seeded)
 
-    def _means_launch(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, world, seeded):
+    def _means_optimistic(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
+        """First round only, results in pinned host memory, the complete sequence when the first round says so."""
+        if self._stats_evt is not None:           # (a stats copy of the complete path still in flight: not needed any more)
+            self._stats_evt = None
+        seeded = (self.use_seeds and self._seed_skip == 0 and self._has_seeds(max(Ks), items_tab.shape[0]))
+        if self.use_seeds and self._seed_skip > 0:
+            self._seed_skip -= 1
+        self._seeded_now = seeded
+        self._first_round_now = True
+        try:
+            out = self._means_launch(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, 1, seeded, first=True)
+        finally:
+            self._first_round_now = False
+        torch.cuda.current_stream().synchronize()
+        self._last_seeded = False                 # (nothing for _seed_feedback to read later)
+        self._last_info = {"seeded": bool(seeded), "query_blocks_relisted": int(self._stats_first[0]), "exact_fallback": 0,
+                           "redone": int(self._stats_first[0]) != 0}
+        if int(self._stats_first[0]) == 0 and int(self._stats_first[1]) == 0:
+            self.fast_stats["fast"] += 1
+            if seeded:
+                self._seed_backoff = 1
+            return out.clone()
+        # a list overflowed or seeds were stale: the complete sequence, thresholds from a sampling pass
+        self.fast_stats["redone"] += 1
+        if seeded:
+            self._seed_skip = self._seed_backoff
+            self._seed_backoff = min(16, 2 * self._seed_backoff)
+        self._seeded_now = False
+        return self._means_launch(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, 1, False)
+
+    def last_eval_info(self):
+        """What the last evaluation did: {"seeded": its thresholds came from the previous ranking's candidates,
+        "query_blocks_relisted": blocks of 256 queries whose lists overflowed / whose seeds were stale, "exact_fallback",
+        "redone": the first round did not stand and the complete sequence ran (optimistic mode)}.  Synchronises."""
+        if getattr(self, "_last_info", None) is not None:
+            return dict(self._last_info)
+        st = self._stats.tolist()
+        return {"seeded": bool(self._last_seeded), "query_blocks_relisted": st[0], "exact_fallback": st[1], "redone": False}
+
+    def _means_launch(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, world, seeded, first=False):
         if not self.use_graph:
             return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
-        key = (flavour, self.filter, kind, seeded, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
+        host_out = None
+        if first:
+            hk = (flavour, Ks)
+            if hk not in self._host_out:
+                shape = (4, len(Ks)) if flavour == "mf" else (5 * max(Ks),)
+                self._host_out[hk] = torch.zeros(shape, dtype=torch.float64).pin_memory()
+            host_out = self._host_out[hk]
+        key = (flavour, first, self.filter, kind, seeded, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
                Ks, None if w is None else w.data_ptr(), None if wu is None else wu.data_ptr(),
                torch.cuda.current_stream().cuda_stream, world)
         entry = self._graphs.get(key)
@@ -266,6 +333,8 @@ class Evaluator(object):
             if self._graph_misses > 12:
                 self.use_graph = False
                 self._graphs.clear()
+                self._first_round_now = False     # (the complete sequence: its result needs no check)
+                self._stats_first.zero_()
                 return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
             self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)     # warm-up: allocations, caches, attributes
             torch.cuda.synchronize()
@@ -274,7 +343,7 @@ class Evaluator(object):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     vals, idx = self.rank_local(kind, users_tab, user_ids, items_tab, K, w, wu, c)
-                    out = self._finish(flavour, vals, idx, Ks)
+                    out = self._finish(flavour, vals, idx, Ks, out=host_out)
                 stages = (g, None, None, None)
             else:
                 # several ranks: the collective stays outside -- one graph up to this shard's merged lists, the

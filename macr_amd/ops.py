@@ -39,6 +39,21 @@ def _ptr(t, dtype=None, allow_none=False):
 _f32, _i32, _f64 = torch.float32, torch.int32, torch.float64
 
 
+def _ptr_visible(t, dtype=None, allow_none=False):
+    """A buffer a kernel WRITES a few words of results to: a device tensor, or a PINNED host tensor -- pinned host memory
+    is mapped into the device's address space, the kernel's stores land in it directly and the host reads them after
+    synchronising with the stream (no copy launched)."""
+    if t is None or t.is_cuda:
+        return _ptr(t, dtype, allow_none)
+    if not t.is_pinned():
+        raise MacrError(_lib.E_INVALID, "macr_amd.ops: a host result buffer must be pinned (tensor.pin_memory())")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def _require_f32(**tensors):
     """the kernels read fp32 tables through raw pointers: any other dtype is refused here, not reinterpreted"""
     for name, t in tensors.items():
@@ -223,14 +238,16 @@ def _c_args(c):
 
 
 def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.0, mask=None,
-               item_offset=0, n_splits=0, seed=None, seed_out=None, stats=None):
+               item_offset=0, n_splits=0, seed=None, seed_out=None, stats=None, first_round=False):
     """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K).
     c: python float, or a 1-element fp32 device tensor (read at run time: graph replays follow its value).
     seed: optional (U, SEED_WIDTH) int32 device tensor of global item ids per query -- what seed_out received last time:
     thresholds then come from the seeds' exact scores instead of a sampling pass -- same result, less time.
     seed_out: optional (U, SEED_WIDTH) int32 device tensor <- the best candidates per query (may be `seed` itself).
-    stats: optional int32[2] device tensor <- (query blocks listed twice because a threshold was too loose, 1 if the
-    exact fallback kernel ran)."""
+    stats: optional int32[2] device (or pinned host) tensor <- (query blocks listed twice because a threshold was too
+    loose, 1 if the exact fallback kernel ran).
+    first_round: macr_score_topk_first_round -- the first round alone, without the launches of the repair round and the
+    fallback; stats (required) then says whether the result stands: stats[0] == 0, else run the complete call."""
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
     n_local, d = items.shape
     if n_splits <= 0:
@@ -242,10 +259,11 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     mb = _ptr(mask.mask_bits(U, n_local, item_offset)) if mask is not None else None
     ws = _topk_workspace(U, n_local, d, items.device)
     cv, cp = _c_args(c)
-    check(_lib.lib().macr_score_topk(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
-                                     _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
-                                     cv, cp, mp, mi, mb, item_offset, K, n_splits, _ptr(seed, _i32, True), _ptr(seed_out, _i32, True), _ptr(vals), _ptr(idx),
-                                     _ptr(stats, _i32, True), _ptr(ws), ws.numel(), _stream()))
+    fn = _lib.lib().macr_score_topk_first_round if first_round else _lib.lib().macr_score_topk
+    check(fn(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
+             _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
+             cv, cp, mp, mi, mb, item_offset, K, n_splits, _ptr(seed, _i32, True), _ptr(seed_out, _i32, True), _ptr(vals), _ptr(idx),
+             _ptr_visible(stats, _i32, True), _ptr(ws), ws.numel(), _stream()))
     return vals, idx
 
 
@@ -318,7 +336,8 @@ def metrics_foldout(rankings, gt, hr_in_ap_slot=False):
 
 
 def metrics_mf(rankings, cnt, gt, Ks):
-    """(U,Kmax) rankings -> (U,4,len(Ks)) float64 {precision, recall, ndcg, hit} (macr_mf/train.py:32-117)."""
+    """(U,Kmax) rankings -> (U,4,len(Ks)) float64 {precision, recall, ndcg, hit} (macr_mf/train.py:32-117).
+    cnt None: a list's length is its number of ids >= 0 (-1 = unused slot)."""
     U, Kmax = rankings.shape
     ks = (ctypes.c_int32 * len(Ks))(*[int(k) for k in Ks])
     out = torch.empty((U, 4, len(Ks)), dtype=_f64, device=rankings.device)
@@ -327,13 +346,15 @@ def metrics_mf(rankings, cnt, gt, Ks):
     return out
 
 
-def colmean(x):
+def colmean(x, out=None):
+    """out: optional float64 device or pinned host tensor of x.shape[1:]"""
     rows = x.shape[0]
     cols = x.numel() // rows
-    out = torch.empty(cols, dtype=_f64, device=x.device)
+    if out is None:
+        out = torch.empty(cols, dtype=_f64, device=x.device)
     if x.dtype not in (_f32, _f64):
         raise TypeError("colmean: fp32 or fp64")
-    check(_lib.lib().macr_colmean(_ptr(x), 1 if x.dtype == _f32 else 0, rows, cols, _ptr(out), _stream()))
+    check(_lib.lib().macr_colmean(_ptr(x), 1 if x.dtype == _f32 else 0, rows, cols, _ptr_visible(out, _f64), _stream()))
     return out.reshape(x.shape[1:])
 
 

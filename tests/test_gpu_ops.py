@@ -783,6 +783,71 @@ def test_metrics_match_oracle(ops):
     np.testing.assert_allclose(ops.colmean(dev(f)).cpu().numpy(), f.astype(np.float64).mean(0), rtol=1e-12, atol=1e-15)
 
 
+def test_metrics_mf_counts_a_lists_ids_and_colmean_writes_pinned_host_memory(ops):
+    """macr_metrics_mf without cnt: a list's length is its number of ids >= 0 (what macr_topk_merge would report), so the
+    one list per query of macr_score_topk needs no merge; macr_colmean's result lands in device memory or straight in
+    pinned host memory."""
+    rs = np.random.RandomState(81)
+    U, K, N = 4099, 20, 300
+    rank = np.stack([rs.permutation(N)[:K] for _ in range(U)]).astype(np.int32)
+    cnt = np.full(U, K, np.int32)
+    short = rs.choice(U, 40, replace=False)
+    cnt[short] = rs.randint(0, K + 1, short.size)
+    for q in short:
+        rank[q, cnt[q]:] = -1
+    gt_lists = [sorted(rs.choice(N, size=rs.randint(1, 30), replace=False).tolist()) for _ in range(U)]
+    gptr, gidx = oracle.csr_from_lists(gt_lists)
+    gt = ops.CSR(dev(gptr), dev(gidx))
+    for Ks in ([20], [1, 5, 20]):
+        want = oracle.metrics_mf(rank, cnt, (gptr, gidx), Ks)
+        counted = ops.metrics_mf(dev(rank), None, gt, Ks)
+        np.testing.assert_allclose(counted.cpu().numpy(), want, rtol=1e-14, atol=0, equal_nan=True)
+        assert torch.equal(torch.nan_to_num(counted), torch.nan_to_num(ops.metrics_mf(dev(rank), dev(cnt), gt, Ks)))
+        host = torch.full((4, len(Ks)), -1.0, dtype=torch.float64).pin_memory()
+        on_dev = ops.colmean(counted)
+        ops.colmean(counted, out=host)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(on_dev.cpu()), torch.nan_to_num(host))
+
+
+def test_first_round_alone_says_whether_it_stands(ops, eval_filter):
+    """macr_score_topk_first_round: with thresholds that hold (sampling pass, good or damaged seeds) it returns exactly
+    what macr_score_topk returns and stats == {0, 0} -- written to device memory or to pinned host memory; with seeds the
+    model has moved away from, stats[0] counts the query blocks the complete call would list again."""
+    rs = np.random.RandomState(131)
+    U, N, d, K, S = 700, 7000, 64, 20, ops.SEED_WIDTH
+    P = (rs.standard_normal((U, d)) * 0.4).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.4).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    mask = random_mask(rs, U, N, 30, heavy=(5,))
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    sig_i = ops.branch_sigmoid(dev(Q), dev(w)); sig_u = ops.branch_sigmoid(dev(P), dev(wu))
+    wv, wi, _ = oracle.score_topk(oracle.SCORE_RUBI_BOTH, P, Q, K, sig_u.cpu().numpy(), sig_i.cpu().numpy(), 30.0,
+                                  oracle.csr_from_lists(mask))
+    prev = torch.full((U, S), -1, dtype=torch.int32, device="cuda")
+    ops.score_topk(ops.SCORE_RUBI_BOTH, dev(P), None, dev(Q), K, sig_u, sig_i, 30.0, mcsr, seed_out=prev)
+    rnd = torch.from_numpy(np.stack([rs.choice(N, S, replace=False) for _ in range(U)]).astype(np.int32)).cuda()
+    host_stats = torch.full((2,), 77, dtype=torch.int32).pin_memory()
+    dev_stats = torch.full((2,), 77, dtype=torch.int32, device="cuda")
+    for name, seed, stats in (("sampled", None, dev_stats), ("sampled, host stats", None, host_stats),
+                              ("seeded", prev.clone(), host_stats), ("stale", rnd, host_stats)):
+        stats.fill_(77)
+        seeds_out = torch.full((U, S), -1, dtype=torch.int32, device="cuda")
+        v, ix = ops.score_topk(ops.SCORE_RUBI_BOTH, dev(P), None, dev(Q), K, sig_u, sig_i, 30.0, mcsr, seed=seed,
+                               seed_out=seeds_out, stats=stats, first_round=True)
+        torch.cuda.synchronize()
+        got = stats.cpu().numpy().tolist()
+        if name == "stale":
+            assert got[0] > 0 and got[1] == 0, (name, got)
+            continue
+        assert got == [0, 0], (name, got)
+        assert np.array_equal(ix[0].cpu().numpy(), wi), name
+        assert np.array_equal(v[0].cpu().numpy().view(np.uint32), wv.view(np.uint32)), name
+        assert torch.equal(seeds_out[:, :K], ix[0]), name
+    with pytest.raises(Exception):
+        ops.score_topk(ops.SCORE_RUBI_BOTH, dev(P), None, dev(Q), K, sig_u, sig_i, 30.0, mcsr, first_round=True)     # stats required
+
+
 def test_golden_cpp_evaluator_cases(ops, golden_dir):
     """G7: raw outputs of the reference's C++ evaluator (tools.h + evaluate_foldout.h) on stored inputs."""
     import os
