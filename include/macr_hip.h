@@ -435,6 +435,16 @@ size_t macr_test_bf16_products_workspace_bytes(int d, int U, int N);
 int macr_test_bf16_products(int d, int U, int N, const float *users, const float *items, float c,
                             float *prod, float *margin, void *workspace, size_t workspace_bytes, void *stream);
 
+/* TEST-ONLY: the same for the listing pass macr_score_topk runs (k_score_stream_c: the epilogue in the operand copies --
+ * item rows scaled by sig_i, the bias -c*sig_i as a three-term bf16 slab in the last MFMA, query rows scaled for
+ * DIRECT_MINUS_BOTH).  Writes the SCORE that pass would list for every (query, item) pair of the given kind, scores (dev)
+ * fp32[U][N], and the margin per query; tests/ assert |scores - fp32 score| <= margin element-wise.  sig_u / sig_i (dev)
+ * fp32[U] / [N] as the kind needs them. */
+size_t macr_test_bf16_scores_workspace_bytes(int d, int U, int N);
+int macr_test_bf16_scores(int score_kind, int d, int U, int N, const float *users, const float *items,
+                          const float *sig_u, const float *sig_i, float c, float *scores, float *margin,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* The train-item mask as the ranking kernels read it: mask_bits[tile][query] has bit (i % 32)
  * set when the query masks item 32*tile + i of the shard.  The mask of an evaluator never
  * changes during training (macr_mf/train.py:119-138 filters the same train lists every

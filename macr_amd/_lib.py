@@ -70,6 +70,8 @@ SIGNATURES = {
     "macr_score_topk_sweep": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _z, _p]),
     "macr_test_bf16_products_workspace_bytes": (_z, [_i, _i, _i]),
     "macr_test_bf16_products": (_i, [_i, _i, _i, _p, _p, _f, _p, _p, _p, _z, _p]),
+    "macr_test_bf16_scores_workspace_bytes": (_z, [_i, _i, _i]),
+    "macr_test_bf16_scores": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p]),
     "macr_mask_bits_bytes": (_z, [_i, _i]),
     "macr_mask_bits_build": (_i, [_i, _i, _p, _p, _i, _p, _p]),
     "macr_score_matrix": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),

@@ -1305,6 +1305,416 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
     }   // segments
 }
 
+// ============================================================================
+// The listing pass with the epilogue INSIDE the matrix product (k_score_stream_c; what macr_score_topk runs under the bf16
+// filter -- k_score_stream_b above stays for reference and its bound test, k_score_stream_bs for the c sweep).
+//
+// tools/listing_bench.hip (this kernel and its predecessors side by side, cycle-counter traces, PMC) says what a visit of
+// k_score_stream_b costs a wave: a third of it are the MFMAs; the rest is vector-ALU work that four waves per SIMD queue
+// up for -- the address arithmetic of the tile copy (per-thread divisions and clamps), an fma + compare + three scalar
+// instructions per score for the test on the raw product, the staging of sig_i and 1/sig_i -- and 12 instead of 9 LDS
+// fragment reads.  Here:
+//   * the operand copies carry the epilogue.  Items: q'_i = s_i q_i (s_i = sig_i for the RUBI kinds, 1 otherwise), and one
+//     more 16-byte unit per row with the three-term bf16 split of the bias b_i = -c sig_i (0 for NORMAL), multiplied in the
+//     LAST MFMA against a user-side slab of ones.  Users: u' = u / sig_u for DIRECT_MINUS_BOTH, u otherwise.  Then
+//         acc'' = u'.q' + b_i      listed score v = acc'' * f_u      (f_u = sig_u for the *_BOTH kinds, 1 otherwise)
+//     is the score of every kind, the listing test is acc'' >= (tau - margin) / f_u -- ONE compare against a lane constant --
+//     and nothing per item is staged beside the tile.  (The products accumulate at their own magnitude and the bias joins
+//     last: one rounding at the magnitude of c, as in the fp32 epilogue's (y - c).  A user with sig_u < 1e-30 keeps u' = u
+//     and a zero in place of the ones: her DIRECT_MINUS_BOTH score is y to 1e-30 |c|.)
+//     |v_bf16 - v_fp32| <= filter_margin as before: s_i, sig_u <= 1 only shrink the products the bound is stated on, the
+//     scaled operands and the bias split add roundings of 2^-24 relative (inside the margin's absolute term).
+//   * item rows in global memory exactly as they sit in LDS: RU = 2D/8 + 1 units of 16 bytes (hi[D], lo[D], bias unit; the
+//     odd unit stride that makes the fragment reads conflict-free), the table padded to whole tiles, so a tile is TU
+//     consecutive units: thread t copies unit t (+ 512 k), the tile offset is wave-uniform (SGPRs), nothing is clamped.
+//     Every load is unconditional (a load under a branch makes the compiler wait for it at the join).
+//   * the visit loop is unrolled over the two LDS buffers (immediate offsets); all nine fragment reads first, then the 13
+//     MFMAs back to back; per score one v_cmp + one s_cbranch; a hit costs eight vector instructions (mask bit, LDS counter,
+//     key, store).  A full list keeps counting (the segment's end flags it) instead of raising its threshold.
+// Measured (tools/listing_bench, Gowalla shape, ~176 listed per query): 317 -> 246-252 us; instructions per MFMA:
+// VALU 6.7 -> 3.2, SALU 8.4 -> 2.1; the matrix pipe 40 % -> 52 % busy at the clock the chip then sustains (1.95 GHz).
+// ============================================================================
+template <int D>
+struct StreamCfgC {
+    static constexpr int RU = 2 * D / 8 + 1;                  // 16-byte units per item row
+    static constexpr int TU = kTileItems * RU;                // ... per tile
+    static constexpr int NS = D / 16;
+    static constexpr int LDU = (TU + 511) / 512, REM = TU - 512 * (LDU - 1);      // copy rounds of 512 threads; units of the last one
+    static constexpr size_t smem = (size_t)2 * TU * 16 + kUsersPerBlock * 4;
+};
+static inline size_t items_c_bytes(int n_local, int d) { return (size_t)n_tiles(n_local) * kTileItems * (2 * d / 8 + 1) * 16; }
+
+// item scale / bias / user scale of a score kind (see above); c < 0 or > 0 alike
+template <int KIND> __device__ __forceinline__ float item_scale_c(float sgi) {
+    return (KIND == MACR_SCORE_RUBI_BOTH || KIND == MACR_SCORE_RUBI) ? sgi : 1.0f;
+}
+template <int KIND> __device__ __forceinline__ float item_bias_c(float sgi, float c) {
+    return KIND == MACR_SCORE_NORMAL ? 0.0f : -(c * sgi);
+}
+__device__ __forceinline__ bool sig_u_tiny(float su) { return !(su > 1e-30f); }
+
+// Operand copies for k_score_stream_c: item rows (and the zero rows up to a whole tile) in the RU-unit layout, query rows
+// as in k_bf16_prep (scaled for DIRECT_MINUS_BOTH), |u| per query, max |q| -- norms of the UNscaled rows, which bound the
+// scaled ones.  Row space of a block: [0, n_pad) items, [n_pad, n_pad + U) queries.
+template <int D, int KIND>
+__device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, const float *__restrict__ users_tab,
+                                                  const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                                  const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
+                                                  uint4 *__restrict__ users_c, uint4 *__restrict__ items_c,
+                                                  float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
+    constexpr int LPRB = D / 8, RPB = 256 / LPRB, RU = StreamCfgC<D>::RU;
+    __shared__ float s_max[4];
+    const int n_pad = ((n_local + kTileItems - 1) / kTileItems) * kTileItems;
+    const int sub = threadIdx.x % LPRB, slot = threadIdx.x / LPRB;
+    float4 a[kPrepTrips], b[kPrepTrips];
+    float scale[kPrepTrips], bias[kPrepTrips];
+    long long row[kPrepTrips];
+#pragma unroll
+    for (int t = 0; t < kPrepTrips; ++t) {
+        row[t] = ((long long)blk * kPrepTrips + t) * RPB + slot;
+        const bool is_item = row[t] < n_local;
+        const long long q = row[t] - n_pad;
+        const bool is_user = q >= 0 && q < U;
+        const float *src = is_item ? items + (size_t)row[t] * D : users_tab + (size_t)(is_user ? (user_ids ? user_ids[q] : q) : 0) * D;
+        a[t] = ld4(src + 8 * sub); b[t] = ld4(src + 8 * sub + 4);
+        scale[t] = 1.0f; bias[t] = 0.0f;
+        if (is_item && score_uses_sig_i(KIND)) {
+            const float sgi = sig_i[row[t]];
+            scale[t] = item_scale_c<KIND>(sgi); bias[t] = item_bias_c<KIND>(sgi, c);
+        }
+        if (is_user && KIND == MACR_SCORE_DIRECT_MINUS_BOTH) {
+            const float su = sig_u[q];
+            scale[t] = sig_u_tiny(su) ? 1.0f : 1.0f / su;
+        }
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < kPrepTrips; ++t) {
+        const bool is_item = row[t] < n_local, is_pad = row[t] >= n_local && row[t] < n_pad;
+        const long long q = row[t] - n_pad;
+        const bool is_user = q >= 0 && q < U;
+        float sq = 0.f;
+        if (is_item || is_user || is_pad) {
+            const float x[8] = {a[t].x * scale[t], a[t].y * scale[t], a[t].z * scale[t], a[t].w * scale[t],
+                                b[t].x * scale[t], b[t].y * scale[t], b[t].z * scale[t], b[t].w * scale[t]};
+            uint32_t hi[8], lo[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                hi[k] = is_pad ? 0u : bf16_rne_bits(x[k]);
+                lo[k] = is_pad ? 0u : bf16_rne_bits(x[k] - __uint_as_float(hi[k] << 16));
+            }
+            const uint4 vh = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+            const uint4 vl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+            if (is_user) {
+                uint4 *dst = users_c + (size_t)q * 2 * LPRB;
+                dst[sub] = vh; dst[LPRB + sub] = vl;
+            } else {
+                uint4 *dst = items_c + (size_t)row[t] * RU;
+                dst[sub] = vh; dst[LPRB + sub] = vl;
+                if (sub == 0) {                                // the bias unit: three bf16 terms, then zeros
+                    const float bi = is_pad ? 0.0f : bias[t];
+                    const uint32_t b1 = bf16_rne_bits(bi);
+                    const float r1 = bi - __uint_as_float(b1 << 16);
+                    const uint32_t b2 = bf16_rne_bits(r1);
+                    const uint32_t b3 = bf16_rne_bits(r1 - __uint_as_float(b2 << 16));
+                    dst[2 * LPRB] = make_uint4(b1 | (b2 << 16), b3, 0u, 0u);
+                }
+            }
+            sq = dot4(a[t], a[t]) + dot4(b[t], b[t]);         // (of the row as given, not as scaled)
+        }
+        sq = group_sum<LPRB>(sq);
+        float nrm = sqrtf(sq) * 1.0001f;
+        if (!(nrm == nrm)) nrm = INFINITY;
+        if (is_user && sub == 0) unorm[q] = nrm;
+        if (is_item) m = fmaxf(m, nrm);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        if (m > __uint_as_float(__hip_atomic_load(qmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+            atomicMax(qmax_bits, __float_as_uint(m));
+    }
+}
+static inline unsigned bf16_prep_c_blocks(int U, int n_local, int d) {
+    const size_t rows_per_block = (size_t)kPrepTrips * (256 / (d / 8));
+    return (unsigned)(((size_t)n_tiles(n_local) * kTileItems + U + rows_per_block - 1) / rows_per_block);
+}
+
+template <int D, int KIND>
+__global__ __launch_bounds__(256) void k_bf16_prep_c(int U, int n_local, const float *__restrict__ users_tab,
+                                                     const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                                     const float *__restrict__ sig_u, const float *__restrict__ sig_i,
+                                                     float c_val, const float *__restrict__ c_dev,
+                                                     uint4 *__restrict__ users_c, uint4 *__restrict__ items_c,
+                                                     float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
+    bf16_prep_c_block<D, KIND>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_c, items_c,
+                               unorm, qmax_bits);
+}
+
+template <int D, int KIND, bool REPAIR = false>
+__global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
+    int U, int n_local, const uint4 *__restrict__ users_c, const uint4 *__restrict__ items_c,
+    const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
+    const float *__restrict__ sig_u, float c_val, const float *__restrict__ c_dev,
+    const uint32_t *__restrict__ mask_bits, const uint32_t *__restrict__ zero_word, int item_offset, int ublocks,
+    const float *__restrict__ tau, uint64_t *__restrict__ lists, int32_t *__restrict__ counts, int cap, int32_t *overflow,
+    int ovf_per_user, int32_t *blk_flag, const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev, int slots_full) {
+    using C = StreamCfgC<D>;
+    constexpr int THREADS = 512, NS = C::NS, RU = C::RU, TU = C::TU, LDU = C::LDU, REM = C::REM;
+    constexpr int kCheckTiles = 8;
+    const float c = c_dev ? *c_dev : c_val;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4 *s_t = reinterpret_cast<uint4 *>(smem);                                      // [2][TU]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)2 * TU * 16);       // [256]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int T = (n_local + kTileItems - 1) / kTileItems;
+    int n_ub = ublocks;
+    long long G = gridDim.x;
+    const long long b = blockIdx.x;
+    RepairLayout rl = {false, 0, U};
+    if (REPAIR) {                                             // only the *n_ub_dev user blocks of ub_map, by part of the grid (k_score_stream)
+        n_ub = *n_ub_dev;
+        if (n_ub == 0) return;
+        rl = repair_layout(slots_full, U, n_ub);
+        G = repair_grid(rl, G, ublocks, n_ub, T);
+        if (b >= G) return;
+    }
+    int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream (scattered tile ranges)
+    S = S < 1 ? 1 : S;
+    for (;; ++S) {
+        int x = S, y = T;
+        while (y) { const int r = x % y; x = y; y = r; }
+        if (x == 1) break;
+    }
+    auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T); };
+    auto visit_after = [&](int tile) { const int n = tile + S; return n >= T ? n - T : n; };
+    const float qmax = __uint_as_float(*qmax_bits);
+    const long long W = (long long)n_ub * T;
+    const long long w_end = W * (b + 1) / G;
+    const uint4 *my_src = items_c + tid;                      // + tile * TU (wave-uniform)
+    const int last_off = 512 * (LDU - 1) + (tid < REM ? 0 : tid % REM - tid);      // (everybody loads in the last round too: wrapped)
+    const size_t mask_stride = mask_bits ? (size_t)U : 0;
+    for (long long w = W * b / G; w < w_end;) {
+    const int ubv = (int)(w / T), i0 = (int)(w - (long long)ubv * T);
+    const int i1 = (int)min((long long)T, i0 + (w_end - w));
+    w += i1 - i0;
+    long long first = (long long)ubv * T * G / W;
+    while (W * (first + 1) / G <= (long long)ubv * T) ++first;
+    while (W * first / G > (long long)ubv * T) --first;
+    const int split = (int)(b - first);
+    const int ub = REPAIR ? ub_map[ubv] : ubv;
+    __syncthreads();                                          // (the previous segment's readers are done with s_t and s_cnt)
+    for (int k = tid; k < kUsersPerBlock; k += THREADS) s_cnt[k] = 0u;
+    const int uslot = wid * 32 + col, q = ub * kUsersPerBlock + uslot;
+    const bool q_ok = q < U;
+    bf16x8 bhi[NS], blo[NS];
+    {
+        const uint4 *urow = users_c + (size_t)(q_ok ? q : 0) * (2 * D / 8);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            uint4 v = urow[2 * sI + h], l = urow[D / 8 + 2 * sI + h];
+            if (!q_ok) { v = make_uint4(0u, 0u, 0u, 0u); l = v; }
+            bhi[sI] = *reinterpret_cast<bf16x8 *>(&v);
+            blo[sI] = *reinterpret_cast<bf16x8 *>(&l);
+        }
+    }
+    const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
+    const bool tiny = score_uses_sig_u(KIND) && sig_u_tiny(su);
+    // listed score = acc'' * fu
+    const float fu = (KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny) ? 1.0f : su;
+    // the user side of the bias slab: ones against the three bias terms (k = 0, 1, 2; lanes 0-31 hold k < 8), zeros elsewhere
+    const bool ones_on = KIND != MACR_SCORE_NORMAL && h == 0 && !(KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny);
+    union { uint32_t u[4]; bf16x8 v; } ones;
+    ones.u[0] = ones_on ? 0x3f803f80u : 0u; ones.u[1] = ones_on ? 0x00003f80u : 0u; ones.u[2] = 0u; ones.u[3] = 0u;
+    const bf16x8 bext = ones.v;
+    // listing test: v_bf16 >= tau - margin  <=>  acc'' >= (tau - margin) / fu   (fu > 0; NaN = never: padding queries)
+    float tau_s = __builtin_nanf("");
+    if (q_ok) tau_s = tau[q] - 1.01f * filter_margin(D, unorm[q], qmax, c);
+    float thr = tau_s / fu;
+    if (KIND == MACR_SCORE_RUBI_BOTH && tiny) thr = q_ok ? -INFINITY : thr;       // (scores of the order of sig_u: everything is a candidate)
+    uint64_t *my_list = lists + ((size_t)split * rl.stride + ((REPAIR && rl.compact) ? ubv * kUsersPerBlock + uslot : (q_ok ? q : 0))) * cap;
+    const uint32_t *my_mask = mask_bits ? mask_bits + (q_ok ? q : 0) : zero_word;       // + tile * mask_stride (wave-uniform)
+    uint32_t *my_cnt = &s_cnt[uslot];
+    const int id_lane = item_offset + 4 * h;                  // id of accumulator slot r: tile * 32 + (r & 3) + 8 * (r >> 2) + id_lane
+
+    uint4 stg[LDU];
+    uint32_t tm_next = 0u;
+    auto load_tile = [&](int tile) {
+        const int tu = __builtin_amdgcn_readfirstlane(tile);
+        const uint4 *src = my_src + (size_t)tu * TU;
+#pragma unroll
+        for (int k = 0; k + 1 < LDU; ++k) stg[k] = src[512 * k];
+        stg[LDU - 1] = src[last_off];
+        tm_next = my_mask[(size_t)tu * mask_stride];
+    };
+    auto store_tile = [&](auto BUF) {
+        constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+        for (int k = 0; k < LDU; ++k) {
+            asm volatile("" : "+v"(stg[k].x), "+v"(stg[k].y), "+v"(stg[k].z), "+v"(stg[k].w));
+            if (k + 1 < LDU || tid < REM) s_t[buf * TU + tid + 512 * k] = stg[k];
+        }
+    };
+    // one visit: tile t sits in buffer BUF, the next tile's copy is in flight in stg
+    auto one_visit = [&](auto BUF, int t, uint32_t tm_cur) {
+        constexpr int buf = decltype(BUF)::value;
+        const __bf16 *ua = reinterpret_cast<const __bf16 *>(s_t + buf * TU) + (size_t)col * (8 * RU) + 8 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // fragments of up to four k-slabs (and the bias unit) in registers first, then their MFMAs back to back: an
+        // instruction between two MFMAs on one accumulator costs ~43 cycles (MI355X_MICROARCH.md)
+        constexpr int CH = NS < 4 ? NS : 4;
+        bf16x8 ae;
+        if (KIND != MACR_SCORE_NORMAL)
+            ae = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(s_t + buf * TU) + (size_t)col * (8 * RU) + 2 * D);
+#pragma unroll
+        for (int s0 = 0; s0 < NS; s0 += CH) {
+            bf16x8 ah[CH], al[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                ah[j] = *reinterpret_cast<const bf16x8 *>(ua + 16 * (s0 + j));
+                al[j] = *reinterpret_cast<const bf16x8 *>(ua + D + 16 * (s0 + j));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[j], bhi[s0 + j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], blo[s0 + j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], bhi[s0 + j], acc, 0, 0, 0);
+            }
+            if (KIND != MACR_SCORE_NORMAL && s0 + CH >= NS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ae, bext, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int valid = n_local - t * kTileItems;           // < 32 only in the last tile of the shard
+        const uint32_t tailm = valid < kTileItems ? ~0u << (valid > 0 ? valid : 0) : 0u;
+        const uint32_t tmh = (tm_cur | tailm) >> (4 * h);      // bit (r & 3) + 8 (r >> 2): this lane's row of slot r is masked / past the end
+        const int id0 = t * kTileItems + id_lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool above = acc[r] >= thr;
+            if (__builtin_amdgcn_ballot_w64(above)) {          // wave-uniform: some lane's score r passes
+                const int rbit = (r & 3) + 8 * (r >> 2);
+                uint32_t m = tmh;
+                asm volatile("" : "+v"(m));                    // (the mask test belongs in here, not in front of the branch)
+                if (above && !((m >> rbit) & 1u)) {
+                    const uint32_t pos = atomicAdd(my_cnt, 1u);        // (keeps counting past cap: the segment's end flags it)
+                    if (pos < (uint32_t)cap) my_list[pos] = make_key(acc[r] * fu, id0 + rbit);
+                }
+            }
+        }
+    };
+    // block-uniform: give up on stale seeds / follow the sibling blocks that did (k_score_stream)
+    auto stale_check = [&](int done) -> bool {
+        if (!blk_flag) return false;
+        const bool check = done == 2 || done == kCheckTiles || done == 4 * kCheckTiles;
+        if (!(check || (done & 7) == 0)) return false;
+        bool mine = false;
+        if (check) {
+            uint32_t a = h == 0 ? *my_cnt : 0u;                // appended so far by this wave's 32 users
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, kWave);
+            const float usable = 32.f * (float)(done * kTileItems) * (float)(kSelRegs * 64) / (float)n_local;
+            mine = (float)a > usable + 64.f;
+        } else if (tid == 0) {
+            mine = __hip_atomic_load(blk_flag + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        }
+        const bool stop = __syncthreads_or(mine) != 0;
+        if (stop && tid == 0) __hip_atomic_store(blk_flag + ub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return stop;
+    };
+
+    int t = visit(i0);
+    if (i0 < i1) { load_tile(t); store_tile(std::integral_constant<int, 0>()); }
+    uint32_t tm_cur = tm_next;
+    __syncthreads();
+    int vi = i0;
+    while (vi < i1) {
+        {
+            const int tn = vi + 1 < i1 ? visit_after(t) : t;
+            load_tile(tn);
+            __builtin_amdgcn_sched_barrier(0);
+            one_visit(std::integral_constant<int, 0>(), t, tm_cur);
+            const bool stop = stale_check(vi - i0 + 1);
+            store_tile(std::integral_constant<int, 1>());
+            __syncthreads();
+            tm_cur = tm_next; t = tn; ++vi;
+            if (stop) break;
+        }
+        if (vi >= i1) break;
+        {
+            const int tn = vi + 1 < i1 ? visit_after(t) : t;
+            load_tile(tn);
+            __builtin_amdgcn_sched_barrier(0);
+            one_visit(std::integral_constant<int, 1>(), t, tm_cur);
+            const bool stop = stale_check(vi - i0 + 1);
+            store_tile(std::integral_constant<int, 0>());
+            __syncthreads();
+            tm_cur = tm_next; t = tn; ++vi;
+            if (stop) break;
+        }
+    }
+    for (int k = tid; k < kUsersPerBlock; k += THREADS) {
+        const int qq = ub * kUsersPerBlock + k;
+        const int ql2 = (REPAIR && rl.compact) ? ubv * kUsersPerBlock + k : qq;
+        if (qq < U) {
+            counts[(size_t)split * rl.stride + ql2] = (int32_t)min(s_cnt[k], (uint32_t)cap);
+            if (s_cnt[k] > (uint32_t)cap) overflow[ovf_per_user ? qq : 0] = 1;        // full: her list was cut
+        }
+    }
+    }   // segments
+}
+
+// Test-only (macr_test_bf16_scores): the SCORE k_score_stream_c lists for every (query, item) pair -- its MFMA sequence on
+// the copies k_bf16_prep_c wrote, times the query's factor -- and the margin the filter grants each query.
+template <int D, int KIND>
+__global__ __launch_bounds__(64) void k_test_bf16_scores(int U, int N, const uint4 *__restrict__ users_c, const uint4 *__restrict__ items_c,
+                                                         const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
+                                                         const float *__restrict__ sig_u, float c, float *__restrict__ out,
+                                                         float *__restrict__ margin) {
+    constexpr int RU = StreamCfgC<D>::RU;
+    const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+    const int item = min((int)blockIdx.x * 32 + col, N - 1), user = min((int)blockIdx.y * 32 + col, U - 1);
+    const uint4 *irow = items_c + (size_t)item * RU, *urow = users_c + (size_t)user * (2 * D / 8);
+    const float su = score_uses_sig_u(KIND) ? sig_u[user] : 1.0f;
+    const bool tiny = score_uses_sig_u(KIND) && sig_u_tiny(su);
+    const float fu = (KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny) ? 1.0f : su;
+    const bool ones_on = KIND != MACR_SCORE_NORMAL && h == 0 && !(KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny);
+    union { uint32_t u[4]; bf16x8 v; } ones;
+    ones.u[0] = ones_on ? 0x3f803f80u : 0u; ones.u[1] = ones_on ? 0x00003f80u : 0u; ones.u[2] = 0u; ones.u[3] = 0u;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int sI = 0; sI < D / 16; ++sI) {
+        uint4 v;
+        v = irow[2 * sI + h];          const bf16x8 ah = *reinterpret_cast<bf16x8 *>(&v);
+        v = irow[D / 8 + 2 * sI + h];  const bf16x8 al = *reinterpret_cast<bf16x8 *>(&v);
+        v = urow[2 * sI + h];          const bf16x8 bh = *reinterpret_cast<bf16x8 *>(&v);
+        v = urow[D / 8 + 2 * sI + h];  const bf16x8 bl = *reinterpret_cast<bf16x8 *>(&v);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+    if (KIND != MACR_SCORE_NORMAL) {
+        uint4 v = irow[2 * D / 8];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&v), ones.v, acc, 0, 0, 0);
+    }
+    const int u = (int)blockIdx.y * 32 + col;
+    if (u >= U) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int it = (int)blockIdx.x * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (it < N) out[(size_t)u * N + it] = acc[r] * fu;
+    }
+    if (blockIdx.x == 0 && h == 0) margin[u] = filter_margin(D, unorm[u], __uint_as_float(*qmax_bits), c);
+}
+
 // The listing pass of k_score_stream_b for up to kMaxSweep values of c at once (macr_score_topk_sweep under the bf16
 // filter): one staging of the item tiles, one set of MFMAs and one barrier per tile serve every value; per (score, c)
 // there remain the test on the raw product and, for the hits, the epilogue and the append into that c's lists.
@@ -1722,7 +2132,8 @@ __global__ __launch_bounds__(256) void k_prep_tau_seed(int n_prep, int U, int n_
                                                        const uint32_t *__restrict__ mask_bits, int item_offset, int K,
                                                        const int32_t *__restrict__ seed, float *__restrict__ tau) {
     if ((int)blockIdx.x < n_prep)
-        bf16_prep_block<D>(blockIdx.x, U, n_local, users_tab, user_ids, items, users_bf, items_bf, unorm, qmax_bits);
+        bf16_prep_c_block<D, KIND>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_bf, items_bf,
+                                   unorm, qmax_bits);
     else
         tau_seed_block<D, KIND>(blockIdx.x - n_prep, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_val, c_dev, mask_bits,
                                 item_offset, K, seed, tau);
@@ -2669,6 +3080,7 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
 struct TopkWs {
     float *tau, *maxima; int32_t *counts; int32_t *overflow, *user_ovf, *ub_map, *blk_flag; uint32_t *shared_thr, *mask_bits; uint64_t *lists;
     uint4 *users_bf, *items_bf; float *unorm;        // bf16 filter: operand copies, |u| per query user (max |q|: overflow[8], zeroed per call)
+    uint4 *users_c, *items_c;
     int cap; size_t header_bytes, maxima_bytes, mask_bytes, lists_bytes, bytes;
 };
 static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g, int d = 0) {
@@ -2697,6 +3109,8 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g, 
     w.users_bf = static_cast<uint4 *>(take((size_t)U * d * 4));          // (hi[d], lo[d]) bf16 per row
     w.items_bf = static_cast<uint4 *>(take((size_t)n_local * d * 4));
     w.unorm = static_cast<float *>(take((size_t)U * 4));
+    w.users_c = static_cast<uint4 *>(take((size_t)U * d * 4));           // k_score_stream_c's copies (the epilogue in the operands)
+    w.items_c = static_cast<uint4 *>(take(d ? items_c_bytes(n_local, d) : 0));
     w.bytes = off;
     return w;
 }
@@ -2887,17 +3301,27 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
         };
         const bool seeded = !list_all && seed_idx;
         uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws.overflow + 8);
-        if (filter_bf16 && seeded) {
-            // operand copies (two bf16 per value), |u| per query, max |q| -- and, in the same launch, the seeded thresholds
-            const unsigned n_prep = bf16_prep_blocks(U, n_local, D);
-            k_prep_tau_seed<D, KIND><<<n_prep + (U + 7) / 8, 256, 0, st>>>((int)n_prep, U, n_local, users_tab, user_ids, items, ws.users_bf,
-                                                                           ws.items_bf, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev, mask_bits,
-                                                                           item_offset, K, seed_idx, ws.tau);
-            MACR_CHECK_LAUNCH("bf16_prep+tau_seed", st);
-        } else if (filter_bf16) {
+        // users_c: the scaled query copies exist for DIRECT_MINUS_BOTH only; the other kinds' are the plain ones
+        uint4 *users_c = KIND == MACR_SCORE_DIRECT_MINUS_BOTH ? ws.users_c : ws.users_bf;
+        // the plain copies (k_bf16_prep) feed the sampling pass: needed unless thresholds come from seeds and no repair round can follow
+        const bool need_plain = filter_bf16 && (!seeded || !first_only);
+        if (need_plain) {
             k_bf16_prep<D><<<bf16_prep_blocks(U, n_local, D), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, ws.users_bf, ws.items_bf,
                                                                             ws.unorm, qmax_bits);
             MACR_CHECK_LAUNCH("bf16_prep", st);
+        }
+        if (filter_bf16 && seeded) {
+            // the listing pass's operand copies (the epilogue in the operands), |u| per query, max |q| -- and, in the same
+            // launch, the seeded thresholds
+            const unsigned n_prep = bf16_prep_c_blocks(U, n_local, D);
+            k_prep_tau_seed<D, KIND><<<n_prep + (U + 7) / 8, 256, 0, st>>>((int)n_prep, U, n_local, users_tab, user_ids, items, users_c,
+                                                                           ws.items_c, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev, mask_bits,
+                                                                           item_offset, K, seed_idx, ws.tau);
+            MACR_CHECK_LAUNCH("bf16_prep+tau_seed", st);
+        } else if (filter_bf16) {
+            k_bf16_prep_c<D, KIND><<<bf16_prep_c_blocks(U, n_local, D), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
+                                                                                      users_c, ws.items_c, ws.unorm, qmax_bits);
+            MACR_CHECK_LAUNCH("bf16_prep_c", st);
         }
         if (filter_bf16 && !seeded) {
             auto pass0b = k_score_sample_b<D, KIND>;
@@ -2932,12 +3356,13 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
         if (filter_bf16) {
             // bf16-filtered first round (k_score_stream_b): listing on the bf16 matrix cores, then the selection re-scores
             // its best candidates in fp32
-            auto pass1b = k_score_stream_b<D, KIND>;
-            const size_t smem_b = StreamCfgB<D>::smem;
-            MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass1b), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)smem_b) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_b);
-            pass1b<<<geo.grid1, StreamGroupsB<D>::THREADS, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev,
-                                                   mask_bits, item_offset, geo.ublocks, ws.tau, ws.lists, ws.counts, ws.cap,
+            auto pass1c = k_score_stream_c<D, KIND>;
+            const size_t smem_c = StreamCfgC<D>::smem;
+            MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass1c), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
+            pass1c<<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
+                                                   mask_bits, reinterpret_cast<const uint32_t *>(ws.overflow + 3), item_offset, geo.ublocks,
+                                                   ws.tau, ws.lists, ws.counts, ws.cap,
                                                    repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
                                                    seeded ? ws.blk_flag : nullptr, nullptr, nullptr, 0);
             MACR_CHECK_LAUNCH("score_stream_b", st);
@@ -2969,11 +3394,11 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
                 // the repair round on the bf16 copies too: sampling pass for the re-listed user blocks when the thresholds
                 // came from seeds, listing, selection with fp32 re-scoring
                 auto pass0rb = k_score_sample_b<D, KIND, true>;
-                auto pass1rb = k_score_stream_b<D, KIND, true>;
-                const size_t smem_b = StreamCfgB<D>::smem;
+                auto pass1rc = k_score_stream_c<D, KIND, true>;
+                const size_t smem_b = StreamCfgB<D>::smem, smem_c = StreamCfgC<D>::smem;
                 hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass0rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
-                if (eb == hipSuccess) eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
-                MACR_REQUIRE(eb == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_b);
+                if (eb == hipSuccess) eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1rc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_c);
+                MACR_REQUIRE(eb == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
                 if (seeded) {
                     pass0rb<<<geo.grid0, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, sig_u, sig_i, c, c_dev, mask_bits,
                                                            geo.ublocks, ws.maxima, sample_log2(n_local), ws.ub_map, ws.overflow + 1);
@@ -2981,10 +3406,10 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
                     launch_k_tau<true>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau, ws.unorm, qmax_bits, c, c_dev, D);
                     MACR_CHECK_LAUNCH("tau2", st);
                 }
-                pass1rb<<<geo.grid1, StreamGroupsB<D>::THREADS, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, ws.unorm, qmax_bits, sig_u,
-                                                                            sig_i, c, c_dev, mask_bits, item_offset, geo.ublocks, ws.tau,
-                                                                            ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
-                                                                            ws.ub_map, ws.overflow + 1, geo.slots1);
+                pass1rc<<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev, mask_bits,
+                                                        reinterpret_cast<const uint32_t *>(ws.overflow + 3), item_offset, geo.ublocks, ws.tau,
+                                                        ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
+                                                        ws.ub_map, ws.overflow + 1, geo.slots1);
                 MACR_CHECK_LAUNCH("score_stream2", st);
                 k_select_b<D, KIND, true><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, n_splits, K, ws.cap, ws.lists,
                                                                                 ws.counts, ws.overflow, 0, ws.overflow + 1, ws.blk_flag,
@@ -3224,6 +3649,39 @@ extern "C" int macr_test_bf16_products(int d, int U, int N, const float *users, 
         k_test_bf16_products<D><<<grid, 64, 0, st>>>(U, N, users_bf, items_bf, unorm, qmax_bits, c, prod, margin);
     });
     MACR_CHECK_LAUNCH("test_bf16_products", st);
+    return MACR_OK;
+}
+
+extern "C" size_t macr_test_bf16_scores_workspace_bytes(int d, int U, int N) {
+    if (!dim_supported(d) || U <= 0 || N <= 0) return 0;
+    return align_up((size_t)U * 4 * d, 256) + align_up(items_c_bytes(N, d), 256) + align_up((size_t)U * 4, 256) + 256;
+}
+
+extern "C" int macr_test_bf16_scores(int score_kind, int d, int U, int N, const float *users, const float *items, const float *sig_u,
+                                     const float *sig_i, float c, float *scores, float *margin, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "test_bf16_scores: score_kind=%d", score_kind);
+    MACR_REQUIRE(U > 0 && N > 0, MACR_E_INVALID, "test_bf16_scores: U=%d N=%d", U, N);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "test_bf16_scores: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(users && items && scores && margin && workspace, MACR_E_INVALID, "test_bf16_scores: null pointer");
+    MACR_REQUIRE((!score_uses_sig_i(score_kind) || sig_i) && (!score_uses_sig_u(score_kind) || sig_u), MACR_E_INVALID,
+                 "test_bf16_scores: score_kind %d needs its sigmoids", score_kind);
+    MACR_REQUIRE(workspace_bytes >= macr_test_bf16_scores_workspace_bytes(d, U, N), MACR_E_WORKSPACE,
+                 "test_bf16_scores: workspace %zu < %zu", workspace_bytes, macr_test_bf16_scores_workspace_bytes(d, U, N));
+    unsigned char *p = static_cast<unsigned char *>(workspace);
+    uint4 *users_c = reinterpret_cast<uint4 *>(p);   p += align_up((size_t)U * 4 * d, 256);
+    uint4 *items_c = reinterpret_cast<uint4 *>(p);   p += align_up(items_c_bytes(N, d), 256);
+    float *unorm = reinterpret_cast<float *>(p);     p += align_up((size_t)U * 4, 256);
+    uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(p);
+    fill_words(qmax_bits, 1, 0u, st);
+    dim3 grid((N + 31) / 32, (U + 31) / 32);
+    MACR_DISPATCH_DK(d, score_kind, {
+        k_bf16_prep_c<D, KIND><<<bf16_prep_c_blocks(U, N, D), 256, 0, st>>>(U, N, users, nullptr, items, sig_u, sig_i, c, nullptr, users_c, items_c,
+                                                                            unorm, qmax_bits);
+        k_test_bf16_scores<D, KIND><<<grid, 64, 0, st>>>(U, N, users_c, items_c, unorm, qmax_bits, sig_u, c, scores, margin);
+    });
+    MACR_CHECK_LAUNCH("test_bf16_scores", st);
     return MACR_OK;
 }
 

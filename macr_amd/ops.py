@@ -217,6 +217,21 @@ def test_bf16_products(users, items, c=0.0):
     return prod, margin
 
 
+def test_bf16_scores(kind, users, items, sig_u=None, sig_i=None, c=0.0):
+    """TEST-ONLY (macr_test_bf16_scores): the score the bf16 listing pass of macr_score_topk would list for every
+    (user row, item row) pair of `kind`, and the margin the filter grants each user row -> ((U, N) fp32, (U,) fp32)."""
+    _require_f32(users=users, items=items)
+    U, d = users.shape
+    N = items.shape[0]
+    L = _lib.lib()
+    ws = torch.empty(L.macr_test_bf16_scores_workspace_bytes(d, U, N), dtype=torch.uint8, device=items.device)
+    out = torch.empty((U, N), dtype=_f32, device=items.device)
+    margin = torch.empty(U, dtype=_f32, device=items.device)
+    check(L.macr_test_bf16_scores(kind, d, U, N, _ptr(users, _f32), _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
+                                  float(c), _ptr(out), _ptr(margin), _ptr(ws), ws.numel(), _stream()))
+    return out, margin
+
+
 SEED_WIDTH = 32          # MACR_SEED_WIDTH
 _topk_ws_cache = {}
 

@@ -1246,6 +1246,37 @@ def test_bf16_filter_margin_bounds_the_product_error(ops, case, d, record_proper
     assert (margin <= lim * 1.01).all()
 
 
+ALL_KINDS = [oracle.SCORE_NORMAL, oracle.SCORE_RUBI_BOTH, oracle.SCORE_RUBI, oracle.SCORE_DIRECT_MINUS, oracle.SCORE_DIRECT_MINUS_BOTH]
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("case", ["same_sign", "aligned", "worst_residual", "binades", "dominant", "ties", "gaussian"])
+def test_bf16_listed_scores_stay_within_the_margin(ops, case, d):
+    """The listing pass macr_score_topk runs carries the epilogue in its operands (item rows scaled by sig_i, the bias
+    -c sig_i as a three-term bf16 slab in the last MFMA, query rows scaled for DIRECT_MINUS_BOTH): for every score kind,
+    the score it would list (macr_test_bf16_scores: its own MFMA sequence) stays within the query's margin of the fp32
+    score -- the oracle's epilogue on the fmaf chain -- on the adversarial operands of the product bound, with sigmoids
+    over thirty binades and c of either sign and size."""
+    rs = np.random.RandomState(2000 + d + 11 * BF16_CASES.index(case))
+    U, N = 64 + 5, 320 + 3
+    P, Q = adversarial_operands(case, U, N, d, rs)
+    sig_u = (1.0 / (1.0 + np.exp(-rs.standard_normal(U) * 3.0))).astype(np.float32)
+    sig_i = (1.0 / (1.0 + np.exp(-rs.standard_normal(N) * 3.0))).astype(np.float32)
+    sig_u[:4] = [1.0, 1e-3, 1e-12, 1e-35]          # (the last one is below the kernels' 1e-30 guard)
+    sig_i[:4] = [1.0, 1e-4, 1e-20, 1e-38]
+    for kind in ALL_KINDS:
+        for c in (0.0, 40.0, -3.5, 1000.0):
+            if kind == oracle.SCORE_NORMAL and c != 0.0:
+                continue
+            want = oracle.score_matrix(kind, P, Q, sig_u, sig_i, c)
+            got, margin = ops.test_bf16_scores(kind, dev(P), dev(Q), dev(sig_u), dev(sig_i), c)
+            got, margin = got.cpu().numpy(), margin.cpu().numpy()
+            assert np.isfinite(got).all() and np.isfinite(margin).all() and (margin > 0).all()
+            err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+            worst = (err / margin[:, None].astype(np.float64)).max()
+            assert (err <= margin[:, None]).all(), "kind %d case %s d=%d c=%g: error reaches %.3f of the margin" % (kind, case, d, c, worst)
+
+
 def test_bf16_filter_margin_constant_covers_its_stated_bound():
     """filter_rel(d) >= 3.2 * 2^-16 + 6 d * 2^-24 for every supported d (round 3 shipped 1e-4 < 1.39e-4 at d = 256); the
     header's prose quotes the same numbers."""
