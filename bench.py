@@ -525,7 +525,7 @@ def main():
             # The ranking = sample pass + tau + listing pass + select (+ the fallback launch that returns at once):
             # `achieved` counts the catalogue's U*N*d multiply-adds ONCE over the time of all of them (the sample pass
             # re-multiplies 1/8 of the tiles; that is overhead, not work).  "stream" is the listing pass alone.
-            rank_kernels = ("score_sample", "score_sample_b", "tau", "tau_seed", "bf16_prep", "bf16_prep+tau_seed", "score_stream", "score_stream_b", "select", "select_b",
+            rank_kernels = ("score_sample", "score_sample_b", "tau", "tau_seed", "bf16_prep", "bf16_prep_c", "bf16_prep+tau_seed", "score_stream", "score_stream_b", "select", "select_b",
                             "repair_plan", "score_sample2", "tau2", "score_stream2", "select2", "score_topk")
             st_us = 1e3 * sum(ek.get(k, 0.0) for k in rank_kernels)
             stream_us = 1e3 * ek.get("score_stream_b" if filt == "bf16" else "score_stream", float("nan"))

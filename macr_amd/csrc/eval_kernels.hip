@@ -1670,6 +1670,182 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
     }   // segments
 }
 
+// The sampling pass on the same operand copies (k_score_sample_b's successor): class maxima of acc'' * f_u over a strided
+// 1/2^s sample of the catalogue.  With the epilogue in the operands a score costs its share of the MFMAs and one v_max;
+// masked items are poisoned at accumulator init.  The rows of a virtual tile are 2^s items apart: every unit is gathered
+// by its own address (row and unit index of a thread's units are fixed; the window's base is wave-uniform).
+template <int D, int KIND, bool REPAIR = false>
+__global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
+    int U, int n_local, const uint4 *__restrict__ users_c, const uint4 *__restrict__ items_c,
+    const float *__restrict__ sig_u, const uint32_t *__restrict__ mask_bits, const uint32_t *__restrict__ zero_word,
+    int ublocks, float *__restrict__ maxima, int sample_log2,
+    const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev) {
+    using C = StreamCfgC<D>;
+    constexpr int THREADS = 512, NS = C::NS, RU = C::RU, TU = C::TU, LDU = C::LDU, REM = C::REM;
+    const int kStep = 1 << sample_log2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4 *s_t = reinterpret_cast<uint4 *>(smem);                                      // [2][TU]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int uslot = wid * 32 + col;
+    const int tiles_total = (n_local + kTileItems - 1) / kTileItems;
+    const int n_pad = tiles_total * kTileItems;
+    const int T = (tiles_total + kStep - 1) / kStep;          // windows = virtual tiles per user block
+    int n_ub = ublocks;                                       // (repair round: see k_score_stream)
+    long long G = gridDim.x;
+    const long long b = blockIdx.x;
+    if (REPAIR) {
+        n_ub = *n_ub_dev;
+        if (n_ub == 0) return;
+        G = (long long)n_ub * G / ublocks;                     // (the maxima keep their layout: ranges as long as in the full launch)
+        if (G < 1) G = 1;
+        if (b >= G) return;
+    }
+    int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream
+    S = S < 1 ? 1 : S;
+    for (;; ++S) {
+        int x = S, y = T;
+        while (y) { const int r = x % y; x = y; y = r; }
+        if (x == 1) break;
+    }
+    auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T) * kStep; };
+    // this thread's units of a tile: (row, unit in row); the last round wraps (everybody loads, the owners store)
+    int urow_[LDU], ucol_[LDU];
+#pragma unroll
+    for (int k = 0; k < LDU; ++k) {
+        const int e = (tid + THREADS * k) % TU;
+        urow_[k] = e / RU; ucol_[k] = e % RU;
+    }
+    const size_t mask_stride = mask_bits ? (size_t)U : 0;
+    const long long W = (long long)n_ub * T;
+    const long long w_end = W * (b + 1) / G;
+    for (long long w = W * b / G; w < w_end;) {
+    const int ubv = (int)(w / T), i0 = (int)(w - (long long)ubv * T);
+    const int i1 = (int)min((long long)T, i0 + (w_end - w));
+    w += i1 - i0;
+    long long first = (long long)ubv * T * G / W;
+    while (W * (first + 1) / G <= (long long)ubv * T) ++first;
+    while (W * first / G > (long long)ubv * T) --first;
+    const int split = (int)(b - first);
+    const int ub = REPAIR ? ub_map[ubv] : ubv;
+    const int q = ub * kUsersPerBlock + uslot;
+    const bool q_ok = q < U;
+    __syncthreads();                                          // (the previous segment's readers are done with s_t)
+    bf16x8 bhi[NS], blo[NS];
+    {
+        const uint4 *urow = users_c + (size_t)(q_ok ? q : 0) * (2 * D / 8);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            uint4 v = urow[2 * sI + h], l = urow[D / 8 + 2 * sI + h];
+            if (!q_ok) { v = make_uint4(0u, 0u, 0u, 0u); l = v; }
+            bhi[sI] = *reinterpret_cast<bf16x8 *>(&v);
+            blo[sI] = *reinterpret_cast<bf16x8 *>(&l);
+        }
+    }
+    const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
+    const bool tiny = score_uses_sig_u(KIND) && sig_u_tiny(su);
+    const float fu = (KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny) ? 1.0f : su;
+    const bool ones_on = KIND != MACR_SCORE_NORMAL && h == 0 && !(KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny);
+    union { uint32_t u[4]; bf16x8 v; } ones;
+    ones.u[0] = ones_on ? 0x3f803f80u : 0u; ones.u[1] = ones_on ? 0x00003f80u : 0u; ones.u[2] = 0u; ones.u[3] = 0u;
+    const bf16x8 bext = ones.v;
+    const uint32_t *my_mask = mask_bits ? mask_bits + (q_ok ? q : 0) : zero_word;
+
+    uint4 stg[LDU];
+    uint32_t tm_next = 0u;
+    // item `row` of the virtual tile of window `tile >> s` = every kStep-th item of the window, phase = window index mod kStep
+    auto load_tile = [&](int tile) {
+        const int tu = __builtin_amdgcn_readfirstlane(tile);
+        const int base = tu * kTileItems + ((tu >> sample_log2) & (kStep - 1));
+#pragma unroll
+        for (int k = 0; k < LDU; ++k) {
+            const int it = min(base + kStep * urow_[k], n_pad - 1);            // (rows past the end: zero rows, masked below)
+            stg[k] = items_c[(size_t)it * RU + ucol_[k]];
+        }
+        tm_next = my_mask[((size_t)tiles_total + (tu >> sample_log2)) * mask_stride];
+    };
+    auto store_tile = [&](auto BUF) {
+        constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+        for (int k = 0; k < LDU; ++k) {
+            asm volatile("" : "+v"(stg[k].x), "+v"(stg[k].y), "+v"(stg[k].z), "+v"(stg[k].w));
+            if (k + 1 < LDU || tid < REM) s_t[buf * TU + tid + THREADS * k] = stg[k];
+        }
+    };
+    float cmax[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cmax[r] = -INFINITY;
+    const float kNone = __builtin_nanf("");
+    auto one_visit = [&](auto BUF, int t, uint32_t tm_cur) {
+        constexpr int buf = decltype(BUF)::value;
+        uint32_t tmask = tm_cur;
+        const int valid = (n_local - t * kTileItems - ((t >> sample_log2) & (kStep - 1)) + kStep - 1) >> sample_log2;   // < 32 only in the last window
+        if (valid < kTileItems) tmask |= valid > 0 ? ~0u << valid : ~0u;
+        const uint32_t tmh = tmask >> (4 * h);
+        const __bf16 *ua = reinterpret_cast<const __bf16 *>(s_t + buf * TU) + (size_t)col * (8 * RU) + 8 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = ((tmh >> ((r & 3) + 8 * (r >> 2))) & 1u) ? kNone : 0.f;
+        constexpr int CH = NS < 4 ? NS : 4;
+        bf16x8 ae;
+        if (KIND != MACR_SCORE_NORMAL)
+            ae = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(s_t + buf * TU) + (size_t)col * (8 * RU) + 2 * D);
+#pragma unroll
+        for (int s0 = 0; s0 < NS; s0 += CH) {
+            bf16x8 ah[CH], al[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                ah[j] = *reinterpret_cast<const bf16x8 *>(ua + 16 * (s0 + j));
+                al[j] = *reinterpret_cast<const bf16x8 *>(ua + D + 16 * (s0 + j));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[j], bhi[s0 + j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], blo[s0 + j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], bhi[s0 + j], acc, 0, 0, 0);
+            }
+            if (KIND != MACR_SCORE_NORMAL && s0 + CH >= NS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ae, bext, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cmax[r] = fmaxf(cmax[r], acc[r]);        // (fmaxf drops the NaN of a masked item)
+    };
+    int vi = i0, t = visit(i0);
+    if (vi < i1) { load_tile(t); store_tile(std::integral_constant<int, 0>()); }
+    uint32_t tm_cur = tm_next;
+    __syncthreads();
+    while (vi < i1) {
+        {
+            const int tn = vi + 1 < i1 ? visit(vi + 1) : t;
+            load_tile(tn);
+            __builtin_amdgcn_sched_barrier(0);
+            one_visit(std::integral_constant<int, 0>(), t, tm_cur);
+            store_tile(std::integral_constant<int, 1>());
+            __syncthreads();
+            tm_cur = tm_next; t = tn; ++vi;
+        }
+        if (vi >= i1) break;
+        {
+            const int tn = vi + 1 < i1 ? visit(vi + 1) : t;
+            load_tile(tn);
+            __builtin_amdgcn_sched_barrier(0);
+            one_visit(std::integral_constant<int, 1>(), t, tm_cur);
+            store_tile(std::integral_constant<int, 0>());
+            __syncthreads();
+            tm_cur = tm_next; t = tn; ++vi;
+        }
+    }
+    if (q_ok) {
+        float *o = maxima + ((size_t)split * U + q) * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)       // slots (r&3)+8(r>>2)+4h: four runs of four consecutive floats; scores = acc'' * f_u
+            *reinterpret_cast<float4 *>(o + 8 * g + 4 * h) = make_float4(cmax[4 * g] * fu, cmax[4 * g + 1] * fu, cmax[4 * g + 2] * fu, cmax[4 * g + 3] * fu);
+    }
+    }   // segments
+}
+
 // Test-only (macr_test_bf16_scores): the SCORE k_score_stream_c lists for every (query, item) pair -- its MFMA sequence on
 // the copies k_bf16_prep_c wrote, times the query's factor -- and the margin the filter grants each query.
 template <int D, int KIND>
@@ -3303,13 +3479,7 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
         uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws.overflow + 8);
         // users_c: the scaled query copies exist for DIRECT_MINUS_BOTH only; the other kinds' are the plain ones
         uint4 *users_c = KIND == MACR_SCORE_DIRECT_MINUS_BOTH ? ws.users_c : ws.users_bf;
-        // the plain copies (k_bf16_prep) feed the sampling pass: needed unless thresholds come from seeds and no repair round can follow
-        const bool need_plain = filter_bf16 && (!seeded || !first_only);
-        if (need_plain) {
-            k_bf16_prep<D><<<bf16_prep_blocks(U, n_local, D), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, ws.users_bf, ws.items_bf,
-                                                                            ws.unorm, qmax_bits);
-            MACR_CHECK_LAUNCH("bf16_prep", st);
-        }
+        const uint32_t *zero_word = reinterpret_cast<const uint32_t *>(ws.overflow + 3);
         if (filter_bf16 && seeded) {
             // the listing pass's operand copies (the epilogue in the operands), |u| per query, max |q| -- and, in the same
             // launch, the seeded thresholds
@@ -3324,11 +3494,11 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
             MACR_CHECK_LAUNCH("bf16_prep_c", st);
         }
         if (filter_bf16 && !seeded) {
-            auto pass0b = k_score_sample_b<D, KIND>;
-            const size_t smem_b = StreamCfgB<D>::smem;
-            MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass0b), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)smem_b) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_b);
-            pass0b<<<geo.grid0, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, sig_u, sig_i, c, c_dev, mask_bits,
+            auto pass0c = k_score_sample_c<D, KIND>;
+            const size_t smem_c = StreamCfgC<D>::smem;
+            MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass0c), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
+            pass0c<<<geo.grid0, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
                                                   geo.ublocks, ws.maxima, sample_log2(n_local), nullptr, nullptr);
             MACR_CHECK_LAUNCH("score_sample_b", st);
             launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev, D);
@@ -3361,7 +3531,7 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
             MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass1c), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
             pass1c<<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
-                                                   mask_bits, reinterpret_cast<const uint32_t *>(ws.overflow + 3), item_offset, geo.ublocks,
+                                                   mask_bits, zero_word, item_offset, geo.ublocks,
                                                    ws.tau, ws.lists, ws.counts, ws.cap,
                                                    repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
                                                    seeded ? ws.blk_flag : nullptr, nullptr, nullptr, 0);
@@ -3393,21 +3563,21 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
             } else if (filter_bf16) {
                 // the repair round on the bf16 copies too: sampling pass for the re-listed user blocks when the thresholds
                 // came from seeds, listing, selection with fp32 re-scoring
-                auto pass0rb = k_score_sample_b<D, KIND, true>;
+                auto pass0rb = k_score_sample_c<D, KIND, true>;
                 auto pass1rc = k_score_stream_c<D, KIND, true>;
-                const size_t smem_b = StreamCfgB<D>::smem, smem_c = StreamCfgC<D>::smem;
-                hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass0rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
+                const size_t smem_c = StreamCfgC<D>::smem;
+                hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass0rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_c);
                 if (eb == hipSuccess) eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1rc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_c);
                 MACR_REQUIRE(eb == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
                 if (seeded) {
-                    pass0rb<<<geo.grid0, 512, smem_b, st>>>(U, n_local, ws.users_bf, ws.items_bf, sig_u, sig_i, c, c_dev, mask_bits,
+                    pass0rb<<<geo.grid0, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
                                                            geo.ublocks, ws.maxima, sample_log2(n_local), ws.ub_map, ws.overflow + 1);
                     MACR_CHECK_LAUNCH("score_sample2", st);
                     launch_k_tau<true>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau, ws.unorm, qmax_bits, c, c_dev, D);
                     MACR_CHECK_LAUNCH("tau2", st);
                 }
                 pass1rc<<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev, mask_bits,
-                                                        reinterpret_cast<const uint32_t *>(ws.overflow + 3), item_offset, geo.ublocks, ws.tau,
+                                                        zero_word, item_offset, geo.ublocks, ws.tau,
                                                         ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
                                                         ws.ub_map, ws.overflow + 1, geo.slots1);
                 MACR_CHECK_LAUNCH("score_stream2", st);

@@ -30,6 +30,15 @@ def short(name):
             k = "score_sample"
         if t and t.group(2) in ("true", "1"):
             k += "2"
+    if k in ("score_stream_b", "score_stream_c"):      # the bf16 listing pass (k_score_stream_c since round 4); REPAIR instantiations apart
+        t = re.search(r"k_score_stream_[bc]<\s*\d+\s*,\s*\d+\s*,\s*(true|false|0|1)", name)
+        k = "score_stream2" if (t and t.group(1) in ("true", "1")) else "score_stream_b"
+    if k in ("select_b", "score_sample_b"):
+        t = re.search(r"k_(?:select_b|score_sample_b)<\s*\d+\s*,\s*\d+\s*,\s*(true|false|0|1)", name)
+        if t and t.group(1) in ("true", "1"):
+            k = "select2" if k == "select_b" else "score_sample2"
+    if k == "prep_tau_seed":
+        k = "bf16_prep+tau_seed"
     if k == "spmm_row":              # k_spmm_row<D, SPARSE>: 1 = flagged output rows only, 2 = row-sparse input
         t = re.search(r"k_spmm_row<\s*\d+\s*,\s*(\d+)\s*,\s*(true|false|0|1)", name)
         k = "spmm_csr" + {"1": "_rows", "2": "_sparse"}.get(t.group(1) if t else "0", "")   # (the names the benches use)
