@@ -2640,8 +2640,11 @@ __device__ __forceinline__ void rescore_lists(int q, int ql, int lane, int U, in
     asm volatile("" ::: "memory");
 }
 
+// (five waves per SIMD: the kernel is a chain of dependent memory trips -- list lengths, list entries, the candidates' rows --
+// and at the 133 registers the 1024-candidate path asks for only three waves per SIMD were in flight: 36 -> 28 us seeded,
+// 66 -> 49 us sampled on the Gowalla shape; eight waves per SIMD measured the same as five)
 template <int D, int KIND, bool REPAIR = false>
-__global__ __launch_bounds__(64 * kSelWaves) void k_select_b(int U, int n_local, int n_splits, int n_out, int K, int cap,
+__global__ __launch_bounds__(64 * kSelWaves, 5) void k_select_b(int U, int n_local, int n_splits, int n_out, int K, int cap,
                                                              uint64_t *lists, const int32_t *__restrict__ counts,
                                                              int32_t *overflow, int ovf_per_user, const int32_t *__restrict__ run_if,
                                                              const int32_t *__restrict__ skip_blk,
