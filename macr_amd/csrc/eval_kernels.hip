@@ -1678,7 +1678,7 @@ template <int D, int KIND, bool REPAIR = false>
 __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
     int U, int n_local, const uint4 *__restrict__ users_c, const uint4 *__restrict__ items_c,
     const float *__restrict__ sig_u, const uint32_t *__restrict__ mask_bits, const uint32_t *__restrict__ zero_word,
-    int ublocks, float *__restrict__ maxima, int sample_log2,
+    int ublocks, float *__restrict__ maxima, int sample_log2, int merge_pairs,
     const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev) {
     using C = StreamCfgC<D>;
     constexpr int THREADS = 512, NS = C::NS, RU = C::RU, TU = C::TU, LDU = C::LDU, REM = C::REM;
@@ -1837,11 +1837,22 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
             tm_cur = tm_next; t = tn; ++vi;
         }
     }
-    if (q_ok) {
+    // Classes are merged in pairs (slots r and r + 8: disjoint item sets stay disjoint): 16 maxima per (split, query) for
+    // k_tau to rank instead of 32 -- half its registers and scalar work; two of a query's K best classes share a pair ~once
+    // in K (K - 1) / 2 / 160 = 1.2 cases at K = 20, which lowers the threshold by one rank of ~160.  Scores = acc'' * f_u.
+    // (merge_pairs: the launcher's choice -- only where 16 per split leave several times K classes)
+    if (q_ok && !merge_pairs) {
         float *o = maxima + ((size_t)split * U + q) * 32;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)       // slots (r&3)+8(r>>2)+4h: four runs of four consecutive floats; scores = acc'' * f_u
+        for (int g = 0; g < 4; ++g)       // slots (r&3)+8(r>>2)+4h: four runs of four consecutive floats
             *reinterpret_cast<float4 *>(o + 8 * g + 4 * h) = make_float4(cmax[4 * g] * fu, cmax[4 * g + 1] * fu, cmax[4 * g + 2] * fu, cmax[4 * g + 3] * fu);
+    }
+    if (q_ok && merge_pairs) {
+        float *o = maxima + ((size_t)split * U + q) * 16 + 8 * h;
+        *reinterpret_cast<float4 *>(o) = make_float4(fmaxf(cmax[0], cmax[8]) * fu, fmaxf(cmax[1], cmax[9]) * fu, fmaxf(cmax[2], cmax[10]) * fu,
+                                                     fmaxf(cmax[3], cmax[11]) * fu);
+        *reinterpret_cast<float4 *>(o + 4) = make_float4(fmaxf(cmax[4], cmax[12]) * fu, fmaxf(cmax[5], cmax[13]) * fu, fmaxf(cmax[6], cmax[14]) * fu,
+                                                         fmaxf(cmax[7], cmax[15]) * fu);
     }
     }   // segments
 }
@@ -2330,19 +2341,21 @@ template <int NREG, bool REPAIR = false>
 __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int K, const float *__restrict__ maxima,
                                                         const int32_t *__restrict__ blk_flag, float *__restrict__ tau,
                                                         const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
-                                                        float c_val, const float *__restrict__ c_dev, int d_filter) {
+                                                        float c_val, const float *__restrict__ c_dev, int d_filter, int per_log2) {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x * kSelWaves + wid;
     if (q >= U) return;
     // repair round: only the users of re-listed user blocks were sampled; their threshold is raised, never lowered
     if (REPAIR && blk_flag[q / kUsersPerBlock] == 0) return;
-    const int n = n_splits * 32;
+    // 2^per_log2 class maxima per (split, user): 32 (k_score_stream, k_score_sample_b) or 16 (k_score_sample_c)
+    const int per = 1 << per_log2;
+    const int n = n_splits * per;
     uint32_t key[NREG];
 #pragma unroll
     for (int j = 0; j < NREG; ++j) {
-        const int e = j * 64 + lane;                              // split e/32, class e%32
+        const int e = j * 64 + lane;                              // split e / per, class e % per
         float m = -INFINITY;
-        if (e < n) m = maxima[((size_t)(e >> 5) * U + q) * 32 + (e & 31)];
+        if (e < n) m = maxima[(((size_t)(e >> per_log2) * U + q) << per_log2) + (e & (per - 1))];
         key[j] = m > -INFINITY ? f32_orderable(m) : 0u;           // 0 = the class saw no unmasked item
     }
     int n_valid = 0;
@@ -3351,15 +3364,15 @@ namespace macr {
 template <bool REPAIR>
 static void launch_k_tau(int tau_regs, int blocks, hipStream_t st, int U, int slots0, int K, const float *maxima,
                          const int32_t *blk_flag, float *tau, const float *unorm = nullptr, const uint32_t *qmax_bits = nullptr,
-                         float c = 0.f, const float *c_dev = nullptr, int d_filter = 0) {
+                         float c = 0.f, const float *c_dev = nullptr, int d_filter = 0, int per_log2 = 5) {
     const int th = 64 * kSelWaves;
     // (unorm != NULL: the maxima are bf16 scores, tau = K-th largest - the filter's margin)
-    if (tau_regs <= 1) k_tau<1, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
-    else if (tau_regs <= 2) k_tau<2, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
-    else if (tau_regs <= 4) k_tau<4, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
-    else if (tau_regs <= 8) k_tau<8, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
-    else if (tau_regs <= 16) k_tau<16, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
-    else k_tau<32, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter);
+    if (tau_regs <= 1) k_tau<1, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
+    else if (tau_regs <= 2) k_tau<2, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
+    else if (tau_regs <= 4) k_tau<4, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
+    else if (tau_regs <= 8) k_tau<8, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
+    else if (tau_regs <= 16) k_tau<16, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
+    else k_tau<32, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
 }
 }  // namespace macr
 
@@ -3483,6 +3496,8 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
         // users_c: the scaled query copies exist for DIRECT_MINUS_BOTH only; the other kinds' are the plain ones
         uint4 *users_c = KIND == MACR_SCORE_DIRECT_MINUS_BOTH ? ws.users_c : ws.users_bf;
         const uint32_t *zero_word = reinterpret_cast<const uint32_t *>(ws.overflow + 3);
+        // k_score_sample_c merges its classes in pairs where that still leaves several times K of them (k_tau ranks half as many)
+        const int merge_pairs = geo.slots0 * 16 >= 4 * K ? 1 : 0, per_c = merge_pairs ? 16 : 32;
         if (filter_bf16 && seeded) {
             // the listing pass's operand copies (the epilogue in the operands), |u| per query, max |q| -- and, in the same
             // launch, the seeded thresholds
@@ -3502,9 +3517,10 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
             MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass0c), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
             pass0c<<<geo.grid0, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
-                                                  geo.ublocks, ws.maxima, sample_log2(n_local), nullptr, nullptr);
+                                                  geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, nullptr, nullptr);
             MACR_CHECK_LAUNCH("score_sample_b", st);
-            launch_k_tau<false>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev, D);
+            launch_k_tau<false>((geo.slots0 * per_c + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev, D,
+                                merge_pairs ? 4 : 5);
             MACR_CHECK_LAUNCH("tau", st);
         } else if (seeded && filter_bf16) {
             // (thresholds: in the launch above)
@@ -3574,9 +3590,10 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
                 MACR_REQUIRE(eb == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
                 if (seeded) {
                     pass0rb<<<geo.grid0, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
-                                                           geo.ublocks, ws.maxima, sample_log2(n_local), ws.ub_map, ws.overflow + 1);
+                                                           geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, ws.ub_map, ws.overflow + 1);
                     MACR_CHECK_LAUNCH("score_sample2", st);
-                    launch_k_tau<true>(tau_regs, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau, ws.unorm, qmax_bits, c, c_dev, D);
+                    launch_k_tau<true>((geo.slots0 * per_c + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau, ws.unorm, qmax_bits, c, c_dev, D,
+                                       merge_pairs ? 4 : 5);
                     MACR_CHECK_LAUNCH("tau2", st);
                 }
                 pass1rc<<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev, mask_bits,
