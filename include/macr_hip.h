@@ -503,6 +503,13 @@ int macr_metrics_foldout(int U, int K, const int32_t *rankings,
                          const int32_t *gt_ptr, const int32_t *gt_idx, float *results,
                          int hr_in_ap_slot, void *stream);
 
+/* The same on the one sorted list per query macr_score_topk leaves (ids, -1 in unused slots), completed -- where a query has
+ * fewer than K candidates -- with its masked ids in ascending order from the fill CSR (fill_ptr int32[U+1], fill_idx): what
+ * macr_topk_merge's fill writes for the reference's -inf train items (batch_test.py:124-134), without that launch.
+ * K <= MACR_MAX_TOPK. */
+int macr_metrics_foldout_fill(int U, int K, const int32_t *rankings, const int32_t *fill_ptr, const int32_t *fill_idx,
+                              const int32_t *gt_ptr, const int32_t *gt_idx, float *results, int hr_in_ap_slot, void *stream);
+
 /* MF metrics (macr_mf/train.py:32-117, float64 like NumPy): out (dev) f64
  * [U*4*nK] = per query {precision, recall, ndcg, hit_ratio} x Ks.  cnt (dev,
  * may be NULL) int32[U] = length of each ranked list; NULL: a list's length is its

@@ -78,6 +78,7 @@ SIGNATURES = {
     "macr_topk_scores": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "macr_topk_merge": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "macr_metrics_foldout": (_i, [_i, _i, _p, _p, _p, _p, _i, _p]),
+    "macr_metrics_foldout_fill": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _i, _p]),
     "macr_metrics_mf": (_i, [_i, _i, _p, _p, _p, _p, ctypes.POINTER(ctypes.c_int32), _i, _p, _p]),
     "macr_colmean": (_i, [_p, _i, _i, _i, _p, _p]),
 }

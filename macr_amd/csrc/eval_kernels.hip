@@ -3154,6 +3154,86 @@ __global__ void k_metrics_foldout(int U, int K, const int32_t *__restrict__ rank
     }
 }
 
+// The same, one WAVE per query (K <= 128): the K membership searches -- the dependent loads that are this kernel's time --
+// run side by side (lane l owns rank positions l and 64 + l), the prefix recurrences are the thread version's own
+// statements, run by every lane over the wave's hit mask (no memory in the loop; the discounts 1/log2(i+2) come from a table
+// the block computes once), and lane l keeps the values of its positions.  A list shorter than K (ids < 0 from its first
+// unused slot on) is completed with the query's masked ids in ascending order when a fill CSR is given -- what
+// macr_topk_merge's fill does (-inf scores rank last, batch_test.py:124-134) without a launch of its own.
+__global__ __launch_bounds__(256) void k_metrics_foldout_w(int U, int K, const int32_t *__restrict__ rankings,
+                                                           const int32_t *__restrict__ fill_ptr, const int32_t *__restrict__ fill_idx,
+                                                           const int32_t *__restrict__ gt_ptr, const int32_t *__restrict__ gt_idx,
+                                                           float *__restrict__ results, int hr_in_ap_slot) {
+    __shared__ double s_disc[128];
+    if ((int)threadIdx.x < 128) s_disc[threadIdx.x] = 1.0 / log2((double)(threadIdx.x + 2));
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= U) return;
+    const int32_t *truth = gt_idx + gt_ptr[u];
+    const int truth_len = gt_ptr[u + 1] - gt_ptr[u];
+    int item[2];
+    int n_valid = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pos = lane + 64 * h;
+        item[h] = pos < K ? rankings[(size_t)u * K + pos] : -1;
+        n_valid += __popcll(__ballot(item[h] >= 0));
+    }
+    if (fill_ptr && n_valid < K) {                             // wave-uniform
+        const int f0 = fill_ptr[u], f1 = fill_ptr[u + 1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pos = lane + 64 * h, e = f0 + pos - n_valid;
+            if (pos >= n_valid && pos < K && e < f1) item[h] = fill_idx[e];
+        }
+    }
+    uint64_t hitm[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) hitm[h] = __ballot(item[h] >= 0 && in_sorted(truth, truth_len, item[h]));
+    // Per position, by its own lane: hits so far (a popcount), precision, recall, reciprocal rank -- the double divisions run
+    // once per lane, not once per lane and step.  The running sums whose float roundings depend on the order (sum_pre, dcg,
+    // idcg) are accumulated by every lane over the hit mask with the thread version's statements; `pre` of a hit position comes
+    // from that position's lane.
+    float pre[2], rec[2], rr[2];
+    int hits_at[2];
+    const int first = hitm[0] ? __ffsll((long long)hitm[0]) - 1 : (hitm[1] ? 64 + __ffsll((long long)hitm[1]) - 1 : -1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pos = lane + 64 * h;
+        const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        hits_at[h] = h == 0 ? __popcll(hitm[0] & upto) : __popcll(hitm[0]) + __popcll(hitm[1] & upto);
+        pre[h] = (float)(1.0 * hits_at[h] / (pos + 1));
+        rec[h] = (float)(1.0 * hits_at[h] / truth_len);
+        rr[h] = (first >= 0 && pos >= first) ? (float)(1.0 / (first + 1)) : 0.f;
+    }
+    float sum_pre = 0.f, dcg = 0.f, idcg = 0.f;
+    float my_sum[2] = {0.f, 0.f}, my_dcg[2] = {0.f, 0.f}, my_idcg[2] = {0.f, 0.f};
+    for (int i = 0; i < K; ++i) {
+        const bool hit = (hitm[i >> 6] >> (i & 63)) & 1ull;
+        const float pre_i = __shfl(i < 64 ? pre[0] : pre[1], i & 63, kWave);
+        if (hit) {
+            sum_pre += pre_i;
+            dcg = (float)((double)dcg + s_disc[i]);
+        }
+        if (i < truth_len) idcg = (float)((double)idcg + s_disc[i]);
+        if (i == lane) { my_sum[0] = sum_pre; my_dcg[0] = dcg; my_idcg[0] = idcg; }
+        if (i == lane + 64) { my_sum[1] = sum_pre; my_dcg[1] = dcg; my_idcg[1] = idcg; }
+    }
+    float *res = results + (size_t)u * 5 * K;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pos = lane + 64 * h;
+        if (pos < K) {
+            res[0 * K + pos] = pre[h];
+            res[1 * K + pos] = rec[h];
+            res[2 * K + pos] = hr_in_ap_slot ? ((rec[h] != 0.f) ? 1.0f : 0.0f) : my_sum[h] / (float)truth_len;
+            res[3 * K + pos] = my_dcg[h] / my_idcg[h];
+            res[4 * K + pos] = rr[h];
+        }
+    }
+}
+
 // macr_mf/train.py:32-117 in float64: per query {precision, recall, ndcg, hit} x Ks.
 struct KsArg { int32_t k[8]; int n; };
 // One wave per query: lane i owns rank positions i and 64 + i (Kmax <= 128), so the membership searches and the log2 terms of a
@@ -3917,7 +3997,19 @@ extern "C" int macr_metrics_foldout(int U, int K, const int32_t *rankings, const
     hipStream_t st = as_stream(stream);
     MACR_REQUIRE(U > 0 && K >= 1, MACR_E_INVALID, "metrics_foldout: U=%d K=%d", U, K);
     MACR_REQUIRE(rankings && gt_ptr && gt_idx && results, MACR_E_INVALID, "metrics_foldout: null pointer");
-    k_metrics_foldout<<<(U + 127) / 128, 128, 0, st>>>(U, K, rankings, gt_ptr, gt_idx, results, hr_in_ap_slot);
+    if (K <= 128) k_metrics_foldout_w<<<(U + 3) / 4, 256, 0, st>>>(U, K, rankings, nullptr, nullptr, gt_ptr, gt_idx, results, hr_in_ap_slot);
+    else k_metrics_foldout<<<(U + 127) / 128, 128, 0, st>>>(U, K, rankings, gt_ptr, gt_idx, results, hr_in_ap_slot);
+    MACR_CHECK_LAUNCH("metrics_foldout", st);
+    return MACR_OK;
+}
+
+extern "C" int macr_metrics_foldout_fill(int U, int K, const int32_t *rankings, const int32_t *fill_ptr, const int32_t *fill_idx,
+                                         const int32_t *gt_ptr, const int32_t *gt_idx, float *results, int hr_in_ap_slot,
+                                         void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(U > 0 && K >= 1 && K <= MACR_MAX_TOPK, MACR_E_INVALID, "metrics_foldout_fill: U=%d K=%d (K <= %d)", U, K, MACR_MAX_TOPK);
+    MACR_REQUIRE(rankings && fill_ptr && fill_idx && gt_ptr && gt_idx && results, MACR_E_INVALID, "metrics_foldout_fill: null pointer");
+    k_metrics_foldout_w<<<(U + 3) / 4, 256, 0, st>>>(U, K, rankings, fill_ptr, fill_idx, gt_ptr, gt_idx, results, hr_in_ap_slot);
     MACR_CHECK_LAUNCH("metrics_foldout", st);
     return MACR_OK;
 }

@@ -231,6 +231,10 @@ class Evaluator(object):
                 return ops.colmean(ops.metrics_mf(idx[0], None, self.gt, list(Ks)), out=out)
             _, ix, cnt = ops.topk_merge(vals, idx)
             return ops.colmean(ops.metrics_mf(ix, cnt, self.gt, list(Ks)), out=out)         # (U,4,nK) float64 -> (4,nK)
+        if vals.shape[0] == 1 and vals.shape[2] <= _lib_consts.MAX_TOPK and self._local_own is None:
+            # one sorted list per query: the metrics kernel completes short lists with the masked ids itself (-inf fill,
+            # batch_test.py:124-134) -- no merge launch
+            return ops.colmean(ops.metrics_foldout(idx[0], self.gt, hr_in_ap_slot=True, fill_mask=self.mask), out=out)
         _, ix, _ = ops.topk_merge(vals, idx, self.mask)                                      # -inf fill, batch_test.py:124-134
         return ops.colmean(ops.metrics_foldout(ix, self.gt, hr_in_ap_slot=True), out=out)   # (U,5*max_top) fp32
 

@@ -340,11 +340,17 @@ def topk_merge(vals, idxs, fill_mask=None):
     return ov, oi, oc
 
 
-def metrics_foldout(rankings, gt, hr_in_ap_slot=False):
+def metrics_foldout(rankings, gt, hr_in_ap_slot=False, fill_mask=None):
     """(U,K) rankings + ground-truth CSR -> (U,5K) fp32 (replaces evaluate_foldout, evaluate_foldout.h:115).
-    hr_in_ap_slot: also apply batch_test.py:143-149 (ap block := 1[recall@k != 0])."""
+    hr_in_ap_slot: also apply batch_test.py:143-149 (ap block := 1[recall@k != 0]).
+    fill_mask: lists with fewer than K ids (-1 from their first unused slot on) are completed with the query's masked
+    ids, ascending -- topk_merge's fill without its launch."""
     U, K = rankings.shape
     out = torch.empty((U, 5 * K), dtype=_f32, device=rankings.device)
+    if fill_mask is not None:
+        check(_lib.lib().macr_metrics_foldout_fill(U, K, _ptr(rankings, _i32), _ptr(fill_mask.ptr, _i32), _ptr(fill_mask.idx, _i32),
+                                                   _ptr(gt.ptr, _i32), _ptr(gt.idx, _i32), _ptr(out), int(hr_in_ap_slot), _stream()))
+        return out
     check(_lib.lib().macr_metrics_foldout(U, K, _ptr(rankings, _i32), _ptr(gt.ptr, _i32), _ptr(gt.idx, _i32),
                                           _ptr(out), int(hr_in_ap_slot), _stream()))
     return out

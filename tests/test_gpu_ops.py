@@ -810,6 +810,35 @@ def test_metrics_mf_counts_a_lists_ids_and_colmean_writes_pinned_host_memory(ops
         assert torch.equal(torch.nan_to_num(on_dev.cpu()), torch.nan_to_num(host))
 
 
+@pytest.mark.parametrize("K", [1, 20, 64, 100])
+def test_metrics_foldout_completes_short_lists_like_the_merge(ops, K):
+    """macr_metrics_foldout_fill on the one list per query of macr_score_topk = macr_topk_merge with its -inf fill
+    (batch_test.py:124-134) followed by macr_metrics_foldout, and the oracle's metrics of the filled rankings; the
+    one-wave-per-query kernel (K <= 128) against the oracle for every K; wide column means against numpy."""
+    rs = np.random.RandomState(300 + K)
+    U, N = 700, 400
+    rank = np.stack([rs.permutation(N)[:K] for _ in range(U)]).astype(np.int32)
+    vals = -np.sort(rs.standard_normal((U, K)).astype(np.float32), axis=1)
+    short = rs.choice(U, 60, replace=False)
+    mask_lists = [sorted(rs.choice(N, size=rs.randint(0, 2 * K + 2), replace=False).tolist()) for _ in range(U)]
+    for q in short:
+        n = rs.randint(0, K)
+        rank[q, n:] = -1; vals[q, n:] = -np.inf
+    gt_lists = [sorted(rs.choice(N, size=rs.randint(1, 30), replace=False).tolist()) for _ in range(U)]
+    gptr, gidx = oracle.csr_from_lists(gt_lists)
+    gt = ops.CSR(dev(gptr), dev(gidx))
+    mask = ops.CSR.from_lists(mask_lists, "cuda")
+    _, filled, _ = ops.topk_merge(dev(vals[None]), dev(rank[None]), mask)
+    via_merge = ops.metrics_foldout(filled, gt, hr_in_ap_slot=True)
+    direct = ops.metrics_foldout(dev(rank), gt, hr_in_ap_slot=True, fill_mask=mask)
+    assert torch.equal(via_merge, direct)
+    want = oracle.metrics_foldout(filled.cpu().numpy(), (gptr, gidx))
+    got = ops.metrics_foldout(filled, gt).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=0)
+    np.testing.assert_allclose(ops.colmean(direct).cpu().numpy(), direct.cpu().numpy().astype(np.float64).mean(0), rtol=1e-12, atol=1e-15)
+    assert torch.equal(ops.colmean(direct), ops.colmean(direct))
+
+
 def test_first_round_alone_says_whether_it_stands(ops, eval_filter):
     """macr_score_topk_first_round: with thresholds that hold (sampling pass, good or damaged seeds) it returns exactly
     what macr_score_topk returns and stats == {0, 0} -- written to device memory or to pinned host memory; with seeds the

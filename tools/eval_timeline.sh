@@ -1,10 +1,10 @@
 #!/bin/bash
 # kernel-by-kernel timeline of the last graph replay of tools/eval_timeline.py (seeded and sampled evaluations)
 ROOT=$PWD; OUT=$ROOT/gpurun_out/timeline; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-WL=${1:-gowalla}
+WL=${1:-gowalla}; FL=${2:-mf}
 for seeds in 1 0; do
-  MACR_EVAL_SEEDS=$seeds python $ROOT/tools/eval_timeline.py $WL > $OUT/plain_$seeds.txt 2>&1
-  MACR_EVAL_SEEDS=$seeds rocprofv3 --output-format csv --kernel-trace -d $OUT/s$seeds -o tl -- python $ROOT/tools/eval_timeline.py $WL > $OUT/run_$seeds.txt 2> $OUT/err_$seeds.txt
+  MACR_EVAL_SEEDS=$seeds python $ROOT/tools/eval_timeline.py $WL 8 $FL > $OUT/plain_$seeds.txt 2>&1
+  MACR_EVAL_SEEDS=$seeds rocprofv3 --output-format csv --kernel-trace -d $OUT/s$seeds -o tl -- python $ROOT/tools/eval_timeline.py $WL 8 $FL > $OUT/run_$seeds.txt 2> $OUT/err_$seeds.txt
 done
 cd $ROOT
 python - <<'PY'
