@@ -289,6 +289,9 @@ int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, 
  * -------------------------------------------------------------------------*/
 int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n, int d, const float *w,
                         float *out, void *stream);
+/* Two of them in one launch: the item and the user factors of an evaluation (same arithmetic per row). */
+int macr_branch_sigmoid2(int d, const float *rows_a, const int32_t *idx_a, int n_a, const float *w_a, float *out_a,
+                         const float *rows_b, const int32_t *idx_b, int n_b, const float *w_b, float *out_b, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Fused full-catalogue scoring + train-item masking + top-K: never

@@ -60,6 +60,7 @@ SIGNATURES = {
     "macr_lgcn_train_workspace_bytes": (_z, [_i, _i, _i, _p]),
     "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 2 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _i, _p, _z, _p]),
     "macr_branch_sigmoid": (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    "macr_branch_sigmoid2": (_i, [_i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p]),
     "macr_score_topk_splits": (_i, [_i, _i, _i]),
     "macr_score_topk_uses_seeds": (_i, [_i, _i, _i]),
     "macr_set_eval_filter": (_i, [_i]),

@@ -3113,6 +3113,26 @@ __global__ __launch_bounds__(256) void k_branch_sigmoid(const float *__restrict_
     if (sub == 0) out[r] = sigmoid_acc(s);
 }
 
+// the item and the user branch factors of one evaluation in ONE launch (blocks [0, nb_a) are the first set)
+template <int LPR>
+__global__ __launch_bounds__(256) void k_branch_sigmoid2(int nb_a, const float *__restrict__ rows_a, const int32_t *__restrict__ idx_a, int n_a,
+                                                         const float *__restrict__ w_a, float *__restrict__ out_a,
+                                                         const float *__restrict__ rows_b, const int32_t *__restrict__ idx_b, int n_b,
+                                                         const float *__restrict__ w_b, float *__restrict__ out_b) {
+    constexpr int d = 4 * LPR;
+    const bool first = (int)blockIdx.x < nb_a;
+    const float *rows = first ? rows_a : rows_b, *w = first ? w_a : w_b;
+    const int32_t *idx = first ? idx_a : idx_b;
+    float *out = first ? out_a : out_b;
+    const int n = first ? n_a : n_b, blk = first ? blockIdx.x : blockIdx.x - nb_a;
+    const int sub = threadIdx.x % LPR;
+    const int r = blk * (256 / LPR) + threadIdx.x / LPR;
+    if (r >= n) return;
+    const size_t src = idx ? (size_t)idx[r] : (size_t)r;
+    const float s = group_sum<LPR>(dot4(ld4(rows + src * d + 4 * sub), ld4(w + 4 * sub)));       // (k_branch_sigmoid's arithmetic)
+    if (sub == 0) out[r] = sigmoid_acc(s);
+}
+
 // ----------------------------------------------------------------------------
 // metrics
 // ----------------------------------------------------------------------------
@@ -3992,6 +4012,20 @@ extern "C" int macr_branch_sigmoid(const float *rows, const int32_t *idx, int n,
     return MACR_OK;
 }
 
+extern "C" int macr_branch_sigmoid2(int d, const float *rows_a, const int32_t *idx_a, int n_a, const float *w_a, float *out_a,
+                                    const float *rows_b, const int32_t *idx_b, int n_b, const float *w_b, float *out_b, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(rows_a && w_a && out_a && rows_b && w_b && out_b, MACR_E_INVALID, "branch_sigmoid2: null pointer");
+    MACR_REQUIRE(n_a > 0 && n_b > 0, MACR_E_INVALID, "branch_sigmoid2: n=%d, %d", n_a, n_b);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "branch_sigmoid2: d=%d not in {32,64,128,256}", d);
+    MACR_DISPATCH_LPR(d, {
+        const int rpb = 256 / LPR, nb_a = (n_a + rpb - 1) / rpb, nb_b = (n_b + rpb - 1) / rpb;
+        k_branch_sigmoid2<LPR><<<nb_a + nb_b, 256, 0, st>>>(nb_a, rows_a, idx_a, n_a, w_a, out_a, rows_b, idx_b, n_b, w_b, out_b);
+    });
+    MACR_CHECK_LAUNCH("branch_sigmoid", st);
+    return MACR_OK;
+}
+
 extern "C" int macr_metrics_foldout(int U, int K, const int32_t *rankings, const int32_t *gt_ptr,
                                     const int32_t *gt_idx, float *results, int hr_in_ap_slot, void *stream) {
     hipStream_t st = as_stream(stream);
@@ -4036,6 +4070,8 @@ extern "C" int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const i
 extern "C" int macr_colmean(const void *in, int in_is_f32, int rows, int cols, double *out, void *stream) {
     hipStream_t st = as_stream(stream);
     MACR_REQUIRE(in && out && rows > 0 && cols > 0, MACR_E_INVALID, "colmean: bad arguments");
+    // (wider blocks were tried for wide matrices -- 32 or 8 columns each, coalesced row pieces: 46 and 23 us for 15 424 x 100
+    // floats against 18 with a block per column: too few blocks)
     if (in_is_f32)
         k_colmean<float><<<cols, 1024, 0, st>>>(static_cast<const float *>(in), rows, cols, out);
     else

@@ -104,10 +104,13 @@ class Evaluator(object):
         ws = sharding.world()[1]
         lo, hi, items_local = self._shard(items_tab)
         sig_u = sig_i = None
-        if kind != ops.SCORE_NORMAL:
+        if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH) and items_local.shape[1] == users_tab.shape[1]:
+            # sigmoid(e_i . w), sigmoid(e_u . w_user) (model.py:141-142,:199-201) in one launch
+            sig_i, sig_u = ops.branch_sigmoid2(items_local, w, None, users_tab, wu, user_ids)
+        elif kind != ops.SCORE_NORMAL:
             sig_i = ops.branch_sigmoid(items_local, w)              # sigmoid(e_i . w)      model.py:141-142,:199-201
-        if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH):
-            sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199,:201
+            if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH):
+                sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199,:201
         U = self.n_queries
         ops.set_eval_filter(self.filter)                          # (process-wide switch, read when the launches are issued)
         if U <= self.max_queries_per_pass:

@@ -175,6 +175,17 @@ def branch_sigmoid(rows, w, idx=None):
     return out
 
 
+def branch_sigmoid2(rows_a, w_a, idx_a, rows_b, w_b, idx_b):
+    """(sigmoid(rows_a[idx_a] . w_a), sigmoid(rows_b[idx_b] . w_b)) in one launch."""
+    n_a = rows_a.shape[0] if idx_a is None else idx_a.numel()
+    n_b = rows_b.shape[0] if idx_b is None else idx_b.numel()
+    out_a = torch.empty(n_a, dtype=_f32, device=rows_a.device)
+    out_b = torch.empty(n_b, dtype=_f32, device=rows_b.device)
+    check(_lib.lib().macr_branch_sigmoid2(rows_a.shape[1], _ptr(rows_a, _f32), _ptr(idx_a, _i32, True), n_a, _ptr(w_a.reshape(-1), _f32), _ptr(out_a),
+                                          _ptr(rows_b, _f32), _ptr(idx_b, _i32, True), n_b, _ptr(w_b.reshape(-1), _f32), _ptr(out_b), _stream()))
+    return out_a, out_b
+
+
 def score_topk_splits(U, n_local, d):
     return _lib.lib().macr_score_topk_splits(U, n_local, d)
 
