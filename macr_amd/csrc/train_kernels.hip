@@ -1204,8 +1204,9 @@ static inline int bxb_rows(int B) {
 #ifdef MACR_BXB_ROWS
     return MACR_BXB_ROWS;
 #endif
-    if (B >= 8192) return 4;
-    if (B >= 4096) return 2;
+    static const int forced = getenv("MACR_BXB_ROWS") ? atoi(getenv("MACR_BXB_ROWS")) : 0;     // A/B switch: 1, 2 or 4
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    if (B >= 4096) return 4;            // (measured, same box: 34.5 against 35.8 us per step at B = 4096 with 2; 8 rows at B = 8192: 79 against 76)
     return 1;
 }
 
