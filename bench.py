@@ -476,6 +476,8 @@ def main():
                     one_model()
                 ret = run_eval()
                 torch.cuda.synchronize()
+                if os.environ.get("MACR_BENCH_DEBUG"):
+                    print("settle", r_, ev.last_eval_info(), "skip", ev._seed_skip, "backoff", ev._seed_backoff, file=sys.stderr)
             # Timed evaluations: as in a training run, the tables MOVE between two evaluations (20 untimed training steps
             # here), and an evaluation seeds its thresholds with the ids the previous one returned (Evaluator.rank_local).
             ev_elapsed, ev_modes = 0.0, []
