@@ -1306,6 +1306,44 @@ def test_bf16_listed_scores_stay_within_the_margin(ops, case, d):
             assert (err <= margin[:, None]).all(), "kind %d case %s d=%d c=%g: error reaches %.3f of the margin" % (kind, case, d, c, worst)
 
 
+@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("kind", ALL_KINDS)
+def test_every_score_kind_ranks_bit_exact_under_both_filters(ops, kind, d, eval_filter):
+    """Every test-time tensor of the reference (model.py:45, :141-142, :199-201) through the fused ranking -- sampled,
+    seeded with the previous call's candidates, and as the first round alone -- against the oracle, bit for bit; branch
+    sigmoids from 1 down to 1e-12 (sig_u down to 1e-35, below the kernels' guard for 1 / sig_u, for
+    DIRECT_MINUS_BOTH), c of either sign.  Under the bf16 filter the
+    listing pass carries the epilogue of each kind in its operand copies (k_score_stream_c)."""
+    rs = np.random.RandomState(4000 + 17 * kind + d)
+    U, N, K = 600, 5000, 20
+    P = (rs.standard_normal((U, d)) * 0.4).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.4).astype(np.float32)
+    sig_u = (1.0 / (1.0 + np.exp(-rs.standard_normal(U) * 2.0))).astype(np.float32)
+    sig_i = (1.0 / (1.0 + np.exp(-rs.standard_normal(N) * 2.0))).astype(np.float32)
+    # (products of two tiny sigmoids would be denormal scores, which CPU and GPU arithmetic need not treat alike: the user
+    # factor goes below the kernels' 1e-30 guard only where it multiplies c * sig_i, not the whole score)
+    # (a user factor that scales the WHOLE score below the margin's absolute term makes every item a candidate: the block
+    # is then listed again and, in the end, ranked by the exact kernel -- right, but not what this test is about)
+    sig_u[:5] = [1.0, 1e-3, 1e-12, 1e-31, 1e-35] if kind == oracle.SCORE_DIRECT_MINUS_BOTH else [1.0, 1e-2, 0.03, 0.1, 0.5]
+    sig_i[:5] = [1.0, 1e-4, 1e-8, 1e-12, 0.25]
+    mask = random_mask(rs, U, N, 30, heavy=(7,))
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    for c in ((0.0,) if kind == oracle.SCORE_NORMAL else (40.0, -2.5)):
+        wv, wi, _ = oracle.score_topk(kind, P, Q, K, sig_u, sig_i, c, oracle.csr_from_lists(mask))
+        seeds = torch.full((U, ops.SEED_WIDTH), -1, dtype=torch.int32, device="cuda")
+        stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+        for mode in ("sampled", "seeded", "first round"):
+            v, ix = ops.score_topk(kind, dev(P), None, dev(Q), K, dev(sig_u), dev(sig_i), c, mcsr,
+                                   seed=None if mode == "sampled" else seeds, seed_out=seeds, stats=stats,
+                                   first_round=mode == "first round")
+            st = stats.cpu().numpy().tolist()
+            assert st[1] == 0, (mode, c, st)                    # the exact fallback kernel is not what ranks here
+            if mode == "first round" and st[0] != 0:
+                continue                                       # (it says so itself: the complete call is the answer then)
+            assert np.array_equal(ix[0].cpu().numpy(), wi), (mode, c)
+            assert np.array_equal(v[0].cpu().numpy().view(np.uint32), wv.view(np.uint32)), (mode, c)
+
+
 def test_bf16_filter_margin_constant_covers_its_stated_bound():
     """filter_rel(d) >= 3.2 * 2^-16 + 6 d * 2^-24 for every supported d (round 3 shipped 1e-4 < 1.39e-4 at d = 256); the
     header's prose quotes the same numbers."""
