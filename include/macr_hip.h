@@ -393,8 +393,21 @@ int macr_score_topk(int score_kind, int U, int n_local, int d,
  * repair round nor the exact fallback kernel is launched -- in the common case those five launches find nothing to do.
  * stats (required; device memory or device-visible host memory) receives {query blocks whose candidate lists overflowed
  * or whose seeds were stale, 0}.  stats[0] == 0: out_val / out_idx / seed_out are exactly what macr_score_topk returns.
- * Otherwise they are not the ranking and the caller runs macr_score_topk (without seed_idx) on the same inputs. */
+ * Otherwise they are not the ranking yet: macr_score_topk_repair_round finishes it (or macr_score_topk starts over). */
 int macr_score_topk_first_round(int score_kind, int U, int n_local, int d,
+                    const float *users_tab, const int32_t *user_ids, const float *items,
+                    const float *sig_u, const float *sig_i, float c, const float *c_dev,
+                    const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
+                    int item_offset, int K, int n_splits, const int32_t *seed_idx, int32_t *seed_out,
+                    float *out_val, int32_t *out_idx, int32_t *stats,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ... and the REST of macr_score_topk for the rare call whose first round did not stand: the same arguments (seed_idx as
+ * in the first-round call: it decides whether the re-listed query blocks are sampled first), the workspace exactly as
+ * macr_score_topk_first_round left it and the same out_val / out_idx / seed_out buffers -- the repair round re-lists the
+ * stats[0] query blocks and overwrites their rows; the exact fallback kernel follows if a list overflows again.
+ * first_round + repair_round launch what macr_score_topk launches.  stats as macr_score_topk writes it. */
+int macr_score_topk_repair_round(int score_kind, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
                     const float *sig_u, const float *sig_i, float c, const float *c_dev,
                     const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,

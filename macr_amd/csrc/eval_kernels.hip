@@ -3494,9 +3494,10 @@ static void launch_k_tau(int tau_regs, int blocks, hipStream_t st, int U, int sl
 
 static inline bool score_kind_valid(int k) { return k >= MACR_SCORE_NORMAL && k <= MACR_SCORE_DIRECT_MINUS_BOTH; }
 
-// first_only (macr_score_topk_first_round): the first round alone -- no repair round, no fallback kernel; stats tell
-// whether its result stands.
-static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, int d, const float *users_tab,
+// mode 1 (macr_score_topk_first_round): the first round alone -- no repair round, no fallback kernel; stats tell whether
+// its result stands.  mode 2 (macr_score_topk_repair_round): what the complete call launches after the first round, on the
+// workspace a first-round call with the same arguments left behind.  mode 0: both.
+static int score_topk_impl(int mode, int score_kind, int U, int n_local, int d, const float *users_tab,
                            const int32_t *user_ids, const float *items, const float *sig_u,
                            const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
                            const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, const int32_t *seed_idx,
@@ -3512,6 +3513,7 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
     MACR_REQUIRE((!score_uses_sig_i(score_kind) || sig_i) && (!score_uses_sig_u(score_kind) || sig_u), MACR_E_INVALID,
                  "score_topk: score_kind %d needs sig_i%s", score_kind, score_uses_sig_u(score_kind) ? " and sig_u" : "");
     MACR_REQUIRE((mask_ptr == nullptr) == (mask_idx == nullptr) || mask_ptr, MACR_E_INVALID, "score_topk: mask_idx without mask_ptr");
+    const bool first_only = mode == 1, repair_only = mode == 2;
     if (n_splits <= 0) n_splits = macr_score_topk_splits(U, n_local, d);
     const int ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
     hipStream_t st = as_stream(stream);
@@ -3527,7 +3529,7 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
     const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
     // (a shard small enough to list everything has nothing to filter)
     const bool filter_bf16 = !list_all && eval_filter_bf16();
-    {
+    if (!repair_only) {
         const size_t n_zero = ws.header_bytes / 4;
         const size_t n_tau = (reinterpret_cast<char *>(ws.maxima) - reinterpret_cast<char *>(ws.tau)) / 4;
         const size_t n_max = list_all ? 0 : ws.maxima_bytes / 4;
@@ -3541,11 +3543,18 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
     const uint32_t *mask_bits = mask_bits_in;
     MACR_REQUIRE(!mask_bits_in || mask_ptr, MACR_E_INVALID, "score_topk: mask_bits without the CSR mask it was built from");
     if (mask_ptr && !mask_bits_in) {
-        fill_words(ws.mask_bits, ws.mask_bytes / 4, 0u, st);
-        k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, ws.mask_bits, n_tiles(n_local),
-                                                 sample_log2(n_local));
-        MACR_CHECK_LAUNCH("mask_bits", st);
+        if (!repair_only) {
+            fill_words(ws.mask_bits, ws.mask_bytes / 4, 0u, st);
+            k_mask_bits<<<(U + 3) / 4, 256, 0, st>>>(U, n_local, mask_ptr, mask_idx, item_offset, ws.mask_bits, n_tiles(n_local),
+                                                     sample_log2(n_local));
+            MACR_CHECK_LAUNCH("mask_bits", st);
+        }
         mask_bits = ws.mask_bits;
+    }
+    if (repair_only && (K > MACR_MAX_TOPK_FUSED || list_all)) {
+        // (the wide ranking and a shard that lists everything have no second round: the first call's result is final)
+        if (stats) fill_words(stats, 2, 0u, st);
+        return MACR_OK;
     }
     if (K > MACR_MAX_TOPK_FUSED) {
         // The wide ranking (--Ks up to 128: macr_mf/parse.py:31, utility/parser.py:63 take any list): thresholds at rank ~8K
@@ -3598,6 +3607,10 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
         const uint32_t *zero_word = reinterpret_cast<const uint32_t *>(ws.overflow + 3);
         // k_score_sample_c merges its classes in pairs where that still leaves several times K of them (k_tau ranks half as many)
         const int merge_pairs = geo.slots0 * 16 >= 4 * K ? 1 : 0, per_c = merge_pairs ? 16 : 32;
+        // Round 1 flags overflowing lists per user; the repair round lists the user blocks of those users again with the
+        // threshold their cut lists imply (k_repair_plan); only a second overflow arms the exact fallback kernel.
+        const bool repair = !list_all;
+        if (!repair_only) {                                   // ---- the first round
         if (filter_bf16 && seeded) {
             // the listing pass's operand copies (the epilogue in the operands), |u| per query, max |q| -- and, in the same
             // launch, the seeded thresholds
@@ -3639,9 +3652,6 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
             launch_tau(false);
             MACR_CHECK_LAUNCH("tau", st);
         }
-        // Round 1 flags overflowing lists per user; the repair round lists the user blocks of those users again with the
-        // threshold their cut lists imply (k_repair_plan); only a second overflow arms the exact fallback kernel.
-        const bool repair = !list_all;
         if (filter_bf16) {
             // bf16-filtered first round (k_score_stream_b): listing on the bf16 matrix cores, then the selection re-scores
             // its best candidates in fp32
@@ -3677,6 +3687,9 @@ static int score_topk_impl(bool first_only, int score_kind, int U, int n_local, 
                                                                  ws.ub_map, ws.blk_flag, ws.overflow + 1, ws.overflow + 2,
                                                                  first_only ? stats : nullptr);
             MACR_CHECK_LAUNCH("repair_plan", st);
+        }
+        }                                                     // ---- (first round)
+        if (repair) {
             if (first_only) {
                 // (stats[0] = query blocks whose lists overflowed or whose seeds were stale: their rows of out_* are not the ranking)
             } else if (filter_bf16) {
@@ -3754,7 +3767,7 @@ extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const 
                                const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, const int32_t *seed_idx,
                                int32_t *seed_out, float *out_val, int32_t *out_idx, int32_t *stats, void *workspace,
                                size_t workspace_bytes, void *stream) {
-    return score_topk_impl(false, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
+    return score_topk_impl(0, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
                            mask_bits_in, item_offset, K, n_splits, seed_idx, seed_out, out_val, out_idx, stats, workspace,
                            workspace_bytes, stream);
 }
@@ -3767,7 +3780,19 @@ extern "C" int macr_score_topk_first_round(int score_kind, int U, int n_local, i
                                            int32_t *out_idx, int32_t *stats, void *workspace, size_t workspace_bytes,
                                            void *stream) {
     MACR_REQUIRE(stats, MACR_E_INVALID, "score_topk_first_round: stats is null (it says whether the result stands)");
-    return score_topk_impl(true, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
+    return score_topk_impl(1, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
+                           mask_bits_in, item_offset, K, n_splits, seed_idx, seed_out, out_val, out_idx, stats, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" int macr_score_topk_repair_round(int score_kind, int U, int n_local, int d, const float *users_tab,
+                                            const int32_t *user_ids, const float *items, const float *sig_u,
+                                            const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr,
+                                            const int32_t *mask_idx, const uint32_t *mask_bits_in, int item_offset, int K,
+                                            int n_splits, const int32_t *seed_idx, int32_t *seed_out, float *out_val,
+                                            int32_t *out_idx, int32_t *stats, void *workspace, size_t workspace_bytes,
+                                            void *stream) {
+    return score_topk_impl(2, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
                            mask_bits_in, item_offset, K, n_splits, seed_idx, seed_out, out_val, out_idx, stats, workspace,
                            workspace_bytes, stream);
 }

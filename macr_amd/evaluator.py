@@ -40,11 +40,14 @@ class Evaluator(object):
         ops.eval_filter_code(self.filter)         # a typo in the environment is refused here, by name
         # One GPU, graph replays: an evaluation launches the FIRST ROUND of the ranking only and writes its means and the
         # ranking's stats straight into pinned host memory; the host, which waits for the means anyway, sees whether a
-        # candidate list overflowed or the seeds were stale and, in that rare case, runs the complete sequence (repair
-        # round, fallback) from a sampled start.  Saves the launches that find nothing to do (~25 us of a 0.45 ms
-        # evaluation on the Gowalla shape) and both result copies.  MACR_EVAL_OPTIMISTIC=0: the complete sequence always.
+        # candidate list overflowed or the seeds were stale and, in that rare case, replays the REST of the ranking (repair
+        # round, fallback: macr_score_topk_repair_round) on the same workspace and outputs.  Saves the launches that find
+        # nothing to do (~25 us of a 0.45 ms evaluation on the Gowalla shape) and both result copies.
+        # MACR_EVAL_OPTIMISTIC=0: the complete sequence always.
         self.optimistic = os.environ.get("MACR_EVAL_OPTIMISTIC", "1") != "0"
-        self._first_round_now = False
+        self._topk_mode = None                    # None: the complete call; "first" / "repair": its two halves
+        self._repair_bufs = None
+        self._last_entry = None
         self._host_out = {}
         self.fast_stats = {"fast": 0, "redone": 0}
         self._graphs = {}
@@ -128,10 +131,11 @@ class Evaluator(object):
                 seed = seeds[(K, lo, hi)] = torch.full((U, ops.SEED_WIDTH), -1, dtype=torch.int32, device=self.device)
             # the ranking leaves its best SEED_WIDTH candidates per query in `seed` (in place): the next ranking's seeds
             mask = self._mask_local if self._local_own is not None else self.mask
-            first = self._first_round_now
+            mode = self._topk_mode
             vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, mask, lo,
                                        seed=seed if seeded else None, seed_out=seed,
-                                       stats=self._stats_first if first else self._stats, first_round=first)
+                                       stats=self._stats_first if mode else self._stats, first_round=mode == "first",
+                                       repair_of=self._repair_bufs if mode == "repair" else None)
         else:
             # the ranking workspace (candidate lists, mask bitmap) grows with the number of queries: rank them in
             # chunks; every query is independent of the chunking
@@ -282,34 +286,44 @@ class Evaluator(object):
             self._stats_readback(seeded)
 
     def _means_optimistic(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c):
-        """First round only, results in pinned host memory, the complete sequence when the first round says so."""
+        """First round only, results in pinned host memory; the rest of the ranking when the first round says so."""
         if self._stats_evt is not None:           # (a stats copy of the complete path still in flight: not needed any more)
             self._stats_evt = None
         seeded = (self.use_seeds and self._seed_skip == 0 and self._has_seeds(max(Ks), items_tab.shape[0]))
         if self.use_seeds and self._seed_skip > 0:
             self._seed_skip -= 1
         self._seeded_now = seeded
-        self._first_round_now = True
+        self._topk_mode = "first"
         try:
-            out = self._means_launch(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, 1, seeded, first=True)
+            out = self._means_launch(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, 1, seeded, mode="first")
+            first_entry = self._last_entry
         finally:
-            self._first_round_now = False
+            self._topk_mode = None
         torch.cuda.current_stream().synchronize()
         self._last_seeded = False                 # (nothing for _seed_feedback to read later)
-        self._last_info = {"seeded": bool(seeded), "query_blocks_relisted": int(self._stats_first[0]), "exact_fallback": 0,
-                           "redone": int(self._stats_first[0]) != 0}
-        if int(self._stats_first[0]) == 0 and int(self._stats_first[1]) == 0:
+        relisted = int(self._stats_first[0])
+        self._last_info = {"seeded": bool(seeded), "query_blocks_relisted": relisted, "exact_fallback": 0, "redone": relisted != 0}
+        if relisted == 0:
             self.fast_stats["fast"] += 1
             if seeded:
                 self._seed_backoff = 1
             return out.clone()
-        # a list overflowed or seeds were stale: the complete sequence, thresholds from a sampling pass
+        # a list overflowed or seeds were stale: the repair round (and, behind it, the exact fallback) on the first round's
+        # workspace and outputs -- what the complete call would have launched
         self.fast_stats["redone"] += 1
         if seeded:
             self._seed_skip = self._seed_backoff
             self._seed_backoff = min(16, 2 * self._seed_backoff)
-        self._seeded_now = False
-        return self._means_launch(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, 1, False)
+        if first_entry is None or len(first_entry) < 4:      # (no graph of the first round: it ran as the complete call already)
+            return out.clone()
+        self._topk_mode, self._repair_bufs = "repair", first_entry[3]
+        try:
+            out = self._means_launch(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, 1, seeded, mode="repair")
+        finally:
+            self._topk_mode, self._repair_bufs = None, None
+        torch.cuda.current_stream().synchronize()
+        self._last_info["exact_fallback"] = int(self._stats_first[1])
+        return out.clone()
 
     def last_eval_info(self):
         """What the last evaluation did: {"seeded": its thresholds came from the previous ranking's candidates,
@@ -320,17 +334,18 @@ class Evaluator(object):
         st = self._stats.tolist()
         return {"seeded": bool(self._last_seeded), "query_blocks_relisted": st[0], "exact_fallback": st[1], "redone": False}
 
-    def _means_launch(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, world, seeded, first=False):
+    def _means_launch(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, world, seeded, mode=None):
+        self._last_entry = None
         if not self.use_graph:
             return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
         host_out = None
-        if first:
+        if mode:
             hk = (flavour, Ks)
             if hk not in self._host_out:
                 shape = (4, len(Ks)) if flavour == "mf" else (5 * max(Ks),)
                 self._host_out[hk] = torch.zeros(shape, dtype=torch.float64).pin_memory()
             host_out = self._host_out[hk]
-        key = (flavour, first, self.filter, kind, seeded, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
+        key = (flavour, mode, self.filter, kind, seeded, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
                Ks, None if w is None else w.data_ptr(), None if wu is None else wu.data_ptr(),
                torch.cuda.current_stream().cuda_stream, world)
         entry = self._graphs.get(key)
@@ -340,8 +355,9 @@ class Evaluator(object):
             if self._graph_misses > 12:
                 self.use_graph = False
                 self._graphs.clear()
-                self._first_round_now = False     # (the complete sequence: its result needs no check)
-                self._stats_first.zero_()
+                if mode == "first":
+                    self._topk_mode = None        # (the complete sequence: its result needs no check)
+                    self._stats_first.zero_()
                 return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
             self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)     # warm-up: allocations, caches, attributes
             torch.cuda.synchronize()
@@ -352,6 +368,7 @@ class Evaluator(object):
                     vals, idx = self.rank_local(kind, users_tab, user_ids, items_tab, K, w, wu, c)
                     out = self._finish(flavour, vals, idx, Ks, out=host_out)
                 stages = (g, None, None, None)
+                first_bufs = (vals, idx)
             else:
                 # several ranks: the collective stays outside -- one graph up to this shard's merged lists, the
                 # all-gather (RCCL), one graph from the gathered lists to the means
@@ -364,6 +381,7 @@ class Evaluator(object):
                 with torch.cuda.graph(gb):
                     out = self._finish(flavour, gv, gi, Ks)
                 stages = (ga, (lv, li), (gv, gi), gb)
+                first_bufs = None
             # the graphs bake in the addresses of everything they touched: keep the inputs and the cached scratch
             # (ranking workspace, mask bitmaps) alive for as long as they exist, whatever the caches do later
             keep = [users_tab, user_ids, items_tab, w, wu, c, ops._topk_ws_cache.get(items_tab.device)]
@@ -371,7 +389,8 @@ class Evaluator(object):
             local = [] if self._local_own is None else [self._mask_local] + list(self._mask_local.__dict__.get("_row_ranges", {}).values())
             for csr in [self.mask] + list(self.mask.__dict__.get("_row_ranges", {}).values()) + local:
                 keep.extend(csr.__dict__.get("_mask_bits", {}).values())
-            entry = self._graphs[key] = (stages, out, keep)
+            entry = self._graphs[key] = (stages, out, keep, first_bufs)
+        self._last_entry = entry
         (ga, local, gathered, gb), out = entry[0], entry[1]
         ga.replay()
         if gb is not None:

@@ -264,7 +264,7 @@ def _c_args(c):
 
 
 def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.0, mask=None,
-               item_offset=0, n_splits=0, seed=None, seed_out=None, stats=None, first_round=False):
+               item_offset=0, n_splits=0, seed=None, seed_out=None, stats=None, first_round=False, repair_of=None):
     """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K).
     c: python float, or a 1-element fp32 device tensor (read at run time: graph replays follow its value).
     seed: optional (U, SEED_WIDTH) int32 device tensor of global item ids per query -- what seed_out received last time:
@@ -273,19 +273,27 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     stats: optional int32[2] device (or pinned host) tensor <- (query blocks listed twice because a threshold was too
     loose, 1 if the exact fallback kernel ran).
     first_round: macr_score_topk_first_round -- the first round alone, without the launches of the repair round and the
-    fallback; stats (required) then says whether the result stands: stats[0] == 0, else run the complete call."""
+    fallback; stats (required) then says whether the result stands: stats[0] == 0, else finish it with
+    repair_of=(vals, idx) -- macr_score_topk_repair_round on the same arguments and the first-round call's outputs (or run the
+    complete call)."""
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
     n_local, d = items.shape
     if n_splits <= 0:
         n_splits = score_topk_splits(U, n_local, d)
-    vals = torch.empty((n_splits, U, K), dtype=_f32, device=items.device)
-    idx = torch.empty((n_splits, U, K), dtype=_i32, device=items.device)
+    if repair_of is not None:
+        vals, idx = repair_of
+        assert vals.shape == (n_splits, U, K) and idx.shape == (n_splits, U, K)
+    else:
+        vals = torch.empty((n_splits, U, K), dtype=_f32, device=items.device)
+        idx = torch.empty((n_splits, U, K), dtype=_i32, device=items.device)
     mp = _ptr(mask.ptr, _i32) if mask is not None else None
     mi = _ptr(mask.idx, _i32) if mask is not None else None
     mb = _ptr(mask.mask_bits(U, n_local, item_offset)) if mask is not None else None
     ws = _topk_workspace(U, n_local, d, items.device)
     cv, cp = _c_args(c)
     fn = _lib.lib().macr_score_topk_first_round if first_round else _lib.lib().macr_score_topk
+    if repair_of is not None:
+        fn = _lib.lib().macr_score_topk_repair_round
     check(fn(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
              _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
              cv, cp, mp, mi, mb, item_offset, K, n_splits, _ptr(seed, _i32, True), _ptr(seed_out, _i32, True), _ptr(vals), _ptr(idx),

@@ -868,6 +868,13 @@ def test_first_round_alone_says_whether_it_stands(ops, eval_filter):
         got = stats.cpu().numpy().tolist()
         if name == "stale":
             assert got[0] > 0 and got[1] == 0, (name, got)
+            # ... and macr_score_topk_repair_round finishes that very call: same arguments, workspace and outputs
+            v2, ix2 = ops.score_topk(ops.SCORE_RUBI_BOTH, dev(P), None, dev(Q), K, sig_u, sig_i, 30.0, mcsr, seed=seed,
+                                     seed_out=seeds_out, stats=stats, repair_of=(v, ix))
+            torch.cuda.synchronize()
+            assert stats.cpu().numpy().tolist() == [got[0], 0], name
+            assert v2 is v and np.array_equal(ix[0].cpu().numpy(), wi) and np.array_equal(v[0].cpu().numpy().view(np.uint32), wv.view(np.uint32))
+            assert torch.equal(seeds_out[:, :K], ix[0]), name
             continue
         assert got == [0, 0], (name, got)
         assert np.array_equal(ix[0].cpu().numpy(), wi), name
