@@ -1709,6 +1709,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
         if (x == 1) break;
     }
     auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T) * kStep; };
+    auto visit_after = [&](int tile) { const int n = (tile >> sample_log2) + S; return (n >= T ? n - T : n) << sample_log2; };   // visit(i + 1) from visit(i)
     // this thread's units of a tile: (row, unit in row); the last round wraps (everybody loads, the owners store)
     int urow_[LDU], ucol_[LDU];
 #pragma unroll
@@ -1784,8 +1785,15 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
         const uint32_t tmh = tmask >> (4 * h);
         const __bf16 *ua = reinterpret_cast<const __bf16 *>(s_t + buf * TU) + (size_t)col * (8 * RU) + 8 * h;
         f32x16 acc;
+        // (poisoning costs 16 selects and an accumulator that starts in registers: only where some lane of the wave masks something
+        // in this tile -- about every second visit on the Gowalla shape; 52 -> ~47 us for the pass)
+        if (__builtin_amdgcn_ballot_w64(tmh != 0u)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = ((tmh >> ((r & 3) + 8 * (r >> 2))) & 1u) ? kNone : 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = ((tmh >> ((r & 3) + 8 * (r >> 2))) & 1u) ? kNone : 0.f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
         constexpr int CH = NS < 4 ? NS : 4;
         bf16x8 ae;
         if (KIND != MACR_SCORE_NORMAL)
@@ -1818,7 +1826,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
     __syncthreads();
     while (vi < i1) {
         {
-            const int tn = vi + 1 < i1 ? visit(vi + 1) : t;
+            const int tn = vi + 1 < i1 ? visit_after(t) : t;
             load_tile(tn);
             __builtin_amdgcn_sched_barrier(0);
             one_visit(std::integral_constant<int, 0>(), t, tm_cur);
@@ -1828,7 +1836,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
         }
         if (vi >= i1) break;
         {
-            const int tn = vi + 1 < i1 ? visit(vi + 1) : t;
+            const int tn = vi + 1 < i1 ? visit_after(t) : t;
             load_tile(tn);
             __builtin_amdgcn_sched_barrier(0);
             one_visit(std::integral_constant<int, 1>(), t, tm_cur);
