@@ -1610,6 +1610,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
         }
     };
     // block-uniform: give up on stale seeds / follow the sibling blocks that did (k_score_stream)
+    int polled = 0;
     auto stale_check = [&](int done) -> bool {
         if (!blk_flag) return false;
         const bool check = done == 2 || done == kCheckTiles || done == 4 * kCheckTiles;
@@ -1622,7 +1623,10 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
             const float usable = 32.f * (float)(done * kTileItems) * (float)(kSelRegs * 64) / (float)n_local;
             mine = (float)a > usable + 64.f;
         } else if (tid == 0) {
-            mine = __hip_atomic_load(blk_flag + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            // the siblings' mark: what the PREVIOUS poll fetched (the load issued now has eight visits to arrive: waiting
+            // for it here was ~0.7 us per poll, 19 polls per block on the Gowalla shape)
+            mine = polled != 0;
+            polled = __hip_atomic_load(blk_flag + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const bool stop = __syncthreads_or(mine) != 0;
         if (stop && tid == 0) __hip_atomic_store(blk_flag + ub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
