@@ -607,6 +607,8 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
         if (x == 1) break;
     }
     auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T) * kStep; };
+    // visit(i + 1) from visit(i): no 64-bit modulo per visit (kStep is a power of two, a visit a multiple of it)
+    auto visit_after = [&](int tile) { const int n = tile / kStep + S; return (n >= T ? n - T : n) * kStep; };
     const long long W = (long long)n_ub * T;
     const long long w_end = W * (b + 1) / G;
     for (long long w = W * b / G; w < w_end;) {
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream(
 #endif
     while (vi < i1) {
         const bool has_next = vi + 1 < i1;
-        const int tn = has_next ? visit(vi + 1) : t;
+        const int tn = has_next ? visit_after(t) : t;
         const uint32_t tm_this = tm_cur;
         (void)tm_this;
 #ifndef MACR_ABL_S_NOSTAGE
@@ -2140,6 +2142,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_b(
         if (x == 1) break;
     }
     auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T) * kStep; };
+    auto visit_after = [&](int tile) { const int n = (tile >> sample_log2) + S; return (n >= T ? n - T : n) << sample_log2; };
     const long long W = (long long)n_ub * T;
     const long long w_end = W * (b + 1) / G;
     for (long long w = W * b / G; w < w_end;) {
@@ -2206,7 +2209,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_b(
     const float kNone = __builtin_nanf("");
     while (vi < i1) {
         const bool has_next = vi + 1 < i1;
-        const int tn = has_next ? visit(vi + 1) : t;
+        const int tn = has_next ? visit_after(t) : t;
         if (has_next) load_tile(tn);
 
         uint32_t tmask = tm_cur;
