@@ -3544,10 +3544,17 @@ static int score_topk_impl(int mode, int score_kind, int U, int n_local, int d, 
     const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
     // (a shard small enough to list everything has nothing to filter)
     const bool filter_bf16 = !list_all && eval_filter_bf16();
+    // class maxima start as NaN (= no unmasked item seen).  Under the bf16 filter the sampling pass may keep 16 per split and
+    // query instead of 32 (merge_pairs below), and a seeded first round has no sampling pass at all: its repair round, if one
+    // follows (macr_score_topk_repair_round), fills them itself.
+    const bool bf16_merge = filter_bf16 && geo.slots0 * 16 >= 4 * K;
+    const size_t n_max_words = list_all ? 0 : filter_bf16 ? (size_t)geo.slots0 * U * (bf16_merge ? 16 : 32) : ws.maxima_bytes / 4;
+    const bool lazy_maxima = first_only && filter_bf16 && seed_idx != nullptr;
+    if (repair_only && filter_bf16 && seed_idx != nullptr) fill_words(reinterpret_cast<uint32_t *>(ws.maxima), n_max_words, 0xffffffffu, st);
     if (!repair_only) {
         const size_t n_zero = ws.header_bytes / 4;
         const size_t n_tau = (reinterpret_cast<char *>(ws.maxima) - reinterpret_cast<char *>(ws.tau)) / 4;
-        const size_t n_max = list_all ? 0 : ws.maxima_bytes / 4;
+        const size_t n_max = lazy_maxima ? 0 : n_max_words;
         const size_t total = n_zero + n_tau + n_max;
         const unsigned grid = (unsigned)((total + 256 * 8 - 1) / (256 * 8) < 2048 ? (total + 256 * 8 - 1) / (256 * 8) : 2048);
         k_topk_ws_init<<<grid ? grid : 1, 256, 0, st>>>(static_cast<uint32_t *>(workspace), n_zero, n_tau, 0xff800000u,
