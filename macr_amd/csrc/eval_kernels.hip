@@ -1342,7 +1342,7 @@ struct StreamCfgC {
     static constexpr int TU = kTileItems * RU;                // ... per tile
     static constexpr int NS = D / 16;
     static constexpr int LDU = (TU + 511) / 512, REM = TU - 512 * (LDU - 1);      // copy rounds of 512 threads; units of the last one
-    static constexpr size_t smem = (size_t)2 * TU * 16 + kUsersPerBlock * 4;
+    static constexpr size_t smem = (size_t)2 * TU * 16 + kUsersPerBlock * 4 + 16;
 };
 static inline size_t items_c_bytes(int n_local, int d) { return (size_t)n_tiles(n_local) * kTileItems * (2 * d / 8 + 1) * 16; }
 
@@ -1471,6 +1471,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
     extern __shared__ __align__(16) unsigned char smem[];
     uint4 *s_t = reinterpret_cast<uint4 *>(smem);                                      // [2][TU]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)2 * TU * 16);       // [256]
+    int *s_stop = reinterpret_cast<int *>(s_cnt + kUsersPerBlock);                     // [1]  somebody wants the block to stop listing
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
     const int T = (n_local + kTileItems - 1) / kTileItems;
@@ -1511,6 +1512,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
     const int ub = REPAIR ? ub_map[ubv] : ubv;
     __syncthreads();                                          // (the previous segment's readers are done with s_t and s_cnt)
     for (int k = tid; k < kUsersPerBlock; k += THREADS) s_cnt[k] = 0u;
+    if (tid == 0) *s_stop = 0;
     const int uslot = wid * 32 + col, q = ub * kUsersPerBlock + uslot;
     const bool q_ok = q < U;
     bf16x8 bhi[NS], blo[NS];
@@ -1611,9 +1613,11 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
             }
         }
     };
-    // block-uniform: give up on stale seeds / follow the sibling blocks that did (k_score_stream)
+    // Give up on stale seeds / follow the sibling blocks that did (k_score_stream).  A wave that wants the block to stop
+    // raises s_stop; everybody reads it behind the visit's own barrier (a __syncthreads_or here cost three more barriers
+    // per poll).  Returns whether this visit looks at the flag at all (block-uniform).
     int polled = 0;
-    auto stale_check = [&](int done) -> bool {
+    auto stale_mark = [&](int done) -> bool {
         if (!blk_flag) return false;
         const bool check = done == 2 || done == kCheckTiles || done == 4 * kCheckTiles;
         if (!(check || (done & 7) == 0)) return false;
@@ -1630,7 +1634,12 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
             mine = polled != 0;
             polled = __hip_atomic_load(blk_flag + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const bool stop = __syncthreads_or(mine) != 0;
+        if (mine) *s_stop = 1;
+        return true;
+    };
+    auto stale_read = [&](bool looked) -> bool {              // behind the barrier
+        if (!looked) return false;
+        const bool stop = *s_stop != 0;
         if (stop && tid == 0) __hip_atomic_store(blk_flag + ub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return stop;
     };
@@ -1646,11 +1655,11 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
             load_tile(tn);
             __builtin_amdgcn_sched_barrier(0);
             one_visit(std::integral_constant<int, 0>(), t, tm_cur);
-            const bool stop = stale_check(vi - i0 + 1);
+            const bool looked = stale_mark(vi - i0 + 1);
             store_tile(std::integral_constant<int, 1>());
             __syncthreads();
             tm_cur = tm_next; t = tn; ++vi;
-            if (stop) break;
+            if (stale_read(looked)) break;
         }
         if (vi >= i1) break;
         {
@@ -1658,11 +1667,11 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
             load_tile(tn);
             __builtin_amdgcn_sched_barrier(0);
             one_visit(std::integral_constant<int, 1>(), t, tm_cur);
-            const bool stop = stale_check(vi - i0 + 1);
+            const bool looked = stale_mark(vi - i0 + 1);
             store_tile(std::integral_constant<int, 0>());
             __syncthreads();
             tm_cur = tm_next; t = tn; ++vi;
-            if (stop) break;
+            if (stale_read(looked)) break;
         }
     }
     for (int k = tid; k < kUsersPerBlock; k += THREADS) {
