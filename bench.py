@@ -480,7 +480,7 @@ def main():
                     print("settle", r_, ev.last_eval_info(), "skip", ev._seed_skip, "backoff", ev._seed_backoff, file=sys.stderr)
             # Timed evaluations: as in a training run, the tables MOVE between two evaluations (20 untimed training steps
             # here), and an evaluation seeds its thresholds with the ids the previous one returned (Evaluator.rank_local).
-            ev_elapsed, ev_modes = 0.0, []
+            ev_elapsed, ev_modes, ev_times = 0.0, [], []
             for r_ in range(args.eval_reps):
                 if args.eval_train_steps > 0:
                     run_steps(args.eval_train_steps, args.eval_train_steps * r_)
@@ -489,8 +489,11 @@ def main():
                 t0 = time.perf_counter()
                 ret = run_eval()
                 torch.cuda.synchronize(); barrier()
-                ev_elapsed += sharding.max_over_ranks(time.perf_counter() - t0, dev)
+                ev_times.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))
+                ev_elapsed += ev_times[-1]
                 ev_modes.append(ev.last_eval_info())
+            if os.environ.get("MACR_BENCH_DEBUG"):
+                print("eval times (us)", filt, [int(1e6 * t_) for t_ in ev_times], file=sys.stderr)
             eval_users_per_s = len(users) * args.eval_reps / ev_elapsed
             # the same evaluation without seeds (what a first evaluation costs: sampling pass + k_tau instead of k_tau_seed),
             # also a graph replay
@@ -546,7 +549,7 @@ def main():
             roofline_eval["seeded"] = seeded_run
 
             return {"ret": ret, "eval_users_per_s": eval_users_per_s, "ev_elapsed": ev_elapsed, "ev_unseeded_ms": ev_unseeded_ms,
-                    "ev_modes": ev_modes, "roofline_eval": roofline_eval}
+                    "ev_modes": ev_modes, "ev_times": ev_times, "roofline_eval": roofline_eval}
 
         # "f32": the (U, N) product on the fp32 matrix cores -- `roofline_eval`, priced against the fp32 MFMA peak as in
         # the earlier rounds.  "bf16": the Evaluator's default, a bf16 candidate filter with fp32 re-scoring (the same
@@ -595,7 +598,11 @@ def main():
     if not args.no_eval:
         def _row(su):
             modes = su["ev_modes"]
+            ts = sorted(su["ev_times"])
             return {"users_per_s": su["eval_users_per_s"], "ms_per_eval": 1e3 * su["ev_elapsed"] / args.eval_reps,
+                    # every timed evaluation is a host round trip (replay, synchronise) behind 2 010 training steps: the mean is
+                    # what users_per_s is computed from, median / min / max show what host hiccups did to it
+                    "ms_per_eval_median": 1e3 * ts[len(ts) // 2], "ms_per_eval_min": 1e3 * ts[0], "ms_per_eval_max": 1e3 * ts[-1],
                     "ms_unseeded": su["ev_unseeded_ms"], "evaluations": len(modes),
                     "seeded": sum(1 for m in modes if m["seeded"]),
                     "repaired": sum(1 for m in modes if m["query_blocks_relisted"] > 0 or m["exact_fallback"]),
