@@ -929,7 +929,8 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {          // round t
 
 // Rows of the item table (shard) and the query users' rows -> bf16 copies; |u| per query user; max |q| over the items
 // (atomicMax on the float's bits: norms are >= 0).  One 8-lane group per 64 columns... one lane converts 8 columns.
-constexpr int kPrepTrips = 8;
+constexpr int kPrepTrips = 4;         // (rows per lane group and block; measured on the Gowalla shape: 8 -> 4: k_bf16_prep 17 -> 13.5 us)
+constexpr int kPrepTripsAlone = 2;    // k_bf16_prep_c by itself: 11 us; beside the seed blocks of k_prep_tau_seed 4 is better (32 vs 35 us)
 template <int D>
 __device__ __forceinline__ void bf16_prep_block(int blk, int U, int n_local, const float *__restrict__ users_tab,
                                                 const int32_t *__restrict__ user_ids, const float *__restrict__ items,
@@ -1358,7 +1359,7 @@ __device__ __forceinline__ bool sig_u_tiny(float su) { return !(su > 1e-30f); }
 // Operand copies for k_score_stream_c: item rows (and the zero rows up to a whole tile) in the RU-unit layout, query rows
 // as in k_bf16_prep (scaled for DIRECT_MINUS_BOTH), |u| per query, max |q| -- norms of the UNscaled rows, which bound the
 // scaled ones.  Row space of a block: [0, n_pad) items, [n_pad, n_pad + U) queries.
-template <int D, int KIND>
+template <int D, int KIND, int TRIPS>
 __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, const float *__restrict__ users_tab,
                                                   const int32_t *__restrict__ user_ids, const float *__restrict__ items,
                                                   const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
@@ -1368,12 +1369,12 @@ __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, c
     __shared__ float s_max[4];
     const int n_pad = ((n_local + kTileItems - 1) / kTileItems) * kTileItems;
     const int sub = threadIdx.x % LPRB, slot = threadIdx.x / LPRB;
-    float4 a[kPrepTrips], b[kPrepTrips];
-    float scale[kPrepTrips], bias[kPrepTrips];
-    long long row[kPrepTrips];
+    float4 a[TRIPS], b[TRIPS];
+    float scale[TRIPS], bias[TRIPS];
+    long long row[TRIPS];
 #pragma unroll
-    for (int t = 0; t < kPrepTrips; ++t) {
-        row[t] = ((long long)blk * kPrepTrips + t) * RPB + slot;
+    for (int t = 0; t < TRIPS; ++t) {
+        row[t] = ((long long)blk * TRIPS + t) * RPB + slot;
         const bool is_item = row[t] < n_local;
         const long long q = row[t] - n_pad;
         const bool is_user = q >= 0 && q < U;
@@ -1391,7 +1392,7 @@ __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, c
     }
     float m = 0.f;
 #pragma unroll
-    for (int t = 0; t < kPrepTrips; ++t) {
+    for (int t = 0; t < TRIPS; ++t) {
         const bool is_item = row[t] < n_local, is_pad = row[t] >= n_local && row[t] < n_pad;
         const long long q = row[t] - n_pad;
         const bool is_user = q >= 0 && q < U;
@@ -1440,8 +1441,8 @@ __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, c
             atomicMax(qmax_bits, __float_as_uint(m));
     }
 }
-static inline unsigned bf16_prep_c_blocks(int U, int n_local, int d) {
-    const size_t rows_per_block = (size_t)kPrepTrips * (256 / (d / 8));
+static inline unsigned bf16_prep_c_blocks(int U, int n_local, int d, int trips) {
+    const size_t rows_per_block = (size_t)trips * (256 / (d / 8));
     return (unsigned)(((size_t)n_tiles(n_local) * kTileItems + U + rows_per_block - 1) / rows_per_block);
 }
 
@@ -1452,8 +1453,8 @@ __global__ __launch_bounds__(256) void k_bf16_prep_c(int U, int n_local, const f
                                                      float c_val, const float *__restrict__ c_dev,
                                                      uint4 *__restrict__ users_c, uint4 *__restrict__ items_c,
                                                      float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
-    bf16_prep_c_block<D, KIND>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_c, items_c,
-                               unorm, qmax_bits);
+    bf16_prep_c_block<D, KIND, kPrepTripsAlone>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_c,
+                                                items_c, unorm, qmax_bits);
 }
 
 template <int D, int KIND, bool REPAIR = false>
@@ -2343,8 +2344,8 @@ __global__ __launch_bounds__(256) void k_prep_tau_seed(int n_prep, int U, int n_
                                                        const uint32_t *__restrict__ mask_bits, int item_offset, int K,
                                                        const int32_t *__restrict__ seed, float *__restrict__ tau) {
     if ((int)blockIdx.x < n_prep)
-        bf16_prep_c_block<D, KIND>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_bf, items_bf,
-                                   unorm, qmax_bits);
+        bf16_prep_c_block<D, KIND, kPrepTrips>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_bf,
+                                               items_bf, unorm, qmax_bits);
     else
         tau_seed_block<D, KIND>(blockIdx.x - n_prep, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_val, c_dev, mask_bits,
                                 item_offset, K, seed, tau);
@@ -3645,13 +3646,13 @@ static int score_topk_impl(int mode, int score_kind, int U, int n_local, int d, 
         if (filter_bf16 && seeded) {
             // the listing pass's operand copies (the epilogue in the operands), |u| per query, max |q| -- and, in the same
             // launch, the seeded thresholds
-            const unsigned n_prep = bf16_prep_c_blocks(U, n_local, D);
+            const unsigned n_prep = bf16_prep_c_blocks(U, n_local, D, kPrepTrips);
             k_prep_tau_seed<D, KIND><<<n_prep + (U + 7) / 8, 256, 0, st>>>((int)n_prep, U, n_local, users_tab, user_ids, items, users_c,
                                                                            ws.items_c, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev, mask_bits,
                                                                            item_offset, K, seed_idx, ws.tau);
             MACR_CHECK_LAUNCH("bf16_prep+tau_seed", st);
         } else if (filter_bf16) {
-            k_bf16_prep_c<D, KIND><<<bf16_prep_c_blocks(U, n_local, D), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
+            k_bf16_prep_c<D, KIND><<<bf16_prep_c_blocks(U, n_local, D, kPrepTripsAlone), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
                                                                                       users_c, ws.items_c, ws.unorm, qmax_bits);
             MACR_CHECK_LAUNCH("bf16_prep_c", st);
         }
@@ -4023,7 +4024,7 @@ extern "C" int macr_test_bf16_scores(int score_kind, int d, int U, int N, const 
     fill_words(qmax_bits, 1, 0u, st);
     dim3 grid((N + 31) / 32, (U + 31) / 32);
     MACR_DISPATCH_DK(d, score_kind, {
-        k_bf16_prep_c<D, KIND><<<bf16_prep_c_blocks(U, N, D), 256, 0, st>>>(U, N, users, nullptr, items, sig_u, sig_i, c, nullptr, users_c, items_c,
+        k_bf16_prep_c<D, KIND><<<bf16_prep_c_blocks(U, N, D, kPrepTripsAlone), 256, 0, st>>>(U, N, users, nullptr, items, sig_u, sig_i, c, nullptr, users_c, items_c,
                                                                             unorm, qmax_bits);
         k_test_bf16_scores<D, KIND><<<grid, 64, 0, st>>>(U, N, users_c, items_c, unorm, qmax_bits, sig_u, c, scores, margin);
     });
