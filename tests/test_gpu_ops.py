@@ -1039,6 +1039,33 @@ def test_score_topk_second_overflow_arms_the_exact_kernel(ops, eval_filter):
         assert stats.cpu().numpy().tolist() == want_stats, name
 
 
+def test_first_round_plus_repair_round_is_the_complete_call(ops, eval_filter):
+    """The two halves of macr_score_topk on the cases of the test above: a seeded first round whose lists overflow is
+    finished by the repair round (its thresholds hold); an unseeded one on the catalogue whose sampled items score below
+    everything else overflows again in the repair round and the exact kernel ranks -- same results and stats as the
+    complete call."""
+    rs = np.random.RandomState(77)
+    U, N, d, K = 200, 4096 * 3, 64, 20
+    vrank = listing_visit_rank(N)
+    P = np.abs(rs.standard_normal((U, d)) * 0.5).astype(np.float32)
+    Q = (np.abs(rs.standard_normal((N, d)) * 0.5) * (1.0 + 4.0 * vrank[:, None] / N)).astype(np.float32)
+    mask = random_mask(rs, U, N, 10)
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    first = np.argsort(vrank)[:90]
+    low = np.stack([np.array([x for x in first if x not in set(mask[q])][:ops.SEED_WIDTH]) for q in range(U)]).astype(np.int32)
+    stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for name, items, seed, want_stats in (("seeded", Q, dev(low), [(U + 255) // 256, 0]),
+                                          ("sampled tiles negative", np.where(sampled_items(N)[:, None], -Q, Q), None,
+                                           [(U + 255) // 256, 1])):
+        wv, wi, _ = oracle.score_topk(oracle.SCORE_NORMAL, P, items, K, mask=oracle.csr_from_lists(mask))
+        v, ix = ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(items), K, mask=mcsr, seed=seed, stats=stats, first_round=True)
+        assert stats.cpu().numpy().tolist() == [want_stats[0], 0], name
+        ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(items), K, mask=mcsr, seed=seed, stats=stats, repair_of=(v, ix))
+        assert np.array_equal(ix[0].cpu().numpy(), wi), name
+        assert np.array_equal(v[0].cpu().numpy().view(np.uint32), wv.view(np.uint32)), name
+        assert stats.cpu().numpy().tolist() == want_stats, name
+
+
 @pytest.mark.parametrize("L,hubs", [(1, False), (2, True), (3, True)])
 def test_lgcn_batch_row_sparse_layers_equal_dense_layers(ops, L, hubs):
     """The LightGCN step computes its last forward layer for the batch's rows only and gathers, in the first backward
