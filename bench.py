@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--c4-users", type=int, default=10_000_000)
     ap.add_argument("--c4-items", type=int, default=1_000_000)
     ap.add_argument("--c4-eval-users", type=int, default=100_000)
+    ap.add_argument("--no-config4", action="store_true",
+                    help="N >= 2 only: skip the configs[4] leg (ONE row-sharded model over the ranks) that the default workload's "
+                         "line carries as `config4`")
     ap.add_argument("--train", default="rubibceboth", choices=["normalbce", "rubibceboth"])
     ap.add_argument("--eval-reps", type=int, default=20, help="timed evaluations (more than one period of the seeding policy's back-off)")
     ap.add_argument("--eval-settle", type=int, default=6, help="untimed evaluations (with the training steps between them) before the timed ones")
@@ -98,7 +101,7 @@ def algorithmic_bytes(kernel, cfg, B):
     return None
 
 
-def bench_config4(args, rank, world, dev):
+def bench_config4(args, rank, world, dev, emit=True):
     """BASELINE configs[4]: synthetic 10 M users x 1 M items, d = 128, B = 8192, `rubibceboth`, ONE model whose rows are
     sharded over the ranks, row r on rank r % W (macr_amd/sharded_train.py: three batch-sized collectives per step, dense Adam on the
     rank's shard) and whose evaluation is item-sharded (one all-gather of per-shard top-K).  `value` = interactions/s of
@@ -265,9 +268,30 @@ def bench_config4(args, rank, world, dev):
                                  "max_ms_per_step": 1e3 * max(regions) / args.steps},
                "cpu_baseline": cpu, "last_losses": [float(x) for x in last]}
         out.update(eval_out)
+        if not emit:
+            return out
         print(json.dumps(out))
+    if not emit:
+        return None
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def self_launch(n):
+    """Re-run this script as n ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>.  Exits with the launcher's status."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -275,10 +299,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N ...` as typed: become the launcher.  One process per GPU under torch.distributed.run
+        # (rendezvous on 127.0.0.1, a free port), same arguments; rank 0's JSON line is this process's stdout.
+        return self_launch(args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without a launcher: bench.py "
+                         "starts its own ranks)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     # one process per GPU over RCCL; MACR_DIST_BACKEND=gloo lets several ranks share one GPU (test rig for the N>1 path)
@@ -648,12 +675,39 @@ def main():
                          % (n_cpu, B, n_eval_cpu, len(users)),
                "eval_users_per_s": cpu_eval}
 
+    # ------------------------------------------------------------- N > 1: what the process group reports, the evaluation's
+    # one collective timed on its own, and the configs[4] leg (the training path that SHARDS: one model, rows over the ranks)
+    multi, c4_line = None, None
+    if world > 1:
+        Uq, Kq = len(users), Ks[0]
+        lv = torch.zeros((Uq, Kq), dtype=torch.float32, device=dev)
+        li = torch.zeros((Uq, Kq), dtype=torch.int32, device=dev)
+        for _ in range(3):
+            sharding.gather_topk(lv, li)
+        torch.cuda.synchronize(); barrier()
+        ag = []
+        for _ in range(20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); sharding.gather_topk(lv, li); e1.record()
+            ag.append((e0, e1))
+        torch.cuda.synchronize()
+        ag_us = float(np.median([1e3 * a.elapsed_time(b) for a, b in ag]))
+        multi = {"nranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                 "devices": torch.cuda.device_count(),
+                 "collectives_us": {"eval_all_gather_topk": sharding.max_over_ranks(ag_us, dev)},
+                 "eval_all_gather_bytes_per_rank": Uq * Kq * 8,
+                 "note": "event time of the evaluation's one collective (pack + all_gather_into_tensor + unpack of the (U,K) "
+                         "(score, id) lists), median of 20, max over ranks"}
+        if not args.no_config4:
+            c4_line = bench_config4(args, rank, world, dev, emit=False)
+
     if rank == 0:
         out = {
             "metric": "train interactions/sec + eval users/sec (full-catalog top-K@20)",
             "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "nranks": 1 if multi is None else multi["nranks"], "multi_gpu": multi,
             "config": {"workload": "%s-shape MACR-MF %s d=%d batch=%d c=%g (n_users=%d, n_items=%d); synthetic "
                                    "Xavier tables, Zipf positives, batches as sampled (grouped on the device inside the step)" % (args.workload, args.train, d, B, cfg["c"],
                                                                       cfg["n_users"], cfg["n_items"]),
@@ -682,6 +736,13 @@ def main():
             "roofline_eval": roofline_eval, "roofline_eval_bf16": roofline_eval_bf16, "cpu_baseline": cpu,
             "last_losses": [float(x) for x in losses[(args.warmup + args.steps - 1) % n_batches]],
         }
+        if c4_line is not None:
+            # configs[4] in the same line: interactions/s of ONE model row-sharded over the ranks (strong scaling), its
+            # per-step collectives and the item-sharded evaluation of 100 000 query users against 1 M items
+            out["config4"] = {k: c4_line.get(k) for k in ("value", "unit", "ms_per_step", "scaling", "config", "rows_per_rank",
+                                                          "collectives_ms", "wire_bytes_per_step", "kernels", "roofline",
+                                                          "roofline_step", "eval_users_per_s", "eval_ms_per_pass", "eval_users",
+                                                          "roofline_eval", "timed_regions")}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

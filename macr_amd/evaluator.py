@@ -368,7 +368,9 @@ class Evaluator(object):
                     vals, idx = self.rank_local(kind, users_tab, user_ids, items_tab, K, w, wu, c)
                     out = self._finish(flavour, vals, idx, Ks, out=host_out)
                 stages = (g, None, None, None)
-                first_bufs = (vals, idx)
+                # what a repair round must continue on: the first round's outputs AND the workspace it was captured with
+                # (the per-device cache is regrown whenever a larger evaluator asks: ops._topk_workspace)
+                first_bufs = (vals, idx, ops._topk_ws_cache.get(items_tab.device))
             else:
                 # several ranks: the collective stays outside -- one graph up to this shard's merged lists, the
                 # all-gather (RCCL), one graph from the gathered lists to the means

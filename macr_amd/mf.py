@@ -196,8 +196,10 @@ class BPRMF(object):
         self.user_embedding.copy_(sd["user_embedding"]); self.item_embedding.copy_(sd["item_embedding"])
         self.w.copy_(sd["w"]); self.w_user.copy_(sd["w_user"]); self.rubi_c = float(sd["rubi_c"])
         for kind, st in self._opt.items():
-            for name in ("mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu", "adam_pow"):
-                getattr(st, name).copy_(sd["opt%d.%s" % (kind, name)])
+            fresh = "opt%d.adam_pow" % kind not in sd          # (a row-sharded run's checkpoint carries ITS optimizer only)
+            for name in ("mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu"):
+                getattr(st, name).zero_() if fresh else getattr(st, name).copy_(sd["opt%d.%s" % (kind, name)])
+            st.adam_pow.copy_(torch.tensor([st.hyper.beta1, st.hyper.beta2]) if fresh else sd["opt%d.adam_pow" % kind])
 
 
 class ShardedBPRMF(object):
@@ -252,8 +254,11 @@ class ShardedBPRMF(object):
         return self._models[kind]
 
     def _any(self):
+        """the one model of this run: created with the loss kind the CLI trains with (`default_kind`, set from --train)
+        when a reader -- an evaluation, a checkpoint -- comes before the first step"""
         if not self._models:
-            self._model(ops.LOSS_RUBIBCEBOTH)
+            kind = getattr(self, "default_kind", None)
+            self._model(ops.LOSS_RUBIBCEBOTH if kind is None else kind)
         return next(iter(self._models.values()))
 
     to_device_batch = BPRMF.to_device_batch
@@ -326,11 +331,29 @@ class ShardedBPRMF(object):
         return sd
 
     def load_state_dict(self, sd):
-        kind = int(sd["row_shard_kind"])
+        """`sd` holds FULL tables (what state_dict() / BPRMF.state_dict() write); every rank takes its own rows.  NOT
+        collective.  The loss kind is the checkpoint's (`row_shard_kind`), else the one the CLI trains with, else the one
+        this model already runs; a checkpoint without that optimizer's slots (an unsharded `--pretrain` file of another
+        loss, a weights-only file) starts that optimizer fresh."""
+        if self._models:
+            kind = next(iter(self._models))
+        elif "row_shard_kind" in sd:
+            kind = int(sd["row_shard_kind"])
+        else:
+            kind = getattr(self, "default_kind", None)
+            if kind is None:
+                have = sorted(int(k[3:].split(".")[0]) for k in sd if k.startswith("opt") and k.endswith(".adam_pow"))
+                kind = have[0] if len(have) == 1 else ops.LOSS_RUBIBCEBOTH
         m = self._model(kind)
         dev = self.device
         m.P.copy_(self.own_u.take(sd["user_embedding"].to(dev))); m.Q.copy_(self.own_i.take(sd["item_embedding"].to(dev)))
         m.w.copy_(sd["w"]); m.wu.copy_(sd["w_user"]); self.rubi_c = float(sd["rubi_c"])
+        if "opt%d.adam_pow" % kind not in sd:
+            for name in ("mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu"):
+                getattr(m, name).zero_()
+            h = m.backend.hyper
+            m.backend.adam_pow.copy_(torch.tensor([h.beta1, h.beta2]))
+            return
         for name, own in (("mP", self.own_u), ("vP", self.own_u), ("mQ", self.own_i), ("vQ", self.own_i)):
             getattr(m, name).copy_(own.take(sd["opt%d.%s" % (kind, name)].to(dev)))
         for name in ("mw", "vw", "mwu", "vwu"):

@@ -274,22 +274,26 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     loose, 1 if the exact fallback kernel ran).
     first_round: macr_score_topk_first_round -- the first round alone, without the launches of the repair round and the
     fallback; stats (required) then says whether the result stands: stats[0] == 0, else finish it with
-    repair_of=(vals, idx) -- macr_score_topk_repair_round on the same arguments and the first-round call's outputs (or run the
-    complete call)."""
+    repair_of=(vals, idx, ws) -- macr_score_topk_repair_round on the same arguments, the first-round call's outputs AND the
+    workspace it ran on (thresholds, overflow counters and candidate lists are where the first round left them; the
+    per-device cache may have been regrown by another caller since) -- or run the complete call."""
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
     n_local, d = items.shape
     if n_splits <= 0:
         n_splits = score_topk_splits(U, n_local, d)
+    ws = None
     if repair_of is not None:
-        vals, idx = repair_of
+        vals, idx, ws = repair_of
         assert vals.shape == (n_splits, U, K) and idx.shape == (n_splits, U, K)
+        assert ws is not None and ws.numel() >= _lib.lib().macr_score_topk_workspace_bytes(U, n_local, d)
     else:
         vals = torch.empty((n_splits, U, K), dtype=_f32, device=items.device)
         idx = torch.empty((n_splits, U, K), dtype=_i32, device=items.device)
     mp = _ptr(mask.ptr, _i32) if mask is not None else None
     mi = _ptr(mask.idx, _i32) if mask is not None else None
     mb = _ptr(mask.mask_bits(U, n_local, item_offset)) if mask is not None else None
-    ws = _topk_workspace(U, n_local, d, items.device)
+    if ws is None:
+        ws = _topk_workspace(U, n_local, d, items.device)
     cv, cp = _c_args(c)
     fn = _lib.lib().macr_score_topk_first_round if first_round else _lib.lib().macr_score_topk
     if repair_of is not None:

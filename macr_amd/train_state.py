@@ -49,31 +49,63 @@ def _share(obj):
     return box[0]
 
 
-def resume(model, latest_checkpoint, side_path_of):
+def load_everywhere(model, path):
+    """A weights file read by the MAIN rank only reaches every rank's model: the main rank shares the layout of the state
+    dict (names, shapes, dtypes, the non-tensor entries), every tensor is broadcast from it, and every rank calls its own
+    `model.load_state_dict` on the complete dict -- a replica copies it, a row-sharded model (mf.ShardedBPRMF) takes the
+    rows it owns.  Never goes through the model's `state_dict()`: that one is collective for a row-sharded model and not
+    every rank has a model to reassemble yet."""
+    sd = None
+    if sharding.is_main():
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+    if sharding.world()[1] == 1:
+        model.load_state_dict({k: (v.to(model.device) if isinstance(v, torch.Tensor) else v) for k, v in sd.items()})
+        return
+    layout = _share(None if sd is None else
+                    [(k, tuple(v.shape), str(v.dtype).split(".")[-1]) if isinstance(v, torch.Tensor) else (k, None, v)
+                     for k, v in sd.items()])
+    full = {}
+    for k, shape, meta in layout:
+        if shape is None:
+            full[k] = meta
+            continue
+        if sharding.is_main():
+            t = sd[k].to(model.device).contiguous()
+        else:
+            t = torch.empty(shape, dtype=getattr(torch, meta), device=model.device)
+        sharding.broadcast_params([t])
+        full[k] = t
+    model.load_state_dict(full)
+
+
+def resume(model, latest_checkpoint, side_path_of, warn=print):
     """The resume step of both CLIs.  latest_checkpoint() -> (epoch, weights path) or None, evaluated on the main rank
-    only; side_path_of(epoch) -> the JSON written by save().  Loads the weights on the main rank, broadcasts them, restores
-    the host RNG streams on every rank and returns (epoch or None, bookkeeping dict or None)."""
+    only; side_path_of(epoch) -> the JSON written by save().  The main rank reads the weights and their tensors are
+    broadcast (load_everywhere), the host RNG streams are restored on every rank; returns (epoch or None, bookkeeping dict
+    or None).  Weights without a usable side file (written before the JSON format, or by --save_flag alone) resume the model
+    only: the caller is told, because best-so-far / early-stopping state and the sampler positions start over."""
     found, doc = None, None
     if sharding.is_main():
         found = latest_checkpoint()
         if found is not None:
-            model.load_state_dict(torch.load(found[1], map_location=model.device, weights_only=True))
             side = side_path_of(found[0])
             if os.path.exists(side):
                 with open(side) as f:
                     doc = json.load(f)
                 if doc.get("format") != 1:
+                    warn("WARNING: --resume: %s has format %r (this build reads format 1): resuming the weights only -- bests, "
+                         "early-stopping count, RNG and sampler positions start over" % (side, doc.get("format")))
                     doc = None
-    epoch, doc = _share((None if found is None else found[0], doc))
+            else:
+                legacy = side[:-len(".json")] + ".pt" if side.endswith(".json") else None
+                warn("WARNING: --resume: no %s next to %s%s: resuming the weights only -- bests, early-stopping count, RNG and "
+                     "sampler positions start over" % (os.path.basename(side), os.path.basename(found[1]),
+                                                       " (a legacy %s exists; that pickle format is no longer read)"
+                                                       % os.path.basename(legacy) if legacy and os.path.exists(legacy) else ""))
+    epoch, path, doc = _share((None, None, None) if found is None else (found[0], found[1], doc))
     if epoch is None:
         return None, None
-    if sharding.world()[1] > 1:
-        sd = model.state_dict()
-        sharding.broadcast_params([t for t in sd.values() if isinstance(t, torch.Tensor)])
-        scalars = _share({k: v for k, v in sd.items() if not isinstance(v, torch.Tensor)})
-        if not sharding.is_main():
-            sd.update(scalars)
-            model.load_state_dict(sd)
+    load_everywhere(model, path)
     if doc is None:
         return epoch, None
     _set_rng_state(doc["rng"])

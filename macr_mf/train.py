@@ -167,6 +167,7 @@ def main(sweep=False):
         print('MF model.')
     sess = Session(model)
     kind = model.kind_of(args.train)
+    model.default_kind = kind                    # (a row-sharded model is created lazily: with THIS run's loss, whoever asks first)
     rubi_type = "rubi_both" if args.train == 'rubibceboth' else "rubi_c"        # train.py:548-556
 
     if args.pretrain != 0:

@@ -76,3 +76,19 @@ print(calls["sample"], calls["sample_test"])
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[-2:] == ["4", "4"], out.stdout
+
+
+def test_bench_gpus_n_becomes_its_own_launcher():
+    """`python bench.py --gpus 2 ...` exactly as the driver types it (no torch.distributed.run in front): bench.py must start
+    its two ranks itself.  Without a GPU every rank stops at "needs an MI355X" -- which proves both ranks were started with
+    the rendezvous environment, and that the launcher hands their status back."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    import torch
+    if torch.cuda.is_available():
+        return                                           # (on a GPU box the -m gpu test runs the whole thing)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-3000:]

@@ -870,7 +870,8 @@ def test_first_round_alone_says_whether_it_stands(ops, eval_filter):
             assert got[0] > 0 and got[1] == 0, (name, got)
             # ... and macr_score_topk_repair_round finishes that very call: same arguments, workspace and outputs
             v2, ix2 = ops.score_topk(ops.SCORE_RUBI_BOTH, dev(P), None, dev(Q), K, sig_u, sig_i, 30.0, mcsr, seed=seed,
-                                     seed_out=seeds_out, stats=stats, repair_of=(v, ix))
+                                     seed_out=seeds_out, stats=stats,
+                                     repair_of=(v, ix, ops._topk_ws_cache[v.device]))
             torch.cuda.synchronize()
             assert stats.cpu().numpy().tolist() == [got[0], 0], name
             assert v2 is v and np.array_equal(ix[0].cpu().numpy(), wi) and np.array_equal(v[0].cpu().numpy().view(np.uint32), wv.view(np.uint32))
@@ -1060,7 +1061,8 @@ def test_first_round_plus_repair_round_is_the_complete_call(ops, eval_filter):
         wv, wi, _ = oracle.score_topk(oracle.SCORE_NORMAL, P, items, K, mask=oracle.csr_from_lists(mask))
         v, ix = ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(items), K, mask=mcsr, seed=seed, stats=stats, first_round=True)
         assert stats.cpu().numpy().tolist() == [want_stats[0], 0], name
-        ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(items), K, mask=mcsr, seed=seed, stats=stats, repair_of=(v, ix))
+        ops.score_topk(ops.SCORE_NORMAL, dev(P), None, dev(items), K, mask=mcsr, seed=seed, stats=stats,
+                       repair_of=(v, ix, ops._topk_ws_cache[v.device]))
         assert np.array_equal(ix[0].cpu().numpy(), wi), name
         assert np.array_equal(v[0].cpu().numpy().view(np.uint32), wv.view(np.uint32)), name
         assert stats.cpu().numpy().tolist() == want_stats, name

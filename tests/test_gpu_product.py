@@ -294,8 +294,10 @@ def test_clis_take_Ks_beyond_32(tmp_path):
 
 
 def test_bench_two_ranks_share_one_gpu(tmp_path):
-    """bench.py's N>1 path (replica training, rank-0 broadcast, item-sharded evaluation, all-gather, merge) with
-    two ranks on ONE GPU through the gloo test rig; the single-rank run is the reference for the eval metrics."""
+    """bench.py's N>1 path (replica training, rank-0 broadcast, item-sharded evaluation, all-gather, merge, the
+    configs[4] leg) with two ranks on ONE GPU through the gloo test rig, started EXACTLY as the driver starts it --
+    `python bench.py --gpus 2 --steps 20 --warmup 5`, no launcher: bench.py becomes its own torch.distributed.run.
+    The single-rank run is the reference for the eval metrics."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--workload", "addressa", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--eval-reps", "1",
@@ -304,15 +306,66 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
                          timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     env = dict(os.environ, MACR_DIST_BACKEND="gloo")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "2"] + common,
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + common +
+                         ["--c4-users", "200000", "--c4-items", "50000", "--c4-eval-users", "2000"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stdout[-1000:] + two.stderr[-3000:]
     a = json.loads(one.stdout.strip().splitlines()[-1])
     b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == 2 and b["value"] > 0 and b["config"]["global_batch"] == 2 * a["config"]["global_batch"]
+    assert b["nranks"] == 2 and b["multi_gpu"]["collectives_us"]["eval_all_gather_topk"] > 0
+    c4 = b["config4"]
+    assert c4["scaling"] == "strong" and c4["value"] > 0 and c4["eval_users_per_s"] > 0 and c4["collectives_ms"]
+    assert a["nranks"] == 1 and "config4" not in a
     for k, v in a["eval_metrics"].items():            # same model (rank 0's), item-sharded: same ranking metrics
         assert abs(b["eval_metrics"][k] - v) <= 2e-3 * max(abs(v), 1e-3), (k, v, b["eval_metrics"][k])
+
+
+def test_repair_round_continues_on_the_first_rounds_workspace(ops):
+    """the repair graph of an evaluation is captured long after its first-round graph -- at the first
+    evaluation whose seeds went stale -- and the shared per-device ranking workspace may have been regrown by a larger
+    evaluator in between.  The repair round must run on the workspace the first round was captured with (thresholds,
+    overflow counters and candidate lists live there), not on whatever the cache holds now."""
+    from macr_amd.evaluator import Evaluator
+    rs = np.random.RandomState(17)
+    d, n_items, n_users = 64, 9000, 30000
+    P = dev((rs.standard_normal((n_users, d)) * 0.4).astype(np.float32))
+    Q = dev((rs.standard_normal((n_items, d)) * 0.4).astype(np.float32))
+    w, wu = dev((rs.standard_normal(d) * 0.3).astype(np.float32)), dev((rs.standard_normal(d) * 0.3).astype(np.float32))
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    def mk(U, seed):
+        r = np.random.RandomState(seed)
+        users = np.sort(r.choice(n_users, U, replace=False)).astype(np.int32)
+        mask = [sorted(r.choice(n_items, 20, replace=False).tolist()) for _ in range(U)]
+        gt = [sorted(r.choice(n_items, 5, replace=False).tolist()) for _ in range(U)]
+        return Evaluator(mask, gt, n_items, device), dev(users)
+
+    def direct(ev, uid):
+        ev2 = Evaluator(ev._mask_lists, [[0]] * ev.n_queries, n_items, device)
+        ev2.gt, ev2.use_graph, ev2.use_seeds = ev.gt, False, False
+        return ev2.test_mf(1, P, uid, Q, [20], w, wu, 40.0)
+
+    small, uid_s = mk(700, 1)
+    if not small._shape_uses_seeds(n_items, d):
+        pytest.skip("this shape lists every item: no seeds, no repair round")
+    small.test_mf(1, P, uid_s, Q, [20], w, wu, 40.0)                  # sampled first round: captured, leaves seeds
+    small.test_mf(1, P, uid_s, Q, [20], w, wu, 40.0)                  # seeded first round: captured
+    assert small.last_eval_info()["seeded"] and not small.last_eval_info()["redone"]
+    ws_small = ops._topk_ws_cache[device]
+    big, uid_b = mk(20000, 2)
+    big.test_mf(1, P, uid_b, Q, [20], w, wu, 40.0)                    # regrows the cached workspace
+    assert ops._topk_ws_cache[device] is not ws_small
+    ops._topk_ws_cache[device].fill_(0x5A)                            # whatever the cache holds now is not small's state
+    Q.neg_()                                                          # the model moves away from every seed
+    got = small.test_mf(1, P, uid_s, Q, [20], w, wu, 40.0)            # seeded first round fails -> repair graph captured NOW
+    info = small.last_eval_info()
+    assert info["seeded"] and info["redone"] and info["query_blocks_relisted"] > 0, info
+    want = direct(small, uid_s)
+    for k in want:
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-12, err_msg=k)
+    Q.neg_()
 
 
 def test_evaluator_graphs_survive_scratch_reallocation(ops):
@@ -529,6 +582,45 @@ def test_mf_cli_row_sharded_two_ranks_one_gpu(tmp_path, train, test_):
     for name in ("user_embedding", "item_embedding"):
         assert sd[name].shape == ref_sd[name].shape
         assert float((sd[name] - ref_sd[name]).abs().max()) <= 2e-3 * 1e-3 * 30, name
+
+
+def test_mf_cli_row_sharded_resume_two_ranks_one_gpu(tmp_path):
+    """--resume 1 with --row_shard 1 on two ranks (round 4 deadlocked here: only rank 0 had a model when the collective
+    state_dict() ran): the main rank reads the checkpoint, its tensors are broadcast, every rank takes its rows.  Two epochs +
+    a resumed third and fourth must print the losses of an uninterrupted four-epoch run of the same sharded model, and an
+    UNSHARDED run resumes a sharded run's checkpoint (and the other way round) instead of failing on missing keys."""
+    os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
+    base = [os.path.join(REPO, "macr_mf", "train.py"), "--dataset", "addressa", "--batch_size", "1024", "--cuda", "0",
+            "--log_interval", "2", "--lr", "0.001", "--train", "rubibceboth", "--test", "rubi", "--c", "40", "--alpha", "1e-3",
+            "--beta", "1e-3"]
+    env = dict(os.environ, MACR_DIST_BACKEND="gloo", PYTHONUNBUFFERED="1")
+
+    def two(extra, port):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port)] + base + ["--row_shard", "1"] + extra,
+                           cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return r.stdout
+
+    def losses(text):
+        out, cur = {}, None
+        for l in text.splitlines():
+            if l.startswith("Epoch "):
+                cur = int(l.split()[1].rstrip(":"))
+            if (l.startswith("Epoch ") or l.startswith("c:")) and "train==[" in l:
+                out[cur] = float(l.split("train==[")[1].split("=")[0])
+        return out
+    whole = losses(two(["--saveID", "whole", "--epoch", "4"], 29551))
+    two(["--saveID", "cut", "--epoch", "2"], 29552)
+    out = two(["--saveID", "cut", "--epoch", "4", "--resume", "1"], 29553)
+    assert "resumed from epoch 1" in out
+    got = losses(out)
+    assert sorted(got) == [2, 3] and all(abs(got[e] - whole[e]) <= 2e-5 * abs(whole[e]) + 1.1e-5 for e in got), (got, whole)
+    # across modes: the sharded run's checkpoint continues unsharded, the unsharded one continues sharded
+    out = _run_cli(base + ["--saveID", "cut", "--epoch", "6", "--resume", "1"], str(tmp_path))
+    assert "resumed from epoch 3" in out and sorted(losses(out)) == [4, 5], out
+    out = two(["--saveID", "cut", "--epoch", "8", "--resume", "1"], 29554)
+    assert "resumed from epoch 5" in out and sorted(losses(out)) == [6, 7], out
 
 
 def test_row_sharded_training_two_ranks_one_gpu(tmp_path):
