@@ -70,6 +70,8 @@ def parse():
                     help="N >= 2 only: skip the configs[4] leg (ONE row-sharded model over the ranks) that the default workload's "
                          "line carries as `config4`")
     ap.add_argument("--train", default="rubibceboth", choices=["normalbce", "rubibceboth"])
+    ap.add_argument("--mf", action="store_true", help="--workload yelp2018 runs MACR-LightGCN (BASELINE configs[3]); --mf runs "
+                                                      "MACR-MF at the same shapes instead (diagnostic)")
     ap.add_argument("--eval-reps", type=int, default=20, help="timed evaluations (more than one period of the seeding policy's back-off)")
     ap.add_argument("--eval-settle", type=int, default=6, help="untimed evaluations (with the training steps between them) before the timed ones")
     ap.add_argument("--eval-train-steps", type=int, default=-1,
@@ -277,6 +279,234 @@ def bench_config4(args, rank, world, dev, emit=True):
         torch.distributed.destroy_process_group()
 
 
+def bench_lgcn(args, rank, world, dev):
+    """BASELINE configs[3]: Yelp2018-shape MACR-LightGCN, 2 layers [64,64], `bceboth`, B = 4096, c = 40
+    (macr_lightgcn/LightGCN.py:288-309 propagation, :495-532 loss, :201 Adam; utility/batch_test.py:26-162 evaluation).
+    A step = dense SpMM layer + batch-row-sparse layer forward, the pair kernels on propagated rows, the same two layers
+    backward with the ego regulariser and dense Adam in the last one's epilogue.  `value` = training interactions/s
+    (N ranks: N replicas, weak); the evaluation (propagate once + full-catalogue ranking + fold-out metrics) is item-sharded
+    over the ranks.  `roofline` = the dominant launch, the dense SpMM layer, against HBM with SURVEY 8(d)'s compulsory bytes
+    nnz*8 + (N+1)*4 + 2*N*d*4."""
+    from macr_amd import ops, sharding, synth
+    from macr_amd.evaluator import Evaluator
+    cfg = synth.WORKLOADS[args.workload]
+    n_u, n_i, d, B, L = cfg["n_users"], cfg["n_items"], cfg["d"], cfg["batch"], 2
+    kind = ops.LOSS_RUBIBCEBOTH if args.train == "rubibceboth" else ops.LOSS_NORMALBCE
+    lists, A = synth.lgcn_graph(cfg, seed=9)                       # same graph on every rank
+    N, nnz = A.shape[0], A.nnz
+    gen = torch.Generator(device=dev).manual_seed(12345 + rank)
+    T = synth.xavier_table(N, d, gen, dev)
+    w = synth.xavier_table(d, 1, gen, dev).reshape(-1)
+    wu = synth.xavier_table(d, 1, gen, dev).reshape(-1)
+    adj = ops.CSR.from_scipy(A, dev)
+    hyper = ops.make_hyper(cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
+    state = ops.LGCNState(T, n_u, n_i, w, wu, adj, L, hyper, B)
+    n_batches = 64
+    batches = synth.train_batches(n_batches, n_u, n_i, B, gen, dev)
+    loss_log = torch.zeros((n_batches, 3), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def run_steps(n, first):
+        for s in range(n):
+            k = (first + s) % n_batches
+            state.step(kind, batches[k, 0], batches[k, 1], batches[k, 2], loss_log[k])
+    run_steps(args.warmup, 0)
+
+    def timed_region():
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps, args.warmup)
+        torch.cuda.synchronize(); barrier()
+        return sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    regions = [timed_region()]
+    n_rep = args.regions if args.regions > 0 else int(min(100, max(1, round(0.1 / max(regions[0], 1e-6)))))
+    n_rep = int(sharding.max_over_ranks(float(n_rep), dev))
+    regions += [timed_region() for _ in range(n_rep - 1)]
+    elapsed = float(np.median(regions))
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+    losses = loss_log.cpu().numpy()
+    if not np.isfinite(losses[: min(n_batches, args.steps)]).all():
+        raise SystemExit("ERROR: loss is nan.")
+    # per-kernel HIP events on the launch stream, calibrated against the un-instrumented region as in main()
+    n_prof = 10
+    ops.timing_begin()
+    run_steps(n_prof, 0)
+    marks = ops.timing_end(max_n=n_prof * 16 + 16)
+    agg = {}
+    for name, ms in marks:
+        a = agg.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += ms
+    kern = {n_: {"launches_per_step": c_ / n_prof, "event_us": 1e3 * t / c_} for n_, (c_, t) in agg.items()}
+    ev_sum = sum(v["event_us"] * v["launches_per_step"] for v in kern.values())
+    launches = sum(v["launches_per_step"] for v in kern.values())
+    overhead = max(0.0, (ev_sum - 1e3 * ms_per_step) / launches)
+    for v in kern.values():
+        v["avg_us"] = max(v["event_us"] - overhead, 0.1)
+    pmc = {}
+    pmc_path = os.path.join(REPO, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path)).get(args.workload, {})
+        except Exception:
+            pmc = {}
+    layer_bytes = nnz * 8 + (N + 1) * 4 + 2 * N * d * 4                 # SURVEY 8(d) K5, one dense layer
+    adam_bytes = 24 * d * N
+    alg = {"spmm_csr": layer_bytes, "spmm_stream": layer_bytes,
+           # the last backward layer: a dense layer whose epilogue is the ego regulariser + dense Adam on T (read T, m, v
+           # and write them back instead of writing the layer's output rows)
+           "spmm_csr+adam": nnz * 8 + (N + 1) * 4 + N * d * 4 + adam_bytes, "spmm_stream+adam": nnz * 8 + (N + 1) * 4 + N * d * 4 + adam_bytes}
+    for n_, v in kern.items():
+        if n_ in alg:
+            v["algorithmic_bytes"] = alg[n_]
+            v["GBps"] = alg[n_] / (v["avg_us"] * 1e-6) / 1e9
+        if n_ == "bxb":
+            v["gevals_per_s"] = 2.0 * B * B / (v["avg_us"] * 1e-6) / 1e9
+    dense = "spmm_stream" if "spmm_stream" in kern else "spmm_csr"
+    dk = kern[dense]
+    roofline = {"kernel": dense, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": pmc.get(dense), "avg_us": dk["avg_us"],
+                "us_per_step": dk["avg_us"] * dk["launches_per_step"], "algorithmic_bytes": layer_bytes,
+                "note": "one dense propagation layer E' = A E (LightGCN.py:297-305): nnz*8 + (N+1)*4 + 2*N*d*4 compulsory bytes, "
+                        "N = %d, nnz = %d; `traffic` = PMC HBM bytes per launch (profiles/pmc_latest.json): the gather misses "
+                        "the L2 of the XCD it runs on, which is what it pays above the compulsory bytes" % (N, nnz)}
+    # whole step: SURVEY 8(d) "a LightGCN step = 2 layers fwd + 2 bwd" + the pair part + dense Adam over T
+    step_bytes = 2 * L * layer_bytes + B * (24 * d + 12) + adam_bytes
+    roofline_step = {"bound": "hbm", "algorithmic_bytes": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "note": "2*L dense layers + pair part + dense Adam, as SURVEY 8(d) counts a step; the step here runs the last "
+                             "forward and the first backward layer for the batch's rows only, so it moves fewer bytes than this"}
+    # ------------------------------------------------------------- evaluation: propagate once, rank, fold-out metrics
+    rs = np.random.RandomState(777)
+    U = cfg["n_test_users"]
+    users = np.sort(rs.choice(n_u, U, replace=False)).astype(np.int32)
+    mask_lists = [lists[u_] for u_ in users]                      # the query users' train items (batch_test.py:124-129)
+    gt_lists = []
+    for row in mask_lists:
+        seen, t_ = set(row), []
+        while len(t_) < cfg["test_per_user"]:
+            x = int(rs.randint(0, n_i))
+            if x not in seen:
+                t_.append(x); seen.add(x)
+        gt_lists.append(sorted(t_))
+    Ks = [20]
+    eval_out = {}
+    if not args.no_eval:
+        steps_between = args.eval_train_steps if args.eval_train_steps >= 0 else 10 * (cfg["n_train"] // B + 1)
+        steps_between = min(steps_between, 400)                   # (a 0.2 ms step: 400 steps = what the model moves in ~1 epoch)
+        uid = torch.from_numpy(users).to(dev)
+
+        def one_model():
+            if world > 1:
+                for t in (state.T, state.w, state.wu):
+                    torch.distributed.broadcast(t, 0)
+                state._E = None
+
+        def suite(filt):
+            ev = Evaluator(mask_lists, gt_lists, n_i, dev)
+            ev.filter = filt
+
+            def run_eval():
+                E = state.propagated()                            # E = mean(E0, A E0, A^2 E0): once per evaluation
+                return ev.test_lgcn(ops.SCORE_RUBI_BOTH, E[:n_u], uid, E[n_u:], Ks, state.w, state.wu, cfg["c"])
+            one_model(); run_eval()
+            for r_ in range(min(args.eval_settle, 3)):
+                run_steps(steps_between, steps_between * r_); one_model(); run_eval()
+            times, modes = [], []
+            for r_ in range(args.eval_reps):
+                run_steps(steps_between, steps_between * r_); one_model()
+                barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ret = run_eval()
+                torch.cuda.synchronize(); barrier()
+                times.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))
+                modes.append(ev.last_eval_info())
+            # kernels of one evaluation (direct launches; the propagation included)
+            ev.use_graph = False
+            state._E = None
+            ops.timing_begin()
+            run_eval()
+            ek = {}
+            for name, ms in ops.timing_end():
+                ek[name] = ek.get(name, 0.0) + 1e3 * max(ms - 1e-3 * overhead, 0.0)
+            ev.use_graph = True
+            ts = sorted(times)
+            return {"users_per_s": U * len(times) / sum(times), "ms_per_eval": 1e3 * sum(times) / len(times),
+                    "ms_per_eval_median": 1e3 * ts[len(ts) // 2], "ms_per_eval_min": 1e3 * ts[0], "ms_per_eval_max": 1e3 * ts[-1],
+                    "evaluations": len(times), "seeded": sum(1 for m in modes if m["seeded"]),
+                    "repaired": sum(1 for m in modes if m["query_blocks_relisted"] > 0 or m["exact_fallback"]),
+                    "kernels_us": ek, "metrics": {k: float(v[0]) for k, v in ret.items()}}
+        s32 = suite("f32")
+        sdef = suite(os.environ.get("MACR_EVAL_FILTER", "bf16").lower())
+        lo, hi = sharding.item_shard_range(n_i, rank, world)
+        flops = 2.0 * U * (hi - lo) * d
+        k32 = s32["kernels_us"]
+        rank_us = sum(v for k_, v in k32.items() if k_.startswith(("score_", "tau", "select", "bf16_prep", "repair_plan")))
+        eval_out = {"eval_users_per_s": sdef["users_per_s"], "eval_ms_per_pass": sdef["ms_per_eval"], "eval_users": U,
+                    "eval_metrics": sdef["metrics"],
+                    "eval": {"default_filter": "bf16", "f32": s32, "bf16": sdef, "train_steps_between_evaluations": steps_between,
+                             "note": "one evaluation = propagation (L dense layers + mean) + branch sigmoids + ranking + fold-out "
+                                     "metrics (batch_test.py:26-162), graph replays except the propagation"},
+                    "roofline_eval": {"filter": "f32", "bound": "mfma", "flops": flops, "avg_us": rank_us,
+                                      "achieved": flops / (rank_us * 1e-6) / 1e12 if rank_us else None, "peak": MFMA_F32_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": flops / (rank_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS if rank_us else None,
+                                      "eval_users_per_s": s32["users_per_s"],
+                                      "note": "U*N*d multiply-adds counted once over the ranking kernels of one sampled evaluation"}}
+    # ------------------------------------------------------------- CPU baseline: the oracle's LightGCN step and evaluation
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        Tc, wc, wuc = state.T.cpu().numpy().copy(), state.w.cpu().numpy().copy(), state.wu.cpu().numpy().copy()
+        st = oracle.AdamState([Tc.shape, (d,), (d,)])
+        hb = batches[:4].cpu().numpy()
+        step = lambda k: oracle.lgcn_train_step(kind, n_u, n_i, L, A.indptr, A.indices, A.data, hb[k % 4, 0], hb[k % 4, 1], hb[k % 4, 2],
+                                                Tc, wc, wuc, st, cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
+        step(0)
+        t0, n_cpu = time.perf_counter(), 0
+        while time.perf_counter() - t0 < args.cpu_seconds * 0.6 and n_cpu < 64:
+            step(n_cpu + 1); n_cpu += 1
+        cpu_train = n_cpu * B / (time.perf_counter() - t0)
+        n_ev = min(256, U)
+        mptr, midx = oracle.csr_from_lists(mask_lists[:n_ev]); gptr, gidx = oracle.csr_from_lists(gt_lists[:n_ev])
+        t0 = time.perf_counter()
+        E = oracle.lgcn_propagate(A.indptr, A.indices, A.data, Tc, L)
+        t_prop = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sig_i = oracle.branch_sigmoid(E[n_u:], wc); sig_u = oracle.branch_sigmoid(E[users[:n_ev]], wuc)
+        _, oi, _ = oracle.score_topk(oracle.SCORE_RUBI_BOTH, np.ascontiguousarray(E[users[:n_ev]]), np.ascontiguousarray(E[n_u:]), 20,
+                                     sig_u, sig_i, cfg["c"], (mptr, midx), fill_masked=True)
+        oracle.metrics_foldout(oi, (gptr, gidx))
+        t_rank = time.perf_counter() - t0
+        cpu = {"value": cpu_train, "unit": "interactions/s", "cores": os.cpu_count() or 1, "kind": "port",
+               "what": "oracle/macr_oracle.c (OpenMP): orc_lgcn_train_step = CSR SpMM layers forward and backward, pair loss and "
+                       "gradients, dense Adam on T -- the checker, not a tuned CPU implementation",
+               "sample": "%d LightGCN training steps (B=%d, N=%d, nnz=%d, L=%d); eval: one propagation (%.3f s) + ranking and "
+                         "metrics of %d of the %d query users, extrapolated" % (n_cpu, B, N, nnz, L, t_prop, n_ev, U),
+               "eval_users_per_s": U / (t_prop + t_rank * U / n_ev)}
+    if rank == 0:
+        out = {"metric": "train interactions/sec + eval users/sec (full-catalog top-K@20)",
+               "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic", "nranks": world,
+               "config": {"workload": "%s-shape MACR-LightGCN %s, %d layers [64,64], d=%d batch=%d c=%g (n_users=%d, n_items=%d, "
+                                      "N=%d nodes, nnz=%d = 2*n_train, `pre` adjacency); synthetic graph (lognormal user degrees, Zipf "
+                                      "items), Xavier tables, batches as sampled"
+                                      % (args.workload, "bceboth" if kind == ops.LOSS_RUBIBCEBOTH else "bce", L, d, B, cfg["c"], n_u, n_i, N, nnz),
+                          "parallelism": "replicas x%d (train) / item-sharded x%d + RCCL all-gather (eval)" % (world, world),
+                          "global_batch": B * world},
+               "timed_regions": {"n": len(regions), "each": "exactly %d steps, barrier+synchronize on both sides" % args.steps,
+                                 "reported": "median", "min_ms_per_step": 1e3 * min(regions) / args.steps,
+                                 "max_ms_per_step": 1e3 * max(regions) / args.steps},
+               "event_overhead_us_per_launch": overhead, "kernels": kern, "roofline": roofline, "roofline_step": roofline_step,
+               "cpu_baseline": cpu, "last_losses": [float(x) for x in losses[(args.warmup + args.steps - 1) % n_batches]]}
+        out.update(eval_out)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def self_launch(n):
     """Re-run this script as n ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n
     --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>.  Exits with the launcher's status."""
@@ -325,6 +555,8 @@ def main():
 
     if args.workload == "config4":
         return bench_config4(args, rank, world, dev)
+    if args.workload == "yelp2018" and not args.mf:
+        return bench_lgcn(args, rank, world, dev)
     cfg = synth.WORKLOADS[args.workload]
     B, d = cfg["batch"], cfg["d"]
     if args.eval_train_steps < 0:

@@ -177,9 +177,11 @@ class RowShardedMF(object):
         if self.world == 1 and not sharding.force_collectives():
             return
         if self._host_rig(t):                       # test rig: several ranks on one GPU cannot use RCCL
-            h = t.cpu()
-            dist.all_reduce(h, group=self.group)
-            t.copy_(h)
+            def via_host():
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+            self._timed(name, via_host)
         else:
             self._timed(name, lambda: dist.all_reduce(t, group=self.group))
 
@@ -187,9 +189,11 @@ class RowShardedMF(object):
         if self.world == 1 and not sharding.force_collectives():
             return
         if self._host_rig(t):
-            h = t.cpu()
-            dist.broadcast(h, src, group=self.group)
-            t.copy_(h)
+            def via_host():
+                h = t.cpu()
+                dist.broadcast(h, src, group=self.group)
+                t.copy_(h)
+            self._timed(name, via_host)
         else:
             self._timed(name, lambda: dist.broadcast(t, src, group=self.group))
 

@@ -95,3 +95,23 @@ def eval_problem(cfg, seed):
                 t.append(x); seen.add(x)
         gt.append(sorted(t))
     return users, mask, gt
+
+
+def lgcn_graph(cfg, seed=9):
+    """Synthetic interaction graph of a workload's shape for the LightGCN path: (train lists per user, the `pre` adjacency
+    D^-1/2 A D^-1/2 as scipy CSR fp32 of shape (n_users+n_items)^2 -- macr_lightgcn/utility/load_data.py:112-121 --
+    with sorted column indices, nnz = 2 n_train)."""
+    import scipy.sparse as sp
+    n_u, n_i = cfg["n_users"], cfg["n_items"]
+    lists = interaction_lists(n_u, n_i, cfg["n_train"] / n_u, seed=seed)
+    rows = np.repeat(np.arange(n_u), [len(l) for l in lists])
+    cols = np.concatenate(lists)
+    R = sp.csr_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n_u, n_i))
+    A = sp.bmat([[None, R], [R.T, None]], format="csr", dtype=np.float32)
+    deg = np.asarray(A.sum(1)).ravel()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5).astype(np.float32)
+    dinv[np.isinf(dinv)] = 0
+    A = (sp.diags(dinv) @ A @ sp.diags(dinv)).tocsr().astype(np.float32)
+    A.sort_indices()
+    return lists, A
