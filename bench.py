@@ -240,15 +240,16 @@ def bench_config4(args, rank, world, dev, emit=True):
         wc, wuc = w.cpu().numpy().copy(), wu.cpu().numpy().copy()
         st = oracle.AdamState([Pc.shape, Qc.shape, (d,), (d,)])
         hb = batches[:4].cpu().numpy()
-        t0, n_cpu = time.perf_counter(), 0
-        while time.perf_counter() - t0 < args.cpu_seconds and n_cpu < 16:
-            k = n_cpu % 4
-            oracle.mf_train_step(ops.LOSS_RUBIBCEBOTH, (hb[k, 0] % nu).astype(np.int32), (hb[k, 1] % ni).astype(np.int32),
-                                 (hb[k, 2] % ni).astype(np.int32), Pc, Qc, wc, wuc, st, lr, regs, alpha, beta, B)
-            n_cpu += 1
+        with oracle.fast():                       # the speed build of the C port (oracle/Makefile `fast`)
+            t0, n_cpu = time.perf_counter(), 0
+            while time.perf_counter() - t0 < args.cpu_seconds and n_cpu < 64:
+                k = n_cpu % 4
+                oracle.mf_train_step(ops.LOSS_RUBIBCEBOTH, (hb[k, 0] % nu).astype(np.int32), (hb[k, 1] % ni).astype(np.int32),
+                                     (hb[k, 2] % ni).astype(np.int32), Pc, Qc, wc, wuc, st, lr, regs, alpha, beta, B)
+                n_cpu += 1
         cpu = {"value": n_cpu * B / (time.perf_counter() - t0), "unit": "interactions/s", "cores": os.cpu_count() or 1, "kind": "port",
-               "sample": "%d oracle steps (B=%d, d=%d) on tables of 1/64 of the rows (%d + %d): the dense Adam pass of the "
-                         "full tables would be 64x that part of a step" % (n_cpu, B, d, nu, ni)}
+               "sample": "%d steps of the C port (fast build; B=%d, d=%d) on tables of 1/64 of the rows (%d + %d): the dense Adam "
+                         "pass of the full tables would be 64x that part of a step" % (n_cpu, B, d, nu, ni)}
     if rank == 0:
         out = {"metric": "train interactions/sec + eval users/sec (full-catalog top-K@20)",
                "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -458,33 +459,67 @@ def bench_lgcn(args, rank, world, dev):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
-        Tc, wc, wuc = state.T.cpu().numpy().copy(), state.w.cpu().numpy().copy(), state.wu.cpu().numpy().copy()
-        st = oracle.AdamState([Tc.shape, (d,), (d,)])
+        from oracle import torch_port
+        T0, w0, wu0 = state.T.cpu().numpy().copy(), state.w.cpu().numpy().copy(), state.wu.cpu().numpy().copy()
         hb = batches[:4].cpu().numpy()
-        step = lambda k: oracle.lgcn_train_step(kind, n_u, n_i, L, A.indptr, A.indices, A.data, hb[k % 4, 0], hb[k % 4, 1], hb[k % 4, 2],
-                                                Tc, wc, wuc, st, cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
-        step(0)
-        t0, n_cpu = time.perf_counter(), 0
-        while time.perf_counter() - t0 < args.cpu_seconds * 0.6 and n_cpu < 64:
-            step(n_cpu + 1); n_cpu += 1
-        cpu_train = n_cpu * B / (time.perf_counter() - t0)
-        n_ev = min(256, U)
+
+        def c_steps(seconds, cap):
+            Tc, wc, wuc = T0.copy(), w0.copy(), wu0.copy()
+            st = oracle.AdamState([Tc.shape, (d,), (d,)])
+            step = lambda k: oracle.lgcn_train_step(kind, n_u, n_i, L, A.indptr, A.indices, A.data, hb[k % 4, 0], hb[k % 4, 1],
+                                                    hb[k % 4, 2], Tc, wc, wuc, st, cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
+            step(0)
+            t0, n = time.perf_counter(), 0
+            while n < 2 or (time.perf_counter() - t0 < seconds and n < cap):
+                step(n + 1); n += 1
+            return n * B / (time.perf_counter() - t0), n
+        with oracle.fast():
+            fast_rate, n_fast = c_steps(0.25 * args.cpu_seconds, 256)
+        strict_rate, n_strict = c_steps(0.15 * args.cpu_seconds, 64)
+        torch_rate = n_torch = None
+        try:
+            pk = torch_port.LOSS_RUBIBCEBOTH if kind == ops.LOSS_RUBIBCEBOTH else torch_port.LOSS_NORMALBCE
+            port = torch_port.LGCNPort(T0, n_u, n_i, w0, wu0, torch_port.csr_to_torch(A.indptr, A.indices, A.data, N), L,
+                                       cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
+            port.train_step(pk, hb[0, 0], hb[0, 1], hb[0, 2])
+            t0, n_torch = time.perf_counter(), 0
+            while n_torch < 1 or (time.perf_counter() - t0 < 0.2 * args.cpu_seconds and n_torch < 64):
+                port.train_step(pk, hb[(n_torch + 1) % 4, 0], hb[(n_torch + 1) % 4, 1], hb[(n_torch + 1) % 4, 2]); n_torch += 1
+            torch_rate = n_torch * B / (time.perf_counter() - t0)
+        except Exception as e:
+            n_torch = repr(e)
+        n_ev = min(1024, U)
         mptr, midx = oracle.csr_from_lists(mask_lists[:n_ev]); gptr, gidx = oracle.csr_from_lists(gt_lists[:n_ev])
-        t0 = time.perf_counter()
-        E = oracle.lgcn_propagate(A.indptr, A.indices, A.data, Tc, L)
-        t_prop = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        sig_i = oracle.branch_sigmoid(E[n_u:], wc); sig_u = oracle.branch_sigmoid(E[users[:n_ev]], wuc)
-        _, oi, _ = oracle.score_topk(oracle.SCORE_RUBI_BOTH, np.ascontiguousarray(E[users[:n_ev]]), np.ascontiguousarray(E[n_u:]), 20,
-                                     sig_u, sig_i, cfg["c"], (mptr, midx), fill_masked=True)
-        oracle.metrics_foldout(oi, (gptr, gidx))
-        t_rank = time.perf_counter() - t0
-        cpu = {"value": cpu_train, "unit": "interactions/s", "cores": os.cpu_count() or 1, "kind": "port",
-               "what": "oracle/macr_oracle.c (OpenMP): orc_lgcn_train_step = CSR SpMM layers forward and backward, pair loss and "
-                       "gradients, dense Adam on T -- the checker, not a tuned CPU implementation",
-               "sample": "%d LightGCN training steps (B=%d, N=%d, nnz=%d, L=%d); eval: one propagation (%.3f s) + ranking and "
-                         "metrics of %d of the %d query users, extrapolated" % (n_cpu, B, N, nnz, L, t_prop, n_ev, U),
-               "eval_users_per_s": U / (t_prop + t_rank * U / n_ev)}
+        with oracle.fast():
+            t0 = time.perf_counter()
+            E = oracle.lgcn_propagate(A.indptr, A.indices, A.data, T0, L)
+            t_prop = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            Eu, Ei = np.ascontiguousarray(E[users[:n_ev]]), np.ascontiguousarray(E[n_u:])
+            sig_i = oracle.branch_sigmoid(Ei, w0); sig_u = oracle.branch_sigmoid(Eu, wu0)
+            _, oi, _ = oracle.score_topk(oracle.SCORE_RUBI_BOTH, Eu, Ei, 20, sig_u, sig_i, cfg["c"], (mptr, midx), fill_masked=True)
+            oracle.metrics_foldout(oi, (gptr, gidx))
+            t_rank = time.perf_counter() - t0
+        ev_impl = {"c_port_fast": U / (t_prop + t_rank * U / n_ev)}
+        if oracle.have_ref():
+            # the reference's own C++ evaluator on the dense score rows batch_test.py:134 hands it (train items at -inf)
+            S = oracle.score_matrix(oracle.SCORE_RUBI_BOTH, Eu, Ei, sig_u, sig_i, cfg["c"])
+            for q in range(n_ev):
+                S[q, mask_lists[q]] = -np.inf
+            t0 = time.perf_counter()
+            oracle.ref_eval_score_matrix_foldout(S, gt_lists[:n_ev], top_k=20, thread_num=os.cpu_count() or 4)
+            ev_impl["reference_cpp_ranking_only"] = n_ev / (time.perf_counter() - t0)
+        cpu = {"value": fast_rate, "unit": "interactions/s", "cores": os.cpu_count() or 1, "kind": "port",
+               "what": "c_port_fast = oracle/macr_oracle.c (orc_lgcn_train_step: CSR SpMM layers forward and backward, pair loss "
+                       "and gradients, dense Adam on T), OpenMP, compiled -O3 -march=x86-64-v3 -ffast-math; c_checker = the strict "
+                       "build the parity tests use; torch_graph = oracle/torch_port.py, the reference's graph on torch-CPU "
+                       "(sparse CSR @ dense, dense (B,B) tensors, autograd, TF-form Adam)",
+               "implementations": {"c_port_fast": fast_rate, "c_checker": strict_rate, "torch_graph": torch_rate},
+               "torch_threads": torch.get_num_threads(),
+               "sample": "%d / %d / %s LightGCN training steps (fast C / checker / torch graph; B=%d, N=%d, nnz=%d, L=%d); eval: one "
+                         "propagation (%.3f s) + ranking and metrics of %d of the %d query users, extrapolated"
+                         % (n_fast, n_strict, n_torch, B, N, nnz, L, t_prop, n_ev, U),
+               "eval_users_per_s": ev_impl["c_port_fast"], "eval_implementations": ev_impl}
     if rank == 0:
         out = {"metric": "train interactions/sec + eval users/sec (full-catalog top-K@20)",
                "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -505,6 +540,87 @@ def bench_lgcn(args, rank, world, dev):
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def cpu_baseline_mf(args, kind, cfg, P, Q, w, wu, hb, users, mask_lists, gt_lists, Ks):
+    """The reference's CPU path, restated, timed on this box's host cores on a bounded sample of the same workload
+    (--cpu-seconds).  Three implementations of the same step, all held to each other by tests/test_torch_port_cpu.py:
+      c_port_fast    oracle/macr_oracle.c compiled for speed (-O3, AVX2, -ffast-math: vectorised expf/logf), OpenMP -- `value`
+      c_checker      the same file as the parity tests use it (-O2, strict IEEE, libm scalar calls)
+      torch_graph    oracle/torch_port.py: the reference's TF1 graph op for op on torch-CPU (dense (B,B) tensors, autograd,
+                     TF-form dense Adam) -- the closest thing to the TF1 CPU path that runs here
+    Evaluation: the C port's fused scoring + ranking, the torch port's per-batch score matrix + topk, and the reference's
+    own C++ evaluator (oracle/_ref, built from the reference's headers) on dense score rows."""
+    import oracle
+    from oracle import torch_port
+    B, d = cfg["batch"], cfg["d"]
+    Pc, Qc = P.cpu().numpy().copy(), Q.cpu().numpy().copy()
+    wc, wuc = w.cpu().numpy().copy(), wu.cpu().numpy().copy()
+    budget = args.cpu_seconds
+
+    def c_steps(seconds, cap):
+        Pw, Qw, ww, wuw = Pc.copy(), Qc.copy(), wc.copy(), wuc.copy()
+        st = oracle.AdamState([Pw.shape, Qw.shape, (d,), (d,)])
+        step = lambda k: oracle.mf_train_step(kind, hb[k % 8, 0], hb[k % 8, 1], hb[k % 8, 2], Pw, Qw, ww, wuw, st, cfg["lr"],
+                                              cfg["regs"], cfg["alpha"], cfg["beta"], B)
+        step(0)
+        t0, n = time.perf_counter(), 0
+        while n < 2 or (time.perf_counter() - t0 < seconds and n < cap):
+            step(n + 1); n += 1
+        return n * B / (time.perf_counter() - t0), n
+    with oracle.fast():
+        fast_rate, n_fast = c_steps(0.25 * budget, 512)
+    strict_rate, n_strict = c_steps(0.15 * budget, 64)
+    torch_rate = n_torch = None
+    try:
+        port = torch_port.MFPort(Pc, Qc, wc, wuc, cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
+        pk = torch_port.LOSS_RUBIBCEBOTH if kind == 1 else torch_port.LOSS_NORMALBCE
+        port.train_step(pk, hb[0, 0], hb[0, 1], hb[0, 2])
+        t0, n_torch = time.perf_counter(), 0
+        while n_torch < 1 or (time.perf_counter() - t0 < 0.2 * budget and n_torch < 64):
+            port.train_step(pk, hb[(n_torch + 1) % 8, 0], hb[(n_torch + 1) % 8, 1], hb[(n_torch + 1) % 8, 2]); n_torch += 1
+        torch_rate = n_torch * B / (time.perf_counter() - t0)
+    except Exception as e:                                   # (a baseline leg must not take the bench line with it)
+        torch_rate, n_torch = None, repr(e)
+    # evaluation
+    ev = {}
+    n_c = min(1024, len(users))
+    mptr, midx = oracle.csr_from_lists(mask_lists[:n_c]); gptr, gidx = oracle.csr_from_lists(gt_lists[:n_c])
+    with oracle.fast():
+        t0 = time.perf_counter()
+        sig_i = oracle.branch_sigmoid(Qc, wc); sig_u = oracle.branch_sigmoid(Pc[users[:n_c]], wuc)
+        _, oi, oc = oracle.score_topk(oracle.SCORE_RUBI_BOTH, Pc[users[:n_c]], Qc, Ks[0], sig_u, sig_i, cfg["c"], (mptr, midx))
+        oracle.metrics_mf(oi, oc, (gptr, gidx), Ks)
+        ev["c_port_fast"] = n_c / (time.perf_counter() - t0)
+    try:
+        port = torch_port.MFPort(Pc, Qc, wc, wuc, cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
+        n_t = min(4096, len(users))
+        port.evaluate(users[:256], mask_lists[:256], cfg["c"], K=Ks[0])
+        t0 = time.perf_counter()
+        ids = port.evaluate(users[:n_t], mask_lists[:n_t], cfg["c"], K=Ks[0], batch=B)
+        ev["torch_graph"] = n_t / (time.perf_counter() - t0)
+        if oracle.have_ref():
+            # the reference's own evaluator (tools.h + evaluate_foldout.h, compiled from the reference's headers) on the score rows
+            # the reference would hand it (batch_test.py:134): dense (U,N) fp32 with the train items at -inf
+            n_r = min(1024, len(users))
+            S = port.score_matrix(users[:n_r], cfg["c"]).numpy()
+            for q in range(n_r):
+                S[q, mask_lists[q]] = -np.inf
+            t0 = time.perf_counter()
+            oracle.ref_eval_score_matrix_foldout(S, gt_lists[:n_r], top_k=Ks[0], thread_num=os.cpu_count() or 4)
+            ev["reference_cpp_ranking_only"] = n_r / (time.perf_counter() - t0)
+    except Exception as e:
+        ev["torch_graph_error"] = repr(e)
+    import torch as _t
+    return {"value": fast_rate, "unit": "interactions/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "what": "c_port_fast = oracle/macr_oracle.c, OpenMP, compiled -O3 -march=x86-64-v3 -ffast-math (vectorised "
+                    "expf/logf); gradient tables persistent (no per-step calloc)",
+            "implementations": {"c_port_fast": fast_rate, "c_checker": strict_rate, "torch_graph": torch_rate},
+            "torch_threads": _t.get_num_threads(),
+            "sample": "%d / %d / %s training steps (fast C / checker / torch graph) of the same workload (B=%d) on full-size tables; "
+                      "eval: %d (C port) and up to 4096 (torch graph) of the %d query users"
+                      % (n_fast, n_strict, n_torch, B, n_c, len(users)),
+            "eval_users_per_s": max(v for k_, v in ev.items() if isinstance(v, float)), "eval_implementations": ev}
 
 
 def self_launch(n):
@@ -871,41 +987,10 @@ def main():
                         "train_steps_between_evaluations": args.eval_train_steps, "batch_pool": n_batches,
                         "roofline_eval_frac_f32_sampled": roofline_eval["frac"]}
 
-    # ------------------------------------------------------------- CPU baseline: the oracle ("port") on the host cores
+    # ------------------------------------------------------------- CPU baseline: ports of the reference path on the host cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
-        threads = os.cpu_count() or 1
-        Pc, Qc = P.cpu().numpy().copy(), Q.cpu().numpy().copy()
-        wc, wuc = w.cpu().numpy().copy(), wu.cpu().numpy().copy()
-        st = oracle.AdamState([Pc.shape, Qc.shape, (d,), (d,)])
-        hb = batches[:8].cpu().numpy()
-        oracle.mf_train_step(kind, hb[0, 0], hb[0, 1], hb[0, 2], Pc, Qc, wc, wuc, st, cfg["lr"], cfg["regs"],
-                             cfg["alpha"], cfg["beta"], B)
-        t0, n_cpu = time.perf_counter(), 0
-        while time.perf_counter() - t0 < args.cpu_seconds * 0.6 and n_cpu < 64:
-            k = (n_cpu + 1) % 8
-            oracle.mf_train_step(kind, hb[k, 0], hb[k, 1], hb[k, 2], Pc, Qc, wc, wuc, st, cfg["lr"], cfg["regs"],
-                                 cfg["alpha"], cfg["beta"], B)
-            n_cpu += 1
-        cpu_train = n_cpu * B / (time.perf_counter() - t0)
-        n_eval_cpu = min(256, len(users))
-        mptr, midx = oracle.csr_from_lists(mask_lists[:n_eval_cpu])
-        gptr, gidx = oracle.csr_from_lists(gt_lists[:n_eval_cpu])
-        t0 = time.perf_counter()
-        sig_i = oracle.branch_sigmoid(Qc, wc)
-        sig_u = oracle.branch_sigmoid(Pc[users[:n_eval_cpu]], wuc)
-        _, oi, oc = oracle.score_topk(oracle.SCORE_RUBI_BOTH, Pc[users[:n_eval_cpu]], Qc, 20, sig_u, sig_i, cfg["c"],
-                                      (mptr, midx))
-        oracle.metrics_mf(oi, oc, (gptr, gidx), Ks)
-        cpu_eval = n_eval_cpu / (time.perf_counter() - t0)
-        cpu = {"value": cpu_train, "unit": "interactions/s", "cores": threads, "kind": "port",
-               "what": "oracle (un-tuned checker: serial gather/scatter, a calloc of the full gradient tables per step); "
-                       "a statement about the checker, not about what a tuned CPU implementation could do",
-               "sample": "%d training steps of the same workload (B=%d) on the CPU restatement of the reference "
-                         "path (oracle/macr_oracle.c, OpenMP); eval: %d of the %d query users"
-                         % (n_cpu, B, n_eval_cpu, len(users)),
-               "eval_users_per_s": cpu_eval}
+        cpu = cpu_baseline_mf(args, kind, cfg, P, Q, w, wu, batches[:8].cpu().numpy(), users, mask_lists, gt_lists, Ks)
 
     # ------------------------------------------------------------- N > 1: what the process group reports, the evaluation's
     # one collective timed on its own, and the configs[4] leg (the training path that SHARDS: one model, rows over the ranks)

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "macr_oracle.c")
 _LIB = os.path.join(_HERE, "_build", "libmacr_oracle.so")
+_LIB_FAST = os.path.join(_HERE, "_build", "libmacr_oracle_fast.so")
 _REF_LIB = os.path.join(_HERE, "_ref", "libref_eval.so")
 
 LOSS_NORMALBCE, LOSS_RUBIBCEBOTH, LOSS_RUBIBCE = 0, 1, 2
@@ -30,18 +31,39 @@ def build(force=False):
     stale = (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+    if force or (not os.path.exists(_LIB_FAST)) or os.path.getmtime(_LIB_FAST) < os.path.getmtime(_SRC):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "fast"])
     if os.path.isdir("/root/reference/macr_lightgcn/evaluator/cpp/include"):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
 
 
 _lib = None
+_libs = {}
+_use_fast = False
+
+
+class fast(object):
+    """`with oracle.fast(): ...` -- the calls inside go to the speed build of the same C file (Makefile target `fast`:
+    -O3, AVX2, -ffast-math).  For bench.py's cpu_baseline leg only; the checker is the strict build."""
+
+    def __enter__(self):
+        global _use_fast
+        self._prev, _use_fast = _use_fast, True
+        return self
+
+    def __exit__(self, *exc):
+        global _use_fast
+        _use_fast = self._prev
 
 
 def lib():
     global _lib
-    if _lib is None:
+    path = _LIB_FAST if _use_fast else _LIB
+    if path in _libs:
+        return _libs[path]
+    if True:
         build()
-        L = ctypes.CDLL(_LIB)
+        L = ctypes.CDLL(path)
         L.orc_gather_rows.argtypes = [_f, _i, _ci, _ci, _f]
         L.orc_scatter_add_rows.argtypes = [_f, _i, _ci, _ci, _f]
         L.orc_pair_loss_grad.argtypes = [_ci, _ci, _ci, _f, _f, _f, _f, _f, _cf, _cf,
@@ -72,8 +94,10 @@ def lib():
                    "orc_branch_sigmoid", "orc_score_topk", "orc_topk_scores", "orc_topk_merge", "orc_metrics_foldout",
                    "orc_metrics_mf"):
             getattr(L, fn).restype = None
-        _lib = L
-    return _lib
+        _libs[path] = L
+        if path == _LIB:
+            _lib = L
+    return _libs[path]
 
 
 def _f32(a):
