@@ -240,6 +240,7 @@ def bench_config4(args, rank, world, dev, emit=True):
         wc, wuc = w.cpu().numpy().copy(), wu.cpu().numpy().copy()
         st = oracle.AdamState([Pc.shape, Qc.shape, (d,), (d,)])
         hb = batches[:4].cpu().numpy()
+        omp_set_threads(min(32, os.cpu_count() or 1))
         with oracle.fast():                       # the speed build of the C port (oracle/Makefile `fast`)
             t0, n_cpu = time.perf_counter(), 0
             while time.perf_counter() - t0 < args.cpu_seconds and n_cpu < 64:
@@ -247,7 +248,7 @@ def bench_config4(args, rank, world, dev, emit=True):
                 oracle.mf_train_step(ops.LOSS_RUBIBCEBOTH, (hb[k, 0] % nu).astype(np.int32), (hb[k, 1] % ni).astype(np.int32),
                                      (hb[k, 2] % ni).astype(np.int32), Pc, Qc, wc, wuc, st, lr, regs, alpha, beta, B)
                 n_cpu += 1
-        cpu = {"value": n_cpu * B / (time.perf_counter() - t0), "unit": "interactions/s", "cores": os.cpu_count() or 1, "kind": "port",
+        cpu = {"value": n_cpu * B / (time.perf_counter() - t0), "unit": "interactions/s", "cores": min(32, os.cpu_count() or 1), "kind": "port",
                "sample": "%d steps of the C port (fast build; B=%d, d=%d) on tables of 1/64 of the rows (%d + %d): the dense Adam "
                          "pass of the full tables would be 64x that part of a step" % (n_cpu, B, d, nu, ni)}
     if rank == 0:
@@ -474,10 +475,17 @@ def bench_lgcn(args, rank, world, dev):
                 step(n + 1); n += 1
             return n * B / (time.perf_counter() - t0), n
         with oracle.fast():
-            fast_rate, n_fast = c_steps(0.25 * args.cpu_seconds, 256)
-        strict_rate, n_strict = c_steps(0.15 * args.cpu_seconds, 64)
+            Tw, ww, wuw = T0.copy(), w0.copy(), wu0.copy()
+            stw = oracle.AdamState([Tw.shape, (d,), (d,)])
+            omp_n, omp_seen = best_omp_threads(lambda: oracle.lgcn_train_step(
+                kind, n_u, n_i, L, A.indptr, A.indices, A.data, hb[0, 0], hb[0, 1], hb[0, 2], Tw, ww, wuw, stw, cfg["lr"],
+                cfg["regs"], cfg["alpha"], cfg["beta"], B))
+            fast_rate, n_fast = c_steps(0.2 * args.cpu_seconds, 1024)
+        strict_rate, n_strict = c_steps(0.15 * args.cpu_seconds, 256)
         torch_rate = n_torch = None
+        torch_threads0 = torch.get_num_threads()
         try:
+            torch.set_num_threads(min(torch_threads0, max(omp_n, 32)))
             pk = torch_port.LOSS_RUBIBCEBOTH if kind == ops.LOSS_RUBIBCEBOTH else torch_port.LOSS_NORMALBCE
             port = torch_port.LGCNPort(T0, n_u, n_i, w0, wu0, torch_port.csr_to_torch(A.indptr, A.indices, A.data, N), L,
                                        cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
@@ -509,13 +517,16 @@ def bench_lgcn(args, rank, world, dev):
             t0 = time.perf_counter()
             oracle.ref_eval_score_matrix_foldout(S, gt_lists[:n_ev], top_k=20, thread_num=os.cpu_count() or 4)
             ev_impl["reference_cpp_ranking_only"] = n_ev / (time.perf_counter() - t0)
-        cpu = {"value": fast_rate, "unit": "interactions/s", "cores": os.cpu_count() or 1, "kind": "port",
+        used_torch_threads = torch.get_num_threads()
+        torch.set_num_threads(torch_threads0)
+        cpu = {"value": fast_rate, "unit": "interactions/s", "cores": omp_n, "host_cpus": os.cpu_count() or 1, "kind": "port",
+               "omp_threads_s_per_step": omp_seen,
                "what": "c_port_fast = oracle/macr_oracle.c (orc_lgcn_train_step: CSR SpMM layers forward and backward, pair loss "
                        "and gradients, dense Adam on T), OpenMP, compiled -O3 -march=x86-64-v3 -ffast-math; c_checker = the strict "
                        "build the parity tests use; torch_graph = oracle/torch_port.py, the reference's graph on torch-CPU "
                        "(sparse CSR @ dense, dense (B,B) tensors, autograd, TF-form Adam)",
                "implementations": {"c_port_fast": fast_rate, "c_checker": strict_rate, "torch_graph": torch_rate},
-               "torch_threads": torch.get_num_threads(),
+               "torch_threads": used_torch_threads,
                "sample": "%d / %d / %s LightGCN training steps (fast C / checker / torch graph; B=%d, N=%d, nnz=%d, L=%d); eval: one "
                          "propagation (%.3f s) + ranking and metrics of %d of the %d query users, extrapolated"
                          % (n_fast, n_strict, n_torch, B, N, nnz, L, t_prop, n_ev, U),
@@ -540,6 +551,34 @@ def bench_lgcn(args, rank, world, dev):
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def omp_set_threads(n):
+    """thread count of the C port's OpenMP regions (libgomp, the runtime oracle/_build/*.so link): the default -- every
+    hardware thread of a 2-socket SMT host -- is its worst setting (measured on the GPU box: 701 ms per Gowalla step at 256
+    threads, 23 ms at 32)"""
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+        return True
+    except OSError:
+        return False
+
+
+def best_omp_threads(step, candidates=(16, 32, 64, 128)):
+    """time `step()` under each thread count (one warm call, two timed) and leave the fastest set; -> (threads, {n: s/step})"""
+    ncpu = os.cpu_count() or 1
+    seen, best = {}, None
+    for n in [c for c in candidates if c <= ncpu] or [ncpu]:
+        if not omp_set_threads(n):
+            return ncpu, {}
+        step()
+        t0 = time.perf_counter(); step(); step()
+        seen[n] = (time.perf_counter() - t0) / 2
+        if best is None or seen[n] < seen[best]:
+            best = n
+    omp_set_threads(best)
+    return best, seen
 
 
 def cpu_baseline_mf(args, kind, cfg, P, Q, w, wu, hb, users, mask_lists, gt_lists, Ks):
@@ -569,10 +608,17 @@ def cpu_baseline_mf(args, kind, cfg, P, Q, w, wu, hb, users, mask_lists, gt_list
             step(n + 1); n += 1
         return n * B / (time.perf_counter() - t0), n
     with oracle.fast():
-        fast_rate, n_fast = c_steps(0.25 * budget, 512)
-    strict_rate, n_strict = c_steps(0.15 * budget, 64)
+        Pw, Qw, ww, wuw = Pc.copy(), Qc.copy(), wc.copy(), wuc.copy()
+        stw = oracle.AdamState([Pw.shape, Qw.shape, (d,), (d,)])
+        omp_n, omp_seen = best_omp_threads(lambda: oracle.mf_train_step(kind, hb[0, 0], hb[0, 1], hb[0, 2], Pw, Qw, ww, wuw, stw,
+                                                                         cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B))
+        fast_rate, n_fast = c_steps(0.2 * budget, 2048)
+    strict_rate, n_strict = c_steps(0.15 * budget, 256)
     torch_rate = n_torch = None
+    import torch as _t
+    torch_threads0 = _t.get_num_threads()
     try:
+        _t.set_num_threads(min(torch_threads0, max(omp_n, 32)))
         port = torch_port.MFPort(Pc, Qc, wc, wuc, cfg["lr"], cfg["regs"], cfg["alpha"], cfg["beta"], B)
         pk = torch_port.LOSS_RUBIBCEBOTH if kind == 1 else torch_port.LOSS_NORMALBCE
         port.train_step(pk, hb[0, 0], hb[0, 1], hb[0, 2])
@@ -611,12 +657,15 @@ def cpu_baseline_mf(args, kind, cfg, P, Q, w, wu, hb, users, mask_lists, gt_list
             ev["reference_cpp_ranking_only"] = n_r / (time.perf_counter() - t0)
     except Exception as e:
         ev["torch_graph_error"] = repr(e)
-    import torch as _t
-    return {"value": fast_rate, "unit": "interactions/s", "cores": os.cpu_count() or 1, "kind": "port",
+    used_torch_threads = _t.get_num_threads()
+    _t.set_num_threads(torch_threads0)
+    return {"value": fast_rate, "unit": "interactions/s", "cores": omp_n, "host_cpus": os.cpu_count() or 1, "kind": "port",
             "what": "c_port_fast = oracle/macr_oracle.c, OpenMP, compiled -O3 -march=x86-64-v3 -ffast-math (vectorised "
-                    "expf/logf); gradient tables persistent (no per-step calloc)",
+                    "expf/logf); gradient tables persistent (no per-step calloc); `cores` = the OpenMP thread count that was "
+                    "fastest on this host (omp_threads_s_per_step: what each candidate took)",
+            "omp_threads_s_per_step": omp_seen,
             "implementations": {"c_port_fast": fast_rate, "c_checker": strict_rate, "torch_graph": torch_rate},
-            "torch_threads": _t.get_num_threads(),
+            "torch_threads": used_torch_threads,
             "sample": "%d / %d / %s training steps (fast C / checker / torch graph) of the same workload (B=%d) on full-size tables; "
                       "eval: %d (C port) and up to 4096 (torch graph) of the %d query users"
                       % (n_fast, n_strict, n_torch, B, n_c, len(users)),

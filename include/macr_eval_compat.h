@@ -23,7 +23,8 @@
  *   - errors: the reference has no error channel.  Here a failed call fills
  *     its output with -1 (rankings) / NaN (results), prints one line to
  *     stderr and sets macr_eval_compat_status() (0 = last call succeeded);
- *   - top_k <= MACR_MAX_TOPK_SCORES (128); thread_num is ignored.
+ *   - any top_k, as in the reference (above 128 the ranking runs in rounds of 128 positions; positions past the
+ *     number of columns hold -1); thread_num is ignored.
  * ==========================================================================*/
 #ifndef MACR_EVAL_COMPAT_H
 #define MACR_EVAL_COMPAT_H

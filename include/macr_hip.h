@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     9
+#define MACR_ABI_VERSION     10
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -59,7 +59,8 @@ extern "C" {
 #define MACR_MAX_TOPK_FUSED 32     /* up to here macr_score_topk is the fused ranking (thresholds, candidate lists, seeds); above,
                                       blocks of dense score rows + streaming selection -- same results, no seeds; the c sweep
                                       (macr_score_topk_sweep) stays at K <= 32 */
-#define MACR_MAX_TOPK_SCORES 128   /* = MACR_MAX_TOPK (c_top_k_array_index of the reference has no bound) */
+/* macr_topk_scores itself takes ANY K, like c_top_k_array_index of the reference (tools.h:13-22): above MACR_MAX_TOPK it
+ * ranks in rounds of MACR_MAX_TOPK positions and needs macr_topk_scores_workspace_bytes(rows, K) of scratch */
 #define MACR_SEED_WIDTH 32       /* threshold seeds per query of macr_score_topk (seed_idx / seed_out) */
 
 int         macr_abi_version(void);
@@ -373,14 +374,15 @@ size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
  *                          repair round; the selection takes each query's 64 best candidates by bf16 score, checks that
  *                          nothing else can belong to the top K, re-computes the fp32 score of those that can and ranks
  *                          them; a query that fails the check has all its listed candidates re-scored in fp32.
- *   MACR_EVAL_FILTER_ENV   (default) follow MACR_EVAL_FILTER=f32|bf16 in the environment, f32 when unset.
- * Process-wide; not meant to be flipped while rankings are in flight on other threads. */
+ *   MACR_EVAL_FILTER_ENV   follow MACR_EVAL_FILTER=f32|bf16 in the environment, f32 when unset.
+ * An ARGUMENT of every ranking call (`filter`, second parameter) since abi 10: the library keeps no filter state (round 4's
+ * process-wide macr_set_eval_filter is gone).  A first-round call and the repair-round call that finishes it take the
+ * same value. */
 #define MACR_EVAL_FILTER_ENV  0
 #define MACR_EVAL_FILTER_F32  1
 #define MACR_EVAL_FILTER_BF16 2
-int macr_set_eval_filter(int mode);
 
-int macr_score_topk(int score_kind, int U, int n_local, int d,
+int macr_score_topk(int score_kind, int filter, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
                     const float *sig_u, const float *sig_i, float c, const float *c_dev,
                     const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
@@ -394,7 +396,7 @@ int macr_score_topk(int score_kind, int U, int n_local, int d,
  * stats (required; device memory or device-visible host memory) receives {query blocks whose candidate lists overflowed
  * or whose seeds were stale, 0}.  stats[0] == 0: out_val / out_idx / seed_out are exactly what macr_score_topk returns.
  * Otherwise they are not the ranking yet: macr_score_topk_repair_round finishes it (or macr_score_topk starts over). */
-int macr_score_topk_first_round(int score_kind, int U, int n_local, int d,
+int macr_score_topk_first_round(int score_kind, int filter, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
                     const float *sig_u, const float *sig_i, float c, const float *c_dev,
                     const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
@@ -407,7 +409,7 @@ int macr_score_topk_first_round(int score_kind, int U, int n_local, int d,
  * macr_score_topk_first_round left it and the same out_val / out_idx / seed_out buffers -- the repair round re-lists the
  * stats[0] query blocks and overwrites their rows; the exact fallback kernel follows if a list overflows again.
  * first_round + repair_round launch what macr_score_topk launches.  stats as macr_score_topk writes it. */
-int macr_score_topk_repair_round(int score_kind, int U, int n_local, int d,
+int macr_score_topk_repair_round(int score_kind, int filter, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
                     const float *sig_u, const float *sig_i, float c, const float *c_dev,
                     const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
@@ -428,37 +430,17 @@ int macr_score_topk_repair_round(int score_kind, int U, int n_local, int d,
  *              macr_score_topk writes them (one list per value: n_splits = 1)
  *   workspace >= macr_score_topk_sweep_workspace_bytes(U, n_local, d, n_c), 256-B aligned
  * score_kind: any kind that uses c (not MACR_SCORE_NORMAL).  Results per value are
- * identical to macr_score_topk with that c.  Follows the candidate filter (macr_set_eval_filter):
+ * identical to macr_score_topk with that c.  Follows the candidate filter (`filter`, as above):
  * with the bf16 filter the shared listing pass, the sampling passes and the selections are the
  * bf16 kernels.
  * -------------------------------------------------------------------------*/
 #define MACR_MAX_SWEEP 4
 size_t macr_score_topk_sweep_workspace_bytes(int U, int n_local, int d, int n_c);
-int macr_score_topk_sweep(int score_kind, int U, int n_local, int d,
+int macr_score_topk_sweep(int score_kind, int filter, int U, int n_local, int d,
                           const float *users_tab, const int32_t *user_ids, const float *items,
                           const float *sig_u, const float *sig_i, int n_c, const float *c_dev,
                           const int32_t *mask_ptr, const int32_t *mask_idx, const uint32_t *mask_bits,
                           int item_offset, int K, float *out_val, int32_t *out_idx,
-                          void *workspace, size_t workspace_bytes, void *stream);
-
-/* TEST-ONLY: the invariant the bf16 candidate filter rests on, made observable.  Writes, for U query rows and N item
- * rows (dev, fp32 [U][d] / [N][d]), the RAW product the bf16 kernels compute -- two-term bf16 splits, hi*hi + hi*lo +
- * lo*hi on v_mfma_f32_32x32x16_bf16 in the listing pass's instruction order -- to prod (dev) fp32[U][N], and to margin
- * (dev) fp32[U] the error margin the filter grants each query at this c (what it subtracts from her threshold).
- * tests/ assert |prod - fp32 fmaf chain| <= margin element-wise on adversarial operands for every d; no product code
- * calls this.  (The reference scores in fp32: macr_mf/model.py:199.) */
-size_t macr_test_bf16_products_workspace_bytes(int d, int U, int N);
-int macr_test_bf16_products(int d, int U, int N, const float *users, const float *items, float c,
-                            float *prod, float *margin, void *workspace, size_t workspace_bytes, void *stream);
-
-/* TEST-ONLY: the same for the listing pass macr_score_topk runs (k_score_stream_c: the epilogue in the operand copies --
- * item rows scaled by sig_i, the bias -c*sig_i as a three-term bf16 slab in the last MFMA, query rows scaled for
- * DIRECT_MINUS_BOTH).  Writes the SCORE that pass would list for every (query, item) pair of the given kind, scores (dev)
- * fp32[U][N], and the margin per query; tests/ assert |scores - fp32 score| <= margin element-wise.  sig_u / sig_i (dev)
- * fp32[U] / [N] as the kind needs them. */
-size_t macr_test_bf16_scores_workspace_bytes(int d, int U, int N);
-int macr_test_bf16_scores(int score_kind, int d, int U, int N, const float *users, const float *items,
-                          const float *sig_u, const float *sig_i, float c, float *scores, float *margin,
                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* The train-item mask as the ranking kernels read it: mask_bits[tile][query] has bit (i % 32)
@@ -486,10 +468,13 @@ int macr_score_matrix(int score_kind, int U, int n_local, int d,
  * apt_evaluate_foldout.pyx:11-13).  scores (dev) fp32[rows*cols]; -inf entries
  * (masked train items, batch_test.py:129) rank last; ties by ascending index
  * (the reference leaves tie order to std::partial_sort_copy).
- * out_idx (dev) int32[rows*K], out_val (dev, may be NULL) fp32[rows*K].
+ * out_idx (dev) int32[rows*K], out_val (dev, may be NULL) fp32[rows*K].  Any K >= 1 (the reference's function has no
+ * bound on top_k; positions past the number of columns hold -1 / -inf); workspace (dev, may be NULL up to
+ * K = MACR_MAX_TOPK) >= macr_topk_scores_workspace_bytes(rows, K).
  * -------------------------------------------------------------------------*/
+size_t macr_topk_scores_workspace_bytes(int rows, int K);      /* 0 for K <= MACR_MAX_TOPK */
 int macr_topk_scores(const float *scores, int cols, int rows, int K,
-                     int32_t *out_idx, float *out_val, void *stream);
+                     int32_t *out_idx, float *out_val, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Merge W lists of K (score,id) pairs per query into one (new; also the merge

@@ -17,7 +17,7 @@ SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINU
 MAX_TOPK = 128
 MAX_TOPK_FUSED = 32
 MAX_SWEEP = 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class MacrError(RuntimeError):
@@ -63,21 +63,17 @@ SIGNATURES = {
     "macr_branch_sigmoid2": (_i, [_i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p]),
     "macr_score_topk_splits": (_i, [_i, _i, _i]),
     "macr_score_topk_uses_seeds": (_i, [_i, _i, _i]),
-    "macr_set_eval_filter": (_i, [_i]),
     "macr_score_topk_workspace_bytes": (_z, [_i, _i, _i]),
-    "macr_score_topk": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
-    "macr_score_topk_first_round": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
-    "macr_score_topk_repair_round": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "macr_score_topk": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "macr_score_topk_first_round": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "macr_score_topk_repair_round": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "macr_score_topk_sweep_workspace_bytes": (_z, [_i, _i, _i, _i]),
-    "macr_score_topk_sweep": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _z, _p]),
-    "macr_test_bf16_products_workspace_bytes": (_z, [_i, _i, _i]),
-    "macr_test_bf16_products": (_i, [_i, _i, _i, _p, _p, _f, _p, _p, _p, _z, _p]),
-    "macr_test_bf16_scores_workspace_bytes": (_z, [_i, _i, _i]),
-    "macr_test_bf16_scores": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p]),
+    "macr_score_topk_sweep": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _z, _p]),
     "macr_mask_bits_bytes": (_z, [_i, _i]),
     "macr_mask_bits_build": (_i, [_i, _i, _p, _p, _i, _p, _p]),
     "macr_score_matrix": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),
-    "macr_topk_scores": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "macr_topk_scores_workspace_bytes": (_z, [_i, _i]),
+    "macr_topk_scores": (_i, [_p, _i, _i, _i, _p, _p, _p, _z, _p]),
     "macr_topk_merge": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "macr_metrics_foldout": (_i, [_i, _i, _p, _p, _p, _p, _i, _p]),
     "macr_metrics_foldout_fill": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _i, _p]),
@@ -85,7 +81,34 @@ SIGNATURES = {
     "macr_colmean": (_i, [_p, _i, _i, _i, _p, _p]),
 }
 
+# include/macr_hip_test.h: entry points of libmacr_hip_test.so only (tests/); the product library exports none of them
+TEST_LIB_PATH = os.path.join(_HERE, "csrc", "libmacr_hip_test.so")
+TEST_SIGNATURES = {
+    "macr_test_bf16_products_workspace_bytes": (_z, [_i, _i, _i]),
+    "macr_test_bf16_products": (_i, [_i, _i, _i, _p, _p, _f, _p, _p, _p, _z, _p]),
+    "macr_test_bf16_scores_workspace_bytes": (_z, [_i, _i, _i]),
+    "macr_test_bf16_scores": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p]),
+}
+
 _lib = None
+_test = None
+
+
+def test_lib():
+    """libmacr_hip_test.so: the product sources + the test-only entry points (tests/ only)."""
+    global _test
+    if _test is None:
+        _load_hip_runtime_first()
+        if not os.path.exists(TEST_LIB_PATH):
+            raise RuntimeError("macr_amd: %s is missing; build it with `python -m macr_amd.build`" % TEST_LIB_PATH)
+        L = ctypes.CDLL(TEST_LIB_PATH)
+        for name, (res, args) in TEST_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        L.macr_last_error.restype = ctypes.c_char_p
+        _test = L
+    return _test
 
 
 def _load_hip_runtime_first():

@@ -47,13 +47,15 @@ int top_k_impl(const float *scores, int cols, int rows, int K, int *rankings) {
     const size_t row_bytes = (size_t)cols * sizeof(float);
     int slab = (int)std::max<size_t>(1, (size_t(256) << 20) / row_bytes);
     slab = std::min(slab, rows);
-    DevBuf d_scores, d_idx;
+    DevBuf d_scores, d_idx, d_ws;
+    const size_t ws_bytes = macr_topk_scores_workspace_bytes(slab, K);      // top_k above 128: rounds of 128 positions
     HIP_TRY(d_scores.alloc((size_t)slab * row_bytes), "hipMalloc(scores)");
     HIP_TRY(d_idx.alloc((size_t)slab * K * sizeof(int)), "hipMalloc(rankings)");
+    if (ws_bytes) HIP_TRY(d_ws.alloc(ws_bytes), "hipMalloc(workspace)");
     for (int r0 = 0; r0 < rows; r0 += slab) {
         const int n = std::min(slab, rows - r0);
         HIP_TRY(hipMemcpy(d_scores.p, scores + (size_t)r0 * cols, (size_t)n * row_bytes, hipMemcpyHostToDevice), "copy scores");
-        const int rc = macr_topk_scores(d_scores.as<float>(), cols, n, K, d_idx.as<int32_t>(), nullptr, nullptr);
+        const int rc = macr_topk_scores(d_scores.as<float>(), cols, n, K, d_idx.as<int32_t>(), nullptr, d_ws.p, ws_bytes, nullptr);
         if (rc != MACR_OK) return fail(rc, "c_top_k_array_index: %s", macr_last_error());
         HIP_TRY(hipMemcpy(rankings + (size_t)r0 * K, d_idx.p, (size_t)n * K * sizeof(int), hipMemcpyDeviceToHost), "copy rankings");
     }

@@ -2921,7 +2921,7 @@ __global__ __launch_bounds__(256) void k_topk_scores(const float *__restrict__ s
 }
 
 // ----------------------------------------------------------------------------
-// k_topk_scores_wide: the same for MACR_MAX_TOPK < K <= MACR_MAX_TOPK_SCORES (c_top_k_array_index has no bound on
+// k_topk_scores_wide: the same for MACR_MAX_TOPK_FUSED < K <= MACR_MAX_TOPK per round (c_top_k_array_index has no bound on
 // top_k, tools.h:13-22; the reference's CLIs use 20, its tuning scripts up to 100).  One wave per row; candidates above
 // the running threshold collect in a 256-key LDS buffer; when it could overflow, the K-th largest is found by the MSB-first
 // radix select on lane masks (four keys per lane) and the best K move to the front.  The final K are ordered by rank
@@ -3018,10 +3018,15 @@ __device__ __forceinline__ void admit_wide(uint64_t *keys, int &cnt, uint64_t &t
 
 // mask_bits (may be NULL): the (item tile, query) bitmap of macr_mask_bits_build with `mask_stride` queries; row r of the
 // matrix is query q0 + r; a masked column is no candidate at all (as in the fused ranking).  Ids leave as column + id_offset.
+// Rows may be ranked PAST 128 in rounds of <= 128 (macr_topk_scores with any K): a round writes positions out_off .. out_off + K - 1
+// of rows `out_stride` long, admits only keys below the row's `below` key (the last key of the round before; 0 = the row ran out
+// of candidates) and leaves its own last key in `last_key` -- the keys are a total order (score descending, id ascending), so the
+// rounds concatenate to exactly the ranking one pass with a larger buffer would give.
 __global__ __launch_bounds__(256) void k_topk_scores_wide(const float *__restrict__ scores, int cols, int rows, int K,
                                                           int32_t *__restrict__ out_idx, float *__restrict__ out_val,
                                                           const uint32_t *__restrict__ mask_bits, int mask_stride, int q0,
-                                                          int id_offset) {
+                                                          int id_offset, int out_stride, int out_off,
+                                                          const uint64_t *__restrict__ below, uint64_t *__restrict__ last_key) {
     __shared__ uint64_t s_keys[4][kWideCap];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wid;
@@ -3030,14 +3035,28 @@ __global__ __launch_bounds__(256) void k_topk_scores_wide(const float *__restric
     uint64_t *keys = s_keys[wid];
     int cnt = 0;
     uint64_t thr_key = 0ull;                        // admission: key > thr_key
+    const bool bounded = below != nullptr;
+    const uint64_t ceil_key = bounded ? below[row] : 0ull;
     for (int base = 0; base < cols; base += kWave) {
         const int cidx = base + lane;
         uint64_t key = cidx < cols ? make_key(src[cidx], cidx) : 0ull;
         if (mask_bits && cidx < cols && ((mask_bits[(size_t)(cidx >> 5) * mask_stride + q0 + row] >> (cidx & 31)) & 1u)) key = 0ull;
+        if (bounded && key >= ceil_key) key = 0ull;               // ranked by an earlier round (ceil_key 0: nothing is left)
         admit_wide(keys, cnt, thr_key, key, K);
     }
     if (keep_best_wide(keys, cnt, K)) cnt = K;
-    emit_wide(keys, cnt, K, out_idx + (size_t)row * K, out_val ? out_val + (size_t)row * K : nullptr, id_offset);
+    const size_t o = (size_t)row * out_stride + out_off;
+    emit_wide(keys, cnt, K, out_idx + o, out_val ? out_val + o : nullptr, id_offset);
+    if (last_key) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint64_t lo = ~0ull;
+        for (int e = lane; e < cnt; e += kWave) lo = keys[e] < lo ? keys[e] : lo;
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const uint64_t other = ((uint64_t)__shfl_xor((uint32_t)(lo >> 32), sft, kWave) << 32) | __shfl_xor((uint32_t)lo, sft, kWave);
+            lo = other < lo ? other : lo;
+        }
+        if (lane == 0) last_key[row] = cnt == K ? lo : 0ull;     // a short round: the row has no further candidates
+    }
 }
 
 // k_topk_merge for MACR_MAX_TOPK_FUSED < K <= MACR_MAX_TOPK: the W*K entries stream through the same 256-key buffer.
@@ -3441,15 +3460,10 @@ extern "C" size_t macr_score_topk_workspace_bytes(int U, int n_local, int d) {
     return carve_topk_ws(nullptr, U, n_local, stream_geo(U, n_local, d), d).bytes;
 }
 
-// 0 = follow MACR_EVAL_FILTER in the environment (default f32), 1 = f32, 2 = bf16
-static int g_eval_filter = 0;
-extern "C" int macr_set_eval_filter(int mode) {
-    MACR_REQUIRE(mode >= 0 && mode <= 2, MACR_E_INVALID, "set_eval_filter: mode=%d", mode);
-    g_eval_filter = mode;
-    return MACR_OK;
-}
-static bool eval_filter_bf16() {
-    if (g_eval_filter) return g_eval_filter == 2;
+// `filter` argument of the ranking entry points: MACR_EVAL_FILTER_ENV (0) follows MACR_EVAL_FILTER in the environment (f32 when
+// unset), MACR_EVAL_FILTER_F32 (1), MACR_EVAL_FILTER_BF16 (2).  Per call: the library keeps no filter state (abi 10).
+static bool eval_filter_bf16(int filter) {
+    if (filter) return filter == MACR_EVAL_FILTER_BF16;
     const char *e = getenv("MACR_EVAL_FILTER");
     return e && (e[0] == 'b' || e[0] == 'B');
 }
@@ -3522,7 +3536,7 @@ static inline bool score_kind_valid(int k) { return k >= MACR_SCORE_NORMAL && k 
 // mode 1 (macr_score_topk_first_round): the first round alone -- no repair round, no fallback kernel; stats tell whether
 // its result stands.  mode 2 (macr_score_topk_repair_round): what the complete call launches after the first round, on the
 // workspace a first-round call with the same arguments left behind.  mode 0: both.
-static int score_topk_impl(int mode, int score_kind, int U, int n_local, int d, const float *users_tab,
+static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_local, int d, const float *users_tab,
                            const int32_t *user_ids, const float *items, const float *sig_u,
                            const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
                            const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, const int32_t *seed_idx,
@@ -3531,6 +3545,7 @@ static int score_topk_impl(int mode, int score_kind, int U, int n_local, int d, 
     // MACR_TOPK_FALLBACK=1 in the environment runs the fallback kernel unconditionally (tests of that path)
     static const bool force_fallback = getenv("MACR_TOPK_FALLBACK") && getenv("MACR_TOPK_FALLBACK")[0] == '1';
     MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "score_topk: score_kind=%d", score_kind);
+    MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_BF16, MACR_E_INVALID, "score_topk: filter=%d", filter);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk: d=%d not in {32,64,128,256}", d);
     MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "score_topk: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
@@ -3553,7 +3568,7 @@ static int score_topk_impl(int mode, int score_kind, int U, int n_local, int d, 
     // workspace head: counts, flag, shared_thr <- 0; tau <- -inf on the list-everything path; maxima <- NaN
     const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
     // (a shard small enough to list everything has nothing to filter)
-    const bool filter_bf16 = !list_all && eval_filter_bf16();
+    const bool filter_bf16 = !list_all && eval_filter_bf16(filter);
     // class maxima start as NaN (= no unmasked item seen).  Under the bf16 filter the sampling pass may keep 16 per split and
     // query instead of 32 (merge_pairs below), and a seeded first round has no sampling pass at all: its repair round, if one
     // follows (macr_score_topk_repair_round), fills them itself.
@@ -3606,7 +3621,7 @@ static int score_topk_impl(int mode, int score_kind, int U, int n_local, int d, 
                                                 items, sig_u ? sig_u + q0 : nullptr, sig_i, c, c_dev, scores)));
             MACR_CHECK_LAUNCH("score_matrix", st);
             k_topk_scores_wide<<<(nq + 3) / 4, 256, 0, st>>>(scores, n_local, nq, K, out_idx + (size_t)q0 * K, out_val + (size_t)q0 * K,
-                                                             mask_bits, U, q0, item_offset);
+                                                             mask_bits, U, q0, item_offset, K, 0, nullptr, nullptr);
             MACR_CHECK_LAUNCH("topk_scores", st);
         }
         if (n_splits > 1) {
@@ -3793,18 +3808,18 @@ static int score_topk_impl(int mode, int score_kind, int U, int n_local, int d, 
     return MACR_OK;
 }
 
-extern "C" int macr_score_topk(int score_kind, int U, int n_local, int d, const float *users_tab,
+extern "C" int macr_score_topk(int score_kind, int filter, int U, int n_local, int d, const float *users_tab,
                                const int32_t *user_ids, const float *items, const float *sig_u,
                                const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
                                const uint32_t *mask_bits_in, int item_offset, int K, int n_splits, const int32_t *seed_idx,
                                int32_t *seed_out, float *out_val, int32_t *out_idx, int32_t *stats, void *workspace,
                                size_t workspace_bytes, void *stream) {
-    return score_topk_impl(0, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
+    return score_topk_impl(0, filter, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
                            mask_bits_in, item_offset, K, n_splits, seed_idx, seed_out, out_val, out_idx, stats, workspace,
                            workspace_bytes, stream);
 }
 
-extern "C" int macr_score_topk_first_round(int score_kind, int U, int n_local, int d, const float *users_tab,
+extern "C" int macr_score_topk_first_round(int score_kind, int filter, int U, int n_local, int d, const float *users_tab,
                                            const int32_t *user_ids, const float *items, const float *sig_u,
                                            const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr,
                                            const int32_t *mask_idx, const uint32_t *mask_bits_in, int item_offset, int K,
@@ -3812,19 +3827,19 @@ extern "C" int macr_score_topk_first_round(int score_kind, int U, int n_local, i
                                            int32_t *out_idx, int32_t *stats, void *workspace, size_t workspace_bytes,
                                            void *stream) {
     MACR_REQUIRE(stats, MACR_E_INVALID, "score_topk_first_round: stats is null (it says whether the result stands)");
-    return score_topk_impl(1, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
+    return score_topk_impl(1, filter, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
                            mask_bits_in, item_offset, K, n_splits, seed_idx, seed_out, out_val, out_idx, stats, workspace,
                            workspace_bytes, stream);
 }
 
-extern "C" int macr_score_topk_repair_round(int score_kind, int U, int n_local, int d, const float *users_tab,
+extern "C" int macr_score_topk_repair_round(int score_kind, int filter, int U, int n_local, int d, const float *users_tab,
                                             const int32_t *user_ids, const float *items, const float *sig_u,
                                             const float *sig_i, float c, const float *c_dev, const int32_t *mask_ptr,
                                             const int32_t *mask_idx, const uint32_t *mask_bits_in, int item_offset, int K,
                                             int n_splits, const int32_t *seed_idx, int32_t *seed_out, float *out_val,
                                             int32_t *out_idx, int32_t *stats, void *workspace, size_t workspace_bytes,
                                             void *stream) {
-    return score_topk_impl(2, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
+    return score_topk_impl(2, filter, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
                            mask_bits_in, item_offset, K, n_splits, seed_idx, seed_out, out_val, out_idx, stats, workspace,
                            workspace_bytes, stream);
 }
@@ -3836,13 +3851,14 @@ extern "C" size_t macr_score_topk_sweep_workspace_bytes(int U, int n_local, int 
     return (size_t)n_c * align_up(carve_topk_ws(nullptr, U, n_local, geo, d).bytes, 256);
 }
 
-extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, const float *users_tab,
+extern "C" int macr_score_topk_sweep(int score_kind, int filter, int U, int n_local, int d, const float *users_tab,
                                      const int32_t *user_ids, const float *items, const float *sig_u, const float *sig_i,
                                      int n_c, const float *c_dev, const int32_t *mask_ptr, const int32_t *mask_idx,
                                      const uint32_t *mask_bits_in, int item_offset, int K, float *out_val, int32_t *out_idx,
                                      void *workspace, size_t workspace_bytes, void *stream) {
     MACR_REQUIRE(score_kind_valid(score_kind) && score_uses_sig_i(score_kind), MACR_E_INVALID,
                  "score_topk_sweep: score_kind=%d does not depend on c", score_kind);
+    MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_BF16, MACR_E_INVALID, "score_topk_sweep: filter=%d", filter);
     MACR_REQUIRE(n_c >= 1 && n_c <= kMaxSweep, MACR_E_UNSUPPORTED, "score_topk_sweep: n_c=%d outside [1,%d]", n_c, kMaxSweep);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk_sweep: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk_sweep: d=%d not in {32,64,128,256}", d);
@@ -3873,7 +3889,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int U, int n_local, int d, 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
         MACR_REQUIRE(e == hipSuccess, MACR_E_LAUNCH, "score_topk_sweep: cannot reserve %zu B of LDS: %s", smem1, hipGetErrorString(e));
-        const bool filter_bf16 = !list_all && eval_filter_bf16();
+        const bool filter_bf16 = !list_all && eval_filter_bf16(filter);
         uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws[0].overflow + 8);      // (value 0's workspace holds the operand copies)
         const size_t smem_b = StreamCfgB<D>::smem, smem_bs = StreamCfgB<D>::smem + (size_t)(kMaxSweep - 1) * kUsersPerBlock * 4;
         if (filter_bf16) {
@@ -3970,6 +3986,8 @@ extern "C" int macr_score_matrix(int score_kind, int U, int n_local, int d, cons
     return MACR_OK;
 }
 
+#ifdef MACR_TEST_ENTRY_POINTS       // libmacr_hip_test.so only (include/macr_hip_test.h)
+#include "../../include/macr_hip_test.h"
 extern "C" size_t macr_test_bf16_products_workspace_bytes(int d, int U, int N) {
     if (!dim_supported(d) || U <= 0 || N <= 0) return 0;
     return align_up((size_t)U * 4 * d, 256) + align_up((size_t)N * 4 * d, 256) + align_up((size_t)U * 4, 256) + 256;
@@ -4031,15 +4049,33 @@ extern "C" int macr_test_bf16_scores(int score_kind, int d, int U, int N, const 
     MACR_CHECK_LAUNCH("test_bf16_scores", st);
     return MACR_OK;
 }
+#endif  // MACR_TEST_ENTRY_POINTS
+
+extern "C" size_t macr_topk_scores_workspace_bytes(int rows, int K) {
+    return (rows > 0 && K > MACR_MAX_TOPK) ? align_up((size_t)rows * sizeof(uint64_t), 256) : 0;
+}
 
 extern "C" int macr_topk_scores(const float *scores, int cols, int rows, int K, int32_t *out_idx,
-                                float *out_val, void *stream) {
+                                float *out_val, void *workspace, size_t workspace_bytes, void *stream) {
     hipStream_t st = as_stream(stream);
     MACR_REQUIRE(scores && out_idx, MACR_E_INVALID, "topk_scores: null pointer");
     MACR_REQUIRE(cols > 0 && rows > 0, MACR_E_INVALID, "topk_scores: cols=%d rows=%d", cols, rows);
-    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK_SCORES, MACR_E_UNSUPPORTED, "topk_scores: K=%d outside [1,%d]", K, MACR_MAX_TOPK_SCORES);
+    MACR_REQUIRE(K >= 1, MACR_E_INVALID, "topk_scores: K=%d", K);
     if (K <= MACR_MAX_TOPK_FUSED) k_topk_scores<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val);
-    else k_topk_scores_wide<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val, nullptr, 0, 0, 0);
+    else if (K <= MACR_MAX_TOPK) k_topk_scores_wide<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, K, out_idx, out_val, nullptr, 0, 0, 0, K, 0, nullptr, nullptr);
+    else {
+        // c_top_k_array_index takes any top_k (tools.h:13-22): rounds of 128 positions, each bounded by the last key of the one before
+        MACR_REQUIRE(workspace && workspace_bytes >= macr_topk_scores_workspace_bytes(rows, K), MACR_E_WORKSPACE,
+                     "topk_scores: K=%d > %d needs a workspace of %zu bytes (macr_topk_scores_workspace_bytes)", K, MACR_MAX_TOPK,
+                     macr_topk_scores_workspace_bytes(rows, K));
+        uint64_t *last = static_cast<uint64_t *>(workspace);
+        for (int off = 0; off < K; off += MACR_MAX_TOPK) {
+            const int k = std::min(MACR_MAX_TOPK, K - off);
+            k_topk_scores_wide<<<(rows + 3) / 4, 256, 0, st>>>(scores, cols, rows, k, out_idx, out_val, nullptr, 0, 0, 0, K, off,
+                                                                off ? last : nullptr, last);
+            MACR_CHECK_LAUNCH("topk_scores", st);
+        }
+    }
     MACR_CHECK_LAUNCH("topk_scores", st);
     return MACR_OK;
 }

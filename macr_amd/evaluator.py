@@ -33,7 +33,7 @@ class Evaluator(object):
         self.max_queries_per_pass = 131072       # bounds the ranking workspace (~1.5 GB of candidate lists)
         self.use_graph = os.environ.get("MACR_EVAL_GRAPH", "1") != "0"    # replay the evaluation as one HIP graph (_means)
         self.use_seeds = os.environ.get("MACR_EVAL_SEEDS", "1") != "0"    # thresholds from the previous top K (rank_local)
-        # candidate filter of the listing pass (include/macr_hip.h MACR_EVAL_FILTER_*): "bf16" = two-term bf16 products on
+        # candidate filter of the listing pass, an argument of every ranking call (include/macr_hip.h MACR_EVAL_FILTER_*): "bf16" = two-term bf16 products on
         # the bf16 matrix cores + fp32 re-scoring of the best candidates, "f32" = fp32 products throughout.  The ranking
         # is the fp32 ranking bit for bit either way; MACR_EVAL_FILTER in the environment overrides the default.
         self.filter = os.environ.get("MACR_EVAL_FILTER", "bf16").strip().lower()
@@ -115,7 +115,6 @@ class Evaluator(object):
             if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH):
                 sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199,:201
         U = self.n_queries
-        ops.set_eval_filter(self.filter)                          # (process-wide switch, read when the launches are issued)
         if U <= self.max_queries_per_pass:
             # Seeds: the ids this shard returned last time (same queries, tables that moved by a few training steps).
             # Their exact current scores bound every query's K-th best score from below far more tightly than a
@@ -135,7 +134,7 @@ class Evaluator(object):
             vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, mask, lo,
                                        seed=seed if seeded else None, seed_out=seed,
                                        stats=self._stats_first if mode else self._stats, first_round=mode == "first",
-                                       repair_of=self._repair_bufs if mode == "repair" else None)
+                                       repair_of=self._repair_bufs if mode == "repair" else None, filter=self.filter)
         else:
             # the ranking workspace (candidate lists, mask bitmap) grows with the number of queries: rank them in
             # chunks; every query is independent of the chunking
@@ -145,7 +144,7 @@ class Evaluator(object):
                 uid = user_ids[a:b] if user_ids is not None else torch.arange(a, b, dtype=torch.int32, device=self.device)
                 mask = self._mask_local if self._local_own is not None else self.mask
                 parts.append(ops.score_topk(kind, users_tab, uid, items_local, K, None if sig_u is None else sig_u[a:b],
-                                            sig_i, c, mask.row_range(a, b), lo))
+                                            sig_i, c, mask.row_range(a, b), lo, filter=self.filter))
             vals = torch.cat([p[0] for p in parts], dim=1)
             idx = torch.cat([p[1] for p in parts], dim=1)
         if self._local_own is not None:           # local row -> item id (the order by id within the shard is the same either way)
@@ -403,10 +402,10 @@ class Evaluator(object):
 
     # ------------------------------------------------------------------ c sweep (tuners)
     def _sweep_direct(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c_dev):
-        ops.set_eval_filter(self.filter)          # (process-wide switch, read when the launches are issued)
         sig_i = ops.branch_sigmoid(items_tab, w)
         sig_u = ops.branch_sigmoid(users_tab, wu, user_ids) if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH) else None
-        vals, idx = ops.score_topk_sweep(kind, users_tab, user_ids, items_tab, max(Ks), sig_u, sig_i, c_dev, self.mask, 0)
+        vals, idx = ops.score_topk_sweep(kind, users_tab, user_ids, items_tab, max(Ks), sig_u, sig_i, c_dev, self.mask, 0,
+                                         filter=self.filter)
         return torch.stack([self._finish(flavour, vals[g:g + 1], idx[g:g + 1], Ks) for g in range(c_dev.numel())])
 
     def sweep_means(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, cs):

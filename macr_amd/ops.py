@@ -206,11 +206,24 @@ def eval_filter_code(mode):
     raise MacrError(_lib.E_INVALID, "eval filter %r: accepted values are 'env', 'f32', 'bf16' (or 0, 1, 2)" % (mode,))
 
 
+_default_filter = EVAL_FILTER_ENV
+
+
 def set_eval_filter(mode):
-    """How macr_score_topk's listing pass forms its candidate lists (include/macr_hip.h MACR_EVAL_FILTER_*): "f32", "bf16"
-    (bf16 matrix cores + fp32 re-scoring of the best candidates: the same ranking, bit for bit) or "env" (default:
-    MACR_EVAL_FILTER in the environment, f32 when unset)."""
-    check(_lib.lib().macr_set_eval_filter(eval_filter_code(mode)))
+    """The filter ranking calls of THIS MODULE pass when their caller names none (`filter=None`): "f32", "bf16" or "env"
+    (MACR_EVAL_FILTER in the environment, f32 when unset).  Host-side convenience for tests and tools; the C ABI takes the
+    filter per call (include/macr_hip.h, abi 10) and keeps no state."""
+    global _default_filter
+    _default_filter = eval_filter_code(mode)
+
+
+def _filter_arg(filter):
+    return _default_filter if filter is None else eval_filter_code(filter)
+
+
+def _check_test(rc):
+    if rc != _lib.OK:
+        raise MacrError(rc, _lib.test_lib().macr_last_error().decode("utf-8", "replace"))
 
 
 def test_bf16_products(users, items, c=0.0):
@@ -219,11 +232,11 @@ def test_bf16_products(users, items, c=0.0):
     _require_f32(users=users, items=items)
     U, d = users.shape
     N = items.shape[0]
-    L = _lib.lib()
+    L = _lib.test_lib()
     ws = torch.empty(L.macr_test_bf16_products_workspace_bytes(d, U, N), dtype=torch.uint8, device=items.device)
     prod = torch.empty((U, N), dtype=_f32, device=items.device)
     margin = torch.empty(U, dtype=_f32, device=items.device)
-    check(L.macr_test_bf16_products(d, U, N, _ptr(users, _f32), _ptr(items, _f32), float(c), _ptr(prod), _ptr(margin),
+    _check_test(L.macr_test_bf16_products(d, U, N, _ptr(users, _f32), _ptr(items, _f32), float(c), _ptr(prod), _ptr(margin),
                                     _ptr(ws), ws.numel(), _stream()))
     return prod, margin
 
@@ -234,11 +247,11 @@ def test_bf16_scores(kind, users, items, sig_u=None, sig_i=None, c=0.0):
     _require_f32(users=users, items=items)
     U, d = users.shape
     N = items.shape[0]
-    L = _lib.lib()
+    L = _lib.test_lib()
     ws = torch.empty(L.macr_test_bf16_scores_workspace_bytes(d, U, N), dtype=torch.uint8, device=items.device)
     out = torch.empty((U, N), dtype=_f32, device=items.device)
     margin = torch.empty(U, dtype=_f32, device=items.device)
-    check(L.macr_test_bf16_scores(kind, d, U, N, _ptr(users, _f32), _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
+    _check_test(L.macr_test_bf16_scores(kind, d, U, N, _ptr(users, _f32), _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
                                   float(c), _ptr(out), _ptr(margin), _ptr(ws), ws.numel(), _stream()))
     return out, margin
 
@@ -264,12 +277,14 @@ def _c_args(c):
 
 
 def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.0, mask=None,
-               item_offset=0, n_splits=0, seed=None, seed_out=None, stats=None, first_round=False, repair_of=None):
+               item_offset=0, n_splits=0, seed=None, seed_out=None, stats=None, first_round=False, repair_of=None,
+               filter=None):
     """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K).
     c: python float, or a 1-element fp32 device tensor (read at run time: graph replays follow its value).
     seed: optional (U, SEED_WIDTH) int32 device tensor of global item ids per query -- what seed_out received last time:
     thresholds then come from the seeds' exact scores instead of a sampling pass -- same result, less time.
     seed_out: optional (U, SEED_WIDTH) int32 device tensor <- the best candidates per query (may be `seed` itself).
+    filter: "f32" | "bf16" | "env" candidate filter of the listing pass (None: this module's default, set_eval_filter).
     stats: optional int32[2] device (or pinned host) tensor <- (query blocks listed twice because a threshold was too
     loose, 1 if the exact fallback kernel ran).
     first_round: macr_score_topk_first_round -- the first round alone, without the launches of the repair round and the
@@ -298,7 +313,7 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     fn = _lib.lib().macr_score_topk_first_round if first_round else _lib.lib().macr_score_topk
     if repair_of is not None:
         fn = _lib.lib().macr_score_topk_repair_round
-    check(fn(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
+    check(fn(kind, _filter_arg(filter), U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
              _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
              cv, cp, mp, mi, mb, item_offset, K, n_splits, _ptr(seed, _i32, True), _ptr(seed_out, _i32, True), _ptr(vals), _ptr(idx),
              _ptr_visible(stats, _i32, True), _ptr(ws), ws.numel(), _stream()))
@@ -308,7 +323,7 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
 _sweep_ws_cache = {}
 
 
-def score_topk_sweep(kind, users_tab, user_ids, items, K, sig_u, sig_i, c_dev, mask=None, item_offset=0):
+def score_topk_sweep(kind, users_tab, user_ids, items, K, sig_u, sig_i, c_dev, mask=None, item_offset=0, filter=None):
     """The fused ranking for SEVERAL values of c with ONE listing pass (macr_score_topk_sweep; tune.py:545-578).
     c_dev: fp32 device tensor of 1.._lib.MAX_SWEEP values.  Returns (vals, idx) of shape (n_c, U, K)."""
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
@@ -323,7 +338,7 @@ def score_topk_sweep(kind, users_tab, user_ids, items, K, sig_u, sig_i, c_dev, m
     ws = _sweep_ws_cache.get(items.device)
     if ws is None or ws.numel() < need:
         ws = _sweep_ws_cache[items.device] = torch.empty(need, dtype=torch.uint8, device=items.device)
-    check(_lib.lib().macr_score_topk_sweep(kind, U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
+    check(_lib.lib().macr_score_topk_sweep(kind, _filter_arg(filter), U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
                                            _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32), n_c,
                                            _ptr(c_dev, _f32), mp, mi, mb, item_offset, K, _ptr(vals), _ptr(idx),
                                            _ptr(ws), ws.numel(), _stream()))
@@ -342,11 +357,16 @@ def score_matrix(kind, users_tab, user_ids, items, sig_u=None, sig_i=None, c=0.0
 
 
 def topk_scores(scores, K, want_vals=True):
-    """Top-K column ids of every row (replaces c_top_k_array_index, tools.h:24)."""
+    """Top-K column ids of every row (replaces c_top_k_array_index, tools.h:24); any K >= 1, as the reference's."""
     rows, cols = scores.shape
+    if K < 1:
+        raise MacrError(_lib.E_INVALID, "topk_scores: K=%d" % K)
     idx = torch.empty((rows, K), dtype=_i32, device=scores.device)
     val = torch.empty((rows, K), dtype=_f32, device=scores.device) if want_vals else None
-    check(_lib.lib().macr_topk_scores(_ptr(scores, _f32), cols, rows, K, _ptr(idx), _ptr(val, None, True), _stream()))
+    need = _lib.lib().macr_topk_scores_workspace_bytes(rows, K)
+    ws = torch.empty(need, dtype=torch.uint8, device=scores.device) if need else None
+    check(_lib.lib().macr_topk_scores(_ptr(scores, _f32), cols, rows, K, _ptr(idx), _ptr(val, None, True),
+                                      _ptr(ws, None, True), need, _stream()))
     return idx, val
 
 

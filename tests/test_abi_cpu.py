@@ -32,16 +32,41 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(_lib.SIGNATURES) == names          # the ctypes table mirrors the header exactly
 
 
+def test_test_only_entry_points_live_in_their_own_library(lib):
+    """include/macr_hip_test.h: exported by libmacr_hip_test.so (what tests load), by the product library not at all"""
+    src = open(os.path.join(REPO, "include", "macr_hip_test.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(macr_[a-z0-9_]+)\s*\(", src)))
+    assert declared == sorted(_lib.TEST_SIGNATURES) and len(declared) == 4
+    T = _lib.test_lib()
+    for name in declared:
+        assert hasattr(T, name), name
+        assert not hasattr(lib, name), "%s must not ship in libmacr_hip.so" % name
+    assert not any(n.startswith("macr_test_") for n in header_symbols())
+    assert T.macr_abi_version() == _lib.ABI_VERSION          # the same sources, the same ABI
+
+
+def test_ranking_calls_take_the_filter_per_call(lib):
+    """abi 10: no process-wide filter switch; an out-of-range filter is refused before any device work"""
+    assert not hasattr(lib, "macr_set_eval_filter")
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.macr_score_topk(_lib.SCORE_NORMAL, 7, 4, 4, 64, p, None, p, None, None, 0.0, None, None, None, None, 0, 2, 1, None, None,
+                             p, p, None, p, 1 << 20, None)
+    assert rc == _lib.E_INVALID and b"filter=7" in lib.macr_last_error(), lib.macr_last_error()
+
+
 def test_version_and_error_plumbing(lib):
     assert lib.macr_abi_version() == _lib.ABI_VERSION
     assert b"gfx950" in lib.macr_build_info()
     # argument validation happens before any device work, so it is checkable without a GPU
-    rc = lib.macr_topk_scores(None, 10, 10, 20, None, None, None)
+    rc = lib.macr_topk_scores(None, 10, 10, 20, None, None, None, 0, None)
     assert rc == _lib.E_INVALID and b"null pointer" in lib.macr_last_error()
     buf = ctypes.create_string_buffer(64)
     p = ctypes.cast(buf, ctypes.c_void_p)
-    rc = lib.macr_topk_scores(p, 10, 10, 129, p, None, None)       # K > MACR_MAX_TOPK_SCORES
-    assert rc == _lib.E_UNSUPPORTED
+    rc = lib.macr_topk_scores(p, 10, 10, 129, p, None, None, 0, None)       # any K, but past 128 it wants its scratch
+    assert rc == _lib.E_WORKSPACE and lib.macr_topk_scores_workspace_bytes(10, 129) >= 80
+    assert lib.macr_topk_scores_workspace_bytes(10, 128) == 0
     rc = lib.macr_branch_sigmoid(p, None, 1, 48, p, p, None)
     assert rc == _lib.E_UNSUPPORTED and b"d=48" in lib.macr_last_error()
     assert lib.macr_mf_train_workspace_bytes(4096, 64) > 0

@@ -929,11 +929,16 @@ def test_golden_cpp_evaluator_cases_through_the_reference_abi(golden_dir):
     # no error channel in the reference: a failed call poisons its output and sets the status
     bad = np.zeros((2, 200), np.float32)
     out = np.zeros((2, 200), np.int32)
-    L.c_top_k_array_index(bad.ctypes.data, 200, 2, 200, 1, out.ctypes.data)         # top_k > MACR_MAX_TOPK_SCORES
-    assert L.macr_eval_compat_status() != 0 and (out == -1).all()
+    L.c_top_k_array_index(bad.ctypes.data, 200, 2, 0, 1, out.ctypes.data)           # top_k = 0
+    assert L.macr_eval_compat_status() != 0
+    L.c_top_k_array_index(None, 200, 2, 20, 1, out.ctypes.data)
+    assert L.macr_eval_compat_status() != 0 and (out[:, :20] == -1).all()
     # top_k beyond 32 (tools.h:13-22 has no bound; the tuning scripts rank 100): the wide kernel, same tie rule
     rs = np.random.RandomState(3)
-    for cols, k in [(744, 100), (90, 64), (5000, 128), (50, 50), (33, 33)]:
+    # ... and beyond 128 (round 5: rounds of 128 positions bounded by the last key of the round before -- any rank_len, as
+    # evaluate_foldout.h:115-118 and tools.h:24 take it), through the metrics too
+    for cols, k in [(744, 100), (90, 64), (5000, 128), (50, 50), (33, 33), (5000, 129), (744, 300), (40981, 500), (700, 700),
+                    (260, 257)]:
         sc = rs.standard_normal((37, cols)).astype(np.float32)
         sc[:, ::7] = np.round(sc[:, ::7])                                            # ties
         sc[3, : cols // 2] = -np.inf
@@ -942,11 +947,21 @@ def test_golden_cpp_evaluator_cases_through_the_reference_abi(golden_dir):
         assert L.macr_eval_compat_status() == 0, L.macr_eval_compat_error()
         want = oracle.topk_scores(sc, k)[1]
         assert np.array_equal(out, want), (cols, k)
+        if k > 128:
+            lens = np.full(37, 9, np.int32)
+            rows_gt = [np.ascontiguousarray(rs.choice(cols, 9, replace=False).astype(np.int32)) for _ in range(37)]
+            ptrs = (ctypes.c_void_p * 37)(*[r.ctypes.data for r in rows_gt])
+            res = np.zeros((37, 5 * k), np.float32)
+            L.evaluate_foldout(37, out.ctypes.data, k, ctypes.cast(ptrs, ctypes.c_void_p), lens.ctypes.data, 4, res.ctypes.data)
+            assert L.macr_eval_compat_status() == 0, L.macr_eval_compat_error()
+            gp = np.arange(0, 9 * 37 + 1, 9, dtype=np.int32)
+            ref = oracle.metrics_foldout(out, (gp, np.concatenate([np.sort(r) for r in rows_gt]).astype(np.int32)))
+            np.testing.assert_allclose(res, ref, rtol=2e-7, atol=0)
 
 
 def test_errors_are_loud(ops):
     with pytest.raises(ops.MacrError):
-        ops.topk_scores(dev(np.zeros((2, 5), np.float32)), 129)             # K > MACR_MAX_TOPK_SCORES
+        ops.topk_scores(dev(np.zeros((2, 5), np.float32)), 0)               # K < 1
     with pytest.raises(ops.MacrError):
         ops.branch_sigmoid(dev(np.zeros((4, 48), np.float32)), dev(np.zeros(48, np.float32)))   # unsupported d
     with pytest.raises(ops.MacrError):
