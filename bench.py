@@ -672,6 +672,65 @@ def cpu_baseline_mf(args, kind, cfg, P, Q, w, wu, hb, users, mask_lists, gt_list
             "eval_users_per_s": max(v for k_, v in ev.items() if isinstance(v, float)), "eval_implementations": ev}
 
 
+def roofline_bxb(workload, B, kern_avg):
+    """The (B,B) launch against ITS bound: VALU issue ("transcendental VALU -- not HBM, not MFMA").
+    Instruction counts per launch come from the PMC passes of the same command (profiles/pmc_sq_latest.json: SQ_INSTS_VALU,
+    SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, separate rocprofv3 --pmc runs), the share of transcendentals from the static mix of the
+    kernel's two pair loops (profiles/bxb_isa_mix.json, tools/isa_mix.py on the shipped code object), the issue cost of each class
+    from tools/valu_rate_bench.hip on this chip (profiles/valu_rates.json; defaults: 4 cycles a full-rate or packed wave64
+    instruction, 16 a transcendental).  issue_limit_us = sum over classes of count x cycles / 1024 SIMDs / 2.4 GHz peak clock;
+    frac = issue_limit_us / measured time: 1.0 = the launch takes exactly what issuing its own instructions costs."""
+    def load(name):
+        path = os.path.join(REPO, "profiles", name)
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    sq = (load("pmc_sq_latest.json") or {}).get(workload, {})
+    mix = load("bxb_isa_mix.json") or {}
+    rates = load("valu_rates.json") or {}
+    out = {"bound": "valu-issue", "pairs": B * B, "fused_bce_evaluations": 2 * B * B, "simds": 1024, "peak_clock_ghz": 2.4}
+    # static mix: the kernel's two pair loops (6- and 4-transcendental forms), R = 4 rows per lane
+    loops = []
+    for name, k in mix.items():
+        if "k_bxbILi4ELb1ELb0E" in name or (B > 4096 and "k_bxbILi4ELb1ELb0E" in name):
+            loops = [l for l in k["loops"] if l["mix"].get("valu_trans", 0) >= 8][:2]
+    if loops:
+        share = [l["trans_share_of_valu"] for l in loops]
+        out["static_mix"] = {"loops": [{"valu": l["valu_total"], "trans": l["mix"].get("valu_trans", 0), "packed": l["mix"].get("valu_packed", 0),
+                                        "pairs_per_lane_trip": l["mix"].get("valu_trans", 0) // (6 if l is loops[0] else 4) or None} for l in loops],
+                             "trans_share_of_valu": {"six_transcendental_form": share[0], "four_transcendental_form": share[-1]}}
+    cls = (rates.get("classes") or {}).get("waves_per_simd_2", {})
+    cyc_full = cls.get("v_fma_f32", {}).get("cycles_at_2p4GHz", 4.0)
+    cyc_pk = cls.get("v_pk_fma_f32", {}).get("cycles_at_2p4GHz", 4.0)
+    cyc_tr = cls.get("v_exp_f32", {}).get("cycles_at_2p4GHz", 16.0)
+    out["issue_cycles_per_wave_instr"] = {"full_rate": cyc_full, "packed_f32": cyc_pk, "transcendental": cyc_tr,
+                                          "source": "profiles/valu_rates.json" if cls else "defaults (no measurement committed)"}
+    for variant in ("bxb", "bxb+adam"):
+        if variant not in kern_avg:
+            continue
+        e = {"avg_us": kern_avg[variant]["avg_us"]}
+        c = sq.get(variant)
+        if c and loops:
+            insts = c["SQ_INSTS_VALU"]
+            e["valu_wave_insts_per_launch"] = insts
+            e["valu_thread_insts_per_pair"] = insts * 64.0 / (B * B)
+            # bounds of the launch's issue time: every pair through the 4-transcendental form ... through the 6-transcendental form
+            lim = {}
+            for form, l in (("six", loops[0]), ("four", loops[-1])):
+                v, t, pk = l["valu_total"], l["mix"].get("valu_trans", 0), l["mix"].get("valu_packed", 0)
+                per_inst = ((v - t - pk) * cyc_full + pk * cyc_pk + t * cyc_tr) / v
+                lim[form] = insts * per_inst / 1024.0 / 2.4e3
+            e["issue_limit_us"] = {"all_pairs_six_transcendental_form": lim["six"], "all_pairs_four_transcendental_form": lim["four"]}
+            e["frac"] = {"vs_six_form": lim["six"] / e["avg_us"], "vs_four_form": lim["four"] / e["avg_us"]}
+            if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
+                e["pmc"] = {k_: c[k_] for k_ in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES",
+                                                 "SQ_INSTS_VALU_TRANS_F32", "avg_ns_under_pmc") if k_ in c}
+        e["gevals_per_s"] = 2.0 * B * B / (e["avg_us"] * 1e-6) / 1e9
+        out[variant] = e
+    return out
+
+
 def self_launch(n):
     """Re-run this script as n ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n
     --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>.  Exits with the launcher's status."""
@@ -1098,7 +1157,9 @@ def main():
                               "reported": "median", "min_ms_per_step": 1e3 * min(regions) / args.steps,
                               "max_ms_per_step": 1e3 * max(regions) / args.steps},
             "step_kernel_us": step_kernel_us, "event_overhead_us_per_launch": event_overhead_us, "kernels": kern_avg,
-            "roofline": roofline, "roofline_step": roofline_step, "roofline_aux": aux, "end_to_end": end_to_end,
+            "roofline": roofline, "roofline_step": roofline_step, "roofline_aux": aux,
+            "roofline_bxb": roofline_bxb(args.workload, B, kern_avg) if kind == ops.LOSS_RUBIBCEBOTH else None,
+            "end_to_end": end_to_end,
             "roofline_eval": roofline_eval, "roofline_eval_bf16": roofline_eval_bf16, "cpu_baseline": cpu,
             "last_losses": [float(x) for x in losses[(args.warmup + args.steps - 1) % n_batches]],
         }

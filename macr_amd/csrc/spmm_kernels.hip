@@ -154,6 +154,15 @@ __device__ __forceinline__ float ld_elem_v(const float *__restrict__ X, int c, u
 
 __device__ __forceinline__ bool row_flag(const int32_t *cnt, int r) { return cnt[r] != 0; }
 
+#ifdef MACR_SPMM_TRACE                                            // kernel-development probe (tools/spmm_bench.hip): per-wave phase stamps
+__device__ unsigned long long g_spmm_trace[1 << 17][8];
+#define SPMM_STAMP(w_, k_) do { if (lane == 0 && (w_) < (1 << 17)) g_spmm_trace[(w_)][(k_)] = __builtin_readcyclecounter(); } while (0)
+#define SPMM_STAMP_RT(w_, k_) do { if (lane == 0 && (w_) < (1 << 17)) g_spmm_trace[(w_)][(k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SPMM_STAMP(w_, k_) do {} while (0)
+#define SPMM_STAMP_RT(w_, k_) do {} while (0)
+#endif
+
 // Lane geometry: D >= 64: lane l holds columns l + 64 v (v < NV), one entry per step; D = 32: lane l holds column
 // l % 32, the half-waves take alternate entries (two per step).
 template <int D> struct RowGeom {
@@ -217,6 +226,7 @@ __device__ __forceinline__ void gather_batches(const int32_t *__restrict__ col, 
         for (int v = 0; v < G::NV; ++v) acc[v] = fmaf(w[k], x[k][v], acc[v]);
     }
 }
+
 
 // The same for a ROW-SPARSE X: `m` marks the chunk's entries whose source row is active; the steps walk its set bits in
 // ascending order (when the mask runs out, the last entry is repeated with weight 0).
@@ -327,10 +337,19 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
     };
     const int w = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (w >= total) return;
+#ifdef MACR_SPMM_TRACE
+    const unsigned long long tr_rt0 = __builtin_amdgcn_s_memrealtime(), tr_c0 = __builtin_readcyclecounter();
+#endif
     const int4 cur = fetch(w);
     const int r = cur.x, beg = cur.y, slot = cur.w;
     int end = cur.z;
     if (r < 0) return;
+#ifdef MACR_SPMM_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SPMM_STAMP(w, 2);
+    if (lane == 0 && w < (1 << 17)) { g_spmm_trace[w][0] = tr_rt0; g_spmm_trace[w][1] = tr_c0; g_spmm_trace[w][3] = 0;
+        g_spmm_trace[w][7] = ((unsigned long long)(unsigned)(end - beg) << 32) | (unsigned)(slot >= 0); }
+#endif
     const bool s_on = (A.S_out || FUSE) && (SPARSE != kSparseIn || row_flag(A.sp.rows, r));   // else S_in[r] counts as zero
     float s[NV];
 #pragma unroll
@@ -386,6 +405,9 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
 #endif
         for (int pos = beg; pos < end; pos += MAXNB * EPB) {    // wave-uniform
             const int left = end - pos;
+#ifdef MACR_SPMM_TRACE
+            if (pos == beg + MAXNB * EPB) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SPMM_STAMP(w, 3); }   // first window done
+#endif
             if (pos + MAXNB * EPB - 1 > last) {                 // (a window that could leave the arrays)
                 for (int q = pos; q < end && q < pos + MAXNB * EPB; q += EPB)
                     gather_batches<D, 1, true>(col, val, q, end - q, last, X, lane, acc);
@@ -397,6 +419,10 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
         }
     }
     if (G::kHalf) acc[0] += __shfl_xor(acc[0], 32, kWave);
+#ifdef MACR_SPMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SPMM_STAMP(w, 4);                                             // all gathers consumed
+#endif
 #ifdef MACR_ABL_SPMM_NOPIECE
     if (slot >= 0) return;
 #endif
@@ -510,6 +536,10 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
             if (A.S_out) A.S_out[o] = (s[v] + acc[v]) * A.scale;
         }
     }
+#ifdef MACR_SPMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SPMM_STAMP(w, 5); SPMM_STAMP_RT(w, 6);
+#endif
 }
 
 // =====================================================================================================================

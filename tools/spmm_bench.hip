@@ -118,6 +118,42 @@ int main(int argc, char **argv) {
             fprintf(stderr, "\n");
         }
     }
+#ifdef MACR_SPMM_TRACE
+    {   // phase stamps of the LAST launch (the last dense layer): per class of row length, the mean cycles of each phase of a wave's
+        // life, and how many waves were resident over the launch (100 MHz real-time stamps)
+        const PlanHeader *phh = reinterpret_cast<const PlanHeader *>(plan.data());
+        std::vector<unsigned long long> tr((size_t)(1 << 17) * 8);
+        CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(macr::g_spmm_trace), tr.size() * 8));
+        const int nw = std::min(phh->n_items, 1 << 17);   // (bundle waves have ids below n_items too)
+        struct Acc { double n = 0, desc = 0, first = 0, rest = 0, store = 0, total = 0, entries = 0; };
+        std::map<int, Acc> cls;
+        unsigned long long t_min = ~0ull, t_max = 0;
+        for (int w = 0; w < nw; ++w) { const auto *t = &tr[(size_t)w * 8]; if (t[0] && t[6]) { t_min = std::min(t_min, t[0]); t_max = std::max(t_max, t[6]); } }
+        std::vector<int> resident((size_t)(t_max - t_min) + 2, 0);
+        for (int w = 0; w < nw; ++w) {
+            const auto *t = &tr[(size_t)w * 8];
+            if (!t[0] || !t[6]) continue;
+            const int len = (int)(t[7] >> 32), piece = (int)(t[7] & 1), bun = (int)((t[7] >> 1) & 7);
+            const int c = bun ? 1000 * bun : piece ? -1 : len <= 8 ? 8 : len <= 32 ? 32 : len <= 64 ? 64 : len <= 128 ? 128 : 512;
+            Acc &a = cls[c];
+            a.n += 1; a.entries += len; a.desc += (double)(t[2] - t[1]);
+            const bool multi = t[3] > t[2];
+            a.first += multi ? (double)(t[3] - t[2]) : (double)(t[4] - t[2]);
+            a.rest += multi ? (double)(t[4] - t[3]) : 0.0;
+            a.store += (double)(t[5] - t[4]); a.total += (double)(t[5] - t[1]);
+            for (unsigned long long x = t[0]; x <= t[6]; ++x) resident[(size_t)(x - t_min)]++;
+        }
+        fprintf(stderr, "trace of the last launch: %d waves, span %.2f us (100 MHz stamps)\n", nw, (t_max - t_min) / 100.0);
+        for (auto &kv : cls) {
+            const Acc &a = kv.second;
+            fprintf(stderr, "  rows <= %4d%s: %6.0f waves, %5.1f entries; cycles: descriptor %6.0f | first window (index + gathers) %6.0f | further windows %7.0f | store %5.0f | life %7.0f\n",
+                    kv.first < 0 ? 512 : kv.first, kv.first < 0 ? " (hub pieces)" : "", a.n, a.entries / a.n, a.desc / a.n, a.first / a.n, a.rest / a.n, a.store / a.n, a.total / a.n);
+        }
+        fprintf(stderr, "  resident waves per 1 us:");
+        for (size_t x = 0; x + 100 <= resident.size(); x += 100) { long sum = 0; for (int q = 0; q < 100; ++q) sum += resident[x + q]; fprintf(stderr, " %ld", sum / 100); }
+        fprintf(stderr, "\n");
+    }
+#endif
     const PlanHeader *ph = reinterpret_cast<const PlanHeader *>(plan.data());
     if (err > 1e-5 && ph->reserved > 0) {                        // walk the stream on the host: builder or kernel?
         const StreamHeader *shh = reinterpret_cast<const StreamHeader *>(reinterpret_cast<const int32_t *>(plan.data()) + ph->reserved);

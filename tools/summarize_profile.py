@@ -3,6 +3,7 @@
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (all kernels of the run)
   profiles/<tag>_pmc.json           per-kernel averages of the PMC passes
   profiles/pmc_latest.json          {workload: {kernel: HBM bytes per launch}} read by bench.py (`traffic`)
+  profiles/pmc_sq_latest.json       {workload: {kernel: {SQ_* counter: average per launch}}} read by bench.py (`roofline_bxb`)
 Usage:  python tools/summarize_profile.py condense <dir>        (on the GPU box: raw counter tables -> averages)
         python tools/summarize_profile.py <run> <tag> [workload] (here: gpurun_out/prof_<run> -> profiles/<tag>_*)
 HBM bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE reports half of a wide coalesced
@@ -70,7 +71,7 @@ def pmc_avgs(path):
 
 def condense(src):
     """raw per-dispatch counter tables -> <sub>/avgs.json (+ the kernel durations of the SQ pass), raw tables removed"""
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_valu"):
         p = os.path.join(src, sub, "bench_counter_collection.csv")
         if os.path.exists(p):
             json.dump(pmc_avgs(p), open(os.path.join(src, sub, "avgs.json"), "w"))
@@ -83,7 +84,7 @@ def condense(src):
             if k:
                 dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
         json.dump({k: sum(v) / len(v) for k, v in dur.items()}, open(os.path.join(src, "pmc_sq", "durations.json"), "w"))
-    for sub in ("trace", "pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("trace", "pmc_fetch", "pmc_write", "pmc_sq", "pmc_valu"):
         t = os.path.join(src, sub, "bench_kernel_trace.csv")
         if os.path.exists(t):
             os.remove(t)
@@ -97,7 +98,7 @@ def main(run, tag, workload=None):
     if os.path.exists(out_txt) and os.path.getsize(out_txt):
         shutil.copyfile(out_txt, os.path.join(DST, tag + "_under_rocprof.json"))
     pmc = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_valu"):
         p = os.path.join(src, sub, "avgs.json")
         if os.path.exists(p):
             for k, d in json.load(open(p)).items():
@@ -126,6 +127,11 @@ def main(run, tag, workload=None):
         latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
         latest[workload] = traffic
         json.dump(latest, open(latest_path, "w"), indent=1, sort_keys=True)
+        # the instruction / cycle counters of the same run, per kernel: bench.py prices the (B,B) launch with them (roofline_bxb)
+        sq_path = os.path.join(DST, "pmc_sq_latest.json")
+        sq = json.load(open(sq_path)) if os.path.exists(sq_path) else {}
+        sq[workload] = {k: {c: v for c, v in d.items() if c.startswith(("SQ_", "avg_ns"))} for k, d in pmc.items()}
+        json.dump(sq, open(sq_path, "w"), indent=1, sort_keys=True)
     for k, d in sorted(pmc.items()):
         print(k, {c: round(v, 1) for c, v in d.items()})
 
