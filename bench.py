@@ -963,16 +963,20 @@ def main():
                     print("settle", r_, ev.last_eval_info(), "skip", ev._seed_skip, "backoff", ev._seed_backoff, file=sys.stderr)
             # Timed evaluations: as in a training run, the tables MOVE between two evaluations (20 untimed training steps
             # here), and an evaluation seeds its thresholds with the ids the previous one returned (Evaluator.rank_local).
-            ev_elapsed, ev_modes, ev_times = 0.0, [], []
+            ev_elapsed, ev_modes, ev_times, ev_dev_us = 0.0, [], [], []
             for r_ in range(args.eval_reps):
                 if args.eval_train_steps > 0:
                     run_steps(args.eval_train_steps, args.eval_train_steps * r_)
                     one_model()
                 barrier(); torch.cuda.synchronize()
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0 = time.perf_counter()
+                g0.record()
                 ret = run_eval()
+                g1.record()
                 torch.cuda.synchronize(); barrier()
                 ev_times.append(sharding.max_over_ranks(time.perf_counter() - t0, dev))
+                ev_dev_us.append(1e3 * g0.elapsed_time(g1))      # what the stream was busy with between the two records
                 ev_elapsed += ev_times[-1]
                 ev_modes.append(ev.last_eval_info())
             if os.environ.get("MACR_BENCH_DEBUG"):
@@ -1032,7 +1036,7 @@ def main():
             roofline_eval["seeded"] = seeded_run
 
             return {"ret": ret, "eval_users_per_s": eval_users_per_s, "ev_elapsed": ev_elapsed, "ev_unseeded_ms": ev_unseeded_ms,
-                    "ev_modes": ev_modes, "ev_times": ev_times, "roofline_eval": roofline_eval}
+                    "ev_modes": ev_modes, "ev_times": ev_times, "ev_dev_us": ev_dev_us, "roofline_eval": roofline_eval}
 
         # "f32": the (U, N) product on the fp32 matrix cores -- `roofline_eval`, priced against the fp32 MFMA peak as in
         # the earlier rounds.  "bf16": the Evaluator's default, a bf16 candidate filter with fp32 re-scoring (the same
@@ -1086,6 +1090,11 @@ def main():
                     # every timed evaluation is a host round trip (replay, synchronise) behind 2 010 training steps: the mean is
                     # what users_per_s is computed from, median / min / max show what host hiccups did to it
                     "ms_per_eval_median": 1e3 * ts[len(ts) // 2], "ms_per_eval_min": 1e3 * ts[0], "ms_per_eval_max": 1e3 * ts[-1],
+                    # host_gap_us: wall time of an evaluation (replay call -> means on the host) minus the time between two events
+                    # recorded on the stream around it -- launch of the replay, the wait for the pinned-memory results, the
+                    # python between them.  A property of the box's host as much as of the code: what separates boxes.
+                    "device_us_per_eval": float(np.mean(su["ev_dev_us"])),
+                    "host_gap_us": float(np.mean([1e6 * t_ - d_ for t_, d_ in zip(su["ev_times"], su["ev_dev_us"])])),
                     "ms_unseeded": su["ev_unseeded_ms"], "evaluations": len(modes),
                     "seeded": sum(1 for m in modes if m["seeded"]),
                     "repaired": sum(1 for m in modes if m["query_blocks_relisted"] > 0 or m["exact_fallback"]),

@@ -347,6 +347,7 @@ def test_repair_round_continues_on_the_first_rounds_workspace(ops):
         ev2.gt, ev2.use_graph, ev2.use_seeds = ev.gt, False, False
         return ev2.test_mf(1, P, uid, Q, [20], w, wu, 40.0)
 
+    ops._topk_ws_cache.pop(device, None)        # (earlier tests may have grown the cache past what `big` below asks for)
     small, uid_s = mk(700, 1)
     if not small._shape_uses_seeds(n_items, d):
         pytest.skip("this shape lists every item: no seeds, no repair round")
