@@ -135,11 +135,17 @@ def bench_config4(args, rank, world, dev, emit=True):
         if world > 1:
             torch.distributed.barrier()
 
+    # the split step's routing table per batch, as a caller that knows its batches on the host has it (the CLI's sampler does):
+    # W*W integers per batch, computed once here, so that no step synchronises with the host
+    counts_pool = [None] * n_batches
+    if world > 1 and model.split:
+        counts_pool = [model.route(batches[k, 0], batches[k, 1], batches[k, 2])[0].tolist() for k in range(n_batches)]
+
     def run_steps(n, first):
         out = None
         for s in range(n):
             k = (first + s) % n_batches
-            out = model.step(batches[k, 0], batches[k, 1], batches[k, 2])
+            out = model.step(batches[k, 0], batches[k, 1], batches[k, 2], counts=counts_pool[k])
         return out
     run_steps(args.warmup, 0)
 
@@ -259,11 +265,19 @@ def bench_config4(args, rank, world, dev, emit=True):
                "config": {"workload": "configs[4]: synthetic %d users x %d items, MACR-MF rubibceboth d=%d batch=%d c=%g; ONE model, "
                                       "rows sharded over %d rank(s), row r on rank r %% W (training), item-sharded evaluation of %d query users"
                                       % (n_users, n_items, d, B, c, world, args.c4_eval_users),
-                          "parallelism": "row-sharded x%d: all-reduce of the batch's 3B rows (%.1f MB) + all-reduce of the (B,B) "
-                                         "partials + broadcast of the branch-vector partials per step; evaluation: all-reduce of "
-                                         "the query rows + one all-gather of per-shard top-K" % (world, 3 * B * d * 4 / 1e6),
+                          "parallelism": "row-sharded x%d: %s; evaluation: all-reduce of the query rows + one all-gather of per-shard "
+                                         "top-K" % (world, ("split step -- all-to-all of the 3B/W rows a rank's slice needs, all-reduces of the "
+                                                            "forward scalars, the (B,B) partials and the branch-vector partials, all-to-all of the "
+                                                            "gradient rows back to their owners") if (world > 1 and model.split) else
+                                                    ("all-reduce of the batch's 3B rows (%.1f MB) + all-reduce of the (B,B) partials + broadcast "
+                                                     "of the branch-vector partials per step" % (3 * B * d * 4 / 1e6))),
                           "global_batch": B},
                "rows_per_rank": rows_local, "bytes_per_rank": 4.0 * d * rows_local * 4 + 4.0 * rows_local,
+               "wire_bytes_per_step": None if model.wire_rows is None else {
+                   "rows_crossing_ranks_each_way": model.wire_rows, "row_bytes": model.wire_rows * d * 4,
+                   "replicated_step_all_reduce_buffer_bytes": 3 * B * d * 4,
+                   "note": "split step: rows to the slices + gradient rows back (two all-to-alls, this rank, last step) against the "
+                           "(3,B,d) buffer the replicated step all-reduces (a ring moves ~2x that per rank)"},
                "collectives_ms": coll, "kernels": kern, "roofline": roofline,
                "roofline_step": {"bound": "hbm", "algorithmic_bytes": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1),
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",

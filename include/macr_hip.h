@@ -188,6 +188,26 @@ int macr_shard_bxb(int B, int d, int rank, int world, void **partials, size_t *p
 int macr_shard_backward(int loss_kind, int B, int d, const float *rows3, const float *w, const float *wu,
                         float *adam_pow, const macr_hyper *hp, float *losses, void **branch_grads,
                         size_t *branch_bytes, void *workspace, size_t workspace_bytes, void *stream);
+/* The SPLIT step (branch losses): rank r runs forward and backward only for the positions [t0, t1) of the batch whose (B,B) row
+ * blocks it evaluates (macr_shard_slice), on rows their owners sent it, and returns the gradient rows to the owners -- two
+ * all-to-alls of 3B/W rows per rank instead of an all-reduce of 3B rows (macr_amd/sharded_train.py::RowShardedMF.step_split).
+ *   macr_shard_forward_slice   rows3_slice (dev) fp32[3][n][d]: user / positive / negative rows of positions t0 .. t0+n-1; returns
+ *                              a region of the workspace (zero outside the slice) whose SUM over the ranks is the forward state
+ *                              of the whole batch -- sum it (one all-reduce) before macr_shard_bxb
+ *   macr_shard_backward_slice  after the partials of macr_shard_bxb were summed: gradient rows of the slice into stage_slice
+ *                              (dev) fp32[3][n][d], losses of the whole batch, this slice's share of the branch-vector gradient
+ *                              rows (returned region: sum over the ranks)
+ *   macr_shard_stage           where macr_shard_apply reads gradient rows: (dev) fp32[3][B][d] inside the workspace, row
+ *                              role * B + t; the caller fills the rows of the references this rank owns */
+int macr_shard_slice(int B, int d, int rank, int world, int *t0, int *t1);
+int macr_shard_forward_slice(int loss_kind, int B, int d, int t0, int n, const float *rows3_slice, const float *w,
+                             const float *wu, void **region, size_t *region_bytes, void *workspace,
+                             size_t workspace_bytes, void *stream);
+int macr_shard_backward_slice(int loss_kind, int B, int d, int t0, int n, const float *rows3_slice, const float *w,
+                              const float *wu, float *adam_pow, const macr_hyper *hp, float *losses,
+                              float *stage_slice, void **branch_grads, size_t *branch_bytes, void *workspace,
+                              size_t workspace_bytes, void *stream);
+int macr_shard_stage(int B, int d, float **stage, void *workspace, size_t workspace_bytes);
 int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int u_stride, int i_lo,
                      int i_stride, const int32_t *u, const int32_t *i, const int32_t *j,
                      float *P_loc, float *Q_loc, float *w, float *wu,

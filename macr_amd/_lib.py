@@ -50,6 +50,10 @@ SIGNATURES = {
     "macr_shard_forward": (_i, [_i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "macr_shard_bxb": (_i, [_i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "macr_shard_backward": (_i, [_i, _i, _i, _p, _p, _p, _p, ctypes.POINTER(Hyper), _p, _p, _p, _p, _z, _p]),
+    "macr_shard_slice": (_i, [_i, _i, _i, _i, _p, _p]),
+    "macr_shard_forward_slice": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "macr_shard_backward_slice": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, ctypes.POINTER(Hyper), _p, _p, _p, _p, _p, _z, _p]),
+    "macr_shard_stage": (_i, [_i, _i, _p, _p, _z]),
     "macr_shard_apply": (_i, [_i] * 9 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), _p, _z, _p]),
     "macr_sample_triples": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _i, _p, _i, _p, _p, _p, _p]),
     "macr_sample_triples_many": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),

@@ -899,7 +899,9 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
     const float *__restrict__ w, const float *__restrict__ wu, const float *__restrict__ fwd,
     const float *__restrict__ rowpart, const float *__restrict__ colpart, float *__restrict__ stage,
     float *__restrict__ wpart, float alpha, float beta, float coef, float *adam_pow, StepScalars *scal, float lr,
-    float b1, float b2, LossArgs L, const uint32_t *__restrict__ place = nullptr) {
+    float b1, float b2, LossArgs L, const uint32_t *__restrict__ place = nullptr, int Bnorm = 0) {
+    // Bnorm > 0: the launch covers a SLICE of a batch of Bnorm triples (row-sharded training, macr_shard_backward_slice): u/i/j,
+    // fwd, rowpart and colpart arrive offset to the slice, B is its length, the means are taken over the whole batch
     constexpr int d = 4 * LPR, RPB = RowGroup<LPR>::kRowsPerBlock;
     __shared__ float4 s_w[2][256];
     const int nblk = gridDim.x - 1;
@@ -916,7 +918,8 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
     RowGroup<LPR> g;
     const float4 w4 = ld4(w + 4 * g.sub), wu4 = ld4(wu + 4 * g.sub);
     float4 aw = make_float4(0, 0, 0, 0), awu = make_float4(0, 0, 0, 0);
-    const float inv_b2 = 1.0f / ((float)B * (float)B), eps = 1e-10f, invB = 1.0f / (float)B;
+    const float Bn = (float)(Bnorm > 0 ? Bnorm : B);
+    const float inv_b2 = 1.0f / (Bn * Bn), eps = 1e-10f, invB = 1.0f / Bn;
     for (long long base = (long long)blockIdx.x * RPB; base < B; base += (long long)nblk * RPB) {
         const long long t = base + g.slot;
         if (t >= B) continue;
@@ -1763,6 +1766,93 @@ extern "C" int macr_shard_backward(int loss_kind, int B, int d, const float *row
     MACR_CHECK_LAUNCH("pair_bwd", st);
     if (branch_grads) *branch_grads = ws.gw;
     if (branch_bytes) *branch_bytes = (size_t)kBranchSlots * 2 * d * 4;
+    return MACR_OK;
+}
+
+/* ---- the SPLIT step (round 5): forward and backward of a rank's SLICE of the batch only ------------------------------------
+ * Rank r runs the per-pair forward and backward for the positions [t0, t1) whose (B,B) row blocks it evaluates anyway
+ * (macr_shard_bxb), on rows it received from their owners (all-to-all #1), and sends the gradient rows back to the owners
+ * (all-to-all #2) -- a rank moves 2 * 3B/W rows per step instead of taking part in an all-reduce of 3B.  Host side:
+ * macr_amd/sharded_train.py::RowShardedMF.step_split.  Branch losses only (the losses with a (B,B) term). */
+extern "C" int macr_shard_slice(int B, int d, int rank, int world, int *t0, int *t1) {
+    MACR_REQUIRE(B > 0 && dim_supported(d) && world >= 1 && rank >= 0 && rank < world && t0 && t1, MACR_E_INVALID, "shard_slice: bad argument");
+    const PairWs ws = carve_pair_ws(nullptr, B, d, true);
+    const int rows = 64 * ws.rows;
+    const long long a = (long long)ws.nrb * rank / world * rows, b = (long long)ws.nrb * (rank + 1) / world * rows;
+    *t0 = (int)(a < B ? a : B);
+    *t1 = (int)(b < B ? b : B);
+    return MACR_OK;
+}
+
+/* forward of the slice: rows3_slice (dev) fp32[3][n][d] = the user, positive and negative rows of positions t0 .. t0+n-1.
+ * Writes the slice of the forward arrays and the slice's loss partials into a ZEROED region of the workspace and returns that
+ * region: its sum over the ranks is the forward state of the whole batch on every rank (x + 0 = x: exact). */
+extern "C" int macr_shard_forward_slice(int loss_kind, int B, int d, int t0, int n, const float *rows3_slice, const float *w,
+                                        const float *wu, void **region, size_t *region_bytes, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE, MACR_E_UNSUPPORTED,
+                 "shard_forward_slice: loss_kind=%d (the split step serves the losses with a (B,B) term)", loss_kind);
+    MACR_REQUIRE(w && wu && t0 >= 0 && n >= 0 && t0 + n <= B && (n == 0 || rows3_slice), MACR_E_INVALID, "shard_forward_slice: bad argument");
+    MACR_SHARD_COMMON("shard_forward_slice");
+    char *lo = reinterpret_cast<char *>(ws.fwd), *hi = reinterpret_cast<char *>(ws.lpart);      // fwd | part | part2
+    fill_words(lo, (size_t)(hi - lo) / 4, 0u, st);
+    fill_words(ws.gw, (size_t)kBranchSlots * 2 * d, 0u, st);
+    if (region) *region = lo;
+    if (region_bytes) *region_bytes = (size_t)(hi - lo);
+    if (n > 0) {
+        k_iota3<<<grid_for(n), 256, 0, st>>>(n, sw.iota);
+        PendingAdam none = {};
+        const int lpr = d / 4, rpb = 256 / lpr, nblk = (n + rpb - 1) / rpb;
+        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, false><<<nblk, 256, 0, st>>>(n, ws.Bp, sw.iota, sw.iota + n, sw.iota + 2 * (size_t)n, rows3_slice,
+                                                                          rows3_slice + (size_t)n * d, w, wu, ws.fwd + t0, ws.part, 1, ws.gw,
+                                                                          none, loss_kind == MACR_LOSS_RUBIBCEBOTH ? 1 : 0)));
+    }
+    MACR_CHECK_LAUNCH("pair_fwd", st);
+    return MACR_OK;
+}
+
+/* backward of the slice (after the partial sums of macr_shard_bxb have been summed over the ranks): gradient rows of positions
+ * t0 .. t0+n-1 into stage_slice (dev) fp32[3][n][d]; losses of the WHOLE batch (identical on every rank); the branch-vector
+ * partial rows (returned region) hold this slice's share: sum them over the ranks. */
+extern "C" int macr_shard_backward_slice(int loss_kind, int B, int d, int t0, int n, const float *rows3_slice, const float *w,
+                                         const float *wu, float *adam_pow, const macr_hyper *hp, float *losses,
+                                         float *stage_slice, void **branch_grads, size_t *branch_bytes, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE, MACR_E_UNSUPPORTED,
+                 "shard_backward_slice: loss_kind=%d", loss_kind);
+    MACR_REQUIRE(w && wu && adam_pow && losses && t0 >= 0 && n >= 0 && t0 + n <= B && (n == 0 || (rows3_slice && stage_slice)),
+                 MACR_E_INVALID, "shard_backward_slice: bad argument");
+    if (int e = validate_hyper(hp, "shard_backward_slice")) return e;
+    MACR_SHARD_COMMON("shard_backward_slice");
+    LossArgs L;
+    L.part = ws.part; L.n_part = ws.nblk_pair; L.part2 = nullptr; L.n_part2 = 0;      // (every rank's blocks were summed index by index)
+    L.lpart = ws.lpart; L.n_lpart = ws.nrb * ws.ncb;
+    L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
+    L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
+    const float coef = hp->decay / (float)hp->batch_size_cfg;
+    const int lpr = d / 4, rpb = 256 / lpr;
+    int nblk = (n + rpb - 1) / rpb;
+    nblk = nblk < 4096 ? nblk : 4096;
+    // (the branch-vector partial rows were zeroed by the forward of the slice; a slice without triples still runs the last block:
+    // the step's lr_t, the beta powers and the losses)
+    MACR_DISPATCH_LPR(d, (k_pair_bwd_stage<LPR><<<nblk + 1, 256, 0, st>>>(
+                             n, ws.Bp, ws.nrb, ws.ncb, sw.iota, sw.iota + n, sw.iota + 2 * (size_t)n, rows3_slice,
+                             rows3_slice + (size_t)n * d, w, wu, ws.fwd + t0, ws.rowpart + t0, ws.colpart + t0, stage_slice, ws.gw,
+                             hp->alpha, hp->beta, coef, adam_pow, ws.scal, hp->lr, hp->beta1, hp->beta2, L, nullptr, B)));
+    MACR_CHECK_LAUNCH("pair_bwd", st);
+    if (branch_grads) *branch_grads = ws.gw;
+    if (branch_bytes) *branch_bytes = (size_t)kBranchSlots * 2 * d * 4;
+    return MACR_OK;
+}
+
+/* where macr_shard_apply reads the batch's gradient rows: (dev) fp32[3][B][d], row role * B + t = the gradient of position t's
+ * user / positive / negative row.  The split step fills the rows this rank owns from what all-to-all #2 delivered. */
+extern "C" int macr_shard_stage(int B, int d, float **stage, void *workspace, size_t workspace_bytes) {
+    MACR_REQUIRE(stage, MACR_E_INVALID, "shard_stage: null pointer");
+    void *stream = nullptr;
+    MACR_SHARD_COMMON("shard_stage");
+    (void)st;
+    *stage = ws.stage;
     return MACR_OK;
 }
 

@@ -261,13 +261,24 @@ class ShardedBPRMF(object):
             self._model(ops.LOSS_RUBIBCEBOTH if kind is None else kind)
         return next(iter(self._models.values()))
 
-    to_device_batch = BPRMF.to_device_batch
+    def to_device_batch(self, users, pos_items, neg_items):
+        """as BPRMF.to_device_batch; the host copy is kept for the step that consumes it (routing table of the split step
+        without a device synchronisation: sharded_train.RowShardedMF.route_counts_host)"""
+        arr = np.asarray([users, pos_items, neg_items], dtype=np.int32)
+        dev = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory().to(self.device, non_blocking=True)
+        self._host_batch = (dev.data_ptr(), arr)
+        return dev
 
     def update_c(self, sess, c):
         self.rubi_c = float(c)
 
     def train_step(self, kind, batch, losses=None, defer=False):
-        out = self._model(kind).step(batch[0], batch[1], batch[2])
+        m = self._model(kind)
+        counts = None
+        hb = getattr(self, "_host_batch", None)
+        if hb is not None and hb[0] == batch.data_ptr() and self.world > 1 and m.split and kind != ops.LOSS_NORMALBCE:
+            counts = m.route_counts_host(hb[1][0], hb[1][1], hb[1][2])
+        out = m.step(batch[0], batch[1], batch[2], counts=counts)
         if losses is not None:
             losses.copy_(out)
         return out

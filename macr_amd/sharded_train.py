@@ -57,6 +57,17 @@ class Owned(object):
         """this rank's rows of a full table"""
         return full[self.lo::self.stride][:self.n] if self.stride > 1 else full[self.lo:self.lo + self.n]
 
+    def owner_of(self, ids):
+        """rank that owns each of the global row ids (any rank can tell: the layout is a function of the id)"""
+        if self.layout == "interleaved":
+            return ids % self.world
+        bounds = torch.tensor([row_range(self.n_rows, r, self.world)[1] for r in range(self.world)], device=ids.device)
+        return torch.bucketize(ids, bounds, right=True)
+
+    def local_index(self, ids):
+        """local row of ids THIS rank owns"""
+        return (ids - self.lo) // self.stride
+
     def local_of(self, ids):
         """(mask of the ids this rank owns, their local indices) for an integer tensor / array of global row ids"""
         rel = ids - self.lo
@@ -121,6 +132,45 @@ class HipBackend(object):
             return self.losses, None                        # normalbce: no branch vectors
         return self.losses, self._view(ptr, nbytes)         # losses; branch-vector partial rows (broadcast from rank 0)
 
+    # ---- the split step: forward / backward of this rank's slice of the batch (macr_shard_*_slice)
+    def slice_of(self, B, rank, world):
+        t0, t1 = ctypes.c_int(), ctypes.c_int()
+        self._lib.check(self._lib.lib().macr_shard_slice(B, self.d, rank, world, ctypes.byref(t0), ctypes.byref(t1)))
+        return t0.value, t1.value
+
+    def forward_slice(self, shard, B, t0, rows3_slice):
+        self._reserve(B)
+        o, L = self.ops, self._lib.lib()
+        ptr, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
+        self._lib.check(L.macr_shard_forward_slice(self.kind, B, self.d, t0, rows3_slice.shape[1], o._ptr(rows3_slice), o._ptr(shard.w),
+                                                   o._ptr(shard.wu), ctypes.byref(ptr), ctypes.byref(nbytes), o._ptr(self.ws),
+                                                   self.ws.numel(), o._stream()))
+        return self._view(ptr, nbytes)                      # forward state + loss partials of the slice: sum over the ranks
+
+    def bxb(self, B, rank, world):
+        o, L = self.ops, self._lib.lib()
+        ptr, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
+        self._lib.check(L.macr_shard_bxb(B, self.d, rank, world, ctypes.byref(ptr), ctypes.byref(nbytes), o._ptr(self.ws),
+                                         self.ws.numel(), o._stream()))
+        return self._view(ptr, nbytes)
+
+    def backward_slice(self, shard, B, t0, rows3_slice):
+        o, L = self.ops, self._lib.lib()
+        n = rows3_slice.shape[1]
+        stage = torch.empty((3, n, self.d), dtype=torch.float32, device=self.device)
+        ptr, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
+        self._lib.check(L.macr_shard_backward_slice(self.kind, B, self.d, t0, n, o._ptr(rows3_slice), o._ptr(shard.w), o._ptr(shard.wu),
+                                                    o._ptr(self.adam_pow), ctypes.byref(self.hyper), o._ptr(self.losses), o._ptr(stage),
+                                                    ctypes.byref(ptr), ctypes.byref(nbytes), o._ptr(self.ws), self.ws.numel(),
+                                                    o._stream()))
+        return self.losses, stage, self._view(ptr, nbytes)
+
+    def stage_rows(self, B):
+        """(3*B, d) view of the staging buffer macr_shard_apply reads (row role*B + t)"""
+        ptr = ctypes.c_void_p()
+        self._lib.check(self._lib.lib().macr_shard_stage(B, self.d, ctypes.byref(ptr), self.ops._ptr(self.ws), self.ws.numel()))
+        return self._view(ptr, ctypes.c_size_t(3 * B * self.d * 4)).view(3 * B, self.d)
+
     def apply(self, shard, u, i, j):
         o, L = self.ops, self._lib.lib()
         ou, oi = shard.own_u, shard.own_i
@@ -153,6 +203,9 @@ class RowShardedMF(object):
             self.P, self.Q = clone(self.own_u.take(P_full)), clone(self.own_i.take(Q_full))
         self.w, self.wu = clone(w.reshape(-1)), clone(wu.reshape(-1))
         self.collective_ms = None                   # bench: {"rows": [...], "partials": [...], "branch": [...]} event times
+        import os
+        self.split = os.environ.get("MACR_SHARD_SPLIT", "1") != "0"
+        self.wire_rows = None
         z = torch.zeros_like
         self.mP, self.vP, self.mQ, self.vQ = z(self.P), z(self.P), z(self.Q), z(self.Q)
         self.mw, self.vw, self.mwu, self.vwu = z(self.w), z(self.w), z(self.wu), z(self.wu)
@@ -197,10 +250,111 @@ class RowShardedMF(object):
         else:
             self._timed(name, lambda: dist.broadcast(t, src, group=self.group))
 
+    def _all_to_all(self, recv, send, recv_counts, send_counts, name):
+        """rows (n, d): send_counts[q] rows go to rank q, recv_counts[q] arrive from it (python ints, the same on every rank)"""
+        def run(r, s_):
+            dist.all_to_all_single(r, s_, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=self.group)
+        if self._host_rig(send):                    # test rig: several ranks on one GPU cannot use RCCL
+            def via_host():
+                r = torch.empty(recv.shape, dtype=recv.dtype)
+                run(r, send.cpu())
+                recv.copy_(r)
+            self._timed(name, via_host)
+        else:
+            self._timed(name, lambda: run(recv, send))
+
+    def route(self, u, i, j):
+        """Who sends what to whom in the split step, from the batch alone (every rank computes the same tables).
+        References are numbered role * B + t (role 0/1/2 = user / positive / negative row of position t).  Returns
+          counts   (W, W) python ints: counts[q][p] = rows owner q sends to the rank whose slice holds their position, p
+          send_ref (n_send,) references whose rows THIS rank owns, ordered by (destination, reference): what it sends
+          recv_ref (n_recv,) references of THIS rank's slice ordered by (owner, reference): the order they arrive in
+        The one host synchronisation of a split step is reading `counts` (W*W integers); callers that know the batch on the
+        host (the CLI's sampler, the bench's batch pool) pass it to step_split instead."""
+        B, W = u.numel(), self.world
+        bounds = self._slice_bounds(B)
+        t1s = torch.tensor([b[1] for b in bounds], device=u.device)
+        dest = torch.bucketize(torch.arange(B, device=u.device), t1s, right=True).repeat(3)             # (3B,)
+        rows = torch.cat([u, i, j]).long()
+        owner = torch.cat([self.own_u.owner_of(u.long()), self.own_i.owner_of(i.long()), self.own_i.owner_of(j.long())])
+        counts = torch.bincount(owner * W + dest, minlength=W * W).view(W, W)
+        mine = owner == self.rank
+        send_ref = torch.argsort(torch.where(mine, dest, torch.full_like(dest, W)), stable=True)        # mine first, by destination
+        in_slice = dest == self.rank
+        recv_ref = torch.argsort(torch.where(in_slice, owner, torch.full_like(owner, W)), stable=True)  # my slice first, by owner
+        return counts, send_ref, recv_ref, rows
+
+    def route_counts_host(self, u, i, j):
+        """the `counts` table of route() from a HOST copy of the batch (numpy int arrays): what a caller whose sampler runs on
+        the host hands to step() so that the split step never waits for the device"""
+        import numpy as np
+        B, W = len(u), self.world
+        t1s = np.asarray([b[1] for b in self._slice_bounds(B)])
+        dest = np.tile(np.searchsorted(t1s, np.arange(B), side="right"), 3)
+        ids = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int64))
+        owner = torch.cat([self.own_u.owner_of(ids(u)), self.own_i.owner_of(ids(i)), self.own_i.owner_of(ids(j))]).numpy()
+        return np.bincount(owner * W + dest, minlength=W * W).reshape(W, W).tolist()
+
+    def _slice_bounds(self, B):
+        key = ("slices", B)
+        if key not in self.__dict__:
+            self.__dict__[key] = [self.backend.slice_of(B, r, self.world) for r in range(self.world)]
+        return self.__dict__[key]
+
+    def step_split(self, u, i, j, counts=None):
+        """One step with forward and backward SPLIT over the ranks (branch losses): rank p handles the positions of its
+        (B,B) row blocks.  Per rank and step: all-to-all of the 3B/W rows its slice needs (from their owners), an all-reduce of
+        the forward scalars (7 floats per position), the all-reduce of the (B,B) partial sums, an all-reduce of the
+        branch-vector gradient partials, all-to-all of the 3B/W gradient rows back to the owners, then the local Adam pass.
+        counts: the (W, W) table of route() as python ints when the caller knows the batch on the host (no synchronisation)."""
+        be, W, B = self.backend, self.world, u.numel()
+        cnt, send_ref, recv_ref, rows = self.route(u, i, j)
+        counts = cnt.tolist() if counts is None else counts         # (the step's one host synchronisation when not given)
+        t0, t1 = self._slice_bounds(B)[self.rank]
+        n = t1 - t0
+        send_counts = [counts[self.rank][p] for p in range(W)]       # rows I own, by the rank whose slice needs them
+        recv_counts = [counts[q][self.rank] for q in range(W)]       # rows of my slice, by owner
+        n_send, n_recv = sum(send_counts), sum(recv_counts)
+        assert n_recv == 3 * n
+        send_ref, recv_ref = send_ref[:n_send], recv_ref[:n_recv]
+        d = self.P.shape[1]
+        # 1. rows of my slice from their owners
+        sr = rows[send_ref]
+        is_user = (send_ref < B).unsqueeze(1)
+        from_p = self.P[self.own_u.local_index(sr).clamp(0, max(self.P.shape[0] - 1, 0))]     # (both tables are indexed for every
+        from_q = self.Q[self.own_i.local_index(sr).clamp(0, max(self.Q.shape[0] - 1, 0))]     # reference: n_send rows each, no branch)
+        send = torch.where(is_user, from_p, from_q)
+        recv = torch.empty((n_recv, d), dtype=self.P.dtype, device=self.P.device)
+        self._all_to_all(recv, send.contiguous(), recv_counts, send_counts, "rows_a2a")
+        # arrival order -> (role, position in the slice)
+        role, t = recv_ref // B, recv_ref % B
+        slot = role * n + (t - t0)
+        rows3 = torch.empty((3 * n, d), dtype=self.P.dtype, device=self.P.device)
+        rows3[slot] = recv
+        rows3 = rows3.view(3, n, d)
+        # 2. forward of the slice; its scalars and loss partials summed into the whole batch's
+        self._all_reduce(be.forward_slice(self, B, t0, rows3), "fwd")
+        # 3. my (B,B) row blocks; partial row / column sums over the ranks
+        self._all_reduce(be.bxb(B, self.rank, W), "partials")
+        # 4. backward of the slice; branch-vector gradient partials summed (identical on every rank afterwards)
+        losses, stage, branch = be.backward_slice(self, B, t0, rows3)
+        self._all_reduce(branch, "branch")
+        # 5. gradient rows back to the owners, into the staging rows macr_shard_apply reads
+        back = torch.empty((n_send, d), dtype=self.P.dtype, device=self.P.device)
+        self._all_to_all(back, stage.view(3 * n, d)[slot].contiguous(), send_counts, recv_counts, "grads_a2a")
+        be.stage_rows(B)[send_ref] = back
+        be.apply(self, u, i, j)
+        self.wire_rows = (n_send - send_counts[self.rank]) + (n_recv - recv_counts[self.rank])   # rows that crossed ranks, one way each
+        return losses
+
     # ------------------------------------------------------------------ one step
-    def step(self, u, i, j):
-        """u, i, j: the SAME batch on every rank (int32, global row ids).  Returns {loss, mf_loss, reg_loss} (3,)."""
+    def step(self, u, i, j, counts=None):
+        """u, i, j: the SAME batch on every rank (int32, global row ids).  Returns {loss, mf_loss, reg_loss} (3,).
+        With several ranks and a branch loss the step is the SPLIT one (step_split; MACR_SHARD_SPLIT=0: the replicated
+        forward / backward around one all-reduce of the batch's rows, below); `counts`: see step_split."""
         be = self.backend
+        if (self.world > 1 and self.split and hasattr(be, "slice_of") and getattr(be, "kind", 1) != 0):   # (kind 0 = normalbce: no (B,B) term)
+            return self.step_split(u, i, j, counts)
         rows3 = be.gather(self, u, i, j)
         self._all_reduce(rows3, "rows")                           # 1. the batch's rows, everywhere
         partials = be.forward_and_bxb(self, rows3, self.rank, self.world)

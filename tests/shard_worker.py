@@ -29,6 +29,7 @@ def main():
     t = lambda a: torch.from_numpy(a).to(dev)
     hyper = ops.make_hyper(lr, decay, alpha, beta, bs)
     model = sharded_train.RowShardedMF(t(P), t(Q), t(w), t(wu), sharded_train.HipBackend(kind, d, hyper, dev))
+    split = os.environ.get("MACR_SHARD_SPLIT", "0") == "1"          # forward / backward split over the ranks, all-to-all exchange
     single = ops.MFState(t(P), t(Q), t(w), t(wu), hyper, B)
     st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
     Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
@@ -37,6 +38,7 @@ def main():
         u = rs.choice(n_users, B, replace=False).astype(np.int32)
         i = (rs.zipf(1.3, B) % n_items).astype(np.int32)
         j = rs.randint(0, n_items, B).astype(np.int32)
+        model.split = split
         got = model.step(t(u), t(i), t(j)).cpu().numpy()
         ref = single.step(kind, t(u), t(i), t(j)).cpu().numpy()
         want = oracle.mf_train_step(kind, u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, bs)
@@ -57,7 +59,8 @@ def main():
     if rank == 0:
         print(json.dumps({"ok": bool(ok_loss and max(dP, dQ, dPs, dQs, dw) < tol and same_w), "worst_loss_rel": worst,
                           "dP": dP, "dQ": dQ, "dP_single": dPs, "dQ_single": dQs, "dw": dw, "tol": tol, "same_w": same_w,
-                          "world": world, "rows_on_rank0": shard_rows, "rows_total": n_users + n_items}))
+                          "world": world, "rows_on_rank0": shard_rows, "rows_total": n_users + n_items, "split": split,
+                          "wire_rows": getattr(model, "wire_rows", None), "batch_rows": 3 * B}))
     dist.destroy_process_group()
 
 

@@ -629,7 +629,7 @@ def test_row_sharded_training_two_ranks_one_gpu(tmp_path):
     GPU), the macr_shard_* device entry points, three collectives per step; losses and the reassembled tables must
     equal the single-GPU step and the oracle within the single-GPU tolerances."""
     import json
-    env = dict(os.environ, PYTHONUNBUFFERED="1")
+    env = dict(os.environ, PYTHONUNBUFFERED="1", MACR_SHARD_SPLIT="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(REPO, "tests", "shard_worker.py")],
                          cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
@@ -637,6 +637,21 @@ def test_row_sharded_training_two_ranks_one_gpu(tmp_path):
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["ok"], res
     assert res["world"] == 2 and res["rows_on_rank0"] < 0.51 * res["rows_total"]     # a rank holds half of the rows
+
+
+def test_row_sharded_split_step_two_ranks_one_gpu(tmp_path):
+    """The split step (round 5): forward and backward of each rank's slice only, rows to the slices and gradient rows back to
+    the owners by two all-to-alls -- same losses and tables as the single-GPU step and the oracle, and a rank moves about
+    (W-1)/W * 3B/W rows each way instead of reducing a 3B-row buffer."""
+    import json
+    env = dict(os.environ, PYTHONUNBUFFERED="1", MACR_SHARD_SPLIT="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(REPO, "tests", "shard_worker.py")],
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] and res["split"], res
+    assert 0 < res["wire_rows"] < 0.6 * res["batch_rows"], res       # ~ 2 * (1/2) * 3B/2 at two ranks
 
 
 def test_rccl_code_paths_in_a_world_of_one(tmp_path):

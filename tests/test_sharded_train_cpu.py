@@ -173,3 +173,113 @@ def test_row_sharded_training_gloo_world3_uneven_shards_normalbce():
 
 def test_row_sharded_training_gloo_world3_ranges_rubibce():
     _run_world(3, "rubibce", "range")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The SPLIT step (RowShardedMF.step_split): rows travel to the rank whose slice of the batch needs them and gradient rows
+# travel back to their owners, by two all-to-alls.  The rig below plays the device half with the oracle: the routing, both
+# exchanges, the placement of the received rows and the owners' apply must reproduce the single-process oracle step exactly.
+# (The slice kernels themselves are checked on the GPU: tests/test_gpu_product.py::test_row_sharded_split_step_two_ranks_one_gpu.)
+class SplitOracleBackend(OracleBackend):
+    def slice_of(self, B, rank, world):
+        return sharded_train.row_range(B, rank, world)
+
+    def forward_slice(self, shard, B, t0, rows3_slice):
+        n = rows3_slice.shape[1]
+        self.region = torch.zeros((3, B, self.d), dtype=torch.float32)
+        self.region[:, t0:t0 + n] = rows3_slice                   # "forward state of the slice": here simply its rows
+        return self.region                                        # summed over the ranks by the caller (x + 0 = x)
+
+    def bxb(self, B, rank, world):
+        return torch.zeros(1)
+
+    def backward_slice(self, shard, B, t0, rows3_slice):
+        n = rows3_slice.shape[1]
+        losses, branch = self.backward(shard, self.region)        # the oracle's gradients of the whole batch
+        full = [torch.from_numpy(g) for g in self.stage]
+        stage_slice = torch.stack([g[t0:t0 + n] for g in full]).contiguous()
+        if shard.rank != 0:
+            self.gw[:] = 0                                        # the branch-vector partials are SUMMED over the ranks
+        # what apply() reads: a buffer nobody but all-to-all #2 fills
+        self.stage_buf = torch.full((3 * B, self.d), float("nan"))
+        self.stage = tuple(self.stage_buf.view(3, B, self.d)[k].numpy() for k in range(3))
+        return losses, stage_slice, torch.from_numpy(self.gw)
+
+    def stage_rows(self, B):
+        return self.stage_buf
+
+
+def _split_worker(rank, world, port, q, kind_name, layout):
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, Q, w, wu, batches = _problem()
+        kind = {"rubibceboth": oracle.LOSS_RUBIBCEBOTH, "rubibce": oracle.LOSS_RUBIBCE}[kind_name]
+        model = sharded_train.RowShardedMF(torch.from_numpy(P), torch.from_numpy(Q), torch.from_numpy(w), torch.from_numpy(wu),
+                                           SplitOracleBackend(kind, P.shape[1], **HYP), layout=layout)
+        Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
+        st = oracle.AdamState([P.shape, Q.shape, w.shape, wu.shape])
+        ok, wire = True, []
+        for k, (u, i, j) in enumerate(batches):
+            tu, ti, tj = torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(j)
+            counts = model.route(tu, ti, tj)[0].tolist() if k == 1 else None          # (given by the caller once, computed inside otherwise)
+            got = model.step_split(tu, ti, tj, counts=counts).numpy()
+            want = oracle.mf_train_step(kind, u, i, j, Po, Qo, wo, wuo, st, HYP["lr"], HYP["decay"], HYP["alpha"], HYP["beta"],
+                                        HYP["bs"])
+            ok = ok and np.allclose(got, want, rtol=1e-6)
+            wire.append(model.wire_rows)
+        Pf, Qf = model.full_tables()
+        ok = ok and np.array_equal(Pf.numpy(), Po) and np.array_equal(Qf.numpy(), Qo)
+        ok = ok and np.array_equal(model.w.numpy(), wo) and np.array_equal(model.wu.numpy(), wuo)
+        B = len(batches[0][0])
+        q.put((rank, bool(ok), max(wire) < 2 * 3 * B // world + 3 * B // 4))       # ~ 2 * (W-1)/W * 3B/W rows cross ranks, not 3B
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_split(world, kind_name, layout):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q, kind_name, layout)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(r, True, True) for r in range(world)], res
+
+
+def test_split_step_gloo_world2_interleaved():
+    _run_split(2, "rubibceboth", "interleaved")
+
+
+def test_split_step_gloo_world3_ranges_uneven_slices():
+    """three ranks, contiguous row ranges (every hot item on rank 0: very unequal send counts), 96 positions in slices of 32"""
+    _run_split(3, "rubibce", "range")
+
+
+def test_route_tables_are_consistent():
+    """counts[q][p] = rows owner q sends to slice p; every reference appears exactly once on the sending and on the receiving side"""
+    P, Q, w, wu, batches = _problem()
+    u, i, j = (torch.from_numpy(x) for x in batches[0])
+    B, W = u.numel(), 3
+    sends, recvs, tabs = [], [], []
+    for r in range(W):
+        m = sharded_train.RowShardedMF(torch.from_numpy(P), torch.from_numpy(Q), torch.from_numpy(w), torch.from_numpy(wu),
+                                       SplitOracleBackend(1, P.shape[1], **HYP), rank=r, world=W)
+        counts, send_ref, recv_ref, rows = m.route(u, i, j)
+        tabs.append(counts)
+        sends.append(send_ref[:int(counts[r].sum())]); recvs.append(recv_ref[:int(counts[:, r].sum())])
+    assert all(torch.equal(tabs[0], t) for t in tabs) and int(tabs[0].sum()) == 3 * B
+    assert sorted(torch.cat(sends).tolist()) == list(range(3 * B)) == sorted(torch.cat(recvs).tolist())
+    # what q sends to p, in order, is what p expects from q, in order
+    for q_ in range(W):
+        off_s = 0
+        for p_ in range(W):
+            n = int(tabs[0][q_][p_])
+            off_r = int(tabs[0][:q_, p_].sum())
+            assert torch.equal(sends[q_][off_s:off_s + n], recvs[p_][off_r:off_r + n]), (q_, p_)
+            off_s += n
