@@ -737,6 +737,16 @@ def roofline_bxb(workload, B, kern_avg):
                 lim[form] = insts * per_inst / 1024.0 / 2.4e3
             e["issue_limit_us"] = {"all_pairs_six_transcendental_form": lim["six"], "all_pairs_four_transcendental_form": lim["four"]}
             e["frac"] = {"vs_six_form": lim["six"] / e["avg_us"], "vs_four_form": lim["four"] / e["avg_us"]}
+            if c.get("SQ_INSTS_VALU_TRANS_F32"):
+                # the transcendental count itself, where this rocprofv3 has the counter: the launch's own mix of the two forms
+                t_ = c["SQ_INSTS_VALU_TRANS_F32"]
+                pk_share = sum(l["mix"].get("valu_packed", 0) for l in loops) / float(sum(l["valu_total"] for l in loops))
+                pk_ = pk_share * insts
+                lim_m = ((insts - t_ - pk_) * cyc_full + pk_ * cyc_pk + t_ * cyc_tr) / 1024.0 / 2.4e3
+                e["transcendental_share_measured"] = t_ / insts
+                e["transcendentals_per_pair"] = t_ * 64.0 / (B * B)
+                e["issue_limit_us"]["measured_mix"] = lim_m
+                e["frac"]["vs_measured_mix"] = lim_m / e["avg_us"]
             if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
                 e["pmc"] = {k_: c[k_] for k_ in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES",
                                                  "SQ_INSTS_VALU_TRANS_F32", "avg_ns_under_pmc") if k_ in c}

@@ -42,10 +42,16 @@ constexpr int kChunk = 512;       // non-zeros per work item (kernel-development
 
 struct PlanHeader {               // all int32, followed by the arrays below
     int32_t magic, n_items, n_split, n_slots, N, chunk, n_groups, reserved;
+    // RECORDS of the short rows (round 5, spmm_records below): item[0 .. n_single) are the pieces and the rows of more than
+    // kRecEntries neighbours -- one wave each in a dense layer -- and every shorter row also sits in a record, several to a
+    // wave: n_rec[c] records of class c (8, 4, 2, 1 rows of at most 4, 8, 16, 32 neighbours) from int32 offset rec_off on
+    int32_t n_single, rec_off, n_rec[4], pad[2];
 };
-constexpr int32_t kPlanMagic = 0x4d414355;   // "MACU" (layout 4)
+constexpr int32_t kPlanMagic = 0x4d414356;   // "MACV" (layout 5)
+constexpr int kRecEntries = 32;              // neighbours per record
+constexpr int kRecInts = 16 + 2 * kRecEntries;   // a record: 16 header ints (row ids, -1 = none) + 32 (column, weight) pairs = 320 B
 constexpr int kGroup = 16;        // pieces per group
-// layout after the header (32 bytes, so the descriptors are 16-byte aligned):
+// layout after the header (64 bytes, so the descriptors are 16-byte aligned):
 //   item[n_items] = {row, beg, end, slot}   the n_slots pieces of the split rows first (slot >= 0, in slot order), then
 //                                           the other rows (slot = -1), longest first
 //   slot_group[n_slots]                     the group a piece belongs to (kGroup consecutive pieces of one row)
@@ -266,6 +272,96 @@ __device__ __forceinline__ void gather_batches_masked(int cv, float av, uint64_t
     }
 }
 
+
+// RECORDS (round 5): the short rows of a dense layer.
+// Per-wave phase stamps of a Yelp2018-shape layer (tools/spmm_bench.hip -DMACR_SPMM_TRACE, profiles/r05_spmm_trace_*.txt): 51 k
+// of the layer's 73 k waves are rows of <= 32 neighbours; such a wave lives ~3 900 cycles -- descriptor 850, index window and
+// gathers 2 000, store 1 000 -- for 2 to 19 gathers, the chip holds ~5 800 of them at a time whatever the workgroup size, and
+// the second half of the launch is that: waves being started to walk a chain of dependent trips while the vector memory pipe
+// idles.  Several short rows per wave with the CSR arrays did not help (each row's window is a scalar load of its own, a miss
+// costs ~800 cycles and a wave's misses are served one after the other: 6 800 cycles for eight windows).  So the plan owns a
+// packed copy of the short rows: a RECORD is 16 header ints (row ids) + 32 (column, weight) pairs, contiguous, for R = 8 / 4 /
+// 2 / 1 rows of at most 32 / R neighbours (padding weighs 0).  A wave knows its record from its index alone: ONE coalesced
+// vector load brings rows, columns and weights (no descriptor trip, no scalar loads), LDS hands every lane the pair of step k
+// (broadcast ds_read_b64), the 32 gathers and the rows' S_in / optimizer operands fly together, R epilogues follow.  Two
+// dependent trips for up to eight rows instead of three per row; 20 k waves instead of 51 k.  Same arithmetic per row (CSR
+// order, one fma chain).  6.6 MB of plan for the Yelp2018-shape graph.
+template <int D, int R, bool FUSE>
+__device__ __forceinline__ void spmm_records(const int32_t *__restrict__ rec, const float *__restrict__ X, float *Y, const float *S_in,
+                                             float *S_out, float scale, int32_t *sp_rows, float *fT, float *fm, float *fv,
+                                             const StepScalars *__restrict__ fscal, float *fdE, double *femb, float b1, float b2,
+                                             float eps, float coef, int w_trace = 0) {
+    static_assert(D == 64, "records: one column per lane");
+#ifdef MACR_SPMM_TRACE
+    const unsigned long long tr_rt0 = __builtin_amdgcn_s_memrealtime(), tr_c0 = __builtin_readcyclecounter();
+#endif
+    constexpr int E = kRecEntries / R;                           // neighbours per row
+    __shared__ uint2 s_rec[4][64];
+    const int lane = threadIdx.x & 63;
+    uint2 *win = s_rec[threadIdx.x >> 6];
+    // lanes 0..31: pair l; lanes 32..39: header ints 2 (l - 32), 2 (l - 32) + 1 (row ids)
+    const uint2 mine = lane < 32 ? reinterpret_cast<const uint2 *>(rec + 16)[lane]
+                                 : (lane < 40 ? reinterpret_cast<const uint2 *>(rec)[lane - 32] : make_uint2(0u, 0u));
+    win[lane] = mine;
+    int row[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const uint2 h = win[32 + (q >> 1)];                      // wave-uniform address: a broadcast read
+        row[q] = __builtin_amdgcn_readfirstlane((int)((q & 1) ? h.y : h.x));
+    }
+#ifdef MACR_SPMM_TRACE
+    SPMM_STAMP(w_trace, 2);                                       // the record has arrived
+    if (lane == 0 && w_trace < (1 << 17)) { g_spmm_trace[w_trace][0] = tr_rt0; g_spmm_trace[w_trace][1] = tr_c0; g_spmm_trace[w_trace][3] = 0;
+        g_spmm_trace[w_trace][7] = ((unsigned long long)(unsigned)kRecEntries << 32) | (unsigned)(R << 1); }
+#endif
+    float s[R], th0[R], m0[R], v0[R];
+    int c0[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const size_t o = (size_t)(row[q] < 0 ? 0 : row[q]) * D + lane;
+        s[q] = (S_out != nullptr || FUSE) ? S_in[o] : 0.f;
+        if (FUSE) { c0[q] = sp_rows[row[q] < 0 ? 0 : row[q]]; th0[q] = fT[o]; m0[q] = fm[o]; v0[q] = fv[o]; }
+    }
+    float x[kRecEntries];
+    const uint32_t lane_bytes = (uint32_t)lane * 4u;
+#pragma unroll
+    for (int k = 0; k < kRecEntries; ++k) {
+        const uint32_t cb = win[k].x * (uint32_t)(D * 4);
+        x[k] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(X) + (cb + lane_bytes));
+    }
+#ifdef MACR_SPMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SPMM_STAMP(w_trace, 4);
+#endif
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc = fmaf(__builtin_bit_cast(float, win[q * E + e].y), x[q * E + e], acc);
+        if (row[q] < 0) continue;                                // (wave-uniform: padding of the last record of a class)
+        const size_t o = (size_t)row[q] * D + lane;
+        if (FUSE) {
+            const int cr = __builtin_amdgcn_readfirstlane(c0[q]);
+            float th = th0[q], m = m0[q], vv = v0[q], sq = 0.f;
+            float g = (s[q] + acc) * scale;
+            if (cr) { g = fmaf(coef * (float)cr, th, g); sq = th * th; fdE[o] = 0.f; }
+            adam1(th, m, vv, g, fscal->lr_t, b1, b2, eps);
+            fT[o] = th; fm[o] = m; fv[o] = vv;
+            if (cr) {
+                sq = wave_sum(sq);
+                if (lane == 0) { atomicAdd(femb + (row[q] & 2047), (double)cr * (double)sq); sp_rows[row[q]] = 0; }
+            }
+        } else {
+            if (Y) Y[o] = acc;
+            if (S_out) S_out[o] = (s[q] + acc) * scale;
+        }
+    }
+#ifdef MACR_SPMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SPMM_STAMP(w_trace, 5); SPMM_STAMP_RT(w_trace, 6);
+#endif
+}
+
 // Y = A X (if Y), S_out = (S_in + A X) * scale (if S_out).  S_out may alias S_in in the dense modes (a row is read and
 // written by its own wave only); in kSparseOut mode a row may be computed by several waves, so it must not.
 // Every read-only array is a kernel parameter of its own with __restrict__: pointers that arrive inside a struct carry no
@@ -276,6 +372,8 @@ struct SpmmScalars {
     float scale;
     int B, n_users, chunk, count; // SparseCtx
     float b1, b2, eps, coef;      // AdamFuse
+    int n_single, n_rec8, n_rec4, n_rec2, n_rec1;   // RECORDS (dense layers at d = 64; n_single = 0: off): waves [0, n_single) take one
+                                  // item each, the waves behind them one record each, class by class
 };
 template <int D, int SPARSE, bool FUSE>
 __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int32_t *__restrict__ rowptr,
@@ -288,7 +386,8 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
                                                   float *slab, int32_t *sp_cnt,
                                                   const int32_t *__restrict__ sp_u, const int32_t *__restrict__ sp_i,
                                                   const int32_t *__restrict__ sp_j, float *fT, float *fm, float *fv,
-                                                  const StepScalars *__restrict__ fscal, float *fdE, double *femb) {
+                                                  const StepScalars *__restrict__ fscal, float *fdE, double *femb,
+                                                  const int32_t *__restrict__ records) {
     struct {                       // (the names the body uses)
         int N, n_items, n_slots, n_groups; float scale;
         const int32_t *rowptr; const int4 *items;
@@ -336,6 +435,19 @@ __global__ __launch_bounds__(256) void k_spmm_row(const SpmmScalars P, const int
         return d;
     };
     const int w = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if constexpr (SPARSE == kDense && D == 64) {
+        if (P.n_single > 0 && w >= P.n_single) {                 // (wave-uniform) a record of short rows
+            const int k = w - P.n_single;
+            const int32_t *rec = records + (size_t)k * kRecInts;
+#define MACR_REC_ARGS rec, X, Y, S_in, S_out, P.scale, sp_cnt, fT, fm, fv, fscal, fdE, femb, P.b1, P.b2, P.eps, P.coef, w
+            if (k < P.n_rec8) spmm_records<D, 8, FUSE>(MACR_REC_ARGS);
+            else if (k < P.n_rec8 + P.n_rec4) spmm_records<D, 4, FUSE>(MACR_REC_ARGS);
+            else if (k < P.n_rec8 + P.n_rec4 + P.n_rec2) spmm_records<D, 2, FUSE>(MACR_REC_ARGS);
+            else if (k < P.n_rec8 + P.n_rec4 + P.n_rec2 + P.n_rec1) spmm_records<D, 1, FUSE>(MACR_REC_ARGS);
+#undef MACR_REC_ARGS
+            return;
+        }
+    }
     if (w >= total) return;
 #ifdef MACR_SPMM_TRACE
     const unsigned long long tr_rt0 = __builtin_amdgcn_s_memrealtime(), tr_c0 = __builtin_readcyclecounter();
@@ -934,17 +1046,23 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
             S_in = sum;
             continue;
         }
+        // dense layers at d = 64: the plan's short rows run from its records, several to a wave (MACR_SPMM_RECORDS=0: one row per wave)
+        static const bool rec_on = !(getenv("MACR_SPMM_RECORDS") && atoi(getenv("MACR_SPMM_RECORDS")) == 0);
+        const bool rec = rec_on && plan_dev && mode == kDense && d == 64 && ph.rec_off > 0 && ph.n_single > 0;
+        const int n_rec = ph.n_rec[0] + ph.n_rec[1] + ph.n_rec[2] + ph.n_rec[3];
+        const int rgrid = rec ? (ph.n_single + n_rec + 3) / 4 : grid;
+        const int32_t *records = rec ? static_cast<const int32_t *>(plan_dev) + ph.rec_off : nullptr;
         const SpmmScalars ps = {a.N, a.n_items, a.n_slots, a.n_groups, a.scale, a.sp.B, a.sp.n_users, a.sp.chunk, a.sp.count,
-                                af.b1, af.b2, af.eps, af.coef};
+                                af.b1, af.b2, af.eps, af.coef, rec ? ph.n_single : 0, ph.n_rec[0], ph.n_rec[1], ph.n_rec[2], ph.n_rec[3]};
 #define MACR_SPMM_ARGS ps, a.rowptr, a.col, a.val, a.items, a.slot_group, a.group_slot0, a.group_split, a.split_group0, \
                        a.arrivals, a.X, a.Y, a.S_in, a.S_out, a.slab, a.sp.cnt, a.sp.u, a.sp.i, a.sp.j, af.T, af.m, af.v,  \
-                       af.scal, af.dE, af.emb_acc
+                       af.scal, af.dE, af.emb_acc, records
 #define MACR_SPMM_ROW(D_)                                                                                         \
     do {                                                                                                          \
         if (mode == kSparseOut) k_spmm_row<D_, kSparseOut, false><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);          \
         else if (mode == kSparseIn) k_spmm_row<D_, kSparseIn, false><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);       \
-        else if (fused) k_spmm_row<D_, kDense, true><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);                       \
-        else k_spmm_row<D_, kDense, false><<<grid, 256, 0, st>>>(MACR_SPMM_ARGS);                                 \
+        else if (fused) k_spmm_row<D_, kDense, true><<<rgrid, 256, 0, st>>>(MACR_SPMM_ARGS);                       \
+        else k_spmm_row<D_, kDense, false><<<rgrid, 256, 0, st>>>(MACR_SPMM_ARGS);                                 \
     } while (0)
         switch (d) {
             case 32: MACR_SPMM_ROW(32); break;
@@ -1016,7 +1134,7 @@ static std::vector<int32_t> xcd_order(std::vector<int32_t> (&q)[kNumXcd], const 
     return order;
 }
 
-static void build_plan(int N, const int32_t *rowptr, const int32_t *col, std::vector<int32_t> &out) {
+static void build_plan(int N, const int32_t *rowptr, const int32_t *col, const float *val, std::vector<int32_t> &out) {
     struct Item { int32_t row, beg, end, slot; };
     std::vector<Item> items;
     std::vector<int32_t> slot_group, group_slot0, group_split, split_group0, split_row, piece_xcd;
@@ -1081,6 +1199,41 @@ static void build_plan(int N, const int32_t *rowptr, const int32_t *col, std::ve
     out.insert(out.end(), group_split.begin(), group_split.end());
     out.insert(out.end(), split_group0.begin(), split_group0.end());
     out.insert(out.end(), split_row.begin(), split_row.end());
+    // records of the short rows (spmm_records): the items are sorted longest first, so the rows of <= kRecEntries neighbours are
+    // the tail of the item list; class c packs 8 >> c rows of at most 4 << c neighbours into one record
+    if (col && val) {
+        size_t first_short = n_slots;
+        while (first_short < items.size() && items[first_short].end - items[first_short].beg > kRecEntries) ++first_short;
+        while (out.size() % 4) out.push_back(0);                 // (records are read as 8-byte pairs: keep them 16-byte aligned)
+        PlanHeader *hp = reinterpret_cast<PlanHeader *>(out.data());
+        hp->n_single = (int32_t)first_short;
+        hp->rec_off = (int32_t)out.size();
+        size_t k = items.size();                                 // walk from the shortest rows up: class 0 first
+        int32_t n_rec[4] = {0, 0, 0, 0};
+        for (int c = 0; c < 4; ++c) {
+            const int R = 8 >> c, E = kRecEntries / R;
+            size_t lo = k;
+            while (lo > first_short && items[lo - 1].end - items[lo - 1].beg <= E) --lo;     // rows of this class: [lo, k)
+            for (size_t r0 = lo; r0 < k; r0 += R) {
+                int32_t recbuf[kRecInts];
+                for (int q = 0; q < 16; ++q) recbuf[q] = -1;
+                for (int q = 0; q < 2 * kRecEntries; ++q) recbuf[16 + q] = 0;
+                for (int q = 0; q < R && r0 + q < k; ++q) {
+                    const Item &it = items[r0 + q];
+                    recbuf[q] = it.row;
+                    for (int e = 0; e < it.end - it.beg; ++e) {
+                        recbuf[16 + 2 * (q * E + e)] = col[it.beg + e];
+                        memcpy(&recbuf[16 + 2 * (q * E + e) + 1], &val[it.beg + e], 4);
+                    }
+                }
+                out.insert(out.end(), recbuf, recbuf + kRecInts);
+                ++n_rec[c];
+            }
+            k = lo;
+        }
+        hp = reinterpret_cast<PlanHeader *>(out.data());
+        for (int c = 0; c < 4; ++c) hp->n_rec[c] = n_rec[c];
+    }
 }
 
 
@@ -1227,7 +1380,7 @@ using namespace macr;
 
 // ---- plan (host) ----------------------------------------------------------------
 static void build_whole_plan(int N, const int32_t *rowptr, const int32_t *col, const float *val, std::vector<int32_t> &v) {
-    build_plan(N, rowptr, col, v);
+    build_plan(N, rowptr, col, val, v);
     // The entry stream is an option (MACR_SPMM_STREAM=1 at plan time): with the XCD-affine piece order both kernels sit at
     // the same level (stand-alone dense layer at the Yelp2018 shape: row kernel 42.7 us, stream kernel 46.3; LightGCN step
     // 205-209 us either way), and the row kernel needs no second copy of the matrix.

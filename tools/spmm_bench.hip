@@ -124,7 +124,7 @@ int main(int argc, char **argv) {
         const PlanHeader *phh = reinterpret_cast<const PlanHeader *>(plan.data());
         std::vector<unsigned long long> tr((size_t)(1 << 17) * 8);
         CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(macr::g_spmm_trace), tr.size() * 8));
-        const int nw = std::min(phh->n_items, 1 << 17);   // (bundle waves have ids below n_items too)
+        const int nw = std::min(phh->n_single + phh->n_rec[0] + phh->n_rec[1] + phh->n_rec[2] + phh->n_rec[3], 1 << 17);   // (bundle waves have ids below n_items too)
         struct Acc { double n = 0, desc = 0, first = 0, rest = 0, store = 0, total = 0, entries = 0; };
         std::map<int, Acc> cls;
         unsigned long long t_min = ~0ull, t_max = 0;
