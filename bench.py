@@ -130,6 +130,7 @@ def bench_config4(args, rank, world, dev, emit=True):
                                        shards=(xavier_rows(own_u.n, n_users), xavier_rows(own_i.n, n_items), n_users, n_items))
     n_batches = 32                  # (independent of --steps: same batches, same model, whatever the call)
     batches = synth.train_batches(n_batches, n_users, n_items, B, gen_all, dev)
+    sharding.broadcast_params([batches])      # ONE batch stream for the one model (the draws are seeded; this makes it a fact)
 
     def barrier():
         if world > 1:

@@ -30,16 +30,21 @@ def xavier_table(rows, d, gen, device):
     return ((torch.rand((rows, d), generator=gen, device=device, dtype=torch.float32) * 2 - 1) * limit).contiguous()
 
 
-def zipf_probs(n, device, s=1.0):
-    p = 1.0 / torch.arange(1, n + 1, device=device, dtype=torch.float64) ** s
-    return (p / p.sum()).to(torch.float32)
+def zipf_cdf(n, device, s=1.0):
+    """the Zipf law's CDF, summed on the HOST in float64: a device cumsum (decoupled look-back scan) is not bit-reproducible
+    from run to run, and ranks that must draw the SAME batch (row-sharded training) would differ in a sample now and then"""
+    p = 1.0 / np.arange(1, n + 1, dtype=np.float64) ** s
+    cdf = np.cumsum(p / p.sum())
+    cdf[-1] = 1.0
+    return torch.from_numpy(cdf).to(device)
 
 
 def train_batches(n_steps, n_users, n_items, batch, gen, device, zipf=True, sort_by_pos=False):
-    """(n_steps,3,B) int32: users w/o replacement per step, Zipf positives, uniform negatives.
+    """(n_steps,3,B) int32: users w/o replacement per step, Zipf positives, uniform negatives.  A function of the
+    generator's seed alone (inverse-CDF draws against a host-summed CDF: see zipf_cdf).
     sort_by_pos: pre-order the triples of every batch by positive item id (diagnostic only: the training step orders
     its batch itself, on the device, so benchmarks feed batches exactly as a sampler emits them)."""
-    probs = zipf_probs(n_items, device)
+    cdf = zipf_cdf(n_items, device) if zipf else None
     out = torch.empty((n_steps, 3, batch), dtype=torch.int32, device=device)
     for s in range(n_steps):
         if batch <= n_users:
@@ -48,7 +53,8 @@ def train_batches(n_steps, n_users, n_items, batch, gen, device, zipf=True, sort
             u = torch.randint(0, n_users, (batch,), generator=gen, device=device)
         out[s, 0] = u.to(torch.int32)
         if zipf:
-            out[s, 1] = torch.multinomial(probs, batch, replacement=True, generator=gen).to(torch.int32)
+            r = torch.rand((batch,), generator=gen, device=device, dtype=torch.float64)
+            out[s, 1] = torch.searchsorted(cdf, r, right=True).clamp_(max=n_items - 1).to(torch.int32)
         else:
             out[s, 1] = torch.randint(0, n_items, (batch,), generator=gen, device=device).to(torch.int32)
         out[s, 2] = torch.randint(0, n_items, (batch,), generator=gen, device=device).to(torch.int32)
