@@ -545,12 +545,92 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
             cn.x = wave_rol1(cn.x); cn.y = wave_rol1(cn.y); acc.x = wave_rol1(acc.x); acc.y = wave_rol1(acc.y);
         }
     };
-#ifdef MACR_ABL_BXB_EXACT
+    // FAST with the rows of a lane taken in PAIRS (R = 2, 4): a packed register holds the SAME quantity of two rows instead
+    // of the x and y halves of one pair, so every instruction of the chain is packed with both halves useful -- 17 packed,
+    // 2 plain, 7 transcendental per TWO pairs (PMC, profiles/pmc_sq_latest.json: a plain or packed VALU instruction is 4
+    // issue cycles, a transcendental 8, and the kernel's VALU is busy for all of its time: instruction count is the bound).
+    // In this form's range (y <= 6) e^-y + eps*(1 + e^-y) is e^-y to 4e-8 relative (eps/e^-y), so ny = ey and
+    //     r = 1/(dx nx dy),  -f'(x) = ex dy r,  g'(y) = dx nx r (= 1/dy),  tx ty = nx^2 ey r,
+    // and one logarithm serves the product of the two rows' tx ty (each >= 5e-12: tx >= sig(-20), ty >= 1 - sig(6)).
+    auto run_tile_pairs = [&]() {
+        constexpr int H = R / 2 > 0 ? R / 2 : 1;
+        v2f sa[H], sb[H], a2[H], b2[H], dax[H], dby[H];
+        bool ok0[H], ok1[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            a2[h] = v2f{ab[2 * h].x, ab[(2 * h + 1) % R].x}; b2[h] = v2f{ab[2 * h].y, ab[(2 * h + 1) % R].y};
+            sa[h] = a2[h] * (-kLog2e); sb[h] = b2[h] * (-kLog2e);
+            dax[h] = v2f{0.f, 0.f}; dby[h] = v2f{0.f, 0.f};
+            ok0[h] = rok[2 * h]; ok1[h] = rok[(2 * h + 1) % R];
+        }
+        v2f accx = {0.f, 0.f}, accy = {0.f, 0.f};
+        float lsum = 0.f;
+#pragma unroll 2
+        for (int k = 0; k < 64; ++k) {
+            bool colok = true;
+            if (!FULL) colok = cb * 256 + wid * 64 + ((lane + k) & 63) < B;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const v2f zx = sa[h] * cn.x, zy = sb[h] * cn.y;
+                const v2f ex = {__builtin_amdgcn_exp2f(zx.x), __builtin_amdgcn_exp2f(zx.y)};
+                const v2f ey = {__builtin_amdgcn_exp2f(zy.x), __builtin_amdgcn_exp2f(zy.y)};
+                const v2f dx = ex + one, dy = ey + one;
+                const v2f nx = __builtin_elementwise_fma(eps, dx, one);
+                const v2f u = dx * nx;
+                const v2f w = u * dy;
+                const v2f r = {__builtin_amdgcn_rcpf(w.x), __builtin_amdgcn_rcpf(w.y)};
+                const v2f exr = ex * r, eyr = ey * r;
+                v2f gx = exr * dy, gy = u * r;
+                v2f T = (nx * nx) * eyr;
+                if (!FULL) {
+                    const bool k0 = ok0[h] && colok, k1 = ok1[h] && colok;
+                    gx = v2f{k0 ? gx.x : 0.f, k1 ? gx.y : 0.f}; gy = v2f{k0 ? gy.x : 0.f, k1 ? gy.y : 0.f};
+                    T = v2f{k0 ? T.x : 1.0f, k1 ? T.y : 1.0f};
+                }
+                lsum += __builtin_amdgcn_logf(T.x * T.y);
+                dax[h] = __builtin_elementwise_fma(gx, v2f{cn.x, cn.x}, dax[h]);
+                dby[h] = __builtin_elementwise_fma(gy, v2f{cn.y, cn.y}, dby[h]);
+                accx = __builtin_elementwise_fma(gx, a2[h], accx);
+                accy = __builtin_elementwise_fma(gy, b2[h], accy);
+            }
+            cn.x = wave_rol1(cn.x); cn.y = wave_rol1(cn.y);
+            accx.x = wave_rol1(accx.x); accx.y = wave_rol1(accx.y); accy.x = wave_rol1(accy.x); accy.y = wave_rol1(accy.y);
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            dab[2 * h] = v2f{dax[h].x, dby[h].x};
+            if (2 * h + 1 < R) dab[2 * h + 1] = v2f{dax[h].y, dby[h].y};
+        }
+        acc = v2f{accx.x + accx.y, accy.x + accy.y};
+        l2 = v2f{lsum, 0.f};
+    };
+#if defined(MACR_ABL_BXB_EXACT)
     const bool fast = false;
+#elif defined(MACR_ABL_BXB_FORCEFAST)
+    const bool fast = true;
 #else
-    const bool fast = !__any(!(cn.x >= -20.0f) || !(cn.y >= -20.0f) || !(cn.y <= 3.0f));   // (NaN -> exact path)
+    // The window of the 4-transcendental form is a statement about x = p*a and y = n*b: -20 <= x, YLO <= y <= 3.  a and b
+    // are products of sigmoids, in (0,1) and usually well below 1, so the wave bounds them by the maxima over ITS rows:
+    // x >= min(p,0)*amax, y <= max(n,0)*bmax, y >= min(n,0)*bmax.  (Columns alone -- a, b bounded by 1 -- put 40-60 % of
+    // the tiles of a model a few hundred steps old on the exact side for the 1 % of its negatives that score above 3:
+    // profiles/r05_logit_probe.txt.)  YLO: the row-pair form has no e^-2y product and holds down to y = -60.
+    float amax = 0.f, bmax = 0.f;
+#pragma unroll
+    for (int q = 0; q < R; ++q) { amax = fmaxf(amax, ab[q].x); bmax = fmaxf(bmax, ab[q].y); }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { amax = fmaxf(amax, __shfl_xor(amax, m, 64)); bmax = fmaxf(bmax, __shfl_xor(bmax, m, 64)); }
+    // YHI: above it the reference's own rounding is what the exact form reproduces -- fl(1 - fl(sig(y))) is off by up to
+    // 3e-8 (1 + e^y) relative, which is this form's distance from it: <= 1.2e-5 of a term that is >= 6 at y = 6, i.e.
+    // <= 2e-6 relative on a loss that is a sum of positive terms (tolerance 1e-5); 2e-7 at y = 3, 1.1e-5 at y = 8.
+    constexpr float YLO = R >= 2 ? -60.0f : -20.0f, YHI = 6.0f;
+    const float xlo = cn.x * amax, yv = cn.y * bmax;
+    const bool fast = !__any(!(xlo >= -20.0f) || !(yv >= YLO) || !(yv <= YHI) || !(amax <= 1.0f) || !(bmax <= 1.0f));   // (NaN -> exact path)
 #endif
-    if (fast) run_tile(std::true_type{}); else run_tile(std::false_type{});
+    if (fast) {
+        if constexpr (R >= 2) run_tile_pairs(); else run_tile(std::true_type{});
+    } else {
+        run_tile(std::false_type{});
+    }
     if (cok) {                                  // home again: column c over this wave's 64*R rows
         colpart[((size_t)rb * 2 + 0) * Bp + c] = -acc.x;
         colpart[((size_t)rb * 2 + 1) * Bp + c] = acc.y;
