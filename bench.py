@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--c4-users", type=int, default=10_000_000)
     ap.add_argument("--c4-items", type=int, default=1_000_000)
     ap.add_argument("--c4-eval-users", type=int, default=100_000)
+    ap.add_argument("--c4-lazy", type=int, default=0,
+                    help="config4: period K of the lazy dense Adam pass (1 = the dense pass every step; 0 = by shard size)")
     ap.add_argument("--no-config4", action="store_true",
                     help="N >= 2 only: skip the configs[4] leg (ONE row-sharded model over the ranks) that the default workload's "
                          "line carries as `config4`")
@@ -127,7 +129,8 @@ def bench_config4(args, rank, world, dev, emit=True):
     hyper = ops.make_hyper(lr, regs, alpha, beta, B)
     model = sharded_train.RowShardedMF(None, None, w, wu, sharded_train.HipBackend(ops.LOSS_RUBIBCEBOTH, d, hyper, dev),
                                        rank=rank, world=world,
-                                       shards=(xavier_rows(own_u.n, n_users), xavier_rows(own_i.n, n_items), n_users, n_items))
+                                       shards=(xavier_rows(own_u.n, n_users), xavier_rows(own_i.n, n_items), n_users, n_items),
+                                       lazy_period=args.c4_lazy if args.c4_lazy > 0 else None)
     n_batches = 32                  # (independent of --steps: same batches, same model, whatever the call)
     batches = synth.train_batches(n_batches, n_users, n_items, B, gen_all, dev)
     sharding.broadcast_params([batches])      # ONE batch stream for the one model (the draws are seeded; this makes it a fact)
@@ -154,6 +157,7 @@ def bench_config4(args, rank, world, dev, emit=True):
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_steps(args.steps, args.warmup)
+        model.flush()               # lazy dense Adam: the region ends with every row at its last step (the tables a reader would see)
         torch.cuda.synchronize(); barrier()
         return sharding.max_over_ranks(time.perf_counter() - t0, dev)
     regions = [timed_region()]
@@ -181,7 +185,7 @@ def bench_config4(args, rank, world, dev, emit=True):
     kern = {n_: {"launches_per_step": c_ / n_prof, "event_us": 1e3 * t / c_} for n_, (c_, t) in ku.items()}
     rows_local = own_u.n + own_i.n
     adam_bytes = 24.0 * d * rows_local
-    adam_name = "adam_indexed" if "adam_indexed" in kern else "adam_dense"    # (indexed: the pass sums the staged gradient rows itself)
+    adam_name = "adam_lazy" if "adam_lazy" in kern else "adam_indexed" if "adam_indexed" in kern else "adam_dense"    # (indexed: the pass sums the staged gradient rows itself)
     adam_us = kern.get(adam_name, {}).get("event_us")
     roofline = None
     if adam_us:
@@ -190,6 +194,18 @@ def bench_config4(args, rank, world, dev, emit=True):
                     "frac": gbps / HBM_PEAK_GBS, "traffic": None, "avg_us": adam_us, "algorithmic_bytes": adam_bytes,
                     "note": "TF-style dense Adam over this rank's %d rows (24*d bytes per row and step); event-timed, "
                             "includes ~3 us of event overhead" % rows_local}
+        if adam_name == "adam_lazy":
+            K = model.lazy_period
+            moved = adam_bytes / K + 3.0 * B / world * (24 * d + 4)
+            elems = 1.0 * d * rows_local
+            valu_us = elems * 13 / 64 * 4.5 / (1024 * 2.4e9) * 1e6
+            roofline.update({"period": K, "moved_bytes_model": moved, "moved_gbps": moved / (adam_us * 1e-6) / 1e9,
+                             "valu_floor_us_model": valu_us,
+                             "note": "lazy dense Adam (period %d): every row still receives every step's update (the algorithmic bytes of SURVEY "
+                                     "8(d): 24*d per row and step), but K steps of a row share ONE trip to HBM -- `achieved` is algorithmic bytes "
+                                     "per second and can exceed the HBM peak; `moved_bytes_model` = a K-th of the shard + the batch's rows is what "
+                                     "a launch really moves; the pass is bound by the VALU time of the same arithmetic (13 instructions per "
+                                     "element and step, ~4.5 cycles each per wave64: `valu_floor_us_model`)" % K})
     step_bytes = B * (24 * d + 12) + 24.0 * d * (n_users + n_items)
     # ------------------------------------------------------------- evaluation: item shards + one all-gather
     eval_out = {}
@@ -273,7 +289,7 @@ def bench_config4(args, rank, world, dev, emit=True):
                                                     ("all-reduce of the batch's 3B rows (%.1f MB) + all-reduce of the (B,B) partials + broadcast "
                                                      "of the branch-vector partials per step" % (3 * B * d * 4 / 1e6))),
                           "global_batch": B},
-               "rows_per_rank": rows_local, "bytes_per_rank": 4.0 * d * rows_local * 4 + 4.0 * rows_local,
+               "rows_per_rank": rows_local, "bytes_per_rank": 4.0 * d * rows_local * 4 + 4.0 * rows_local, "lazy_adam_period": model.lazy_period,
                "wire_bytes_per_step": None if model.wire_rows is None else {
                    "rows_crossing_ranks_each_way": model.wire_rows, "row_bytes": model.wire_rows * d * 4,
                    "replicated_step_all_reduce_buffer_bytes": 3 * B * d * 4,

@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     10
+#define MACR_ABI_VERSION     11
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -214,6 +214,52 @@ int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_l
                      float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu, float *vwu,
                      float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ, const macr_hyper *hp,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Lazy dense Adam: the dense pass of tf.train.AdamOptimizer (macr_mf/model.py:74,:95 -- every row of P and Q moves every
+ * step, touched by the batch or not) blocked in TIME (new; the reference has one device and small tables).
+ * A row without gradient moves by a recurrence of its own state and the step's lr_t (m <- b1 m, v <- b2 v,
+ * theta <- theta - lr_t m / (sqrt(v) + eps)), so K such steps can be applied in registers in one trip to memory:
+ * every row carries a STAMP (Adam steps received), the library keeps the lr_t of the last 256 steps, and a step
+ *   - updates the rows its batch touched (their missing steps without gradient, then this step with it),
+ *   - sweeps one K-th of every table up to the step (K = period),
+ *   - leaves every other row alone: 24*d bytes per row every K steps instead of every step.
+ * Rows are read through macr_shard_gather_lazy / macr_lazy_rows (brought to the current step in registers, nothing
+ * written); macr_lazy_flush brings every row to the current step -- the tables then hold, bit for bit, what the
+ * per-step dense pass leaves (call it before anything else reads P, Q or the slots).  The arithmetic per row and step
+ * is the dense pass's; at BASELINE configs[4] (11 M rows, d = 128) the pass goes from 33.8 GB of HBM traffic per step
+ * to the VALU time of the same arithmetic.
+ *   state   (dev) MACR_LAZY_STATE_BYTES, zero-filled once: step counter + ring of lr_t
+ *   stampP/Q (dev) uint32[rows of the (local) table], zero-filled once
+ *   period  1 .. MACR_LAZY_MAX_PERIOD (1 = every row every step, through the lazy kernels)
+ * -------------------------------------------------------------------------*/
+#define MACR_LAZY_STATE_BYTES 1040
+#define MACR_LAZY_MAX_PERIOD  64
+typedef struct macr_lazy_adam {
+    void     *state;
+    uint32_t *stampP;
+    uint32_t *stampQ;
+    int       period;
+} macr_lazy_adam;
+
+/* macr_shard_gather on lazily updated shards (mP .. vQ: the slots of the local tables) */
+int macr_shard_gather_lazy(int B, int d, const float *P_loc, const float *mP, const float *vP, int u_lo, int u_stride,
+                           int n_users_loc, const float *Q_loc, const float *mQ, const float *vQ, int i_lo, int i_stride,
+                           int n_items_loc, const int32_t *u, const int32_t *i, const int32_t *j, const macr_hyper *hp,
+                           const macr_lazy_adam *lazy, float *rows3, void *stream);
+/* out (dev) fp32[n][d]: row rows[k] (dev int32, local index; < 0: a zero row) of one lazily updated table as of the current step */
+int macr_lazy_rows(long long n, int d, const int32_t *rows, const float *theta, const float *m, const float *v,
+                   const uint32_t *stamp, const void *state, const macr_hyper *hp, float *out, void *stream);
+/* macr_shard_apply with the lazy pass in place of the dense one (same arguments + lazy) */
+int macr_shard_apply_lazy(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int u_stride, int i_lo,
+                          int i_stride, const int32_t *u, const int32_t *i, const int32_t *j,
+                          float *P_loc, float *Q_loc, float *w, float *wu,
+                          float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu, float *vwu,
+                          float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ, const macr_hyper *hp,
+                          const macr_lazy_adam *lazy, void *workspace, size_t workspace_bytes, void *stream);
+/* every row of both tables brought to the current step (n_rows_p / n_rows_q: rows of the local tables) */
+int macr_lazy_flush(int d, long long n_rows_p, long long n_rows_q, float *P, float *Q, float *mP, float *vP, float *mQ,
+                    float *vQ, const macr_hyper *hp, const macr_lazy_adam *lazy, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Device-side sampler of (user, positive, negative) triples (new).

@@ -17,7 +17,8 @@ SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINU
 MAX_TOPK = 128
 MAX_TOPK_FUSED = 32
 MAX_SWEEP = 4
-ABI_VERSION = 10
+ABI_VERSION = 11
+LAZY_STATE_BYTES, LAZY_MAX_PERIOD = 1040, 64
 
 
 class MacrError(RuntimeError):
@@ -33,7 +34,13 @@ class Hyper(ctypes.Structure):
                 ("beta", ctypes.c_float), ("batch_size_cfg", ctypes.c_int32)]
 
 
+class LazyAdam(ctypes.Structure):
+    """struct macr_lazy_adam"""
+    _fields_ = [("state", ctypes.c_void_p), ("stampP", ctypes.c_void_p), ("stampQ", ctypes.c_void_p), ("period", ctypes.c_int)]
+
+
 _p, _i, _f, _z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_ll = ctypes.c_longlong
 
 # name -> (restype, argtypes); mirrors include/macr_hip.h declaration by declaration
 SIGNATURES = {
@@ -55,6 +62,11 @@ SIGNATURES = {
     "macr_shard_backward_slice": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, ctypes.POINTER(Hyper), _p, _p, _p, _p, _p, _z, _p]),
     "macr_shard_stage": (_i, [_i, _i, _p, _p, _z]),
     "macr_shard_apply": (_i, [_i] * 9 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), _p, _z, _p]),
+    "macr_shard_gather_lazy": (_i, [_i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, ctypes.POINTER(Hyper),
+                                    ctypes.POINTER(LazyAdam), _p, _p]),
+    "macr_lazy_rows": (_i, [_ll, _i, _p, _p, _p, _p, _p, _p, ctypes.POINTER(Hyper), _p, _p]),
+    "macr_shard_apply_lazy": (_i, [_i] * 9 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), ctypes.POINTER(LazyAdam), _p, _z, _p]),
+    "macr_lazy_flush": (_i, [_i, _ll, _ll] + [_p] * 6 + [ctypes.POINTER(Hyper), ctypes.POINTER(LazyAdam), _p]),
     "macr_sample_triples": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _i, _p, _i, _p, _p, _p, _p]),
     "macr_sample_triples_many": (_i, [ctypes.c_uint64, ctypes.c_uint64, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "macr_spmm_plan_bytes": (_z, [_i, _p, _p, _p]),

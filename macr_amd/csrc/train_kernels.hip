@@ -62,6 +62,7 @@ struct AdamSeg {
     int n_parts;             // > 0: g holds n_parts partial rows (stride part_stride floats) to be summed
     int part_stride;
     int32_t *touched;        // NULL: gradient is dense, always read, left untouched
+    uint32_t *stamp;         // lazy pass only (k_adam_lazy): Adam steps the row has received
     const uint32_t *sv;      // INDEXED pass (large batches): sorted reference list (values = staging rows) and the staging
     const float *stage;      //   buffer; a flag with a length field names a row's references instead of a row of g
     long long n_vec;         // number of float4 in the segment
@@ -236,6 +237,226 @@ __global__ __launch_bounds__(256) void k_adam_dense(AdamArgs a, const StepScalar
     __shared__ float4 s_red[256];
     adam_block<true, INDEXED>(a, blockIdx.x, scal->lr_t, s_red);
     if (blockIdx.x == 0 && L.losses && threadIdx.x < 64) finalize_losses(L, threadIdx.x);
+}
+
+// ----------------------------------------------------------------------------
+// Lazy dense Adam: the dense pass blocked in TIME (include/macr_hip.h: macr_lazy_adam).
+// tf.train.AdamOptimizer moves every row every step (above), and a row the batch did not touch moves by a recurrence that
+// needs nothing but the row itself and the step's lr_t:
+//     m <- b1 m ;  v <- b2 v ;  theta <- theta - lr_t m / (sqrt(v) + eps)          (adam4 with g = 0, bit for bit *)
+// So K such steps can be applied in registers in ONE trip to memory instead of K: every row carries a stamp (the number
+// of Adam steps it has received), the library keeps the lr_t of the last kLazyRing steps, and step T
+//   * updates the rows the batch touched (stamp .. T-1 without gradient, then step T with it),
+//   * sweeps one K-th of the table (chunk c of kAdamVecPerBlock float4 belongs to step T when c % K == T % K) up to T,
+//   * reads every other row NOWHERE: 24 d bytes per row every K steps instead of every step.
+// Whoever needs a row in between (the gather of the next batch) brings it up to date in registers and writes nothing; a
+// flush brings every row to T -- the tables are then what the per-step dense pass leaves, bit for bit (tests: lazy vs dense
+// with torch.equal).  The arithmetic per row and step is unchanged, so the pass turns from HBM-bound (33.8 GB per step at
+// 11 M rows, d = 128: 6.2 ms) into VALU-bound (13 instructions per element and step: ~0.5 ms).
+// (*) with g = 0 the dense pass computes m*b1 + 0 and v*b2 + 0 (as an fma or a mul + add, whichever way the compiler
+// contracts them): round(m*b1), round(v*b2) either way; only the sign of a zero can differ, and no later value depends on it.
+// ----------------------------------------------------------------------------
+constexpr int kLazyRing = 256;
+struct LazyState {
+    uint32_t t;                  // Adam steps whose lr_t is known: lr[s % kLazyRing] holds step s for s in (t - kLazyRing, t]
+    uint32_t pad[3];
+    float lr[kLazyRing];
+};
+static_assert(sizeof(LazyState) == MACR_LAZY_STATE_BYTES, "macr_hip.h: MACR_LAZY_STATE_BYTES");
+static_assert(MACR_LAZY_MAX_PERIOD * 2 <= kLazyRing, "a row is at most one sweep period (+ the pending step) behind");
+
+__device__ __forceinline__ void adam4_idle(float4 &th, float4 &m, float4 &v, float lr_t, float b1, float b2, float eps) {
+#ifdef MACR_LAZY_IDLE_FULL
+    float4 zero = make_float4(0, 0, 0, 0);
+    asm volatile("" : "+v"(zero.x), "+v"(zero.y), "+v"(zero.z), "+v"(zero.w));
+    adam4(th, m, v, zero, lr_t, b1, b2, eps);
+    return;
+#endif
+    m.x *= b1; m.y *= b1; m.z *= b1; m.w *= b1;
+    v.x *= b2; v.y *= b2; v.z *= b2; v.w *= b2;
+    th.x = adam_update(th.x, m.x, v.x, lr_t, eps); th.y = adam_update(th.y, m.y, v.y, lr_t, eps);
+    th.z = adam_update(th.z, m.z, v.z, lr_t, eps); th.w = adam_update(th.w, m.w, v.w, lr_t, eps);
+}
+
+// the step counter advances and the step's lr_t enters the ring (one thread, in a kernel that runs after the step's lr_t
+// is known and before the step's lazy pass)
+__device__ __forceinline__ void lazy_tick(LazyState *ls, float lr_t) {
+    const uint32_t t = ls->t + 1u;
+    ls->lr[t & (kLazyRing - 1)] = lr_t;
+    ls->t = t;
+}
+
+// N float4 of one segment per thread (vi[k] < 0: none): bring each from its row's stamp to step `upto` without gradient,
+// then -- STEP -- apply step upto + 1 with the row's gradient (flag protocol of adam_block), store, stamp.  All loads of a
+// thread are issued before anything is consumed; the idle steps of the N vectors walk the steps together (one LDS read of
+// lr_t per step, N independent chains in flight).
+template <int N, bool INDEXED, bool STEP>
+__device__ __forceinline__ void adam_lazy_vecs(const AdamArgs &a, const AdamSeg &sg, const long long (&vi)[N], uint32_t upto,
+                                               const float *s_lr) {
+    float4 th[N], m[N], v[N], gr[N];
+    int flag[N];
+    uint32_t stamp[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        flag[k] = 0; stamp[k] = upto;
+        if (vi[k] >= 0) {
+            const long long row = vi[k] >> a.lpr_shift;
+            if (STEP) flag[k] = sg.touched[row];
+            stamp[k] = sg.stamp[row];
+            th[k] = ld4(sg.theta + vi[k] * 4); m[k] = ld4(sg.m + vi[k] * 4); v[k] = ld4(sg.v + vi[k] * 4);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        gr[k] = make_float4(0, 0, 0, 0);
+        if (!STEP) continue;
+        if (INDEXED && (flag[k] >> kRefShift)) {                // (see adam_block: the row's staged gradient rows, in list order)
+            const int len = flag[k] >> kRefShift;
+            const uint32_t pos = (uint32_t)(flag[k] & (int)(kRefMaxRefs - 1));
+            const float *src = sg.stage + 4 * (vi[k] & (a.lpr - 1));
+            const size_t d = (size_t)4 * a.lpr;
+            float4 acc = make_float4(0, 0, 0, 0);
+            int q = 0;
+            if (sg.sv) {
+                const uint32_t *sv = sg.sv + pos;
+                for (; q + 4 <= len; q += 4) {
+                    const uint32_t r0 = sv[q], r1 = sv[q + 1], r2 = sv[q + 2], r3 = sv[q + 3];
+                    const float4 x0 = ld4(src + r0 * d), x1 = ld4(src + r1 * d), x2 = ld4(src + r2 * d), x3 = ld4(src + r3 * d);
+                    acc = add4(add4(add4(add4(acc, x0), x1), x2), x3);
+                }
+                for (; q < len; ++q) acc = add4(acc, ld4(src + sv[q] * d));
+            } else {
+                const float *run = src + (size_t)pos * d;
+                for (; q + 4 <= len; q += 4) {
+                    const float4 x0 = ld4(run + (size_t)q * d), x1 = ld4(run + (size_t)(q + 1) * d);
+                    const float4 x2 = ld4(run + (size_t)(q + 2) * d), x3 = ld4(run + (size_t)(q + 3) * d);
+                    acc = add4(add4(add4(add4(acc, x0), x1), x2), x3);
+                }
+                for (; q < len; ++q) acc = add4(acc, ld4(run + (size_t)q * d));
+            }
+            gr[k] = acc;
+        } else if (flag[k]) {
+            gr[k] = ld4(sg.g + vi[k] * 4);
+            st4(sg.g + vi[k] * 4, make_float4(0, 0, 0, 0));
+        }
+    }
+    uint32_t lag = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) lag = upto - stamp[k] > lag ? upto - stamp[k] : lag;       // (stamp <= upto always)
+    for (uint32_t s = upto - lag + 1u; s - 1u != upto; ++s) {                                 // s = upto - lag + 1 .. upto
+        const float lr_s = s_lr[s & (kLazyRing - 1)];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (s - 1u - stamp[k] < lag) adam4_idle(th[k], m[k], v[k], lr_s, a.b1, a.b2, a.eps);   // stamp[k] < s (unsigned: s - 1 - stamp in [0, lag))
+    }
+    const float lr_T = s_lr[(upto + 1u) & (kLazyRing - 1)];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (vi[k] < 0) continue;
+        if (STEP) adam4(th[k], m[k], v[k], gr[k], lr_T, a.b1, a.b2, a.eps);
+        st4(sg.theta + vi[k] * 4, th[k]); st4(sg.m + vi[k] * 4, m[k]); st4(sg.v + vi[k] * 4, v[k]);
+        if ((vi[k] & (a.lpr - 1)) == 0) {
+            const long long row = vi[k] >> a.lpr_shift;
+            sg.stamp[row] = STEP ? upto + 1u : upto;
+            if (STEP && flag[k]) sg.touched[row] = 0;
+        }
+    }
+}
+
+// the lazy pass of one step (STEP) or the flush (!STEP).  Grid: sweep blocks of every table segment (n_sweep[s] each, block k
+// of a segment = chunk phase + k * period), then -- STEP -- n_touch blocks over the sorted reference list (one LPR-lane group per
+// position; the group at a row's first reference updates the row unless this step's sweep does), then one block per
+// branch-vector segment (dense every step: one row each).
+struct LazyArgs {
+    const LazyState *state;
+    int period;
+    long long sweep_first[3];        // first block of segment s's sweep blocks; [n_tab] = their end
+    int n_tab;                       // table segments = a.seg[0 .. n_tab)
+    long long touch_first, branch_first;
+    int n_refs, n_users, item_seg;   // sorted reference list: keys [0, n_users) = user rows (segment 0), [n_users, key_end) = item rows
+    uint32_t key_end;
+    const uint32_t *sk;
+};
+
+template <bool INDEXED, bool STEP>
+__global__ __launch_bounds__(256) void k_adam_lazy(AdamArgs a, LazyArgs z, const StepScalars *scal) {
+    __shared__ float s_lr[kLazyRing];
+    __shared__ float4 s_red[256];
+    const long long blk = blockIdx.x;
+    if (STEP && blk >= z.branch_first) {
+        adam_block<true, false>(a, a.seg[z.n_tab + (int)(blk - z.branch_first)].first_block, scal->lr_t, s_red);
+        return;
+    }
+    s_lr[threadIdx.x] = z.state->lr[threadIdx.x];
+    const uint32_t T = z.state->t;                  // STEP: the step being applied; flush: the last step applied anywhere
+    const uint32_t upto = STEP ? T - 1u : T;
+    const uint32_t phase = T % (uint32_t)z.period;
+    __syncthreads();
+    if (blk < z.touch_first) {
+        int s = 0;
+        if (z.n_tab > 1 && blk >= z.sweep_first[1]) s = 1;
+        const AdamSeg &sg = a.seg[s];
+        const long long chunk = (STEP ? (long long)phase : 0) + (blk - z.sweep_first[s]) * (STEP ? z.period : 1);
+        const long long base = chunk * kAdamVecPerBlock + threadIdx.x;
+        long long vi[kAdamIters];
+#pragma unroll
+        for (int it = 0; it < kAdamIters; ++it) {
+            vi[it] = base + (long long)it * 256;
+            if (vi[it] >= sg.n_vec) vi[it] = -1;
+        }
+        adam_lazy_vecs<kAdamIters, INDEXED, STEP>(a, sg, vi, upto, s_lr);
+        return;
+    }
+    if (STEP) {
+        const int sub = threadIdx.x & (a.lpr - 1);
+        const long long p = (blk - z.touch_first) * (256 >> a.lpr_shift) + (threadIdx.x >> a.lpr_shift);
+        long long vi[1] = {-1};
+        int s = 0;
+        if (p < z.n_refs) {
+            const uint32_t key = z.sk[p], prev = p > 0 ? z.sk[p - 1] : 0xffffffffu;
+            if (key < z.key_end && key != prev) {
+                const bool is_user = key < (uint32_t)z.n_users;
+                s = is_user ? 0 : z.item_seg;
+                const long long row = is_user ? key : key - (uint32_t)z.n_users;
+                const long long chunk = (row << a.lpr_shift) / kAdamVecPerBlock;      // (a row never straddles two chunks)
+                if (chunk % z.period != phase) vi[0] = (row << a.lpr_shift) + sub;
+            }
+        }
+        if (vi[0] >= 0) adam_lazy_vecs<1, INDEXED, true>(a, a.seg[s], vi, upto, s_lr);
+    }
+}
+
+// rows of a lazily updated table as the per-step dense pass would hold them now: theta brought from the row's stamp to the
+// current step in registers, nothing written back.  One LPR-lane group per output row; rows[k] < 0: a zero row.
+struct LazyTable { const float *theta, *m, *v; const uint32_t *stamp; };
+template <int LPR>
+__device__ __forceinline__ float4 lazy_row4(const LazyTable &tb, long long row, int sub, uint32_t T, const float *s_lr, float b1,
+                                            float b2, float eps) {
+    const size_t at = ((size_t)row * LPR + sub) * 4;
+    float4 th = ld4(tb.theta + at);
+    if (tb.stamp) {
+        const uint32_t st = tb.stamp[row];
+        if (st != T) {
+            float4 m = ld4(tb.m + at), v = ld4(tb.v + at);
+            for (uint32_t s = st + 1u; s - 1u != T; ++s) adam4_idle(th, m, v, s_lr[s & (kLazyRing - 1)], b1, b2, eps);
+        }
+    }
+    return th;
+}
+template <int LPR>
+__global__ __launch_bounds__(256) void k_lazy_rows(long long n, const int32_t *__restrict__ rows, LazyTable tb, const LazyState *state,
+                                                   float b1, float b2, float eps, float *__restrict__ out) {
+    __shared__ float s_lr[kLazyRing];
+    s_lr[threadIdx.x] = state->lr[threadIdx.x];
+    const uint32_t T = state->t;
+    __syncthreads();
+    const int sub = threadIdx.x % LPR;
+    for (long long k = blockIdx.x * (256LL / LPR) + threadIdx.x / LPR; k < n; k += gridDim.x * (256LL / LPR)) {
+        const int row = rows[k];
+        float4 x = make_float4(0, 0, 0, 0);
+        if (row >= 0) x = lazy_row4<LPR>(tb, row, sub, T, s_lr, b1, b2, eps);
+        st4(out + ((size_t)k * LPR + sub) * 4, x);
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -1526,7 +1747,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
 static void add_seg(AdamArgs &a, float *theta, float *m, float *v, float *g, int32_t *touched, long long rows,
                     long long &next_block, int n_parts = 0, int part_stride = 0) {
     AdamSeg &s = a.seg[a.n_seg++];
-    s.theta = theta; s.m = m; s.v = v; s.g = g; s.touched = touched;
+    s.theta = theta; s.m = m; s.v = v; s.g = g; s.touched = touched; s.stamp = nullptr;
     s.sv = nullptr; s.stage = nullptr;
     s.n_parts = n_parts; s.part_stride = part_stride;
     s.n_vec = rows * a.lpr;
@@ -1697,18 +1918,30 @@ __device__ __forceinline__ int owned_local(const Owned o, int row) {      // loc
     const int l = o.stride == 1 ? rel : rel / o.stride;
     return (l < o.n_loc && l * o.stride == rel) ? l : -1;
 }
-__global__ __launch_bounds__(256) void k_rows_gather_owned(int B, int lpr, const float *__restrict__ P, const Owned ou,
-                                                           const float *__restrict__ Q, const Owned oi,
+template <int LPR, bool LAZY>
+__global__ __launch_bounds__(256) void k_rows_gather_owned(int B, const LazyTable P, const Owned ou, const LazyTable Q, const Owned oi,
                                                            const int32_t *__restrict__ u, const int32_t *__restrict__ i,
-                                                           const int32_t *__restrict__ j, float *__restrict__ rows3) {
-    const long long n4 = 3LL * B * lpr;
+                                                           const int32_t *__restrict__ j, float *__restrict__ rows3,
+                                                           const LazyState *state, float b1, float b2, float eps) {
+    // LAZY: the tables are updated lazily (k_adam_lazy) -- a row is brought to the current step on its way out
+    __shared__ float s_lr[LAZY ? kLazyRing : 1];
+    uint32_t T = 0;
+    if (LAZY) {
+        s_lr[threadIdx.x] = state->lr[threadIdx.x];
+        T = state->t;
+        __syncthreads();
+    }
+    const long long n4 = 3LL * B * LPR;
     for (long long g = blockIdx.x * 256LL + threadIdx.x; g < n4; g += gridDim.x * 256LL) {
-        const long long ref = g / lpr;
-        const int sub = (int)(g % lpr), role = (int)(ref / B), t = (int)(ref % B);
+        const long long ref = g / LPR;
+        const int sub = (int)(g % LPR), role = (int)(ref / B), t = (int)(ref % B);
         const int row = role == 0 ? u[t] : role == 1 ? i[t] : j[t];
         const int l = owned_local(role == 0 ? ou : oi, row);
         float4 v = make_float4(0, 0, 0, 0);
-        if (l >= 0) v = ld4((role == 0 ? P : Q) + ((size_t)l * lpr + sub) * 4);
+        if (l >= 0) {
+            if (LAZY) v = lazy_row4<LPR>(role == 0 ? P : Q, l, sub, T, s_lr, b1, b2, eps);
+            else v = ld4((role == 0 ? P.theta : Q.theta) + ((size_t)l * LPR + sub) * 4);
+        }
         st4(rows3 + (size_t)g * 4, v);
     }
 }
@@ -1719,8 +1952,11 @@ __global__ __launch_bounds__(256) void k_iota3(int B, int32_t *__restrict__ a) {
 __global__ __launch_bounds__(256) void k_shard_keys(int B, const Owned ou, const Owned oi, const int32_t *__restrict__ u,
                                                     const int32_t *__restrict__ i, const int32_t *__restrict__ j,
                                                     uint32_t *__restrict__ key, uint32_t *__restrict__ val,
-                                                    uint32_t *__restrict__ n_work) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_work = 0u;           // work list of k_seg_scan, empty again
+                                                    uint32_t *__restrict__ n_work, LazyState *lazy, const StepScalars *scal) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *n_work = 0u;                                                // work list of k_seg_scan, empty again
+        if (lazy) lazy_tick(lazy, scal->lr_t);                       // (the backward kernel of this step wrote lr_t)
+    }
     const uint32_t none = (uint32_t)(ou.n_loc + oi.n_loc);
     for (int t = blockIdx.x * 256 + threadIdx.x; t < B; t += gridDim.x * 256) {
         const int ru = owned_local(ou, u[t]), ri = owned_local(oi, i[t]), rj = owned_local(oi, j[t]);
@@ -1753,14 +1989,65 @@ extern "C" size_t macr_shard_workspace_bytes(int B, int d) {
     return carve_shard_ws(nullptr, B, d).bytes;
 }
 
-extern "C" int macr_shard_gather(int B, int d, const float *P_loc, int u_lo, int u_stride, int n_users_loc, const float *Q_loc,
-                                 int i_lo, int i_stride, int n_items_loc, const int32_t *u, const int32_t *i, const int32_t *j,
-                                 float *rows3, void *stream) {
+namespace macr {
+static int validate_lazy(const macr_lazy_adam *lz, bool need_p, bool need_q, const char *who) {
+    MACR_REQUIRE(lz->state && (lz->stampP || !need_p) && (lz->stampQ || !need_q), MACR_E_INVALID, "%s: lazy: null pointer", who);
+    MACR_REQUIRE(lz->period >= 1 && lz->period <= MACR_LAZY_MAX_PERIOD, MACR_E_INVALID, "%s: lazy period %d outside [1, %d]", who,
+                 lz->period, MACR_LAZY_MAX_PERIOD);
+    return MACR_OK;
+}
+static int shard_gather(int B, int d, const float *P_loc, const float *mP, const float *vP, int u_lo, int u_stride, int n_users_loc,
+                        const float *Q_loc, const float *mQ, const float *vQ, int i_lo, int i_stride, int n_items_loc,
+                        const int32_t *u, const int32_t *i, const int32_t *j, const macr_hyper *hp, const macr_lazy_adam *lz,
+                        float *rows3, void *stream) {
     MACR_REQUIRE(B > 0 && dim_supported(d) && P_loc && Q_loc && u && i && j && rows3 && u_lo >= 0 && i_lo >= 0 && u_stride >= 1 &&
                      i_stride >= 1 && n_users_loc >= 0 && n_items_loc >= 0, MACR_E_INVALID, "shard_gather: bad argument");
     const Owned ou = {u_lo, u_stride, n_users_loc}, oi = {i_lo, i_stride, n_items_loc};
-    k_rows_gather_owned<<<grid_for(3LL * B * (d / 4)), 256, 0, as_stream(stream)>>>(B, d / 4, P_loc, ou, Q_loc, oi, u, i, j, rows3);
+    LazyTable tp = {P_loc, mP, vP, nullptr}, tq = {Q_loc, mQ, vQ, nullptr};
+    const int grid = grid_for(3LL * B * (d / 4));
+    if (lz) {
+        MACR_REQUIRE(mP && vP && mQ && vQ && hp, MACR_E_INVALID, "shard_gather_lazy: null pointer");
+        if (int e = validate_lazy(lz, n_users_loc > 0, n_items_loc > 0, "shard_gather_lazy")) return e;
+        tp.stamp = lz->stampP; tq.stamp = lz->stampQ;
+        MACR_DISPATCH_LPR(d, (k_rows_gather_owned<LPR, true><<<grid, 256, 0, as_stream(stream)>>>(
+                                 B, tp, ou, tq, oi, u, i, j, rows3, static_cast<const LazyState *>(lz->state), hp->beta1, hp->beta2,
+                                 hp->adam_eps)));
+    } else {
+        MACR_DISPATCH_LPR(d, (k_rows_gather_owned<LPR, false><<<grid, 256, 0, as_stream(stream)>>>(B, tp, ou, tq, oi, u, i, j, rows3,
+                                                                                                    nullptr, 0.f, 0.f, 0.f)));
+    }
     MACR_CHECK_LAUNCH("shard_gather", as_stream(stream));
+    return MACR_OK;
+}
+}  // namespace macr
+
+extern "C" int macr_shard_gather(int B, int d, const float *P_loc, int u_lo, int u_stride, int n_users_loc, const float *Q_loc,
+                                 int i_lo, int i_stride, int n_items_loc, const int32_t *u, const int32_t *i, const int32_t *j,
+                                 float *rows3, void *stream) {
+    return shard_gather(B, d, P_loc, nullptr, nullptr, u_lo, u_stride, n_users_loc, Q_loc, nullptr, nullptr, i_lo, i_stride,
+                        n_items_loc, u, i, j, nullptr, nullptr, rows3, stream);
+}
+
+extern "C" int macr_shard_gather_lazy(int B, int d, const float *P_loc, const float *mP, const float *vP, int u_lo, int u_stride,
+                                      int n_users_loc, const float *Q_loc, const float *mQ, const float *vQ, int i_lo, int i_stride,
+                                      int n_items_loc, const int32_t *u, const int32_t *i, const int32_t *j, const macr_hyper *hp,
+                                      const macr_lazy_adam *lazy, float *rows3, void *stream) {
+    MACR_REQUIRE(lazy, MACR_E_INVALID, "shard_gather_lazy: lazy is null");
+    return shard_gather(B, d, P_loc, mP, vP, u_lo, u_stride, n_users_loc, Q_loc, mQ, vQ, i_lo, i_stride, n_items_loc, u, i, j, hp,
+                        lazy, rows3, stream);
+}
+
+extern "C" int macr_lazy_rows(long long n, int d, const int32_t *rows, const float *theta, const float *m, const float *v,
+                              const uint32_t *stamp, const void *state, const macr_hyper *hp, float *out, void *stream) {
+    MACR_REQUIRE(n >= 0 && dim_supported(d), n >= 0 ? MACR_E_UNSUPPORTED : MACR_E_INVALID, "lazy_rows: n=%lld d=%d", n, d);
+    MACR_REQUIRE(n == 0 || (rows && theta && m && v && stamp && state && hp && out), MACR_E_INVALID, "lazy_rows: null pointer");
+    if (n == 0) return MACR_OK;
+    const LazyTable tb = {theta, m, v, stamp};
+    const long long groups_per_block = 256 / (d / 4);
+    const int grid = (int)((n + groups_per_block - 1) / groups_per_block < 4096 ? (n + groups_per_block - 1) / groups_per_block : 4096);
+    MACR_DISPATCH_LPR(d, (k_lazy_rows<LPR><<<grid, 256, 0, as_stream(stream)>>>(n, rows, tb, static_cast<const LazyState *>(state),
+                                                                               hp->beta1, hp->beta2, hp->adam_eps, out)));
+    MACR_CHECK_LAUNCH("lazy_rows", as_stream(stream));
     return MACR_OK;
 }
 
@@ -1936,20 +2223,24 @@ extern "C" int macr_shard_stage(int B, int d, float **stage, void *workspace, si
     return MACR_OK;
 }
 
-/* this rank's rows: sort the references to them, one owner per row sums its staging rows, dense Adam over the shard */
-extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int u_stride, int i_lo,
-                                int i_stride, const int32_t *u, const int32_t *i, const int32_t *j, float *P, float *Q, float *w,
-                                float *wu, float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu, float *vwu,
-                                float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ, const macr_hyper *hp,
-                                void *workspace, size_t workspace_bytes, void *stream) {
+/* this rank's rows: sort the references to them, one owner per row sums its staging rows, dense Adam over the shard
+ * (lazy != NULL: the lazy pass -- the batch's rows and this step's K-th of the shard) */
+namespace macr {
+static int shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int u_stride, int i_lo,
+                       int i_stride, const int32_t *u, const int32_t *i, const int32_t *j, float *P, float *Q, float *w,
+                       float *wu, float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu, float *vwu,
+                       float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ, const macr_hyper *hp,
+                       const macr_lazy_adam *lz, void *workspace, size_t workspace_bytes, void *stream) {
     MACR_REQUIRE(n_users_loc >= 0 && n_items_loc >= 0 && u_stride >= 1 && i_stride >= 1 && u && i && j && P && Q && w && wu && mP &&
                      vP && mQ && vQ && mw && vw && mwu && vwu && gP && gQ && touchedP && touchedQ, MACR_E_INVALID,
                  "shard_apply: bad argument");
     if (int e = validate_hyper(hp, "shard_apply")) return e;
+    if (lz) if (int e = validate_lazy(lz, n_users_loc > 0, n_items_loc > 0, "shard_apply_lazy")) return e;
     MACR_SHARD_COMMON("shard_apply");
     const int n = 3 * B;
     const Owned ou = {u_lo, u_stride, n_users_loc}, oi = {i_lo, i_stride, n_items_loc};
-    k_shard_keys<<<grid_for(B), 256, 0, st>>>(B, ou, oi, u, i, j, ws.ska, ws.sva, ws.n_work);
+    k_shard_keys<<<grid_for(B), 256, 0, st>>>(B, ou, oi, u, i, j, ws.ska, ws.sva, ws.n_work,
+                                              lz ? static_cast<LazyState *>(lz->state) : nullptr, ws.scal);
     const int flip = launch_radix_sort(ws.ska, ws.sva, ws.skb, ws.svb, n, (uint32_t)(n_users_loc + n_items_loc), ws.ghist, st);
     MACR_CHECK_LAUNCH("ref_sort", st);
     const uint32_t *sk = flip ? ws.skb : ws.ska, *sv = flip ? ws.svb : ws.sva;
@@ -1980,14 +2271,85 @@ extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, in
     if (loss_kind != MACR_LOSS_NORMALBCE) add_seg(a, w, mw, vw, ws.gw, nullptr, 1, nb, kBranchSlots, 2 * d);
     if (loss_kind == MACR_LOSS_RUBIBCEBOTH) add_seg(a, wu, mwu, vwu, ws.gw + d, nullptr, 1, nb, kBranchSlots, 2 * d);
     LossArgs L; L.losses = nullptr;
-    if (indexed) {
+    if (indexed)
         for (int k = 0; k < n_tab; ++k) { a.seg[k].sv = sv; a.seg[k].stage = ws.stage; }
+    if (lz) {
+        // (a rank without user rows has its item rows in segment 0: the list's keys are [0, n_users_loc) | [n_users_loc, end) either way)
+        LazyArgs z;
+        z.state = static_cast<const LazyState *>(lz->state); z.period = lz->period; z.n_tab = n_tab;
+        long long at = 0;
+        for (int k = 0; k < n_tab; ++k) {
+            a.seg[k].stamp = a.seg[k].theta == P ? lz->stampP : lz->stampQ;
+            const long long chunks = (a.seg[k].n_vec + kAdamVecPerBlock - 1) / kAdamVecPerBlock;
+            z.sweep_first[k] = at;
+            at += (chunks + lz->period - 1) / lz->period;
+        }
+        for (int k = n_tab; k < 3; ++k) z.sweep_first[k] = at;
+        z.touch_first = at;
+        at += (n + (256 / a.lpr) - 1) / (256 / a.lpr);
+        z.branch_first = at;
+        at += a.n_seg - n_tab;
+        z.n_refs = n; z.n_users = n_users_loc; z.item_seg = n_users_loc ? 1 : 0;
+        z.key_end = (uint32_t)(n_users_loc + n_items_loc); z.sk = sk;
+        if (indexed) k_adam_lazy<true, true><<<(unsigned)at, 256, 0, st>>>(a, z, ws.scal);
+        else         k_adam_lazy<false, true><<<(unsigned)at, 256, 0, st>>>(a, z, ws.scal);
+        MACR_CHECK_LAUNCH("adam_lazy", st);
+        return MACR_OK;
+    }
+    if (indexed) {
         k_adam_dense<true><<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
         MACR_CHECK_LAUNCH("adam_indexed", st);
         return MACR_OK;
     }
     k_adam_dense<false><<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
+    return MACR_OK;
+}
+}  // namespace macr
+
+extern "C" int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int u_stride, int i_lo,
+                                int i_stride, const int32_t *u, const int32_t *i, const int32_t *j, float *P, float *Q, float *w,
+                                float *wu, float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu, float *vwu,
+                                float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ, const macr_hyper *hp,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    return shard_apply(loss_kind, B, d, n_users_loc, n_items_loc, u_lo, u_stride, i_lo, i_stride, u, i, j, P, Q, w, wu, mP, vP, mQ, vQ,
+                       mw, vw, mwu, vwu, gP, gQ, touchedP, touchedQ, hp, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int macr_shard_apply_lazy(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int u_stride, int i_lo,
+                                     int i_stride, const int32_t *u, const int32_t *i, const int32_t *j, float *P, float *Q, float *w,
+                                     float *wu, float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
+                                     float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ, const macr_hyper *hp,
+                                     const macr_lazy_adam *lazy, void *workspace, size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(lazy, MACR_E_INVALID, "shard_apply_lazy: lazy is null");
+    return shard_apply(loss_kind, B, d, n_users_loc, n_items_loc, u_lo, u_stride, i_lo, i_stride, u, i, j, P, Q, w, wu, mP, vP, mQ, vQ,
+                       mw, vw, mwu, vwu, gP, gQ, touchedP, touchedQ, hp, lazy, workspace, workspace_bytes, stream);
+}
+
+/* every row of the (local) tables brought to the current step: afterwards P, Q and the slots are what the per-step dense pass
+ * leaves (before evaluation, checkpoints, anything that reads the tables) */
+extern "C" int macr_lazy_flush(int d, long long n_rows_p, long long n_rows_q, float *P, float *Q, float *mP, float *vP, float *mQ,
+                               float *vQ, const macr_hyper *hp, const macr_lazy_adam *lazy, void *stream) {
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "lazy_flush: d=%d", d);
+    MACR_REQUIRE(n_rows_p >= 0 && n_rows_q >= 0 && lazy && (n_rows_p == 0 || (P && mP && vP)) && (n_rows_q == 0 || (Q && mQ && vQ)),
+                 MACR_E_INVALID, "lazy_flush: bad argument");
+    if (int e = validate_hyper(hp, "lazy_flush")) return e;
+    if (int e = validate_lazy(lazy, n_rows_p > 0, n_rows_q > 0, "lazy_flush")) return e;
+    AdamArgs a;
+    long long nb = 0;
+    a.n_seg = 0; a.lpr = d / 4; a.lpr_shift = d == 32 ? 3 : d == 64 ? 4 : d == 128 ? 5 : 6;
+    a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
+    if (n_rows_p) { add_seg(a, P, mP, vP, nullptr, nullptr, n_rows_p, nb); a.seg[a.n_seg - 1].stamp = lazy->stampP; }
+    if (n_rows_q) { add_seg(a, Q, mQ, vQ, nullptr, nullptr, n_rows_q, nb); a.seg[a.n_seg - 1].stamp = lazy->stampQ; }
+    if (a.n_seg == 0) return MACR_OK;
+    LazyArgs z;
+    z.state = static_cast<const LazyState *>(lazy->state); z.period = 1; z.n_tab = a.n_seg;
+    for (int k = 0; k < 3; ++k) z.sweep_first[k] = k < a.n_seg ? a.seg[k].first_block : nb;
+    z.touch_first = z.branch_first = nb;
+    z.n_refs = 0; z.n_users = 0; z.item_seg = 0; z.key_end = 0; z.sk = nullptr;
+    hipStream_t st = as_stream(stream);
+    k_adam_lazy<false, false><<<(unsigned)nb, 256, 0, st>>>(a, z, nullptr);
+    MACR_CHECK_LAUNCH("lazy_flush", st);
     return MACR_OK;
 }
 

@@ -21,6 +21,7 @@ the single-GPU step's (macr_mf_train_step) up to summation order, for all three 
 term and no branch vectors: steps 2-4 are one kernel and there is ONE collective per step); `backend` is the device half (HIP: the macr_shard_*
 entry points of include/macr_hip.h; the CPU tests plug the oracle in its place)."""
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -75,8 +76,16 @@ class Owned(object):
         return own, rel // self.stride
 
 
+def lazy_period_for(n_rows, d, target_bytes=512 << 20):
+    """K of the lazy dense Adam pass for a shard of n_rows rows: the dense pass moves 24*d bytes per row and step; sweep a K-th
+    of that per step, about target_bytes -- 1 (dense every step) for tables the size of the reference's datasets"""
+    k = int(round(24.0 * d * n_rows / target_bytes))
+    return max(1, min(k, 64))
+
+
 class HipBackend(object):
     """Device half on the MI355X: thin calls into libmacr_hip.so (no fallback)."""
+    lazy_capable = True                 # the lazy dense Adam pass (include/macr_hip.h: macr_lazy_adam) exists on this backend
 
     def __init__(self, kind, d, hyper, device):
         from . import _lib, ops
@@ -99,14 +108,45 @@ class HipBackend(object):
         off = ptr.value - self.ws.data_ptr()
         return self.ws[off:off + nbytes.value].view(torch.float32)
 
+    def _lazy(self, shard):
+        """struct macr_lazy_adam of a shard whose dense pass is blocked in time (None: dense every step)"""
+        if shard.lazy_period <= 1:
+            return None
+        o = self.ops
+        return self._lib.LazyAdam(o._ptr(shard.lazy_state), o._ptr(shard.stP), o._ptr(shard.stQ), shard.lazy_period)
+
     def gather(self, shard, u, i, j):
         B = u.numel()
         self._reserve(B)
         o, L = self.ops, self._lib.lib()
         ou, oi = shard.own_u, shard.own_i
-        self._lib.check(L.macr_shard_gather(B, self.d, o._ptr(shard.P), ou.lo, ou.stride, ou.n, o._ptr(shard.Q), oi.lo, oi.stride,
+        lz = self._lazy(shard)
+        if lz is not None:
+            self._lib.check(L.macr_shard_gather_lazy(B, self.d, o._ptr(shard._P), o._ptr(shard._mP), o._ptr(shard._vP), ou.lo, ou.stride,
+                                                     ou.n, o._ptr(shard._Q), o._ptr(shard._mQ), o._ptr(shard._vQ), oi.lo, oi.stride, oi.n,
+                                                     o._ptr(u), o._ptr(i), o._ptr(j), ctypes.byref(self.hyper), ctypes.byref(lz),
+                                                     o._ptr(self.rows3), o._stream()))
+            return self.rows3
+        self._lib.check(L.macr_shard_gather(B, self.d, o._ptr(shard._P), ou.lo, ou.stride, ou.n, o._ptr(shard._Q), oi.lo, oi.stride,
                                             oi.n, o._ptr(u), o._ptr(i), o._ptr(j), o._ptr(self.rows3), o._stream()))
         return self.rows3
+
+    def lazy_rows(self, shard, table, rows):
+        """(n, d) rows of the local table `table` ("P" / "Q") as of the current step; rows: int32 local indices, < 0 = a zero row"""
+        o, L = self.ops, self._lib.lib()
+        rows = rows.to(torch.int32).contiguous()
+        out = torch.empty((rows.numel(), self.d), dtype=torch.float32, device=self.device)
+        th, m, v, st = ((shard._P, shard._mP, shard._vP, shard.stP) if table == "P" else (shard._Q, shard._mQ, shard._vQ, shard.stQ))
+        self._lib.check(L.macr_lazy_rows(rows.numel(), self.d, o._ptr(rows), o._ptr(th), o._ptr(m), o._ptr(v), o._ptr(st),
+                                         o._ptr(shard.lazy_state), ctypes.byref(self.hyper), o._ptr(out), o._stream()))
+        return out
+
+    def lazy_flush(self, shard):
+        o, L = self.ops, self._lib.lib()
+        lz = self._lazy(shard)
+        self._lib.check(L.macr_lazy_flush(self.d, shard._P.shape[0], shard._Q.shape[0], o._ptr(shard._P), o._ptr(shard._Q),
+                                          o._ptr(shard._mP), o._ptr(shard._vP), o._ptr(shard._mQ), o._ptr(shard._vQ),
+                                          ctypes.byref(self.hyper), ctypes.byref(lz), o._stream()))
 
     def forward_and_bxb(self, shard, rows3, rank, world):
         o, L = self.ops, self._lib.lib()
@@ -174,22 +214,38 @@ class HipBackend(object):
     def apply(self, shard, u, i, j):
         o, L = self.ops, self._lib.lib()
         ou, oi = shard.own_u, shard.own_i
-        self._lib.check(L.macr_shard_apply(self.kind, u.numel(), self.d, ou.n, oi.n, ou.lo, ou.stride, oi.lo, oi.stride,
-                                           o._ptr(u), o._ptr(i), o._ptr(j),
-                                           o._ptr(shard.P), o._ptr(shard.Q), o._ptr(shard.w), o._ptr(shard.wu),
-                                           o._ptr(shard.mP), o._ptr(shard.vP), o._ptr(shard.mQ), o._ptr(shard.vQ),
-                                           o._ptr(shard.mw), o._ptr(shard.vw), o._ptr(shard.mwu), o._ptr(shard.vwu),
-                                           o._ptr(shard.gP), o._ptr(shard.gQ), o._ptr(shard.tP), o._ptr(shard.tQ),
-                                           ctypes.byref(self.hyper), o._ptr(self.ws), self.ws.numel(), o._stream()))
+        head = (self.kind, u.numel(), self.d, ou.n, oi.n, ou.lo, ou.stride, oi.lo, oi.stride, o._ptr(u), o._ptr(i), o._ptr(j),
+                o._ptr(shard._P), o._ptr(shard._Q), o._ptr(shard.w), o._ptr(shard.wu),
+                o._ptr(shard._mP), o._ptr(shard._vP), o._ptr(shard._mQ), o._ptr(shard._vQ),
+                o._ptr(shard.mw), o._ptr(shard.vw), o._ptr(shard.mwu), o._ptr(shard.vwu),
+                o._ptr(shard.gP), o._ptr(shard.gQ), o._ptr(shard.tP), o._ptr(shard.tQ), ctypes.byref(self.hyper))
+        tail = (o._ptr(self.ws), self.ws.numel(), o._stream())
+        lz = self._lazy(shard)
+        if lz is not None:
+            self._lib.check(L.macr_shard_apply_lazy(*(head + (ctypes.byref(lz),) + tail)))
+        else:
+            self._lib.check(L.macr_shard_apply(*(head + tail)))
+
+
+def _current_table(name):
+    """property of RowShardedMF: a table or slot as the per-step dense pass would hold it (rows the lazy pass left behind catch up first)"""
+    def get(self):
+        self.flush()
+        return getattr(self, name)
+    return property(get)
 
 
 class RowShardedMF(object):
     """This rank's shard of the MF model + its optimizer state.  P_full / Q_full (any rank-identical source) are only
     sliced at construction; afterwards a rank holds rows [u_lo,u_hi) of P and [i_lo,i_hi) of Q, nothing else."""
 
-    def __init__(self, P_full, Q_full, w, wu, backend, rank=None, world=None, group=None, shards=None, layout="interleaved"):
+    def __init__(self, P_full, Q_full, w, wu, backend, rank=None, world=None, group=None, shards=None, layout="interleaved",
+                 lazy_period=None):
         """shards=(P_shard, Q_shard, n_users, n_items): this rank's rows directly (P_full / Q_full are ignored) -- for
-        tables whose full copy exists nowhere (10 M x 1 M rows, d = 128).  layout: see Owned."""
+        tables whose full copy exists nowhere (10 M x 1 M rows, d = 128).  layout: see Owned.
+        lazy_period: K of the lazy dense Adam pass (include/macr_hip.h: macr_lazy_adam) -- a step updates the batch's rows and
+        one K-th of the shard, every row catching up its K steps in registers; 1 = the dense pass every step; None: the
+        environment's MACR_LAZY_ADAM, else by shard size (lazy_period_for)."""
         r, ws = sharding.world()
         self.rank, self.world, self.group = (r if rank is None else rank), (ws if world is None else world), group
         self.n_users, self.n_items = (shards[2], shards[3]) if shards else (P_full.shape[0], Q_full.shape[0])
@@ -197,22 +253,43 @@ class RowShardedMF(object):
         self.own_i = Owned(self.n_items, self.rank, self.world, layout)
         clone = lambda t: t.clone().contiguous()
         if shards:
-            self.P, self.Q = shards[0].contiguous(), shards[1].contiguous()
-            assert self.P.shape[0] == self.own_u.n and self.Q.shape[0] == self.own_i.n
+            self._P, self._Q = shards[0].contiguous(), shards[1].contiguous()
+            assert self._P.shape[0] == self.own_u.n and self._Q.shape[0] == self.own_i.n
         else:
-            self.P, self.Q = clone(self.own_u.take(P_full)), clone(self.own_i.take(Q_full))
+            self._P, self._Q = clone(self.own_u.take(P_full)), clone(self.own_i.take(Q_full))
         self.w, self.wu = clone(w.reshape(-1)), clone(wu.reshape(-1))
         self.collective_ms = None                   # bench: {"rows": [...], "partials": [...], "branch": [...]} event times
-        import os
         self.split = os.environ.get("MACR_SHARD_SPLIT", "1") != "0"
         self.wire_rows = None
         z = torch.zeros_like
-        self.mP, self.vP, self.mQ, self.vQ = z(self.P), z(self.P), z(self.Q), z(self.Q)
+        self._mP, self._vP, self._mQ, self._vQ = z(self._P), z(self._P), z(self._Q), z(self._Q)
         self.mw, self.vw, self.mwu, self.vwu = z(self.w), z(self.w), z(self.wu), z(self.wu)
-        self.gP, self.gQ = z(self.P), z(self.Q)
-        self.tP = torch.zeros(self.P.shape[0], dtype=torch.int32, device=self.P.device)
-        self.tQ = torch.zeros(self.Q.shape[0], dtype=torch.int32, device=self.Q.device)
+        self.gP, self.gQ = z(self._P), z(self._Q)
+        dev = self._P.device
+        self.tP = torch.zeros(self._P.shape[0], dtype=torch.int32, device=dev)
+        self.tQ = torch.zeros(self._Q.shape[0], dtype=torch.int32, device=dev)
         self.backend = backend
+        # lazy dense Adam: row stamps + the library's step counter / lr_t ring; `_stale` = some row is behind the current step
+        if lazy_period is None:
+            env = os.environ.get("MACR_LAZY_ADAM", "")
+            lazy_period = int(env) if env else lazy_period_for(self._P.shape[0] + self._Q.shape[0], self._P.shape[1])
+        if not getattr(backend, "lazy_capable", False):
+            lazy_period = 1
+        self.lazy_period, self._stale = max(1, int(lazy_period)), False
+        if self.lazy_period > 1:
+            self.stP = torch.zeros(self._P.shape[0], dtype=torch.int32, device=dev)
+            self.stQ = torch.zeros(self._Q.shape[0], dtype=torch.int32, device=dev)
+            self.lazy_state = torch.zeros(1040, dtype=torch.uint8, device=dev)
+
+    # ------------------------------------------------------------------ the tables, as the per-step dense pass would hold them
+    def flush(self):
+        """every row of the shard brought to the current step (no-op unless the lazy pass left rows behind)"""
+        if self._stale:
+            self.backend.lazy_flush(self)
+            self._stale = False
+
+    P, Q = _current_table("_P"), _current_table("_Q")
+    mP, vP, mQ, vQ = _current_table("_mP"), _current_table("_vP"), _current_table("_mQ"), _current_table("_vQ")
 
     # ------------------------------------------------------------------ collectives (RCCL over xGMI; gloo in the tests)
     def _host_rig(self, t):
@@ -317,19 +394,25 @@ class RowShardedMF(object):
         n_send, n_recv = sum(send_counts), sum(recv_counts)
         assert n_recv == 3 * n
         send_ref, recv_ref = send_ref[:n_send], recv_ref[:n_recv]
-        d = self.P.shape[1]
+        d = self._P.shape[1]
         # 1. rows of my slice from their owners
         sr = rows[send_ref]
-        is_user = (send_ref < B).unsqueeze(1)
-        from_p = self.P[self.own_u.local_index(sr).clamp(0, max(self.P.shape[0] - 1, 0))]     # (both tables are indexed for every
-        from_q = self.Q[self.own_i.local_index(sr).clamp(0, max(self.Q.shape[0] - 1, 0))]     # reference: n_send rows each, no branch)
-        send = torch.where(is_user, from_p, from_q)
-        recv = torch.empty((n_recv, d), dtype=self.P.dtype, device=self.P.device)
+        if self.lazy_period > 1:                        # rows as of this step, brought up to date on their way out (nothing written)
+            user = send_ref < B
+            neg = torch.full_like(sr, -1)
+            send = (be.lazy_rows(self, "P", torch.where(user, self.own_u.local_index(sr), neg)) +
+                    be.lazy_rows(self, "Q", torch.where(user, neg, self.own_i.local_index(sr))))     # (x + 0: exact)
+        else:
+            is_user = (send_ref < B).unsqueeze(1)
+            from_p = self._P[self.own_u.local_index(sr).clamp(0, max(self._P.shape[0] - 1, 0))]     # (both tables are indexed for every
+            from_q = self._Q[self.own_i.local_index(sr).clamp(0, max(self._Q.shape[0] - 1, 0))]     # reference: n_send rows each, no branch)
+            send = torch.where(is_user, from_p, from_q)
+        recv = torch.empty((n_recv, d), dtype=self._P.dtype, device=self._P.device)
         self._all_to_all(recv, send.contiguous(), recv_counts, send_counts, "rows_a2a")
         # arrival order -> (role, position in the slice)
         role, t = recv_ref // B, recv_ref % B
         slot = role * n + (t - t0)
-        rows3 = torch.empty((3 * n, d), dtype=self.P.dtype, device=self.P.device)
+        rows3 = torch.empty((3 * n, d), dtype=self._P.dtype, device=self._P.device)
         rows3[slot] = recv
         rows3 = rows3.view(3, n, d)
         # 2. forward of the slice; its scalars and loss partials summed into the whole batch's
@@ -340,10 +423,11 @@ class RowShardedMF(object):
         losses, stage, branch = be.backward_slice(self, B, t0, rows3)
         self._all_reduce(branch, "branch")
         # 5. gradient rows back to the owners, into the staging rows macr_shard_apply reads
-        back = torch.empty((n_send, d), dtype=self.P.dtype, device=self.P.device)
+        back = torch.empty((n_send, d), dtype=self._P.dtype, device=self._P.device)
         self._all_to_all(back, stage.view(3 * n, d)[slot].contiguous(), send_counts, recv_counts, "grads_a2a")
         be.stage_rows(B)[send_ref] = back
         be.apply(self, u, i, j)
+        self._stale = self.lazy_period > 1
         self.wire_rows = (n_send - send_counts[self.rank]) + (n_recv - recv_counts[self.rank])   # rows that crossed ranks, one way each
         return losses
 
@@ -364,6 +448,7 @@ class RowShardedMF(object):
         if branch is not None:
             self._broadcast(branch, 0, "branch")                  # 4. one copy of the branch-vector gradients
         be.apply(self, u, i, j)                                   # 5. local segment reduce + dense Adam on the shard
+        self._stale = self.lazy_period > 1
         return losses
 
     def full_tables(self):

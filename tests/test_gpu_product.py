@@ -654,6 +654,20 @@ def test_row_sharded_split_step_two_ranks_one_gpu(tmp_path):
     assert 0 < res["wire_rows"] < 0.6 * res["batch_rows"], res       # ~ 2 * (1/2) * 3B/2 at two ranks
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_row_sharded_lazy_adam_two_ranks_one_gpu(tmp_path, split):
+    """Both step forms with the lazy dense Adam pass (period 2, five steps: rows are behind when the next batch gathers them, the
+    owners bring them up to date on their way out) -- same losses and tables as the single-GPU step and the oracle."""
+    import json
+    env = dict(os.environ, PYTHONUNBUFFERED="1", MACR_SHARD_SPLIT=split, MACR_LAZY_ADAM="2", MACR_TEST_STEPS="5")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(REPO, "tests", "shard_worker.py")],
+                         cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] and res["lazy_period"] == 2 and res["split"] == (split == "1"), res
+
+
 def test_rccl_code_paths_in_a_world_of_one(tmp_path):
     """The collectives of the multi-GPU paths on backend "nccl" (RCCL) with device tensors, driven from ONE GPU
     (MACR_FORCE_COLLECTIVES=1: world-size-1 collectives are issued instead of skipped): the packed int64 all-gather of
