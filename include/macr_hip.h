@@ -242,6 +242,31 @@ typedef struct macr_lazy_adam {
     int       period;
 } macr_lazy_adam;
 
+/* macr_mf_train_step / macr_mf_train_flush with the lazy pass in place of the dense one (the (B,B) losses; same arguments +
+ * lazy; stampP / stampQ: uint32[n_users] / uint32[n_items]).  Use ONE form for all calls of a deferred sequence (from the
+ * first MACR_STEP_DEFER call to the flush or the call that completes it): the step counter advances in every call of the
+ * lazy form.  In deferred mode the pass riding in a step's (B,B) launch updates the rows of the previous and of the current
+ * batch (flag bit 0: gradient pending, bit 1: set by this step's forward kernel) and the step's K-th of the tables; the
+ * forward kernel brings the rows it gathers up to date in registers.  A call that completes its step (no MACR_STEP_DEFER)
+ * and macr_mf_train_flush_lazy end with every row at the current step: P, Q and the slots are then what the dense form
+ * leaves, bit for bit -- between the calls of a deferred sequence they are NOT. */
+int macr_mf_train_step_lazy(int loss_kind, int B, int d, int n_users, int n_items,
+                            const int32_t *u, const int32_t *i, const int32_t *j,
+                            float *P, float *Q, float *w, float *wu,
+                            float *mP, float *vP, float *mQ, float *vQ,
+                            float *mw, float *vw, float *mwu, float *vwu,
+                            float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                            float *adam_pow, const macr_hyper *hp,
+                            float *losses, int flags, const macr_lazy_adam *lazy,
+                            void *workspace, size_t workspace_bytes, void *stream);
+int macr_mf_train_flush_lazy(int loss_kind, int B, int d, int n_users, int n_items,
+                             float *P, float *Q, float *w, float *wu,
+                             float *mP, float *vP, float *mQ, float *vQ,
+                             float *mw, float *vw, float *mwu, float *vwu,
+                             float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                             const macr_hyper *hp, const macr_lazy_adam *lazy,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* macr_shard_gather on lazily updated shards (mP .. vQ: the slots of the local tables) */
 int macr_shard_gather_lazy(int B, int d, const float *P_loc, const float *mP, const float *vP, int u_lo, int u_stride,
                            int n_users_loc, const float *Q_loc, const float *mQ, const float *vQ, int i_lo, int i_stride,

@@ -52,6 +52,8 @@ SIGNATURES = {
     "macr_mf_train_workspace_bytes": (_z, [_i, _i]),
     "macr_mf_train_step": (_i, [_i] * 5 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [_p, ctypes.POINTER(Hyper), _p, _i, _p, _z, _p]),
     "macr_mf_train_flush": (_i, [_i] * 5 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), _p, _z, _p]),
+    "macr_mf_train_step_lazy": (_i, [_i] * 5 + [_p] * 3 + [_p] * 12 + [_p] * 4 + [_p, ctypes.POINTER(Hyper), _p, _i, ctypes.POINTER(LazyAdam), _p, _z, _p]),
+    "macr_mf_train_flush_lazy": (_i, [_i] * 5 + [_p] * 12 + [_p] * 4 + [ctypes.POINTER(Hyper), ctypes.POINTER(LazyAdam), _p, _z, _p]),
     "macr_shard_workspace_bytes": (_z, [_i, _i]),
     "macr_shard_gather": (_i, [_i, _i, _p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "macr_shard_forward": (_i, [_i, _i, _i, _p, _p, _p, _p, _z, _p]),

@@ -53,8 +53,10 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // ---- device helpers ----------------------------------------------------------
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// (the fused chain written out: left to -ffp-contract, which product stays un-fused depends on the surrounding code, and
+// instantiations of one kernel -- k_pair_fwd<LPR, 0/1/2> -- must produce the same bits)
 __device__ __forceinline__ float dot4(float4 a, float4 b) {
-    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
 }
 __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
     return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
@@ -124,8 +126,8 @@ __device__ __forceinline__ float adam_update(float th, float m, float v, float l
 
 // m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; theta -= lr_t*m/(sqrt(v)+eps)      (TF 1.14 Adam), one element
 __device__ __forceinline__ void adam1(float &th, float &m, float &v, float g, float lr_t, float b1, float b2, float eps) {
-    m = m * b1 + g * (1.0f - b1);
-    v = v * b2 + (g * g) * (1.0f - b2);
+    m = fmaf(m, b1, g * (1.0f - b1));             // (explicit fused forms: see adam4 in train_kernels.hip)
+    v = fmaf(v, b2, (g * g) * (1.0f - b2));
     th = adam_update(th, m, v, lr_t, eps);
 }
 

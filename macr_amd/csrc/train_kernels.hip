@@ -68,12 +68,15 @@ struct AdamSeg {
     long long n_vec;         // number of float4 in the segment
     long long first_block;   // first block index serving this segment
 };
+struct LazyState;
 struct AdamArgs {
     AdamSeg seg[4];
     int n_seg;
     int lpr;                 // float4 per row (8, 16, 32 or 64)
     int lpr_shift;           // log2(lpr): row of a float4 = index >> lpr_shift (a 64-bit division per access otherwise)
     float b1, b2, eps;
+    const LazyState *lazy = nullptr;   // lazy pass riding in the (B,B) launch (adam_lazy_scan_block): step counter + lr_t ring
+    int period = 1;
 };
 struct LossArgs {
     const float *part; int n_part;       // pair-kernel partials  [n_part][4]
@@ -91,12 +94,16 @@ constexpr int kAdamIters = MACR_ADAM_ITERS;          // float4 per thread and ar
 constexpr int kAdamVecPerBlock = 256 * kAdamIters;
 constexpr int kBranchSlots = 8;             // partial rows of the branch-vector gradients (pair_bwd adds, Adam consumes)
 
+// The two moment updates are written as the fused forms the compiler chose for the dense pass (one product rounded, the
+// other inside the fma) instead of `m*b1 + g*(1-b1)`: left to -ffp-contract the choice depends on the surrounding code, and
+// the same row is updated in different kernels (the dense pass, the look-ahead of pair_fwd, the lazy passes) whose results
+// must agree bit for bit.
 __device__ __forceinline__ void adam4(float4 &th, float4 &m, float4 &v, const float4 gr, float lr_t, float b1,
                                       float b2, float eps) {
     const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-    m.x = m.x * b1 + gr.x * omb1; m.y = m.y * b1 + gr.y * omb1; m.z = m.z * b1 + gr.z * omb1; m.w = m.w * b1 + gr.w * omb1;
-    v.x = v.x * b2 + (gr.x * gr.x) * omb2; v.y = v.y * b2 + (gr.y * gr.y) * omb2;
-    v.z = v.z * b2 + (gr.z * gr.z) * omb2; v.w = v.w * b2 + (gr.w * gr.w) * omb2;
+    m.x = fmaf(m.x, b1, gr.x * omb1); m.y = fmaf(m.y, b1, gr.y * omb1); m.z = fmaf(m.z, b1, gr.z * omb1); m.w = fmaf(m.w, b1, gr.w * omb1);
+    v.x = fmaf(v.x, b2, (gr.x * gr.x) * omb2); v.y = fmaf(v.y, b2, (gr.y * gr.y) * omb2);
+    v.z = fmaf(v.z, b2, (gr.z * gr.z) * omb2); v.w = fmaf(v.w, b2, (gr.w * gr.w) * omb2);
     th.x = adam_update(th.x, m.x, v.x, lr_t, eps); th.y = adam_update(th.y, m.y, v.y, lr_t, eps);
     th.z = adam_update(th.z, m.z, v.z, lr_t, eps); th.w = adam_update(th.w, m.w, v.w, lr_t, eps);
 }
@@ -335,7 +342,7 @@ __device__ __forceinline__ void adam_lazy_vecs(const AdamArgs &a, const AdamSeg 
                 for (; q < len; ++q) acc = add4(acc, ld4(run + (size_t)q * d));
             }
             gr[k] = acc;
-        } else if (flag[k]) {
+        } else if (flag[k] & 1) {                               // (bit 1: adam_lazy_scan_block)
             gr[k] = ld4(sg.g + vi[k] * 4);
             st4(sg.g + vi[k] * 4, make_float4(0, 0, 0, 0));
         }
@@ -426,6 +433,43 @@ __global__ __launch_bounds__(256) void k_adam_lazy(AdamArgs a, LazyArgs z, const
     }
 }
 
+// The lazy pass of the SMALL tables (macr_mf_train_step in deferred mode): no sorted reference list names the touched rows,
+// but scanning every row's flag is a few hundred KB, so block `blk` owns chunk blk of its segment and updates
+//   - every row of the chunk when the chunk belongs to this step's sweep,
+//   - else the rows with a flag: bit 0 = pair_bwd left a gradient row for the pending step, bit 1 = pair_fwd<2> marked
+//     the row as one of the CURRENT batch (pair_bwd of this step reads its rows in place, so they must be at the step).
+// Per step that is the rows of two batches + a K-th of the tables instead of every row.  Branch-vector segments stay
+// dense (one row each).  s_red doubles as the block's copy of the lr_t ring.
+__device__ __forceinline__ void adam_lazy_scan_block(const AdamArgs &a, long long blk, float lr_t, float4 *s_red) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < a.n_seg && blk >= a.seg[k].first_block) s = k;
+    if (a.seg[s].n_parts > 0) { adam_block<true, false>(a, blk, lr_t, s_red); return; }
+    float *s_lr = reinterpret_cast<float *>(s_red);
+    s_lr[threadIdx.x] = a.lazy->lr[threadIdx.x];
+    const uint32_t T = a.lazy->t;                   // the pending step
+    __syncthreads();
+    const AdamSeg &sg = a.seg[s];
+    const long long chunk = blk - sg.first_block;
+    const bool sweep = (uint32_t)(chunk % a.period) == T % (uint32_t)a.period;
+    long long vi[kAdamIters];
+#pragma unroll
+    for (int it = 0; it < kAdamIters; ++it) {
+        const long long v = chunk * kAdamVecPerBlock + threadIdx.x + (long long)it * 256;
+        vi[it] = -1;
+        if (v < sg.n_vec && (sweep || sg.touched[v >> a.lpr_shift] != 0)) vi[it] = v;
+    }
+    adam_lazy_vecs<kAdamIters, false, true>(a, sg, vi, T - 1u, s_lr);
+}
+
+// the same pass as a launch of its own (a step that completes in its call, macr_mf_train_flush); block 0 also reduces the loss partials
+__global__ __launch_bounds__(256) void k_adam_lazy_scan(AdamArgs a, const StepScalars *scal, LossArgs L) {
+    __shared__ float4 s_red[256];
+    adam_lazy_scan_block(a, blockIdx.x, scal->lr_t, s_red);
+    if (blockIdx.x == 0 && L.losses && threadIdx.x < 64) finalize_losses(L, threadIdx.x);
+}
+
 // rows of a lazily updated table as the per-step dense pass would hold them now: theta brought from the row's stamp to the
 // current step in registers, nothing written back.  One LPR-lane group per output row; rows[k] < 0: a zero row.
 struct LazyTable { const float *theta, *m, *v; const uint32_t *stamp; };
@@ -471,10 +515,12 @@ __global__ __launch_bounds__(256) void k_lazy_rows(long long n, const int32_t *_
 // Tables the deferred-mode forward needs to see one update ahead (below).
 struct PendingAdam {
     const float *mU, *vU, *gU, *mI, *vI, *gI;      // slots and gradient sums of the user / item table
-    const int32_t *tU, *tI;                          // row flags: gradient present
+    int32_t *tU, *tI;                                // row flags: gradient present (PENDING = 2: bit 1 added for the batch's rows)
     const float *mw, *vw, *mwu, *vwu;                // slots of the branch vectors
     const StepScalars *scal;
     float b1, b2, eps;
+    const uint32_t *stU, *stI;                       // PENDING = 2 (lazy dense Adam): row stamps, step counter + lr_t ring
+    const LazyState *lazy;
 };
 
 // PENDING (deferred mode): the previous step's Adam update has not been applied yet -- it is applied to ALL rows
@@ -482,7 +528,11 @@ struct PendingAdam {
 // computes theta' = adam(theta, m, v, g) for the float4 it gathers (and for w, w_user) in registers, with exactly
 // the arithmetic the pass will use, and writes nothing back: 3x more bytes gathered per row, no atomics, no
 // ordering between references to the same row, no extra launch.
-template <int LPR, bool PENDING>
+// PENDING = 2: the tables are updated lazily (adam_lazy_scan_block) -- a gathered row may be several steps behind: its idle
+// steps first (stamp + 1 .. pending step - 1, in registers), then the pending step as above.  The lane group also marks
+// its three rows (flag bit 1) so that the pass riding in this step's (B,B) launch brings them to the pending step IN
+// MEMORY before pair_bwd reads them in place.
+template <int LPR, int PENDING>
 __global__ __launch_bounds__(256) void k_pair_fwd(
     int B, int Bp, const int32_t *__restrict__ u, const int32_t *__restrict__ i, const int32_t *__restrict__ j,
     const float *__restrict__ Usrc, const float *__restrict__ Isrc,
@@ -491,9 +541,16 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
     int user_branch) {
     constexpr int d = 4 * LPR;
     __shared__ float red[16];
+    __shared__ float s_lr[PENDING == 2 ? kLazyRing : 1];
     RowGroup<LPR> g;
     const int t = blockIdx.x * RowGroup<LPR>::kRowsPerBlock + g.slot;
     float sq = 0.f, litem = 0.f, luser = 0.f;
+    uint32_t T = 0;
+    if (PENDING == 2) {
+        s_lr[threadIdx.x] = pa.lazy->lr[threadIdx.x];
+        T = pa.lazy->t;
+        __syncthreads();
+    }
     if (!PENDING && blockIdx.x == 0) {
         // nothing reads the branch-vector partial rows before this step's pair_bwd adds into them
         for (int k = threadIdx.x; k < kBranchSlots * 2 * d; k += 256) gw[k] = 0.f;
@@ -520,6 +577,24 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
             }
             float4 mw4 = ld4(pa.mw + 4 * g.sub), vw4 = ld4(pa.vw + 4 * g.sub);
             float4 mwu4 = ld4(pa.mwu + 4 * g.sub), vwu4 = ld4(pa.vwu + 4 * g.sub);
+            if (PENDING == 2) {
+                const uint32_t upto = T - 1u, su_ = pa.stU[ru], si_ = pa.stI[ri], sj_ = pa.stI[rj];
+                if (g.sub == 0) {                        // (every writer of a flag writes old | 2: equal rows of the batch agree)
+                    const int fu = pa.tU[ru], fi = pa.tI[ri], fj = pa.tI[rj];
+                    if (!(fu & 2)) pa.tU[ru] = fu | 2;
+                    if (!(fi & 2)) pa.tI[ri] = fi | 2;
+                    if (!(fj & 2)) pa.tI[rj] = fj | 2;
+                }
+                uint32_t lag = upto - su_;
+                lag = upto - si_ > lag ? upto - si_ : lag;
+                lag = upto - sj_ > lag ? upto - sj_ : lag;
+                for (uint32_t s = upto - lag + 1u; s - 1u != upto; ++s) {
+                    const float lr_s = s_lr[s & (kLazyRing - 1)];
+                    if (s - 1u - su_ < lag) adam4_idle(eu, mu, vu, lr_s, pa.b1, pa.b2, pa.eps);
+                    if (s - 1u - si_ < lag) adam4_idle(ei, mi, vi, lr_s, pa.b1, pa.b2, pa.eps);
+                    if (s - 1u - sj_ < lag) adam4_idle(ej, mj, vj, lr_s, pa.b1, pa.b2, pa.eps);
+                }
+            }
             adam4(eu, mu, vu, gu, lr_t, pa.b1, pa.b2, pa.eps);
             adam4(ei, mi, vi, gi, lr_t, pa.b1, pa.b2, pa.eps);
             adam4(ej, mj, vj, gj, lr_t, pa.b1, pa.b2, pa.eps);
@@ -655,7 +730,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // dense pass (they touch only theta/m/v/g, never the bxb inputs): the bxb blocks are resident for the whole
 // launch and bound by the transcendental rate, the Adam blocks stream through the remaining wave slots and are
 // bound by HBM, so the two costs overlap instead of adding.
-template <int R, bool FULL, bool ADAM>
+// ADAM = 2: the lazy pass (adam_lazy_scan_block) in place of the dense one.
+template <int R, bool FULL, int ADAM>
 __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, const float *__restrict__ fwd,
                                              float *__restrict__ rowpart, float *__restrict__ colpart,
                                              float *__restrict__ lpart, AdamArgs adam, const StepScalars *scal,
@@ -681,7 +757,8 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
 #ifndef MACR_ABL_ADAM_NOPRIO
         __builtin_amdgcn_s_setprio(3);
 #endif
-        adam_block<true>(adam, (long long)ablk, scal->lr_t, s_red);
+        if (ADAM == 2) adam_lazy_scan_block(adam, (long long)ablk, scal->lr_t, s_red);
+        else adam_block<true>(adam, (long long)ablk, scal->lr_t, s_red);
         return;
     }
     const int cb = bblk % ncb, rb = sort.rb0 + bblk / ncb, t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -937,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     const float *__restrict__ rowpart, const float *__restrict__ colpart,
     float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *__restrict__ wpart,
     float alpha, float beta, float coef, float *adam_pow, StepScalars *scal, float lr, float b1, float b2,
-    LossArgs L, int32_t *cnt_pos) {
+    LossArgs L, int32_t *cnt_pos, LazyState *lazy = nullptr) {
     constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float s_w[4][2][D];
     __shared__ float s_gi[kChunkT][D];
@@ -949,9 +1026,11 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
         // change: Adam bias correction for this step, then advance TF's fp32 beta powers.
         if (threadIdx.x == 0) {
             const float p1 = adam_pow[0], p2 = adam_pow[1];
-            scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
+            const float lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
+            scal->lr_t = lr_t;
             adam_pow[0] = p1 * b1;
             adam_pow[1] = p2 * b2;
+            if (lazy) lazy_tick(lazy, lr_t);
         }
         if (L.losses && threadIdx.x < 64) finalize_losses(L, threadIdx.x);   // deferred mode: no adam_dense launch to do it
         return;
@@ -1200,7 +1279,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
     const float *__restrict__ w, const float *__restrict__ wu, const float *__restrict__ fwd,
     const float *__restrict__ rowpart, const float *__restrict__ colpart, float *__restrict__ stage,
     float *__restrict__ wpart, float alpha, float beta, float coef, float *adam_pow, StepScalars *scal, float lr,
-    float b1, float b2, LossArgs L, const uint32_t *__restrict__ place = nullptr, int Bnorm = 0) {
+    float b1, float b2, LossArgs L, const uint32_t *__restrict__ place = nullptr, int Bnorm = 0, LazyState *lazy = nullptr) {
     // Bnorm > 0: the launch covers a SLICE of a batch of Bnorm triples (row-sharded training, macr_shard_backward_slice): u/i/j,
     // fwd, rowpart and colpart arrive offset to the slice, B is its length, the means are taken over the whole batch
     constexpr int d = 4 * LPR, RPB = RowGroup<LPR>::kRowsPerBlock;
@@ -1209,9 +1288,11 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
     if ((int)blockIdx.x == nblk) {
         if (threadIdx.x == 0) {
             const float p1 = adam_pow[0], p2 = adam_pow[1];
-            scal->lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
+            const float lr_t = lr * sqrtf(1.0f - p2) / (1.0f - p1);
+            scal->lr_t = lr_t;
             adam_pow[0] = p1 * b1;
             adam_pow[1] = p2 * b2;
+            if (lazy) lazy_tick(lazy, lr_t);
         }
         if (L.losses && threadIdx.x < 64) finalize_losses(L, threadIdx.x);
         return;
@@ -1593,15 +1674,19 @@ static void launch_bxb_rows(const PairWs &ws, int B, const AdamArgs *pending, lo
 #ifdef MACR_ABL_XNOADAM
     n_adam_blocks = 0;                 // timing probe: the ADAM instantiation of the kernel without any Adam block (wrong results)
 #endif
-    if (pending) {
+    if (pending && pending->lazy) {
         const unsigned grid = (unsigned)(nbxb + nsort + n_adam_blocks);
-        if (full) k_bxb<R, true, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal, sort);
-        else      k_bxb<R, false, true><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal, sort);
+        if (full) k_bxb<R, true, 2><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal, sort);
+        else      k_bxb<R, false, 2><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal, sort);
+    } else if (pending) {
+        const unsigned grid = (unsigned)(nbxb + nsort + n_adam_blocks);
+        if (full) k_bxb<R, true, 1><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal, sort);
+        else      k_bxb<R, false, 1><<<grid, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, *pending, ws.scal, sort);
     } else {
         AdamArgs none;
         none.n_seg = 0;
-        if (full) k_bxb<R, true, false><<<nbxb + nsort, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort);
-        else      k_bxb<R, false, false><<<nbxb + nsort, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort);
+        if (full) k_bxb<R, true, 0><<<nbxb + nsort, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort);
+        else      k_bxb<R, false, 0><<<nbxb + nsort, 256, 0, st>>>(B, ws.Bp, ws.ncb, nbxb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort);
     }
 }
 
@@ -1665,7 +1750,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
                        float *adam_pow, const macr_hyper *hp, const PairWs &ws, hipStream_t st,
                        const PendingAdam *pa = nullptr, const AdamArgs *pending = nullptr,
                        long long n_pending_blocks = 0, const LossArgs *finalize = nullptr, bool loss_only = false,
-                       int32_t *cnt_pos = nullptr, const uint32_t **sv_sorted = nullptr) {
+                       int32_t *cnt_pos = nullptr, const uint32_t **sv_sorted = nullptr, LazyState *tick = nullptr) {
     const int grid = ws.nblk_pair;
     const int user_branch = kind == MACR_LOSS_RUBIBCEBOTH;
     BatchSort sort = batch_sort_args(ws, B, u, i, j);
@@ -1709,13 +1794,16 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
         MACR_CHECK_LAUNCH("pair_normal", st);
         return MACR_OK;
     }
-    if (pa) {
-        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, true><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                         ws.part, reg_on_gathered, ws.gw, *pa, user_branch)));
+    if (pa && pa->lazy) {
+        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 2><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
+                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch)));
+    } else if (pa) {
+        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 1><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
+                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch)));
     } else {
         PendingAdam none = {};
-        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, false><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                          ws.part, reg_on_gathered, ws.gw, none, user_branch)));
+        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 0><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
+                                                                      ws.part, reg_on_gathered, ws.gw, none, user_branch)));
     }
     MACR_CHECK_LAUNCH("pair_fwd", st);
     switch (ws.rows) {
@@ -1731,7 +1819,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
         MACR_DISPATCH_LPR(d, (k_pair_bwd_stage<LPR><<<ws.nblk_bwd + 1, 256, 0, st>>>(
                                  B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, ws.stage,
                                  ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal, hp->lr, hp->beta1, hp->beta2, L,
-                                 listed ? rs.free_val : nullptr)));
+                                 listed ? rs.free_val : nullptr, 0, tick)));
         MACR_CHECK_LAUNCH("pair_bwd", st);
         if (listed) return launch_seg_index(B, d, n_urows, n_irows, rs, true, gU, gI, tU, tI, ws, st);
         return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st, sv_sorted);
@@ -1739,7 +1827,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
     MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd + 1, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, ws.perm, ws.us, ws.is, ws.js,
                                                                       Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, gU,
                                                                       gI, tU, tI, ws.gw, hp->alpha, hp->beta, coef, adam_pow,
-                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2, L, cnt_pos)));
+                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2, L, cnt_pos, tick)));
     MACR_CHECK_LAUNCH("pair_bwd", st);
     return MACR_OK;
 }
@@ -1755,6 +1843,7 @@ static void add_seg(AdamArgs &a, float *theta, float *m, float *v, float *g, int
     next_block += (s.n_vec + kAdamVecPerBlock - 1) / kAdamVecPerBlock;
 }
 
+static int validate_lazy(const macr_lazy_adam *lz, bool need_p, bool need_q, const char *who);
 static int validate_hyper(const macr_hyper *hp, const char *who) {
     MACR_REQUIRE(hp, MACR_E_INVALID, "%s: hyper is null", who);
     MACR_REQUIRE(hp->batch_size_cfg > 0, MACR_E_INVALID, "%s: batch_size_cfg=%d", who, hp->batch_size_cfg);
@@ -1793,12 +1882,40 @@ static void mf_adam_args(AdamArgs &a, long long &nb, bool tables, int loss_kind,
 }
 }  // namespace macr
 
-extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items, const int32_t *u,
-                                  const int32_t *i, const int32_t *j, float *P, float *Q, float *w, float *wu,
-                                  float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
-                                  float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
-                                  float *adam_pow, const macr_hyper *hp, float *losses, int flags, void *workspace,
-                                  size_t workspace_bytes, void *stream) {
+namespace macr {
+// lazy dense Adam on the tables of the MF model: stamps of the segments, the ring, the period
+static void lazy_adam_args(AdamArgs &a, const macr_lazy_adam *lz, const float *P) {
+    a.lazy = static_cast<const LazyState *>(lz->state);
+    a.period = lz->period;
+    for (int k = 0; k < a.n_seg; ++k)
+        if (a.seg[k].n_parts == 0) a.seg[k].stamp = a.seg[k].theta == P ? lz->stampP : lz->stampQ;
+}
+// every row of both tables to the current step (k_adam_lazy in flush form)
+static int lazy_flush_tables(int d, long long n_rows_p, long long n_rows_q, float *P, float *Q, float *mP, float *vP, float *mQ,
+                             float *vQ, const macr_hyper *hp, const macr_lazy_adam *lazy, hipStream_t st) {
+    AdamArgs a;
+    long long nb = 0;
+    a.n_seg = 0; a.lpr = d / 4; a.lpr_shift = d == 32 ? 3 : d == 64 ? 4 : d == 128 ? 5 : 6;
+    a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
+    if (n_rows_p) { add_seg(a, P, mP, vP, nullptr, nullptr, n_rows_p, nb); a.seg[a.n_seg - 1].stamp = lazy->stampP; }
+    if (n_rows_q) { add_seg(a, Q, mQ, vQ, nullptr, nullptr, n_rows_q, nb); a.seg[a.n_seg - 1].stamp = lazy->stampQ; }
+    if (a.n_seg == 0) return MACR_OK;
+    LazyArgs z;
+    z.state = static_cast<const LazyState *>(lazy->state); z.period = 1; z.n_tab = a.n_seg;
+    for (int k = 0; k < 3; ++k) z.sweep_first[k] = k < a.n_seg ? a.seg[k].first_block : nb;
+    z.touch_first = z.branch_first = nb;
+    z.n_refs = 0; z.n_users = 0; z.item_seg = 0; z.key_end = 0; z.sk = nullptr;
+    k_adam_lazy<false, false><<<(unsigned)nb, 256, 0, st>>>(a, z, nullptr);
+    MACR_CHECK_LAUNCH("lazy_flush", st);
+    return MACR_OK;
+}
+
+static int mf_train_step(int loss_kind, int B, int d, int n_users, int n_items, const int32_t *u,
+                         const int32_t *i, const int32_t *j, float *P, float *Q, float *w, float *wu,
+                         float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
+                         float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                         float *adam_pow, const macr_hyper *hp, float *losses, int flags, const macr_lazy_adam *lz,
+                         void *workspace, size_t workspace_bytes, void *stream) {
     MACR_REQUIRE(loss_kind == MACR_LOSS_NORMALBCE || loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE,
                  MACR_E_INVALID, "mf_train_step: loss_kind=%d", loss_kind);
     MACR_REQUIRE(B > 0 && n_users > 0 && n_items > 0, MACR_E_INVALID, "mf_train_step: B=%d n_users=%d n_items=%d", B,
@@ -1811,7 +1928,10 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
     MACR_REQUIRE((flags & ~(MACR_STEP_DEFER | MACR_STEP_PENDING)) == 0, MACR_E_INVALID, "mf_train_step: flags=%d", flags);
     MACR_REQUIRE(!flags || loss_kind != MACR_LOSS_NORMALBCE, MACR_E_INVALID,
                  "mf_train_step: deferred mode exists for the (B,B) losses only (flags=%d)", flags);
+    MACR_REQUIRE(!lz || loss_kind != MACR_LOSS_NORMALBCE, MACR_E_UNSUPPORTED,
+                 "mf_train_step_lazy: the lazy pass rides in the (B,B) launch (rubibceboth, rubibce)");
     if (int e = validate_hyper(hp, "mf_train_step")) return e;
+    if (lz) if (int e = validate_lazy(lz, true, true, "mf_train_step_lazy")) return e;
     PairWs ws = carve_pair_ws(workspace, B, d);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "mf_train_step: workspace %zu < %zu bytes",
                  workspace_bytes, ws.bytes);
@@ -1838,20 +1958,32 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
         pa.b1 = hp->beta1; pa.b2 = hp->beta2; pa.eps = hp->adam_eps;
         mf_adam_args(a, nb, true, loss_kind, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
                      touchedP, touchedQ, hp, ws);
+        if (lz) {
+            pa.stU = lz->stampP; pa.stI = lz->stampQ; pa.lazy = static_cast<const LazyState *>(lz->state);
+            lazy_adam_args(a, lz, P);
+        }
     }
     // Large batches, step complete in this call: the reference sort is followed by the Adam pass at once, which can sum
     // a row's staged gradient rows itself instead of reading a row some kernel wrote for it (adam_block INDEXED).
     // (MACR_SEG_UNFUSED=1: the segment reduce writes every row, as in deferred mode -- for A/B measurements and tests.)
     const char *unfused = getenv("MACR_SEG_UNFUSED");
-    const bool indexed = ws.staged && !flags && (size_t)3 * B <= kRefMaxRefs && !(unfused && unfused[0] == '1');
+    const bool indexed = ws.staged && !flags && !lz && (size_t)3 * B <= kRefMaxRefs && !(unfused && unfused[0] == '1');
     const uint32_t *sv_sorted = nullptr;
     if (int e = launch_pair(loss_kind, B, d, n_users, n_items, u, i, j, P, Q, w, wu, gP, gQ, touchedP, touchedQ, coef, 1,
                             adam_pow, hp, ws, st, pending ? &pa : nullptr, pending ? &a : nullptr, nb, defer ? &L : nullptr,
-                            false, nullptr, indexed ? &sv_sorted : nullptr))
+                            false, nullptr, indexed ? &sv_sorted : nullptr, lz ? static_cast<LazyState *>(lz->state) : nullptr))
         return e;
     if (defer) return MACR_OK;
     mf_adam_args(a, nb, true, loss_kind, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ,
                  touchedP, touchedQ, hp, ws);
+    if (lz) {
+        // the step completes in this call: its own pass over the flagged rows and the step's sweep, then every row to the
+        // step -- P, Q and the slots are up to date when the call returns
+        lazy_adam_args(a, lz, P);
+        k_adam_lazy_scan<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
+        MACR_CHECK_LAUNCH("adam_lazy", st);
+        return lazy_flush_tables(d, n_users, n_items, P, Q, mP, vP, mQ, vQ, hp, lz, st);
+    }
     if (indexed) {
         a.seg[0].sv = a.seg[1].sv = sv_sorted;
         a.seg[0].stage = a.seg[1].stage = ws.stage;
@@ -1864,10 +1996,10 @@ extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int 
     return MACR_OK;
 }
 
-extern "C" int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int n_items, float *P, float *Q, float *w, float *wu,
-                                   float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
-                                   float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
-                                   const macr_hyper *hp, void *workspace, size_t workspace_bytes, void *stream) {
+static int mf_train_flush(int loss_kind, int B, int d, int n_users, int n_items, float *P, float *Q, float *w, float *wu,
+                          float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
+                          float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                          const macr_hyper *hp, const macr_lazy_adam *lz, void *workspace, size_t workspace_bytes, void *stream) {
     MACR_REQUIRE(loss_kind == MACR_LOSS_RUBIBCEBOTH || loss_kind == MACR_LOSS_RUBIBCE, MACR_E_INVALID,
                  "mf_train_flush: loss_kind=%d has no deferred mode", loss_kind);
     MACR_REQUIRE(B > 0 && n_users > 0 && n_items > 0, MACR_E_INVALID, "mf_train_flush: B=%d n_users=%d n_items=%d", B,
@@ -1876,6 +2008,7 @@ extern "C" int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int
     MACR_REQUIRE(P && Q && w && wu && mP && vP && mQ && vQ && mw && vw && mwu && vwu && gP && gQ && touchedP &&
                      touchedQ && workspace, MACR_E_INVALID, "mf_train_flush: null pointer");
     if (int e = validate_hyper(hp, "mf_train_flush")) return e;
+    if (lz) if (int e = validate_lazy(lz, true, true, "mf_train_flush_lazy")) return e;
     PairWs ws = carve_pair_ws(workspace, B, d);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "mf_train_flush: workspace %zu < %zu bytes",
                  workspace_bytes, ws.bytes);
@@ -1886,9 +2019,55 @@ extern "C" int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int
     LossArgs L;
     L.losses = nullptr;
     hipStream_t st = as_stream(stream);
+    if (lz) {
+        lazy_adam_args(a, lz, P);
+        k_adam_lazy_scan<<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
+        MACR_CHECK_LAUNCH("adam_lazy", st);
+        return lazy_flush_tables(d, n_users, n_items, P, Q, mP, vP, mQ, vQ, hp, lz, st);
+    }
     k_adam_dense<false><<<(unsigned)nb, 256, 0, st>>>(a, ws.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
     return MACR_OK;
+}
+}  // namespace macr
+
+extern "C" int macr_mf_train_step(int loss_kind, int B, int d, int n_users, int n_items, const int32_t *u,
+                                  const int32_t *i, const int32_t *j, float *P, float *Q, float *w, float *wu,
+                                  float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
+                                  float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                                  float *adam_pow, const macr_hyper *hp, float *losses, int flags, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+    return mf_train_step(loss_kind, B, d, n_users, n_items, u, i, j, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ, touchedP,
+                         touchedQ, adam_pow, hp, losses, flags, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int macr_mf_train_step_lazy(int loss_kind, int B, int d, int n_users, int n_items, const int32_t *u,
+                                       const int32_t *i, const int32_t *j, float *P, float *Q, float *w, float *wu,
+                                       float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
+                                       float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                                       float *adam_pow, const macr_hyper *hp, float *losses, int flags,
+                                       const macr_lazy_adam *lazy, void *workspace, size_t workspace_bytes, void *stream) {
+    MACR_REQUIRE(lazy, MACR_E_INVALID, "mf_train_step_lazy: lazy is null");
+    return mf_train_step(loss_kind, B, d, n_users, n_items, u, i, j, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ, touchedP,
+                         touchedQ, adam_pow, hp, losses, flags, lazy, workspace, workspace_bytes, stream);
+}
+
+extern "C" int macr_mf_train_flush(int loss_kind, int B, int d, int n_users, int n_items, float *P, float *Q, float *w, float *wu,
+                                   float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
+                                   float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                                   const macr_hyper *hp, void *workspace, size_t workspace_bytes, void *stream) {
+    return mf_train_flush(loss_kind, B, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ, touchedP, touchedQ,
+                          hp, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int macr_mf_train_flush_lazy(int loss_kind, int B, int d, int n_users, int n_items, float *P, float *Q, float *w,
+                                        float *wu, float *mP, float *vP, float *mQ, float *vQ, float *mw, float *vw, float *mwu,
+                                        float *vwu, float *gP, float *gQ, int32_t *touchedP, int32_t *touchedQ,
+                                        const macr_hyper *hp, const macr_lazy_adam *lazy, void *workspace, size_t workspace_bytes,
+                                        void *stream) {
+    MACR_REQUIRE(lazy, MACR_E_INVALID, "mf_train_flush_lazy: lazy is null");
+    return mf_train_flush(loss_kind, B, d, n_users, n_items, P, Q, w, wu, mP, vP, mQ, vQ, mw, vw, mwu, vwu, gP, gQ, touchedP, touchedQ,
+                          hp, lazy, workspace, workspace_bytes, stream);
 }
 
 // ============================================================================
@@ -2062,7 +2241,7 @@ extern "C" int macr_shard_forward(int loss_kind, int B, int d, const float *rows
     PendingAdam none = {};
     const int user_branch = loss_kind == MACR_LOSS_RUBIBCEBOTH;
     const float *Isrc = rows3 + (size_t)B * d;
-    MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, false><<<ws.nblk_pair, 256, 0, st>>>(B, ws.Bp, sw.iota, sw.iota + B, sw.iota + 2 * (size_t)B,
+    MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 0><<<ws.nblk_pair, 256, 0, st>>>(B, ws.Bp, sw.iota, sw.iota + B, sw.iota + 2 * (size_t)B,
                                                                               rows3, Isrc, w, wu, ws.fwd, ws.part, 1, ws.gw, none,
                                                                               user_branch)));
     MACR_CHECK_LAUNCH("pair_fwd", st);
@@ -2086,8 +2265,8 @@ extern "C" int macr_shard_bxb(int B, int d, int rank, int world, void **partials
         const bool full = B % 256 == 0;
         AdamArgs none; none.n_seg = 0;
 #define MACR_BXB_ROWS_LAUNCH(R)                                                                                               \
-        if (full) k_bxb<R, true, false><<<nb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort); \
-        else      k_bxb<R, false, false><<<nb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort)
+        if (full) k_bxb<R, true, 0><<<nb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort); \
+        else      k_bxb<R, false, 0><<<nb, 256, 0, st>>>(B, ws.Bp, ws.ncb, nb, ws.fwd, ws.rowpart, ws.colpart, ws.lpart, none, ws.scal, sort)
         switch (ws.rows) { case 1: MACR_BXB_ROWS_LAUNCH(1); break; case 2: MACR_BXB_ROWS_LAUNCH(2); break; default: MACR_BXB_ROWS_LAUNCH(4); break; }
 #undef MACR_BXB_ROWS_LAUNCH
     }
@@ -2170,7 +2349,7 @@ extern "C" int macr_shard_forward_slice(int loss_kind, int B, int d, int t0, int
         k_iota3<<<grid_for(n), 256, 0, st>>>(n, sw.iota);
         PendingAdam none = {};
         const int lpr = d / 4, rpb = 256 / lpr, nblk = (n + rpb - 1) / rpb;
-        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, false><<<nblk, 256, 0, st>>>(n, ws.Bp, sw.iota, sw.iota + n, sw.iota + 2 * (size_t)n, rows3_slice,
+        MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 0><<<nblk, 256, 0, st>>>(n, ws.Bp, sw.iota, sw.iota + n, sw.iota + 2 * (size_t)n, rows3_slice,
                                                                           rows3_slice + (size_t)n * d, w, wu, ws.fwd + t0, ws.part, 1, ws.gw,
                                                                           none, loss_kind == MACR_LOSS_RUBIBCEBOTH ? 1 : 0)));
     }
@@ -2335,22 +2514,7 @@ extern "C" int macr_lazy_flush(int d, long long n_rows_p, long long n_rows_q, fl
                  MACR_E_INVALID, "lazy_flush: bad argument");
     if (int e = validate_hyper(hp, "lazy_flush")) return e;
     if (int e = validate_lazy(lazy, n_rows_p > 0, n_rows_q > 0, "lazy_flush")) return e;
-    AdamArgs a;
-    long long nb = 0;
-    a.n_seg = 0; a.lpr = d / 4; a.lpr_shift = d == 32 ? 3 : d == 64 ? 4 : d == 128 ? 5 : 6;
-    a.b1 = hp->beta1; a.b2 = hp->beta2; a.eps = hp->adam_eps;
-    if (n_rows_p) { add_seg(a, P, mP, vP, nullptr, nullptr, n_rows_p, nb); a.seg[a.n_seg - 1].stamp = lazy->stampP; }
-    if (n_rows_q) { add_seg(a, Q, mQ, vQ, nullptr, nullptr, n_rows_q, nb); a.seg[a.n_seg - 1].stamp = lazy->stampQ; }
-    if (a.n_seg == 0) return MACR_OK;
-    LazyArgs z;
-    z.state = static_cast<const LazyState *>(lazy->state); z.period = 1; z.n_tab = a.n_seg;
-    for (int k = 0; k < 3; ++k) z.sweep_first[k] = k < a.n_seg ? a.seg[k].first_block : nb;
-    z.touch_first = z.branch_first = nb;
-    z.n_refs = 0; z.n_users = 0; z.item_seg = 0; z.key_end = 0; z.sk = nullptr;
-    hipStream_t st = as_stream(stream);
-    k_adam_lazy<false, false><<<(unsigned)nb, 256, 0, st>>>(a, z, nullptr);
-    MACR_CHECK_LAUNCH("lazy_flush", st);
-    return MACR_OK;
+    return lazy_flush_tables(d, n_rows_p, n_rows_q, P, Q, mP, vP, mQ, vQ, hp, lazy, as_stream(stream));
 }
 
 // ---- LightGCN ---------------------------------------------------------------

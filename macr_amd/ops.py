@@ -5,6 +5,7 @@ below hands raw device pointers to libmacr_hip.so.  Nothing in this module has
 a CPU or eager-PyTorch fallback -- CPU tensors are rejected.
 """
 import ctypes
+import os
 
 import torch
 
@@ -468,15 +469,32 @@ def make_hyper(lr, decay, alpha, beta, batch_size_cfg, beta1=0.9, beta2=0.999, a
     return Hyper(lr, beta1, beta2, adam_eps, decay, alpha, beta, int(batch_size_cfg))
 
 
+def mf_lazy_period_for(n_rows, d, B):
+    """K of the lazy dense Adam pass for deferred MF training (1 = off).  The dense pass rides in the (B,B) launch: it costs
+    time only where its HBM traffic (24*d bytes per row, ~6.2 TB/s) outlasts the (B,B) arithmetic (2*B*B pair terms at ~2.2 T/s);
+    lazily the launch moves the rows of two batches and a K-th of the tables instead -- worth it when the tables are several
+    batches large.  (Gowalla at B = 4096: 17.5 us of traffic beside 15.2 us of arithmetic -> 4; ML-10M at B = 8192: 20 beside 61 -> 1.)"""
+    adam_us = 24.0 * d * n_rows / 6.2e6
+    bxb_us = 2.0 * B * B / 2.2e6
+    return 4 if (adam_us > 0.9 * bxb_us and n_rows >= 12 * B) else 1
+
+
 class MFState(object):
     """Device state of the MF model + its optimizer (one tf.train.AdamOptimizer instance).
 
     P,Q,w,wu mirror weights['user_embedding'], ['item_embedding'], self.w, self.w_user of
     macr_mf/model.py:107-122,:59-60.  Adam slots start at zero, beta powers at (beta1,beta2)."""
 
-    def __init__(self, P, Q, w, wu, hyper, batch_cap):
+    def __init__(self, P, Q, w, wu, hyper, batch_cap, lazy_period=None):
+        """lazy_period: K of the lazy dense Adam pass in deferred mode (include/macr_hip.h: macr_lazy_adam; 1 = the dense pass
+        every step); None: the environment's MACR_LAZY_ADAM_MF, else by table and batch size (mf_lazy_period_for)"""
         _require_f32(P=P, Q=Q, w=w, wu=wu)
         dev = P.device
+        if lazy_period is None and os.environ.get("MACR_LAZY_ADAM_MF", ""):
+            lazy_period = int(os.environ["MACR_LAZY_ADAM_MF"])
+        self.lazy_period = lazy_period        # None: decided per deferred sequence from its batch size
+        self._seq_lazy = None                 # struct macr_lazy_adam of the running deferred sequence (None: the dense form)
+        self._lazy_bufs = None
         self.P, self.Q = P.contiguous(), Q.contiguous()
         self.w, self.wu = w.reshape(-1).contiguous(), wu.reshape(-1).contiguous()
         self.hyper = hyper
@@ -540,20 +558,46 @@ class MFState(object):
             self.flush()
         flags = (_lib.STEP_DEFER if defer else 0) | (_lib.STEP_PENDING if self.pending_B else 0)
         tabs = self._tables()
-        check(_lib.lib().macr_mf_train_step(
-            kind, B, self.d, self.P.shape[0], self.Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
-            *tabs, self._pow_ptr, ctypes.byref(self.hyper),
-            _ptr(out, _f32), flags, _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
+        if not self.pending_B:                  # a deferred sequence starts (or a single complete step): its form
+            self._seq_lazy = self._lazy_struct(B) if defer else None
+        if self._seq_lazy is not None:
+            check(_lib.lib().macr_mf_train_step_lazy(
+                kind, B, self.d, self.P.shape[0], self.Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
+                *tabs, self._pow_ptr, ctypes.byref(self.hyper),
+                _ptr(out, _f32), flags, ctypes.byref(self._seq_lazy), _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
+        else:
+            check(_lib.lib().macr_mf_train_step(
+                kind, B, self.d, self.P.shape[0], self.Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
+                *tabs, self._pow_ptr, ctypes.byref(self.hyper),
+                _ptr(out, _f32), flags, _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
         self.pending_B = B if defer else 0
         self.pending_kind = kind
         return out
 
+    def _lazy_struct(self, B):
+        """struct macr_lazy_adam for a deferred sequence of batches of B triples, or None (the dense pass every step)"""
+        k = self.lazy_period if self.lazy_period is not None else mf_lazy_period_for(self.P.shape[0] + self.Q.shape[0], self.d, B)
+        if k <= 1:
+            return None
+        if self._lazy_bufs is None:
+            dev = self.P.device
+            self._lazy_bufs = (torch.zeros(_lib.LAZY_STATE_BYTES, dtype=torch.uint8, device=dev),
+                               torch.zeros(self.P.shape[0], dtype=_i32, device=dev), torch.zeros(self.Q.shape[0], dtype=_i32, device=dev))
+        st, sp, sq = self._lazy_bufs
+        return _lib.LazyAdam(_ptr(st), _ptr(sp), _ptr(sq), int(k))
+
     def flush(self):
-        """Complete a pending dense Adam pass (no-op when nothing is pending)."""
+        """Complete a pending dense Adam pass (no-op when nothing is pending); a lazy sequence also brings every row to its
+        last step: P, Q and the slots are then what the dense pass leaves."""
         if self.pending_B:
-            check(_lib.lib().macr_mf_train_flush(
-                self.pending_kind, self.pending_B, self.d, self.P.shape[0], self.Q.shape[0], *self._tables(),
-                ctypes.byref(self.hyper), _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
+            if self._seq_lazy is not None:
+                check(_lib.lib().macr_mf_train_flush_lazy(
+                    self.pending_kind, self.pending_B, self.d, self.P.shape[0], self.Q.shape[0], *self._tables(),
+                    ctypes.byref(self.hyper), ctypes.byref(self._seq_lazy), _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
+            else:
+                check(_lib.lib().macr_mf_train_flush(
+                    self.pending_kind, self.pending_B, self.d, self.P.shape[0], self.Q.shape[0], *self._tables(),
+                    ctypes.byref(self.hyper), _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
             self.pending_B = 0
 
 

@@ -173,3 +173,101 @@ def test_lazy_period_rule_and_argument_checks():
         lz = _lib.LazyAdam(p, p, p, period)
         rc = L.macr_lazy_flush(64, 4, 4, p, p, p, p, p, p, ctypes.byref(hyper), ctypes.byref(lz), None)
         assert rc == _lib.E_INVALID and b"period" in L.macr_last_error()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The MF step in deferred mode (macr_mf_train_step_lazy): the lazy pass rides in the (B,B) launch, the forward kernel looks
+# stamp .. pending step ahead in registers and marks its rows for the pass.
+# ---------------------------------------------------------------------------------------------------------------------
+def _mf_states(n_users, n_items, d, B, periods, seed=9):
+    from macr_amd import ops
+    rs = np.random.RandomState(seed)
+    P = (rs.standard_normal((n_users, d)) * 0.3).astype(np.float32)
+    Q = (rs.standard_normal((n_items, d)) * 0.3).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()
+    return [ops.MFState(t(P), t(Q), t(w), t(wu), ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, 1024), B, lazy_period=k) for k in periods], rs
+
+
+_MF_NAMES = ("P", "Q", "w", "wu", "mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu")
+
+
+@pytest.mark.parametrize("d,kind_name", [(32, "LOSS_RUBIBCEBOTH"), (64, "LOSS_RUBIBCEBOTH"), (128, "LOSS_RUBIBCE"), (256, "LOSS_RUBIBCEBOTH")])
+def test_mf_lazy_sequence_equals_the_dense_sequence_bit_for_bit(d, kind_name):
+    """Batches without a repeated row and with at most eight backward blocks: every atomic add of the step lands on a zero (one
+    per gradient element, one per branch-vector partial slot), so a deferred sequence is reproducible bit for bit -- and the
+    lazy form (periods 2, 3, 7) must reproduce the dense form: every step's losses, and the tables whenever they are flushed."""
+    from macr_amd import ops
+    kind = getattr(ops, kind_name)
+    n_users, n_items, B, steps = 2000, 1500, 128, 26
+    states, rs = _mf_states(n_users, n_items, d, B, [1, 2, 3, 7])
+    for step in range(steps):
+        u = rs.choice(n_users, B, replace=False).astype(np.int32)
+        ij = rs.choice(n_items, 2 * B, replace=False).astype(np.int32)
+        b = [torch.from_numpy(a).cuda() for a in (u, ij[:B], ij[B:])]
+        losses = [s.step(kind, *b, defer=True).clone() for s in states]
+        assert states[1]._seq_lazy is not None and states[0]._seq_lazy is None
+        for l in losses[1:]:
+            assert torch.equal(l, losses[0]), (step, l, losses[0])
+        if step in (9, steps - 1):
+            for s in states:
+                s.flush()
+            for s in states[1:]:
+                for name in _MF_NAMES:
+                    assert torch.equal(getattr(s, name), getattr(states[0], name)), (step, name)
+                assert int(s.tP.abs().sum()) == 0 and int(s.tQ.abs().sum()) == 0 and float(s.gP.abs().max()) == 0.0
+                st, sp, sq = s._lazy_bufs
+                assert int(sp.min()) == step + 1 and int(sq.max()) == step + 1
+
+
+@pytest.mark.parametrize("B,d,n_users,n_items,K", [(1024, 64, 13485, 744, 4), (4096, 64, 29858, 40981, 4), (257, 32, 5000, 3000, 2),
+                                                   (9000, 64, 120000, 30000, 8), (4096, 128, 50000, 9000, 16)])
+def test_mf_lazy_sequence_on_real_batches(B, d, n_users, n_items, K):
+    """popularity-skewed batches (duplicates, the bucketed backward, B > 8192: the staged backward): the lazy sequence against the
+    dense sequence and against complete steps, within what the order of the float atomics leaves (the bounds of
+    test_mf_deferred_random_shapes)"""
+    from macr_amd import ops
+    kind = ops.LOSS_RUBIBCEBOTH
+    (dense, lazy, eager), rs = _mf_states(n_users, n_items, d, B, [1, K, 1])
+    for step in range(11):
+        u = rs.choice(n_users, B, replace=False).astype(np.int32)
+        i = (rs.zipf(1.3, B) % n_items).astype(np.int32)
+        j = rs.randint(0, n_items, B).astype(np.int32)
+        b = [torch.from_numpy(a).cuda() for a in (u, i, j)]
+        a_, l_, e_ = dense.step(kind, *b, defer=True), lazy.step(kind, *b, defer=True), eager.step(kind, *b)
+        assert lazy._seq_lazy is not None
+        np.testing.assert_allclose(l_.cpu().numpy(), a_.cpu().numpy(), rtol=5e-6)
+        np.testing.assert_allclose(l_.cpu().numpy(), e_.cpu().numpy(), rtol=5e-6)
+        if step == 5:
+            lazy.flush()                                 # a reader in mid-sequence; the next step starts a new sequence
+    dense.flush(); lazy.flush()
+    for name in _MF_NAMES:
+        x, y, z = (getattr(s, name).cpu().numpy() for s in (lazy, dense, eager))
+        np.testing.assert_allclose(x, y, rtol=3e-4, atol=1e-7 + 2e-5 * np.abs(y).max(), err_msg=name)
+        np.testing.assert_allclose(x, z, rtol=3e-4, atol=1e-7 + 2e-5 * np.abs(z).max(), err_msg=name)
+    assert float(lazy.gP.abs().max()) == 0.0 and float(lazy.gQ.abs().max()) == 0.0
+    assert int(lazy.tP.sum()) == 0 and int(lazy.tQ.sum()) == 0
+
+
+def test_mf_lazy_step_that_completes_in_its_call():
+    """a lazy sequence ended by a step without MACR_STEP_DEFER: the step's own pass and the catch-up of every row run in the call"""
+    from macr_amd import ops
+    kind = ops.LOSS_RUBIBCEBOTH
+    n_users, n_items, d, B = 2000, 1500, 64, 128
+    (dense, lazy), rs = _mf_states(n_users, n_items, d, B, [1, 3])
+    for step in range(8):
+        u = rs.choice(n_users, B, replace=False).astype(np.int32)
+        ij = rs.choice(n_items, 2 * B, replace=False).astype(np.int32)
+        b = [torch.from_numpy(a).cuda() for a in (u, ij[:B], ij[B:])]
+        defer = step < 7
+        assert torch.equal(dense.step(kind, *b, defer=defer), lazy.step(kind, *b, defer=defer))
+    assert lazy.pending_B == 0 and dense.pending_B == 0
+    for name in _MF_NAMES:
+        assert torch.equal(getattr(lazy, name), getattr(dense, name)), name
+
+
+def test_mf_lazy_period_rule():
+    from macr_amd import ops
+    assert ops.mf_lazy_period_for(29858 + 40981, 64, 4096) == 4         # Gowalla: the pass's traffic outlasts the (B,B) arithmetic
+    assert ops.mf_lazy_period_for(69878 + 10677, 64, 8192) == 1         # ML-10M: it does not
+    assert ops.mf_lazy_period_for(300 + 50, 64, 96) == 1                # tables of a few batches: nothing to skip
