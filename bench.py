@@ -172,6 +172,7 @@ def bench_config4(args, rank, world, dev, emit=True):
         raise SystemExit("ERROR: loss is nan.")
     # per-kernel events (rank-local launches) and per-collective events
     n_prof = 8
+    run_steps(2 * model.lazy_period if model.lazy_period > 1 else 0, 1)      # lazy pass: every sweep at its full lag again (the regions end in a flush)
     model.collective_ms = {}
     ops.timing_begin()
     run_steps(n_prof, 0)
@@ -290,6 +291,9 @@ def bench_config4(args, rank, world, dev, emit=True):
                                                      "of the branch-vector partials per step" % (3 * B * d * 4 / 1e6))),
                           "global_batch": B},
                "rows_per_rank": rows_local, "bytes_per_rank": 4.0 * d * rows_local * 4 + 4.0 * rows_local, "lazy_adam_period": model.lazy_period,
+               "lazy_adam_note": None if model.lazy_period <= 1 else
+               "every timed region ends with a flush (all rows at the last step); a region shorter than ~4 periods (%d steps) never reaches the "
+               "pass's steady lag and reads faster than training does -- quote --steps >= %d" % (4 * model.lazy_period, 4 * model.lazy_period),
                "wire_bytes_per_step": None if model.wire_rows is None else {
                    "rows_crossing_ranks_each_way": model.wire_rows, "row_bytes": model.wire_rows * d * 4,
                    "replicated_step_all_reduce_buffer_bytes": 3 * B * d * 4,

@@ -470,13 +470,18 @@ def make_hyper(lr, decay, alpha, beta, batch_size_cfg, beta1=0.9, beta2=0.999, a
 
 
 def mf_lazy_period_for(n_rows, d, B):
-    """K of the lazy dense Adam pass for deferred MF training (1 = off).  The dense pass rides in the (B,B) launch: it costs
-    time only where its HBM traffic (24*d bytes per row, ~6.2 TB/s) outlasts the (B,B) arithmetic (2*B*B pair terms at ~2.2 T/s);
-    lazily the launch moves the rows of two batches and a K-th of the tables instead -- worth it when the tables are several
-    batches large.  (Gowalla at B = 4096: 17.5 us of traffic beside 15.2 us of arithmetic -> 4; ML-10M at B = 8192: 20 beside 61 -> 1.)"""
+    """K of the lazy dense Adam pass for deferred MF training (1 = off).  The dense pass rides in the (B,B) launch: 24*d bytes
+    per row at ~6.2 TB/s beside 2*B*B pair terms at ~2.2 T/s.  Lazily the launch moves the rows of two batches and a K-th of
+    the tables -- but the arithmetic of the pass stays (every row still receives every step), the forward kernel pays for the
+    steps its rows are behind, and the flagged rows of a chunk fill a quarter of their waves' lanes.  Measured on the Gowalla
+    shape (17.5 us of traffic beside 15.2 us of arithmetic; profiles/r05_lazy_mf_ab.txt): 34.6 us per step dense, 37.3 / 38.9 /
+    43.7 with K = 2 / 4 / 8 -- so the lazy form is for tables whose pass dwarfs the (B,B) term (millions of rows on one GPU),
+    where it is the difference between a step bound by 24*d*rows bytes and one bound by its batch."""
     adam_us = 24.0 * d * n_rows / 6.2e6
-    bxb_us = 2.0 * B * B / 2.2e6
-    return 4 if (adam_us > 0.9 * bxb_us and n_rows >= 12 * B) else 1
+    bxb_us = max(2.0 * B * B / 2.2e6, 20.0)
+    if adam_us < 4.0 * bxb_us:
+        return 1
+    return int(min(64, max(2, round(adam_us / bxb_us / 2.0))))
 
 
 class MFState(object):

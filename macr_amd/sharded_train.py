@@ -76,9 +76,11 @@ class Owned(object):
         return own, rel // self.stride
 
 
-def lazy_period_for(n_rows, d, target_bytes=512 << 20):
+def lazy_period_for(n_rows, d, target_bytes=256 << 20):
     """K of the lazy dense Adam pass for a shard of n_rows rows: the dense pass moves 24*d bytes per row and step; sweep a K-th
-    of that per step, about target_bytes -- 1 (dense every step) for tables the size of the reference's datasets"""
+    of that per step, about target_bytes (40 us of HBM time: below the VALU time of the pass's arithmetic, which no period
+    removes -- measured at 11 M rows, d = 128: 6.36 ms per step dense, 1.04 / 0.66 / 0.68 / 0.67 ms with K = 8 / 16 / 32 / 63,
+    profiles/r05_c4_lazy_steady.txt) -- 1 (dense every step) for tables the size of the reference's datasets"""
     k = int(round(24.0 * d * n_rows / target_bytes))
     return max(1, min(k, 64))
 

@@ -162,8 +162,8 @@ def test_lazy_rows_reads_a_row_as_of_now_and_writes_nothing():
 def test_lazy_period_rule_and_argument_checks():
     from macr_amd import _lib, ops, sharded_train
     assert sharded_train.lazy_period_for(29858 + 40981, 64) == 1            # Gowalla: dense every step
-    assert sharded_train.lazy_period_for(11_000_000, 128) == 63             # BASELINE configs[4] on one GPU
-    assert sharded_train.lazy_period_for(1_375_000, 128) == 8               # ... on eight
+    assert sharded_train.lazy_period_for(11_000_000, 128) == 64             # BASELINE configs[4] on one GPU
+    assert sharded_train.lazy_period_for(1_375_000, 128) == 16              # ... on eight
     L = _lib.lib()
     hyper = ops.make_hyper(1e-3, 1e-5, 1e-2, 1e-3, 1024)
     buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
@@ -268,6 +268,7 @@ def test_mf_lazy_step_that_completes_in_its_call():
 
 def test_mf_lazy_period_rule():
     from macr_amd import ops
-    assert ops.mf_lazy_period_for(29858 + 40981, 64, 4096) == 4         # Gowalla: the pass's traffic outlasts the (B,B) arithmetic
-    assert ops.mf_lazy_period_for(69878 + 10677, 64, 8192) == 1         # ML-10M: it does not
-    assert ops.mf_lazy_period_for(300 + 50, 64, 96) == 1                # tables of a few batches: nothing to skip
+    assert ops.mf_lazy_period_for(29858 + 40981, 64, 4096) == 1         # Gowalla: measured slower lazily (profiles/r05_lazy_mf_ab.txt)
+    assert ops.mf_lazy_period_for(69878 + 10677, 64, 8192) == 1         # ML-10M
+    assert ops.mf_lazy_period_for(300 + 50, 64, 96) == 1
+    assert ops.mf_lazy_period_for(11_000_000, 128, 8192) == 45          # tables whose dense pass is 5.5 ms beside a 61 us (B,B) term
