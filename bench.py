@@ -195,6 +195,10 @@ def bench_config4(args, rank, world, dev, emit=True):
                     "frac": gbps / HBM_PEAK_GBS, "traffic": None, "avg_us": adam_us, "algorithmic_bytes": adam_bytes,
                     "note": "TF-style dense Adam over this rank's %d rows (24*d bytes per row and step); event-timed, "
                             "includes ~3 us of event overhead" % rows_local}
+        try:            # PMC HBM bytes per launch of the same command (tools/profile.sh c4 -> profiles/pmc_latest.json), when it was profiled
+            roofline["traffic"] = json.load(open(os.path.join(REPO, "profiles", "pmc_latest.json"))).get("config4", {}).get(adam_name)
+        except Exception:
+            pass
         if adam_name == "adam_lazy":
             K = model.lazy_period
             moved = adam_bytes / K + 3.0 * B / world * (24 * d + 4)
@@ -207,6 +211,19 @@ def bench_config4(args, rank, world, dev, emit=True):
                                      "per second and can exceed the HBM peak; `moved_bytes_model` = a K-th of the shard + the batch's rows is what "
                                      "a launch really moves; the pass is bound by the VALU time of the same arithmetic (13 instructions per "
                                      "element and step, ~4.5 cycles each per wave64: `valu_floor_us_model`)" % K})
+            try:        # the pass against the bound it has: VALU issue, from the PMC instruction counts of the same command (tools/profile.sh c4)
+                c = json.load(open(os.path.join(REPO, "profiles", "pmc_sq_latest.json"))).get("config4", {}).get("adam_lazy")
+                rates = json.load(open(os.path.join(REPO, "profiles", "valu_rates.json"))).get("classes", {}).get("waves_per_simd_2", {})
+                cyc_full = rates.get("v_fma_f32", {}).get("cycles_at_2p4GHz", 4.0)
+                cyc_tr = rates.get("v_exp_f32", {}).get("cycles_at_2p4GHz", 16.0)
+                insts, tr = c["SQ_INSTS_VALU"], c.get("SQ_INSTS_VALU_TRANS_F32", 2.0 / 13.0 * c["SQ_INSTS_VALU"])
+                lim = ((insts - tr) * cyc_full + tr * cyc_tr) / 1024.0 / 2.4e3
+                roofline["valu_issue"] = {"bound": "valu-issue", "valu_wave_insts_per_launch": insts, "transcendental_share": tr / insts,
+                                          "issue_cycles_per_wave_instr": {"full_rate": cyc_full, "transcendental": cyc_tr},
+                                          "issue_limit_us": lim, "frac": lim / adam_us, "avg_us_under_pmc": c.get("avg_ns_under_pmc", 0) / 1e3,
+                                          "note": "issue_limit_us = sum over instruction classes of count x measured issue cycles / 1024 SIMDs / 2.4 GHz"}
+            except Exception:
+                pass
     step_bytes = B * (24 * d + 12) + 24.0 * d * (n_users + n_items)
     # ------------------------------------------------------------- evaluation: item shards + one all-gather
     eval_out = {}
@@ -728,7 +745,7 @@ def roofline_bxb(workload, B, kern_avg):
     # static mix: the kernel's two pair loops (6- and 4-transcendental forms), R = 4 rows per lane
     loops = []
     for name, k in mix.items():
-        if "k_bxbILi4ELb1ELb0E" in name or (B > 4096 and "k_bxbILi4ELb1ELb0E" in name):
+        if "k_bxbILi4ELb1ELi0E" in name or "k_bxbILi4ELb1ELb0E" in name:      # (R = 4, FULL, no Adam blocks; the ADAM parameter is an int since abi 11)
             loops = [l for l in k["loops"] if l["mix"].get("valu_trans", 0) >= 8][:2]
     if loops:
         share = [l["trans_share_of_valu"] for l in loops]

@@ -54,7 +54,7 @@ def short(name):
     if k == "tau" and re.search(r"k_tau<\s*\d+\s*,\s*(true|1)\s*>", name):
         k = "tau2"
     if k == "bxb":                   # k_bxb<R, FULL, ADAM>: ADAM=true carries the deferred Adam blocks
-        t = re.search(r"k_bxb<\s*\d+\s*,\s*(?:true|false|\d+)\s*,\s*(true|1)", name)
+        t = re.search(r"k_bxb<\s*\d+\s*,\s*(?:true|false|\d+)\s*,\s*(true|1|2)", name)     # (2: the lazy pass)
         if t:
             k = "bxb+adam"
     return k
