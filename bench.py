@@ -212,15 +212,15 @@ def bench_config4(args, rank, world, dev, emit=True):
                                      "a launch really moves; the pass is bound by the VALU time of the same arithmetic (13 instructions per "
                                      "element and step, ~4.5 cycles each per wave64: `valu_floor_us_model`)" % K})
             try:        # the pass against the bound it has: VALU issue, from the PMC instruction counts of the same command (tools/profile.sh c4)
-                c = json.load(open(os.path.join(REPO, "profiles", "pmc_sq_latest.json"))).get("config4", {}).get("adam_lazy")
+                cnt = json.load(open(os.path.join(REPO, "profiles", "pmc_sq_latest.json"))).get("config4", {}).get("adam_lazy")
                 rates = json.load(open(os.path.join(REPO, "profiles", "valu_rates.json"))).get("classes", {}).get("waves_per_simd_2", {})
                 cyc_full = rates.get("v_fma_f32", {}).get("cycles_at_2p4GHz", 4.0)
                 cyc_tr = rates.get("v_exp_f32", {}).get("cycles_at_2p4GHz", 16.0)
-                insts, tr = c["SQ_INSTS_VALU"], c.get("SQ_INSTS_VALU_TRANS_F32", 2.0 / 13.0 * c["SQ_INSTS_VALU"])
+                insts, tr = cnt["SQ_INSTS_VALU"], cnt.get("SQ_INSTS_VALU_TRANS_F32", 2.0 / 13.0 * cnt["SQ_INSTS_VALU"])
                 lim = ((insts - tr) * cyc_full + tr * cyc_tr) / 1024.0 / 2.4e3
                 roofline["valu_issue"] = {"bound": "valu-issue", "valu_wave_insts_per_launch": insts, "transcendental_share": tr / insts,
                                           "issue_cycles_per_wave_instr": {"full_rate": cyc_full, "transcendental": cyc_tr},
-                                          "issue_limit_us": lim, "frac": lim / adam_us, "avg_us_under_pmc": c.get("avg_ns_under_pmc", 0) / 1e3,
+                                          "issue_limit_us": lim, "frac": lim / adam_us, "avg_us_under_pmc": cnt.get("avg_ns_under_pmc", 0) / 1e3,
                                           "note": "issue_limit_us = sum over instruction classes of count x measured issue cycles / 1024 SIMDs / 2.4 GHz"}
             except Exception:
                 pass
@@ -241,7 +241,7 @@ def bench_config4(args, rank, world, dev, emit=True):
         def query_rows():
             own, loc = own_u.local_of(ud)
             Pq.zero_()
-            Pq[own] = model.P[loc[own]]
+            Pq[own] = model.rows("P", loc[own])      # (the query users' rows as of now: no pass over the 10 M-row user table)
             if world > 1:
                 torch.distributed.all_reduce(Pq)
 
@@ -266,6 +266,7 @@ def bench_config4(args, rank, world, dev, emit=True):
         t_ev, ret = timed(os.environ.get("MACR_EVAL_FILTER", "bf16").lower())
         flops_rank = 2.0 * U * own_i.n * d
         eval_out = {"eval_users_per_s": U / t_ev, "eval_ms_per_pass": 1e3 * t_ev, "eval_users": U, "eval_filter": ev.filter,
+                    "eval_info": ev.last_eval_info(), "eval_fast_stats": dict(getattr(ev, "fast_stats", {})),
                     "eval_metrics": {k: float(v[0]) for k, v in ret.items()},
                     "roofline_eval": {"filter": "f32", "bound": "mfma", "flops_per_rank": flops_rank, "eval_users_per_s": U / t_f32,
                                       "achieved": flops_rank / t_f32 / 1e12,

@@ -118,10 +118,15 @@ __global__ __launch_bounds__(512, 2) void k_score_topk(
     const float *__restrict__ c_dev,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_idx, int item_offset, int K,
     int n_splits, float *__restrict__ out_val, int32_t *__restrict__ out_idx, uint32_t *shared_thr,
-    const int32_t *run_flag, int32_t *stats) {
+    const int32_t *run_flag, int32_t *stats, const int32_t *__restrict__ only_blocks = nullptr) {
     // run_flag[0]: a candidate list overflowed twice (this kernel must run); run_flag[1]: user blocks the repair round re-listed
     if (stats && run_flag && blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = run_flag[1]; stats[1] = run_flag[0]; }
     if (run_flag && *run_flag == 0) return;             // fallback launch: only when a candidate list overflowed
+    // ... and then only for the blocks of 256 queries the repair round listed again (k_repair_plan: blk_flag != 0): a second
+    // overflow can only be among them, every other block's first-round ranking stands.  (One degenerate query -- a user
+    // whose branch factor has collapsed every score to a tie -- used to send a whole 100 000-query evaluation through
+    // this kernel: 445 ms instead of 87 at the configs[4] shape.)
+    if (run_flag && only_blocks && only_blocks[blockIdx.x / n_splits] == 0) return;
     const float c = c_dev ? *c_dev : c_val;             // device-resident c: one captured graph serves a whole c sweep
     constexpr int NKH = D / kUnitK > 0 ? D / kUnitK : 1;     // k-halves per tile (D=32 -> 1 short unit)
     constexpr int UK = D < kUnitK ? D : kUnitK;              // k extent of one unit
@@ -3802,7 +3807,7 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
         kern<<<ublocks * n_splits, 512, smem_old, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
                                                         mask_ptr, mask_idx, item_offset, K, n_splits, out_val, out_idx,
                                                         n_splits > 1 ? ws.shared_thr : nullptr, force_fallback ? nullptr : ws.overflow,
-                                                        stats);
+                                                        stats, force_fallback ? nullptr : ws.blk_flag);
     });
     MACR_CHECK_LAUNCH("score_topk", st);
     return MACR_OK;
@@ -3963,7 +3968,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int filter, int U, int n_lo
         for (int g = 0; g < n_c; ++g)
             kern<<<ublocks, 512, smem_old, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, 0.f, c_dev + g, mask_ptr, mask_idx,
                                                  item_offset, K, 1, out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K,
-                                                 nullptr, force_fallback ? nullptr : ws[g].overflow, nullptr);
+                                                 nullptr, force_fallback ? nullptr : ws[g].overflow, nullptr, nullptr);
     });
     MACR_CHECK_LAUNCH("score_topk", st);
     return MACR_OK;

@@ -170,7 +170,7 @@ class Evaluator(object):
             self._stats_evt = None
             if self._last_seeded:
                 relisted, fell_back = int(self._stats_host[0]), int(self._stats_host[1])
-                if fell_back or relisted > 0:
+                if relisted > self._relist_tolerance():
                     self._seed_skip = self._seed_backoff
                     self._seed_backoff = min(16, 2 * self._seed_backoff)
                 else:
@@ -181,6 +181,13 @@ class Evaluator(object):
         else:
             self._seeded_now = True
         return self._seeded_now
+
+    def _relist_tolerance(self):
+        """blocks of 256 queries a seeded ranking may list twice before the seeds count as stale: none up to 63 blocks (a repair
+        round costs what an unseeded ranking costs there), one per 64 blocks beyond -- on 100 000 queries a handful of
+        re-listed blocks is a few queries with degenerate scores (every item tied), not a model that moved away from its seeds,
+        and the sampling pass would cost every block more than their repair does"""
+        return ((self.n_queries + 255) // 256) // 64
 
     def _shape_uses_seeds(self, n_local, d):
         """False for shards small enough that the ranking lists every unmasked item (no thresholds to seed)"""
@@ -310,7 +317,7 @@ class Evaluator(object):
         # a list overflowed or seeds were stale: the repair round (and, behind it, the exact fallback) on the first round's
         # workspace and outputs -- what the complete call would have launched
         self.fast_stats["redone"] += 1
-        if seeded:
+        if seeded and relisted > self._relist_tolerance():
             self._seed_skip = self._seed_backoff
             self._seed_backoff = min(16, 2 * self._seed_backoff)
         if first_entry is None or len(first_entry) < 4:      # (no graph of the first round: it ran as the complete call already)

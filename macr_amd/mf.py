@@ -314,7 +314,7 @@ class ShardedBPRMF(object):
         buf, m = self._q[key], self._any()
         own, loc = self.own_u.local_of(uid.long())
         buf.zero_()
-        buf[own] = m.P[loc[own]]
+        buf[own] = m.rows("P", loc[own])           # (as of the current step; the user table itself is not brought up to date)
         m._all_reduce(buf, "query_rows")
         return buf
 

@@ -143,10 +143,12 @@ class HipBackend(object):
                                          o._ptr(shard.lazy_state), ctypes.byref(self.hyper), o._ptr(out), o._stream()))
         return out
 
-    def lazy_flush(self, shard):
+    def lazy_flush(self, shard, tables="PQ"):
         o, L = self.ops, self._lib.lib()
         lz = self._lazy(shard)
-        self._lib.check(L.macr_lazy_flush(self.d, shard._P.shape[0], shard._Q.shape[0], o._ptr(shard._P), o._ptr(shard._Q),
+        n_p = shard._P.shape[0] if "P" in tables else 0
+        n_q = shard._Q.shape[0] if "Q" in tables else 0
+        self._lib.check(L.macr_lazy_flush(self.d, n_p, n_q, o._ptr(shard._P), o._ptr(shard._Q),
                                           o._ptr(shard._mP), o._ptr(shard._vP), o._ptr(shard._mQ), o._ptr(shard._vQ),
                                           ctypes.byref(self.hyper), ctypes.byref(lz), o._stream()))
 
@@ -230,9 +232,10 @@ class HipBackend(object):
 
 
 def _current_table(name):
-    """property of RowShardedMF: a table or slot as the per-step dense pass would hold it (rows the lazy pass left behind catch up first)"""
+    """property of RowShardedMF: a table or slot as the per-step dense pass would hold it (rows of THAT table the lazy pass left
+    behind catch up first; the other table is left alone)"""
     def get(self):
-        self.flush()
+        self.flush(name[-1])
         return getattr(self, name)
     return property(get)
 
@@ -277,18 +280,35 @@ class RowShardedMF(object):
             lazy_period = int(env) if env else lazy_period_for(self._P.shape[0] + self._Q.shape[0], self._P.shape[1])
         if not getattr(backend, "lazy_capable", False):
             lazy_period = 1
-        self.lazy_period, self._stale = max(1, int(lazy_period)), False
+        self.lazy_period, self._stale_tabs = max(1, int(lazy_period)), set()
         if self.lazy_period > 1:
             self.stP = torch.zeros(self._P.shape[0], dtype=torch.int32, device=dev)
             self.stQ = torch.zeros(self._Q.shape[0], dtype=torch.int32, device=dev)
             self.lazy_state = torch.zeros(1040, dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------ the tables, as the per-step dense pass would hold them
-    def flush(self):
-        """every row of the shard brought to the current step (no-op unless the lazy pass left rows behind)"""
-        if self._stale:
-            self.backend.lazy_flush(self)
-            self._stale = False
+    @property
+    def _stale(self):
+        return bool(self._stale_tabs)
+
+    @_stale.setter
+    def _stale(self, v):
+        self._stale_tabs = {"P", "Q"} if v else set()
+
+    def flush(self, tables="PQ"):
+        """every row of the shard (of the named tables: "P", "Q", "PQ") brought to the current step; no-op unless the lazy pass
+        left rows behind"""
+        todo = [t for t in tables if t in self._stale_tabs]
+        if todo:
+            self.backend.lazy_flush(self, "".join(todo))
+            self._stale_tabs -= set(todo)
+
+    def rows(self, table, local_idx):
+        """(n, d) rows local_idx (local indices) of table "P" / "Q" as of the current step WITHOUT bringing the table up to date:
+        what an evaluation needs of the user table is its query users' rows, not a pass over every user"""
+        if table in self._stale_tabs:
+            return self.backend.lazy_rows(self, table, local_idx)
+        return getattr(self, "_" + table)[local_idx.long()]
 
     P, Q = _current_table("_P"), _current_table("_Q")
     mP, vP, mQ, vQ = _current_table("_mP"), _current_table("_vP"), _current_table("_mQ"), _current_table("_vQ")

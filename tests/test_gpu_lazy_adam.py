@@ -157,6 +157,13 @@ def test_lazy_rows_reads_a_row_as_of_now_and_writes_nothing():
     for a, b in zip(before, (lazy._P, lazy._mP, lazy._vP, lazy.stP)):
         assert torch.equal(a, b)
     assert int((lazy.stP != 5).sum()) > 1000                    # (most rows really were behind)
+    # what an evaluation touches: the item table (brought up to date: the whole catalogue is scored) and the query users' rows
+    # (read as of now) -- the user table stays behind
+    assert torch.equal(lazy.Q, dense.Q) and int((lazy.stQ != 5).sum()) == 0
+    idx = rows[rows >= 0][:500]
+    assert torch.equal(lazy.rows("P", idx), dense.P[idx.long()])
+    assert int((lazy.stP != 5).sum()) > 1000 and lazy._stale_tabs == {"P"}
+    assert torch.equal(lazy.P, dense.P) and not lazy._stale
 
 
 def test_lazy_period_rule_and_argument_checks():

@@ -1083,6 +1083,35 @@ def test_first_round_plus_repair_round_is_the_complete_call(ops, eval_filter):
         assert stats.cpu().numpy().tolist() == want_stats, name
 
 
+def test_one_degenerate_query_sends_only_its_block_through_the_exact_kernel(ops, eval_filter):
+    """A user whose branch factor sigmoid(e_u . w_user) has gone to zero scores every item 0: every item ties, every list of
+    hers overflows in both rounds and the exact kernel must rank her (ties by ascending id).  The exact kernel then runs for
+    the blocks of 256 queries the repair round listed again and for no other: the ranking of ALL queries is the oracle's, and
+    the stats say one block was listed again and the fallback ran.  (Seen at the configs[4] shape late in a run: one such user
+    among 100 000 sent the whole evaluation through the exact kernel, 445 ms instead of 87.)"""
+    rs = np.random.RandomState(5)
+    U, N, d, K = 1500, 4096 * 3, 64, 20
+    P = (rs.standard_normal((U, d)) * 0.5).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.5).astype(np.float32)
+    sig_i = (1.0 / (1.0 + np.exp(-rs.standard_normal(N)))).astype(np.float32)
+    sig_u = (1.0 / (1.0 + np.exp(-rs.standard_normal(U)))).astype(np.float32)
+    bad = 700                                               # in the third block of 256 queries
+    sig_u[bad] = 0.0
+    mask = random_mask(rs, U, N, 10)
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    stats = torch.zeros(2, dtype=torch.int32, device="cuda")
+    wv, wi, _ = oracle.score_topk(oracle.SCORE_RUBI_BOTH, P, Q, K, sig_u=sig_u, sig_i=sig_i, c=3.0, mask=oracle.csr_from_lists(mask))
+    v, ix = ops.score_topk(ops.SCORE_RUBI_BOTH, dev(P), None, dev(Q), K, dev(sig_u), dev(sig_i), 3.0, mask=mcsr, stats=stats)
+    val, idx, _ = ops.topk_merge(v, ix)
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    ok = np.arange(U) != bad
+    assert np.array_equal(val.cpu().numpy()[ok].view(np.uint32), wv[ok].view(np.uint32))
+    assert np.array_equal(val.cpu().numpy()[bad], wv[bad])          # (zeros of either sign)
+    unmasked = [x for x in range(N) if x not in set(mask[bad])][:K]
+    assert idx[bad].cpu().numpy().tolist() == unmasked      # every score of hers is +-0: ascending id decides
+    assert stats.cpu().numpy().tolist() == [1, 1]
+
+
 @pytest.mark.parametrize("L,hubs", [(1, False), (2, True), (3, True)])
 def test_lgcn_batch_row_sparse_layers_equal_dense_layers(ops, L, hubs):
     """The LightGCN step computes its last forward layer for the batch's rows only and gathers, in the first backward
