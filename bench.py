@@ -131,7 +131,10 @@ def bench_config4(args, rank, world, dev, emit=True):
                                        rank=rank, world=world,
                                        shards=(xavier_rows(own_u.n, n_users), xavier_rows(own_i.n, n_items), n_users, n_items),
                                        lazy_period=args.c4_lazy if args.c4_lazy > 0 else None)
-    n_batches = 32                  # (independent of --steps: same batches, same model, whatever the call)
+    # (independent of --steps: same batches, same model, whatever the call.  256 since round 5: regions long enough for the lazy
+    # optimizer pass's steady lag -- hundreds of steps -- revisited a pool of 32 batches twenty times, and the model memorised
+    # them to the point of users whose branch factor underflows to 0, i.e. whose scores all tie: the evaluator's exact kernel)
+    n_batches = 256
     batches = synth.train_batches(n_batches, n_users, n_items, B, gen_all, dev)
     sharding.broadcast_params([batches])      # ONE batch stream for the one model (the draws are seeded; this makes it a fact)
 

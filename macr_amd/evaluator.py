@@ -55,6 +55,11 @@ class Evaluator(object):
         # seeding policy: thresholds come from the previous ranking unless that went badly last time
         self._seeded_now = True                   # what the ranking about to be launched does (if it has seeds at all)
         self._seed_skip, self._seed_backoff = 0, 1
+        # filter policy (the same shape): a bf16-filter evaluation that ended in the exact kernel -- candidate lists overflowed in
+        # both rounds: scores packed tighter at the top than the filter's error bound resolves, e.g. a catalogue of a million
+        # barely trained items under c = 40 -- cost 2-3x an fp32-filter evaluation; the next 1, 2, 4 ... 16 evaluations take the
+        # fp32 filter before bf16 is tried again.  The ranking is the same either way.
+        self._bf16_skip, self._bf16_backoff = 0, 1
         self._stats = torch.zeros(2, dtype=torch.int32, device=device)          # macr_score_topk stats of the last ranking
         self._stats_host = torch.zeros(2, dtype=torch.int32)
         self._stats_first = torch.zeros(2, dtype=torch.int32)          # written by the first-round ranking's own kernel
@@ -134,7 +139,7 @@ class Evaluator(object):
             vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, mask, lo,
                                        seed=seed if seeded else None, seed_out=seed,
                                        stats=self._stats_first if mode else self._stats, first_round=mode == "first",
-                                       repair_of=self._repair_bufs if mode == "repair" else None, filter=self.filter)
+                                       repair_of=self._repair_bufs if mode == "repair" else None, filter=self.filter_now)
         else:
             # the ranking workspace (candidate lists, mask bitmap) grows with the number of queries: rank them in
             # chunks; every query is independent of the chunking
@@ -144,7 +149,7 @@ class Evaluator(object):
                 uid = user_ids[a:b] if user_ids is not None else torch.arange(a, b, dtype=torch.int32, device=self.device)
                 mask = self._mask_local if self._local_own is not None else self.mask
                 parts.append(ops.score_topk(kind, users_tab, uid, items_local, K, None if sig_u is None else sig_u[a:b],
-                                            sig_i, c, mask.row_range(a, b), lo, filter=self.filter))
+                                            sig_i, c, mask.row_range(a, b), lo, filter=self.filter_now))
             vals = torch.cat([p[0] for p in parts], dim=1)
             idx = torch.cat([p[1] for p in parts], dim=1)
         if self._local_own is not None:           # local row -> item id (the order by id within the shard is the same either way)
@@ -181,6 +186,11 @@ class Evaluator(object):
         else:
             self._seeded_now = True
         return self._seeded_now
+
+    @property
+    def filter_now(self):
+        """the candidate filter of the ranking about to be launched: `filter`, or "f32" while the bf16 filter is backed off"""
+        return "f32" if (self.filter == "bf16" and self._bf16_skip > 0) else self.filter
 
     def _relist_tolerance(self):
         """blocks of 256 queries a seeded ranking may list twice before the seeds count as stale: none up to 63 blocks (a repair
@@ -298,6 +308,23 @@ class Evaluator(object):
         seeded = (self.use_seeds and self._seed_skip == 0 and self._has_seeds(max(Ks), items_tab.shape[0]))
         if self.use_seeds and self._seed_skip > 0:
             self._seed_skip -= 1
+        used_bf16 = self.filter_now == "bf16"
+        try:
+            return self._means_optimistic_run(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, seeded)
+        finally:
+            info = getattr(self, "_last_info", None) or {}
+            if used_bf16:
+                if info.get("exact_fallback"):
+                    self._bf16_skip = self._bf16_backoff
+                    self._bf16_backoff = min(16, 2 * self._bf16_backoff)
+                elif not info.get("redone"):
+                    self._bf16_backoff = 1
+            elif self._bf16_skip > 0:
+                self._bf16_skip -= 1
+            if getattr(self, "_last_info", None) is not None:
+                self._last_info["filter"] = "bf16" if used_bf16 else ("f32" if self.filter == "bf16" else self.filter)
+
+    def _means_optimistic_run(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, seeded):
         self._seeded_now = seeded
         self._topk_mode = "first"
         try:
@@ -351,7 +378,7 @@ class Evaluator(object):
                 shape = (4, len(Ks)) if flavour == "mf" else (5 * max(Ks),)
                 self._host_out[hk] = torch.zeros(shape, dtype=torch.float64).pin_memory()
             host_out = self._host_out[hk]
-        key = (flavour, mode, self.filter, kind, seeded, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
+        key = (flavour, mode, self.filter_now, kind, seeded, users_tab.data_ptr(), None if user_ids is None else user_ids.data_ptr(), items_tab.data_ptr(),
                Ks, None if w is None else w.data_ptr(), None if wu is None else wu.data_ptr(),
                torch.cuda.current_stream().cuda_stream, world)
         entry = self._graphs.get(key)
