@@ -1065,8 +1065,13 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
         const bool own_ok = slot0 + q_own < B;
 #ifndef MACR_ABL_NOPART
         if (own_ok) {
+#ifdef MACR_ABL_TPART            // timing probe (wrong results): the partials read as if stored [t][2][16] -- one line per slot and array
+            for (int k = kk; k < nrb; k += 16) { dp += colpart[((size_t)t_own * 2) * 16 + (k & 15)]; dn += colpart[((size_t)t_own * 2 + 1) * 16 + (k & 15)]; }
+            for (int k = kk; k < ncb; k += 16) { da += rowpart[((size_t)t_own * 2) * 16 + (k & 15)]; db += rowpart[((size_t)t_own * 2 + 1) * 16 + (k & 15)]; }
+#else
             for (int k = kk; k < nrb; k += 16) { dp += colpart[((size_t)k * 2) * Bp + t_own]; dn += colpart[((size_t)k * 2 + 1) * Bp + t_own]; }
             for (int k = kk; k < ncb; k += 16) { da += rowpart[((size_t)k * 2) * Bp + t_own]; db += rowpart[((size_t)k * 2 + 1) * Bp + t_own]; }
+#endif
             if (kk < 3) ssi = fwd[(4 + kk) * (size_t)Bp + t_own];      // lane kk = 0,1,2: sig(si), sig(sj), sig(su)
         }
 #endif
