@@ -512,6 +512,10 @@ __global__ __launch_bounds__(256) void k_lazy_rows(long long n, const int32_t *_
 //   partials: l2 regulariser sum (:219), L_item (:213), L_user (:215) terms
 // fwd layout: 7 arrays of Bp floats: p, n, a, b, sig_si, sig_sj, sig_su  (Bp = padded B).
 // ----------------------------------------------------------------------------
+// Window of the (B,B) kernel's 4-transcendental form in y = n*b (see k_bxb): shared with pair_fwd, which flags the columns outside it
+constexpr float kBxbYHi = 6.0f, kBxbYLoPairs = -60.0f, kBxbYLoSingle = -20.0f;
+constexpr int kNeutralTileMax = 8;      // a 64-column tile with more flagged columns than this is not neutralised (its wave decides as before)
+
 // Tables the deferred-mode forward needs to see one update ahead (below).
 struct PendingAdam {
     const float *mU, *vU, *gU, *mI, *vI, *gI;      // slots and gradient sums of the user / item table
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
     const float *__restrict__ Usrc, const float *__restrict__ Isrc,
     const float *__restrict__ w, const float *__restrict__ wu,
     float *__restrict__ fwd, float *__restrict__ part, int reg_on_gathered, float *__restrict__ gw, PendingAdam pa,
-    int user_branch) {
+    int user_branch, float *__restrict__ outflag = nullptr) {
     constexpr int d = 4 * LPR;
     __shared__ float red[16];
     __shared__ float s_lr[PENDING == 2 ? kLazyRing : 1];
@@ -619,6 +623,9 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
             fwd[4 * (size_t)Bp + t] = ssi;
             fwd[5 * (size_t)Bp + t] = ssj;
             fwd[6 * (size_t)Bp + t] = ssu;
+            // column t of the (B,B) term outside the window of the 4-transcendental form whatever its row (a, b <= 1): k_bxb takes
+            // such columns out of the rotation (see "neutralised columns" there)
+            if (outflag) outflag[t] = (p < -20.0f || n > kBxbYHi || n < kBxbYLoPairs) ? 1.0f : 0.0f;
             litem = -logf(ssi + eps) + -logf((1.0f - ssj) + eps);
             luser = user_branch ? -logf(ssu + eps) + -logf((1.0f - ssu) + eps) : 0.0f;
         }
@@ -670,6 +677,10 @@ struct BatchSort {
     int B;
     int rb0;                            // (B,B) launch: first row block of the launch (row-sharded training), else 0
     int32_t *perm, *us, *is, *js;       // [B] each
+    // (B,B) blocks: neutralised columns (k_bxb).  outflag = pair_fwd's column flags (NULL: off), nneu = neutral blocks per row block,
+    // ncbx = ncb + nneu = row-sum slabs / loss partials per row block
+    const float *outflag;
+    int nneu, ncbx;
 };
 
 constexpr int kBucketSpan = 512;        // triples bucketed by one workgroup (independently of the other spans)
@@ -742,15 +753,92 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
     __shared__ float4 s_red[ADAM ? 256 : 1];
     __shared__ uint32_t s_hist[4 * kRadix + 4];
     const int nsort = (sort.B + kBucketSpan - 1) / kBucketSpan;
-    if ((int)blockIdx.x >= nbxb && (int)blockIdx.x < nbxb + nsort) {     // these blocks group the batch for pair_bwd
+    const int ncbx = sort.nneu ? sort.ncbx : ncb;      // row-sum slabs / loss partials per row block
+    const int nbn = sort.nneu * (nbxb / ncb);          // neutral blocks (below): nneu per row block of the launch
+    if ((int)blockIdx.x >= nbxb && (int)blockIdx.x < nbxb + nbn) {
+        // NEUTRAL BLOCK (rb, part): the exact form for the columns the rotation blocks took out (see there), against the rows of
+        // row block rb; flagged column number idx (in column order, over the neutralised tiles) belongs to wave
+        // idx mod (4 nneu) of the row block's nneu blocks.  Row sums and loss go to slab / partial ncb + part.
+        const int nb_idx = (int)blockIdx.x - nbxb, part = nb_idx % sort.nneu, rb = sort.rb0 + nb_idx / sort.nneu;
+        const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+        const float *p = fwd, *n = fwd + Bp, *a = fwd + 2 * (size_t)Bp, *b = fwd + 3 * (size_t)Bp;
+        const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+        const v2f one = {1.0f, 1.0f}, eps = {1e-10f, 1e-10f};
+        v2f abn[R], dabn[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = rb * RB + q * 64 + lane;
+            abn[q] = v2f{a[r], b[r]};
+            dabn[q] = v2f{0.f, 0.f};
+        }
+        float l2n = 0.f;
+        const int slot = part * 4 + wid, nslot = 4 * sort.nneu;
+        int idx = 0;
+        for (int base = 0; base < B; base += 1024) {            // 1024 columns per trip: lane l holds columns base + 16 l .. + 15 (4 x float4, all in flight)
+            const int at = base + 16 * lane;
+            uint32_t bits = 0;                                  // bit k: column at + k flagged
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 f4 = at < B ? ld4(sort.outflag + at + 4 * e) : make_float4(0, 0, 0, 0);
+                bits |= ((f4.x != 0.f ? 1u : 0u) | (f4.y != 0.f ? 2u : 0u) | (f4.z != 0.f ? 4u : 0u) | (f4.w != 0.f ? 8u : 0u)) << (4 * e);
+            }
+            int mine = __popc(bits);
+            const int pair2 = mine + __shfl_xor(mine, 1, 64);
+            const int tile = pair2 + __shfl_xor(pair2, 2, 64);             // sum over the 4 lanes of a 64-column tile
+            if (tile > kNeutralTileMax) mine = 0;               // (that tile's waves decide for themselves)
+            for (uint64_t hit = __ballot(mine != 0); hit; hit &= hit - 1) {
+                const int src = __builtin_ctzll(hit);
+                for (uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)bits, src); wv; wv &= wv - 1) {
+                    const int mine_now = idx++ % nslot == slot;
+                    if (!mine_now) continue;                    // (wave-uniform)
+                    const int cj = base + 16 * src + __builtin_ctz(wv);
+                    const v2f pn = {p[cj], n[cj]};
+                    v2f accj = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {
+                        const v2f z = pn * (abn[q] * (-kLog2e));
+                        const v2f dd = v2f{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + one;
+                        const v2f sg = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+                        const v2f om = one - sg;
+                        const v2f ts = sg + eps, tom = om + eps;
+                        const float txy = ts.x * tom.y;
+                        l2n += __builtin_amdgcn_logf(txy);
+                        const float r2 = __builtin_amdgcn_rcpf(txy);
+                        const v2f h = (sg * om) * r2;
+                        const v2f g = v2f{h.x * tom.y, h.y * ts.x};
+                        dabn[q] = __builtin_elementwise_fma(g, pn, dabn[q]);
+                        accj = __builtin_elementwise_fma(g, abn[q], accj);
+                    }
+                    const float sx = wave_sum(accj.x), sy = wave_sum(accj.y);
+                    if (lane == 0) {
+                        colpart[((size_t)rb * 2 + 0) * Bp + cj] = -sx;
+                        colpart[((size_t)rb * 2 + 1) * Bp + cj] = sy;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            s_row[wid][0][q * 64 + lane] = -dabn[q].x;
+            s_row[wid][1][q * 64 + lane] = dabn[q].y;
+        }
+        const float lsum = block_sum(-l2n * kLn2, red);
+        if (t == 0) lpart[(size_t)rb * ncbx + ncb + part] = lsum;
+        for (int e = t; e < 2 * RB; e += 256) {
+            const int q = e / RB, rr = e % RB, r = rb * RB + rr;
+            rowpart[((size_t)(ncb + part) * 2 + q) * Bp + r] = (s_row[0][q][rr] + s_row[1][q][rr]) + (s_row[2][q][rr] + s_row[3][q][rr]);
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= nbxb + nbn && (int)blockIdx.x < nbxb + nbn + nsort) {     // these blocks group the batch for pair_bwd
         __builtin_amdgcn_s_setprio(3);         // a chain of latencies beside VALU-bound waves: go first when ready
 #ifndef MACR_ABL_NOGROUP
-        batch_bucket_block<4>(sort, blockIdx.x - nbxb, s_hist);
+        batch_bucket_block<4>(sort, blockIdx.x - nbxb - nbn, s_hist);
 #endif
         return;
     }
-    const bool is_adam = ADAM && (int)blockIdx.x >= nbxb + nsort;
-    const int ablk = blockIdx.x - nbxb - nsort, bblk = blockIdx.x;
+    const bool is_adam = ADAM && (int)blockIdx.x >= nbxb + nbn + nsort;
+    const int ablk = blockIdx.x - nbxb - nbn - nsort, bblk = blockIdx.x;
     if (is_adam) {
         // the bxb waves are older and would win every issue slot: the Adam waves (a handful of VALU instructions
         // between long memory waits) go first whenever they are ready
@@ -778,6 +866,21 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
     const int c = cb * 256 + wid * 64 + lane;  // the column this lane is home to
     const bool cok = FULL || c < B;
     v2f cn = {cok ? p[c] : 0.f, cok ? n[c] : 0.f};
+    // NEUTRALISED COLUMNS (sort.nneu: full batches).  One column outside the window of the 4-transcendental form (below) sends its
+    // whole 64-column tile through the exact form (1.24x the time); a model a few hundred steps old has 0.1-1 % of them
+    // (negatives scoring above 6), almost half of its tiles hold one -- and at one wave per SIMD the launch lasts as long as
+    // its slowest wave.  So a column that pair_fwd flagged (outside the window for ANY row) rotates as (p, n) = (0, 0): its
+    // contributions to the row sums are g * 0 = 0 exactly, its own column sums are dropped, and each of its evaluations adds
+    // exactly log2(1/2 * 1/2) = -2 to the loss sum, which is taken back below.  The flagged columns are evaluated by the exact
+    // form in the launch's NEUTRAL BLOCKS (above): a few (column, R rows) evaluations per wave there instead of 64 R exact
+    // ones here.  A tile with more than kNeutralTileMax flagged columns stays as it is (a saturated model: no cliff).
+    bool own_out = false;
+    if (FULL && sort.nneu) {
+        own_out = sort.outflag[c] != 0.f;
+        const int lw = (int)__popcll(__ballot(own_out));
+        if (lw > kNeutralTileMax) own_out = false;
+        if (own_out) cn = v2f{0.f, 0.f};
+    }
     v2f acc = {0.f, 0.f}, l2 = {0.f, 0.f};     // column sums travelling with cn; log2 terms (scaled by ln2 at the end)
     // Two forms of the pair arithmetic.  EXACT follows the reference operation by operation: s = 1/(1+e^-z), then
     // s+eps and (1-s)+eps with 1-s by subtraction (6 transcendentals with the shared log/rcp of tx*ty).  FAST works
@@ -920,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
     // YHI: above it the reference's own rounding is what the exact form reproduces -- fl(1 - fl(sig(y))) is off by up to
     // 3e-8 (1 + e^y) relative, which is this form's distance from it: <= 1.2e-5 of a term that is >= 6 at y = 6, i.e.
     // <= 2e-6 relative on a loss that is a sum of positive terms (tolerance 1e-5); 2e-7 at y = 3, 1.1e-5 at y = 8.
-    constexpr float YLO = R >= 2 ? -60.0f : -20.0f, YHI = 6.0f;
+    constexpr float YLO = R >= 2 ? kBxbYLoPairs : kBxbYLoSingle, YHI = kBxbYHi;
     const float xlo = cn.x * amax, yv = cn.y * bmax;
     const bool fast = !__any(!(xlo >= -20.0f) || !(yv >= YLO) || !(yv <= YHI) || !(amax <= 1.0f) || !(bmax <= 1.0f));   // (NaN -> exact path)
 #endif
@@ -929,7 +1032,8 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
     } else {
         run_tile(std::false_type{});
     }
-    if (cok) {                                  // home again: column c over this wave's 64*R rows
+    if (FULL && sort.nneu) l2.x += 2.0f * (float)(R * (int)__popcll(__ballot(own_out)));     // the neutral evaluations of this lane: -2 each
+    if (cok && !own_out) {                      // home again: column c over this wave's 64*R rows
         colpart[((size_t)rb * 2 + 0) * Bp + c] = -acc.x;
         colpart[((size_t)rb * 2 + 1) * Bp + c] = acc.y;
     }
@@ -939,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
         s_row[wid][1][q * 64 + lane] = dab[q].y;
     }
     const float lsum = block_sum(-(l2.x + l2.y) * kLn2, red);   // contains the barrier that publishes s_row
-    if (t == 0) lpart[(size_t)rb * ncb + cb] = lsum;
+    if (t == 0) lpart[(size_t)rb * ncbx + cb] = lsum;
     for (int e = t; e < 2 * RB; e += 256) {
         const int q = e / RB, rr = e % RB, r = rb * RB + rr;
         if (FULL || r < B)
@@ -1014,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
     const float *__restrict__ rowpart, const float *__restrict__ colpart,
     float *gU, float *gI, int32_t *touchedU, int32_t *touchedI, float *__restrict__ wpart,
     float alpha, float beta, float coef, float *adam_pow, StepScalars *scal, float lr, float b1, float b2,
-    LossArgs L, int32_t *cnt_pos, LazyState *lazy = nullptr) {
+    LossArgs L, int32_t *cnt_pos, LazyState *lazy = nullptr, int nneu = 0) {
     constexpr int EPL = WaveRow<D>::EPL;
     __shared__ float s_w[4][2][D];
     __shared__ float s_gi[kChunkT][D];
@@ -1070,7 +1174,12 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
             for (int k = kk; k < ncb; k += 16) { da += rowpart[((size_t)t_own * 2) * 16 + (k & 15)]; db += rowpart[((size_t)t_own * 2 + 1) * 16 + (k & 15)]; }
 #else
             for (int k = kk; k < nrb; k += 16) { dp += colpart[((size_t)k * 2) * Bp + t_own]; dn += colpart[((size_t)k * 2 + 1) * Bp + t_own]; }
+            // (the neutral blocks' slab of row sums -- k_bxb -- is loaded AHEAD of the loop: as slab number ncb of the loop it was a
+            // second dependent trip for the lanes with kk = 0)
+            float dan = 0.f, dbn = 0.f;
+            if (kk < nneu) { dan = rowpart[((size_t)(ncb + kk) * 2) * Bp + t_own]; dbn = rowpart[((size_t)(ncb + kk) * 2 + 1) * Bp + t_own]; }
             for (int k = kk; k < ncb; k += 16) { da += rowpart[((size_t)k * 2) * Bp + t_own]; db += rowpart[((size_t)k * 2 + 1) * Bp + t_own]; }
+            da += dan; db += dbn;
 #endif
             if (kk < 3) ssi = fwd[(4 + kk) * (size_t)Bp + t_own];      // lane kk = 0,1,2: sig(si), sig(sj), sig(su)
         }
@@ -1284,7 +1393,8 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
     const float *__restrict__ w, const float *__restrict__ wu, const float *__restrict__ fwd,
     const float *__restrict__ rowpart, const float *__restrict__ colpart, float *__restrict__ stage,
     float *__restrict__ wpart, float alpha, float beta, float coef, float *adam_pow, StepScalars *scal, float lr,
-    float b1, float b2, LossArgs L, const uint32_t *__restrict__ place = nullptr, int Bnorm = 0, LazyState *lazy = nullptr) {
+    float b1, float b2, LossArgs L, const uint32_t *__restrict__ place = nullptr, int Bnorm = 0, LazyState *lazy = nullptr,
+    int nneu = 0) {
     // Bnorm > 0: the launch covers a SLICE of a batch of Bnorm triples (row-sharded training, macr_shard_backward_slice): u/i/j,
     // fwd, rowpart and colpart arrive offset to the slice, B is its length, the means are taken over the whole batch
     constexpr int d = 4 * LPR, RPB = RowGroup<LPR>::kRowsPerBlock;
@@ -1312,7 +1422,10 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
         if (t >= B) continue;
         float dp = 0.f, dn = 0.f, da = 0.f, db = 0.f;
         for (int k = g.sub; k < nrb; k += LPR) { dp += colpart[((size_t)k * 2) * Bp + t]; dn += colpart[((size_t)k * 2 + 1) * Bp + t]; }
+        float dan = 0.f, dbn = 0.f;                 // (the neutral blocks' slab: see k_pair_bwd)
+        if (g.sub < nneu) { dan = rowpart[((size_t)(ncb + g.sub) * 2) * Bp + t]; dbn = rowpart[((size_t)(ncb + g.sub) * 2 + 1) * Bp + t]; }
         for (int k = g.sub; k < ncb; k += LPR) { da += rowpart[((size_t)k * 2) * Bp + t]; db += rowpart[((size_t)k * 2 + 1) * Bp + t]; }
+        da += dan; db += dbn;
         dp = group_sum<LPR>(dp) * inv_b2; dn = group_sum<LPR>(dn) * inv_b2;
         da = group_sum<LPR>(da) * inv_b2; db = group_sum<LPR>(db) * inv_b2;
         const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
@@ -1618,12 +1731,14 @@ struct PairWs {
     float *stage;                            // staged: [3][B][d] gradient rows in batch order
     int nblk_bwd;
     float *fwd;         // [7*Bp]
+    float *outflag;     // [Bp] (1.0 / 0.0) column outside the window of the (B,B) kernel's 4-transcendental form (pair_fwd -> k_bxb)
     float *part;        // [nblk_pair*4]
     float *part2;       // [nblk_pair*4]   (LightGCN ego regulariser)
     float *lpart;       // [nrb*ncb]
     float *rowpart;     // [ncb*2*Bp]
     float *colpart;     // [nrb*2*Bp]
     int Bp, nrb, ncb, rows, nblk_pair;
+    int nneu, ncbx;     // neutral blocks per row block of the (B,B) launch (0: off); ncbx = ncb + nneu row-sum slabs / loss partials per row block
     size_t bytes;
 };
 
@@ -1634,6 +1749,9 @@ static PairWs carve_pair_ws(void *base, int B, int d, bool force_staged = false)
     w.rows = bxb_rows(B);
     w.nrb = w.Bp / (64 * w.rows);
     w.ncb = w.Bp / 256;
+    static const bool no_neutral = getenv("MACR_BXB_NEUTRAL") && getenv("MACR_BXB_NEUTRAL")[0] == '0';      // A/B switch
+    w.nneu = (!force_staged && B % 256 == 0 && !no_neutral) ? 1 : 0;     // (full batches; the row-sharded step keeps the plain launch)
+    w.ncbx = w.ncb + w.nneu;
     w.nblk_pair = (B + rpb - 1) / rpb;
     w.staged = force_staged || use_staging(B);
     if (w.staged) w.nblk_bwd = w.nblk_pair < 4096 ? w.nblk_pair : 4096;                      // grid-strided row groups
@@ -1644,14 +1762,15 @@ static PairWs carve_pair_ws(void *base, int B, int d, bool force_staged = false)
     w.scal = static_cast<StepScalars *>(take(sizeof(StepScalars)));
     w.gw = static_cast<float *>(take((size_t)kBranchSlots * 2 * d * 4));
     w.fwd = static_cast<float *>(take((size_t)7 * w.Bp * 4));
+    w.outflag = static_cast<float *>(take((size_t)w.Bp * 4));
     // (the loss-only normalbce pass launches min(ceil(B / kChunkT), 1024) blocks whatever path the workspace is carved for)
     const int nblk_loss = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;
     int npart = w.nblk_pair > w.nblk_bwd ? w.nblk_pair : w.nblk_bwd;
     npart = npart > nblk_loss ? npart : nblk_loss;
     w.part = static_cast<float *>(take((size_t)npart * kPartStride * 4));
     w.part2 = static_cast<float *>(take((size_t)npart * kPartStride * 4));
-    w.lpart = static_cast<float *>(take((size_t)w.nrb * w.ncb * 4));
-    w.rowpart = static_cast<float *>(take((size_t)w.ncb * 2 * w.Bp * 4));
+    w.lpart = static_cast<float *>(take((size_t)w.nrb * w.ncbx * 4));
+    w.rowpart = static_cast<float *>(take((size_t)w.ncbx * 2 * w.Bp * 4));
     w.colpart = static_cast<float *>(take((size_t)w.nrb * 2 * w.Bp * 4));
     const size_t nsort = 3 * (size_t)B;
     w.ska = w.sva = w.skb = w.svb = nullptr;
@@ -1674,7 +1793,7 @@ static PairWs carve_pair_ws(void *base, int B, int d, bool force_staged = false)
 template <int R>
 static void launch_bxb_rows(const PairWs &ws, int B, const AdamArgs *pending, long long n_adam_blocks,
                             const BatchSort &sort, hipStream_t st) {
-    const int nbxb = ws.ncb * ws.nrb, nsort = (sort.B + kBucketSpan - 1) / kBucketSpan;
+    const int nbxb = ws.ncb * ws.nrb, nsort = (sort.B + kBucketSpan - 1) / kBucketSpan + sort.nneu * ws.nrb;    // (+ the neutral blocks)
     const bool full = B % 256 == 0;
 #ifdef MACR_ABL_XNOADAM
     n_adam_blocks = 0;                 // timing probe: the ADAM instantiation of the kernel without any Adam block (wrong results)
@@ -1699,6 +1818,7 @@ static BatchSort batch_sort_args(const PairWs &ws, int B, const int32_t *u, cons
     BatchSort s;
     s.u = u; s.i = i; s.j = j; s.B = B; s.rb0 = 0;
     s.perm = ws.perm; s.us = ws.us; s.is = ws.is; s.js = ws.js;
+    s.outflag = nullptr; s.nneu = 0; s.ncbx = ws.ncb;
     return s;
 }
 
@@ -1760,6 +1880,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
     const int user_branch = kind == MACR_LOSS_RUBIBCEBOTH;
     BatchSort sort = batch_sort_args(ws, B, u, i, j);
     if (ws.staged || loss_only) sort.B = 0;
+    sort.outflag = ws.outflag; sort.nneu = ws.nneu; sort.ncbx = ws.ncbx;      // neutralised columns of the (B,B) launch (pair_fwd flags them)
     if (kind == MACR_LOSS_NORMALBCE && loss_only) {            // forward of the per-pair loss, nothing written but partials
         const int nb = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;
         MACR_DISPATCH_D(d, (k_pair_normal<D><<<nb, 256, 0, st>>>(B, u, i, j, Usrc, Isrc, nullptr, nullptr, nullptr, nullptr,
@@ -1801,14 +1922,14 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
     }
     if (pa && pa->lazy) {
         MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 2><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch)));
+                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch, ws.outflag)));
     } else if (pa) {
         MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 1><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch)));
+                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch, ws.outflag)));
     } else {
         PendingAdam none = {};
         MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 0><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                      ws.part, reg_on_gathered, ws.gw, none, user_branch)));
+                                                                      ws.part, reg_on_gathered, ws.gw, none, user_branch, ws.outflag)));
     }
     MACR_CHECK_LAUNCH("pair_fwd", st);
     switch (ws.rows) {
@@ -1824,7 +1945,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
         MACR_DISPATCH_LPR(d, (k_pair_bwd_stage<LPR><<<ws.nblk_bwd + 1, 256, 0, st>>>(
                                  B, ws.Bp, ws.nrb, ws.ncb, u, i, j, Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, ws.stage,
                                  ws.gw, hp->alpha, hp->beta, coef, adam_pow, ws.scal, hp->lr, hp->beta1, hp->beta2, L,
-                                 listed ? rs.free_val : nullptr, 0, tick)));
+                                 listed ? rs.free_val : nullptr, 0, tick, ws.nneu)));
         MACR_CHECK_LAUNCH("pair_bwd", st);
         if (listed) return launch_seg_index(B, d, n_urows, n_irows, rs, true, gU, gI, tU, tI, ws, st);
         return launch_ref_sort_reduce(B, d, n_urows, n_irows, u, i, j, gU, gI, tU, tI, ws, st, sv_sorted);
@@ -1832,7 +1953,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
     MACR_DISPATCH_D(d, (k_pair_bwd<D><<<ws.nblk_bwd + 1, 256, 0, st>>>(B, ws.Bp, ws.nrb, ws.ncb, ws.perm, ws.us, ws.is, ws.js,
                                                                       Usrc, Isrc, w, wu, ws.fwd, ws.rowpart, ws.colpart, gU,
                                                                       gI, tU, tI, ws.gw, hp->alpha, hp->beta, coef, adam_pow,
-                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2, L, cnt_pos, tick)));
+                                                                      ws.scal, hp->lr, hp->beta1, hp->beta2, L, cnt_pos, tick, ws.nneu)));
     MACR_CHECK_LAUNCH("pair_bwd", st);
     return MACR_OK;
 }
@@ -1948,7 +2069,7 @@ static int mf_train_step(int loss_kind, int B, int d, int n_users, int n_items, 
     LossArgs L;
     L.part = ws.part; L.n_part = rubi ? ws.nblk_pair : ws.nblk_bwd;
     L.part2 = nullptr; L.n_part2 = 0;
-    L.lpart = ws.lpart; L.n_lpart = rubi ? ws.nrb * ws.ncb : 0;
+    L.lpart = ws.lpart; L.n_lpart = rubi ? ws.nrb * ws.ncbx : 0;
     L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
     L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
     AdamArgs a;
@@ -2291,7 +2412,7 @@ extern "C" int macr_shard_backward(int loss_kind, int B, int d, const float *row
     MACR_SHARD_COMMON("shard_backward");
     LossArgs L;
     L.part = ws.part; L.n_part = ws.nblk_pair; L.part2 = nullptr; L.n_part2 = 0;
-    L.lpart = ws.lpart; L.n_lpart = ws.nrb * ws.ncb;
+    L.lpart = ws.lpart; L.n_lpart = ws.nrb * ws.ncbx;
     L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
     L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
     const float coef = hp->decay / (float)hp->batch_size_cfg;
@@ -2377,7 +2498,7 @@ extern "C" int macr_shard_backward_slice(int loss_kind, int B, int d, int t0, in
     MACR_SHARD_COMMON("shard_backward_slice");
     LossArgs L;
     L.part = ws.part; L.n_part = ws.nblk_pair; L.part2 = nullptr; L.n_part2 = 0;      // (every rank's blocks were summed index by index)
-    L.lpart = ws.lpart; L.n_lpart = ws.nrb * ws.ncb;
+    L.lpart = ws.lpart; L.n_lpart = ws.nrb * ws.ncbx;
     L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
     L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
     const float coef = hp->decay / (float)hp->batch_size_cfg;
@@ -2604,7 +2725,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     LossArgs L;
     L.part = ws.pair.part;
     L.part2 = ws.pair.part2; L.n_part2 = ws.pair.nblk_bwd;
-    L.lpart = ws.pair.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.pair.nrb * ws.pair.ncb : 0;
+    L.lpart = ws.pair.lpart; L.n_lpart = loss_kind == MACR_LOSS_RUBIBCEBOTH ? ws.pair.nrb * ws.pair.ncbx : 0;
     L.kind = loss_kind; L.B = B; L.batch_size_cfg = hp->batch_size_cfg;
     L.alpha = hp->alpha; L.beta = hp->beta; L.decay = hp->decay; L.losses = losses;
     const float coef = hp->decay / (float)hp->batch_size_cfg;

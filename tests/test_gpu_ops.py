@@ -173,6 +173,42 @@ def test_mf_rubibceboth_large_logits(ops, scale, B):
     np.testing.assert_allclose(state.mwu.cpu().numpy(), st.m[3], rtol=5e-4, atol=2e-6 * np.abs(st.m[3]).max())
 
 
+@pytest.mark.parametrize("B,d", [(512, 32), (1024, 64), (4096, 64), (4096, 128)])
+def test_mf_rubibceboth_a_few_columns_outside_the_window(ops, B, d):
+    """Full batches (B % 256 == 0): columns outside the window of the (B,B) kernel's 4-transcendental form are taken out of
+    the rotation and evaluated by the exact form in the launch's neutral blocks (k_bxb).  A tame batch with a handful of
+    extreme columns -- negatives scoring +25 and -70, a positive scoring -40, ten of them inside one 64-column tile (more than
+    a tile neutralises) -- must follow the oracle like any other: loss 1e-5, gradients of every row."""
+    n_users, n_items = max(6000, 2 * B), max(5000, 3 * B)
+    rs = np.random.RandomState(B + d)
+    P = (rs.standard_normal((n_users, d)) * 0.25).astype(np.float32)
+    Q = (rs.standard_normal((n_items, d)) * 0.25).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    u = rs.choice(n_users, B, replace=False).astype(np.int32)
+    ij = rs.choice(n_items, 2 * B, replace=False).astype(np.int32)
+    i, j = ij[:B].copy(), ij[B:].copy()
+    def aim(row, target, at):                       # make row . P[u[at]] = target
+        pu = P[u[at]]
+        row += (target - float(row @ pu)) * pu / float(pu @ pu)
+    for at, tgt in ((3, 25.0), (70, -70.0), (200, 9.0), (B - 1, 30.0)):
+        aim(Q[j[at]], tgt, at)
+    aim(Q[i[130]], -40.0, 130)
+    for at in range(256, 266):                      # ten extreme columns in ONE tile
+        aim(Q[j[at]], 12.0 + at % 5, at)
+    alpha, beta, decay, lr, bs = 1e-2, 1e-3, 1e-5, 1e-3, 1024
+    st = oracle.AdamState([P.shape, Q.shape, (d,), (d,)])
+    Po, Qo, wo, wuo = P.copy(), Q.copy(), w.copy(), wu.copy()
+    state = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), ops.make_hyper(lr, decay, alpha, beta, bs), B)
+    want = oracle.mf_train_step(oracle.LOSS_RUBIBCEBOTH, u, i, j, Po, Qo, wo, wuo, st, lr, decay, alpha, beta, bs)
+    got = state.step(oracle.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+    for name, gm, om in (("P", state.mP, st.m[0]), ("Q", state.mQ, st.m[1])):
+        g_hip, g_orc = gm.cpu().numpy() / 0.1, om / 0.1
+        np.testing.assert_allclose(g_hip, g_orc, rtol=5e-4, atol=2e-6 * np.abs(g_orc).max(), err_msg=name)
+    np.testing.assert_allclose(state.mw.cpu().numpy(), st.m[2], rtol=5e-4, atol=2e-6 * np.abs(st.m[2]).max())
+    np.testing.assert_allclose(state.mwu.cpu().numpy(), st.m[3], rtol=5e-4, atol=2e-6 * np.abs(st.m[3]).max())
+
+
 @pytest.mark.parametrize("B,d,n_users,n_items,sort", [(96, 64, 300, 50, False), (257, 64, 300, 50, True),
                                                       (1024, 64, 13485, 744, True), (64, 32, 100, 40, True),
                                                       (128, 128, 500, 300, False), (64, 256, 100, 40, True),
