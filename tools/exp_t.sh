@@ -1,2 +1,4 @@
-timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -k "outside_the_window or large_logits" 2>&1 | tail -6
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+bash tools/final_bench.sh > gpurun_out/final_bench.log 2>&1
+bash tools/round_profiles.sh > gpurun_out/round_profiles.log 2>&1
+python -c "
+import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
