@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
     const float *__restrict__ Usrc, const float *__restrict__ Isrc,
     const float *__restrict__ w, const float *__restrict__ wu,
     float *__restrict__ fwd, float *__restrict__ part, int reg_on_gathered, float *__restrict__ gw, PendingAdam pa,
-    int user_branch, float *__restrict__ outflag = nullptr) {
+    int user_branch) {
     constexpr int d = 4 * LPR;
     __shared__ float red[16];
     __shared__ float s_lr[PENDING == 2 ? kLazyRing : 1];
@@ -622,10 +622,10 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
             fwd[3 * (size_t)Bp + t] = ssj * ssu;
             fwd[4 * (size_t)Bp + t] = ssi;
             fwd[5 * (size_t)Bp + t] = ssj;
-            fwd[6 * (size_t)Bp + t] = ssu;
-            // column t of the (B,B) term outside the window of the 4-transcendental form whatever its row (a, b <= 1): k_bxb takes
-            // such columns out of the rotation (see "neutralised columns" there)
-            if (outflag) outflag[t] = (p < -20.0f || n > kBxbYHi || n < kBxbYLoPairs) ? 1.0f : 0.0f;
+            // The SIGN of the stored sig(su) (a value in [0, 1]; its readers take fabsf) flags column t of the (B,B) term as outside
+            // the window of the 4-transcendental form whatever its row (a, b <= 1): k_bxb takes such columns out of the rotation
+            // (see "neutralised columns" there).  An array of its own cost pair_fwd 0.5 us for the extra store.
+            fwd[6 * (size_t)Bp + t] = (p < -20.0f || n > kBxbYHi || n < kBxbYLoPairs) ? -ssu : ssu;
             litem = -logf(ssi + eps) + -logf((1.0f - ssj) + eps);
             luser = user_branch ? -logf(ssu + eps) + -logf((1.0f - ssu) + eps) : 0.0f;
         }
@@ -677,7 +677,7 @@ struct BatchSort {
     int B;
     int rb0;                            // (B,B) launch: first row block of the launch (row-sharded training), else 0
     int32_t *perm, *us, *is, *js;       // [B] each
-    // (B,B) blocks: neutralised columns (k_bxb).  outflag = pair_fwd's column flags (NULL: off), nneu = neutral blocks per row block,
+    // (B,B) blocks: neutralised columns (k_bxb).  outflag = pair_fwd's column flags = the SIGNS of fwd[6] (NULL: off), nneu = neutral blocks per row block,
     // ncbx = ncb + nneu = row-sum slabs / loss partials per row block
     const float *outflag;
     int nneu, ncbx;
@@ -780,7 +780,8 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float4 f4 = at < B ? ld4(sort.outflag + at + 4 * e) : make_float4(0, 0, 0, 0);
-                bits |= ((f4.x != 0.f ? 1u : 0u) | (f4.y != 0.f ? 2u : 0u) | (f4.z != 0.f ? 4u : 0u) | (f4.w != 0.f ? 8u : 0u)) << (4 * e);
+                bits |= ((__float_as_uint(f4.x) >> 31) | ((__float_as_uint(f4.y) >> 31) << 1) | ((__float_as_uint(f4.z) >> 31) << 2) |
+                         ((__float_as_uint(f4.w) >> 31) << 3)) << (4 * e);
             }
             int mine = __popc(bits);
             const int pair2 = mine + __shfl_xor(mine, 1, 64);
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, c
     // ones here.  A tile with more than kNeutralTileMax flagged columns stays as it is (a saturated model: no cliff).
     bool own_out = false;
     if (FULL && sort.nneu) {
-        own_out = sort.outflag[c] != 0.f;
+        own_out = (__float_as_uint(sort.outflag[c]) >> 31) != 0u;
         const int lw = (int)__popcll(__ballot(own_out));
         if (lw > kNeutralTileMax) own_out = false;
         if (own_out) cn = v2f{0.f, 0.f};
@@ -1181,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
             for (int k = kk; k < ncb; k += 16) { da += rowpart[((size_t)k * 2) * Bp + t_own]; db += rowpart[((size_t)k * 2 + 1) * Bp + t_own]; }
             da += dan; db += dbn;
 #endif
-            if (kk < 3) ssi = fwd[(4 + kk) * (size_t)Bp + t_own];      // lane kk = 0,1,2: sig(si), sig(sj), sig(su)
+            if (kk < 3) ssi = fabsf(fwd[(4 + kk) * (size_t)Bp + t_own]);      // lane kk = 0,1,2: sig(si), sig(sj), |sig(su)| (its sign: a flag of pair_fwd)
         }
 #endif
 #pragma unroll
@@ -1428,7 +1429,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_stage(
         da += dan; db += dbn;
         dp = group_sum<LPR>(dp) * inv_b2; dn = group_sum<LPR>(dn) * inv_b2;
         da = group_sum<LPR>(da) * inv_b2; db = group_sum<LPR>(db) * inv_b2;
-        const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fwd[6 * (size_t)Bp + t];
+        const float ssi = fwd[4 * (size_t)Bp + t], ssj = fwd[5 * (size_t)Bp + t], ssu = fabsf(fwd[6 * (size_t)Bp + t]);    // (the sign: a flag of pair_fwd)
         const float dsi = da * (ssi * (1.0f - ssi)) * ssu + (alpha * invB) * dneglog_sig(ssi, eps);
         const float dsj = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
         const float dsu = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
@@ -1731,7 +1732,6 @@ struct PairWs {
     float *stage;                            // staged: [3][B][d] gradient rows in batch order
     int nblk_bwd;
     float *fwd;         // [7*Bp]
-    float *outflag;     // [Bp] (1.0 / 0.0) column outside the window of the (B,B) kernel's 4-transcendental form (pair_fwd -> k_bxb)
     float *part;        // [nblk_pair*4]
     float *part2;       // [nblk_pair*4]   (LightGCN ego regulariser)
     float *lpart;       // [nrb*ncb]
@@ -1762,7 +1762,6 @@ static PairWs carve_pair_ws(void *base, int B, int d, bool force_staged = false)
     w.scal = static_cast<StepScalars *>(take(sizeof(StepScalars)));
     w.gw = static_cast<float *>(take((size_t)kBranchSlots * 2 * d * 4));
     w.fwd = static_cast<float *>(take((size_t)7 * w.Bp * 4));
-    w.outflag = static_cast<float *>(take((size_t)w.Bp * 4));
     // (the loss-only normalbce pass launches min(ceil(B / kChunkT), 1024) blocks whatever path the workspace is carved for)
     const int nblk_loss = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;
     int npart = w.nblk_pair > w.nblk_bwd ? w.nblk_pair : w.nblk_bwd;
@@ -1880,7 +1879,7 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
     const int user_branch = kind == MACR_LOSS_RUBIBCEBOTH;
     BatchSort sort = batch_sort_args(ws, B, u, i, j);
     if (ws.staged || loss_only) sort.B = 0;
-    sort.outflag = ws.outflag; sort.nneu = ws.nneu; sort.ncbx = ws.ncbx;      // neutralised columns of the (B,B) launch (pair_fwd flags them)
+    sort.outflag = ws.fwd + 6 * (size_t)ws.Bp; sort.nneu = ws.nneu; sort.ncbx = ws.ncbx;      // neutralised columns of the (B,B) launch (pair_fwd flags them)
     if (kind == MACR_LOSS_NORMALBCE && loss_only) {            // forward of the per-pair loss, nothing written but partials
         const int nb = (B + kChunkT - 1) / kChunkT < 1024 ? (B + kChunkT - 1) / kChunkT : 1024;
         MACR_DISPATCH_D(d, (k_pair_normal<D><<<nb, 256, 0, st>>>(B, u, i, j, Usrc, Isrc, nullptr, nullptr, nullptr, nullptr,
@@ -1922,14 +1921,14 @@ static int launch_pair(int kind, int B, int d, int n_urows, int n_irows, const i
     }
     if (pa && pa->lazy) {
         MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 2><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch, ws.outflag)));
+                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch)));
     } else if (pa) {
         MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 1><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch, ws.outflag)));
+                                                                      ws.part, reg_on_gathered, ws.gw, *pa, user_branch)));
     } else {
         PendingAdam none = {};
         MACR_DISPATCH_LPR(d, (k_pair_fwd<LPR, 0><<<grid, 256, 0, st>>>(B, ws.Bp, u, i, j, Usrc, Isrc, w, wu, ws.fwd,
-                                                                      ws.part, reg_on_gathered, ws.gw, none, user_branch, ws.outflag)));
+                                                                      ws.part, reg_on_gathered, ws.gw, none, user_branch)));
     }
     MACR_CHECK_LAUNCH("pair_fwd", st);
     switch (ws.rows) {
