@@ -1,4 +1,1 @@
-bash tools/final_bench.sh > gpurun_out/final_bench.log 2>&1
-bash tools/round_profiles.sh > gpurun_out/round_profiles.log 2>&1
-python -c "
-import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+bash tools/ab_step.sh gpurun_out/r05_ab_lazy_mf2.txt "MACR_LAZY_ADAM_MF=1" "MACR_LAZY_ADAM_MF=2" "MACR_LAZY_ADAM_MF=3" "MACR_LAZY_ADAM_MF=4"
