@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     11
+#define MACR_ABI_VERSION     12
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -472,6 +472,9 @@ size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
 #define MACR_EVAL_FILTER_ENV  0
 #define MACR_EVAL_FILTER_F32  1
 #define MACR_EVAL_FILTER_BF16 2
+/* OR into `filter` of macr_score_topk / macr_score_topk_first_round (abi 12): the head of `workspace` was initialised by
+ * macr_score_topk_prologue for exactly this call, which then launches no initialisation of its own. */
+#define MACR_EVAL_WS_READY    0x100
 
 int macr_score_topk(int score_kind, int filter, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
@@ -507,6 +510,17 @@ int macr_score_topk_repair_round(int score_kind, int filter, int U, int n_local,
                     int item_offset, int K, int n_splits, const int32_t *seed_idx, int32_t *seed_out,
                     float *out_val, int32_t *out_idx, int32_t *stats,
                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* What an evaluation of the two-branch scores launches before its ranking, as ONE launch (abi 12): the branch factors
+ * sig_i[n_local] = sigmoid(items . w_item) and, when sig_u is given, sig_u[U] = sigmoid(users_tab[user_ids] . w_user)
+ * (macr_mf/model.py:141-142,:199-201; macr_branch_sigmoid's arithmetic, bit for bit), and the initialisation of the head of
+ * `workspace` that macr_score_topk(_first_round) would start with.  filter, U, n_local, d, K as in the ranking call that
+ * follows on the same stream with MACR_EVAL_WS_READY in its filter; seeded_first_round != 0: that call is
+ * macr_score_topk_first_round with seed_idx != NULL.  sig_u, w_user may both be NULL (one-branch scores). */
+int macr_score_topk_prologue(int filter, int U, int n_local, int d, int K, int seeded_first_round,
+                             const float *items, const float *w_item, float *sig_i,
+                             const float *users_tab, const int32_t *user_ids, const float *w_user, float *sig_u,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * The same ranking for SEVERAL values of c at once -- the c sweep of the tuners
@@ -610,6 +624,19 @@ int macr_metrics_foldout_fill(int U, int K, const int32_t *rankings, const int32
 int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const int32_t *cnt,
                     const int32_t *gt_ptr, const int32_t *gt_idx,
                     const int32_t *Ks /*host*/, int nK, double *out, void *stream);
+
+/* macr_metrics_mf and the means over the query users in ONE launch (abi 12): what macr_metrics_mf followed by macr_colmean
+ * returns for the "/ n_test_users" accumulation of macr_mf/train.py:286-290, without the second launch and the (U,4,nK) trip
+ * through memory.  mean f64[4*nK]: device memory or device-visible (pinned) host memory.  per_user (dev, may be NULL):
+ * macr_metrics_mf's out, for callers that want both.  The sum is a fixed two-level tree over blocks of 64 queries
+ * (a function of U and nK only: deterministic; it differs from macr_colmean's tree in the last bits).  workspace (dev, 8-byte
+ * aligned, macr_metrics_mf_mean_workspace_bytes): its first 4 bytes are a ticket that must be ZERO on entry and is zero on
+ * return (zero-fill the buffer once); one call at a time per workspace. */
+size_t macr_metrics_mf_mean_workspace_bytes(int U, int nK);
+int macr_metrics_mf_mean(int U, int Kmax, const int32_t *rankings, const int32_t *cnt,
+                         const int32_t *gt_ptr, const int32_t *gt_idx,
+                         const int32_t *Ks /*host*/, int nK, double *per_user, double *mean,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* Column means of a (rows, cols) matrix in float64 (deterministic tree):
  * the "/ n_test_users" accumulation of macr_mf/train.py:286-290 and the

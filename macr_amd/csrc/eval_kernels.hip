@@ -2677,9 +2677,11 @@ __device__ __forceinline__ void rescore_lists(int q, int ql, int lane, int U, in
             lists[rel[j]] = k ? exact_key<D, KIND>(q, key_id(k), users_tab, user_ids, items, sig_u, sig_i, c, item_offset) : 0ull;
         }
     }
-    // the selection reads these words again (through a pointer it was promised nobody writes): the stores first, stale
-    // L1 lines gone, and no load of the compiler's moved above this point
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    // the selection reads these words again (through a pointer it was promised nobody writes): the stores first, and no load
+    // of the compiler's moved above this point.  Workgroup scope: writer and reader are the same wave, whose CU's L1 is
+    // write-through and coherent for its own workgroup; an agent-scope release here wrote back the XCD's whole L2 -- full of the
+    // listing pass's lists -- in the wave that is the tail of the launch (profiles/r05_eval_fold_ab.txt on what that costs)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     asm volatile("" ::: "memory");
 }
 
@@ -2814,9 +2816,11 @@ __global__ __launch_bounds__(kUsersPerBlock) void k_repair_plan(int U, int K, in
     }
     // the last block to get here knows how many query blocks are listed again: if they take the compact layout, its
     // counts (which overlay other queries' counts, all read by now) start at zero
+    // (one agent-scope release per block, behind the barrier that orders the block's writes before it: a release by every wave
+    // writes back its XCD's L2 each time -- profiles/r05_eval_fold_ab.txt)
     __shared__ int s_last;
-    __threadfence();
-    if (threadIdx.x == 0) s_last = atomicAdd(n_done, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(n_done, 1) == (int)gridDim.x - 1; }
     __syncthreads();
     if (!s_last) return;
     const int n = __hip_atomic_load(n_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3182,6 +3186,39 @@ __global__ __launch_bounds__(256) void k_branch_sigmoid2(int nb_a, const float *
     if (sub == 0) out[r] = sigmoid_acc(s);
 }
 
+// The launches an evaluation starts with, as ONE (macr_score_topk_prologue): the branch factors of the items (blocks
+// [0, nb_a)) and of the queries (the next nb_b blocks; nb_b may be 0) -- k_branch_sigmoid's arithmetic -- and, in the
+// remaining blocks, k_topk_ws_init's statements on the head of the ranking workspace.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_eval_prologue(int nb_a, const float *__restrict__ rows_a, int n_a, const float *__restrict__ w_a,
+                                                       float *__restrict__ out_a, int nb_b, const float *__restrict__ rows_b,
+                                                       const int32_t *__restrict__ idx_b, int n_b, const float *__restrict__ w_b,
+                                                       float *__restrict__ out_b, uint32_t *__restrict__ base, size_t n_zero, size_t n_tau,
+                                                       uint32_t tau_bits, int set_tau, size_t n_max) {
+    constexpr int d = 4 * LPR;
+    if ((int)blockIdx.x >= nb_a + nb_b) {
+        const size_t blk = blockIdx.x - (nb_a + nb_b), nblk = gridDim.x - (nb_a + nb_b);
+        const size_t total = n_zero + n_tau + n_max;
+        for (size_t w = blk * (size_t)blockDim.x + threadIdx.x; w < total; w += nblk * blockDim.x) {
+            if (w < n_zero) base[w] = 0u;
+            else if (w < n_zero + n_tau) { if (set_tau) base[w] = tau_bits; }
+            else base[w] = 0xffffffffu;
+        }
+        return;
+    }
+    const bool first = (int)blockIdx.x < nb_a;
+    const float *rows = first ? rows_a : rows_b, *w = first ? w_a : w_b;
+    const int32_t *idx = first ? nullptr : idx_b;
+    float *out = first ? out_a : out_b;
+    const int n = first ? n_a : n_b, blk = first ? blockIdx.x : blockIdx.x - nb_a;
+    const int sub = threadIdx.x % LPR;
+    const int r = blk * (256 / LPR) + threadIdx.x / LPR;
+    if (r >= n) return;
+    const size_t src = idx ? (size_t)idx[r] : (size_t)r;
+    const float s = group_sum<LPR>(dot4(ld4(rows + src * d + 4 * sub), ld4(w + 4 * sub)));       // (k_branch_sigmoid's arithmetic)
+    if (sub == 0) out[r] = sigmoid_acc(s);
+}
+
 // ----------------------------------------------------------------------------
 // metrics
 // ----------------------------------------------------------------------------
@@ -3349,6 +3386,133 @@ __global__ __launch_bounds__(256) void k_metrics_mf(int U, int Kmax, const int32
             o[3 * Ks.n + qk] = hits > 0 ? 1.0 : 0.0;
         }
     }
+}
+
+// k_metrics_mf AND the means over the query users (the "/ n_test_users" accumulation of macr_mf/train.py:286-290) in ONE
+// launch: a block of 16 waves takes 64 consecutive queries, four per wave; a wave sums its queries' values in query order, the
+// block the waves' sums in wave order (LDS) and writes one partial row; the block that takes the last ticket sums the partial
+// rows -- 32 strided slices in block order, then the slices in order: the shape of the sum depends on (U, columns) only,
+// never on who arrives last.  ticket: zero on entry, zero on return.
+constexpr int kMeanWaves = 16, kMeanPerWave = 4, kMeanSlices = 32, kMeanCols = 32;
+constexpr int kMeanPerBlock = kMeanWaves * kMeanPerWave;
+__global__ __launch_bounds__(64 * kMeanWaves) void k_metrics_mf_mean(int U, int Kmax, const int32_t *__restrict__ rankings,
+                                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ gt_ptr,
+                                                                     const int32_t *__restrict__ gt_idx, KsArg Ks, double *__restrict__ per_user,
+                                                                     double *partials, int32_t *ticket, double *mean) {
+    __shared__ double s_val[kMeanSlices][kMeanCols];      // [wave][column] first, [slice][column] in the last block
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ncols = 4 * Ks.n;
+    if (lane < kMeanCols) s_val[wv][lane] = 0.0;          // (each wave touches its own row only: no barrier needed before the loop)
+    double term[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) term[h] = 1.0 / log2((double)(lane + 64 * h + 2));       // DCG discount of position lane + 64 h
+    // A wave's four queries side by side in memory: one load for their five list bounds, then the four ranked lists and the
+    // first 64 ids of the four truth lists in flight together -- two dependent trips for the wave instead of the 1 + log2(len)
+    // of a binary search per query (what k_metrics_mf's 13 us are).  A truth list of <= 64 ids is searched across lanes.
+    const int u0 = blockIdx.x * kMeanPerBlock + wv * kMeanPerWave;
+    int bound = 0;
+    if (lane <= kMeanPerWave) bound = gt_ptr[u0 + lane < U ? u0 + lane : U];
+    int beg[kMeanPerWave], tlen[kMeanPerWave], item[kMeanPerWave][2], tr[kMeanPerWave], len_in[kMeanPerWave];
+#pragma unroll
+    for (int k = 0; k < kMeanPerWave; ++k) {
+        beg[k] = __builtin_amdgcn_readlane(bound, k);
+        tlen[k] = __builtin_amdgcn_readlane(bound, k + 1) - beg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kMeanPerWave; ++k) {
+        const int u = u0 + k;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pos = lane + 64 * h;
+            item[k][h] = (u < U && pos < Kmax) ? rankings[(size_t)u * Kmax + pos] : -1;
+        }
+        tr[k] = (u < U && lane < tlen[k]) ? gt_idx[beg[k] + lane] : -1;
+        len_in[k] = (cnt && u < U) ? cnt[u] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kMeanPerWave; ++k) {
+        const int u = u0 + k;
+        if (u >= U) break;                                // wave-uniform
+        const int truth_len = tlen[k];
+        bool hit[2];
+        int n_valid = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) n_valid += __popcll(__ballot(item[k][h] >= 0));
+        if (truth_len <= 64) {
+            hit[0] = hit[1] = false;
+            for (int j = 0; j < truth_len; ++j) {         // (wave-uniform bound; ids are >= 0, so an unused slot's -1 never matches)
+                const int t = __builtin_amdgcn_readlane(tr[k], j);
+                hit[0] = hit[0] || item[k][0] == t;
+                hit[1] = hit[1] || item[k][1] == t;
+            }
+        } else {
+            const int32_t *truth = gt_idx + beg[k];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) hit[h] = item[k][h] >= 0 && in_sorted(truth, truth_len, item[k][h]);
+        }
+        const int len = cnt ? len_in[k] : n_valid;
+        for (int qk = 0; qk < Ks.n; ++qk) {               // (k_metrics_mf's statements)
+            const int K = Ks.k[qk];
+            const int m = len < K ? len : K;
+            const int lim = truth_len < K ? truth_len : K;
+            double hits = 0.0, dcg = 0.0, dcg_max = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pos = lane + 64 * h;
+                const bool mine = hit[h] && pos < m;
+                hits += (double)__popcll(__ballot(mine));
+                dcg += wave_sum_d(mine ? term[h] : 0.0);
+                dcg_max += wave_sum_d(pos < lim ? term[h] : 0.0);
+            }
+            if (lane == 0) {
+                const double v0 = m > 0 ? hits / m : NAN, v1 = hits / truth_len, v2 = dcg_max != 0 ? dcg / dcg_max : 0.0,
+                             v3 = hits > 0 ? 1.0 : 0.0;
+                s_val[wv][0 * Ks.n + qk] += v0; s_val[wv][1 * Ks.n + qk] += v1;
+                s_val[wv][2 * Ks.n + qk] += v2; s_val[wv][3 * Ks.n + qk] += v3;
+                if (per_user) {
+                    double *o = per_user + ((size_t)u * 4) * Ks.n;
+                    o[0 * Ks.n + qk] = v0; o[1 * Ks.n + qk] = v1; o[2 * Ks.n + qk] = v2; o[3 * Ks.n + qk] = v3;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ncols) {
+        double s = 0.0;
+        for (int w = 0; w < kMeanWaves; ++w) s += s_val[w][threadIdx.x];       // (a wave without queries holds zeros)
+        // write-through stores and loads (spmm_kernels.hip's publish / last_of): a partial row is out in memory before its
+        // block's arrival is counted -- no fence: an agent-scope release by every wave writes back its XCD's L2 each time
+        // (this launch took 238 us that way)
+        __hip_atomic_store(partials + (size_t)blockIdx.x * ncols + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    const int col = threadIdx.x % kMeanCols, slice = threadIdx.x / kMeanCols;       // 1024 threads = 32 slices x 32 columns
+    double acc = 0.0;
+    if (col < ncols) {
+        for (int b0 = slice; b0 < (int)gridDim.x; b0 += 8 * kMeanSlices) {          // eight loads in flight, added in block order
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = b0 + j * kMeanSlices;
+                v[j] = b < (int)gridDim.x ? __hip_atomic_load(partials + (size_t)b * ncols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+    }
+    s_val[slice][col] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < ncols) {
+        double t = 0.0;
+        for (int k = 0; k < kMeanSlices; ++k) t += s_val[k][threadIdx.x];
+        mean[threadIdx.x] = t / (double)U;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // for the next launch
 }
 
 // column means in float64, one 1024-thread block per column, fixed-shape tree => deterministic
@@ -3528,6 +3692,25 @@ static void launch_k_tau(int tau_regs, int blocks, hipStream_t st, int U, int sl
         case MACR_SCORE_DIRECT_MINUS:      { constexpr int D = Dv, KIND = MACR_SCORE_DIRECT_MINUS; __VA_ARGS__; } break;      \
         case MACR_SCORE_DIRECT_MINUS_BOTH: { constexpr int D = Dv, KIND = MACR_SCORE_DIRECT_MINUS_BOTH; __VA_ARGS__; } break; \
     }
+// what k_topk_ws_init / k_eval_prologue write to the head of the ranking workspace before a first round: counts, flags,
+// shared_thr <- 0; tau <- -inf on the list-everything path; the class maxima <- NaN ("this class saw nothing") -- none for a
+// seeded first round under the bf16 filter (no sampling pass: its repair round, if one follows, fills them itself)
+struct WsHeadPlan { size_t n_zero, n_tau, n_max; int set_tau; unsigned grid; };
+static WsHeadPlan ws_head_plan(const TopkWs &ws, const StreamGeo &geo, int U, int n_local, int K, int filter, bool seeded_first_round) {
+    const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
+    const bool filter_bf16 = !list_all && eval_filter_bf16(filter);
+    const bool bf16_merge = filter_bf16 && geo.slots0 * 16 >= 4 * K;
+    const size_t n_max_words = list_all ? 0 : filter_bf16 ? (size_t)geo.slots0 * U * (bf16_merge ? 16 : 32) : ws.maxima_bytes / 4;
+    WsHeadPlan p;
+    p.n_zero = ws.header_bytes / 4;
+    p.n_tau = (reinterpret_cast<char *>(ws.maxima) - reinterpret_cast<char *>(ws.tau)) / 4;
+    p.n_max = (seeded_first_round && filter_bf16) ? 0 : n_max_words;
+    p.set_tau = list_all ? 1 : 0;
+    const size_t total = p.n_zero + p.n_tau + p.n_max, blocks = (total + 256 * 8 - 1) / (256 * 8);
+    p.grid = (unsigned)(blocks < 1 ? 1 : blocks < 2048 ? blocks : 2048);
+    return p;
+}
+
 #define MACR_DISPATCH_DK(d, kind, ...)                              \
     switch (d) {                                                    \
         case 32:  MACR_DISPATCH_K(32, kind, __VA_ARGS__); break;    \
@@ -3550,7 +3733,11 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
     // MACR_TOPK_FALLBACK=1 in the environment runs the fallback kernel unconditionally (tests of that path)
     static const bool force_fallback = getenv("MACR_TOPK_FALLBACK") && getenv("MACR_TOPK_FALLBACK")[0] == '1';
     MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "score_topk: score_kind=%d", score_kind);
+    // MACR_EVAL_WS_READY: macr_score_topk_prologue has initialised the workspace head for exactly this call
+    const bool ws_ready = (filter & MACR_EVAL_WS_READY) != 0;
+    filter &= ~MACR_EVAL_WS_READY;
     MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_BF16, MACR_E_INVALID, "score_topk: filter=%d", filter);
+    MACR_REQUIRE(!ws_ready || mode != 2, MACR_E_INVALID, "score_topk: MACR_EVAL_WS_READY on a repair round");
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk: d=%d not in {32,64,128,256}", d);
     MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "score_topk: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
@@ -3579,16 +3766,10 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
     // follows (macr_score_topk_repair_round), fills them itself.
     const bool bf16_merge = filter_bf16 && geo.slots0 * 16 >= 4 * K;
     const size_t n_max_words = list_all ? 0 : filter_bf16 ? (size_t)geo.slots0 * U * (bf16_merge ? 16 : 32) : ws.maxima_bytes / 4;
-    const bool lazy_maxima = first_only && filter_bf16 && seed_idx != nullptr;
     if (repair_only && filter_bf16 && seed_idx != nullptr) fill_words(reinterpret_cast<uint32_t *>(ws.maxima), n_max_words, 0xffffffffu, st);
-    if (!repair_only) {
-        const size_t n_zero = ws.header_bytes / 4;
-        const size_t n_tau = (reinterpret_cast<char *>(ws.maxima) - reinterpret_cast<char *>(ws.tau)) / 4;
-        const size_t n_max = lazy_maxima ? 0 : n_max_words;
-        const size_t total = n_zero + n_tau + n_max;
-        const unsigned grid = (unsigned)((total + 256 * 8 - 1) / (256 * 8) < 2048 ? (total + 256 * 8 - 1) / (256 * 8) : 2048);
-        k_topk_ws_init<<<grid ? grid : 1, 256, 0, st>>>(static_cast<uint32_t *>(workspace), n_zero, n_tau, 0xff800000u,
-                                                     list_all ? 1 : 0, n_max);
+    if (!repair_only && !ws_ready) {
+        const WsHeadPlan hp = ws_head_plan(ws, geo, U, n_local, K, filter, first_only && seed_idx != nullptr);
+        k_topk_ws_init<<<hp.grid, 256, 0, st>>>(static_cast<uint32_t *>(workspace), hp.n_zero, hp.n_tau, 0xff800000u, hp.set_tau, hp.n_max);
         MACR_CHECK_LAUNCH("ws_init", st);
     }
     const int sel_blocks = (U + kSelWaves - 1) / kSelWaves;
@@ -3847,6 +4028,34 @@ extern "C" int macr_score_topk_repair_round(int score_kind, int filter, int U, i
     return score_topk_impl(2, filter, score_kind, U, n_local, d, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_ptr, mask_idx,
                            mask_bits_in, item_offset, K, n_splits, seed_idx, seed_out, out_val, out_idx, stats, workspace,
                            workspace_bytes, stream);
+}
+
+extern "C" int macr_score_topk_prologue(int filter, int U, int n_local, int d, int K, int seeded_first_round,
+                                        const float *items, const float *w_item, float *sig_i,
+                                        const float *users_tab, const int32_t *user_ids, const float *w_user, float *sig_u,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_BF16, MACR_E_INVALID, "score_topk_prologue: filter=%d", filter);
+    MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk_prologue: U=%d n_local=%d", U, n_local);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk_prologue: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "score_topk_prologue: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
+    MACR_REQUIRE(items && w_item && sig_i, MACR_E_INVALID, "score_topk_prologue: null pointer (items, w_item, sig_i)");
+    MACR_REQUIRE((sig_u == nullptr) == (w_user == nullptr) && (!sig_u || users_tab), MACR_E_INVALID,
+                 "score_topk_prologue: sig_u, w_user and users_tab come together");
+    MACR_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
+                 "score_topk_prologue: workspace is null or not 256-byte aligned");
+    const StreamGeo geo = stream_geo(U, n_local, d);
+    TopkWs ws = carve_topk_ws(workspace, U, n_local, geo, d);
+    MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "score_topk_prologue: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    const WsHeadPlan hp = ws_head_plan(ws, geo, U, n_local, K, filter, seeded_first_round != 0);
+    MACR_DISPATCH_LPR(d, {
+        const int rpb = 256 / LPR, nb_a = (n_local + rpb - 1) / rpb, nb_b = sig_u ? (U + rpb - 1) / rpb : 0;
+        k_eval_prologue<LPR><<<nb_a + nb_b + hp.grid, 256, 0, st>>>(nb_a, items, n_local, w_item, sig_i, nb_b, users_tab, user_ids, U, w_user, sig_u,
+                                                                   static_cast<uint32_t *>(workspace), hp.n_zero, hp.n_tau, 0xff800000u,
+                                                                   hp.set_tau, hp.n_max);
+    });
+    MACR_CHECK_LAUNCH("eval_prologue", st);
+    return MACR_OK;
 }
 
 /* ---- c sweep -------------------------------------------------------------------------------------------------- */
@@ -4162,6 +4371,37 @@ extern "C" int macr_metrics_mf(int U, int Kmax, const int32_t *rankings, const i
     }
     k_metrics_mf<<<(U + 3) / 4, 256, 0, st>>>(U, Kmax, rankings, cnt, gt_ptr, gt_idx, ka, out);
     MACR_CHECK_LAUNCH("metrics_mf", st);
+    return MACR_OK;
+}
+
+extern "C" size_t macr_metrics_mf_mean_workspace_bytes(int U, int nK) {
+    if (U <= 0 || nK < 1 || nK > 8) return 0;
+    return 256 + (size_t)((U + kMeanPerBlock - 1) / kMeanPerBlock) * 4 * nK * sizeof(double);
+}
+
+extern "C" int macr_metrics_mf_mean(int U, int Kmax, const int32_t *rankings, const int32_t *cnt,
+                                    const int32_t *gt_ptr, const int32_t *gt_idx, const int32_t *Ks, int nK,
+                                    double *per_user, double *mean, void *workspace, size_t workspace_bytes, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(U > 0 && Kmax >= 1, MACR_E_INVALID, "metrics_mf_mean: U=%d Kmax=%d", U, Kmax);
+    MACR_REQUIRE(Kmax <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "metrics_mf_mean: Kmax=%d > %d", Kmax, MACR_MAX_TOPK);
+    MACR_REQUIRE(rankings && gt_ptr && gt_idx && Ks && mean, MACR_E_INVALID, "metrics_mf_mean: null pointer");
+    MACR_REQUIRE(nK >= 1 && nK <= 8, MACR_E_UNSUPPORTED, "metrics_mf_mean: nK=%d outside [1,8]", nK);
+    MACR_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0, MACR_E_INVALID,
+                 "metrics_mf_mean: workspace is null or not 8-byte aligned (macr_metrics_mf_mean_workspace_bytes)");
+    MACR_REQUIRE(workspace_bytes >= macr_metrics_mf_mean_workspace_bytes(U, nK), MACR_E_WORKSPACE,
+                 "metrics_mf_mean: workspace %zu < %zu bytes", workspace_bytes, macr_metrics_mf_mean_workspace_bytes(U, nK));
+    KsArg ka;
+    ka.n = nK;
+    for (int q = 0; q < nK; ++q) {
+        MACR_REQUIRE(Ks[q] >= 1 && Ks[q] <= Kmax, MACR_E_INVALID, "metrics_mf_mean: Ks[%d]=%d outside [1,%d]", q, Ks[q], Kmax);
+        ka.k[q] = Ks[q];
+    }
+    int32_t *ticket = static_cast<int32_t *>(workspace);
+    double *partials = reinterpret_cast<double *>(static_cast<char *>(workspace) + 256);
+    k_metrics_mf_mean<<<(U + kMeanPerBlock - 1) / kMeanPerBlock, 64 * kMeanWaves, 0, st>>>(U, Kmax, rankings, cnt, gt_ptr, gt_idx, ka, per_user,
+                                                                                     partials, ticket, mean);
+    MACR_CHECK_LAUNCH("metrics_mf_mean", st);
     return MACR_OK;
 }
 

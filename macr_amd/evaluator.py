@@ -45,6 +45,12 @@ class Evaluator(object):
         # nothing to do (~25 us of a 0.45 ms evaluation on the Gowalla shape) and both result copies.
         # MACR_EVAL_OPTIMISTIC=0: the complete sequence always.
         self.optimistic = os.environ.get("MACR_EVAL_OPTIMISTIC", "1") != "0"
+        # Launch folds.  "p" (default): the branch factors and the ranking's workspace initialisation are one launch
+        # (macr_score_topk_prologue): -6 .. -8 us per graph-replayed evaluation on the Gowalla shape, same box.  "m": the
+        # MF metrics and their means as one launch (macr_metrics_mf_mean): 20 us against 12.6 + 7.5 us for the two kernels it
+        # replaces -- no gain under graph replay (profiles/r05_eval_fold_ab.txt), so off unless asked for.  "1": both, "0": none.
+        fold = os.environ.get("MACR_EVAL_FOLD", "p").strip().lower()
+        self.fold_prologue, self.fold_metrics = fold in ("1", "p"), fold in ("1", "m")
         self._topk_mode = None                    # None: the complete call; "first" / "repair": its two halves
         self._repair_bufs = None
         self._last_entry = None
@@ -112,14 +118,21 @@ class Evaluator(object):
         ws = sharding.world()[1]
         lo, hi, items_local = self._shard(items_tab)
         sig_u = sig_i = None
-        if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH) and items_local.shape[1] == users_tab.shape[1]:
+        U = self.n_queries
+        both = kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH)
+        # one ranking call that initialises its own workspace: the branch factors and that initialisation are ONE launch
+        # (macr_score_topk_prologue, below, once it is known whether the call is seeded)
+        fold = (kind != ops.SCORE_NORMAL and U <= self.max_queries_per_pass and self._topk_mode != "repair"
+                and items_local.shape[1] == users_tab.shape[1] and self.fold_prologue)
+        if fold:
+            pass
+        elif both and items_local.shape[1] == users_tab.shape[1]:
             # sigmoid(e_i . w), sigmoid(e_u . w_user) (model.py:141-142,:199-201) in one launch
             sig_i, sig_u = ops.branch_sigmoid2(items_local, w, None, users_tab, wu, user_ids)
         elif kind != ops.SCORE_NORMAL:
             sig_i = ops.branch_sigmoid(items_local, w)              # sigmoid(e_i . w)      model.py:141-142,:199-201
-            if kind in (ops.SCORE_RUBI_BOTH, ops.SCORE_DIRECT_MINUS_BOTH):
+            if both:
                 sig_u = ops.branch_sigmoid(users_tab, wu, user_ids)     # sigmoid(e_u . w_user) model.py:199,:201
-        U = self.n_queries
         if U <= self.max_queries_per_pass:
             # Seeds: the ids this shard returned last time (same queries, tables that moved by a few training steps).
             # Their exact current scores bound every query's K-th best score from below far more tightly than a
@@ -136,10 +149,14 @@ class Evaluator(object):
             # the ranking leaves its best SEED_WIDTH candidates per query in `seed` (in place): the next ranking's seeds
             mask = self._mask_local if self._local_own is not None else self.mask
             mode = self._topk_mode
+            if fold:
+                sig_i, sig_u = ops.score_topk_prologue(users_tab, user_ids, items_local, K, w, wu if both else None,
+                                                       seeded_first_round=seeded and mode == "first", filter=self.filter_now)
             vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, mask, lo,
                                        seed=seed if seeded else None, seed_out=seed,
                                        stats=self._stats_first if mode else self._stats, first_round=mode == "first",
-                                       repair_of=self._repair_bufs if mode == "repair" else None, filter=self.filter_now)
+                                       repair_of=self._repair_bufs if mode == "repair" else None, filter=self.filter_now,
+                                       ws_ready=fold)
         else:
             # the ranking workspace (candidate lists, mask bitmap) grows with the number of queries: rank them in
             # chunks; every query is independent of the chunking
@@ -249,11 +266,21 @@ class Evaluator(object):
         """(W,U,K) lists (splits of one shard, or the gathered shards) -> column means of the per-user metrics.
         out: optional pinned host tensor the last kernel writes the means to."""
         if flavour == "mf":
+            # metrics and their means over the queries in one launch (macr_metrics_mf_mean); its scratch is this evaluator's
+            # own (a captured graph bakes the address in)
+            if not self.fold_metrics:
+                if vals.shape[0] == 1:
+                    return ops.colmean(ops.metrics_mf(idx[0], None, self.gt, list(Ks)), out=out)
+                _, ix, cnt = ops.topk_merge(vals, idx)
+                return ops.colmean(ops.metrics_mf(ix, cnt, self.gt, list(Ks)), out=out)         # (U,4,nK) float64 -> (4,nK)
+            mws = self.__dict__.setdefault("_mean_ws", {})
+            if len(Ks) not in mws:
+                mws[len(Ks)] = ops.metrics_mf_mean_workspace(idx.shape[1], len(Ks), idx.device)
             if vals.shape[0] == 1:
                 # one sorted list per query: nothing to merge (the metrics kernel counts a list's ids itself)
-                return ops.colmean(ops.metrics_mf(idx[0], None, self.gt, list(Ks)), out=out)
+                return ops.metrics_mf_mean(idx[0], None, self.gt, list(Ks), mws[len(Ks)], out=out)
             _, ix, cnt = ops.topk_merge(vals, idx)
-            return ops.colmean(ops.metrics_mf(ix, cnt, self.gt, list(Ks)), out=out)         # (U,4,nK) float64 -> (4,nK)
+            return ops.metrics_mf_mean(ix, cnt, self.gt, list(Ks), mws[len(Ks)], out=out)   # (4,nK) float64
         if vals.shape[0] == 1 and vals.shape[2] <= _lib_consts.MAX_TOPK and self._local_own is None:
             # one sorted list per query: the metrics kernel completes short lists with the masked ids itself (-inf fill,
             # batch_test.py:124-134) -- no merge launch

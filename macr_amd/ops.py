@@ -277,9 +277,31 @@ def _c_args(c):
     return float(c), None
 
 
+EVAL_WS_READY = 0x100
+
+
+def score_topk_prologue(users_tab, user_ids, items, K, w_item, w_user=None, seeded_first_round=False, filter=None):
+    """The launches an evaluation of the two-branch scores starts with, as one (macr_score_topk_prologue): returns
+    (sig_i, sig_u) -- branch_sigmoid(items, w_item), branch_sigmoid(users_tab, w_user, user_ids) or None -- and leaves the head
+    of the device's ranking workspace initialised for the score_topk call that follows with ws_ready=True and the same U,
+    items, K, filter (seeded_first_round: that call is first_round=True with seeds)."""
+    U = users_tab.shape[0] if user_ids is None else user_ids.numel()
+    n_local, d = items.shape
+    sig_i = torch.empty(n_local, dtype=_f32, device=items.device)
+    sig_u = torch.empty(U, dtype=_f32, device=items.device) if w_user is not None else None
+    ws = _topk_workspace(U, n_local, d, items.device)
+    check(_lib.lib().macr_score_topk_prologue(_filter_arg(filter), U, n_local, d, K, int(bool(seeded_first_round)),
+                                              _ptr(items, _f32), _ptr(w_item.reshape(-1), _f32), _ptr(sig_i),
+                                              _ptr(users_tab, _f32) if w_user is not None else None,
+                                              _ptr(user_ids, _i32, True) if w_user is not None else None,
+                                              _ptr(w_user.reshape(-1), _f32) if w_user is not None else None, _ptr(sig_u, _f32, True),
+                                              _ptr(ws), ws.numel(), _stream()))
+    return sig_i, sig_u
+
+
 def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.0, mask=None,
                item_offset=0, n_splits=0, seed=None, seed_out=None, stats=None, first_round=False, repair_of=None,
-               filter=None):
+               filter=None, ws_ready=False):
     """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K).
     c: python float, or a 1-element fp32 device tensor (read at run time: graph replays follow its value).
     seed: optional (U, SEED_WIDTH) int32 device tensor of global item ids per query -- what seed_out received last time:
@@ -292,7 +314,8 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     fallback; stats (required) then says whether the result stands: stats[0] == 0, else finish it with
     repair_of=(vals, idx, ws) -- macr_score_topk_repair_round on the same arguments, the first-round call's outputs AND the
     workspace it ran on (thresholds, overflow counters and candidate lists are where the first round left them; the
-    per-device cache may have been regrown by another caller since) -- or run the complete call."""
+    per-device cache may have been regrown by another caller since) -- or run the complete call.
+    ws_ready: score_topk_prologue ran for this call (same stream, nothing of the ranking workspace touched in between)."""
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
     n_local, d = items.shape
     if n_splits <= 0:
@@ -314,7 +337,8 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     fn = _lib.lib().macr_score_topk_first_round if first_round else _lib.lib().macr_score_topk
     if repair_of is not None:
         fn = _lib.lib().macr_score_topk_repair_round
-    check(fn(kind, _filter_arg(filter), U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
+    assert not (ws_ready and repair_of is not None)
+    check(fn(kind, _filter_arg(filter) | (EVAL_WS_READY if ws_ready else 0), U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
              _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
              cv, cp, mp, mi, mb, item_offset, K, n_splits, _ptr(seed, _i32, True), _ptr(seed_out, _i32, True), _ptr(vals), _ptr(idx),
              _ptr_visible(stats, _i32, True), _ptr(ws), ws.numel(), _stream()))
@@ -409,6 +433,27 @@ def metrics_mf(rankings, cnt, gt, Ks):
     check(_lib.lib().macr_metrics_mf(U, Kmax, _ptr(rankings, _i32), _ptr(cnt, _i32, True), _ptr(gt.ptr, _i32),
                                      _ptr(gt.idx, _i32), ks, len(Ks), _ptr(out), _stream()))
     return out
+
+
+def metrics_mf_mean_workspace(U, nK, device):
+    """the zero-filled scratch of metrics_mf_mean (ticket + one partial row per block of 64 queries)"""
+    return torch.zeros(_lib.lib().macr_metrics_mf_mean_workspace_bytes(U, nK), dtype=torch.uint8, device=device)
+
+
+def metrics_mf_mean(rankings, cnt, gt, Ks, ws, out=None, per_user=False):
+    """colmean(metrics_mf(...)) in ONE launch (macr_metrics_mf_mean): (4, len(Ks)) float64 means over the query users
+    (macr_mf/train.py:286-290); with per_user also the (U,4,len(Ks)) values.  ws: metrics_mf_mean_workspace(U, len(Ks)) -- one
+    call at a time per buffer; out: optional float64 device or pinned host tensor of 4*len(Ks) elements."""
+    U, Kmax = rankings.shape
+    ks = (ctypes.c_int32 * len(Ks))(*[int(k) for k in Ks])
+    if out is None:
+        out = torch.empty(4 * len(Ks), dtype=_f64, device=rankings.device)
+    pu = torch.empty((U, 4, len(Ks)), dtype=_f64, device=rankings.device) if per_user else None
+    check(_lib.lib().macr_metrics_mf_mean(U, Kmax, _ptr(rankings, _i32), _ptr(cnt, _i32, True), _ptr(gt.ptr, _i32),
+                                          _ptr(gt.idx, _i32), ks, len(Ks), _ptr(pu, _f64, True), _ptr_visible(out, _f64),
+                                          _ptr(ws), ws.numel(), _stream()))
+    m = out.reshape(4, len(Ks))
+    return (m, pu) if per_user else m
 
 
 def colmean(x, out=None):

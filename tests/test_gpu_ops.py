@@ -846,6 +846,45 @@ def test_metrics_mf_counts_a_lists_ids_and_colmean_writes_pinned_host_memory(ops
         assert torch.equal(torch.nan_to_num(on_dev.cpu()), torch.nan_to_num(host))
 
 
+@pytest.mark.parametrize("U", [1, 3, 4, 5, 63, 64, 65, 4099, 15424])
+def test_metrics_mf_mean_is_metrics_mf_then_the_mean_in_one_launch(ops, U):
+    """macr_metrics_mf_mean: the per-query values are macr_metrics_mf's bit for bit, the means are the oracle's per-query values
+    averaged (macr_mf/train.py:286-290) -- a NaN precision (empty list) propagates like numpy's mean --, the same bits on every
+    call (the tree is a function of U only), in device or pinned host memory; the ticket is left at zero (calls repeat on one
+    workspace)."""
+    rs = np.random.RandomState(83 + U)
+    K, N = (100 if U in (5, 65, 4099) else 20), 300          # (lists longer than 64: a lane owns two rank positions)
+    rank = np.stack([rs.permutation(N)[:K] for _ in range(U)]).astype(np.int32)
+    cnt = np.full(U, K, np.int32)
+    short = rs.choice(U, min(U, 40), replace=False)
+    cnt[short] = rs.randint(1, K + 1, short.size)
+    for q in short:
+        rank[q, cnt[q]:] = -1
+    gt_lists = [sorted(rs.choice(N, size=rs.randint(1, 30), replace=False).tolist()) for _ in range(U)]
+    for q, n in zip(rs.choice(U, min(U, 12), replace=False), (63, 64, 65, 100, 128, 200, 64, 65, 1, 2, 129, 299)):
+        gt_lists[q] = sorted(rs.choice(N, size=n, replace=False).tolist())      # (up to 64 ids are searched across lanes, longer lists by bisection)
+    gptr, gidx = oracle.csr_from_lists(gt_lists)
+    gt = ops.CSR(dev(gptr), dev(gidx))
+    for Ks in ([20], [1, 5, 20], [1, 2, 3, 4, 5, 10, 15, 20]):
+        ws = ops.metrics_mf_mean_workspace(U, len(Ks), torch.device("cuda", 0))
+        want = oracle.metrics_mf(rank, cnt, (gptr, gidx), Ks)
+        for c in (None, dev(cnt)):
+            mean, per_user = ops.metrics_mf_mean(dev(rank), c, gt, Ks, ws, per_user=True)
+            assert torch.equal(per_user, ops.metrics_mf(dev(rank), c, gt, Ks))
+            np.testing.assert_allclose(mean.cpu().numpy(), want.mean(0), rtol=1e-13, atol=0)
+            host = torch.full((4, len(Ks)), -1.0, dtype=torch.float64).pin_memory()
+            again = ops.metrics_mf_mean(dev(rank), c, gt, Ks, ws, out=host)
+            torch.cuda.synchronize()
+            assert again.data_ptr() == host.data_ptr() and torch.equal(host, mean.cpu())
+            assert int(ws[:4].view(torch.int32).item()) == 0
+    if U >= 16:
+        # an empty list: its precision is NaN (0 / 0 in train.py:36 with an empty r), and so is the mean of that column
+        rank[3, :] = -1
+        mean = ops.metrics_mf_mean(dev(rank), None, gt, [20], ops.metrics_mf_mean_workspace(U, 1, torch.device("cuda", 0)))
+        m = mean.cpu().numpy()
+        assert np.isnan(m[0, 0]) and np.all(np.isfinite(m[1:, 0]))
+
+
 @pytest.mark.parametrize("K", [1, 20, 64, 100])
 def test_metrics_foldout_completes_short_lists_like_the_merge(ops, K):
     """macr_metrics_foldout_fill on the one list per query of macr_score_topk = macr_topk_merge with its -inf fill
@@ -919,6 +958,47 @@ def test_first_round_alone_says_whether_it_stands(ops, eval_filter):
         assert torch.equal(seeds_out[:, :K], ix[0]), name
     with pytest.raises(Exception):
         ops.score_topk(ops.SCORE_RUBI_BOTH, dev(P), None, dev(Q), K, sig_u, sig_i, 30.0, mcsr, first_round=True)     # stats required
+
+
+@pytest.mark.parametrize("shape", [(700, 7000, 64, 20), (300, 900, 32, 5), (513, 20011, 128, 32), (260, 5000, 64, 100)])
+def test_prologue_is_the_branch_sigmoids_and_the_workspace_initialisation(ops, eval_filter, shape):
+    """macr_score_topk_prologue + a ranking call with MACR_EVAL_WS_READY: the branch factors are macr_branch_sigmoid's bit for
+    bit and the ranking -- complete call, sampled first round, seeded first round -- is what the same call returns when it
+    initialises its own workspace, also when the workspace was left dirty by another ranking (and by garbage) before."""
+    U, N, d, K = shape
+    rs = np.random.RandomState(141 + U)
+    S = ops.SEED_WIDTH
+    P = (rs.standard_normal((U + 50, d)) * 0.4).astype(np.float32)
+    Q = (rs.standard_normal((N, d)) * 0.4).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    uid = dev(rs.permutation(U + 50)[:U].astype(np.int32))
+    mask = random_mask(rs, U, N, 30, heavy=(5,))
+    mcsr = ops.CSR.from_lists(mask, "cuda")
+    Pd, Qd, wd, wud = dev(P), dev(Q), dev(w), dev(wu)
+    sig_i = ops.branch_sigmoid(Qd, wd); sig_u = ops.branch_sigmoid(Pd, wud, uid)
+    seeds = torch.full((U, S), -1, dtype=torch.int32, device="cuda")
+    want_v, want_i = ops.score_topk(ops.SCORE_RUBI_BOTH, Pd, uid, Qd, K, sig_u, sig_i, 30.0, mcsr, seed_out=seeds, filter=eval_filter)
+    want_v, want_i = want_v.clone(), want_i.clone()
+    stats = torch.full((2,), 77, dtype=torch.int32).pin_memory()
+    use_seeds = K <= 32 and ops._lib.lib().macr_score_topk_uses_seeds(U, N, d)
+    for name, seed, first in (("complete", None, False), ("sampled first round", None, True), ("seeded first round", seeds.clone(), True)):
+        if seed is not None and not use_seeds:
+            continue
+        ops._topk_ws_cache[Qd.device].fill_(0xA5)                 # whatever was there before
+        gi, gu = ops.score_topk_prologue(Pd, uid, Qd, K, wd, wud, seeded_first_round=first and seed is not None, filter=eval_filter)
+        assert torch.equal(gi, sig_i) and torch.equal(gu, sig_u), name
+        stats.fill_(77)
+        v, ix = ops.score_topk(ops.SCORE_RUBI_BOTH, Pd, uid, Qd, K, gu, gi, 30.0, mcsr, seed=seed, seed_out=torch.empty_like(seeds),
+                               stats=stats, first_round=first, filter=eval_filter, ws_ready=True)
+        torch.cuda.synchronize()
+        assert stats.tolist() == [0, 0], (name, stats.tolist())
+        assert torch.equal(ix, want_i) and torch.equal(v.view(torch.int32), want_v.view(torch.int32)), name
+    # one-branch scores: no query factors
+    gi, gu = ops.score_topk_prologue(Pd, uid, Qd, K, wd, None, filter=eval_filter)
+    assert gu is None and torch.equal(gi, sig_i)
+    v, ix = ops.score_topk(ops.SCORE_RUBI, Pd, uid, Qd, K, None, gi, 30.0, mcsr, filter=eval_filter, ws_ready=True)
+    v0, ix0 = ops.score_topk(ops.SCORE_RUBI, Pd, uid, Qd, K, None, sig_i, 30.0, mcsr, filter=eval_filter)
+    assert torch.equal(ix, ix0) and torch.equal(v.view(torch.int32), v0.view(torch.int32))
 
 
 def test_golden_cpp_evaluator_cases(ops, golden_dir):
