@@ -20,7 +20,12 @@
  *     The optimizer -- tf.train.AdamOptimizer's update rule, epsilon placement,
  *     bias correction and its dense net effect on IndexedSlices -- stays PARITY
  *     UNPINNED: TensorFlow 1.14 cannot be run in this environment and the
- *     reference ships no golden values; orc_adam_dense follows SURVEY.md A.2.
+ *     reference ships no golden values; orc_adam_dense follows SURVEY.md A.2
+ *     (the rule as tf.train.AdamOptimizer's documentation states it, held to
+ *     its float64 evaluation over gradients from 1e-12 to 1e-1 -- epsilon
+ *     placement and bias correction included -- by tests/test_oracle_model.py
+ *     ::test_oracle_adam_known_answers_from_1e_12_to_1e_1; that pins the
+ *     restatement to the DOCUMENTED rule, not to TF 1.14's kernels).
  *
  * All tensors are fp32 row-major, indices int32, like the TF placeholders
  * (macr_mf/model.py:27-29).  Reductions over many elements accumulate in

@@ -135,6 +135,53 @@ def test_mf_twenty_step_trajectory_stays_on_the_oracle(ops, kind, defer):
         np.testing.assert_allclose(mine.cpu().numpy(), theirs, rtol=2e-4, atol=2e-6 * np.abs(theirs).max(), err_msg=name)
 
 
+def test_adam_pass_known_answers_from_1e_12_to_1e_1(ops):
+    """tf.train.AdamOptimizer as its documentation states it (macr_mf/model.py:74,:95 use it with the defaults):
+        lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;
+        theta -= lr_t * m / (sqrt(v) + epsilon)          -- epsilon OUTSIDE the root, lr_t carrying both bias corrections.
+    The trajectory tests bound the tables by a fraction of a step, which a misplaced epsilon survives on rows whose gradients
+    are far above it.  Here the pass gets gradients of every magnitude from 1e-12 to 1e-1 on tables that start at zero (the
+    new value IS the update) and must return the float64 evaluation of that formula to 1e-5 -- around |g| ~ 3e-7, where
+    sqrt(v) ~ epsilon, the variants (epsilon inside the root, epsilon-hat of the paper's form, no bias correction) are off by
+    factors, which the test checks of itself."""
+    B, d = 256, 64
+    # (the hyper-parameters as the fp32 graph holds them: 1 - 0.999f is 1.3e-5 away from 0.001)
+    lr, b1, b2, eps = (float(np.float32(x)) for x in (1e-3, 0.9, 0.999, 1e-8))
+    rs = np.random.RandomState(5)
+    P = (rs.standard_normal((B, d)) * 0.3).astype(np.float32)
+    Q = (rs.standard_normal((B, d)) * 0.3).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    # every row of both tables is in the batch: the pending pass owns a gradient row for each
+    u, i, j = (rs.permutation(B).astype(np.int32) for _ in range(3))
+    state = ops.MFState(dev(P), dev(Q), dev(w), dev(wu), ops.make_hyper(lr, 1e-5, 1e-2, 1e-3, 1024), B, lazy_period=1)
+    state.step(oracle.LOSS_RUBIBCEBOTH, dev(u), dev(i), dev(j), defer=True)
+    assert int(state.tP.min()) != 0 and int(state.tQ.min()) != 0
+    g = {}
+    for name, tab, grad in (("P", state.P, state.gP), ("Q", state.Q, state.gQ)):
+        mag = 10.0 ** rs.uniform(-12, -1, size=(B, d))
+        g[name] = (mag * rs.choice([-1.0, 1.0], size=(B, d))).astype(np.float32)
+        grad.copy_(dev(g[name]))                      # the pending pass's gradient rows, replaced
+        tab.zero_()
+    state.flush()
+    lr_t = lr * np.sqrt(1.0 - b2) / (1.0 - b1)
+    discriminated = 0
+    for name, tab, m_, v_ in (("P", state.P, state.mP, state.vP), ("Q", state.Q, state.mQ, state.vQ)):
+        g64 = g[name].astype(np.float64)
+        m, v = (1.0 - b1) * g64, (1.0 - b2) * g64 * g64
+        want = -lr_t * m / (np.sqrt(v) + eps)
+        got = tab.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0, err_msg=name)
+        np.testing.assert_allclose(m_.cpu().numpy(), m, rtol=1e-6, atol=0, err_msg="m" + name)
+        np.testing.assert_allclose(v_.cpu().numpy(), v, rtol=1e-6, atol=1e-44, err_msg="v" + name)
+        # what the bound above excludes: each of these differs from the result by more than 10 % somewhere
+        for wrong in (-lr_t * m / np.sqrt(v + eps),                                                   # epsilon inside the root
+                      -lr * (m / (1.0 - b1)) / (np.sqrt(v / (1.0 - b2)) + eps),                       # Kingma & Ba's epsilon (not epsilon-hat)
+                      -lr * m / (np.sqrt(v) + eps)):                                                  # no bias correction
+            discriminated += int(np.max(np.abs(wrong - got) / np.abs(got)) > 0.1)
+    assert discriminated == 6
+    assert float(state.gP.abs().max()) == 0.0 and float(state.gQ.abs().max()) == 0.0 and int(state.tP.sum()) == 0
+
+
 def test_mf_trajectory_with_ieee_adam():
     """The same 20-step trajectory test against the build whose Adam pass keeps IEEE sqrtf and division
     (macr_amd/csrc/libmacr_hip_ieee.so, -DMACR_ADAM_IEEE) -- in a process of its own: a process binds one library."""

@@ -168,6 +168,41 @@ def test_mf_train_steps_match_literal_adam(kind):
     assert st.power[0] == pytest.approx(0.9 ** 6, rel=1e-6)
 
 
+def test_oracle_adam_known_answers_from_1e_12_to_1e_1():
+    """orc_adam_dense against tf.train.AdamOptimizer's documented rule evaluated in float64 -- lr_t = lr sqrt(1-beta2^t) /
+    (1-beta1^t), theta -= lr_t m / (sqrt(v) + epsilon): epsilon outside the root -- over three steps of gradients of every
+    magnitude from 1e-12 to 1e-1 on tables that start at zero (the value IS the sum of the updates).  Around |g| ~ 3e-7,
+    where sqrt(v) ~ epsilon, the other forms of the rule are off by factors; the -m gpu test of the same name holds the HIP
+    pass to the same answers."""
+    from oracle.oracle import _ptr
+    lr, b1, b2, eps = (float(np.float32(x)) for x in (1e-3, 0.9, 0.999, 1e-8))      # as the fp32 graph holds them
+    rs = np.random.RandomState(5)
+    n = 4096
+    theta, m, v = (np.zeros(n, np.float32) for _ in range(3))
+    power = np.array([b1, b2], np.float32)
+    t64, m64, v64 = (np.zeros(n) for _ in range(3))
+    wrong = np.zeros(n)                                  # epsilon inside the root
+    m_tol = np.zeros(n)
+    for t in range(1, 4):
+        g = (10.0 ** rs.uniform(-12, -1, n) * rs.choice([-1.0, 1.0], n)).astype(np.float32)
+        lr_t = oracle.lib().orc_adam_lr_t(lr, power)
+        oracle.lib().orc_adam_dense(theta, m, v, _ptr(g), n, lr_t, b1, b2, eps)
+        p1, p2 = float(power[0]), float(power[1])
+        assert lr_t == pytest.approx(lr * np.sqrt(1 - p2) / (1 - p1), rel=1e-6)
+        m_terms = np.abs(b1 * m64) + np.abs((1 - b1) * g.astype(np.float64))        # (gradients of either sign: m may cancel)
+        m64 = b1 * m64 + (1 - b1) * g.astype(np.float64)
+        v64 = b2 * v64 + (1 - b2) * g.astype(np.float64) ** 2
+        t64 = t64 - lr * np.sqrt(1 - p2) / (1 - p1) * m64 / (np.sqrt(v64) + eps)
+        wrong = wrong - lr * np.sqrt(1 - p2) / (1 - p1) * m64 / np.sqrt(v64 + eps)
+        power *= np.array([b1, b2], np.float32)
+        m_tol = 2.5e-7 * m_terms + b1 * m_tol            # (three roundings per step on the terms, and what was inherited)
+        assert np.all(np.abs(m - m64) <= m_tol)
+        np.testing.assert_allclose(v, v64, rtol=2e-6, atol=1e-44)
+        # (sums of three updates of either sign: a relative bound on the value, an absolute one where they cancel)
+        np.testing.assert_allclose(theta, t64, rtol=1e-5, atol=1e-9)
+    assert np.max(np.abs(wrong - theta) / np.maximum(np.abs(theta), 1e-12)) > 0.1
+
+
 def _toy_graph(n_users, n_items, seed):
     import scipy.sparse as sp
     rs = np.random.RandomState(seed)
