@@ -148,7 +148,7 @@ void orc_pair_loss_grad(int kind, int B, int d,
         double *dpd = (double *)calloc(B, sizeof(double)), *dnd = (double *)calloc(B, sizeof(double));
         double l_ori = 0;
         const double inv_b2 = 1.0 / ((double)B * (double)B);
-        /* the (B,B) term: X[r,c] = a[r]*p[c], Y[r,c] = b[r]*n[c] */
+        /* the (B,B) term: X[r,c] = p[c]*ssi[r]*ssu[r], Y[r,c] = n[c]*ssj[r]*ssu[r] */
 #pragma omp parallel
         {
             double *dp_loc = (double *)calloc(B, sizeof(double));
@@ -158,7 +158,9 @@ void orc_pair_loss_grad(int kind, int B, int d,
             for (int r = 0; r < B; ++r) {
                 double da_r = 0, db_r = 0;
                 for (int c = 0; c < B; ++c) {
-                    float x = p[c] * a[r], y = n[c] * b[r];
+                    /* model.py:204-205 as written: pos_scores * sigmoid(item) * sigmoid(user), left to right (the
+                     * gradient sums below go through a[r] = ssi*ssu: the same derivative) */
+                    float x = (p[c] * ssi[r]) * ssu[r], y = (n[c] * ssj[r]) * ssu[r];
                     float sx = sigmoidf_(x), sy = sigmoidf_(y);
                     l_loc += (double)(-logf(sx + eps) + -logf((1.0f - sy) + eps));
                     float gx = dneglog_sig(sx, eps), gy = dneglog_1msig(sy, eps);
