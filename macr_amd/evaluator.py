@@ -51,7 +51,6 @@ class Evaluator(object):
         # replaces -- no gain under graph replay (profiles/r05_eval_fold_ab.txt), so off unless asked for.  "1": both, "0": none.
         fold = os.environ.get("MACR_EVAL_FOLD", "p").strip().lower()
         self.fold_prologue, self.fold_metrics = fold in ("1", "p"), fold in ("1", "m")
-        self.poll_results = os.environ.get("MACR_EVAL_POLL", "1") != "0"
         self._topk_mode = None                    # None: the complete call; "first" / "repair": its two halves
         self._repair_bufs = None
         self._last_entry = None
@@ -355,17 +354,12 @@ class Evaluator(object):
     def _means_optimistic_run(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, seeded):
         self._seeded_now = seeded
         self._topk_mode = "first"
-        # The results of a replayed first round land in pinned host memory (means: the last kernel's stores; stats: an earlier
-        # kernel's).  Instead of a stream synchronisation -- whose wake-up is 10-15 us of a 0.4 ms evaluation -- the host
-        # marks those words before the replay and watches them change (MACR_EVAL_POLL=0: synchronise).
-        armed = self.poll_results and self._arm_host_results(flavour, Ks)
         try:
             out = self._means_launch(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, 1, seeded, mode="first")
             first_entry = self._last_entry
         finally:
             self._topk_mode = None
-        if not (armed and first_entry is not None and self._await_host_results(flavour, Ks)):
-            torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream().synchronize()
         self._last_seeded = False                 # (nothing for _seed_feedback to read later)
         relisted = int(self._stats_first[0])
         self._last_info = {"seeded": bool(seeded), "query_blocks_relisted": relisted, "exact_fallback": 0, "redone": relisted != 0}
@@ -390,29 +384,6 @@ class Evaluator(object):
         torch.cuda.current_stream().synchronize()
         self._last_info["exact_fallback"] = int(self._stats_first[1])
         return out.clone()
-
-    _UNWRITTEN = -0x2152411021524111                   # 0xdeadbeefdeadbeef: as a double -1.19e148, which no mean of metrics is
-
-    def _arm_host_results(self, flavour, Ks):
-        """mark the pinned result words of a first-round replay as not yet written; False when they do not exist yet (the
-        call that captures the graph)"""
-        ho = self._host_out.get((flavour, Ks))
-        if ho is None or (flavour, "first") not in {(k[0], k[1]) for k in self._graphs}:
-            return False
-        ho.view(torch.int64).fill_(self._UNWRITTEN)
-        self._stats_first[0] = -1
-        return True
-
-    def _await_host_results(self, flavour, Ks):
-        """spin until the kernels' stores have replaced every mark; False (caller synchronises) if that takes over a second"""
-        import time
-        words = self._host_out[(flavour, Ks)].view(torch.int64).numpy().reshape(-1)
-        stats = self._stats_first.numpy()
-        t0 = time.perf_counter()
-        while stats[0] < 0 or (words == self._UNWRITTEN).any():
-            if time.perf_counter() - t0 > 1.0:
-                return False
-        return True
 
     def last_eval_info(self):
         """What the last evaluation did: {"seeded": its thresholds came from the previous ranking's candidates,
