@@ -1005,9 +1005,16 @@ int launch_propagate(int N, int d, int n_layers, const int32_t *rowptr, const in
         float *Y = last ? nullptr : pairX[l & 1];
         float *sum = pairS[l & 1];
         const float scale = last ? inv : 1.0f;        // running sum lives in E; first layer reads E0 as S_in
+        // The first backward layer's input (dE) is zero outside the batch's rows: the row-sparse form reads only the flagged
+        // rows (a flag lookup per entry, masked gathers), the dense form reads everything and adds zeros -- the same sums up
+        // to the sign of a zero.  With the records of the short rows (d = 64) the dense form is the faster one: 38 against
+        // 46 us per layer, LightGCN step 199.1 -> 190.3 us at the Yelp2018 shape, same box (profiles/r05_lgcn_bwd1_dense_ab.txt).
+        // MACR_LGCN_BWD1_DENSE=0 / 1 forces either (A/B switch); other widths keep the row-sparse form.
+        static const char *bwd1_env = getenv("MACR_LGCN_BWD1_DENSE");
+        const bool bwd1_dense = bwd1_env && (bwd1_env[0] == '0' || bwd1_env[0] == '1') ? bwd1_env[0] == '1' : (d == 64 && plan_dev != nullptr);
         const int mode = !sp ? kDense
                          : (sparse_mode == kSparseOut && last) ? kSparseOut
-                         : (sparse_mode == kSparseIn && l == 0) ? kSparseIn : kDense;
+                         : (sparse_mode == kSparseIn && l == 0 && !bwd1_dense) ? kSparseIn : kDense;
         const bool fused = last && fuse && fuse->T;          // the optimizer in this layer's epilogue: nothing is stored to E
         a.X = X; a.Y = Y; a.S_in = S_in; a.S_out = fused ? nullptr : last ? E : sum; a.scale = scale;
         if (mode != kDense || fused) a.sp = *sp;

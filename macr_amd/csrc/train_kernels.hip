@@ -2743,8 +2743,8 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         return MACR_OK;
     }
     // dE: the gradient w.r.t. the propagated table; the pair kernels ADD into the rows of the batch.  Dense layers: the
-    // whole buffer is cleared here; sparse layers: those rows are zero already (the fused epilogue of the previous step
-    // cleared them, the workspace starts zeroed) and no other row is ever read.
+    // whole buffer is cleared here (and again on return); sparse layers: every row is zero already (the fused epilogue of the
+    // previous step cleared the batch's rows, the workspace starts zeroed).
     if (!sparse) fill_words(ws.dE, nd, 0u, st);
     // pair loss on the propagated rows; items live at rows n_users.. of E
     float *Ei = ws.E + (size_t)n_users * d, *dEi = ws.dE + (size_t)n_users * d;
@@ -2790,5 +2790,7 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     }
     k_adam_dense<false><<<(unsigned)nb, 256, 0, st>>>(a, ws.pair.scal, L);
     MACR_CHECK_LAUNCH("adam_dense", st);
+    // (dE is zero again on return, as after a step with the sparse layers: their first backward layer may read all of it)
+    fill_words(ws.dE, nd, 0u, st);
     return MACR_OK;
 }
