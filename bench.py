@@ -200,34 +200,62 @@ def bench_config4(args, rank, world, dev, emit=True):
                             "includes ~3 us of event overhead" % rows_local}
         try:            # PMC HBM bytes per launch of the same command (tools/profile.sh c4 -> profiles/pmc_latest.json), when it was profiled
             roofline["traffic"] = json.load(open(os.path.join(REPO, "profiles", "pmc_latest.json"))).get("config4", {}).get(adam_name)
+            roofline["traffic_source"] = REPLAYED % "pmc_latest.json[config4]" if roofline["traffic"] else None
         except Exception:
             pass
         if adam_name == "adam_lazy":
+            # The lazy pass does K steps of a row's arithmetic per trip to HBM (SURVEY section 7 sanctions it): its launch does NOT move
+            # the 24*d bytes per row and step, so an HBM fraction of it would exceed 1 and mean nothing.  Its bound is VALU issue:
+            # `frac` = issue-time limit / measured time (<= 1); the bytes it really moves and the algorithmic-bytes rate are
+            # reported beside it under names of their own.
             K = model.lazy_period
             moved = adam_bytes / K + 3.0 * B / world * (24 * d + 4)
             elems = 1.0 * d * rows_local
             valu_us = elems * 13 / 64 * 4.5 / (1024 * 2.4e9) * 1e6
-            roofline.update({"period": K, "moved_bytes_model": moved, "moved_gbps": moved / (adam_us * 1e-6) / 1e9,
-                             "valu_floor_us_model": valu_us,
-                             "note": "lazy dense Adam (period %d): every row still receives every step's update (the algorithmic bytes of SURVEY "
-                                     "8(d): 24*d per row and step), but K steps of a row share ONE trip to HBM -- `achieved` is algorithmic bytes "
-                                     "per second and can exceed the HBM peak; `moved_bytes_model` = a K-th of the shard + the batch's rows is what "
-                                     "a launch really moves; the pass is bound by the VALU time of the same arithmetic (13 instructions per "
-                                     "element and step, ~4.5 cycles each per wave64: `valu_floor_us_model`)" % K})
-            try:        # the pass against the bound it has: VALU issue, from the PMC instruction counts of the same command (tools/profile.sh c4)
+            lim_us, src, detail = valu_us, "model: 13 VALU instructions per element and step, 4.5 cycles each per wave64, 1024 SIMDs at 2.4 GHz", None
+            try:        # instruction counts of the same command under rocprofv3 --pmc (tools/profile.sh c4), issue cycles per class measured on this chip
                 cnt = json.load(open(os.path.join(REPO, "profiles", "pmc_sq_latest.json"))).get("config4", {}).get("adam_lazy")
                 rates = json.load(open(os.path.join(REPO, "profiles", "valu_rates.json"))).get("classes", {}).get("waves_per_simd_2", {})
                 cyc_full = rates.get("v_fma_f32", {}).get("cycles_at_2p4GHz", 4.0)
                 cyc_tr = rates.get("v_exp_f32", {}).get("cycles_at_2p4GHz", 16.0)
                 insts, tr = cnt["SQ_INSTS_VALU"], cnt.get("SQ_INSTS_VALU_TRANS_F32", 2.0 / 13.0 * cnt["SQ_INSTS_VALU"])
-                lim = ((insts - tr) * cyc_full + tr * cyc_tr) / 1024.0 / 2.4e3
-                roofline["valu_issue"] = {"bound": "valu-issue", "valu_wave_insts_per_launch": insts, "transcendental_share": tr / insts,
-                                          "issue_cycles_per_wave_instr": {"full_rate": cyc_full, "transcendental": cyc_tr},
-                                          "issue_limit_us": lim, "frac": lim / adam_us, "avg_us_under_pmc": cnt.get("avg_ns_under_pmc", 0) / 1e3,
-                                          "note": "issue_limit_us = sum over instruction classes of count x measured issue cycles / 1024 SIMDs / 2.4 GHz"}
+                lim_us = ((insts - tr) * cyc_full + tr * cyc_tr) / 1024.0 / 2.4e3
+                src = REPLAYED % "pmc_sq_latest.json[config4][adam_lazy] + valu_rates.json"
+                detail = {"valu_wave_insts_per_launch": insts, "transcendental_share": tr / insts,
+                          "issue_cycles_per_wave_instr": {"full_rate": cyc_full, "transcendental": cyc_tr},
+                          "avg_us_under_pmc": cnt.get("avg_ns_under_pmc", 0) / 1e3}
             except Exception:
                 pass
+            roofline = {"kernel": adam_name, "bound": "valu-issue", "achieved": lim_us, "peak": adam_us, "unit": "us (issue-time limit / measured)",
+                        "frac": min(1.0, lim_us / adam_us), "traffic": roofline["traffic"],
+                        "traffic_source": REPLAYED % "pmc_latest.json[config4]" if roofline["traffic"] else None,
+                        "avg_us": adam_us, "period": K, "issue_limit_us": lim_us, "issue_limit_source": src, "valu_issue": detail,
+                        "valu_floor_us_model": valu_us,
+                        "hbm_moved": {"bytes_per_launch_model": moved, "GBps": moved / (adam_us * 1e-6) / 1e9,
+                                      "frac_of_hbm_peak": moved / (adam_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "a K-th of the shard's theta/m/v + the batch's rows: what one launch really moves"},
+                        "algorithmic_bytes_rate": {"bytes_per_launch": adam_bytes, "GBps": gbps,
+                                                   "note": "SURVEY 8(d)'s 24*d bytes per row and step divided by the launch time: every row still "
+                                                           "receives every step's update, but K steps share one trip to HBM -- NOT a bandwidth and "
+                                                           "not comparable with the HBM peak (it exceeds it by design)"},
+                        "note": "lazy dense Adam (period %d): bound by the VALU time of the K-step arithmetic per row; frac = issue_limit_us / "
+                                "avg_us" % K}
     step_bytes = B * (24 * d + 12) + 24.0 * d * (n_users + n_items)
+    if model.lazy_period > 1:
+        # a lazy step moves a K-th of the tables, not all of them: the whole-step HBM fraction is taken on the bytes a step moves
+        # (<= 1); SURVEY 8(d)'s algorithmic bytes per second are reported under a name of their own
+        moved_step = B * (24 * d + 12) + 24.0 * d * (n_users + n_items) / model.lazy_period + 3.0 * B * (24 * d + 4)
+        g = moved_step / (ms_per_step * 1e-3) / 1e9 / max(world, 1)
+        roofline_step = {"bound": "hbm", "bytes_moved_model": moved_step, "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                         "frac": g / HBM_PEAK_GBS, "algorithmic_bytes": step_bytes,
+                         "algorithmic_bytes_rate_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1),
+                         "note": "lazy dense Adam (period %d): `achieved` / `frac` = the bytes a step really moves (pair part + a K-th of "
+                                 "theta/m/v + the batch's rows) over the step time; algorithmic_bytes_rate_GBps = SURVEY 8(d)'s bytes per "
+                                 "step over the same time, which exceeds the HBM peak by design and is not a bandwidth" % model.lazy_period}
+    else:
+        g = step_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1)
+        roofline_step = {"bound": "hbm", "algorithmic_bytes": step_bytes, "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
+                         "frac": g / HBM_PEAK_GBS}
     # ------------------------------------------------------------- evaluation: item shards + one all-gather
     eval_out = {}
     if not args.no_eval:
@@ -293,14 +321,15 @@ def bench_config4(args, rank, world, dev, emit=True):
                 oracle.mf_train_step(ops.LOSS_RUBIBCEBOTH, (hb[k, 0] % nu).astype(np.int32), (hb[k, 1] % ni).astype(np.int32),
                                      (hb[k, 2] % ni).astype(np.int32), Pc, Qc, wc, wuc, st, lr, regs, alpha, beta, B)
                 n_cpu += 1
-        cpu = {"value": n_cpu * B / (time.perf_counter() - t0), "unit": "interactions/s", "cores": min(32, os.cpu_count() or 1), "kind": "port",
+        cpu = {"value": n_cpu * B / (time.perf_counter() - t0), "unit": "interactions/s", "cores": min(32, os.cpu_count() or 1),
+               "host_cpus": os.cpu_count() or 1, "cpu_model": cpu_model(), "kind": "port",
                "sample": "%d steps of the C port (fast build; B=%d, d=%d) on tables of 1/64 of the rows (%d + %d): the dense Adam "
                          "pass of the full tables would be 64x that part of a step" % (n_cpu, B, d, nu, ni)}
     if rank == 0:
         out = {"metric": "train interactions/sec + eval users/sec (full-catalog top-K@20)",
                "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32", "data": "synthetic", "eval_users_per_s": eval_out.get("eval_users_per_s"),
                "config": {"workload": "configs[4]: synthetic %d users x %d items, MACR-MF rubibceboth d=%d batch=%d c=%g; ONE model, "
                                       "rows sharded over %d rank(s), row r on rank r %% W (training), item-sharded evaluation of %d query users"
                                       % (n_users, n_items, d, B, c, world, args.c4_eval_users),
@@ -321,9 +350,7 @@ def bench_config4(args, rank, world, dev, emit=True):
                    "note": "split step: rows to the slices + gradient rows back (two all-to-alls, this rank, last step) against the "
                            "(3,B,d) buffer the replicated step all-reduces (a ring moves ~2x that per rank)"},
                "collectives_ms": coll, "kernels": kern, "roofline": roofline,
-               "roofline_step": {"bound": "hbm", "algorithmic_bytes": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1),
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU",
-                                 "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / max(world, 1) / HBM_PEAK_GBS},
+               "roofline_step": roofline_step,
                "timed_regions": {"n": len(regions), "reported": "median", "min_ms_per_step": 1e3 * min(regions) / args.steps,
                                  "max_ms_per_step": 1e3 * max(regions) / args.steps},
                "cpu_baseline": cpu, "last_losses": [float(x) for x in last]}
@@ -425,7 +452,11 @@ def bench_lgcn(args, rank, world, dev):
     dense = "spmm_stream" if "spmm_stream" in kern else "spmm_csr"
     dk = kern[dense]
     roofline = {"kernel": dense, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": pmc.get(dense), "avg_us": dk["avg_us"],
+                "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": pmc.get(dense),
+                "traffic_source": (REPLAYED % ("pmc_latest.json[%s][%s]" % (args.workload, dense))) if pmc.get(dense) else None,
+                "avg_us": dk["avg_us"], "avg_us_source": "HIP events on the launch stream, this run",
+                "working_set_bytes": 4 * N * d * 4 + nnz * 8, "resident": "infinity-cache: tables, layer buffers and the adjacency (%.0f MB) stay in the "
+                "256 MiB Infinity Cache; the gather's cost is L2 misses served from it, not HBM" % ((4 * N * d * 4 + nnz * 8) / 1e6),
                 "us_per_step": dk["avg_us"] * dk["launches_per_step"], "algorithmic_bytes": layer_bytes,
                 "note": "one dense propagation layer E' = A E (LightGCN.py:297-305): nnz*8 + (N+1)*4 + 2*N*d*4 compulsory bytes, "
                         "N = %d, nnz = %d; `traffic` = PMC HBM bytes per launch (profiles/pmc_latest.json): the gather misses "
@@ -575,7 +606,7 @@ def bench_lgcn(args, rank, world, dev):
             ev_impl["reference_cpp_ranking_only"] = n_ev / (time.perf_counter() - t0)
         used_torch_threads = torch.get_num_threads()
         torch.set_num_threads(torch_threads0)
-        cpu = {"value": fast_rate, "unit": "interactions/s", "cores": omp_n, "host_cpus": os.cpu_count() or 1, "kind": "port",
+        cpu = {"value": fast_rate, "unit": "interactions/s", "cores": omp_n, "host_cpus": os.cpu_count() or 1, "cpu_model": cpu_model(), "kind": "port",
                "omp_threads_s_per_step": omp_seen,
                "what": "c_port_fast = oracle/macr_oracle.c (orc_lgcn_train_step: CSR SpMM layers forward and backward, pair loss "
                        "and gradients, dense Adam on T), OpenMP, compiled -O3 -march=x86-64-v3 -ffast-math; c_checker = the strict "
@@ -591,7 +622,7 @@ def bench_lgcn(args, rank, world, dev):
         out = {"metric": "train interactions/sec + eval users/sec (full-catalog top-K@20)",
                "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic", "nranks": world,
+               "dtype": "f32", "data": "synthetic", "nranks": world, "eval_users_per_s": eval_out.get("eval_users_per_s"),
                "config": {"workload": "%s-shape MACR-LightGCN %s, %d layers [64,64], d=%d batch=%d c=%g (n_users=%d, n_items=%d, "
                                       "N=%d nodes, nnz=%d = 2*n_train, `pre` adjacency); synthetic graph (lognormal user degrees, Zipf "
                                       "items), Xavier tables, batches as sampled"
@@ -607,6 +638,21 @@ def bench_lgcn(args, rank, world, dev):
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+REPLAYED = "profiles/%s -- rocprofv3 passes of the same command committed earlier (tools/profile.sh), NOT collected by this run"
+
+
+def cpu_model():
+    """model string of the host CPU the baseline legs run on"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def omp_set_threads(n):
@@ -715,7 +761,7 @@ def cpu_baseline_mf(args, kind, cfg, P, Q, w, wu, hb, users, mask_lists, gt_list
         ev["torch_graph_error"] = repr(e)
     used_torch_threads = _t.get_num_threads()
     _t.set_num_threads(torch_threads0)
-    return {"value": fast_rate, "unit": "interactions/s", "cores": omp_n, "host_cpus": os.cpu_count() or 1, "kind": "port",
+    return {"value": fast_rate, "unit": "interactions/s", "cores": omp_n, "host_cpus": os.cpu_count() or 1, "cpu_model": cpu_model(), "kind": "port",
             "what": "c_port_fast = oracle/macr_oracle.c, OpenMP, compiled -O3 -march=x86-64-v3 -ffast-math (vectorised "
                     "expf/logf); gradient tables persistent (no per-step calloc); `cores` = the OpenMP thread count that was "
                     "fastest on this host (omp_threads_s_per_step: what each candidate took)",
@@ -745,7 +791,11 @@ def roofline_bxb(workload, B, kern_avg):
     sq = (load("pmc_sq_latest.json") or {}).get(workload, {})
     mix = load("bxb_isa_mix.json") or {}
     rates = load("valu_rates.json") or {}
-    out = {"bound": "valu-issue", "pairs": B * B, "fused_bce_evaluations": 2 * B * B, "simds": 1024, "peak_clock_ghz": 2.4}
+    out = {"bound": "valu-issue", "pairs": B * B, "fused_bce_evaluations": 2 * B * B, "simds": 1024, "peak_clock_ghz": 2.4,
+           "sources": {"avg_us / gevals_per_s": "HIP events, this run",
+                       "pmc, valu_wave_insts_per_launch, transcendental_share_measured": REPLAYED % ("pmc_sq_latest.json[%s]" % workload),
+                       "static_mix": "profiles/bxb_isa_mix.json -- tools/isa_mix.py on the code object, committed; not this run",
+                       "issue_cycles_per_wave_instr": "profiles/valu_rates.json -- tools/valu_rate_bench.hip on an MI355X, committed; not this run"}}
     # static mix: the kernel's two pair loops (6- and 4-transcendental forms), R = 4 rows per lane
     loops = []
     for name, k in mix.items():
@@ -909,13 +959,15 @@ def main():
     run_steps(n_prof, 0)
     marks = ops.timing_end(max_n=n_prof * 8 + 8)
     # The Adam pass on its own (complete steps, flags=0): in deferred mode it only runs stand-alone at the flush.
-    alone = []
+    alone, bxb_warm = [], []
     if kind == ops.LOSS_RUBIBCEBOTH and not args.no_defer:
         ops.timing_begin()
         for s_ in range(10):
             k_ = s_ % n_batches
             state.step(kind, batches[k_, 0], batches[k_, 1], batches[k_, 2], loss_log[k_], defer=False)
-        alone = [ms for name, ms in ops.timing_end(max_n=64) if name == "adam_dense"]
+        marks_alone = ops.timing_end(max_n=64)
+        alone = [ms for name, ms in marks_alone if name == "adam_dense"]
+        bxb_warm = [ms for name, ms in marks_alone if name == "bxb"][2:]    # the (B,B) launch WITHOUT Adam blocks, warm (complete steps)
     kernels = {}
     for name, ms in marks:
         k = kernels.setdefault(name, [0, 0.0])
@@ -927,6 +979,12 @@ def main():
     for v in kern_avg.values():
         v["avg_us"] = max(v["event_us"] - event_overhead_us, 0.1)
     step_kernel_us = sum(v["avg_us"] * v["launches_per_step"] for v in kern_avg.values())
+    if bxb_warm and "bxb" in kern_avg:
+        # in deferred mode the (B,B) launch without Adam blocks runs once per region, cold (the first step's): its warm time
+        # comes from the complete steps above (same kernel, same batches), which is what rocprofv3 averages
+        kern_avg["bxb"]["cold_first_launch_us"] = kern_avg["bxb"]["avg_us"]
+        kern_avg["bxb"]["avg_us"] = max(1e3 * sum(bxb_warm) / len(bxb_warm) - event_overhead_us, 0.1)
+        kern_avg["bxb"]["avg_us_source"] = "%d warm launches of complete (non-deferred) steps, this run" % len(bxb_warm)
     pmc = {}
     pmc_path = os.path.join(REPO, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
@@ -945,11 +1003,22 @@ def main():
     per_step_us = {n: v["avg_us"] * v["launches_per_step"] for n, v in kern_avg.items()}
     dom = max(per_step_us, key=per_step_us.get)
 
+    # theta, m, v of both tables + the gradient tables: what a step touches, step after step
+    working_set = 4 * d * (cfg["n_users"] + cfg["n_items"]) * 4
+    resident = ("infinity-cache: the %.0f MB working set of a step stays in the 256 MiB Infinity Cache from step to step, so `achieved` is "
+                "algorithmic bytes / time against the HBM peak, NOT evidence of HBM traffic at that rate; the same pass on tables that "
+                "cannot stay on chip is roofline_aux.adam_dense_out_of_cache (measured in this run)" % (working_set / 1e6)
+                ) if working_set < 256 * 2 ** 20 else "hbm: the working set (%.0f MB) exceeds the 256 MiB Infinity Cache" % (working_set / 1e6)
+
     def roof(name, avg_us, ab):
         gbps = ab / (avg_us * 1e-6) / 1e9
+        tr = pmc.get(args.workload, {}).get(name)
         return {"kernel": name, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbps / HBM_PEAK_GBS, "traffic": pmc.get(args.workload, {}).get(name), "avg_us": avg_us,
-                "us_per_step": per_step_us.get(name), "algorithmic_bytes": ab}
+                "frac": gbps / HBM_PEAK_GBS, "traffic": tr,
+                "traffic_source": (REPLAYED % ("pmc_latest.json[%s][%s]" % (args.workload, name))) if tr else None,
+                "avg_us": avg_us, "avg_us_source": "HIP events on the launch stream, this run",
+                "us_per_step": per_step_us.get(name), "algorithmic_bytes": ab,
+                "working_set_bytes": working_set, "resident": resident}
     if "algorithmic_bytes" in kern_avg[dom]:
         roofline = roof(dom, kern_avg[dom]["avg_us"], kern_avg[dom]["algorithmic_bytes"])
         if dom == "bxb+adam":
@@ -959,6 +1028,7 @@ def main():
     else:   # a launch without HBM work dominates (e.g. non-deferred bxb): report it as such, no bandwidth claim
         roofline = {"kernel": dom, "bound": "valu", "achieved": kern_avg[dom].get("gevals_per_s"), "peak": None,
                     "unit": "G fused-BCE evaluations/s", "frac": None, "traffic": pmc.get(args.workload, {}).get(dom),
+                    "traffic_source": (REPLAYED % "pmc_latest.json") if pmc.get(args.workload, {}).get(dom) else None,
                     "avg_us": kern_avg[dom]["avg_us"], "us_per_step": per_step_us[dom]}
     # the whole step against the HBM roofline: SURVEY.md 8(d) B*(24d+12) + 24d*(n_users+n_items) bytes per step
     step_bytes = B * (24 * d + 12) + 24 * d * (cfg["n_users"] + cfg["n_items"])
@@ -969,6 +1039,34 @@ def main():
         us = max(1e3 * sum(alone) / len(alone) - event_overhead_us, 0.1)
         aux["adam_dense_alone"] = roof("adam_dense", us, algorithmic_bytes("adam_dense", cfg, B))
         aux["adam_dense_alone"]["launches_sampled"] = len(alone)
+
+    # The same dense Adam pass where the tables CANNOT stay in the Infinity Cache: 2.4 M rows of d floats (theta, m, v, gradient
+    # tables; 3.7 GB of algorithmic bytes per step), complete `normalbce` steps, event-timed here.  The out-of-cache companion of `roofline`.
+    if not args.no_defer:
+        try:
+            big_u, big_i = 1_900_000, 500_000
+            gb = torch.Generator(device=dev).manual_seed(7)
+            big = ops.MFState(synth.xavier_table(big_u, d, gb, dev), synth.xavier_table(big_i, d, gb, dev), w.clone(), wu.clone(),
+                              hyper, B, lazy_period=1)
+            bb = synth.train_batches(4, big_u, big_i, B, gb, dev)
+            for k_ in range(3):
+                big.step(ops.LOSS_NORMALBCE, bb[k_ % 4, 0], bb[k_ % 4, 1], bb[k_ % 4, 2])
+            ops.timing_begin()
+            for k_ in range(8):
+                big.step(ops.LOSS_NORMALBCE, bb[k_ % 4, 0], bb[k_ % 4, 1], bb[k_ % 4, 2])
+            ms_big = [ms for name, ms in ops.timing_end(max_n=64) if name == "adam_dense"]
+            ab_big = 24 * d * (big_u + big_i)
+            us_big = max(1e3 * sum(ms_big) / len(ms_big) - event_overhead_us, 0.1)
+            aux["adam_dense_out_of_cache"] = {
+                "kernel": "adam_dense", "bound": "hbm", "achieved": ab_big / (us_big * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ab_big / (us_big * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_us": us_big, "algorithmic_bytes": ab_big,
+                "working_set_bytes": 4 * d * (big_u + big_i) * 4, "resident": "hbm (working set 10x the Infinity Cache)",
+                "launches_sampled": len(ms_big), "source": "measured in this run",
+                "note": "the pass `roofline` prices, on %d + %d rows of d=%d: every byte comes from and goes to HBM" % (big_u, big_i, d)}
+            del big, bb
+            torch.cuda.empty_cache()
+        except Exception as e:                                   # (a diagnostic leg must not take the line with it)
+            aux["adam_dense_out_of_cache"] = {"error": repr(e)[:200]}
 
     # ------------------------------------------------------------- end to end: the device sampler feeds the step
     end_to_end = None
@@ -1090,6 +1188,7 @@ def main():
             roofline_eval = {"kernel": "+".join(k for k in rank_kernels if k in ek), "bound": "mfma",
                              "achieved": flops / (st_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "avg_us": st_us, "flops": flops, "traffic": pmc.get(args.workload, {}).get("score_stream"),
+                             "traffic_source": (REPLAYED % ("pmc_latest.json[%s][score_stream]" % args.workload)) if pmc.get(args.workload, {}).get("score_stream") else None,
                              "stream": {"avg_us": stream_us, "achieved": flops / (stream_us * 1e-6) / 1e12,
                                         "frac": flops / (stream_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS},
                              "kernels_us": {k: 1e3 * v for k, v in ek.items()}, "mode": ev_kernel_mode}
@@ -1140,6 +1239,7 @@ def main():
                                   "stream": {"avg_us": sb, "executed_flops": mult * rb["flops"],
                                              "achieved": mult * rb["flops"] / (sb * 1e-6) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                                              "unit": "TFLOP/s", "frac": mult * rb["flops"] / (sb * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+                                  "eval_users_per_s": suite["eval_users_per_s"],
                                   "speedup_vs_f32_filter": suite["eval_users_per_s"] / suite_f32["eval_users_per_s"],
                                   "note": "same ranking as the f32 filter, bit for bit: bf16 products only pick candidates, "
                                           "the best 64 per query are re-scored in fp32 (DESIGN.md, ranking note)"}
@@ -1212,13 +1312,13 @@ def main():
             "value": value, "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "eval_users_per_s": eval_users_per_s,
             "nranks": 1 if multi is None else multi["nranks"], "multi_gpu": multi,
             "config": {"workload": "%s-shape MACR-MF %s d=%d batch=%d c=%g (n_users=%d, n_items=%d); synthetic "
                                    "Xavier tables, Zipf positives, batches as sampled (grouped on the device inside the step)" % (args.workload, args.train, d, B, cfg["c"],
                                                                       cfg["n_users"], cfg["n_items"]),
                        "parallelism": "replicas x%d (train) / item-sharded x%d + RCCL all-gather (eval)" % (world, world),
                        "global_batch": B * world},
-            "eval_users_per_s": eval_users_per_s,
             "eval": eval_summary,
             "sharded_figure": {"name": "eval_users_per_s", "value": eval_users_per_s, "scaling": "strong",
                                "note": "`value` counts N independent training replicas (these configs' step fits one GPU: "

@@ -193,6 +193,7 @@ def main(sweep=False):
         # the batch of step k is a function of (seed, k): continue the sequences instead of replaying epoch 1's batches
         device_sampler.step = resumed['sampler_step'] if resumed else (start_epoch - 1) * n_batch
         test_sampler.step = resumed['test_sampler_step'] if resumed else ((start_epoch - 1) // args.log_interval) * n_batch
+    users_to_test = list(data_generator.test_set.keys())      # one list object per run: test() finds its evaluator by identity
     for epoch in range(start_epoch, args.epoch + 1):
         t1 = time()
         loss, mf_loss, emb_loss = train_epoch(model, kind, n_batch, loss_log, device_sampler)
@@ -207,7 +208,6 @@ def main(sweep=False):
         # the reference's "test loss" pass (:799-819): n_batch loss-only runs on sample_test() batches
         loss_test, mf_loss_test, emb_loss_test = train_epoch(model, kind, n_batch, loss_log, test_sampler, test_loss=True)
         t2 = time()
-        users_to_test = list(data_generator.test_set.keys())
         sharding.broadcast_params(model.parameters())       # item-sharded evaluation scores ONE model (rank 0's)
         perf_str = ''
         if args.test == 'normal':

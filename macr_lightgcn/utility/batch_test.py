@@ -11,6 +11,7 @@ from evaluator import eval_score_matrix_foldout  # noqa: F401
 
 from macr_amd import ops
 from macr_amd.evaluator import Evaluator
+from macr_amd.eval_cache import EvaluatorCache
 
 cores = multiprocessing.cpu_count() // 2
 args = parse_args()
@@ -20,8 +21,16 @@ N_TRAIN, N_TEST = data_generator.n_train, data_generator.n_test
 BATCH_SIZE = args.batch_size
 
 _METHODS = {"normal": ops.SCORE_NORMAL, "rubiboth": ops.SCORE_RUBI_BOTH}
-_MAX_CACHED = 4
-_evaluators = {}
+_evaluators = EvaluatorCache(max_cached=4)
+
+
+def _evaluator_for(model, users_to_test):
+    """(Evaluator, device user ids) of this user list; built once per list (macr_amd/eval_cache.py)"""
+    def build(users):
+        mask, gt = data_generator.eval_lists(users)
+        return (Evaluator(mask, gt, ITEM_NUM, model.device),
+                torch.tensor(list(users), dtype=torch.int32, device=model.device))
+    return _evaluators.get("test", users_to_test, build)
 
 
 def test(sess, model, users_to_test, drop_flag=False, train_set_flag=0, method="normal"):
@@ -33,15 +42,7 @@ def test(sess, model, users_to_test, drop_flag=False, train_set_flag=0, method="
         raise NotImplementedError("method %r is outside the MI355X hot path (normal | rubiboth)" % method)
     if train_set_flag != 0:
         raise NotImplementedError("train_set_flag != 0 is unused by the reference CLI")
-    key = hash(tuple(users_to_test))             # the whole list: the reference's test() is stateless
-    ev = _evaluators.get(key)
-    if ev is None:
-        if len(_evaluators) >= _MAX_CACHED:
-            _evaluators.clear()
-        mask, gt = data_generator.eval_lists(users_to_test)
-        ev = _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
-                                 torch.tensor(list(users_to_test), dtype=torch.int32, device=model.device))
-    evaluator, uid = ev
+    evaluator, uid = _evaluator_for(model, users_to_test)
     ua, ia = model.propagated()
     ret = evaluator.test_lgcn(_METHODS[method], ua, uid, ia.contiguous(), model.Ks, model.w, model.w_user,
                               model.rubi_c)
@@ -54,14 +55,7 @@ def test_sweep(sess, model, users_to_test, cs, method="rubiboth"):
     listing pass in groups of four (macr_score_topk_sweep)."""
     if _METHODS.get(method, ops.SCORE_NORMAL) == ops.SCORE_NORMAL:
         raise NotImplementedError("method %r has no c to sweep" % method)
-    key = hash(tuple(users_to_test))
-    if key not in _evaluators:
-        if len(_evaluators) >= _MAX_CACHED:
-            _evaluators.clear()
-        mask, gt = data_generator.eval_lists(users_to_test)
-        _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
-                            torch.tensor(list(users_to_test), dtype=torch.int32, device=model.device))
-    evaluator, uid = _evaluators[key]
+    evaluator, uid = _evaluator_for(model, users_to_test)
     ua, ia = model.propagated()
     rets = evaluator.test_lgcn_sweep(_METHODS[method], ua, uid, ia.contiguous(), model.Ks, model.w, model.w_user, list(cs))
     return [{k: np.asarray(v) for k, v in r.items()} for r in rets]

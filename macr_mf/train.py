@@ -24,6 +24,7 @@ from model import BPRMF, Session
 
 from macr_amd import ops
 from macr_amd.evaluator import Evaluator
+from macr_amd.eval_cache import EvaluatorCache
 from macr_amd.metrics_host import (precision_at_k, dcg_at_k, ndcg_at_k, recall_at_k, hit_at_k,   # noqa: F401
                                    get_performance)
 
@@ -32,8 +33,20 @@ logging.getLogger().setLevel(logging.INFO)
 # model_type of the reference's test() (train.py:222-259) -> score kind
 _MODEL_TYPES = {'o': ops.SCORE_NORMAL, 'rubi_both': ops.SCORE_RUBI_BOTH, 'rubi_c': ops.SCORE_RUBI,
                 'direct_minus_c': ops.SCORE_DIRECT_MINUS}
-_evaluators = {}
-_MAX_CACHED = 4
+_evaluators = EvaluatorCache(max_cached=4)
+
+
+def _evaluator_for(model, test_users, valid_set):
+    """(Evaluator, device user ids) of this user list; built once per list (macr_amd/eval_cache.py: keyed by the list object,
+    by content the first time a list is seen -- the reference's test() is stateless, so any list may arrive)"""
+    def build(users):
+        mask, gt = data.eval_lists(users, valid_set)
+        ev = (Evaluator(mask, gt, ITEM_NUM, model.device),
+              torch.tensor(list(users), dtype=torch.int32, device=model.device))
+        if getattr(model, "sharded", False):         # --row_shard 1: the item table this rank holds IS its item shard
+            ev[0].set_local_items(model.own_i)
+        return ev
+    return _evaluators.get(valid_set, test_users, build)
 
 
 def test(sess, model, test_users, batch_test_flag=False, model_type='o', valid_set="test",
@@ -43,17 +56,7 @@ def test(sess, model, test_users, batch_test_flag=False, model_type='o', valid_s
     sess, batch_test_flag, item_pop_test, pop_exp are accepted for compatibility."""
     if model_type not in _MODEL_TYPES:
         raise NotImplementedError("model_type %r is outside the MI355X hot path (%s)" % (model_type, sorted(_MODEL_TYPES)))
-    key = (valid_set, hash(tuple(test_users)))       # the whole list: the reference's test() is stateless
-    ev = _evaluators.get(key)
-    if ev is None:
-        if len(_evaluators) >= _MAX_CACHED:
-            _evaluators.clear()
-        mask, gt = data.eval_lists(test_users, valid_set)
-        ev = _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
-                                 torch.tensor(list(test_users), dtype=torch.int32, device=model.device))
-        if getattr(model, "sharded", False):         # --row_shard 1: the item table this rank holds IS its item shard
-            ev[0].set_local_items(model.own_i)
-    evaluator, uid = ev
+    evaluator, uid = _evaluator_for(model, test_users, valid_set)
     model.sync()
     if getattr(model, "sharded", False):
         return evaluator.test_mf(_MODEL_TYPES[model_type], model.query_rows(uid), None, model.item_embedding, Ks,
@@ -67,16 +70,7 @@ def test_sweep(sess, model, test_users, cs, model_type='rubi_both', valid_set="t
     enters the score epilogue, so the values share the listing pass in groups of four (macr_score_topk_sweep)."""
     if model_type not in _MODEL_TYPES or _MODEL_TYPES[model_type] == ops.SCORE_NORMAL:
         raise NotImplementedError("model_type %r has no c to sweep" % model_type)
-    key = (valid_set, hash(tuple(test_users)))
-    if key not in _evaluators:                       # build (and cache) the evaluator exactly as test() does
-        if len(_evaluators) >= _MAX_CACHED:
-            _evaluators.clear()
-        mask, gt = data.eval_lists(test_users, valid_set)
-        _evaluators[key] = (Evaluator(mask, gt, ITEM_NUM, model.device),
-                            torch.tensor(list(test_users), dtype=torch.int32, device=model.device))
-        if getattr(model, "sharded", False):
-            _evaluators[key][0].set_local_items(model.own_i)
-    evaluator, uid = _evaluators[key]
+    evaluator, uid = _evaluator_for(model, test_users, valid_set)
     model.sync()
     if getattr(model, "sharded", False):
         return evaluator.test_mf_sweep(_MODEL_TYPES[model_type], model.query_rows(uid), None, model.item_embedding, Ks,
@@ -226,6 +220,9 @@ def main(sweep=False):
     if device_sampler is not None and start_epoch:
         # the batch of step k is a function of (seed, k): continue the sequence instead of replaying epoch 0's batches
         device_sampler.step = resumed['sampler_step'] if resumed else start_epoch * n_batch
+    # (the reference rebuilds this list at every evaluation, train.py:505-516; one object per run keeps test()'s evaluator
+    # lookup at an identity check)
+    users_to_test = list((data.test_user_list if args.valid_set == "test" else data.valid_user_list).keys())
     for epoch in range(start_epoch, args.epoch):
         t1 = time()
         loss, mf_loss, reg_loss = train_epoch(model, kind, n_batch, loss_log, device_sampler)
@@ -238,7 +235,6 @@ def main(sweep=False):
             continue
 
         t2 = time()
-        users_to_test = list((data.test_user_list if args.valid_set == "test" else data.valid_user_list).keys())
         sharding.broadcast_params(model.parameters())       # item-sharded evaluation scores ONE model (rank 0's)
         tail = ('train==[%.8f=%.8f + %.8f], recall=[%.5f, %.5f], precision=[%.5f, %.5f], hit=[%.5f, %.5f], '
                 'ndcg=[%.5f, %.5f]')

@@ -274,6 +274,60 @@ def test_lightgcn_cli_addressa(tmp_path):
     assert not [f for f in os.listdir(os.path.join(REPO, "data", "addressa")) if f.endswith(".npz")]
 
 
+def test_clis_abort_on_nan_loss(tmp_path):
+    """the reference stops a run whose epoch loss is NaN (`ERROR: loss is nan.` + sys.exit(): macr_mf/train.py:500-502,
+    macr_lightgcn/LightGCN.py:783-785).  A learning rate of 1e30 overflows the tables within two steps (inf - inf in the
+    next gradients): both CLIs must print the line, stop before --epoch is reached and exit with status 0 like sys.exit()."""
+    os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
+    out = _run_cli([os.path.join(REPO, "macr_mf", "train.py"), "--dataset", "addressa", "--batch_size", "1024",
+                    "--cuda", "0", "--saveID", "n", "--log_interval", "1", "--lr", "1e30", "--epoch", "6", "--verbose", "1",
+                    "--train", "rubibceboth", "--test", "rubi", "--c", "40", "--save_flag", "0"], str(tmp_path))
+    assert "ERROR: loss is nan." in out, out[-2000:]
+    assert out.count("train==[") < 6, out[-2000:]
+    out = _run_cli([os.path.join(REPO, "macr_lightgcn", "LightGCN.py"), "--data_path", os.path.join(REPO, "data") + "/",
+                    "--dataset", "addressa", "--verbose", "1", "--layer_size", "[64,64]", "--Ks", "[20]", "--loss", "bceboth",
+                    "--test", "rubiboth", "--c", "40", "--epoch", "6", "--lr", "1e30", "--batch_size", "1024", "--gpu_id", "0",
+                    "--log_interval", "1", "--save_flag", "0", "--weights_path", str(tmp_path) + "/"], str(tmp_path))
+    assert "ERROR: loss is nan." in out, out[-2000:]
+    assert out.count("train==[") < 6, out[-2000:]
+
+
+def test_cli_test_finds_its_evaluator_by_list_identity(tmp_path):
+    """macr_mf/train.py::test() is stateless like the reference's (:162): any list may arrive.  The evaluator is built once per
+    list; a second call with the SAME list object must not hash the list again, an equal list in a new object is found by
+    content, a different list gets its own evaluator -- and all of them rank like a fresh evaluator."""
+    code = r'''
+import sys, os
+os.chdir("%s"); sys.argv = ["train.py", "--dataset", "addressa", "--batch_size", "1024", "--train", "rubibceboth", "--test", "rubi"]
+sys.path.insert(0, "%s")
+import numpy as np, torch
+import train as cli
+from model import BPRMF, Session
+model = BPRMF(cli.args, dict(n_users=cli.data.n_users, n_items=cli.data.n_items), seed=3)
+sess = Session(model)
+users = list(cli.data.test_user_list.keys())
+r1 = cli.test(sess, model, users, model_type="rubi_both")
+n0 = cli._evaluators.content_lookups
+r2 = cli.test(sess, model, users, model_type="rubi_both")
+assert cli._evaluators.content_lookups == n0, "same list object: no content hash"
+r3 = cli.test(sess, model, list(users), model_type="rubi_both")
+assert cli._evaluators.content_lookups == n0 + 1 and len(cli._evaluators) == 1
+half = users[: len(users) // 2]
+r4 = cli.test(sess, model, half, model_type="rubi_both")
+assert len(cli._evaluators) == 2
+users2 = list(users); users2[0], users2[1] = users2[1], users2[0]       # same users, another order: another list
+r5 = cli.test(sess, model, users2, model_type="rubi_both")
+for k in r1:
+    assert np.array_equal(r1[k], r2[k]) and np.array_equal(r1[k], r3[k])
+    assert np.allclose(r1[k], r5[k], rtol=1e-12)
+assert not np.array_equal(r1["recall"], r4["recall"])
+print("OK", float(r1["hit_ratio"][0]))
+''' % (str(tmp_path), os.path.join(REPO, "macr_mf"))
+    os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_clis_take_Ks_beyond_32(tmp_path):
     """--Ks "[20,50,100]" (the reference takes any list: macr_mf/parse.py:31, utility/parser.py:63) through both CLIs"""
     os.symlink(os.path.join(REPO, "data"), tmp_path / "data")
