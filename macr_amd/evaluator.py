@@ -363,6 +363,12 @@ class Evaluator(object):
         self._last_seeded = False                 # (nothing for _seed_feedback to read later)
         relisted = int(self._stats_first[0])
         self._last_info = {"seeded": bool(seeded), "query_blocks_relisted": relisted, "exact_fallback": 0, "redone": relisted != 0}
+        if self.__dict__.pop("_complete_ran", False):
+            # graph replay was just switched off and the COMPLETE sequence ran in place of the first round: what it relisted and
+            # whether it fell back are in its own statistics (the bf16 back-off must see a fallback there too)
+            st = self._stats.tolist()
+            self._last_info.update(query_blocks_relisted=st[0], exact_fallback=st[1])
+            return out.clone()
         if relisted == 0:
             self.fast_stats["fast"] += 1
             if seeded:
@@ -411,13 +417,21 @@ class Evaluator(object):
         entry = self._graphs.get(key)
         if entry is None:
             # capturing costs about two evaluations: callers that keep changing the sequence are better off launching directly
+            # Misses are counted per evaluation SHAPE (tables, query set, score kind, Ks, stream): one shape legitimately needs up
+            # to 8 graphs (first / repair round x candidate filter x seeded or not), so a run that evaluates two query sets and
+            # meets a back-off must not lose graph replay.  A caller whose tensors change from call to call shows up as many
+            # shapes, or as one shape asking for more graphs than its key space has.
+            shape_key = (flavour, kind) + key[5:]
+            misses = self.__dict__.setdefault("_graph_misses_by_shape", {})
+            misses[shape_key] = misses.get(shape_key, 0) + 1
             self._graph_misses += 1
-            if self._graph_misses > 12:
+            if misses[shape_key] > 8 or len(misses) > 8:
                 self.use_graph = False
                 self._graphs.clear()
                 if mode == "first":
                     self._topk_mode = None        # (the complete sequence: its result needs no check)
                     self._stats_first.zero_()
+                    self._complete_ran = True     # (its own statistics are in self._stats: _means_optimistic_run reads them)
                 return self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)
             self._direct(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c)     # warm-up: allocations, caches, attributes
             torch.cuda.synchronize()

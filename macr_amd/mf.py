@@ -266,7 +266,9 @@ class ShardedBPRMF(object):
         without a device synchronisation: sharded_train.RowShardedMF.route_counts_host)"""
         arr = np.asarray([users, pos_items, neg_items], dtype=np.int32)
         dev = torch.from_numpy(np.ascontiguousarray(arr)).pin_memory().to(self.device, non_blocking=True)
-        self._host_batch = (dev.data_ptr(), arr)
+        # the host copy travels WITH the tensor object (an attribute), not keyed by its address: the caching allocator hands the
+        # same address to the next (3,B) tensor, and a batch from another source must never meet a stale host copy
+        dev._macr_host_batch = arr
         return dev
 
     def update_c(self, sess, c):
@@ -275,9 +277,9 @@ class ShardedBPRMF(object):
     def train_step(self, kind, batch, losses=None, defer=False):
         m = self._model(kind)
         counts = None
-        hb = getattr(self, "_host_batch", None)
-        if hb is not None and hb[0] == batch.data_ptr() and self.world > 1 and m.split and kind != ops.LOSS_NORMALBCE:
-            counts = m.route_counts_host(hb[1][0], hb[1][1], hb[1][2])
+        hb = getattr(batch, "_macr_host_batch", None)        # set by to_device_batch on THIS tensor object only
+        if hb is not None and hb.shape == tuple(batch.shape) and self.world > 1 and m.split and kind != ops.LOSS_NORMALBCE:
+            counts = m.route_counts_host(hb[0], hb[1], hb[2])
         out = m.step(batch[0], batch[1], batch[2], counts=counts)
         if losses is not None:
             losses.copy_(out)

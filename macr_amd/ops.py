@@ -545,14 +545,14 @@ class MFState(object):
         self.lazy_period = lazy_period        # None: decided per deferred sequence from its batch size
         self._seq_lazy = None                 # struct macr_lazy_adam of the running deferred sequence (None: the dense form)
         self._lazy_bufs = None
-        self.P, self.Q = P.contiguous(), Q.contiguous()
+        self._P, self._Q = P.contiguous(), Q.contiguous()
         self.w, self.wu = w.reshape(-1).contiguous(), wu.reshape(-1).contiguous()
         self.hyper = hyper
         self.d = P.shape[1]
         z = torch.zeros_like
-        self.mP, self.vP, self.mQ, self.vQ = z(self.P), z(self.P), z(self.Q), z(self.Q)
+        self.mP, self.vP, self.mQ, self.vQ = z(self._P), z(self._P), z(self._Q), z(self._Q)
         self.mw, self.vw, self.mwu, self.vwu = z(self.w), z(self.w), z(self.wu), z(self.wu)
-        self.gP, self.gQ = z(self.P), z(self.Q)
+        self.gP, self.gQ = z(self._P), z(self._Q)
         self.tP = torch.zeros(P.shape[0], dtype=_i32, device=dev)
         self.tQ = torch.zeros(Q.shape[0], dtype=_i32, device=dev)
         self.adam_pow = torch.tensor([hyper.beta1, hyper.beta2], dtype=_f32, device=dev)
@@ -569,10 +569,34 @@ class MFState(object):
             nbytes = _lib.lib().macr_mf_train_workspace_bytes(B, self.d)
             if nbytes == 0:
                 raise MacrError(_lib.E_UNSUPPORTED, "embed_size %d not in {32,64,128,256}" % self.d)
-            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.P.device)
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self._P.device)
             self.batch_cap = B
 
-    _TABLE_NAMES = ("P", "Q", "w", "wu", "mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu", "gP", "gQ", "tP", "tQ")
+    _TABLE_NAMES = ("_P", "_Q", "w", "wu", "mP", "vP", "mQ", "vQ", "mw", "vw", "mwu", "vwu", "gP", "gQ", "tP", "tQ")
+
+    # P and Q as READERS see them: inside a deferred sequence with the lazy Adam pass individual rows are between 0 and K steps
+    # behind (not merely one step old, inconsistent row to row), so reading a table attribute brings every row to the last step
+    # first.  The kernels and this class use the raw `_P` / `_Q`.  (A deferred sequence with the DENSE pass leaves the tables one
+    # whole step old until flush(), as documented at step().)
+    @property
+    def P(self):
+        if self._seq_lazy is not None and self.pending_B:
+            self.flush()
+        return self._P
+
+    @P.setter
+    def P(self, value):
+        self._P = value
+
+    @property
+    def Q(self):
+        if self._seq_lazy is not None and self.pending_B:
+            self.flush()
+        return self._Q
+
+    @Q.setter
+    def Q(self, value):
+        self._Q = value
 
     def __setattr__(self, name, value):
         # assigning one of the tables (state.P = ...) drops the cached raw pointers
@@ -590,7 +614,7 @@ class MFState(object):
         sixteen data_ptr() round trips per call were 8 us of it)"""
         if getattr(self, "_tab_ptrs", None) is None:
             object.__setattr__(self, "_tab_ptrs", tuple(_ptr(getattr(self, n)) for n in self._TABLE_NAMES))
-            self._dev_index = self.P.device.index if self.P.device.index is not None else torch.cuda.current_device()
+            self._dev_index = self._P.device.index if self._P.device.index is not None else torch.cuda.current_device()
             self._pow_ptr = _ptr(self.adam_pow)
         return self._tab_ptrs
 
@@ -612,12 +636,12 @@ class MFState(object):
             self._seq_lazy = self._lazy_struct(B) if defer else None
         if self._seq_lazy is not None:
             check(_lib.lib().macr_mf_train_step_lazy(
-                kind, B, self.d, self.P.shape[0], self.Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
+                kind, B, self.d, self._P.shape[0], self._Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
                 *tabs, self._pow_ptr, ctypes.byref(self.hyper),
                 _ptr(out, _f32), flags, ctypes.byref(self._seq_lazy), _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
         else:
             check(_lib.lib().macr_mf_train_step(
-                kind, B, self.d, self.P.shape[0], self.Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
+                kind, B, self.d, self._P.shape[0], self._Q.shape[0], _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
                 *tabs, self._pow_ptr, ctypes.byref(self.hyper),
                 _ptr(out, _f32), flags, _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
         self.pending_B = B if defer else 0
@@ -626,13 +650,13 @@ class MFState(object):
 
     def _lazy_struct(self, B):
         """struct macr_lazy_adam for a deferred sequence of batches of B triples, or None (the dense pass every step)"""
-        k = self.lazy_period if self.lazy_period is not None else mf_lazy_period_for(self.P.shape[0] + self.Q.shape[0], self.d, B)
+        k = self.lazy_period if self.lazy_period is not None else mf_lazy_period_for(self._P.shape[0] + self._Q.shape[0], self.d, B)
         if k <= 1:
             return None
         if self._lazy_bufs is None:
-            dev = self.P.device
+            dev = self._P.device
             self._lazy_bufs = (torch.zeros(_lib.LAZY_STATE_BYTES, dtype=torch.uint8, device=dev),
-                               torch.zeros(self.P.shape[0], dtype=_i32, device=dev), torch.zeros(self.Q.shape[0], dtype=_i32, device=dev))
+                               torch.zeros(self._P.shape[0], dtype=_i32, device=dev), torch.zeros(self._Q.shape[0], dtype=_i32, device=dev))
         st, sp, sq = self._lazy_bufs
         return _lib.LazyAdam(_ptr(st), _ptr(sp), _ptr(sq), int(k))
 
@@ -642,11 +666,11 @@ class MFState(object):
         if self.pending_B:
             if self._seq_lazy is not None:
                 check(_lib.lib().macr_mf_train_flush_lazy(
-                    self.pending_kind, self.pending_B, self.d, self.P.shape[0], self.Q.shape[0], *self._tables(),
+                    self.pending_kind, self.pending_B, self.d, self._P.shape[0], self._Q.shape[0], *self._tables(),
                     ctypes.byref(self.hyper), ctypes.byref(self._seq_lazy), _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
             else:
                 check(_lib.lib().macr_mf_train_flush(
-                    self.pending_kind, self.pending_B, self.d, self.P.shape[0], self.Q.shape[0], *self._tables(),
+                    self.pending_kind, self.pending_B, self.d, self._P.shape[0], self._Q.shape[0], *self._tables(),
                     ctypes.byref(self.hyper), _ptr(self.ws), self.ws.numel(), _stream(self._dev_index)))
             self.pending_B = 0
 

@@ -62,7 +62,11 @@ class Owned(object):
         """rank that owns each of the global row ids (any rank can tell: the layout is a function of the id)"""
         if self.layout == "interleaved":
             return ids % self.world
-        bounds = torch.tensor([row_range(self.n_rows, r, self.world)[1] for r in range(self.world)], device=ids.device)
+        cache = self.__dict__.setdefault("_bounds", {})               # per device: no host-to-device copy per step
+        bounds = cache.get(ids.device)
+        if bounds is None:
+            bounds = cache[ids.device] = torch.tensor([row_range(self.n_rows, r, self.world)[1] for r in range(self.world)],
+                                                      device=ids.device)
         return torch.bucketize(ids, bounds, right=True)
 
     def local_index(self, ids):
@@ -308,7 +312,10 @@ class RowShardedMF(object):
         what an evaluation needs of the user table is its query users' rows, not a pass over every user"""
         if table in self._stale_tabs:
             return self.backend.lazy_rows(self, table, local_idx)
-        return getattr(self, "_" + table)[local_idx.long()]
+        # one meaning for an index < 0 in both branches: a zero row (lazy_rows' convention), never "the last row"
+        idx = local_idx.long()
+        out = getattr(self, "_" + table)[idx.clamp(min=0)]
+        return out.masked_fill_((idx < 0).unsqueeze(1), 0.0)            # (no host synchronisation; `out` is a fresh gather)
 
     P, Q = _current_table("_P"), _current_table("_Q")
     mP, vP, mQ, vQ = _current_table("_mP"), _current_table("_vP"), _current_table("_mQ"), _current_table("_vQ")

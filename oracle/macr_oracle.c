@@ -284,13 +284,19 @@ void orc_mf_train_step(int kind, int B, int d, int n_users, int n_items,
     float *eu = (float *)malloc(bd * 4), *ei = (float *)malloc(bd * 4), *ej = (float *)malloc(bd * 4);
     float *deu = (float *)calloc(bd, 4), *dei = (float *)calloc(bd, 4), *dej = (float *)calloc(bd, 4);
     float *fwd = (float *)calloc((size_t)5 * B, 4);
-    /* dense gradient tables: kept between calls and ALL ZERO between calls (the rows a batch touched are cleared again
-     * at the end of its step) -- round 4 calloc'ed 18 MB per step on the Gowalla shape.  Same values, same order. */
+#ifdef ORC_PERSISTENT_SCRATCH
+    /* SPEED BUILD ONLY (oracle/Makefile `fast`, bench.py's tuned CPU port): the dense gradient tables are kept between calls
+     * and are ALL ZERO between calls (the rows a batch touched are cleared again at the end of its step) instead of an 18 MB
+     * calloc per step on the Gowalla shape.  Not re-entrant, not thread-safe, shared by models of equal size: never the checker. */
     static float *s_gP = NULL, *s_gQ = NULL;
     static size_t s_nP = 0, s_nQ = 0;
     if (s_nP != (size_t)n_users * d) { free(s_gP); s_nP = (size_t)n_users * d; s_gP = (float *)calloc(s_nP, 4); }
     if (s_nQ != (size_t)n_items * d) { free(s_gQ); s_nQ = (size_t)n_items * d; s_gQ = (float *)calloc(s_nQ, 4); }
     float *gP = s_gP, *gQ = s_gQ;
+#else
+    /* the checker: fresh zeroed gradient tables per call, freed on return -- re-entrant, no state between calls */
+    float *gP = (float *)calloc((size_t)n_users * d, 4), *gQ = (float *)calloc((size_t)n_items * d, 4);
+#endif
     float *gw = (float *)calloc(d, 4), *gwu = (float *)calloc(d, 4);
     float parts[4];
     orc_gather_rows(P, u, B, d, eu); orc_gather_rows(Q, i, B, d, ei); orc_gather_rows(Q, j, B, d, ej);
@@ -308,11 +314,15 @@ void orc_mf_train_step(int kind, int B, int d, int n_users, int n_items,
         orc_adam_dense(wu, mwu, vwu, gwu, d, lr_t, b1, b2, eps);
     power[0] *= b1; power[1] *= b2;
     losses[1] = parts[0]; losses[2] = reg; losses[0] = parts[0] + reg;   /* model.py:73,:94 */
+#ifdef ORC_PERSISTENT_SCRATCH
     for (int r = 0; r < B; ++r) {                  /* the touched rows are zero again */
         memset(gP + (size_t)u[r] * d, 0, (size_t)d * 4);
         memset(gQ + (size_t)i[r] * d, 0, (size_t)d * 4);
         memset(gQ + (size_t)j[r] * d, 0, (size_t)d * 4);
     }
+#else
+    free(gP); free(gQ);
+#endif
     free(eu); free(ei); free(ej); free(deu); free(dei); free(dej); free(fwd);
     free(gw); free(gwu);
 }

@@ -6,8 +6,10 @@
   profiles/pmc_sq_latest.json       {workload: {kernel: {SQ_* counter: average per launch}}} read by bench.py (`roofline_bxb`)
 Usage:  python tools/summarize_profile.py condense <dir>        (on the GPU box: raw counter tables -> averages)
         python tools/summarize_profile.py <run> <tag> [workload] (here: gpurun_out/prof_<run> -> profiles/<tag>_*)
-HBM bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE reports half of a wide coalesced
-read stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated."""
+HBM bytes = FETCH_FACTOR*FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE counts 128-byte fabric requests at 64 bytes
+(MI355X_MICROARCH.md, HBM section).  The factor is calibrated per load shape in profiles/fetch_calib.json (tools/fetch_calib.sh:
+1 GiB read once as a stream and as a permutation of 256-byte rows, global_load_dword and dwordx4): 2.000 in all four, so one
+factor serves every kernel here, the SpMM's dword gathers included; WRITE_SIZE is uncalibrated."""
 import collections
 import csv
 import json
@@ -18,6 +20,17 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DST = os.path.join(ROOT, "profiles")
+
+
+def fetch_factor(shape=None):
+    """true bytes per counted FETCH_SIZE byte: profiles/fetch_calib.json (per load shape; the mean when no shape is named --
+    the four measured shapes agree to 1e-4), 2.0 when the calibration file is missing"""
+    try:
+        shapes = json.load(open(os.path.join(DST, "fetch_calib.json")))["shapes"]
+        vals = [v["true_over_counter"] for k, v in shapes.items() if shape in (None, k) and "true_over_counter" in v]
+        return sum(vals) / len(vals)
+    except Exception:
+        return 2.0
 
 
 def short(name):
@@ -106,7 +119,7 @@ def main(run, tag, workload=None):
     traffic = {}
     for k, d in pmc.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-            d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+            d["hbm_bytes_per_launch"] = (fetch_factor() * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
             traffic[k] = d["hbm_bytes_per_launch"]
     # GRBM_GUI_ACTIVE per nanosecond of kernel time: proportional to the clock the kernel ran at (DVFS).  This
     # rocprofv3 sums the counter over an unknown number of instances, so only RATIOS between kernels are used.
