@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--regions", type=int, default=0, help="number of timed K-step regions (0 = as many as fit in ~60 ms); the median is reported")
     ap.add_argument("--no-e2e", action="store_true", help="skip the sampler-inclusive end-to-end leg (diagnostic)")
     ap.add_argument("--no-defer", action="store_true", help="complete every step's Adam pass inside the step instead of under the next step's (B,B) kernel (diagnostic)")
+    ap.add_argument("--through-cli-test", action="store_true",
+                    help="also time macr_mf/train.py::test() itself (tools/cli_test_cost.py in a subprocess: a synthetic dataset of the "
+                         "workload's shapes through the MF loader, the CLI's own call) -> `cli_test` in the line")
     ap.add_argument("--presorted", action="store_true", help="feed batches already ordered by positive item (diagnostic; the step orders its batch on the device either way)")
     return ap.parse_args()
 
@@ -1306,6 +1309,15 @@ def main():
                 c4_line = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
                 print("[bench] config4 part failed on rank %d: %s" % (rank, c4_line["error"]), file=sys.stderr)
 
+    cli_test = None
+    if rank == 0 and world == 1 and args.through_cli_test:
+        import subprocess
+        try:
+            r_ = subprocess.run([sys.executable, os.path.join(REPO, "tools", "cli_test_cost.py"), "--workload", args.workload],
+                                capture_output=True, text=True, timeout=600)
+            cli_test = json.loads(r_.stdout.strip().splitlines()[-1])
+        except Exception as e:                                     # noqa: BLE001
+            cli_test = {"error": repr(e)[:200]}
     if rank == 0:
         out = {
             "metric": "train interactions/sec + eval users/sec (full-catalog top-K@20)",
@@ -1339,7 +1351,7 @@ def main():
             "step_kernel_us": step_kernel_us, "event_overhead_us_per_launch": event_overhead_us, "kernels": kern_avg,
             "roofline": roofline, "roofline_step": roofline_step, "roofline_aux": aux,
             "roofline_bxb": roofline_bxb(args.workload, B, kern_avg) if kind == ops.LOSS_RUBIBCEBOTH else None,
-            "end_to_end": end_to_end,
+            "end_to_end": end_to_end, "cli_test": cli_test,
             "roofline_eval": roofline_eval, "roofline_eval_bf16": roofline_eval_bf16, "cpu_baseline": cpu,
             "last_losses": [float(x) for x in losses[(args.warmup + args.steps - 1) % n_batches]],
         }
