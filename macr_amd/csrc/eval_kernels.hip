@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
 // The listing pass with the epilogue INSIDE the matrix product (k_score_stream_c; what macr_score_topk runs under the bf16
 // filter -- k_score_stream_b above stays for reference and its bound test, k_score_stream_bs for the c sweep).
 //
-// tools/listing_bench.hip (this kernel and its predecessors side by side, cycle-counter traces, PMC) says what a visit of
+// A stand-alone bench of this kernel and its predecessors (round 4; cycle-counter traces, PMC: profiles/r04_listing_*) says what a visit of
 // k_score_stream_b costs a wave: a third of it are the MFMAs; the rest is vector-ALU work that four waves per SIMD queue
 // up for -- the address arithmetic of the tile copy (per-thread divisions and clamps), an fma + compare + three scalar
 // instructions per score for the test on the raw product, the staging of sig_i and 1/sig_i -- and 12 instead of 9 LDS
@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(StreamGroupsB<D>::THREADS, D <= 64 ? 4 : 2) void k_
 //   * the visit loop is unrolled over the two LDS buffers (immediate offsets); all nine fragment reads first, then the 13
 //     MFMAs back to back; per score one v_cmp + one s_cbranch; a hit costs eight vector instructions (mask bit, LDS counter,
 //     key, store).  A full list keeps counting (the segment's end flags it) instead of raising its threshold.
-// Measured (tools/listing_bench, Gowalla shape, ~176 listed per query): 317 -> 246-252 us; instructions per MFMA:
+// Measured (that bench, Gowalla shape, ~176 listed per query): 317 -> 246-252 us; instructions per MFMA:
 // VALU 6.7 -> 3.2, SALU 8.4 -> 2.1; the matrix pipe 40 % -> 52 % busy at the clock the chip then sustains (1.95 GHz).
 // ============================================================================
 template <int D>
@@ -3621,8 +3621,8 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g, 
 }
 }  // namespace macr
 
-// (tools/listing_bench.hip includes this file for its kernel templates and launch geometry alone: seconds to compile
-// instead of minutes)
+// (-DMACR_EVAL_KERNELS_ONLY: the kernel templates and launch geometry alone, for a stand-alone kernel bench that #includes
+// this file -- seconds to compile instead of minutes)
 #ifndef MACR_EVAL_KERNELS_ONLY
 extern "C" size_t macr_score_topk_workspace_bytes(int U, int n_local, int d) {
     if (U <= 0 || n_local <= 0 || !dim_supported(d)) return 0;

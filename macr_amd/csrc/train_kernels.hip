@@ -20,7 +20,7 @@
 
 namespace macr {
 
-// Timing probes for tools/ablate.py (never defined in the product build).
+// Timing probes (-DMACR_ABL_*: wrong results, never defined in the product build; the measurements are under profiles/r02_ablations).
 #ifdef MACR_ABL_NOATOMIC
 #define MACR_ATOMIC_ADD(p, v) (*(p) = (v))
 #else
