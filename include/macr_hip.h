@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     12
+#define MACR_ABI_VERSION     13
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -208,6 +208,19 @@ int macr_shard_backward_slice(int loss_kind, int B, int d, int t0, int n, const 
                               float *stage_slice, void **branch_grads, size_t *branch_bytes, void *workspace,
                               size_t workspace_bytes, void *stream);
 int macr_shard_stage(int B, int d, float **stage, void *workspace, size_t workspace_bytes);
+/* macr_shard_route (abi 13): the routing tables of the split step from the batch alone, ONE launch (one workgroup; world <= 16).
+ * References are numbered role * B + t (role 0 / 1 / 2 = user / positive / negative row of batch position t); owner(ref) = the rank
+ * that holds the row, dest(ref) = the rank whose slice of positions (macr_shard_slice) holds t.  The same tables on every rank:
+ *   bounds_u, bounds_i (dev) int32[world] first row NOT owned by rank q (contiguous ranges); NULL = interleaved rows, owner = row % world
+ *   slice_end          (dev) int32[world] end t1 of rank q's slice
+ *   counts             (dev) int32[world * world]  counts[q * world + p] = references owned by q whose position lies in p's slice:
+ *                      row q / column p are this rank's send / receive split sizes of the two all-to-alls
+ *   send_ref           (dev) int32[3B]  first n_send entries: the references THIS rank owns, ordered by (dest, reference)
+ *   recv_ref           (dev) int32[3B]  first n_recv entries: the references of THIS rank's slice, ordered by (owner, reference)
+ * No counterpart in the reference (one process, macr_mf/train.py:340); replaces RowShardedMF.route's bucketize / bincount / argsort. */
+int macr_shard_route(int B, int world, int rank, const int32_t *u, const int32_t *i, const int32_t *j,
+                     const int32_t *bounds_u, const int32_t *bounds_i, const int32_t *slice_end, int32_t *counts,
+                     int32_t *send_ref, int32_t *recv_ref, void *stream);
 int macr_shard_apply(int loss_kind, int B, int d, int n_users_loc, int n_items_loc, int u_lo, int u_stride, int i_lo,
                      int i_stride, const int32_t *u, const int32_t *i, const int32_t *j,
                      float *P_loc, float *Q_loc, float *w, float *wu,

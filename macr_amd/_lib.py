@@ -17,7 +17,7 @@ SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINU
 MAX_TOPK = 128
 MAX_TOPK_FUSED = 32
 MAX_SWEEP = 4
-ABI_VERSION = 12
+ABI_VERSION = 13
 LAZY_STATE_BYTES, LAZY_MAX_PERIOD = 1040, 64
 
 
@@ -60,6 +60,7 @@ SIGNATURES = {
     "macr_shard_bxb": (_i, [_i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "macr_shard_backward": (_i, [_i, _i, _i, _p, _p, _p, _p, ctypes.POINTER(Hyper), _p, _p, _p, _p, _z, _p]),
     "macr_shard_slice": (_i, [_i, _i, _i, _i, _p, _p]),
+    "macr_shard_route": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "macr_shard_forward_slice": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "macr_shard_backward_slice": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, ctypes.POINTER(Hyper), _p, _p, _p, _p, _p, _z, _p]),
     "macr_shard_stage": (_i, [_i, _i, _p, _p, _z]),

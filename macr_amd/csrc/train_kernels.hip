@@ -2269,6 +2269,90 @@ __global__ __launch_bounds__(256) void k_shard_keys(int B, const Owned ou, const
         key[2 * (size_t)B + t] = rj >= 0 ? (uint32_t)(ou.n_loc + rj) : none;      val[2 * (size_t)B + t] = (uint32_t)(2 * (size_t)B + t);
     }
 }
+// ---- routing of the split step (macr_shard_route) ----------------------------------------------------------------------------
+// References are numbered role * B + t (role 0 / 1 / 2 = user / positive / negative row of position t).  owner(ref) = the rank
+// that holds the row (Owned layout of its table), dest(ref) = the rank whose slice [t0, t1) holds position t.  One workgroup:
+//   counts[q * W + p]  references owned by q whose position lies in p's slice                       (the all-to-all split sizes)
+//   send_ref[0 .. n_send)  references THIS rank owns, ordered by (dest, reference)                  (what it sends, in order)
+//   recv_ref[0 .. n_recv)  references of THIS rank's slice, ordered by (owner, reference)           (the order they arrive in)
+// Two stable counting sorts over 3B <= 196 608 keys with W <= 16 buckets: thread k owns a contiguous stretch of references,
+// counts its stretch per bucket, the per-bucket counts of the 1 024 threads are scanned in LDS, and the thread writes its
+// references behind the ones before it -- reference order inside a bucket is preserved by construction.
+constexpr int kRouteThreads = 1024, kRouteMaxW = 16;
+struct RouteOwner { int stride; const int32_t *bounds; };         // stride >= 2: owner = row % stride; else bounds[W]: first row NOT owned by rank q
+__device__ __forceinline__ int route_owner(const RouteOwner o, int W, int row) {
+    if (o.bounds == nullptr) return row % o.stride;
+    int q = 0;
+    while (q + 1 < W && row >= o.bounds[q]) ++q;
+    return q;
+}
+__global__ __launch_bounds__(kRouteThreads) void k_shard_route(int B, int W, int rank, const int32_t *__restrict__ u,
+                                                               const int32_t *__restrict__ i, const int32_t *__restrict__ j,
+                                                               const RouteOwner ou, const RouteOwner oi,
+                                                               const int32_t *__restrict__ slice_end, int32_t *__restrict__ counts,
+                                                               int32_t *__restrict__ send_ref, int32_t *__restrict__ recv_ref) {
+    extern __shared__ int32_t s_route[];                           // [2][W][kRouteThreads] per-thread bucket counts, then [W*W] + [2*W] + scratch
+    int32_t *cs = s_route, *cr = s_route + W * kRouteThreads, *cnt = cr + W * kRouteThreads, *base = cnt + W * W;
+    const int t = threadIdx.x, n = 3 * B;
+    const int per = (n + kRouteThreads - 1) / kRouteThreads;
+    const int lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    for (int k = t; k < W * W; k += kRouteThreads) cnt[k] = 0;
+    for (int q = 0; q < W; ++q) { cs[q * kRouteThreads + t] = 0; cr[q * kRouteThreads + t] = 0; }
+    __syncthreads();
+    auto keys = [&](int ref, int &owner, int &dest) {
+        const int role = ref / B, pos = ref - role * B;
+        const int row = role == 0 ? u[pos] : role == 1 ? i[pos] : j[pos];
+        owner = route_owner(role == 0 ? ou : oi, W, row);
+        dest = 0;
+        while (dest + 1 < W && pos >= slice_end[dest]) ++dest;
+    };
+    for (int ref = lo; ref < hi; ++ref) {
+        int owner, dest;
+        keys(ref, owner, dest);
+        atomicAdd(&cnt[owner * W + dest], 1);
+        if (owner == rank) ++cs[dest * kRouteThreads + t];
+        if (dest == rank) ++cr[owner * kRouteThreads + t];
+    }
+    __syncthreads();
+    // exclusive scan of every bucket's 1 024 per-thread counts (wave scan, then the 16 wave totals), both sorts
+    const int lane = t & 63, wid = t >> 6;
+    int32_t *wtot = base + 2 * W;                                  // [2 * W][16] wave totals
+    for (int a = 0; a < 2; ++a) {
+        int32_t *c = a ? cr : cs;
+        for (int q = 0; q < W; ++q) {
+            const int v = c[q * kRouteThreads + t];
+            int incl = v;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, kWave); if (lane >= m) incl += o; }
+            if (lane == 63) wtot[(a * W + q) * 16 + wid] = incl;
+            c[q * kRouteThreads + t] = incl - v;                   // exclusive inside the wave
+        }
+    }
+    __syncthreads();
+    if (t < 2 * W) {                                               // bucket bases: totals of the buckets before, wave offsets inside a bucket
+        int run = 0;
+        for (int w2 = 0; w2 < 16; ++w2) { const int x = wtot[t * 16 + w2]; wtot[t * 16 + w2] = run; run += x; }
+        base[t] = run;                                             // the bucket's total
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (int a = 0; a < 2; ++a) { int run = 0; for (int q = 0; q < W; ++q) { const int x = base[a * W + q]; base[a * W + q] = run; run += x; } }
+    }
+    __syncthreads();
+    int ps[kRouteMaxW], pr[kRouteMaxW];
+    for (int q = 0; q < W; ++q) {
+        ps[q] = base[q] + wtot[q * 16 + wid] + cs[q * kRouteThreads + t];
+        pr[q] = base[W + q] + wtot[(W + q) * 16 + wid] + cr[q * kRouteThreads + t];
+    }
+    for (int ref = lo; ref < hi; ++ref) {
+        int owner, dest;
+        keys(ref, owner, dest);
+        if (owner == rank) send_ref[ps[dest]++] = ref;
+        if (dest == rank) recv_ref[pr[owner]++] = ref;
+    }
+    for (int k = t; k < W * W; k += kRouteThreads) counts[k] = cnt[k];
+}
+
 struct ShardWs { PairWs pair; int32_t *iota; size_t bytes; };
 static ShardWs carve_shard_ws(void *base, int B, int d) {
     ShardWs w;
@@ -2445,6 +2529,27 @@ extern "C" int macr_shard_backward(int loss_kind, int B, int d, const float *row
  * (macr_shard_bxb), on rows it received from their owners (all-to-all #1), and sends the gradient rows back to the owners
  * (all-to-all #2) -- a rank moves 2 * 3B/W rows per step instead of taking part in an all-reduce of 3B.  Host side:
  * macr_amd/sharded_train.py::RowShardedMF.step_split.  Branch losses only (the losses with a (B,B) term). */
+// the routing tables of the split step in ONE launch (RowShardedMF.route did it with ~10 torch launches: bucketize, three
+// owner lookups, a bincount, two stable argsorts).  bounds_u / bounds_i (dev, int32[world], NULL = interleaved rows: owner =
+// row %% world): first row NOT owned by rank q; slice_end (dev, int32[world]): end of rank q's slice of batch positions.
+extern "C" int macr_shard_route(int B, int world, int rank, const int32_t *u, const int32_t *i, const int32_t *j,
+                                const int32_t *bounds_u, const int32_t *bounds_i, const int32_t *slice_end, int32_t *counts,
+                                int32_t *send_ref, int32_t *recv_ref, void *stream) {
+    MACR_REQUIRE(B > 0 && world >= 1 && world <= kRouteMaxW && rank >= 0 && rank < world, MACR_E_UNSUPPORTED,
+                 "shard_route: B=%d world=%d rank=%d (world <= %d)", B, world, rank, kRouteMaxW);
+    MACR_REQUIRE(3LL * B <= (1LL << 24), MACR_E_UNSUPPORTED, "shard_route: B=%d", B);
+    MACR_REQUIRE(u && i && j && slice_end && counts && send_ref && recv_ref, MACR_E_INVALID, "shard_route: null pointer");
+    const RouteOwner ou = {world, bounds_u}, oi = {world, bounds_i};
+    const size_t smem = ((size_t)2 * world * kRouteThreads + (size_t)world * world + 2 * world + 2 * world * 16) * 4;
+    auto kern = k_shard_route;
+    MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess,
+                 MACR_E_LAUNCH, "shard_route: cannot reserve %zu B of LDS", smem);
+    hipStream_t st = as_stream(stream);
+    kern<<<1, kRouteThreads, smem, st>>>(B, world, rank, u, i, j, ou, oi, slice_end, counts, send_ref, recv_ref);
+    MACR_CHECK_LAUNCH("shard_route", st);
+    return MACR_OK;
+}
+
 extern "C" int macr_shard_slice(int B, int d, int rank, int world, int *t0, int *t1) {
     MACR_REQUIRE(B > 0 && dim_supported(d) && world >= 1 && rank >= 0 && rank < world && t0 && t1, MACR_E_INVALID, "shard_slice: bad argument");
     const PairWs ws = carve_pair_ws(nullptr, B, d, true);

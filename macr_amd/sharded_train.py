@@ -181,6 +181,27 @@ class HipBackend(object):
         return self.losses, self._view(ptr, nbytes)         # losses; branch-vector partial rows (broadcast from rank 0)
 
     # ---- the split step: forward / backward of this rank's slice of the batch (macr_shard_*_slice)
+    def route(self, shard, B, u, i, j, slice_ends):
+        """(counts (W,W) int64 device, send_ref, recv_ref int64 (3B,)) of RowShardedMF.route by macr_shard_route: one launch"""
+        W, dev = shard.world, u.device
+        key = ("route_bufs", B)
+        bufs = self.__dict__.get(key)
+        if bufs is None:
+            def bounds_of(own):
+                if own.layout == "interleaved":
+                    return None
+                return torch.tensor([row_range(own.n_rows, r, W)[1] for r in range(W)], dtype=torch.int32, device=dev)
+            bufs = self.__dict__[key] = dict(
+                ends=torch.tensor(list(slice_ends), dtype=torch.int32, device=dev), bu=bounds_of(shard.own_u), bi=bounds_of(shard.own_i),
+                counts=torch.zeros(W * W, dtype=torch.int32, device=dev), send=torch.zeros(3 * B, dtype=torch.int32, device=dev),
+                recv=torch.zeros(3 * B, dtype=torch.int32, device=dev))
+        b = bufs
+        p = self.ops._ptr
+        self._lib.check(self._lib.lib().macr_shard_route(
+            B, W, shard.rank, p(u, torch.int32), p(i, torch.int32), p(j, torch.int32), p(b["bu"], allow_none=True),
+            p(b["bi"], allow_none=True), p(b["ends"]), p(b["counts"]), p(b["send"]), p(b["recv"]), self.ops._stream(dev.index)))
+        return b["counts"].view(W, W).long(), b["send"].long(), b["recv"].long()
+
     def slice_of(self, B, rank, world):
         t0, t1 = ctypes.c_int(), ctypes.c_int()
         self._lib.check(self._lib.lib().macr_shard_slice(B, self.d, rank, world, ctypes.byref(t0), ctypes.byref(t1)))
@@ -379,9 +400,13 @@ class RowShardedMF(object):
         host (the CLI's sampler, the bench's batch pool) pass it to step_split instead."""
         B, W = u.numel(), self.world
         bounds = self._slice_bounds(B)
+        rows = torch.cat([u, i, j]).long()
+        if u.is_cuda and W <= 16 and hasattr(self.backend, "route") and os.environ.get("MACR_SHARD_ROUTE_TORCH", "0") != "1":
+            # ONE launch behind the C ABI (macr_shard_route) instead of the ~10 torch launches below: same tables, same order
+            counts, send_ref, recv_ref = self.backend.route(self, B, u, i, j, [b[1] for b in bounds])
+            return counts, send_ref, recv_ref, rows
         t1s = torch.tensor([b[1] for b in bounds], device=u.device)
         dest = torch.bucketize(torch.arange(B, device=u.device), t1s, right=True).repeat(3)             # (3B,)
-        rows = torch.cat([u, i, j]).long()
         owner = torch.cat([self.own_u.owner_of(u.long()), self.own_i.owner_of(i.long()), self.own_i.owner_of(j.long())])
         counts = torch.bincount(owner * W + dest, minlength=W * W).view(W, W)
         mine = owner == self.rank

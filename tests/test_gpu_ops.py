@@ -1707,3 +1707,50 @@ def test_metrics_and_evaluator_with_wide_Ks(ops, eval_filter):
         _, oi, oc = oracle.score_topk(kind, P[users], Q, max(Ks), sig_u, sig_i, cc, mcsr)
         want = oracle.metrics_mf(oi, oc, gcsr, Ks).mean(0)
         np.testing.assert_allclose(res_c["recall"], want[1], rtol=1e-12)
+
+
+# ----------------------------------------------------------------------------- routing of the split step (macr_shard_route)
+@pytest.mark.parametrize("W,layout,B", [(2, "interleaved", 1000), (3, "range", 777), (8, "interleaved", 8192), (16, "range", 4096),
+                                        (8, "interleaved", 65536), (1, "interleaved", 300)])
+def test_shard_route_is_the_two_stable_sorts_of_the_batch(ops, W, layout, B):
+    """macr_shard_route against the definition (RowShardedMF.route's torch version, restated in numpy): counts[q][p], the
+    references a rank owns ordered by (destination slice, reference), the references of its slice ordered by (owner,
+    reference) -- for every rank, interleaved rows and contiguous ranges, uneven slices, Zipf-skewed items."""
+    import ctypes
+    from macr_amd import _lib
+    rs = np.random.RandomState(W * 1000 + B)
+    n_users, n_items = 50000, 7000
+    u = rs.randint(0, n_users, B).astype(np.int32)
+    i = np.minimum(rs.zipf(1.3, B), n_items).astype(np.int32) - 1
+    j = rs.randint(0, n_items, B).astype(np.int32)
+    cuts = np.sort(rs.choice(np.arange(1, B), W - 1, replace=False)) if W > 1 else np.zeros(0, np.int64)
+    ends = np.concatenate([cuts, [B]]).astype(np.int32)
+    def bounds(n):      # contiguous ranges of (almost) equal size
+        return np.asarray([(n * (q + 1)) // W for q in range(W)], dtype=np.int32)
+    bu, bi = bounds(n_users), bounds(n_items)
+    def owner(rows, b):
+        return rows % W if layout == "interleaved" else np.searchsorted(b, rows, side="right")
+    own = np.concatenate([owner(u, bu), owner(i, bi), owner(j, bi)])
+    dest = np.tile(np.searchsorted(ends, np.arange(B), side="right"), 3)
+    want_counts = np.bincount(own * W + dest, minlength=W * W).reshape(W, W)
+    t = lambda a: torch.from_numpy(a).cuda()
+    du, di, dj, dends = t(u), t(i), t(j), t(ends)
+    dbu, dbi = (None, None) if layout == "interleaved" else (t(bu), t(bi))
+    counts = torch.zeros(W * W, dtype=torch.int32, device="cuda")
+    send = torch.full((3 * B,), -1, dtype=torch.int32, device="cuda")
+    recv = torch.full((3 * B,), -1, dtype=torch.int32, device="cuda")
+    p = ops._ptr
+    for rank in range(W):
+        send.fill_(-1); recv.fill_(-1)
+        _lib.check(_lib.lib().macr_shard_route(B, W, rank, p(du), p(di), p(dj), p(dbu, allow_none=True), p(dbi, allow_none=True),
+                                               p(dends), p(counts), p(send), p(recv), ops._stream(0)))
+        assert np.array_equal(counts.cpu().numpy().reshape(W, W), want_counts)
+        ref = np.arange(3 * B)
+        mine = ref[own == rank]
+        want_send = mine[np.argsort(dest[own == rank], kind="stable")]
+        got_send = send.cpu().numpy()
+        assert np.array_equal(got_send[: len(want_send)], want_send) and (got_send[len(want_send):] == -1).all()
+        sl = ref[dest == rank]
+        want_recv = sl[np.argsort(own[dest == rank], kind="stable")]
+        got_recv = recv.cpu().numpy()
+        assert np.array_equal(got_recv[: len(want_recv)], want_recv) and (got_recv[len(want_recv):] == -1).all()
