@@ -401,7 +401,9 @@ class RowShardedMF(object):
         B, W = u.numel(), self.world
         bounds = self._slice_bounds(B)
         rows = torch.cat([u, i, j]).long()
-        if u.is_cuda and W <= 16 and hasattr(self.backend, "route") and os.environ.get("MACR_SHARD_ROUTE_TORCH", "0") != "1":
+        # (one workgroup: it wins up to ~16 k triples -- 78-103 us against 296 at B = 8192 -- and loses beyond: 506-665 against 331 at 65 536)
+        if (u.is_cuda and W <= 16 and B <= 16384 and hasattr(self.backend, "route")
+                and os.environ.get("MACR_SHARD_ROUTE_TORCH", "0") != "1"):
             # ONE launch behind the C ABI (macr_shard_route) instead of the ~10 torch launches below: same tables, same order
             counts, send_ref, recv_ref = self.backend.route(self, B, u, i, j, [b[1] for b in bounds])
             return counts, send_ref, recv_ref, rows

@@ -364,8 +364,9 @@ void orc_lgcn_propagate(int N, int d, int n_layers, const int32_t *indptr, const
     for (size_t t = 0; t < nd; ++t) E[t] = E[t] * inv;
 }
 
-/* Backward of the above wrt E0 given dE (A_hat symmetric: SURVEY.md A.5):
- *   dE0 = (dE + A dE + A^2 dE + ...)/(L+1).  work: 2*N*d floats. */
+/* Backward of the above wrt E0 given dE:  dE0 = (dE + A^T dE + (A^T)^2 dE + ...)/(L+1) -- the same propagation with the
+ * TRANSPOSED operator.  The caller passes A^T in CSR; for the symmetric `pre` / `plain` matrices of the README's commands
+ * that is A itself.  work: 2*N*d floats. */
 void orc_lgcn_propagate_bwd(int N, int d, int n_layers, const int32_t *indptr, const int32_t *indices,
                             const float *data, const float *dE, float *dE0, float *work) {
     orc_lgcn_propagate(N, d, n_layers, indptr, indices, data, dE, dE0, work);
@@ -373,8 +374,12 @@ void orc_lgcn_propagate_bwd(int N, int d, int n_layers, const int32_t *indptr, c
 
 /* One whole LightGCN training step (LightGCN.py:598-607 -> :186/:201).
  * T = [P;Q] is the (N,d) ego table, N = n_users+n_items. */
-void orc_lgcn_train_step(int kind, int B, int d, int n_users, int n_items, int n_layers,
+/* indptr_t / indices_t / adj_t: the TRANSPOSED adjacency in CSR, used by the backward pass (tf.gradients of
+ * tf.sparse_tensor_dense_matmul, LightGCN.py:301): --adj_type norm / gcmc / mean are row-normalised, D^-1 A, and not symmetric
+ * (utility/load_data.py:95-164, LightGCN.py:667-678). */
+void orc_lgcn_train_step_t(int kind, int B, int d, int n_users, int n_items, int n_layers,
                          const int32_t *indptr, const int32_t *indices, const float *adj,
+                         const int32_t *indptr_t, const int32_t *indices_t, const float *adj_t,
                          const int32_t *u, const int32_t *i, const int32_t *j,
                          float *T, float *w, float *wu, float *mT, float *vT,
                          float *mw, float *vw, float *mwu, float *vwu, float *power,
@@ -397,7 +402,7 @@ void orc_lgcn_train_step(int kind, int B, int d, int n_users, int n_items, int n
     orc_scatter_add_rows(dE, u, B, d, deu);
     orc_scatter_add_rows(dE, ii, B, d, dei);
     orc_scatter_add_rows(dE, jj, B, d, dej);
-    orc_lgcn_propagate_bwd(N, d, n_layers, indptr, indices, adj, dE, G, work);
+    orc_lgcn_propagate_bwd(N, d, n_layers, indptr_t, indices_t, adj_t, dE, G, work);
     /* regulariser acts on the ego rows (LightGCN.py:525-528) */
     orc_gather_rows(T, u, B, d, eu); orc_gather_rows(T, ii, B, d, ei); orc_gather_rows(T, jj, B, d, ej);
     memset(deu, 0, bd * 4); memset(dei, 0, bd * 4); memset(dej, 0, bd * 4);
@@ -415,6 +420,18 @@ void orc_lgcn_train_step(int kind, int B, int d, int n_users, int n_items, int n
     losses[1] = parts[0]; losses[2] = reg; losses[0] = parts[0] + reg;
     free(E); free(work); free(dE); free(G); free(ii); free(jj);
     free(eu); free(ei); free(ej); free(deu); free(dei); free(dej); free(fwd); free(gw); free(gwu);
+}
+
+/* the same for a symmetric adjacency (A^T = A): what the README's commands run (--adj_type pre) */
+void orc_lgcn_train_step(int kind, int B, int d, int n_users, int n_items, int n_layers,
+                         const int32_t *indptr, const int32_t *indices, const float *adj,
+                         const int32_t *u, const int32_t *i, const int32_t *j,
+                         float *T, float *w, float *wu, float *mT, float *vT,
+                         float *mw, float *vw, float *mwu, float *vwu, float *power,
+                         float lr, float b1, float b2, float eps,
+                         float decay, float alpha, float beta, int batch_size_cfg, float *losses) {
+    orc_lgcn_train_step_t(kind, B, d, n_users, n_items, n_layers, indptr, indices, adj, indptr, indices, adj, u, i, j, T, w, wu,
+                          mT, vT, mw, vw, mwu, vwu, power, lr, b1, b2, eps, decay, alpha, beta, batch_size_cfg, losses);
 }
 
 /* ---------------------------------------------------------------------------

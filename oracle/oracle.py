@@ -78,6 +78,9 @@ def lib():
         L.orc_lgcn_propagate.argtypes = [_ci, _ci, _ci, _i, _i, _f, _f, _f, _f]
         L.orc_lgcn_train_step.argtypes = [_ci] * 6 + [_i, _i, _f, _i, _i, _i] + [_f] * 10 + \
             [_cf] * 7 + [_ci, _f]
+        L.orc_lgcn_train_step_t.argtypes = [_ci] * 6 + [_i, _i, _f, _i, _i, _f, _i, _i, _i] + [_f] * 10 + \
+            [_cf] * 7 + [_ci, _f]
+        L.orc_lgcn_train_step_t.restype = None
         L.orc_branch_sigmoid.argtypes = [_f, _ci, _ci, _f, _f]
         L.orc_score_topk.argtypes = [_ci, _ci, _ci, _ci, _f, _f, _vp, _vp, _cf, _vp, _vp, _ci,
                                      _ci, _ci, _f, _i, _i]
@@ -178,12 +181,14 @@ def lgcn_propagate(indptr, indices, data, E0, n_layers):
 
 
 def lgcn_train_step(kind, n_users, n_items, n_layers, indptr, indices, data, u, i, j, T, w, wu, st,
-                    lr, decay, alpha, beta, batch_size_cfg, b1=0.9, b2=0.999, eps=1e-8):
-    """In-place step on T=[P;Q] (N,d), w, wu; st = AdamState([T.shape,(d,),(d,)])."""
+                    lr, decay, alpha, beta, batch_size_cfg, b1=0.9, b2=0.999, eps=1e-8, transposed=None):
+    """In-place step on T=[P;Q] (N,d), w, wu; st = AdamState([T.shape,(d,),(d,)]).
+    transposed = (indptr, indices, data) of A^T in CSR for an asymmetric adjacency (--adj_type norm / gcmc / mean); None: A^T = A."""
     u, i, j = map(_i32, (u, i, j))
     losses = np.zeros(3, np.float32)
-    lib().orc_lgcn_train_step(kind, len(u), T.shape[1], n_users, n_items, n_layers,
-                              _i32(indptr), _i32(indices), _f32(data), u, i, j, T, w, wu,
+    tp, ti, td = (indptr, indices, data) if transposed is None else transposed
+    lib().orc_lgcn_train_step_t(kind, len(u), T.shape[1], n_users, n_items, n_layers,
+                              _i32(indptr), _i32(indices), _f32(data), _i32(tp), _i32(ti), _f32(td), u, i, j, T, w, wu,
                               st.m[0], st.v[0], st.m[1], st.v[1], st.m[2], st.v[2], st.power,
                               lr, b1, b2, eps, decay, alpha, beta, batch_size_cfg, losses)
     return losses

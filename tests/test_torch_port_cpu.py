@@ -81,6 +81,42 @@ def test_lgcn_port_steps_equal_the_oracle():
         np.testing.assert_allclose(E, oracle.lgcn_propagate(A.indptr, A.indices, A.data, To, L), atol=3e-6)
 
 
+def test_lgcn_steps_on_a_row_normalised_adjacency_need_the_transposed_operator():
+    """--adj_type norm / gcmc / mean (LightGCN.py:667-678) are D^-1 A: not symmetric.  The gradient of A @ E is A^T @ dE
+    (tf.gradients of tf.sparse_tensor_dense_matmul): autograd of the torch port does that by itself, the oracle takes A^T
+    explicitly -- they must agree, and the step with A in place of A^T must NOT (the test would be blind otherwise)."""
+    rs = np.random.RandomState(11)
+    n_u, n_i, d, B, L = 100, 70, 32, 48, 2
+    R = sp.random(n_u, n_i, density=0.1, random_state=rs, format="csr", dtype=np.float32)
+    R.data[:] = 1.0
+    A = sp.bmat([[None, R], [R.T, None]], format="csr", dtype=np.float32)
+    deg = np.asarray(A.sum(1)).ravel()
+    A = (sp.diags(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0).astype(np.float32)) @ A).tocsr().astype(np.float32)   # gcmc: D^-1 A
+    A.sort_indices()
+    AT = A.T.tocsr().astype(np.float32)
+    AT.sort_indices()
+    assert abs(A - AT).max() > 1e-3
+    N = n_u + n_i
+    T = (rs.standard_normal((N, d)) * 0.3).astype(np.float32)
+    w, wu = (rs.standard_normal(d) * 0.3).astype(np.float32), (rs.standard_normal(d) * 0.3).astype(np.float32)
+    lr, decay, alpha, beta = 1e-3, 1e-4, 1e-2, 1e-3
+    port = tp.LGCNPort(T, n_u, n_i, w, wu, tp.csr_to_torch(A.indptr, A.indices, A.data, N), L, lr, decay, alpha, beta, B)
+    To, wo, wuo = T.copy(), w.copy(), wu.copy()
+    Tw = T.copy()
+    st, stw = oracle.AdamState([T.shape, (d,), (d,)]), oracle.AdamState([T.shape, (d,), (d,)])
+    for _ in range(3):
+        u = rs.choice(n_u, B, replace=False).astype(np.int32)
+        i, j = rs.randint(0, n_i, B).astype(np.int32), rs.randint(0, n_i, B).astype(np.int32)
+        got = port.train_step(tp.LOSS_RUBIBCEBOTH, u, i, j)
+        want = oracle.lgcn_train_step(oracle.LOSS_RUBIBCEBOTH, n_u, n_i, L, A.indptr, A.indices, A.data, u, i, j, To, wo, wuo, st,
+                                      lr, decay, alpha, beta, B, transposed=(AT.indptr, AT.indices, AT.data))
+        oracle.lgcn_train_step(oracle.LOSS_RUBIBCEBOTH, n_u, n_i, L, A.indptr, A.indices, A.data, u, i, j, Tw, w.copy(), wu.copy(), stw,
+                               lr, decay, alpha, beta, B)
+        np.testing.assert_allclose(got, want, rtol=3e-6)
+    np.testing.assert_allclose(port.T.detach().numpy(), To, atol=3e-6)
+    assert np.abs(Tw - To).max() > 1e-4          # (A instead of A^T: a different model after three steps)
+
+
 def test_fast_build_of_the_c_port_equals_the_checker():
     """bench.py times oracle/_build/libmacr_oracle_fast.so (same C file, -O3 AVX2 -ffast-math) as the tuned CPU port: it
     must compute the checker's step -- losses to 1e-6 relative, tables to 1e-6 absolute after three steps."""
