@@ -356,7 +356,7 @@ size_t macr_lgcn_work_floats(int N, int d, const void *plan_host);   /* size of 
  *   E0 (dev) fp32[N*d] in, E (dev) fp32[N*d] out
  *   work (dev) fp32[macr_lgcn_work_floats(N, d, plan_host)] scratch.  ZERO-FILL IT ONCE before its first use: with a
  *            plan it holds the hub rows' arrival counters, which every call leaves at zero again.
- * The same call is the backward pass (A symmetric): feed dE, get dE0.
+ * The same call is the backward pass: feed dE and the TRANSPOSED adjacency (A itself when symmetric), get dE0.
  * -------------------------------------------------------------------------*/
 int macr_lgcn_propagate(int N, int d, int n_layers, const int32_t *rowptr, const int32_t *col,
                         const float *val, const void *plan_dev, const void *plan_host,
@@ -386,6 +386,23 @@ int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, 
                          float *mw, float *vw, float *mwu, float *vwu,
                          float *adam_pow, const macr_hyper *hp,
                          float *losses, int flags, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same step for an adjacency that is NOT symmetric (abi 13): --adj_type norm / gcmc / mean of macr_lightgcn/LightGCN.py:667-678
+ * are row-normalised, D^-1 A (utility/load_data.py:95-164), and the gradient of A E is A^T dE (tf.gradients of
+ * tf.sparse_tensor_dense_matmul, LightGCN.py:301).  rowptr_t / col_t / val_t / plan_t_*: the TRANSPOSED adjacency in CSR with a
+ * plan of its own (both plans or neither); the forward propagation uses A, the backward propagation A^T.  macr_lgcn_train_step is
+ * this call with A in both places.  workspace >= macr_lgcn_train_workspace_bytes_t(B, N, d, plan_host, plan_t_host). */
+size_t macr_lgcn_train_workspace_bytes_t(int B, int N, int d, const void *plan_host, const void *plan_t_host);
+int macr_lgcn_train_step_t(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
+                           const int32_t *rowptr, const int32_t *col, const float *val,
+                           const void *plan_dev, const void *plan_host,
+                           const int32_t *rowptr_t, const int32_t *col_t, const float *val_t,
+                           const void *plan_t_dev, const void *plan_t_host,
+                           const int32_t *u, const int32_t *i, const int32_t *j,
+                           float *T, float *w, float *wu, float *mT, float *vT,
+                           float *mw, float *vw, float *mwu, float *vwu,
+                           float *adam_pow, const macr_hyper *hp,
+                           float *losses, int flags, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * out[r] = sigmoid(rows[r] . w)   -- the test-time branch factors

@@ -78,6 +78,8 @@ SIGNATURES = {
     "macr_lgcn_propagate": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "macr_lgcn_train_workspace_bytes": (_z, [_i, _i, _i, _p]),
     "macr_lgcn_train_step": (_i, [_i] * 6 + [_p] * 3 + [_p] * 2 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _i, _p, _z, _p]),
+    "macr_lgcn_train_workspace_bytes_t": (_z, [_i, _i, _i, _p, _p]),
+    "macr_lgcn_train_step_t": (_i, [_i] * 6 + [_p] * 3 + [_p] * 2 + [_p] * 3 + [_p] * 2 + [_p] * 3 + [_p] * 9 + [_p, ctypes.POINTER(Hyper), _p, _i, _p, _z, _p]),
     "macr_branch_sigmoid": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "macr_branch_sigmoid2": (_i, [_i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p]),
     "macr_score_topk_splits": (_i, [_i, _i, _i]),

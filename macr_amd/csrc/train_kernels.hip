@@ -2751,7 +2751,7 @@ extern "C" int macr_lazy_flush(int d, long long n_rows_p, long long n_rows_q, fl
 namespace macr {
 struct PlanHeaderLite { int32_t magic, n_items, n_split, n_slots, N, chunk, n_groups, reserved; };   // = spmm_kernels.hip PlanHeader
 struct LgcnWs { float *E, *dE, *G, *work; int32_t *cnt; double *emb_acc; PairWs pair; size_t bytes; };
-static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, const PlanHeaderLite *ph) {
+static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, const PlanHeaderLite *ph, const PlanHeaderLite *pht = nullptr) {
     LgcnWs w;
     char *p = static_cast<char *>(base);
     const size_t nd = align_up((size_t)N * d * 4, 256);
@@ -2761,7 +2761,9 @@ static LgcnWs carve_lgcn_ws(void *base, int B, int N, int d, const PlanHeaderLit
     w.dE = static_cast<float *>(take(nd));
     w.G = static_cast<float *>(take(nd));
     // layer buffers, partial rows of the hub pieces, their arrival counters (= macr_lgcn_work_floats; zero between steps)
-    w.work = static_cast<float *>(take(align_up(macr_lgcn_work_floats(N, d, ph) * 4, 256)));
+    // (pht: the plan of the transposed adjacency of an asymmetric --adj_type; the two propagations never run at once and share the buffers)
+    const size_t wf = macr_lgcn_work_floats(N, d, ph), wft = pht ? macr_lgcn_work_floats(N, d, pht) : 0;
+    w.work = static_cast<float *>(take(align_up((wf > wft ? wf : wft) * 4, 256)));
     w.cnt = static_cast<int32_t *>(take(align_up((size_t)N * 4, 256)));    // references of the current batch per row (zero between steps)
     w.emb_acc = static_cast<double *>(take(kEmbSlots * 8));                 // emb_loss partial sums (zero between steps)
     w.pair = carve_pair_ws(p ? p + off : nullptr, B, d);
@@ -2777,10 +2779,19 @@ extern "C" size_t macr_lgcn_train_workspace_bytes(int B, int N, int d, const voi
     const PlanHeaderLite *ph = static_cast<const PlanHeaderLite *>(plan_host);
     return carve_lgcn_ws(nullptr, B, N, d, ph).bytes;
 }
+extern "C" size_t macr_lgcn_train_workspace_bytes_t(int B, int N, int d, const void *plan_host, const void *plan_t_host) {
+    if (B <= 0 || N <= 0 || !dim_supported(d)) return 0;
+    return carve_lgcn_ws(nullptr, B, N, d, static_cast<const PlanHeaderLite *>(plan_host), static_cast<const PlanHeaderLite *>(plan_t_host)).bytes;
+}
 
-extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
+// rowptr_t / col_t / val_t / plan_t_*: the TRANSPOSED adjacency, used by the backward propagation (the gradient of A E is A^T dE:
+// tf.gradients of tf.sparse_tensor_dense_matmul, LightGCN.py:301).  For the symmetric `pre` / `plain` matrices it is A itself
+// (macr_lgcn_train_step); --adj_type norm / gcmc / mean are D^-1 A (utility/load_data.py:95-164, LightGCN.py:667-678).
+extern "C" int macr_lgcn_train_step_t(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
                                     const int32_t *rowptr, const int32_t *col, const float *val,
-                                    const void *plan_dev, const void *plan_host, const int32_t *u,
+                                    const void *plan_dev, const void *plan_host,
+                                    const int32_t *rowptr_t, const int32_t *col_t, const float *val_t,
+                                    const void *plan_t_dev, const void *plan_t_host, const int32_t *u,
                                     const int32_t *i, const int32_t *j, float *T, float *w, float *wu, float *mT,
                                     float *vT, float *mw, float *vw, float *mwu, float *vwu, float *adam_pow,
                                     const macr_hyper *hp, float *losses, int flags, void *workspace,
@@ -2790,8 +2801,10 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     MACR_REQUIRE(B > 0 && n_users > 0 && n_items > 0 && n_layers >= 0, MACR_E_INVALID,
                  "lgcn_train_step: B=%d n_users=%d n_items=%d n_layers=%d", B, n_users, n_items, n_layers);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "lgcn_train_step: d=%d not in {32,64,128,256}", d);
-    MACR_REQUIRE(rowptr && col && val && u && i && j && T && mT && vT && adam_pow && losses && workspace,
+    MACR_REQUIRE(rowptr && col && val && rowptr_t && col_t && val_t && u && i && j && T && mT && vT && adam_pow && losses && workspace,
                  MACR_E_INVALID, "lgcn_train_step: null pointer");
+    MACR_REQUIRE((plan_t_dev == nullptr) == (plan_t_host == nullptr) && (plan_t_dev == nullptr) == (plan_dev == nullptr), MACR_E_INVALID,
+                 "lgcn_train_step: the transposed adjacency comes with a plan when the adjacency does");
     MACR_REQUIRE(w && wu && mw && vw && mwu && vwu, MACR_E_INVALID, "lgcn_train_step: null branch vectors");
     MACR_REQUIRE((flags & ~(MACR_STEP_LOSS_ONLY | MACR_STEP_DENSE_LAYERS)) == 0, MACR_E_INVALID, "lgcn_train_step: flags=%d", flags);
     const bool loss_only = flags & MACR_STEP_LOSS_ONLY;
@@ -2801,7 +2814,9 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
                  "lgcn_train_step: plan needs both its device copy and its host copy (or neither)");
     const PlanHeaderLite *ph = static_cast<const PlanHeaderLite *>(plan_host);
     MACR_REQUIRE(!ph || ph->N == N, MACR_E_INVALID, "lgcn_train_step: plan does not belong to this graph");
-    LgcnWs ws = carve_lgcn_ws(workspace, B, N, d, ph);
+    const PlanHeaderLite *pht = static_cast<const PlanHeaderLite *>(plan_t_host);
+    MACR_REQUIRE(!pht || pht->N == N, MACR_E_INVALID, "lgcn_train_step: transposed plan does not belong to this graph");
+    LgcnWs ws = carve_lgcn_ws(workspace, B, N, d, ph, pht == ph ? nullptr : pht);
     MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "lgcn_train_step: workspace %zu < %zu bytes",
                  workspace_bytes, ws.bytes);
     MACR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
@@ -2867,7 +2882,9 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         // backward through the propagation with the optimizer in the last layer's epilogue (spmm_kernels.hip AdamFuse):
         // gradient row + ego-row regulariser (LightGCN.py:525-528) -> Adam on T, no G, no separate pass over the table
         const AdamFuse fuse = {T, mT, vT, ws.pair.scal, hp->beta1, hp->beta2, hp->adam_eps, coef, ws.dE, ws.emb_acc};
-        if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st, &sp,
+        SparseCtx spt = sp;
+        spt.chunk = pht ? pht->chunk : 0x7fffffff;
+        if (int e = launch_propagate(N, d, n_layers, rowptr_t, col_t, val_t, plan_t_dev, plan_t_host, ws.dE, ws.G, ws.work, st, &spt,
                                      kSparseIn, &fuse))
             return e;
         if (loss_kind == MACR_LOSS_RUBIBCEBOTH) {
@@ -2879,8 +2896,8 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
         MACR_CHECK_LAUNCH("lgcn_finalize", st);
         return MACR_OK;
     }
-    // backward through the propagation (A symmetric -> same operator), SURVEY.md A.5
-    if (int e = launch_propagate(N, d, n_layers, rowptr, col, val, plan_dev, plan_host, ws.dE, ws.G, ws.work, st, nullptr,
+    // backward through the propagation: the transposed operator (A itself for the symmetric matrices)
+    if (int e = launch_propagate(N, d, n_layers, rowptr_t, col_t, val_t, plan_t_dev, plan_t_host, ws.dE, ws.G, ws.work, st, nullptr,
                                  kSparseIn, nullptr))
         return e;
     // l2 regulariser on the ego rows (LightGCN.py:525-528)
@@ -2898,4 +2915,17 @@ extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, in
     // (dE is zero again on return, as after a step with the sparse layers: their first backward layer may read all of it)
     fill_words(ws.dE, nd, 0u, st);
     return MACR_OK;
+}
+
+// the symmetric case (A^T = A): --adj_type pre (every README command) and plain
+extern "C" int macr_lgcn_train_step(int loss_kind, int B, int d, int n_users, int n_items, int n_layers,
+                                    const int32_t *rowptr, const int32_t *col, const float *val,
+                                    const void *plan_dev, const void *plan_host, const int32_t *u,
+                                    const int32_t *i, const int32_t *j, float *T, float *w, float *wu, float *mT,
+                                    float *vT, float *mw, float *vw, float *mwu, float *vwu, float *adam_pow,
+                                    const macr_hyper *hp, float *losses, int flags, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    return macr_lgcn_train_step_t(loss_kind, B, d, n_users, n_items, n_layers, rowptr, col, val, plan_dev, plan_host, rowptr, col, val,
+                                  plan_dev, plan_host, u, i, j, T, w, wu, mT, vT, mw, vw, mwu, vwu, adam_pow, hp, losses, flags,
+                                  workspace, workspace_bytes, stream);
 }

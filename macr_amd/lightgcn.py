@@ -34,12 +34,11 @@ class LightGCN(object):
         self.n_users = data_config['n_users']
         self.n_items = data_config['n_items']
         self.norm_adj = data_config['norm_adj']
-        # the backward pass through the propagation reuses the forward operator (dE0 = A^T dE = A dE): true for the
-        # symmetric `pre` and `plain` matrices, false for the row-normalised norm / gcmc / mean ones (D^-1 A)
+        # the backward pass through the propagation runs on the TRANSPOSED operator (dE0 = A^T dE): A itself for the symmetric
+        # `pre` and `plain` matrices, a second CSR (with an SpMM plan of its own) for the row-normalised norm / gcmc / mean
+        # ones, D^-1 A (LightGCN.py:667-678; macr_lgcn_train_step_t)
         asym = abs(self.norm_adj - self.norm_adj.T)
-        if asym.nnz and asym.max() > 1e-6 * abs(self.norm_adj).max():
-            raise NotImplementedError("--adj_type %s is not symmetric; the HIP path propagates gradients with the forward "
-                                      "operator and supports pre | plain" % args.adj_type)
+        self.asymmetric = bool(asym.nnz and asym.max() > 1e-6 * abs(self.norm_adj).max())
         self.n_nonzero_elems = self.norm_adj.count_nonzero()
         self.lr = args.lr
         self.emb_dim = args.embed_size
@@ -78,11 +77,16 @@ class LightGCN(object):
         T, w, wu = ops.pad_cols(T, dp), ops.pad_cols(w, dp), ops.pad_cols(wu, dp)
         self.rubi_c = 0.0
         adj = ops.CSR.from_scipy(self.norm_adj, device)
+        adj_t = None
+        if self.asymmetric:
+            at = self.norm_adj.T.tocsr()
+            at.sort_indices()
+            adj_t = ops.CSR.from_scipy(at, device)
         hyper = ops.make_hyper(self.lr, self.decay, self.alpha, self.beta, self.batch_size)
         self._opt = {}
         for loss, (suffix, kind) in self._LOSS.items():
             self._opt[kind] = ops.LGCNState(T, self.n_users, self.n_items, w, wu, adj, self.n_layers, hyper,
-                                            self.batch_size)
+                                            self.batch_size, adj_t=adj_t)
             setattr(self, "opt_" + suffix, Fetch("opt_" + suffix, "opt", kind))
             setattr(self, "loss_" + suffix, Fetch("loss_" + suffix, "loss", kind))
             setattr(self, "mf_loss_" + suffix, Fetch("mf_loss_" + suffix, "mf_loss", kind))

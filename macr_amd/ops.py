@@ -679,12 +679,15 @@ class LGCNState(object):
     """Device state of LightGCN: ego table T=[user_embedding; item_embedding] (LightGCN.py:226-232),
     branch vectors, Adam slots, the `pre` adjacency (utility/load_data.py:112-121)."""
 
-    def __init__(self, T, n_users, n_items, w, wu, adj, n_layers, hyper, batch_cap):
+    def __init__(self, T, n_users, n_items, w, wu, adj, n_layers, hyper, batch_cap, adj_t=None):
+        """adj_t: the TRANSPOSED adjacency (CSR) of an asymmetric --adj_type (norm / gcmc / mean: D^-1 A); the backward
+        propagation runs on it.  None: the adjacency is symmetric (pre, plain)."""
         _require_f32(T=T, w=w, wu=wu)
         self.T = T.contiguous()
         self.n_users, self.n_items, self.n_layers = n_users, n_items, n_layers
         self.w, self.wu = w.reshape(-1).contiguous(), wu.reshape(-1).contiguous()
         self.adj, self.hyper, self.d = adj, hyper, T.shape[1]
+        self.adj_t = adj_t
         z = torch.zeros_like
         self.mT, self.vT = z(self.T), z(self.T)
         self.mw, self.vw, self.mwu, self.vwu = z(self.w), z(self.w), z(self.wu), z(self.wu)
@@ -696,7 +699,11 @@ class LGCNState(object):
 
     def reserve(self, B):
         if B > self.batch_cap:
-            nbytes = _lib.lib().macr_lgcn_train_workspace_bytes(B, self.T.shape[0], self.d, self.adj._plan_ptrs()[1])
+            if self.adj_t is None:
+                nbytes = _lib.lib().macr_lgcn_train_workspace_bytes(B, self.T.shape[0], self.d, self.adj._plan_ptrs()[1])
+            else:
+                nbytes = _lib.lib().macr_lgcn_train_workspace_bytes_t(B, self.T.shape[0], self.d, self.adj._plan_ptrs()[1],
+                                                                      self.adj_t._plan_ptrs()[1])
             if nbytes == 0:
                 raise MacrError(_lib.E_UNSUPPORTED, "embed_size %d not in {32,64,128,256}" % self.d)
             # zero once (include/macr_hip.h): row flags and the hub rows' arrival counters are
@@ -714,9 +721,12 @@ class LGCNState(object):
         if not loss_only:
             self._E = None
         pd, ph = self.adj._plan_ptrs()
-        check(_lib.lib().macr_lgcn_train_step(
+        at = self.adj if self.adj_t is None else self.adj_t
+        ptd, pth = at._plan_ptrs()
+        check(_lib.lib().macr_lgcn_train_step_t(
             kind, B, self.d, self.n_users, self.n_items, self.n_layers, _ptr(self.adj.ptr, _i32),
-            _ptr(self.adj.idx, _i32), _ptr(self.adj.val, _f32), pd, ph, _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
+            _ptr(self.adj.idx, _i32), _ptr(self.adj.val, _f32), pd, ph,
+            _ptr(at.ptr, _i32), _ptr(at.idx, _i32), _ptr(at.val, _f32), ptd, pth, _ptr(u, _i32), _ptr(i, _i32), _ptr(j, _i32),
             _ptr(self.T), _ptr(self.w), _ptr(self.wu), _ptr(self.mT), _ptr(self.vT), _ptr(self.mw), _ptr(self.vw),
             _ptr(self.mwu), _ptr(self.vwu), _ptr(self.adam_pow), ctypes.byref(self.hyper), _ptr(out, _f32),
             (_lib.STEP_LOSS_ONLY if loss_only else 0) | (_lib.STEP_DENSE_LAYERS if dense_layers else 0), _ptr(self.ws),

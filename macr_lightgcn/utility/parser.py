@@ -21,10 +21,9 @@ _FLAGS = [
     ("lr", float, 0.01, "learning rate"),
     ("c", float, 40.0, "the constant c of counterfactual inference"),
     ("model_type", None, 'lightgcn', "(compat)"),
-    ("adj_type", None, 'pre', "adjacency normalisation {plain, norm, gcmc, mean, pre} (LightGCN.py:667-678).  SYMMETRIC ONLY on the MI355X "
-                              "path: pre (default, every README command) and plain train and evaluate; norm / gcmc / mean are "
-                              "row-normalised (D^-1 A), their backward pass needs the transposed operator, which the HIP step does "
-                              "not carry -- they are refused with NotImplementedError at start-up"),
+    ("adj_type", None, 'pre', "adjacency normalisation {plain, norm, gcmc, mean, pre} (LightGCN.py:667-678); pre is the default of every "
+                              "README command.  The row-normalised ones (norm, gcmc, mean: D^-1 A) are not symmetric: their backward "
+                              "pass runs on the transposed matrix (a second CSR + SpMM plan)"),
     ("alg_type", None, 'lightgcn', "lightgcn (ngcf, gcn, gcmc are out of scope)"),
     ("gpu_id", int, 0, "HIP device index"),
     ("node_dropout_flag", int, 0, "0 (node dropout is out of scope)"),

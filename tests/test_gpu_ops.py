@@ -594,6 +594,49 @@ def test_lgcn_train_step_matches_oracle(ops, kind, d, B):
 
 
 @pytest.mark.parametrize("kind", [oracle.LOSS_NORMALBCE, oracle.LOSS_RUBIBCEBOTH])
+@pytest.mark.parametrize("d,B,dense", [(64, 256, False), (64, 300, True), (128, 100, False), (32, 64, False)])
+def test_lgcn_train_step_on_a_row_normalised_adjacency(ops, kind, d, B, dense):
+    """--adj_type norm / gcmc / mean are D^-1 A (LightGCN.py:667-678, utility/load_data.py:95-164): the forward propagation runs
+    on A, the backward propagation on A^T (macr_lgcn_train_step_t; a plan of its own, hub rows on both sides) -- losses,
+    first-step gradients and tables against the oracle, which takes A^T explicitly; the step with A in both places differs."""
+    import scipy.sparse as sp
+    n_users, n_items, L = 900, 500, 2                            # (items 0 and 1 are hub rows of A^T and of A: > 512 neighbours)
+    A = toy_graph(n_users, n_items, 5)
+    deg = np.asarray((A != 0).sum(1)).ravel()
+    An = (sp.diags(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0)) @ (A != 0).astype(np.float32)).tocsr().astype(np.float32)
+    An.sort_indices()
+    AT = An.T.tocsr().astype(np.float32)
+    AT.sort_indices()
+    assert abs(An - AT).max() > 1e-3
+    P, Q, w, wu, u, i, j = make_problem(d + 1, n_users, n_items, d, B)
+    T = np.concatenate([P, Q]).astype(np.float32)
+    alpha, beta, decay, lr = 1e-2, 1e-3, 1e-4, 1e-3
+    st = oracle.AdamState([T.shape, (d,), (d,)])
+    To, wo, wuo = T.copy(), w.copy(), wu.copy()
+    hyper = ops.make_hyper(lr, decay, alpha, beta, B)
+    state = ops.LGCNState(dev(T), n_users, n_items, dev(w), dev(wu), ops.CSR.from_scipy(An, "cuda"), L, hyper, B,
+                          adj_t=ops.CSR.from_scipy(AT, "cuda"))
+    wrong = ops.LGCNState(dev(T), n_users, n_items, dev(w), dev(wu), ops.CSR.from_scipy(An, "cuda"), L, hyper, B)
+    rs = np.random.RandomState(4)
+    for t in range(3):
+        if t:
+            u = rs.choice(n_users, B, replace=False).astype(np.int32)
+            i = (rs.zipf(1.3, B) % n_items).astype(np.int32)
+            j = rs.randint(0, n_items, B).astype(np.int32)
+        want = oracle.lgcn_train_step(kind, n_users, n_items, L, An.indptr, An.indices, An.data, u, i, j, To, wo, wuo, st, lr, decay,
+                                      alpha, beta, B, transposed=(AT.indptr, AT.indices, AT.data))
+        got = state.step(kind, dev(u), dev(i), dev(j), dense_layers=dense).cpu().numpy()
+        wrong.step(kind, dev(u), dev(i), dev(j), dense_layers=dense)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+        if t == 0:
+            g_hip, g_orc = state.mT.cpu().numpy() / 0.1, st.m[0] / 0.1
+            np.testing.assert_allclose(g_hip, g_orc, rtol=5e-4, atol=2e-6 * np.abs(g_orc).max())
+            g_wrong = wrong.mT.cpu().numpy() / 0.1
+            assert np.abs(g_wrong - g_orc).max() > 1e-2 * np.abs(g_orc).max()       # (A for A^T: visibly another gradient)
+        np.testing.assert_allclose(state.T.cpu().numpy(), To, rtol=0, atol=0.02 * lr * (t + 1))
+
+
+@pytest.mark.parametrize("kind", [oracle.LOSS_NORMALBCE, oracle.LOSS_RUBIBCEBOTH])
 def test_lgcn_loss_only_pass(ops, kind):
     """MACR_STEP_LOSS_ONLY (the reference's "test loss" pass, LightGCN.py:799-819): the losses of a batch, equal to
     the losses the oracle's next step reports for that batch, with the model, the slots and the step count untouched."""
