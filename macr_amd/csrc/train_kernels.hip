@@ -742,8 +742,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // launch and bound by the transcendental rate, the Adam blocks stream through the remaining wave slots and are
 // bound by HBM, so the two costs overlap instead of adding.
 // ADAM = 2: the lazy pass (adam_lazy_scan_block) in place of the dense one.
+// ADAM 0 / 1 are compiled for six waves per SIMD (67 / 80 VGPRs, no spills; the compiler's own choice is 94 = five waves): the dense Adam
+// blocks riding in the launch are bound by memory-level parallelism, and one more of their waves beside each (B,B) wave is worth
+// 0.3-0.5 us per step -- bxb+adam 19.12-19.41 -> 18.87-19.17 us, bxb alone 12.7-13.2 -> 12.1-12.6, same box (profiles/
+// r06_bxb_waves_ab.txt; seven waves spill and cost 4.5 us).  The lazy form (ADAM == 2) needs its registers: left alone.
 template <int R, bool FULL, int ADAM>
-__global__ __launch_bounds__(256) void k_bxb(int B, int Bp, int ncb, int nbxb, const float *__restrict__ fwd,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ADAM == 2 ? 4 : 6, 8))) void k_bxb(int B, int Bp, int ncb, int nbxb, const float *__restrict__ fwd,
                                              float *__restrict__ rowpart, float *__restrict__ colpart,
                                              float *__restrict__ lpart, AdamArgs adam, const StepScalars *scal,
                                              BatchSort sort) {
