@@ -1166,29 +1166,58 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
             const int tq = slot0 + (lane % SPW);
             if (lane < 4 * SPW && tq < B) my_idx = (lane < SPW ? u : lane < 2 * SPW ? i : lane < 3 * SPW ? j : perm)[tq];
         }
+        // Everything that depends on the indices goes out in ONE straight-line burst (clamped addresses, no branch between the
+        // loads): the wave's SPW x 3 rows first, then the bxb partials and the forward scalars.  (Round 6: the ISA of the
+        // version before showed what its source did not -- a wait inside each partial loop, then per slot "load three rows,
+        // wait, atomics": eight dependent trips per wave instead of two; exec-mask branches end basic blocks and the
+        // compiler hoists no load over them.)
+        float reu[SPW][EPL], rei[SPW][EPL], rej[SPW][EPL];
+        int rru[SPW], rri[SPW], rrj[SPW];
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {             // (slots behind the end of the batch hold index 0: row 0, loaded and ignored)
+            rru[q] = __shfl(my_idx, q, kWave); rri[q] = __shfl(my_idx, SPW + q, kWave); rrj[q] = __shfl(my_idx, 2 * SPW + q, kWave);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int k = act ? lane + 64 * e : 0;
+                reu[q][e] = Usrc[(size_t)rru[q] * D + k]; rei[q][e] = Isrc[(size_t)rri[q] * D + k]; rej[q][e] = Isrc[(size_t)rrj[q] * D + k];
+            }
+        }
         // column sums dp,dn and row sums da,db of the (B,B) term: lane (q = lane/16, kk = lane%16) adds partials
         // kk, kk+16, ... of slot q, then the 16 lanes of a slot meet by shuffles
         const int q_own = lane >> 4, kk = lane & 15;
         float dp = 0.f, dn = 0.f, da = 0.f, db = 0.f, ssi = 0.f, ssj = 0.f, ssu = 0.f;
-        const int t_own = __shfl(my_idx, 3 * SPW + q_own, kWave);
         const bool own_ok = slot0 + q_own < B;
-#ifndef MACR_ABL_NOPART
-        if (own_ok) {
-#ifdef MACR_ABL_TPART            // timing probe (wrong results): the partials read as if stored [t][2][16] -- one line per slot and array
-            for (int k = kk; k < nrb; k += 16) { dp += colpart[((size_t)t_own * 2) * 16 + (k & 15)]; dn += colpart[((size_t)t_own * 2 + 1) * 16 + (k & 15)]; }
-            for (int k = kk; k < ncb; k += 16) { da += rowpart[((size_t)t_own * 2) * 16 + (k & 15)]; db += rowpart[((size_t)t_own * 2 + 1) * 16 + (k & 15)]; }
-#else
-            for (int k = kk; k < nrb; k += 16) { dp += colpart[((size_t)k * 2) * Bp + t_own]; dn += colpart[((size_t)k * 2 + 1) * Bp + t_own]; }
-            // (the neutral blocks' slab of row sums -- k_bxb -- is loaded AHEAD of the loop: as slab number ncb of the loop it was a
-            // second dependent trip for the lanes with kk = 0)
-            float dan = 0.f, dbn = 0.f;
-            if (kk < nneu) { dan = rowpart[((size_t)(ncb + kk) * 2) * Bp + t_own]; dbn = rowpart[((size_t)(ncb + kk) * 2 + 1) * Bp + t_own]; }
-            for (int k = kk; k < ncb; k += 16) { da += rowpart[((size_t)k * 2) * Bp + t_own]; db += rowpart[((size_t)k * 2 + 1) * Bp + t_own]; }
-            da += dan; db += dbn;
-#endif
-            if (kk < 3) ssi = fabsf(fwd[(4 + kk) * (size_t)Bp + t_own]);      // lane kk = 0,1,2: sig(si), sig(sj), |sig(su)| (its sign: a flag of pair_fwd)
+        const int t_own = own_ok ? __shfl(my_idx, 3 * SPW + q_own, kWave) : 0;
+        {
+            // up to 64 row blocks and 32 column blocks unrolled with clamped indices (every small-batch shape: B <= 8192 at
+            // R = 4 is nrb <= 32, R = 1 below 4096 is nrb <= 64); a loop behind them for forced shapes beyond
+            float cp[4], cn[4], ra[2], rb[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int k = kk + 16 * m, kc = k < nrb ? k : 0;
+                cp[m] = colpart[((size_t)kc * 2) * Bp + t_own]; cn[m] = colpart[((size_t)kc * 2 + 1) * Bp + t_own];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int k = kk + 16 * m, kc = k < ncb ? k : 0;
+                ra[m] = rowpart[((size_t)kc * 2) * Bp + t_own]; rb[m] = rowpart[((size_t)kc * 2 + 1) * Bp + t_own];
+            }
+            // (the neutral blocks' slab of row sums -- k_bxb -- is slab number ncb .. ncb + nneu - 1)
+            const int kn = kk < nneu ? ncb + kk : 0;
+            const float dan = rowpart[((size_t)kn * 2) * Bp + t_own], dbn = rowpart[((size_t)kn * 2 + 1) * Bp + t_own];
+            const float sg = fabsf(fwd[(4 + (kk < 3 ? kk : 0)) * (size_t)Bp + t_own]);   // lane kk = 0,1,2: sig(si), sig(sj), |sig(su)| (its sign: a flag of pair_fwd)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { const bool ok = own_ok && kk + 16 * m < nrb; dp += ok ? cp[m] : 0.f; dn += ok ? cn[m] : 0.f; }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { const bool ok = own_ok && kk + 16 * m < ncb; da += ok ? ra[m] : 0.f; db += ok ? rb[m] : 0.f; }
+            const bool neu_ok = own_ok && kk < nneu;               // (selects, not branches: a load whose only use sits under a branch is
+            da += neu_ok ? dan : 0.f; db += neu_ok ? dbn : 0.f;    // sunk into it by the compiler and becomes a trip of its own)
+            ssi = (own_ok && kk < 3) ? sg : 0.f;
+            if (own_ok) {                           // (wave-uniform trip counts: shapes beyond the unrolled part)
+                for (int k = kk + 64; k < nrb; k += 16) { dp += colpart[((size_t)k * 2) * Bp + t_own]; dn += colpart[((size_t)k * 2 + 1) * Bp + t_own]; }
+                for (int k = kk + 32; k < ncb; k += 16) { da += rowpart[((size_t)k * 2) * Bp + t_own]; db += rowpart[((size_t)k * 2 + 1) * Bp + t_own]; }
+            }
         }
-#endif
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) {
             dp += __shfl_xor(dp, m, kWave); dn += __shfl_xor(dn, m, kWave);
@@ -1200,18 +1229,18 @@ __global__ __launch_bounds__(256) void k_pair_bwd(
         const float dsj_own = db * (ssj * (1.0f - ssj)) * ssu + (alpha * invB) * dneglog_1msig(ssj, eps);
         const float dsu_own = (da * ssi + db * ssj) * (ssu * (1.0f - ssu)) +
                               (beta * invB) * (dneglog_sig(ssu, eps) + dneglog_1msig(ssu, eps));
-#pragma unroll                                   // the SPW triples' row gathers are issued together
+#pragma unroll
         for (int q = 0; q < SPW; ++q) {
             const int slot = wid * SPW + q;
             if (slot0 + q >= B) { if (lane == 0) s_pos[slot] = -1; continue; }
             const float dpq = __shfl(dp, q * 16, kWave), dnq = __shfl(dn, q * 16, kWave);
             const float dsi = __shfl(dsi_own, q * 16, kWave), dsj = __shfl(dsj_own, q * 16, kWave), dsu = __shfl(dsu_own, q * 16, kWave);
-            const int ru = __shfl(my_idx, q, kWave), ri = __shfl(my_idx, SPW + q, kWave), rj = __shfl(my_idx, 2 * SPW + q, kWave);
+            const int ru = rru[q], ri = rri[q], rj = rrj[q];
             if (act) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     const int k = lane + 64 * e;
-                    const float eu = Usrc[(size_t)ru * D + k], ei = Isrc[(size_t)ri * D + k], ej = Isrc[(size_t)rj * D + k];
+                    const float eu = reu[q][e], ei = rei[q][e], ej = rej[q][e];
                     const float gu = fmaf(coef, eu, fmaf(dsu, wuk[e], fmaf(dnq, ej, dpq * ei)));
                     const float gi = fmaf(coef, ei, fmaf(dsi, wk[e], dpq * eu));
                     const float gj = fmaf(coef, ej, fmaf(dsj, wk[e], dnq * eu));
