@@ -91,6 +91,20 @@ __device__ __forceinline__ float block_sum(float v, float *scratch) {
     return t;
 }
 
+// Three block-wide sums behind ONE pair of barriers (the same additions in the same order as three block_sum calls);
+// results valid in thread 0.  scratch: >= 48 floats of LDS.
+__device__ __forceinline__ void block_sum3(float &a, float &b, float &c, float *scratch) {
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { scratch[wid] = a; scratch[16 + wid] = b; scratch[32 + wid] = c; }
+    __syncthreads();
+    float ta = 0.f, tb = 0.f, tc = 0.f;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < nw; ++k) { ta += scratch[k]; tb += scratch[16 + k]; tc += scratch[32 + k]; }
+    a = ta; b = tb; c = tc;
+}
+
 // sigmoid as the oracle writes it: 1/(1+exp(-x)), fp32.
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 // d/dx of -log(sigmoid(x)+eps)   and   d/dy of -log((1-sigmoid(y))+eps)   (see oracle/macr_oracle.c)

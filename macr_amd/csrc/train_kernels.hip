@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
     float *__restrict__ fwd, float *__restrict__ part, int reg_on_gathered, float *__restrict__ gw, PendingAdam pa,
     int user_branch) {
     constexpr int d = 4 * LPR;
-    __shared__ float red[16];
+    __shared__ float red[48];
     __shared__ float s_lr[PENDING == 2 ? kLazyRing : 1];
     RowGroup<LPR> g;
     const int t = blockIdx.x * RowGroup<LPR>::kRowsPerBlock + g.slot;
@@ -630,9 +630,8 @@ __global__ __launch_bounds__(256) void k_pair_fwd(
             luser = user_branch ? -logf(ssu + eps) + -logf((1.0f - ssu) + eps) : 0.0f;
         }
     }
-    const float s0 = block_sum(sq, red);
-    const float s1 = block_sum(litem, red);
-    const float s2 = block_sum(luser, red);
+    float s0 = sq, s1 = litem, s2 = luser;
+    block_sum3(s0, s1, s2, red);                     // (one pair of barriers for the three sums)
     if (threadIdx.x == 0) {
         float *o = part + (size_t)blockIdx.x * kPartStride;
         o[0] = s0; o[1] = s1; o[2] = s2; o[3] = 0.f;
