@@ -3260,6 +3260,43 @@ __global__ void k_metrics_foldout(int U, int K, const int32_t *__restrict__ rank
     }
 }
 
+// 1 / log2(pos + 2) for pos = 0 .. 127 in float64 (the DCG discount of rank position pos: macr_mf/train.py:61-79, evaluate_foldout.h:71-88),
+// tabulated: the double-precision log2 and division per lane were about half of k_metrics_mf's time (generated by Python: 1.0 / math.log2(pos + 2)).
+__device__ const double kDcgDiscount[128] = {
+    0x1.0000000000000p+0, 0x1.430939835353ep-1, 0x1.0000000000000p-1, 0x1.b903469050f73p-2,
+    0x1.8c23246dc0aa0p-2, 0x1.6cc193acea9b5p-2, 0x1.5555555555555p-2, 0x1.430939835353ep-2,
+    0x1.34413509f79ffp-2, 0x1.28009c1dd6454p-2, 0x1.1da3383416064p-2, 0x1.14b94f8d9641fp-2,
+    0x1.0cf3ffed2d6acp-2, 0x1.0619dc46d3e15p-2, 0x1.0000000000000p-2, 0x1.f50b57eac5885p-3,
+    0x1.eb22cc68aa6e3p-3, 0x1.e21e1180c5dabp-3, 0x1.d9dcd21439834p-3, 0x1.d244c78367a0dp-3,
+    0x1.cb40589ac173ep-3, 0x1.c4bd95ba8d72bp-3, 0x1.bead76898f8cep-3, 0x1.b903469050f73p-3,
+    0x1.b3b433f2eb070p-3, 0x1.aeb6f759c46fdp-3, 0x1.aa038eb0e3bfep-3, 0x1.a593062b38d8dp-3,
+    0x1.a15f4c32b95a3p-3, 0x1.9d630dccc7ddfp-3, 0x1.999999999999ap-3, 0x1.95fec808a6094p-3,
+    0x1.928ee7b0b4f23p-3, 0x1.8f46acf8c06e3p-3, 0x1.8c23246dc0aa0p-3, 0x1.8921a744e1aedp-3,
+    0x1.863fd1a4a3053p-3, 0x1.837b7a642195ep-3, 0x1.80d2abffdfee9p-3, 0x1.7e439e8fed2b0p-3,
+    0x1.7bccb2952736ep-3, 0x1.796c6c7b22305p-3, 0x1.772170b2747aap-3, 0x1.74ea804c2020fp-3,
+    0x1.72c67602d3540p-3, 0x1.70b443a1f7c88p-3, 0x1.6eb2efbd2c1adp-3, 0x1.6cc193acea9b5p-3,
+    0x1.6adf59c6e689dp-3, 0x1.690b7bca1f15ep-3, 0x1.67454177dda00p-3, 0x1.658bff53d6bf2p-3,
+    0x1.63df15867d0dep-3, 0x1.623deedd496bap-3, 0x1.60a7ffe55458ap-3, 0x1.5f1cc61d1c5f1p-3,
+    0x1.5d9bc73ac2288p-3, 0x1.5c2490845f2f3p-3, 0x1.5ab6b6386aaa4p-3, 0x1.5951d3046396fp-3,
+    0x1.57f587883063fp-3, 0x1.56a179e4d652cp-3, 0x1.5555555555555p-3, 0x1.5410c9d09a12cp-3,
+    0x1.52d38bb397b32p-3, 0x1.519d5372b6ce4p-3, 0x1.506ddd51defe8p-3, 0x1.4f44e92275a60p-3,
+    0x1.4e223a06beda9p-3, 0x1.4d05963a1d8a7p-3, 0x1.4beec6ddbe115p-3, 0x1.4add97c942e46p-3,
+    0x1.49d1d75f15f0ep-3, 0x1.48cb56640af5fp-3, 0x1.47c9e7da07ae1p-3, 0x1.46cd60dd6e321p-3,
+    0x1.45d598850cb5ap-3, 0x1.44e267c45bba2p-3, 0x1.43f3a94fd9227p-3, 0x1.430939835353ep-3,
+    0x1.4222f649fbc95p-3, 0x1.4140bf081c4a9p-3, 0x1.406274864d58fp-3, 0x1.3f87f8de0f744p-3,
+    0x1.3eb12f67ab8e2p-3, 0x1.3dddfca9417e7p-3, 0x1.3d0e4646ed7c2p-3, 0x1.3c41f2f3ef9fbp-3,
+    0x1.3b78ea64c23f4p-3, 0x1.3ab315420d981p-3, 0x1.39f05d1c68ad2p-3, 0x1.3930ac60d89e8p-3,
+    0x1.3873ee4e00ec7p-3, 0x1.37ba0ee9f8387p-3, 0x1.3702faf8b610bp-3, 0x1.364e9ff30f403p-3,
+    0x1.359cebfe36ed5p-3, 0x1.34edcde3bb953p-3, 0x1.34413509f79ffp-3, 0x1.3397116cededfp-3,
+    0x1.32ef53978b4e7p-3, 0x1.3249ec9d46592p-3, 0x1.31a6ce14179f8p-3, 0x1.3105ea0ec499ep-3,
+    0x1.3067331778205p-3, 0x1.2fca9c2aa39aap-3, 0x1.2f3018b2246ddp-3, 0x1.2e979c80a97bbp-3,
+    0x1.2e011bcd54d68p-3, 0x1.2d6c8b2f960c4p-3, 0x1.2cd9df9b39ae5p-3, 0x1.2c490e5caaf3bp-3,
+    0x1.2bba0d15648b9p-3, 0x1.2b2cd1b88de42p-3, 0x1.2aa15287c25cep-3, 0x1.2a1786100001cp-3,
+    0x1.298f6326bb95ep-3, 0x1.2908e0e717dadp-3, 0x1.2883f6af3e1f6p-3, 0x1.28009c1dd6454p-3,
+    0x1.277ec90f9c85ep-3, 0x1.26fe759d135d9p-3, 0x1.267f9a18501a1p-3, 0x1.26022f0ae0a4dp-3,
+    0x1.25862d33c933dp-3, 0x1.250b8d8598a31p-3, 0x1.2492492492492p-3, 0x1.241a5964ec2e7p-3,
+};
+
 // The same, one WAVE per query (K <= 128): the K membership searches -- the dependent loads that are this kernel's time --
 // run side by side (lane l owns rank positions l and 64 + l), the prefix recurrences are the thread version's own
 // statements, run by every lane over the wave's hit mask (no memory in the loop; the discounts 1/log2(i+2) come from a table
@@ -3271,7 +3308,7 @@ __global__ __launch_bounds__(256) void k_metrics_foldout_w(int U, int K, const i
                                                            const int32_t *__restrict__ gt_ptr, const int32_t *__restrict__ gt_idx,
                                                            float *__restrict__ results, int hr_in_ap_slot) {
     __shared__ double s_disc[128];
-    if ((int)threadIdx.x < 128) s_disc[threadIdx.x] = 1.0 / log2((double)(threadIdx.x + 2));
+    if ((int)threadIdx.x < 128) s_disc[threadIdx.x] = kDcgDiscount[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -3361,7 +3398,7 @@ __global__ __launch_bounds__(256) void k_metrics_mf(int U, int Kmax, const int32
         const int item = pos < Kmax ? rankings[(size_t)u * Kmax + pos] : -1;
         n_valid += __popcll(__ballot(item >= 0));
         hit[h] = item >= 0 && in_sorted(truth, truth_len, item);
-        term[h] = 1.0 / log2((double)(pos + 2));                  // DCG discount of position `pos`
+        term[h] = kDcgDiscount[pos];                              // DCG discount of position `pos` (pos < 128)
     }
     // cnt == NULL: a list's length is its number of ids >= 0 -- what macr_topk_merge reports for it
     const int len = cnt ? cnt[u] : n_valid;
@@ -3406,7 +3443,7 @@ __global__ __launch_bounds__(64 * kMeanWaves) void k_metrics_mf_mean(int U, int 
     if (lane < kMeanCols) s_val[wv][lane] = 0.0;          // (each wave touches its own row only: no barrier needed before the loop)
     double term[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) term[h] = 1.0 / log2((double)(lane + 64 * h + 2));       // DCG discount of position lane + 64 h
+    for (int h = 0; h < 2; ++h) term[h] = kDcgDiscount[lane + 64 * h];                    // DCG discount of position lane + 64 h
     // A wave's four queries side by side in memory: one load for their five list bounds, then the four ranked lists and the
     // first 64 ids of the four truth lists in flight together -- two dependent trips for the wave instead of the 1 + log2(len)
     // of a binary search per query (what k_metrics_mf's 13 us are).  A truth list of <= 64 ids is searched across lanes.
