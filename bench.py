@@ -51,7 +51,14 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16, dense (MI355X_MICROARCH.md)
+# reduced-precision candidate filters of the evaluator (same ranking as "f32", bit for bit); the Evaluator's default
+LP_FILTERS = ("bf16", "f16")
+DEFAULT_EVAL_FILTER = "bf16"
+
+
+def lp_filter_name():
+    return os.environ.get("MACR_EVAL_FILTER", DEFAULT_EVAL_FILTER).strip().lower()
 N_BATCHES = 256                # pre-generated sampler batches every leg of the default workloads cycles through
 
 
@@ -297,7 +304,7 @@ def bench_config4(args, rank, world, dev, emit=True):
         # fp32 products throughout (priced against the fp32 MFMA peak), then the evaluator's default: the bf16 candidate
         # filter with fp32 re-scoring -- the same ranking, bit for bit
         t_f32, _ = timed("f32")
-        t_ev, ret = timed(os.environ.get("MACR_EVAL_FILTER", "bf16").lower())
+        t_ev, ret = timed(lp_filter_name())
         flops_rank = 2.0 * U * own_i.n * d
         eval_out = {"eval_users_per_s": U / t_ev, "eval_ms_per_pass": 1e3 * t_ev, "eval_users": U, "eval_filter": ev.filter,
                     "eval_info": ev.last_eval_info(), "eval_fast_stats": dict(getattr(ev, "fast_stats", {})),
@@ -531,14 +538,14 @@ def bench_lgcn(args, rank, world, dev):
                     "repaired": sum(1 for m in modes if m["query_blocks_relisted"] > 0 or m["exact_fallback"]),
                     "kernels_us": ek, "metrics": {k: float(v[0]) for k, v in ret.items()}}
         s32 = suite("f32")
-        sdef = suite(os.environ.get("MACR_EVAL_FILTER", "bf16").lower())
+        sdef = suite(lp_filter_name())
         lo, hi = sharding.item_shard_range(n_i, rank, world)
         flops = 2.0 * U * (hi - lo) * d
         k32 = s32["kernels_us"]
         rank_us = sum(v for k_, v in k32.items() if k_.startswith(("score_", "tau", "select", "bf16_prep", "repair_plan")))
         eval_out = {"eval_users_per_s": sdef["users_per_s"], "eval_ms_per_pass": sdef["ms_per_eval"], "eval_users": U,
                     "eval_metrics": sdef["metrics"],
-                    "eval": {"default_filter": "bf16", "f32": s32, "bf16": sdef, "train_steps_between_evaluations": steps_between,
+                    "eval": {"default_filter": lp_filter_name(), "f32": s32, lp_filter_name(): sdef, "train_steps_between_evaluations": steps_between,
                              "note": "one evaluation = propagation (L dense layers + mean) + branch sigmoids + ranking + fold-out "
                                      "metrics (batch_test.py:26-162), graph replays except the propagation"},
                     "roofline_eval": {"filter": "f32", "bound": "mfma", "flops": flops, "avg_us": rank_us,
@@ -1187,7 +1194,7 @@ def main():
             rank_kernels = ("score_sample", "score_sample_b", "tau", "tau_seed", "bf16_prep", "bf16_prep_c", "bf16_prep+tau_seed", "score_stream", "score_stream_b", "select", "select_b",
                             "repair_plan", "score_sample2", "tau2", "score_stream2", "select2", "score_topk")
             st_us = 1e3 * sum(ek.get(k, 0.0) for k in rank_kernels)
-            stream_us = 1e3 * ek.get("score_stream_b" if filt == "bf16" else "score_stream", float("nan"))
+            stream_us = 1e3 * ek.get("score_stream_b" if filt in LP_FILTERS else "score_stream", float("nan"))
             roofline_eval = {"kernel": "+".join(k for k in rank_kernels if k in ek), "bound": "mfma",
                              "achieved": flops / (st_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "avg_us": st_us, "flops": flops, "traffic": pmc.get(args.workload, {}).get("score_stream"),
@@ -1217,11 +1224,11 @@ def main():
         snapshot = {n_: getattr(state, n_).clone() for n_ in snap_names}
         suite_f32 = eval_suite("f32")
         suite = suite_f32
-        if os.environ.get("MACR_EVAL_FILTER", "bf16").lower() == "bf16":
+        if lp_filter_name() in LP_FILTERS:
             state.flush()
             for n_, t_ in snapshot.items():
                 getattr(state, n_).copy_(t_)
-            suite = eval_suite("bf16")
+            suite = eval_suite(lp_filter_name())
         del snapshot
         ret, eval_users_per_s, ev_elapsed = suite["ret"], suite["eval_users_per_s"], suite["ev_elapsed"]
         ev_unseeded_ms, ev_modes = suite["ev_unseeded_ms"], suite["ev_modes"]
@@ -1235,16 +1242,17 @@ def main():
             rb = suite["roofline_eval"]
             # what the bf16 matrix cores execute: three products per fp32 multiply-add (hi*hi + hi*lo + lo*hi) and one more
             # MFMA per tile for the bias slab that carries the score epilogue (k_score_stream_c): 3 + 16/d
+            # (the fp16 filter: one product and the slab, 1 + 16/d)
             sb = rb["stream"]["avg_us"]
-            mult = 3.0 + 16.0 / d
-            roofline_eval_bf16 = {"filter": "bf16", "bound": "mfma-bf16", "kernel": rb["kernel"], "avg_us": rb["avg_us"],
+            mult = (1.0 if lp_filter_name() == "f16" else 3.0) + 16.0 / d
+            roofline_eval_bf16 = {"filter": lp_filter_name(), "bound": "mfma-" + lp_filter_name(), "kernel": rb["kernel"], "avg_us": rb["avg_us"],
                                   "kernels_us": rb["kernels_us"], "seeded": rb["seeded"], "mode": rb["mode"],
                                   "stream": {"avg_us": sb, "executed_flops": mult * rb["flops"],
                                              "achieved": mult * rb["flops"] / (sb * 1e-6) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                                              "unit": "TFLOP/s", "frac": mult * rb["flops"] / (sb * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
                                   "eval_users_per_s": suite["eval_users_per_s"],
                                   "speedup_vs_f32_filter": suite["eval_users_per_s"] / suite_f32["eval_users_per_s"],
-                                  "note": "same ranking as the f32 filter, bit for bit: bf16 products only pick candidates, "
+                                  "note": "same ranking as the f32 filter, bit for bit: reduced-precision products only pick candidates, "
                                           "the best 64 per query are re-scored in fp32 (DESIGN.md, ranking note)"}
             for key in ("frac",):
                 rb["seeded"].pop(key, None)
@@ -1268,8 +1276,8 @@ def main():
                     "seeded": sum(1 for m in modes if m["seeded"]),
                     "repaired": sum(1 for m in modes if m["query_blocks_relisted"] > 0 or m["exact_fallback"]),
                     "query_blocks_relisted": sum(m["query_blocks_relisted"] for m in modes)}
-        eval_summary = {"default_filter": "bf16" if suite is not suite_f32 else "f32", "f32": _row(suite_f32),
-                        "bf16": _row(suite) if suite is not suite_f32 else None,
+        eval_summary = {"default_filter": lp_filter_name() if suite is not suite_f32 else "f32", "f32": _row(suite_f32),
+                        (lp_filter_name() if suite is not suite_f32 else "bf16"): _row(suite) if suite is not suite_f32 else None,
                         "train_steps_between_evaluations": args.eval_train_steps, "batch_pool": n_batches,
                         "roofline_eval_frac_f32_sampled": roofline_eval["frac"]}
 
@@ -1352,7 +1360,7 @@ def main():
             "roofline": roofline, "roofline_step": roofline_step, "roofline_aux": aux,
             "roofline_bxb": roofline_bxb(args.workload, B, kern_avg) if kind == ops.LOSS_RUBIBCEBOTH else None,
             "end_to_end": end_to_end, "cli_test": cli_test,
-            "roofline_eval": roofline_eval, "roofline_eval_bf16": roofline_eval_bf16, "cpu_baseline": cpu,
+            "roofline_eval": roofline_eval, ("roofline_eval_" + (roofline_eval_bf16 or {}).get("filter", "bf16")): roofline_eval_bf16, "cpu_baseline": cpu,
             "last_losses": [float(x) for x in losses[(args.warmup + args.steps - 1) % n_batches]],
         }
         if c4_line is not None:

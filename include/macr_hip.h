@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     13
+#define MACR_ABI_VERSION     14
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -495,13 +495,22 @@ size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
  *                          repair round; the selection takes each query's 64 best candidates by bf16 score, checks that
  *                          nothing else can belong to the top K, re-computes the fp32 score of those that can and ranks
  *                          them; a query that fails the check has all its listed candidates re-scored in fp32.
- *   MACR_EVAL_FILTER_ENV   follow MACR_EVAL_FILTER=f32|bf16 in the environment, f32 when unset.
+ *   MACR_EVAL_FILTER_F16   (abi 14) the product on ONE fp16 number per operand (v_mfma_f32_32x32x16_f16: a third of the
+ *                          bf16 filter's matrix-core work, half its operand bytes), margin (1.001 * 2^-10 + 8 d * 2^-24)
+ *                          |u| max|q| + roundings (1.0e-3 at d = 64) -- 12x the bf16 filter's, still several times
+ *                          below the gap between a query's K-th and 64th best score; the selection, the fp32 re-scoring
+ *                          and the per-query fall-back are the bf16 filter's.  An operand outside fp16's range
+ *                          (|x| > 65504) is clamped and voids the bound for its row: that query (every query, for an
+ *                          item row) ends in the exact kernel.  macr_score_topk_sweep has no fp16 kernels and runs
+ *                          its bf16 ones under this value.
+ *   MACR_EVAL_FILTER_ENV   follow MACR_EVAL_FILTER=f32|bf16|f16 in the environment, f32 when unset.
  * An ARGUMENT of every ranking call (`filter`, second parameter) since abi 10: the library keeps no filter state (round 4's
  * process-wide macr_set_eval_filter is gone).  A first-round call and the repair-round call that finishes it take the
  * same value. */
 #define MACR_EVAL_FILTER_ENV  0
 #define MACR_EVAL_FILTER_F32  1
 #define MACR_EVAL_FILTER_BF16 2
+#define MACR_EVAL_FILTER_F16  3
 /* OR into `filter` of macr_score_topk / macr_score_topk_first_round (abi 12): the head of `workspace` was initialised by
  * macr_score_topk_prologue for exactly this call, which then launches no initialisation of its own. */
 #define MACR_EVAL_WS_READY    0x100

@@ -31,6 +31,13 @@ int macr_test_bf16_scores(int score_kind, int d, int U, int N, const float *user
                           const float *sig_u, const float *sig_i, float c, float *scores, float *margin,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* TEST-ONLY: the same for the fp16 filter (MACR_EVAL_FILTER_F16; k_score_stream_h: one fp16 number per operand, the bias
+ * -c*sig_i (x sig_u for DIRECT_MINUS_BOTH) as six cross terms of two three-term fp16 splits in the slab).  Workspace:
+ * macr_test_bf16_scores_workspace_bytes.  A query whose row leaves fp16's range gets margin = +inf. */
+int macr_test_f16_scores(int score_kind, int d, int U, int N, const float *users, const float *items,
+                         const float *sig_u, const float *sig_i, float c, float *scores, float *margin,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINU
 MAX_TOPK = 128
 MAX_TOPK_FUSED = 32
 MAX_SWEEP = 4
-ABI_VERSION = 13
+ABI_VERSION = 14
 LAZY_STATE_BYTES, LAZY_MAX_PERIOD = 1040, 64
 
 
@@ -112,6 +112,7 @@ TEST_SIGNATURES = {
     "macr_test_bf16_products": (_i, [_i, _i, _i, _p, _p, _f, _p, _p, _p, _z, _p]),
     "macr_test_bf16_scores_workspace_bytes": (_z, [_i, _i, _i]),
     "macr_test_bf16_scores": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p]),
+    "macr_test_f16_scores": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p]),
 }
 
 _lib = None

@@ -926,6 +926,55 @@ __device__ __forceinline__ float filter_margin(int d, float unorm, float qmax, f
     return filter_rel(d) * b + kFilterAbs * (b + fabsf(c)) + 1e-37f;
 }
 
+// ----------------------------------------------------------------------------
+// fp16 FILTER (MACR_EVAL_FILTER_F16, round 6): ONE fp16 number per operand, one MFMA per 16 k instead of three.
+// fp16 keeps 11 significant bits where bf16 keeps 8, so x ~ fp16(x) alone (round to nearest even) is 8x closer than one
+// bf16 and the margin -- 2^-10 |u| max|q| -- stays several times below the gap between a query's K-th and 64th best score
+// (which the one-bf16 filter's 2^-7 did not: see above); what the wider margin costs is a few more exact re-scores in
+// k_select_b.  Everything else is the bf16 filter's: thresholds minus margin, 64 best by filter score, fp32 re-scoring,
+// per-query fall-back -- the fp32 ranking bit for bit.  The bound, element-wise:
+//   * |x - fp16(x)| <= 2^-11 |x| for |x| >= 2^-14, <= 2^-25 below (fp16 subnormals; v_mfma_f32_32x32x16_f16 does NOT flush
+//     them: tools/f16_mfma_check.hip, and the element-wise test runs operands over 24 binades), so
+//     sum_k |u_k q_k - u^_k q^_k| <= (2^-10 + 2^-22) sum_k |u_k q_k| + 2^-25 (1 + 2^-11)(|u|_1 + |q|_1) + d 2^-50
+//                                 <= 1.0005 * 2^-10 |u| max|q| + 2^-25 * 1.001 sqrt(d) (|u| + max|q|);
+//   * products of two fp16 numbers are exact in fp32; the accumulation and the exact score's own chain as for bf16 (8 d 2^-24
+//     covers d + 4 added terms with room to spare);
+//   * the bias -c sig_i as three fp16 terms: residual <= 2^-33 |bias| or, where the third term would be subnormal, 2^-25;
+//   * |x| > 65504 (a query row scaled by 1 / sig_u for DIRECT_MINUS_BOTH with sig_u below ~1e-5, an absurd embedding or c):
+//     the operand is CLAMPED (no inf, hence no NaN, enters an accumulator) and its norm reported as +inf: an infinite
+//     margin lists everything for that query (for every query when an item row did it), the lists overflow and the exact
+//     kernel ranks -- right, slow, and not a case a trained model produces.
+//   * RUBI_BOTH lists acc'' * sig_u: off by sig_u times the accumulator's margin -- the thresholds, the listing test and
+//     k_select_b scale the margin by sig_u there (a query with sig_u = 0.01 has scores, and score gaps, a hundred times smaller).
+// filter_rel_h(d) = 1.001 * 2^-10 + 8 d 2^-24: d = 32: 9.93e-4, 64: 1.008e-3, 128: 1.039e-3, 256: 1.100e-3.
+// ----------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__host__ __device__ constexpr float filter_rel_h(int d) { return 1.001f / 1024.f + 8.f * (float)d / 16777216.f; }
+constexpr float kHalfTiny = 3.0e-8f;         // > 2^-25: what rounding to fp16 costs an operand below fp16's normal range
+constexpr float kHalfMax = 65504.f;
+__device__ __forceinline__ float filter_margin_h(int d, float unorm, float qmax, float c) {
+    const float b = unorm * qmax * 1.0001f;
+    const float m = filter_rel_h(d) * b + kFilterAbs * (b + fabsf(c)) + kHalfTiny * (sqrtf((float)d) * (unorm + qmax) + 2.0f) + 1e-37f;
+    return m == m ? m : INFINITY;            // (inf * 0: a flagged query against an all-zero catalogue)
+}
+// the margin of the filter in use: half != 0 = the fp16 filter
+__device__ __forceinline__ float filter_margin_of(int half, int d, float unorm, float qmax, float c) {
+    return half ? filter_margin_h(d, unorm, qmax, c) : filter_margin(d, unorm, qmax, c);
+}
+__device__ __forceinline__ uint32_t f16_rne_bits(float f) {            // round to nearest even, clamped to the finite range
+    f = fminf(fmaxf(f, -kHalfMax), kHalfMax);
+    const _Float16 hv = (_Float16)f;
+    uint16_t b;
+    __builtin_memcpy(&b, &hv, 2);
+    return b;
+}
+__device__ __forceinline__ float f16_bits_value(uint32_t b) {
+    const uint16_t s = (uint16_t)b;
+    _Float16 hv;
+    __builtin_memcpy(&hv, &s, 2);
+    return (float)hv;
+}
+
 __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {          // round to nearest even; NaN stays NaN
     const uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
@@ -1351,6 +1400,54 @@ struct StreamCfgC {
     static constexpr size_t smem = (size_t)2 * TU * 16 + kUsersPerBlock * 4 + 16;
 };
 static inline size_t items_c_bytes(int n_local, int d) { return (size_t)n_tiles(n_local) * kTileItems * (2 * d / 8 + 1) * 16; }
+// the fp16 filter's copies (bf16_prep_c_block<.., HALF>): RU = D/8 + 1 units per item row; they live in the same buffers
+template <int D>
+struct StreamCfgH1 {                                           // one tile per visit (k_score_sample_c<.., HALF>)
+    static constexpr int RU = D / 8 + 1;
+    static constexpr int TU = kTileItems * RU;
+    static constexpr int NS = D / 16;
+    static constexpr int LDU = (TU + 511) / 512, REM = TU - 512 * (LDU - 1);
+    static constexpr size_t smem = (size_t)2 * TU * 16 + kUsersPerBlock * 4 + 16;
+};
+template <int D>
+struct StreamCfgH {                                            // two tiles per step (k_score_stream_h)
+    static constexpr int RU = D / 8 + 1;
+    static constexpr int TU = kTileItems * RU;
+    static constexpr int NS = D / 16;
+    static constexpr int SU = 2 * TU;                          // units staged per step
+    static constexpr int LDU = (SU + 511) / 512, REM = SU - 512 * (LDU - 1);
+    static constexpr size_t smem = (size_t)2 * SU * 16 + kUsersPerBlock * 4 + 16;
+};
+// eight fp16 numbers per operand register group, carried in the bf16 vector type of the surrounding code
+__device__ __forceinline__ f32x16 mfma_f16(bf16x8 a, bf16x8 b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+
+// The bias slab of the fp16 filter.  DIRECT_MINUS_BOTH subtracts c sig_i sig_u: the bf16 copies divide the query row by sig_u
+// and multiply the listed score by it (a bf16 slab entry holds 8 bits of sig_u); 1 / sig_u can leave fp16's range, so here both
+// factors stay in the slab instead, as three fp16 terms each -- item side b = -c sig_i ~ b1 + b2 + b3, query side
+// s = sig_u ~ s1 + s2 + s3 -- and six of the nine cross products ride in the slab's k slots:
+//   item unit  [b1 b1 b2 b1 b2 b3 0 0],  query unit [s1 s2 s1 s3 s2 s1 0 0]      (dropped: b2 s3 + b3 s2 + b3 s3 <= 2^-32 |b s|)
+// every product exact in fp32.  The other kinds put s = 1 there (s1 = 1, s2 = s3 = 0: the slab adds b1 + b2 + b3).
+// |b s - slab| <= 2^-25 (|c| + 1) where terms fall below fp16's subnormals: inside filter_margin_h's absolute terms.
+template <int KIND> __device__ __forceinline__ bf16x8 bias_query_unit_h(float su, bool on) {
+    const float sv = KIND == MACR_SCORE_DIRECT_MINUS_BOTH ? su : 1.0f;
+    const uint32_t s1 = f16_rne_bits(sv);
+    const float r1 = sv - f16_bits_value(s1);
+    const uint32_t s2 = f16_rne_bits(r1), s3 = f16_rne_bits(r1 - f16_bits_value(s2));
+    union { uint32_t u[4]; bf16x8 v; } w;
+    w.u[0] = on ? (s1 | (s2 << 16)) : 0u; w.u[1] = on ? (s1 | (s3 << 16)) : 0u; w.u[2] = on ? (s2 | (s1 << 16)) : 0u; w.u[3] = 0u;
+    return w.v;
+}
+__device__ __forceinline__ uint4 bias_item_unit_h(float bias) {
+    const float bc = fminf(fmaxf(bias, -kHalfMax), kHalfMax);
+    const uint32_t b1 = f16_rne_bits(bc);
+    const float r1 = bc - f16_bits_value(b1);
+    const uint32_t b2 = f16_rne_bits(r1), b3 = f16_rne_bits(r1 - f16_bits_value(b2));
+    return make_uint4(b1 | (b1 << 16), b2 | (b1 << 16), b2 | (b3 << 16), 0u);
+}
+// the factor a listed score carries outside the accumulator under the fp16 filter
+template <int KIND> __device__ __forceinline__ float query_factor_h(float su) { return KIND == MACR_SCORE_RUBI_BOTH ? su : 1.0f; }
 
 // item scale / bias / user scale of a score kind (see above); c < 0 or > 0 alike
 template <int KIND> __device__ __forceinline__ float item_scale_c(float sgi) {
@@ -1364,13 +1461,15 @@ __device__ __forceinline__ bool sig_u_tiny(float su) { return !(su > 1e-30f); }
 // Operand copies for k_score_stream_c: item rows (and the zero rows up to a whole tile) in the RU-unit layout, query rows
 // as in k_bf16_prep (scaled for DIRECT_MINUS_BOTH), |u| per query, max |q| -- norms of the UNscaled rows, which bound the
 // scaled ones.  Row space of a block: [0, n_pad) items, [n_pad, n_pad + U) queries.
-template <int D, int KIND, int TRIPS>
+// HALF: the fp16 filter's copies instead -- fp16[D] per row (item rows: + the bias unit, RU = D/8 + 1), clamped to the
+// finite range; a row that was clamped reports an infinite norm (filter_margin_h).
+template <int D, int KIND, int TRIPS, bool HALF = false>
 __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, const float *__restrict__ users_tab,
                                                   const int32_t *__restrict__ user_ids, const float *__restrict__ items,
                                                   const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
                                                   uint4 *__restrict__ users_c, uint4 *__restrict__ items_c,
                                                   float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
-    constexpr int LPRB = D / 8, RPB = 256 / LPRB, RU = StreamCfgC<D>::RU;
+    constexpr int LPRB = D / 8, RPB = 256 / LPRB, RU = HALF ? D / 8 + 1 : StreamCfgC<D>::RU;
     __shared__ float s_max[4];
     const int n_pad = ((n_local + kTileItems - 1) / kTileItems) * kTileItems;
     const int sub = threadIdx.x % LPRB, slot = threadIdx.x / LPRB;
@@ -1390,7 +1489,7 @@ __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, c
             const float sgi = sig_i[row[t]];
             scale[t] = item_scale_c<KIND>(sgi); bias[t] = item_bias_c<KIND>(sgi, c);
         }
-        if (is_user && KIND == MACR_SCORE_DIRECT_MINUS_BOTH) {
+        if (is_user && KIND == MACR_SCORE_DIRECT_MINUS_BOTH && !HALF) {     // (HALF: sig_u sits in the bias slab, bias_query_unit_h)
             const float su = sig_u[q];
             scale[t] = sig_u_tiny(su) ? 1.0f : 1.0f / su;
         }
@@ -1401,31 +1500,44 @@ __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, c
         const bool is_item = row[t] < n_local, is_pad = row[t] >= n_local && row[t] < n_pad;
         const long long q = row[t] - n_pad;
         const bool is_user = q >= 0 && q < U;
-        float sq = 0.f;
+        float sq = 0.f, clamped = 0.f;
         if (is_item || is_user || is_pad) {
             const float x[8] = {a[t].x * scale[t], a[t].y * scale[t], a[t].z * scale[t], a[t].w * scale[t],
                                 b[t].x * scale[t], b[t].y * scale[t], b[t].z * scale[t], b[t].w * scale[t]};
             uint32_t hi[8], lo[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                hi[k] = is_pad ? 0u : bf16_rne_bits(x[k]);
-                lo[k] = is_pad ? 0u : bf16_rne_bits(x[k] - __uint_as_float(hi[k] << 16));
+                if (HALF) {
+                    hi[k] = is_pad ? 0u : f16_rne_bits(x[k]);
+                    lo[k] = 0u;
+                    if (!is_pad && fabsf(x[k]) > kHalfMax) clamped = 1.0f;
+                } else {
+                    hi[k] = is_pad ? 0u : bf16_rne_bits(x[k]);
+                    lo[k] = is_pad ? 0u : bf16_rne_bits(x[k] - __uint_as_float(hi[k] << 16));
+                }
             }
             const uint4 vh = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
             const uint4 vl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
             if (is_user) {
-                uint4 *dst = users_c + (size_t)q * 2 * LPRB;
-                dst[sub] = vh; dst[LPRB + sub] = vl;
+                uint4 *dst = users_c + (size_t)q * (HALF ? 1 : 2) * LPRB;
+                dst[sub] = vh;
+                if (!HALF) dst[LPRB + sub] = vl;
             } else {
                 uint4 *dst = items_c + (size_t)row[t] * RU;
-                dst[sub] = vh; dst[LPRB + sub] = vl;
-                if (sub == 0) {                                // the bias unit: three bf16 terms, then zeros
+                dst[sub] = vh;
+                if (!HALF) dst[LPRB + sub] = vl;
+                if (sub == 0) {                                // the bias unit: three bf16 (fp16) terms, then zeros
                     const float bi = is_pad ? 0.0f : bias[t];
-                    const uint32_t b1 = bf16_rne_bits(bi);
-                    const float r1 = bi - __uint_as_float(b1 << 16);
-                    const uint32_t b2 = bf16_rne_bits(r1);
-                    const uint32_t b3 = bf16_rne_bits(r1 - __uint_as_float(b2 << 16));
-                    dst[2 * LPRB] = make_uint4(b1 | (b2 << 16), b3, 0u, 0u);
+                    if (HALF) {
+                        if (fabsf(bi) > kHalfMax) clamped = 1.0f;
+                        dst[LPRB] = bias_item_unit_h(bi);
+                    } else {
+                        const uint32_t b1 = bf16_rne_bits(bi);
+                        const float r1 = bi - __uint_as_float(b1 << 16);
+                        const uint32_t b2 = bf16_rne_bits(r1);
+                        const uint32_t b3 = bf16_rne_bits(r1 - __uint_as_float(b2 << 16));
+                        dst[2 * LPRB] = make_uint4(b1 | (b2 << 16), b3, 0u, 0u);
+                    }
                 }
             }
             sq = dot4(a[t], a[t]) + dot4(b[t], b[t]);         // (of the row as given, not as scaled)
@@ -1433,6 +1545,7 @@ __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, c
         sq = group_sum<LPRB>(sq);
         float nrm = sqrtf(sq) * 1.0001f;
         if (!(nrm == nrm)) nrm = INFINITY;
+        if (HALF && group_sum<LPRB>(clamped) > 0.f) nrm = INFINITY;     // an operand outside fp16's range: no bound for this row
         if (is_user && sub == 0) unorm[q] = nrm;
         if (is_item) m = fmaxf(m, nrm);
     }
@@ -1451,14 +1564,14 @@ static inline unsigned bf16_prep_c_blocks(int U, int n_local, int d, int trips) 
     return (unsigned)(((size_t)n_tiles(n_local) * kTileItems + U + rows_per_block - 1) / rows_per_block);
 }
 
-template <int D, int KIND>
+template <int D, int KIND, bool HALF = false>
 __global__ __launch_bounds__(256) void k_bf16_prep_c(int U, int n_local, const float *__restrict__ users_tab,
                                                      const int32_t *__restrict__ user_ids, const float *__restrict__ items,
                                                      const float *__restrict__ sig_u, const float *__restrict__ sig_i,
                                                      float c_val, const float *__restrict__ c_dev,
                                                      uint4 *__restrict__ users_c, uint4 *__restrict__ items_c,
                                                      float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
-    bf16_prep_c_block<D, KIND, kPrepTripsAlone>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_c,
+    bf16_prep_c_block<D, KIND, kPrepTripsAlone, HALF>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_c,
                                                 items_c, unorm, qmax_bits);
 }
 
@@ -1695,13 +1808,14 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
 // 1/2^s sample of the catalogue.  With the epilogue in the operands a score costs its share of the MFMAs and one v_max;
 // masked items are poisoned at accumulator init.  The rows of a virtual tile are 2^s items apart: every unit is gathered
 // by its own address (row and unit index of a thread's units are fixed; the window's base is wave-uniform).
-template <int D, int KIND, bool REPAIR = false>
+template <int D, int KIND, bool REPAIR = false, bool HALF = false>
 __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
     int U, int n_local, const uint4 *__restrict__ users_c, const uint4 *__restrict__ items_c,
     const float *__restrict__ sig_u, const uint32_t *__restrict__ mask_bits, const uint32_t *__restrict__ zero_word,
     int ublocks, float *__restrict__ maxima, int sample_log2, int merge_pairs,
     const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev) {
-    using C = StreamCfgC<D>;
+    using C = std::conditional_t<HALF, StreamCfgH1<D>, StreamCfgC<D>>;      // HALF: the fp16 filter's copies (one MFMA per 16 k)
+    constexpr int UR = HALF ? D / 8 : 2 * D / 8;              // 16-byte units per query row
     constexpr int THREADS = 512, NS = C::NS, RU = C::RU, TU = C::TU, LDU = C::LDU, REM = C::REM;
     const int kStep = 1 << sample_log2;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1755,22 +1869,22 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
     __syncthreads();                                          // (the previous segment's readers are done with s_t)
     bf16x8 bhi[NS], blo[NS];
     {
-        const uint4 *urow = users_c + (size_t)(q_ok ? q : 0) * (2 * D / 8);
+        const uint4 *urow = users_c + (size_t)(q_ok ? q : 0) * UR;
 #pragma unroll
         for (int sI = 0; sI < NS; ++sI) {
-            uint4 v = urow[2 * sI + h], l = urow[D / 8 + 2 * sI + h];
+            uint4 v = urow[2 * sI + h], l = HALF ? v : urow[D / 8 + 2 * sI + h];
             if (!q_ok) { v = make_uint4(0u, 0u, 0u, 0u); l = v; }
-            bhi[sI] = *reinterpret_cast<bf16x8 *>(&v);
+            bhi[sI] = *reinterpret_cast<bf16x8 *>(&v);        // (HALF: eight fp16 numbers travelling in the bf16 type)
             blo[sI] = *reinterpret_cast<bf16x8 *>(&l);
         }
     }
     const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
     const bool tiny = score_uses_sig_u(KIND) && sig_u_tiny(su);
-    const float fu = (KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny) ? 1.0f : su;
+    const float fu = HALF ? query_factor_h<KIND>(su) : (KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny) ? 1.0f : su;
     const bool ones_on = KIND != MACR_SCORE_NORMAL && h == 0 && !(KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny);
     union { uint32_t u[4]; bf16x8 v; } ones;
     ones.u[0] = ones_on ? 0x3f803f80u : 0u; ones.u[1] = ones_on ? 0x00003f80u : 0u; ones.u[2] = 0u; ones.u[3] = 0u;
-    const bf16x8 bext = ones.v;
+    const bf16x8 bext = HALF ? bias_query_unit_h<KIND>(su, KIND != MACR_SCORE_NORMAL && h == 0) : ones.v;
     const uint32_t *my_mask = mask_bits ? mask_bits + (q_ok ? q : 0) : zero_word;
 
     uint4 stg[LDU];
@@ -1818,24 +1932,28 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
         constexpr int CH = NS < 4 ? NS : 4;
         bf16x8 ae;
         if (KIND != MACR_SCORE_NORMAL)
-            ae = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(s_t + buf * TU) + (size_t)col * (8 * RU) + 2 * D);
+            ae = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(s_t + buf * TU) + (size_t)col * (8 * RU) + (HALF ? D : 2 * D));
 #pragma unroll
         for (int s0 = 0; s0 < NS; s0 += CH) {
             bf16x8 ah[CH], al[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 ah[j] = *reinterpret_cast<const bf16x8 *>(ua + 16 * (s0 + j));
-                al[j] = *reinterpret_cast<const bf16x8 *>(ua + D + 16 * (s0 + j));
+                if (!HALF) al[j] = *reinterpret_cast<const bf16x8 *>(ua + D + 16 * (s0 + j));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[j], bhi[s0 + j], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], blo[s0 + j], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], bhi[s0 + j], acc, 0, 0, 0);
+                if (HALF) {
+                    acc = mfma_f16(ah[j], bhi[s0 + j], acc);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[j], bhi[s0 + j], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], blo[s0 + j], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], bhi[s0 + j], acc, 0, 0, 0);
+                }
             }
-            if (KIND != MACR_SCORE_NORMAL && s0 + CH >= NS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ae, bext, acc, 0, 0, 0);
+            if (KIND != MACR_SCORE_NORMAL && s0 + CH >= NS) acc = HALF ? mfma_f16(ae, bext, acc) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(ae, bext, acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -1886,23 +2004,317 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
     }   // segments
 }
 
+// ----------------------------------------------------------------------------
+// k_score_stream_h: the listing pass of the fp16 filter.  Same work decomposition, lists, counters, stale-seed protocol
+// and repair layout as k_score_stream_c (a block = one 256-query block x a scattered range of item tiles), but with one
+// MFMA per 16 k the matrix cores are no longer what a visit costs -- the LDS reads of the item fragments and the barrier
+// are -- so a wave keeps TWO 32-query groups in registers (64 queries; B operands 2 x D/2 bytes per lane) and every item
+// fragment it reads serves two MFMAs; the block's eight waves then cover the 256 queries twice, and the two halves take
+// two DIFFERENT tiles of one step (waves 0-3 the first, 4-7 the second): two tiles staged per barrier, each tile's
+// fragments read by four waves instead of eight.  LDS reads per 32 x 32 products: a quarter of k_score_stream_c's in
+// count, an eighth in bytes.  The two waves that share a query append to her list through the same LDS counter.
+// ----------------------------------------------------------------------------
+template <int D, int KIND, bool REPAIR = false>
+__global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
+    int U, int n_local, const uint4 *__restrict__ users_h, const uint4 *__restrict__ items_h,
+    const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
+    const float *__restrict__ sig_u, float c_val, const float *__restrict__ c_dev,
+    const uint32_t *__restrict__ mask_bits, const uint32_t *__restrict__ zero_word, int item_offset, int ublocks,
+    const float *__restrict__ tau, uint64_t *__restrict__ lists, int32_t *__restrict__ counts, int cap, int32_t *overflow,
+    int ovf_per_user, int32_t *blk_flag, const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev, int slots_full,
+    int xcd_pieces) {
+    using C = StreamCfgH<D>;
+    constexpr int THREADS = 512, NS = C::NS, RU = C::RU, TU = C::TU, SU = C::SU, LDU = C::LDU;
+    constexpr int kCheckTiles = 8;
+    const float c = c_dev ? *c_dev : c_val;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4 *s_t = reinterpret_cast<uint4 *>(smem);                                      // [2 buffers][2 tiles][TU]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)2 * SU * 16);       // [256]
+    int *s_stop = reinterpret_cast<int *>(s_cnt + kUsersPerBlock);                     // [1]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int tslot = __builtin_amdgcn_readfirstlane(wid >> 2), uw = wid & 3;          // this wave's tile of a step; its 64 queries
+    const int T = (n_local + kTileItems - 1) / kTileItems;
+    int n_ub = ublocks;
+    long long G = gridDim.x;
+    const long long b = blockIdx.x;
+    RepairLayout rl = {false, 0, U};
+    if (REPAIR) {
+        n_ub = *n_ub_dev;
+        if (n_ub == 0) return;
+        rl = repair_layout(slots_full, U, n_ub);
+        G = repair_grid(rl, G, ublocks, n_ub, T);
+        if (b >= G) return;
+    }
+    int S = (int)(0.6180339f * (float)T);                     // the visit order of k_score_stream (scattered tile ranges)
+    S = S < 1 ? 1 : S;
+    for (;; ++S) {
+        int x = S, y = T;
+        while (y) { const int r = x % y; x = y; y = r; }
+        if (x == 1) break;
+    }
+    auto visit = [&](int i) { return (int)(((unsigned long long)i * (unsigned)S) % (unsigned)T); };
+    auto visit_after = [&](int tile) { const int n = tile + S; return n >= T ? n - T : n; };
+    const float qmax = __uint_as_float(*qmax_bits);
+    const long long W = (long long)n_ub * T;
+    const long long w_end = W * (b + 1) / G;
+    const size_t mask_stride = mask_bits ? (size_t)U : 0;
+    // segments of this block: (query block, visits [i0, i1), result slot).  Linear decomposition: a contiguous share of the
+    // n_ub * T visits (k_score_stream_c).  XCD-aware (first round, xcd_pieces > 0; StreamGeo): this XCD's eighth of the visit
+    // sequence for the units (query block, piece) j, j + blocks per XCD, ...
+    const bool by_xcd = !REPAIR && xcd_pieces > 0;
+    const int xcd = (int)(b & 7), bx = (int)(G >> 3);
+    const int x0 = (int)((long long)T * xcd / 8), x1 = (int)((long long)T * (xcd + 1) / 8);
+    const int n_units = n_ub * xcd_pieces;
+    int unit = (int)(b >> 3);
+    for (long long w = W * b / G; by_xcd ? unit < n_units : w < w_end;) {
+    int ubv, i0, i1, split;
+    if (by_xcd) {
+        ubv = unit / xcd_pieces;
+        const int piece = unit - ubv * xcd_pieces;
+        i0 = x0 + (int)((long long)(x1 - x0) * piece / xcd_pieces);
+        i1 = x0 + (int)((long long)(x1 - x0) * (piece + 1) / xcd_pieces);
+        split = xcd * xcd_pieces + piece;
+        unit += bx;
+    } else {
+        ubv = (int)(w / T); i0 = (int)(w - (long long)ubv * T);
+        i1 = (int)min((long long)T, i0 + (w_end - w));
+        w += i1 - i0;
+        long long first = (long long)ubv * T * G / W;
+        while (W * (first + 1) / G <= (long long)ubv * T) ++first;
+        while (W * first / G > (long long)ubv * T) --first;
+        split = (int)(b - first);
+    }
+    const int ub = REPAIR ? ub_map[ubv] : ubv;
+    __syncthreads();                                          // (the previous segment's readers are done with s_t and s_cnt)
+    for (int k = tid; k < kUsersPerBlock; k += THREADS) s_cnt[k] = 0u;
+    if (tid == 0) *s_stop = 0;
+    bf16x8 bq[2][NS], bext[2];
+    float thr[2], fu[2];
+    uint32_t my_list[2], my_q[2];                             // list index (units of cap) / clamped query index: addresses are formed where used
+    uint32_t *my_cnt[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int uslot = uw * 64 + g * 32 + col, q = ub * kUsersPerBlock + uslot;
+        const bool q_ok = q < U;
+        const uint4 *urow = users_h + (size_t)(q_ok ? q : 0) * (D / 8);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            uint4 v = urow[2 * sI + h];
+            if (!q_ok) v = make_uint4(0u, 0u, 0u, 0u);
+            bq[g][sI] = *reinterpret_cast<bf16x8 *>(&v);
+        }
+        const float su = (score_uses_sig_u(KIND) && q_ok) ? sig_u[q] : 1.0f;
+        const bool tiny = KIND == MACR_SCORE_RUBI_BOTH && sig_u_tiny(su);
+        fu[g] = query_factor_h<KIND>(su);                     // listed score = acc'' * fu
+        bext[g] = bias_query_unit_h<KIND>(su, KIND != MACR_SCORE_NORMAL && h == 0);
+        float tau_s = __builtin_nanf("");
+        if (q_ok) tau_s = tau[q] - 1.01f * filter_margin_h(D, unorm[q], qmax, c) * fu[g];      // (the margin of acc'' times the score's outer factor)
+        thr[g] = tau_s / fu[g];
+        if (tiny) thr[g] = q_ok ? -INFINITY : thr[g];        // (scores of the order of sig_u: everything is a candidate)
+        my_list[g] = (uint32_t)((size_t)split * rl.stride + ((REPAIR && rl.compact) ? ubv * kUsersPerBlock + uslot : (q_ok ? q : 0)));
+        my_q[g] = mask_bits ? (uint32_t)(q_ok ? q : 0) : 0u;
+        my_cnt[g] = &s_cnt[uslot];
+    }
+    const int id_lane = item_offset + 4 * h;                  // id of accumulator slot r: tile * 32 + (r & 3) + 8 * (r >> 2) + id_lane
+
+    uint4 stg[LDU];
+    uint32_t tm_next[2] = {0u, 0u};
+    // Tiles (ta, tb) of the next step into registers (unit e of [tile A | tile B] by thread e mod 512; the last round wraps:
+    // everybody loads, the owners store), then the mask words of THIS wave's tile.  (LDS-DMA -- global_load_lds_dwordx4
+    // with scalar bases, no registers -- was built and measured 20 us slower for the pass: profiles/r06_eval_f16_filter.txt.)
+    auto load_step = [&](int ta, int tb) {
+        const int tau_ = __builtin_amdgcn_readfirstlane(ta), tbu = __builtin_amdgcn_readfirstlane(tb);
+#pragma unroll
+        for (int k = 0; k < LDU; ++k) {
+            int e = tid + THREADS * k;
+            if (k + 1 == LDU && e >= SU) e -= SU;              // (the wrapped loads of the last round: any valid unit)
+            const bool second = e >= TU;
+            stg[k] = items_h[(size_t)(second ? tbu : tau_) * TU + (second ? e - TU : e)];
+        }
+        const int mine = tslot ? tbu : tau_;
+        const uint32_t *mrow = (mask_bits ? mask_bits : zero_word) + (size_t)mine * mask_stride;
+        tm_next[0] = mrow[my_q[0]];
+        tm_next[1] = mrow[my_q[1]];
+    };
+    auto store_step = [&](auto BUF) {
+        constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+        for (int k = 0; k < LDU; ++k) {
+            asm volatile("" : "+v"(stg[k].x), "+v"(stg[k].y), "+v"(stg[k].z), "+v"(stg[k].w));
+            if (k + 1 < LDU || tid < SU - THREADS * (LDU - 1)) s_t[buf * SU + tid + THREADS * k] = stg[k];
+        }
+    };
+    // one step: this wave's tile t (t < 0: none -- the odd tile out of a range) sits in half `tslot` of buffer BUF
+    auto one_step = [&](auto BUF, int t, uint32_t tm0, uint32_t tm1) {
+        constexpr int buf = decltype(BUF)::value;
+        const __bf16 *ua = reinterpret_cast<const __bf16 *>(s_t + buf * SU + tslot * TU) + (size_t)col * (8 * RU) + 8 * h;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        // (fragments two k-slabs at a time at d <= 64: with four, the kernel needs 132 registers and the spill's reload waits for
+        // the tile prefetch -- vmcnt counts scratch and global loads alike)
+        constexpr int CH = NS < 2 ? NS : (D <= 64 ? 2 : 4);
+        bf16x8 ae;
+        if (KIND != MACR_SCORE_NORMAL) ae = *reinterpret_cast<const bf16x8 *>(ua - 8 * h + D);      // (the bias unit: lanes of both halves read k < 8)
+#pragma unroll
+        for (int s0 = 0; s0 < NS; s0 += CH) {
+            bf16x8 af[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) af[j] = *reinterpret_cast<const bf16x8 *>(ua + 16 * (s0 + j));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {                    // (two independent accumulators: back to back without the dependent-issue gap)
+#ifndef MACR_ABL_H_NOMFMA
+                acc0 = mfma_f16(af[j], bq[0][s0 + j], acc0);
+                acc1 = mfma_f16(af[j], bq[1][s0 + j], acc1);
+#else
+                acc0[j] += (float)af[j][0] * (float)bq[0][s0 + j][0];
+                acc1[j] += (float)af[j][1] * (float)bq[1][s0 + j][1];
+#endif
+            }
+            if (KIND != MACR_SCORE_NORMAL && s0 + CH >= NS) {
+                acc0 = mfma_f16(ae, bext[0], acc0);
+                acc1 = mfma_f16(ae, bext[1], acc1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int valid = t < 0 ? 0 : n_local - t * kTileItems;           // < 32 only in the last tile of the shard
+        const uint32_t tailm = valid < kTileItems ? ~0u << (valid > 0 ? valid : 0) : 0u;
+        const int id0 = t * kTileItems + id_lane;
+        // Epilogue: per score one v_cmp + one s_cbranch (k_score_stream_c's), a hit costs eight vector instructions (mask bit,
+        // LDS counter, key, store).  With one MFMA per 16 k those compare/branch pairs -- ~18 cycles each: the scalar branch
+        // waits for the vector compare -- were 85 of the pass's 181 us (ablation: profiles/r06_eval_f16_filter.txt), so four scores
+        // (one row quad of the tile) are first tested together: v_max3 + v_max + one pair, and only a quad somebody passes is
+        // looked at score by score -- 2/3 of the quads under sampled thresholds (~176 listed per query), 1/6 under seeded ones.
+        // (A branch-free form -- per-lane hit words by v_cmp + v_addc, one counter bump per lane and tile, a scalar loop
+        // over the slots hit with a wave-uniform register index -- was built and measured: 195 / 178 us sampled / seeded
+        // against 178 / 176 for the plain pairs; the loop's ~35 cycles per slot hit cost what the branches had.)
+        auto epilogue = [&](const f32x16 &acc, uint32_t tm_cur, float thr_g, float fu_g, uint32_t *cnt_g, uint32_t list_g) {
+            const uint32_t tmh = (tm_cur | tailm) >> (4 * h);  // bit (r & 3) + 8 (r >> 2): this lane's row of slot r is masked / past the end
+#pragma unroll
+            for (int r4 = 0; r4 < 16; r4 += 4) {
+                const float quad = fmaxf(fmaxf(fmaxf(acc[r4], acc[r4 + 1]), acc[r4 + 2]), acc[r4 + 3]);       // (fmaxf drops a NaN: as the compare below would)
+                if (!__builtin_amdgcn_ballot_w64(quad >= thr_g)) continue;
+#pragma unroll
+                for (int r = r4; r < r4 + 4; ++r) {
+                    const bool above = acc[r] >= thr_g;
+                    if (__builtin_amdgcn_ballot_w64(above)) {  // wave-uniform: some lane's score r passes
+                        const int rbit = (r & 3) + 8 * (r >> 2);
+                        uint32_t m = tmh;
+                        asm volatile("" : "+v"(m));            // (the mask test belongs in here, not in front of the branch)
+                        if (above && !((m >> rbit) & 1u)) {
+                            const uint32_t pos = atomicAdd(cnt_g, 1u);     // (keeps counting past cap: the segment's end flags it)
+                            if (pos < (uint32_t)cap) lists[(size_t)list_g * cap + pos] = make_key(acc[r] * fu_g, id0 + rbit);
+                        }
+                    }
+                }
+            }
+        };
+#ifndef MACR_ABL_H_NOEPI
+        epilogue(acc0, tm0, thr[0], fu[0], my_cnt[0], my_list[0]);
+        epilogue(acc1, tm1, thr[1], fu[1], my_cnt[1], my_list[1]);
+#else
+        {
+            float m0 = acc0[0], m1 = acc1[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, acc0[r]); m1 = fmaxf(m1, acc1[r]); }
+            if (m0 == 1.2345e30f || m1 == 1.2345e30f) epilogue(acc0, tm0, thr[0], fu[0], my_cnt[0], my_list[0]);
+        }
+#endif
+    };
+    // stale seeds (k_score_stream_c): `done` = tiles of this segment visited by the block so far
+    int polled = 0;
+    auto stale_mark = [&](int done_before, int done) -> bool {
+        if (!blk_flag) return false;
+        auto crossed = [&](int v) { return done_before < v && done >= v; };
+        const bool check = crossed(2) || crossed(kCheckTiles) || crossed(4 * kCheckTiles);
+        if (!(check || (done >> 3) != (done_before >> 3))) return false;
+        bool mine = false;
+        if (check) {
+            uint32_t a = tslot == 0 ? s_cnt[uw * 64 + lane] : 0u;                      // appended so far to the lists of this wave's 64 queries (by both waves that share them)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, kWave);
+            const float usable = 64.f * (float)(done * kTileItems) * (float)(kSelRegs * 64) / (float)n_local;
+            mine = tslot == 0 && (float)a > usable + 128.f;
+        } else if (tid == 0) {
+            mine = polled != 0;
+            polled = __hip_atomic_load(blk_flag + ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (mine) *s_stop = 1;
+        return true;
+    };
+    auto stale_read = [&](bool looked) -> bool {              // behind the barrier
+        if (!looked) return false;
+        const bool stop = *s_stop != 0;
+        if (stop && tid == 0) __hip_atomic_store(blk_flag + ub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return stop;
+    };
+
+    // steps of two tiles: (ta, tb) = (visit(vi), visit(vi + 1)); an odd range ends with a step whose second tile is none
+    int vi = i0;
+    int ta = visit(i0), tb = vi + 1 < i1 ? visit_after(ta) : -1;
+    if (vi < i1) { load_step(ta, tb < 0 ? ta : tb); store_step(std::integral_constant<int, 0>()); }
+    uint32_t tm0 = tm_next[0], tm1 = tm_next[1];
+    __syncthreads();
+    while (vi < i1) {
+        {
+            const int na = vi + 2 < i1 ? visit_after(tb) : ta, nb = vi + 3 < i1 ? visit_after(na) : -1;
+            load_step(na, nb < 0 ? na : nb);
+            __builtin_amdgcn_sched_barrier(0);
+            one_step(std::integral_constant<int, 0>(), tslot ? tb : ta, tm0, tm1);
+            const int done = min(vi + 2, i1) - i0;
+            const bool looked = stale_mark(vi - i0, done);
+            store_step(std::integral_constant<int, 1>());
+            __syncthreads();
+            tm0 = tm_next[0]; tm1 = tm_next[1]; ta = na; tb = nb; vi += 2;
+            if (stale_read(looked)) break;
+        }
+        if (vi >= i1) break;
+        {
+            const int na = vi + 2 < i1 ? visit_after(tb) : ta, nb = vi + 3 < i1 ? visit_after(na) : -1;
+            load_step(na, nb < 0 ? na : nb);
+            __builtin_amdgcn_sched_barrier(0);
+            one_step(std::integral_constant<int, 1>(), tslot ? tb : ta, tm0, tm1);
+            const int done = min(vi + 2, i1) - i0;
+            const bool looked = stale_mark(vi - i0, done);
+            store_step(std::integral_constant<int, 0>());
+            __syncthreads();
+            tm0 = tm_next[0]; tm1 = tm_next[1]; ta = na; tb = nb; vi += 2;
+            if (stale_read(looked)) break;
+        }
+    }
+    for (int k = tid; k < kUsersPerBlock; k += THREADS) {
+        const int qq = ub * kUsersPerBlock + k;
+        const int ql2 = (REPAIR && rl.compact) ? ubv * kUsersPerBlock + k : qq;
+        if (qq < U) {
+            counts[(size_t)split * rl.stride + ql2] = (int32_t)min(s_cnt[k], (uint32_t)cap);
+            if (s_cnt[k] > (uint32_t)cap) overflow[ovf_per_user ? qq : 0] = 1;        // full: her list was cut
+        }
+    }
+    }   // segments
+}
+
 // Test-only (macr_test_bf16_scores): the SCORE k_score_stream_c lists for every (query, item) pair -- its MFMA sequence on
 // the copies k_bf16_prep_c wrote, times the query's factor -- and the margin the filter grants each query.
-template <int D, int KIND>
+// HALF: the fp16 filter's copies and k_score_stream_h's sequence (one MFMA per 16 k, then the bias slab).
+template <int D, int KIND, bool HALF = false>
 __global__ __launch_bounds__(64) void k_test_bf16_scores(int U, int N, const uint4 *__restrict__ users_c, const uint4 *__restrict__ items_c,
                                                          const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
                                                          const float *__restrict__ sig_u, float c, float *__restrict__ out,
                                                          float *__restrict__ margin) {
-    constexpr int RU = StreamCfgC<D>::RU;
+    constexpr int RU = HALF ? D / 8 + 1 : StreamCfgC<D>::RU;
     const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
     const int item = min((int)blockIdx.x * 32 + col, N - 1), user = min((int)blockIdx.y * 32 + col, U - 1);
-    const uint4 *irow = items_c + (size_t)item * RU, *urow = users_c + (size_t)user * (2 * D / 8);
+    const uint4 *irow = items_c + (size_t)item * RU, *urow = users_c + (size_t)user * (HALF ? D / 8 : 2 * D / 8);
     const float su = score_uses_sig_u(KIND) ? sig_u[user] : 1.0f;
     const bool tiny = score_uses_sig_u(KIND) && sig_u_tiny(su);
-    const float fu = (KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny) ? 1.0f : su;
+    const float fu = HALF ? query_factor_h<KIND>(su) : (KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny) ? 1.0f : su;
     const bool ones_on = KIND != MACR_SCORE_NORMAL && h == 0 && !(KIND == MACR_SCORE_DIRECT_MINUS_BOTH && tiny);
     union { uint32_t u[4]; bf16x8 v; } ones;
     ones.u[0] = ones_on ? 0x3f803f80u : 0u; ones.u[1] = ones_on ? 0x00003f80u : 0u; ones.u[2] = 0u; ones.u[3] = 0u;
+    if (HALF) ones.v = bias_query_unit_h<KIND>(su, KIND != MACR_SCORE_NORMAL && h == 0);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1910,16 +2322,21 @@ __global__ __launch_bounds__(64) void k_test_bf16_scores(int U, int N, const uin
     for (int sI = 0; sI < D / 16; ++sI) {
         uint4 v;
         v = irow[2 * sI + h];          const bf16x8 ah = *reinterpret_cast<bf16x8 *>(&v);
-        v = irow[D / 8 + 2 * sI + h];  const bf16x8 al = *reinterpret_cast<bf16x8 *>(&v);
         v = urow[2 * sI + h];          const bf16x8 bh = *reinterpret_cast<bf16x8 *>(&v);
-        v = urow[D / 8 + 2 * sI + h];  const bf16x8 bl = *reinterpret_cast<bf16x8 *>(&v);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        if (HALF) {
+            acc = mfma_f16(ah, bh, acc);
+        } else {
+            v = irow[D / 8 + 2 * sI + h];  const bf16x8 al = *reinterpret_cast<bf16x8 *>(&v);
+            v = urow[D / 8 + 2 * sI + h];  const bf16x8 bl = *reinterpret_cast<bf16x8 *>(&v);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        }
     }
     if (KIND != MACR_SCORE_NORMAL) {
-        uint4 v = irow[2 * D / 8];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&v), ones.v, acc, 0, 0, 0);
+        uint4 v = irow[HALF ? D / 8 : 2 * D / 8];
+        acc = HALF ? mfma_f16(*reinterpret_cast<bf16x8 *>(&v), ones.v, acc)
+                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&v), ones.v, acc, 0, 0, 0);
     }
     const int u = (int)blockIdx.y * 32 + col;
     if (u >= U) return;
@@ -1928,7 +2345,7 @@ __global__ __launch_bounds__(64) void k_test_bf16_scores(int U, int N, const uin
         const int it = (int)blockIdx.x * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (it < N) out[(size_t)u * N + it] = acc[r] * fu;
     }
-    if (blockIdx.x == 0 && h == 0) margin[u] = filter_margin(D, unorm[u], __uint_as_float(*qmax_bits), c);
+    if (blockIdx.x == 0 && h == 0) margin[u] = filter_margin_of(HALF ? 1 : 0, D, unorm[u], __uint_as_float(*qmax_bits), c) * (HALF ? fu : 1.0f);
 }
 
 // The listing pass of k_score_stream_b for up to kMaxSweep values of c at once (macr_score_topk_sweep under the bf16
@@ -2339,7 +2756,7 @@ __global__ __launch_bounds__(256) void k_tau_seed(int U, int n_local, const floa
 
 // Seeded ranking under the bf16 filter: the operand copies and the seeded thresholds do not depend on each other -- two
 // short, latency-bound kernels -- and go out as ONE launch (blocks [0, n_prep) convert, the others score seeds).
-template <int D, int KIND>
+template <int D, int KIND, bool HALF = false>
 __global__ __launch_bounds__(256) void k_prep_tau_seed(int n_prep, int U, int n_local, const float *__restrict__ users_tab,
                                                        const int32_t *__restrict__ user_ids, const float *__restrict__ items,
                                                        uint4 *__restrict__ users_bf, uint4 *__restrict__ items_bf,
@@ -2349,8 +2766,8 @@ __global__ __launch_bounds__(256) void k_prep_tau_seed(int n_prep, int U, int n_
                                                        const uint32_t *__restrict__ mask_bits, int item_offset, int K,
                                                        const int32_t *__restrict__ seed, float *__restrict__ tau) {
     if ((int)blockIdx.x < n_prep)
-        bf16_prep_c_block<D, KIND, kPrepTrips>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_bf,
-                                               items_bf, unorm, qmax_bits);
+        bf16_prep_c_block<D, KIND, kPrepTrips, HALF>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_bf,
+                                                     items_bf, unorm, qmax_bits);
     else
         tau_seed_block<D, KIND>(blockIdx.x - n_prep, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_val, c_dev, mask_bits,
                                 item_offset, K, seed, tau);
@@ -2371,7 +2788,8 @@ template <int NREG, bool REPAIR = false>
 __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int K, const float *__restrict__ maxima,
                                                         const int32_t *__restrict__ blk_flag, float *__restrict__ tau,
                                                         const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
-                                                        float c_val, const float *__restrict__ c_dev, int d_filter, int per_log2) {
+                                                        float c_val, const float *__restrict__ c_dev, int d_filter, int per_log2, int half,
+                                                        const float *__restrict__ mscale) {
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.x * kSelWaves + wid;
     if (q >= U) return;
@@ -2421,7 +2839,8 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_tau(int U, int n_splits, int
         t_out = orderable_f32(prefix);                            // (all 32 bits decided when equal maxima remain)
     }
     // maxima of bf16 scores (k_score_sample_b): K items score >= t_out - margin in fp32
-    if (unorm) t_out -= 1.01f * filter_margin(d_filter, unorm[q], __uint_as_float(*qmax_bits), c_dev ? *c_dev : c_val);
+    // (mscale: the fp16 filter states its margin on the accumulator; a score that leaves it times sig_u -- RUBI_BOTH -- is off by sig_u times that)
+    if (unorm) t_out -= 1.01f * filter_margin_of(half, d_filter, unorm[q], __uint_as_float(*qmax_bits), c_dev ? *c_dev : c_val) * (mscale ? mscale[q] : 1.0f);
     if (lane == 0) tau[q] = REPAIR ? fmaxf(tau[q], t_out) : t_out;
 }
 
@@ -2699,7 +3118,7 @@ __global__ __launch_bounds__(64 * kSelWaves, 5) void k_select_b(int U, int n_loc
                                                              int item_offset, const float *__restrict__ unorm,
                                                              const uint32_t *__restrict__ qmax_bits,
                                                              float *__restrict__ out_val, int32_t *__restrict__ out_idx,
-                                                             int32_t *__restrict__ seed_out) {
+                                                             int32_t *__restrict__ seed_out, int half) {
     __shared__ uint64_t s_top[kSelWaves][64];
     // first selection: not the user blocks the listing pass gave up on; second one (REPAIR): only after a repair round,
     // and only the user blocks that were listed again (k_select)
@@ -2747,7 +3166,7 @@ __global__ __launch_bounds__(64 * kSelWaves, 5) void k_select_b(int U, int n_loc
     // no item outside these 64 may belong to the exact top K
     const int R = K;
     const uint32_t hi_r = __shfl((uint32_t)(ka >> 32), R - 1, kWave), hi_last = __shfl((uint32_t)(ka >> 32), 63, kWave);
-    const float m2 = 2.02f * filter_margin(D, unorm[q], __uint_as_float(*qmax_bits), c);
+    const float m2 = 2.02f * filter_margin_of(half, D, unorm[q], __uint_as_float(*qmax_bits), c) * ((half && KIND == MACR_SCORE_RUBI_BOTH) ? sig_u[q] : 1.0f);
     // (hi_r == 0: fewer than R candidates -- all of them matter)
     const float a_cut = hi_r ? orderable_f32(hi_r) - m2 : -INFINITY;
     if (flag && lane == 0) overflow[ovf_per_user ? q : 0] = 1;
@@ -3594,7 +4013,14 @@ extern "C" void macr_dbg_counters(unsigned long long *out) {
 namespace macr {
 // Launch geometry of the two streaming passes (see k_score_stream): grid sizes and the number of result slots a
 // user block can have (= blocks overlapping its tile range).
-struct StreamGeo { int ublocks, grid0, slots0, grid1, slots1, range1; };   // range1: longest tile range of pass 1
+// grid_x / pieces_x (fp16 listing pass, k_score_stream_h): the XCD-aware decomposition -- block b runs on XCD b % 8 (workgroups go
+// to the eight XCDs round-robin) and lists only visits of that XCD's EIGHTH of the visit sequence, for one query block after
+// another; a (query block, eighth) is cut into pieces_x pieces where there are fewer query blocks than blocks per XCD.  All
+// blocks of an XCD then stream the same T/8 tiles (0.7 MB of fp16 rows at the Gowalla catalogue: resident in its 4 MB L2)
+// instead of every block pulling its own range through the L2 from the Infinity Cache -- the pass was bound by exactly that
+// latency (bytes in flight / latency = its 2 TB/s).  pieces_x = 0: the linear decomposition (small catalogues).  A query has
+// 8 * pieces_x result slots under it; slots1 covers both decompositions.
+struct StreamGeo { int ublocks, grid0, slots0, grid1, slots1, range1, grid_x, pieces_x; };   // range1: longest tile range of pass 1
 static StreamGeo stream_geo(int U, int n_local, int d) {
     StreamGeo g;
     g.ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
@@ -3613,6 +4039,25 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
     plan(T0, g.grid0, g.slots0);
     plan(T1, g.grid1, g.slots1);
     g.range1 = (int)(((long long)g.ublocks * T1 + g.grid1 - 1) / g.grid1);
+    g.grid_x = 0; g.pieces_x = 0;
+    if (T1 >= 8 * 32) {                                       // (an eighth of the visits is worth a block's prologue)
+        const int bx = resident / 8;                          // blocks per XCD
+        int best_p = 1;
+        double best = 1e30;
+        for (int pc = 1; pc <= 4; ++pc) {                     // pieces per (query block, eighth): the first whose rounds fill >= 94 % of the blocks, else the best
+            if (T1 / (8 * pc) < 16 && pc > 1) break;
+            const long long units = (long long)g.ublocks * pc;
+            const long long rounds = (units + bx - 1) / bx;
+            const double waste = (double)(rounds * std::min<long long>(bx, units)) / (double)units;
+            if (waste < best - 1e-9) { best = waste; best_p = pc; }
+            if (waste <= 1.0 / 0.94) break;
+        }
+        g.pieces_x = best_p;
+        const long long units = (long long)g.ublocks * best_p;
+        g.grid_x = 8 * (int)std::min<long long>(bx, units);
+        // longest list range of the decomposition must fit the list-everything test's assumption too: (T1/8)/pieces <= range1 holds
+        g.slots1 = std::max(g.slots1, 8 * best_p);
+    }
     return g;
 }
 
@@ -3668,11 +4113,17 @@ extern "C" size_t macr_score_topk_workspace_bytes(int U, int n_local, int d) {
 
 // `filter` argument of the ranking entry points: MACR_EVAL_FILTER_ENV (0) follows MACR_EVAL_FILTER in the environment (f32 when
 // unset), MACR_EVAL_FILTER_F32 (1), MACR_EVAL_FILTER_BF16 (2).  Per call: the library keeps no filter state (abi 10).
-static bool eval_filter_bf16(int filter) {
-    if (filter) return filter == MACR_EVAL_FILTER_BF16;
+static int eval_filter_resolved(int filter) {            // MACR_EVAL_FILTER_F32 | _BF16 | _F16
+    if (filter) return filter;
     const char *e = getenv("MACR_EVAL_FILTER");
-    return e && (e[0] == 'b' || e[0] == 'B');
+    if (e && (e[0] == 'b' || e[0] == 'B')) return MACR_EVAL_FILTER_BF16;
+    if (e && (e[0] == 'f' || e[0] == 'F') && e[1] == '1') return MACR_EVAL_FILTER_F16;      // "f16" ("f32": the default)
+    return MACR_EVAL_FILTER_F32;
 }
+// the reduced-precision candidate filters share one path (operand copies, thresholds less a margin, k_select_b); `half`
+// picks the fp16 kernels and margin on it.  (The c sweep has bf16 kernels only: the fp16 filter takes those there.)
+static bool eval_filter_bf16(int filter) { return eval_filter_resolved(filter) != MACR_EVAL_FILTER_F32; }
+static bool eval_filter_half(int filter) { return eval_filter_resolved(filter) == MACR_EVAL_FILTER_F16; }
 
 extern "C" int macr_score_topk_uses_seeds(int U, int n_local, int d) {
     if (U <= 0 || n_local <= 0 || !dim_supported(d)) return 0;
@@ -3709,18 +4160,28 @@ namespace macr {
 template <bool REPAIR>
 static void launch_k_tau(int tau_regs, int blocks, hipStream_t st, int U, int slots0, int K, const float *maxima,
                          const int32_t *blk_flag, float *tau, const float *unorm = nullptr, const uint32_t *qmax_bits = nullptr,
-                         float c = 0.f, const float *c_dev = nullptr, int d_filter = 0, int per_log2 = 5) {
+                         float c = 0.f, const float *c_dev = nullptr, int d_filter = 0, int per_log2 = 5, int half = 0,
+                         const float *mscale = nullptr) {
     const int th = 64 * kSelWaves;
     // (unorm != NULL: the maxima are bf16 scores, tau = K-th largest - the filter's margin)
-    if (tau_regs <= 1) k_tau<1, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
-    else if (tau_regs <= 2) k_tau<2, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
-    else if (tau_regs <= 4) k_tau<4, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
-    else if (tau_regs <= 8) k_tau<8, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
-    else if (tau_regs <= 16) k_tau<16, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
-    else k_tau<32, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2);
+    if (tau_regs <= 1) k_tau<1, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2, half, mscale);
+    else if (tau_regs <= 2) k_tau<2, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2, half, mscale);
+    else if (tau_regs <= 4) k_tau<4, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2, half, mscale);
+    else if (tau_regs <= 8) k_tau<8, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2, half, mscale);
+    else if (tau_regs <= 16) k_tau<16, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2, half, mscale);
+    else k_tau<32, REPAIR><<<blocks, th, 0, st>>>(U, slots0, K, maxima, blk_flag, tau, unorm, qmax_bits, c, c_dev, d_filter, per_log2, half, mscale);
 }
 }  // namespace macr
 
+// (-DMACR_DEV_FAST: d = 64 and the kinds NORMAL / RUBI_BOTH only -- a build for kernel work that compiles in a fraction of the
+// four minutes the full set of instantiations takes; never shipped: the Makefile does not know it)
+#ifdef MACR_DEV_FAST
+#define MACR_DISPATCH_K(Dv, kind, ...)                                                                    \
+    switch (kind) {                                                                                       \
+        case MACR_SCORE_NORMAL:            { constexpr int D = Dv, KIND = MACR_SCORE_NORMAL; __VA_ARGS__; } break;            \
+        case MACR_SCORE_RUBI_BOTH:         { constexpr int D = Dv, KIND = MACR_SCORE_RUBI_BOTH; __VA_ARGS__; } break;         \
+    }
+#else
 #define MACR_DISPATCH_K(Dv, kind, ...)                                                                    \
     switch (kind) {                                                                                       \
         case MACR_SCORE_NORMAL:            { constexpr int D = Dv, KIND = MACR_SCORE_NORMAL; __VA_ARGS__; } break;            \
@@ -3729,6 +4190,7 @@ static void launch_k_tau(int tau_regs, int blocks, hipStream_t st, int U, int sl
         case MACR_SCORE_DIRECT_MINUS:      { constexpr int D = Dv, KIND = MACR_SCORE_DIRECT_MINUS; __VA_ARGS__; } break;      \
         case MACR_SCORE_DIRECT_MINUS_BOTH: { constexpr int D = Dv, KIND = MACR_SCORE_DIRECT_MINUS_BOTH; __VA_ARGS__; } break; \
     }
+#endif
 // what k_topk_ws_init / k_eval_prologue write to the head of the ranking workspace before a first round: counts, flags,
 // shared_thr <- 0; tau <- -inf on the list-everything path; the class maxima <- NaN ("this class saw nothing") -- none for a
 // seeded first round under the bf16 filter (no sampling pass: its repair round, if one follows, fills them itself)
@@ -3748,6 +4210,12 @@ static WsHeadPlan ws_head_plan(const TopkWs &ws, const StreamGeo &geo, int U, in
     return p;
 }
 
+#ifdef MACR_DEV_FAST
+#define MACR_DISPATCH_DK(d, kind, ...)                              \
+    switch (d) {                                                    \
+        case 64:  MACR_DISPATCH_K(64, kind, __VA_ARGS__); break;    \
+    }
+#else
 #define MACR_DISPATCH_DK(d, kind, ...)                              \
     switch (d) {                                                    \
         case 32:  MACR_DISPATCH_K(32, kind, __VA_ARGS__); break;    \
@@ -3755,6 +4223,7 @@ static WsHeadPlan ws_head_plan(const TopkWs &ws, const StreamGeo &geo, int U, in
         case 128: MACR_DISPATCH_K(128, kind, __VA_ARGS__); break;   \
         case 256: MACR_DISPATCH_K(256, kind, __VA_ARGS__); break;   \
     }
+#endif
 
 static inline bool score_kind_valid(int k) { return k >= MACR_SCORE_NORMAL && k <= MACR_SCORE_DIRECT_MINUS_BOTH; }
 
@@ -3773,7 +4242,7 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
     // MACR_EVAL_WS_READY: macr_score_topk_prologue has initialised the workspace head for exactly this call
     const bool ws_ready = (filter & MACR_EVAL_WS_READY) != 0;
     filter &= ~MACR_EVAL_WS_READY;
-    MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_BF16, MACR_E_INVALID, "score_topk: filter=%d", filter);
+    MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_F16, MACR_E_INVALID, "score_topk: filter=%d", filter);
     MACR_REQUIRE(!ws_ready || mode != 2, MACR_E_INVALID, "score_topk: MACR_EVAL_WS_READY on a repair round");
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk: d=%d not in {32,64,128,256}", d);
@@ -3798,6 +4267,7 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
     const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
     // (a shard small enough to list everything has nothing to filter)
     const bool filter_bf16 = !list_all && eval_filter_bf16(filter);
+    const bool half = filter_bf16 && eval_filter_half(filter);          // the fp16 filter's kernels on the reduced-precision path
     // class maxima start as NaN (= no unmasked item seen).  Under the bf16 filter the sampling pass may keep 16 per split and
     // query instead of 32 (merge_pairs below), and a seeded first round has no sampling pass at all: its repair round, if one
     // follows (macr_score_topk_repair_round), fills them itself.
@@ -3875,7 +4345,8 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
         const bool f32_sample_bf16 = !filter_bf16 && !f32_sample_env;      // fp32 filter: thresholds from the bf16 sampling pass (see below)
         uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(ws.overflow + 8);
         // users_c: the scaled query copies exist for DIRECT_MINUS_BOTH only; the other kinds' are the plain ones
-        uint4 *users_c = KIND == MACR_SCORE_DIRECT_MINUS_BOTH ? ws.users_c : ws.users_bf;
+        // (the fp16 copies have a layout of their own: always in users_c)
+        uint4 *users_c = (half || KIND == MACR_SCORE_DIRECT_MINUS_BOTH) ? ws.users_c : ws.users_bf;
         const uint32_t *zero_word = reinterpret_cast<const uint32_t *>(ws.overflow + 3);
         // k_score_sample_c merges its classes in pairs where that still leaves several times K of them (k_tau ranks half as many)
         const int merge_pairs = geo.slots0 * 16 >= 4 * K ? 1 : 0, per_c = merge_pairs ? 16 : 32;
@@ -3887,25 +4358,27 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
             // the listing pass's operand copies (the epilogue in the operands), |u| per query, max |q| -- and, in the same
             // launch, the seeded thresholds
             const unsigned n_prep = bf16_prep_c_blocks(U, n_local, D, kPrepTrips);
-            k_prep_tau_seed<D, KIND><<<n_prep + (U + 7) / 8, 256, 0, st>>>((int)n_prep, U, n_local, users_tab, user_ids, items, users_c,
-                                                                           ws.items_c, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev, mask_bits,
-                                                                           item_offset, K, seed_idx, ws.tau);
+            auto prep_seed = half ? k_prep_tau_seed<D, KIND, true> : k_prep_tau_seed<D, KIND, false>;
+            prep_seed<<<n_prep + (U + 7) / 8, 256, 0, st>>>((int)n_prep, U, n_local, users_tab, user_ids, items, users_c,
+                                                            ws.items_c, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev, mask_bits,
+                                                            item_offset, K, seed_idx, ws.tau);
             MACR_CHECK_LAUNCH("bf16_prep+tau_seed", st);
         } else if (filter_bf16) {
-            k_bf16_prep_c<D, KIND><<<bf16_prep_c_blocks(U, n_local, D, kPrepTripsAlone), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
-                                                                                      users_c, ws.items_c, ws.unorm, qmax_bits);
+            auto prep = half ? k_bf16_prep_c<D, KIND, true> : k_bf16_prep_c<D, KIND, false>;
+            prep<<<bf16_prep_c_blocks(U, n_local, D, kPrepTripsAlone), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
+                                                                                   users_c, ws.items_c, ws.unorm, qmax_bits);
             MACR_CHECK_LAUNCH("bf16_prep_c", st);
         }
         if (filter_bf16 && !seeded) {
-            auto pass0c = k_score_sample_c<D, KIND>;
-            const size_t smem_c = StreamCfgC<D>::smem;
+            auto pass0c = half ? k_score_sample_c<D, KIND, false, true> : k_score_sample_c<D, KIND, false, false>;
+            const size_t smem_c = half ? StreamCfgH1<D>::smem : StreamCfgC<D>::smem;
             MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass0c), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
             pass0c<<<geo.grid0, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
                                                   geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, nullptr, nullptr);
             MACR_CHECK_LAUNCH("score_sample_b", st);
             launch_k_tau<false>((geo.slots0 * per_c + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev, D,
-                                merge_pairs ? 4 : 5);
+                                merge_pairs ? 4 : 5, half ? 1 : 0, (half && KIND == MACR_SCORE_RUBI_BOTH) ? sig_u : nullptr);
             MACR_CHECK_LAUNCH("tau", st);
         } else if (seeded && filter_bf16) {
             // (thresholds: in the launch above)
@@ -3947,21 +4420,31 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
         if (filter_bf16) {
             // bf16-filtered first round (k_score_stream_b): listing on the bf16 matrix cores, then the selection re-scores
             // its best candidates in fp32
-            auto pass1c = k_score_stream_c<D, KIND>;
-            const size_t smem_c = StreamCfgC<D>::smem;
-            MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass1c), hipFuncAttributeMaxDynamicSharedMemorySize,
+            const void *pass1c = half ? reinterpret_cast<const void *>(k_score_stream_h<D, KIND>) : reinterpret_cast<const void *>(k_score_stream_c<D, KIND>);
+            const size_t smem_c = half ? StreamCfgH<D>::smem : StreamCfgC<D>::smem;
+            MACR_REQUIRE(hipFuncSetAttribute(pass1c, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
-            pass1c<<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
-                                                   mask_bits, zero_word, item_offset, geo.ublocks,
-                                                   ws.tau, ws.lists, ws.counts, ws.cap,
-                                                   repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
-                                                   seeded ? ws.blk_flag : nullptr, nullptr, nullptr, 0);
+            if (half) {
+                // (the XCD-aware decomposition where the catalogue is long enough: StreamGeo)
+                static const bool no_xcd = getenv("MACR_EVAL_XCD") && getenv("MACR_EVAL_XCD")[0] == '0';      // A/B switch
+                const bool by_xcd = geo.pieces_x > 0 && !no_xcd;
+                k_score_stream_h<D, KIND><<<by_xcd ? geo.grid_x : geo.grid1, 512, smem_c, st>>>(
+                    U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev, mask_bits, zero_word, item_offset, geo.ublocks,
+                    ws.tau, ws.lists, ws.counts, ws.cap, repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
+                    seeded ? ws.blk_flag : nullptr, nullptr, nullptr, 0, by_xcd ? geo.pieces_x : 0);
+            } else {
+                k_score_stream_c<D, KIND><<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
+                                                                       mask_bits, zero_word, item_offset, geo.ublocks,
+                                                                       ws.tau, ws.lists, ws.counts, ws.cap,
+                                                                       repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
+                                                                       seeded ? ws.blk_flag : nullptr, nullptr, nullptr, 0);
+            }
             MACR_CHECK_LAUNCH("score_stream_b", st);
             k_select_b<D, KIND><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts,
                                                                       repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, nullptr,
                                                                       seeded ? ws.blk_flag : nullptr, users_tab, user_ids, items,
                                                                       sig_u, sig_i, c, c_dev, item_offset, ws.unorm, qmax_bits,
-                                                                      out_val, out_idx, seed_out);
+                                                                      out_val, out_idx, seed_out, half ? 1 : 0);
             MACR_CHECK_LAUNCH("select_b", st);
         } else {
         pass1<<<geo.grid1, 512, smem, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev, mask_bits, item_offset,
@@ -3987,29 +4470,35 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
             } else if (filter_bf16) {
                 // the repair round on the bf16 copies too: sampling pass for the re-listed user blocks when the thresholds
                 // came from seeds, listing, selection with fp32 re-scoring
-                auto pass0rb = k_score_sample_c<D, KIND, true>;
-                auto pass1rc = k_score_stream_c<D, KIND, true>;
-                const size_t smem_c = StreamCfgC<D>::smem;
-                hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass0rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_c);
-                if (eb == hipSuccess) eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass1rc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_c);
+                auto pass0rb = half ? k_score_sample_c<D, KIND, true, true> : k_score_sample_c<D, KIND, true, false>;
+                const void *pass1rc = half ? reinterpret_cast<const void *>(k_score_stream_h<D, KIND, true>) : reinterpret_cast<const void *>(k_score_stream_c<D, KIND, true>);
+                const size_t smem_c0 = half ? StreamCfgH1<D>::smem : StreamCfgC<D>::smem, smem_c = half ? StreamCfgH<D>::smem : StreamCfgC<D>::smem;
+                hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void *>(pass0rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_c0);
+                if (eb == hipSuccess) eb = hipFuncSetAttribute(pass1rc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_c);
                 MACR_REQUIRE(eb == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
                 if (seeded) {
-                    pass0rb<<<geo.grid0, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
-                                                           geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, ws.ub_map, ws.overflow + 1);
+                    pass0rb<<<geo.grid0, 512, smem_c0, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
+                                                            geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, ws.ub_map, ws.overflow + 1);
                     MACR_CHECK_LAUNCH("score_sample2", st);
                     launch_k_tau<true>((geo.slots0 * per_c + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau, ws.unorm, qmax_bits, c, c_dev, D,
-                                       merge_pairs ? 4 : 5);
+                                       merge_pairs ? 4 : 5, half ? 1 : 0, (half && KIND == MACR_SCORE_RUBI_BOTH) ? sig_u : nullptr);
                     MACR_CHECK_LAUNCH("tau2", st);
                 }
-                pass1rc<<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev, mask_bits,
-                                                        zero_word, item_offset, geo.ublocks, ws.tau,
-                                                        ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
-                                                        ws.ub_map, ws.overflow + 1, geo.slots1);
+                if (half)
+                    k_score_stream_h<D, KIND, true><<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
+                                                                                mask_bits, zero_word, item_offset, geo.ublocks, ws.tau,
+                                                                                ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
+                                                                                ws.ub_map, ws.overflow + 1, geo.slots1, 0);
+                else
+                    k_score_stream_c<D, KIND, true><<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
+                                                                                mask_bits, zero_word, item_offset, geo.ublocks, ws.tau,
+                                                                                ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
+                                                                                ws.ub_map, ws.overflow + 1, geo.slots1);
                 MACR_CHECK_LAUNCH("score_stream2", st);
                 k_select_b<D, KIND, true><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, n_splits, K, ws.cap, ws.lists,
                                                                                 ws.counts, ws.overflow, 0, ws.overflow + 1, ws.blk_flag,
                                                                                 users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
-                                                                                item_offset, ws.unorm, qmax_bits, out_val, out_idx, seed_out);
+                                                                                item_offset, ws.unorm, qmax_bits, out_val, out_idx, seed_out, half ? 1 : 0);
                 MACR_CHECK_LAUNCH("select2", st);
             } else {
             if (seeded) {
@@ -4094,7 +4583,7 @@ extern "C" int macr_score_topk_prologue(int filter, int U, int n_local, int d, i
                                         const float *users_tab, const int32_t *user_ids, const float *w_user, float *sig_u,
                                         void *workspace, size_t workspace_bytes, void *stream) {
     hipStream_t st = as_stream(stream);
-    MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_BF16, MACR_E_INVALID, "score_topk_prologue: filter=%d", filter);
+    MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_F16, MACR_E_INVALID, "score_topk_prologue: filter=%d", filter);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk_prologue: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk_prologue: d=%d not in {32,64,128,256}", d);
     MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK, MACR_E_UNSUPPORTED, "score_topk_prologue: K=%d outside [1,%d]", K, MACR_MAX_TOPK);
@@ -4131,7 +4620,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int filter, int U, int n_lo
                                      void *workspace, size_t workspace_bytes, void *stream) {
     MACR_REQUIRE(score_kind_valid(score_kind) && score_uses_sig_i(score_kind), MACR_E_INVALID,
                  "score_topk_sweep: score_kind=%d does not depend on c", score_kind);
-    MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_BF16, MACR_E_INVALID, "score_topk_sweep: filter=%d", filter);
+    MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_F16, MACR_E_INVALID, "score_topk_sweep: filter=%d", filter);
     MACR_REQUIRE(n_c >= 1 && n_c <= kMaxSweep, MACR_E_UNSUPPORTED, "score_topk_sweep: n_c=%d outside [1,%d]", n_c, kMaxSweep);
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk_sweep: U=%d n_local=%d", U, n_local);
     MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk_sweep: d=%d not in {32,64,128,256}", d);
@@ -4212,7 +4701,7 @@ extern "C" int macr_score_topk_sweep(int score_kind, int filter, int U, int n_lo
                 k_select_b<D, KIND><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, 1, K, ws[g].cap, ws[g].lists, ws[g].counts,
                                                                           ws[g].overflow, 0, nullptr, nullptr, users_tab, user_ids, items, sig_u,
                                                                           sig_i, 0.f, c_dev + g, item_offset, ws[0].unorm, qmax_bits,
-                                                                          out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K, nullptr);
+                                                                          out_val + (size_t)g * U * K, out_idx + (size_t)g * U * K, nullptr, 0);
                 MACR_CHECK_LAUNCH("select_b", st);
             }
         } else {
@@ -4320,6 +4809,35 @@ extern "C" int macr_test_bf16_scores(int score_kind, int d, int U, int N, const 
         k_test_bf16_scores<D, KIND><<<grid, 64, 0, st>>>(U, N, users_c, items_c, unorm, qmax_bits, sig_u, c, scores, margin);
     });
     MACR_CHECK_LAUNCH("test_bf16_scores", st);
+    return MACR_OK;
+}
+
+// the same for the fp16 filter (k_score_stream_h's sequence on the copies bf16_prep_c_block<.., HALF> writes; workspace as above)
+extern "C" int macr_test_f16_scores(int score_kind, int d, int U, int N, const float *users, const float *items, const float *sig_u,
+                                    const float *sig_i, float c, float *scores, float *margin, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "test_f16_scores: score_kind=%d", score_kind);
+    MACR_REQUIRE(U > 0 && N > 0, MACR_E_INVALID, "test_f16_scores: U=%d N=%d", U, N);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "test_f16_scores: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(users && items && scores && margin && workspace, MACR_E_INVALID, "test_f16_scores: null pointer");
+    MACR_REQUIRE((!score_uses_sig_i(score_kind) || sig_i) && (!score_uses_sig_u(score_kind) || sig_u), MACR_E_INVALID,
+                 "test_f16_scores: score_kind %d needs its sigmoids", score_kind);
+    MACR_REQUIRE(workspace_bytes >= macr_test_bf16_scores_workspace_bytes(d, U, N), MACR_E_WORKSPACE,
+                 "test_f16_scores: workspace %zu < %zu", workspace_bytes, macr_test_bf16_scores_workspace_bytes(d, U, N));
+    unsigned char *p = static_cast<unsigned char *>(workspace);
+    uint4 *users_c = reinterpret_cast<uint4 *>(p);   p += align_up((size_t)U * 4 * d, 256);
+    uint4 *items_c = reinterpret_cast<uint4 *>(p);   p += align_up(items_c_bytes(N, d), 256);
+    float *unorm = reinterpret_cast<float *>(p);     p += align_up((size_t)U * 4, 256);
+    uint32_t *qmax_bits = reinterpret_cast<uint32_t *>(p);
+    fill_words(qmax_bits, 1, 0u, st);
+    dim3 grid((N + 31) / 32, (U + 31) / 32);
+    MACR_DISPATCH_DK(d, score_kind, {
+        k_bf16_prep_c<D, KIND, true><<<bf16_prep_c_blocks(U, N, D, kPrepTripsAlone), 256, 0, st>>>(U, N, users, nullptr, items, sig_u, sig_i, c, nullptr, users_c,
+                                                                                                 items_c, unorm, qmax_bits);
+        k_test_bf16_scores<D, KIND, true><<<grid, 64, 0, st>>>(U, N, users_c, items_c, unorm, qmax_bits, sig_u, c, scores, margin);
+    });
+    MACR_CHECK_LAUNCH("test_f16_scores", st);
     return MACR_OK;
 }
 #endif  // MACR_TEST_ENTRY_POINTS

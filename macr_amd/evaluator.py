@@ -19,6 +19,8 @@ import torch
 from . import ops, sharding
 from . import _lib as _lib_consts
 
+_LP_FILTERS = ("bf16", "f16")       # reduced-precision candidate filters (fp32 re-scoring; include/macr_hip.h MACR_EVAL_FILTER_*)
+
 
 class Evaluator(object):
     def __init__(self, mask_lists, gt_lists, n_items, device):
@@ -66,6 +68,11 @@ class Evaluator(object):
         # barely trained items under c = 40 -- cost 2-3x an fp32-filter evaluation; the next 1, 2, 4 ... 16 evaluations take the
         # fp32 filter before bf16 is tried again.  The ranking is the same either way.
         self._bf16_skip, self._bf16_backoff = 0, 1
+        # ... and one tier above it: the fp16 filter's margin is 12x the bf16 filter's.  An UNSEEDED fp16 evaluation that had
+        # to list query blocks again (lists that overflowed under a threshold less that margin: scores at the top closer
+        # together than fp16 resolves, e.g. (y - c) sig_i sig_u with c = 30 on barely trained rows of d = 128), or one that
+        # ended in the exact kernel, sends the next 1, 2, 4 ... 16 evaluations to the bf16 filter (whose own back-off leads on to fp32).
+        self._f16_skip, self._f16_backoff = 0, 1
         self._stats = torch.zeros(2, dtype=torch.int32, device=device)          # macr_score_topk stats of the last ranking
         self._stats_host = torch.zeros(2, dtype=torch.int32)
         self._stats_first = torch.zeros(2, dtype=torch.int32)          # written by the first-round ranking's own kernel
@@ -206,8 +213,13 @@ class Evaluator(object):
 
     @property
     def filter_now(self):
-        """the candidate filter of the ranking about to be launched: `filter`, or "f32" while the bf16 filter is backed off"""
-        return "f32" if (self.filter == "bf16" and self._bf16_skip > 0) else self.filter
+        """the candidate filter of the ranking about to be launched: `filter`, or "f32" while a reduced-precision filter
+        ("bf16", "f16") is backed off"""
+        if self.filter == "f16" and self._f16_skip == 0:
+            return "f16"
+        if self.filter in _LP_FILTERS:
+            return "f32" if self._bf16_skip > 0 else "bf16"
+        return self.filter
 
     def _relist_tolerance(self):
         """blocks of 256 queries a seeded ranking may list twice before the seeds count as stale: none up to 63 blocks (a repair
@@ -335,21 +347,30 @@ class Evaluator(object):
         seeded = (self.use_seeds and self._seed_skip == 0 and self._has_seeds(max(Ks), items_tab.shape[0]))
         if self.use_seeds and self._seed_skip > 0:
             self._seed_skip -= 1
-        used_bf16 = self.filter_now == "bf16"
+        used = self.filter_now
         try:
             return self._means_optimistic_run(flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, seeded)
         finally:
             info = getattr(self, "_last_info", None) or {}
-            if used_bf16:
-                if info.get("exact_fallback"):
-                    self._bf16_skip = self._bf16_backoff
-                    self._bf16_backoff = min(16, 2 * self._bf16_backoff)
+            if used == "f16":
+                if info.get("exact_fallback") or (not seeded and info.get("query_blocks_relisted")):
+                    self._f16_skip = self._f16_backoff
+                    self._f16_backoff = min(16, 2 * self._f16_backoff)
                 elif not info.get("redone"):
-                    self._bf16_backoff = 1
-            elif self._bf16_skip > 0:
-                self._bf16_skip -= 1
+                    self._f16_backoff = 1
+            else:
+                if self.filter == "f16" and self._f16_skip > 0 and not (used == "f32" and self._bf16_skip > 0):
+                    self._f16_skip -= 1                  # (an evaluation spent in the bf16 tier; fp32 ones count for the bf16 tier's own wait)
+                if used == "bf16":
+                    if info.get("exact_fallback"):
+                        self._bf16_skip = self._bf16_backoff
+                        self._bf16_backoff = min(16, 2 * self._bf16_backoff)
+                    elif not info.get("redone"):
+                        self._bf16_backoff = 1
+                elif self._bf16_skip > 0:
+                    self._bf16_skip -= 1
             if getattr(self, "_last_info", None) is not None:
-                self._last_info["filter"] = "bf16" if used_bf16 else ("f32" if self.filter == "bf16" else self.filter)
+                self._last_info["filter"] = used
 
     def _means_optimistic_run(self, flavour, kind, users_tab, user_ids, items_tab, Ks, w, wu, c, seeded):
         self._seeded_now = seeded

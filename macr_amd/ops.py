@@ -191,27 +191,27 @@ def score_topk_splits(U, n_local, d):
     return _lib.lib().macr_score_topk_splits(U, n_local, d)
 
 
-EVAL_FILTER_ENV, EVAL_FILTER_F32, EVAL_FILTER_BF16 = 0, 1, 2
+EVAL_FILTER_ENV, EVAL_FILTER_F32, EVAL_FILTER_BF16, EVAL_FILTER_F16 = 0, 1, 2, 3
 
 
-_FILTER_NAMES = {"env": EVAL_FILTER_ENV, "f32": EVAL_FILTER_F32, "bf16": EVAL_FILTER_BF16}
+_FILTER_NAMES = {"env": EVAL_FILTER_ENV, "f32": EVAL_FILTER_F32, "bf16": EVAL_FILTER_BF16, "f16": EVAL_FILTER_F16}
 
 
 def eval_filter_code(mode):
-    """"env" | "f32" | "bf16" (any case) or 0..2 -> MACR_EVAL_FILTER_*; anything else is refused by name (a typo in
+    """"env" | "f32" | "bf16" | "f16" (any case) or 0..3 -> MACR_EVAL_FILTER_*; anything else is refused by name (a typo in
     MACR_EVAL_FILTER must not surface as a bare ValueError inside the first evaluation)."""
     if isinstance(mode, str) and mode.strip().lower() in _FILTER_NAMES:
         return _FILTER_NAMES[mode.strip().lower()]
     if isinstance(mode, int) and not isinstance(mode, bool) and mode in _FILTER_NAMES.values():
         return mode
-    raise MacrError(_lib.E_INVALID, "eval filter %r: accepted values are 'env', 'f32', 'bf16' (or 0, 1, 2)" % (mode,))
+    raise MacrError(_lib.E_INVALID, "eval filter %r: accepted values are 'env', 'f32', 'bf16', 'f16' (or 0, 1, 2, 3)" % (mode,))
 
 
 _default_filter = EVAL_FILTER_ENV
 
 
 def set_eval_filter(mode):
-    """The filter ranking calls of THIS MODULE pass when their caller names none (`filter=None`): "f32", "bf16" or "env"
+    """The filter ranking calls of THIS MODULE pass when their caller names none (`filter=None`): "f32", "bf16", "f16" or "env"
     (MACR_EVAL_FILTER in the environment, f32 when unset).  Host-side convenience for tests and tools; the C ABI takes the
     filter per call (include/macr_hip.h, abi 10) and keeps no state."""
     global _default_filter
@@ -254,6 +254,21 @@ def test_bf16_scores(kind, users, items, sig_u=None, sig_i=None, c=0.0):
     margin = torch.empty(U, dtype=_f32, device=items.device)
     _check_test(L.macr_test_bf16_scores(kind, d, U, N, _ptr(users, _f32), _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
                                   float(c), _ptr(out), _ptr(margin), _ptr(ws), ws.numel(), _stream()))
+    return out, margin
+
+
+def test_f16_scores(kind, users, items, sig_u=None, sig_i=None, c=0.0):
+    """TEST-ONLY (macr_test_f16_scores): the same for the fp16 filter's listing pass (k_score_stream_h's MFMA sequence on
+    the fp16 operand copies) -> ((U, N) fp32, (U,) fp32); a query whose scaled row leaves fp16's range has margin +inf."""
+    _require_f32(users=users, items=items)
+    U, d = users.shape
+    N = items.shape[0]
+    L = _lib.test_lib()
+    ws = torch.empty(L.macr_test_bf16_scores_workspace_bytes(d, U, N), dtype=torch.uint8, device=items.device)
+    out = torch.empty((U, N), dtype=_f32, device=items.device)
+    margin = torch.empty(U, dtype=_f32, device=items.device)
+    _check_test(L.macr_test_f16_scores(kind, d, U, N, _ptr(users, _f32), _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
+                                 float(c), _ptr(out), _ptr(margin), _ptr(ws), ws.numel(), _stream()))
     return out, margin
 
 

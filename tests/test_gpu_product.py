@@ -23,7 +23,7 @@ def ops():
     return _ops
 
 
-@pytest.fixture(params=["f32", "bf16"])
+@pytest.fixture(params=["f32", "bf16", "f16"])
 def eval_filter(request, ops, monkeypatch):
     """run the test once per candidate filter of the listing pass (include/macr_hip.h MACR_EVAL_FILTER_*): the ranking
     must be the fp32 ranking bit for bit either way"""
