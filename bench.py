@@ -12,11 +12,12 @@ c=40 (the other configs are parity-test cases, selectable with --workload).
 `value` = training interactions/s of the whole job; the evaluator (full
 catalogue, train-masked, top-20, metrics) is timed in the same run, under both
 candidate filters of its listing pass, from the same model state:
-`eval_users_per_s` = the evaluator as the CLIs run it (bf16 candidate filter +
-fp32 re-scoring: the fp32 ranking bit for bit), `roofline_eval` = the same
-evaluations with fp32 products throughout, priced against the fp32 MFMA peak
-(`roofline_eval.eval_users_per_s` is that configuration's rate),
-`roofline_eval_bf16` = what the bf16 matrix cores execute in the default one.
+`eval_users_per_s` = the evaluator as the CLIs run it (fp16 candidate filter +
+fp32 re-scoring: the fp32 ranking bit for bit; MACR_EVAL_FILTER=bf16|f32 for the
+others), `roofline_eval` = the same evaluations with fp32 products throughout,
+priced against the fp32 MFMA peak (`roofline_eval.eval_users_per_s` is that
+configuration's rate), `roofline_eval_f16` (`_bf16`) = what the fp16 (bf16)
+matrix cores execute in the default one.
 
 Multi-GPU: the training step of these configs fits one GPU and the
 (B,B) loss couples every pair of a batch, so N GPUs run N independent replicas
@@ -54,7 +55,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16, dense (MI355X_MICROARCH.md)
 # reduced-precision candidate filters of the evaluator (same ranking as "f32", bit for bit); the Evaluator's default
 LP_FILTERS = ("bf16", "f16")
-DEFAULT_EVAL_FILTER = "bf16"
+DEFAULT_EVAL_FILTER = "f16"
 
 
 def lp_filter_name():

@@ -35,10 +35,12 @@ class Evaluator(object):
         self.max_queries_per_pass = 131072       # bounds the ranking workspace (~1.5 GB of candidate lists)
         self.use_graph = os.environ.get("MACR_EVAL_GRAPH", "1") != "0"    # replay the evaluation as one HIP graph (_means)
         self.use_seeds = os.environ.get("MACR_EVAL_SEEDS", "1") != "0"    # thresholds from the previous top K (rank_local)
-        # candidate filter of the listing pass, an argument of every ranking call (include/macr_hip.h MACR_EVAL_FILTER_*): "bf16" = two-term bf16 products on
-        # the bf16 matrix cores + fp32 re-scoring of the best candidates, "f32" = fp32 products throughout.  The ranking
-        # is the fp32 ranking bit for bit either way; MACR_EVAL_FILTER in the environment overrides the default.
-        self.filter = os.environ.get("MACR_EVAL_FILTER", "bf16").strip().lower()
+        # candidate filter of the listing pass, an argument of every ranking call (include/macr_hip.h MACR_EVAL_FILTER_*): "f16" (default, round 6) =
+        # one fp16 number per operand on the fp16 matrix cores, "bf16" = two-term bf16 products on the bf16 matrix cores -- both
+        # with fp32 re-scoring of the best candidates -- "f32" = fp32 products throughout.  The ranking is the fp32 ranking bit
+        # for bit whichever it is; MACR_EVAL_FILTER in the environment overrides the default; the policy below steps down
+        # f16 -> bf16 -> f32 where a model's scores are packed closer than a filter resolves.
+        self.filter = os.environ.get("MACR_EVAL_FILTER", "f16").strip().lower()
         ops.eval_filter_code(self.filter)         # a typo in the environment is refused here, by name
         # One GPU, graph replays: an evaluation launches the FIRST ROUND of the ranking only and writes its means and the
         # ranking's stats straight into pinned host memory; the host, which waits for the means anyway, sees whether a

@@ -902,6 +902,42 @@ def test_lightgcn_tune_cli(tmp_path):
         assert abs(hr - hit_of(sweep_line)) < 6e-6, (pre[c_key], sweep_line)
 
 
+def test_evaluator_steps_down_from_the_fp16_filter_where_it_cannot_resolve_the_top(ops, monkeypatch):
+    """Filter policy: (y - 30) sig_i sig_u on untrained rows of d = 128 packs every query's top closer than the fp16 filter's
+    margin (tests/test_gpu_ops.py, the prologue test's third shape): the first, unseeded fp16 evaluation lists query blocks
+    twice, so the next one runs under the bf16 filter (whose margin is 12x tighter), after which fp16 is tried again with
+    the seeds the bf16 ranking left.  The metrics are the fp32-filter evaluator's throughout."""
+    from macr_amd.evaluator import Evaluator
+    monkeypatch.setenv("MACR_EVAL_FILTER", "f16")
+    rs = np.random.RandomState(141 + 513)
+    U, N, d = 513, 20011, 128
+    P = dev((rs.standard_normal((U + 50, d)) * 0.4).astype(np.float32))
+    Q = dev((rs.standard_normal((N, d)) * 0.4).astype(np.float32))
+    w, wu = dev((rs.standard_normal(d) * 0.3).astype(np.float32)), dev((rs.standard_normal(d) * 0.3).astype(np.float32))
+    uid = dev(rs.permutation(U + 50)[:U].astype(np.int32))
+    mask = [sorted(rs.choice(N, 30, replace=False).tolist()) for _ in range(U)]
+    gt = [sorted(rs.choice(N, 5, replace=False).tolist()) for _ in range(U)]
+    ev = Evaluator(mask, gt, N, torch.device("cuda"))
+    assert ev.filter == "f16"
+    monkeypatch.setenv("MACR_EVAL_FILTER", "f32")
+    plain = Evaluator(mask, gt, N, torch.device("cuda"))
+    plain.use_seeds, plain.use_graph = False, False
+    want = plain.test_mf(ops.SCORE_RUBI_BOTH, P, uid, Q, [20], w, wu, 30.0)
+    used = []
+    for step in range(4):
+        got = ev.test_mf(ops.SCORE_RUBI_BOTH, P, uid, Q, [20], w, wu, 30.0)
+        torch.cuda.synchronize()
+        info = ev.last_eval_info()
+        used.append((info.get("filter"), info["seeded"], info["query_blocks_relisted"], info["exact_fallback"]))
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (step, k, used)
+    assert used[0][0] == "f16" and not used[0][1]
+    if used[0][2] or used[0][3]:                  # (what this shape does today; were the margin ever tightened, nothing to step down from)
+        assert used[1][0] == "bf16", used
+        assert used[2][0] == "f16", used          # back-off of one evaluation, then fp16 again -- seeded this time
+    assert all(u[3] == 0 for u in used if u[0] != "f16"), used
+
+
 def test_evaluator_seeds_follow_the_model_and_back_off_when_it_jumps(ops, eval_filter):
     """Evaluator.rank_local seeds every ranking's thresholds with the best candidates of the previous one.  Tables that
     drift a little between two evaluations keep the seeds good (no query block listed twice); a model that jumps
