@@ -2013,6 +2013,11 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
 // two DIFFERENT tiles of one step (waves 0-3 the first, 4-7 the second): two tiles staged per barrier, each tile's
 // fragments read by four waves instead of eight.  LDS reads per 32 x 32 products: a quarter of k_score_stream_c's in
 // count, an eighth in bytes.  The two waves that share a query append to her list through the same LDS counter.
+// Measured on the Gowalla shape (15 424 queries x 40 981 items, d = 64; profiles/r06_eval_f16_filter.txt): 165-172 us under
+// sampled thresholds, 145-148 under seeded ones (k_score_stream_c: 247 / 228); by ablation (-DMACR_ABL_H_*): without the
+// epilogue 97 us, without epilogue and MFMAs 82 us, without the barrier no change -- the skeleton of a step (two tiles from
+// global memory through registers into LDS, five fragment reads per wave, the visit arithmetic) is most of the pass, the 10
+// MFMAs of a wave's step hide under it, and the epilogue is the rest.  The matrix cores alone would need 46 us.
 // ----------------------------------------------------------------------------
 template <int D, int KIND, bool REPAIR = false>
 __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
@@ -2021,8 +2026,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
     const float *__restrict__ sig_u, float c_val, const float *__restrict__ c_dev,
     const uint32_t *__restrict__ mask_bits, const uint32_t *__restrict__ zero_word, int item_offset, int ublocks,
     const float *__restrict__ tau, uint64_t *__restrict__ lists, int32_t *__restrict__ counts, int cap, int32_t *overflow,
-    int ovf_per_user, int32_t *blk_flag, const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev, int slots_full,
-    int xcd_pieces) {
+    int ovf_per_user, int32_t *blk_flag, const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev, int slots_full) {
     using C = StreamCfgH<D>;
     constexpr int THREADS = 512, NS = C::NS, RU = C::RU, TU = C::TU, SU = C::SU, LDU = C::LDU;
     constexpr int kCheckTiles = 8;
@@ -2059,32 +2063,17 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
     const long long W = (long long)n_ub * T;
     const long long w_end = W * (b + 1) / G;
     const size_t mask_stride = mask_bits ? (size_t)U : 0;
-    // segments of this block: (query block, visits [i0, i1), result slot).  Linear decomposition: a contiguous share of the
-    // n_ub * T visits (k_score_stream_c).  XCD-aware (first round, xcd_pieces > 0; StreamGeo): this XCD's eighth of the visit
-    // sequence for the units (query block, piece) j, j + blocks per XCD, ...
-    const bool by_xcd = !REPAIR && xcd_pieces > 0;
-    const int xcd = (int)(b & 7), bx = (int)(G >> 3);
-    const int x0 = (int)((long long)T * xcd / 8), x1 = (int)((long long)T * (xcd + 1) / 8);
-    const int n_units = n_ub * xcd_pieces;
-    int unit = (int)(b >> 3);
-    for (long long w = W * b / G; by_xcd ? unit < n_units : w < w_end;) {
-    int ubv, i0, i1, split;
-    if (by_xcd) {
-        ubv = unit / xcd_pieces;
-        const int piece = unit - ubv * xcd_pieces;
-        i0 = x0 + (int)((long long)(x1 - x0) * piece / xcd_pieces);
-        i1 = x0 + (int)((long long)(x1 - x0) * (piece + 1) / xcd_pieces);
-        split = xcd * xcd_pieces + piece;
-        unit += bx;
-    } else {
-        ubv = (int)(w / T); i0 = (int)(w - (long long)ubv * T);
-        i1 = (int)min((long long)T, i0 + (w_end - w));
-        w += i1 - i0;
-        long long first = (long long)ubv * T * G / W;
-        while (W * (first + 1) / G <= (long long)ubv * T) ++first;
-        while (W * first / G > (long long)ubv * T) --first;
-        split = (int)(b - first);
-    }
+    // (An XCD-aware decomposition -- block b lists only visits of XCD (b % 8)'s eighth of the visit sequence, so that the blocks
+    // of an XCD stream the same 0.7 MB of tiles through its L2 -- was built and measured: 166 against 164 us, no gain; the pass
+    // is not bound by where its tiles come from.  profiles/r06_eval_f16_filter.txt)
+    for (long long w = W * b / G; w < w_end;) {
+    const int ubv = (int)(w / T), i0 = (int)(w - (long long)ubv * T);
+    const int i1 = (int)min((long long)T, i0 + (w_end - w));
+    w += i1 - i0;
+    long long first = (long long)ubv * T * G / W;
+    while (W * (first + 1) / G <= (long long)ubv * T) ++first;
+    while (W * first / G > (long long)ubv * T) --first;
+    const int split = (int)(b - first);
     const int ub = REPAIR ? ub_map[ubv] : ubv;
     __syncthreads();                                          // (the previous segment's readers are done with s_t and s_cnt)
     for (int k = tid; k < kUsersPerBlock; k += THREADS) s_cnt[k] = 0u;
@@ -2267,7 +2256,9 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
             const int done = min(vi + 2, i1) - i0;
             const bool looked = stale_mark(vi - i0, done);
             store_step(std::integral_constant<int, 1>());
+#ifndef MACR_ABL_H_NOBARRIER
             __syncthreads();
+#endif
             tm0 = tm_next[0]; tm1 = tm_next[1]; ta = na; tb = nb; vi += 2;
             if (stale_read(looked)) break;
         }
@@ -2280,7 +2271,9 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
             const int done = min(vi + 2, i1) - i0;
             const bool looked = stale_mark(vi - i0, done);
             store_step(std::integral_constant<int, 0>());
+#ifndef MACR_ABL_H_NOBARRIER
             __syncthreads();
+#endif
             tm0 = tm_next[0]; tm1 = tm_next[1]; ta = na; tb = nb; vi += 2;
             if (stale_read(looked)) break;
         }
@@ -4013,14 +4006,7 @@ extern "C" void macr_dbg_counters(unsigned long long *out) {
 namespace macr {
 // Launch geometry of the two streaming passes (see k_score_stream): grid sizes and the number of result slots a
 // user block can have (= blocks overlapping its tile range).
-// grid_x / pieces_x (fp16 listing pass, k_score_stream_h): the XCD-aware decomposition -- block b runs on XCD b % 8 (workgroups go
-// to the eight XCDs round-robin) and lists only visits of that XCD's EIGHTH of the visit sequence, for one query block after
-// another; a (query block, eighth) is cut into pieces_x pieces where there are fewer query blocks than blocks per XCD.  All
-// blocks of an XCD then stream the same T/8 tiles (0.7 MB of fp16 rows at the Gowalla catalogue: resident in its 4 MB L2)
-// instead of every block pulling its own range through the L2 from the Infinity Cache -- the pass was bound by exactly that
-// latency (bytes in flight / latency = its 2 TB/s).  pieces_x = 0: the linear decomposition (small catalogues).  A query has
-// 8 * pieces_x result slots under it; slots1 covers both decompositions.
-struct StreamGeo { int ublocks, grid0, slots0, grid1, slots1, range1, grid_x, pieces_x; };   // range1: longest tile range of pass 1
+struct StreamGeo { int ublocks, grid0, slots0, grid1, slots1, range1; };   // range1: longest tile range of pass 1
 static StreamGeo stream_geo(int U, int n_local, int d) {
     StreamGeo g;
     g.ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
@@ -4039,25 +4025,6 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
     plan(T0, g.grid0, g.slots0);
     plan(T1, g.grid1, g.slots1);
     g.range1 = (int)(((long long)g.ublocks * T1 + g.grid1 - 1) / g.grid1);
-    g.grid_x = 0; g.pieces_x = 0;
-    if (T1 >= 8 * 32) {                                       // (an eighth of the visits is worth a block's prologue)
-        const int bx = resident / 8;                          // blocks per XCD
-        int best_p = 1;
-        double best = 1e30;
-        for (int pc = 1; pc <= 4; ++pc) {                     // pieces per (query block, eighth): the first whose rounds fill >= 94 % of the blocks, else the best
-            if (T1 / (8 * pc) < 16 && pc > 1) break;
-            const long long units = (long long)g.ublocks * pc;
-            const long long rounds = (units + bx - 1) / bx;
-            const double waste = (double)(rounds * std::min<long long>(bx, units)) / (double)units;
-            if (waste < best - 1e-9) { best = waste; best_p = pc; }
-            if (waste <= 1.0 / 0.94) break;
-        }
-        g.pieces_x = best_p;
-        const long long units = (long long)g.ublocks * best_p;
-        g.grid_x = 8 * (int)std::min<long long>(bx, units);
-        // longest list range of the decomposition must fit the list-everything test's assumption too: (T1/8)/pieces <= range1 holds
-        g.slots1 = std::max(g.slots1, 8 * best_p);
-    }
     return g;
 }
 
@@ -4424,21 +4391,18 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
             const size_t smem_c = half ? StreamCfgH<D>::smem : StreamCfgC<D>::smem;
             MACR_REQUIRE(hipFuncSetAttribute(pass1c, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
-            if (half) {
-                // (the XCD-aware decomposition where the catalogue is long enough: StreamGeo)
-                static const bool no_xcd = getenv("MACR_EVAL_XCD") && getenv("MACR_EVAL_XCD")[0] == '0';      // A/B switch
-                const bool by_xcd = geo.pieces_x > 0 && !no_xcd;
-                k_score_stream_h<D, KIND><<<by_xcd ? geo.grid_x : geo.grid1, 512, smem_c, st>>>(
-                    U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev, mask_bits, zero_word, item_offset, geo.ublocks,
-                    ws.tau, ws.lists, ws.counts, ws.cap, repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
-                    seeded ? ws.blk_flag : nullptr, nullptr, nullptr, 0, by_xcd ? geo.pieces_x : 0);
-            } else {
+            if (half)
+                k_score_stream_h<D, KIND><<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
+                                                                       mask_bits, zero_word, item_offset, geo.ublocks,
+                                                                       ws.tau, ws.lists, ws.counts, ws.cap,
+                                                                       repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
+                                                                       seeded ? ws.blk_flag : nullptr, nullptr, nullptr, 0);
+            else
                 k_score_stream_c<D, KIND><<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
                                                                        mask_bits, zero_word, item_offset, geo.ublocks,
                                                                        ws.tau, ws.lists, ws.counts, ws.cap,
                                                                        repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
                                                                        seeded ? ws.blk_flag : nullptr, nullptr, nullptr, 0);
-            }
             MACR_CHECK_LAUNCH("score_stream_b", st);
             k_select_b<D, KIND><<<sel_blocks, 64 * kSelWaves, 0, st>>>(U, n_local, geo.slots1, n_splits, K, ws.cap, ws.lists, ws.counts,
                                                                       repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0, nullptr,
@@ -4488,7 +4452,7 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
                     k_score_stream_h<D, KIND, true><<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
                                                                                 mask_bits, zero_word, item_offset, geo.ublocks, ws.tau,
                                                                                 ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
-                                                                                ws.ub_map, ws.overflow + 1, geo.slots1, 0);
+                                                                                ws.ub_map, ws.overflow + 1, geo.slots1);
                 else
                     k_score_stream_c<D, KIND, true><<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
                                                                                 mask_bits, zero_word, item_offset, geo.ublocks, ws.tau,
