@@ -4355,24 +4355,25 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
                                                                mask_bits, item_offset, K, seed_idx, ws.tau);
             MACR_CHECK_LAUNCH("tau_seed", st);
         } else if (!list_all && f32_sample_bf16) {
-            // fp32 listing, thresholds from the BF16 sampling pass (round 6).  k_tau's threshold under that pass is already a
-            // statement about fp32 scores -- "K sampled items score >= tau in fp32" (the filter's margin is taken off there) --
-            // which is all the fp32 listing pass asks of it; the operand copies + the bf16 sampling pass + k_tau cost 12 + 46 + 11 us
-            // at the Gowalla shape where the fp32 sampling pass + k_tau cost 104 + 20.  The ranking is the fp32 ranking either
-            // way (tests/ under both filters); MACR_EVAL_F32_SAMPLE=f32 keeps the fp32 sampling pass (A/B).  The class maxima
-            // were NaN-filled for the 32-per-class layout, which covers the 16-per-class one the merged sampling pass writes.
-            k_bf16_prep_c<D, KIND><<<bf16_prep_c_blocks(U, n_local, D, kPrepTripsAlone), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
-                                                                                      users_c, ws.items_c, ws.unorm, qmax_bits);
+            // fp32 listing, thresholds from the reduced-precision sampling pass (round 6).  k_tau's threshold under that pass is already
+            // a statement about fp32 scores -- "K sampled items score >= tau in fp32" (the filter's margin is taken off there) --
+            // which is all the fp32 listing pass asks of it.  The pass runs on the FP16 copies (one MFMA per 16 k): operand copies +
+            // sampling pass + k_tau cost 9 + 28 + 13 us at the Gowalla shape where the bf16 copies cost 12 + 46 + 11 and the fp32
+            // sampling pass + k_tau 104 + 20.  The ranking is the fp32 ranking either way (tests/ under every filter);
+            // MACR_EVAL_F32_SAMPLE=f32 keeps the fp32 sampling pass (A/B).  The class maxima were NaN-filled for the 32-per-class
+            // layout, which covers the 16-per-class one the merged sampling pass writes.
+            k_bf16_prep_c<D, KIND, true><<<bf16_prep_c_blocks(U, n_local, D, kPrepTripsAlone), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
+                                                                                            ws.users_c, ws.items_c, ws.unorm, qmax_bits);
             MACR_CHECK_LAUNCH("bf16_prep_c", st);
-            auto pass0c = k_score_sample_c<D, KIND>;
-            const size_t smem_c = StreamCfgC<D>::smem;
+            auto pass0c = k_score_sample_c<D, KIND, false, true>;
+            const size_t smem_c = StreamCfgH1<D>::smem;
             MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass0c), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
-            pass0c<<<geo.grid0, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
+            pass0c<<<geo.grid0, 512, smem_c, st>>>(U, n_local, ws.users_c, ws.items_c, sig_u, mask_bits, zero_word,
                                                   geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, nullptr, nullptr);
             MACR_CHECK_LAUNCH("score_sample_b", st);
             launch_k_tau<false>((geo.slots0 * per_c + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev, D,
-                                merge_pairs ? 4 : 5);
+                                merge_pairs ? 4 : 5, 1, KIND == MACR_SCORE_RUBI_BOTH ? sig_u : nullptr);
             MACR_CHECK_LAUNCH("tau", st);
         } else if (!list_all) {
             // (a catalogue (shard) whose every tile range fits a candidate list needs no threshold: tau = -inf lists every
