@@ -39,7 +39,7 @@ extern "C" {
 #define MACR_E_WORKSPACE    -3   /* workspace too small                                         */
 #define MACR_E_LAUNCH       -4   /* hipLaunch / runtime failure                                 */
 
-#define MACR_ABI_VERSION     14
+#define MACR_ABI_VERSION     15
 
 /* loss kinds */
 #define MACR_LOSS_NORMALBCE   0  /* --train normalbce   macr_mf/model.py:277-287 ; --loss bce     LightGCN.py:415-429 */
@@ -514,6 +514,9 @@ size_t macr_score_topk_workspace_bytes(int U, int n_local, int d);
 /* OR into `filter` of macr_score_topk / macr_score_topk_first_round (abi 12): the head of `workspace` was initialised by
  * macr_score_topk_prologue for exactly this call, which then launches no initialisation of its own. */
 #define MACR_EVAL_WS_READY    0x100
+/* OR into `filter` together with MACR_EVAL_WS_READY and MACR_EVAL_FILTER_F16 (abi 15): macr_score_topk_prologue_prep has also
+ * written the fp16 filter's operand copies for exactly this call (same score_kind, c, tables), which then converts nothing. */
+#define MACR_EVAL_PREP_READY  0x200
 
 int macr_score_topk(int score_kind, int filter, int U, int n_local, int d,
                     const float *users_tab, const int32_t *user_ids, const float *items,
@@ -560,6 +563,18 @@ int macr_score_topk_prologue(int filter, int U, int n_local, int d, int K, int s
                              const float *items, const float *w_item, float *sig_i,
                              const float *users_tab, const int32_t *user_ids, const float *w_user, float *sig_u,
                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same and, in the same launch, the fp16 filter's operand copies for the ranking call that follows (abi 15): every row of
+ * `items` and every query row is read ONCE -- for its branch factor (computed from the row in hand, macr_branch_sigmoid's
+ * arithmetic bit for bit) and for its fp16 copy, norm and bias -- where macr_score_topk_prologue + the ranking call's own
+ * conversion read them twice, cold after a log interval of training (the tables are what training has just rewritten).
+ * That call takes filter = MACR_EVAL_FILTER_F16 | MACR_EVAL_WS_READY | MACR_EVAL_PREP_READY and the same score_kind, c / c_dev,
+ * U, n_local, d, K, tables, workspace and stream.  K <= MACR_MAX_TOPK_FUSED; a catalogue small enough to list every item
+ * (no filter runs there) is refused with MACR_E_UNSUPPORTED: use macr_score_topk_prologue. */
+int macr_score_topk_prologue_prep(int score_kind, int U, int n_local, int d, int K, int seeded_first_round,
+                                  const float *items, const float *w_item, float *sig_i,
+                                  const float *users_tab, const int32_t *user_ids, const float *w_user, float *sig_u,
+                                  float c, const float *c_dev, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * The same ranking for SEVERAL values of c at once -- the c sweep of the tuners

@@ -17,7 +17,7 @@ SCORE_NORMAL, SCORE_RUBI_BOTH, SCORE_RUBI, SCORE_DIRECT_MINUS, SCORE_DIRECT_MINU
 MAX_TOPK = 128
 MAX_TOPK_FUSED = 32
 MAX_SWEEP = 4
-ABI_VERSION = 14
+ABI_VERSION = 15
 LAZY_STATE_BYTES, LAZY_MAX_PERIOD = 1040, 64
 
 
@@ -89,6 +89,7 @@ SIGNATURES = {
     "macr_score_topk_first_round": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "macr_score_topk_repair_round": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "macr_score_topk_prologue": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "macr_score_topk_prologue_prep": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _z, _p]),
     "macr_score_topk_sweep_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "macr_score_topk_sweep": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _z, _p]),
     "macr_mask_bits_bytes": (_z, [_i, _i]),

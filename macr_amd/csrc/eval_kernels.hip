@@ -1463,12 +1463,19 @@ __device__ __forceinline__ bool sig_u_tiny(float su) { return !(su > 1e-30f); }
 // scaled ones.  Row space of a block: [0, n_pad) items, [n_pad, n_pad + U) queries.
 // HALF: the fp16 filter's copies instead -- fp16[D] per row (item rows: + the bias unit, RU = D/8 + 1), clamped to the
 // finite range; a row that was clamped reports an infinite norm (filter_margin_h).
-template <int D, int KIND, int TRIPS, bool HALF = false>
+// FUSED (k_eval_prologue_prep): the branch factors are not read but COMPUTED here, from the rows this block holds anyway --
+// sigmoid(row . w), k_branch_sigmoid's arithmetic bit for bit (a lane's two float4 are two of its lanes; its butterfly pairs
+// them last) -- and written to sig_i_out / sig_u_out; the block's largest item norm goes to qpart[blk] instead of an atomic
+// max (the launch also zeroes the workspace head: no word of it may be accumulated into), for qmax_from_parts to reduce.
+template <int D, int KIND, int TRIPS, bool HALF = false, bool FUSED = false>
 __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, const float *__restrict__ users_tab,
                                                   const int32_t *__restrict__ user_ids, const float *__restrict__ items,
                                                   const float *__restrict__ sig_u, const float *__restrict__ sig_i, float c,
                                                   uint4 *__restrict__ users_c, uint4 *__restrict__ items_c,
-                                                  float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits) {
+                                                  float *__restrict__ unorm, uint32_t *__restrict__ qmax_bits,
+                                                  const float *__restrict__ w_item = nullptr, const float *__restrict__ w_user = nullptr,
+                                                  float *__restrict__ sig_i_out = nullptr, float *__restrict__ sig_u_out = nullptr,
+                                                  float *__restrict__ qpart = nullptr) {
     constexpr int LPRB = D / 8, RPB = 256 / LPRB, RU = HALF ? D / 8 + 1 : StreamCfgC<D>::RU;
     __shared__ float s_max[4];
     const int n_pad = ((n_local + kTileItems - 1) / kTileItems) * kTileItems;
@@ -1485,12 +1492,23 @@ __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, c
         const float *src = is_item ? items + (size_t)row[t] * D : users_tab + (size_t)(is_user ? (user_ids ? user_ids[q] : q) : 0) * D;
         a[t] = ld4(src + 8 * sub); b[t] = ld4(src + 8 * sub + 4);
         scale[t] = 1.0f; bias[t] = 0.0f;
+        float sg_row = 0.0f;
+        if (FUSED) {
+            const float *wv = is_item ? w_item : w_user;      // (uniform over the row's lanes; w_user == NULL: one-branch scores)
+            float pa = 0.f, pb = 0.f;
+            if (wv && (is_item || is_user)) { pa = dot4(a[t], ld4(wv + 8 * sub)); pb = dot4(b[t], ld4(wv + 8 * sub + 4)); }
+#pragma unroll
+            for (int m = LPRB >> 1; m >= 1; m >>= 1) { pa += __shfl_xor(pa, m, kWave); pb += __shfl_xor(pb, m, kWave); }
+            sg_row = sigmoid_acc(pa + pb);
+            if (sub == 0 && is_item && sig_i_out) sig_i_out[row[t]] = sg_row;
+            if (sub == 0 && is_user && w_user && sig_u_out) sig_u_out[q] = sg_row;
+        }
         if (is_item && score_uses_sig_i(KIND)) {
-            const float sgi = sig_i[row[t]];
+            const float sgi = FUSED ? sg_row : sig_i[row[t]];
             scale[t] = item_scale_c<KIND>(sgi); bias[t] = item_bias_c<KIND>(sgi, c);
         }
         if (is_user && KIND == MACR_SCORE_DIRECT_MINUS_BOTH && !HALF) {     // (HALF: sig_u sits in the bias slab, bias_query_unit_h)
-            const float su = sig_u[q];
+            const float su = FUSED ? sg_row : sig_u[q];
             scale[t] = sig_u_tiny(su) ? 1.0f : 1.0f / su;
         }
     }
@@ -1555,9 +1573,25 @@ __device__ __forceinline__ void bf16_prep_c_block(int blk, int U, int n_local, c
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-        if (m > __uint_as_float(__hip_atomic_load(qmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        if (FUSED) qpart[blk] = m;
+        else if (m > __uint_as_float(__hip_atomic_load(qmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
             atomicMax(qmax_bits, __float_as_uint(m));
     }
+}
+// max |q| from the per-block maxima k_eval_prologue_prep left: one block of a later launch (k_tau_seed, k_score_sample_c)
+__device__ __forceinline__ void qmax_from_parts(const float *__restrict__ qpart, int n_part, uint32_t *__restrict__ qmax_bits) {
+    __shared__ float s_qm[16];
+    float m = 0.f;
+    for (int k = threadIdx.x; k < n_part; k += blockDim.x) m = fmaxf(m, qpart[k]);      // (norms: >= 0, +inf for a row without a bound)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+    if ((threadIdx.x & 63) == 0) s_qm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x + 63) / 64; ++k) m = fmaxf(m, s_qm[k]);
+        *qmax_bits = __float_as_uint(m);
+    }
+    __syncthreads();
 }
 static inline unsigned bf16_prep_c_blocks(int U, int n_local, int d, int trips) {
     const size_t rows_per_block = (size_t)trips * (256 / (d / 8));
@@ -1813,7 +1847,10 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
     int U, int n_local, const uint4 *__restrict__ users_c, const uint4 *__restrict__ items_c,
     const float *__restrict__ sig_u, const uint32_t *__restrict__ mask_bits, const uint32_t *__restrict__ zero_word,
     int ublocks, float *__restrict__ maxima, int sample_log2, int merge_pairs,
-    const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev) {
+    const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev,
+    const float *__restrict__ qpart = nullptr, int n_part = 0, uint32_t *__restrict__ qmax_bits = nullptr) {
+    // (after k_eval_prologue_prep: the last block first turns its per-block item norms into max |q| -- k_tau reads it next)
+    if (qpart && blockIdx.x == gridDim.x - 1) qmax_from_parts(qpart, n_part, qmax_bits);
     using C = std::conditional_t<HALF, StreamCfgH1<D>, StreamCfgC<D>>;      // HALF: the fp16 filter's copies (one MFMA per 16 k)
     constexpr int UR = HALF ? D / 8 : 2 * D / 8;              // 16-byte units per query row
     constexpr int THREADS = 512, NS = C::NS, RU = C::RU, TU = C::TU, LDU = C::LDU, REM = C::REM;
@@ -2743,7 +2780,10 @@ __global__ __launch_bounds__(256) void k_tau_seed(int U, int n_local, const floa
                                                   const float *__restrict__ sig_u, const float *__restrict__ sig_i,
                                                   float c_val, const float *__restrict__ c_dev,
                                                   const uint32_t *__restrict__ mask_bits, int item_offset, int K,
-                                                  const int32_t *__restrict__ seed, float *__restrict__ tau) {
+                                                  const int32_t *__restrict__ seed, float *__restrict__ tau,
+                                                  const float *__restrict__ qpart = nullptr, int n_part = 0, uint32_t *__restrict__ qmax_bits = nullptr) {
+    // (after k_eval_prologue_prep: one extra block turns its per-block item norms into max |q| for the listing pass)
+    if (qpart && blockIdx.x == gridDim.x - 1) { qmax_from_parts(qpart, n_part, qmax_bits); return; }
     tau_seed_block<D, KIND>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_val, c_dev, mask_bits, item_offset, K, seed, tau);
 }
 
@@ -3631,6 +3671,35 @@ __global__ __launch_bounds__(256) void k_eval_prologue(int nb_a, const float *__
     if (sub == 0) out[r] = sigmoid_acc(s);
 }
 
+// k_eval_prologue and the fp16 filter's operand copies as ONE launch (macr_score_topk_prologue_prep): the rows an evaluation
+// starts by reading twice -- once for the branch factors, once for the copies, 15 MB at the Gowalla shape and COLD after a
+// log interval of training (profiles/r06_eval_cold_start.txt) -- are read once.  Blocks [0, n_prep): bf16_prep_c_block<FUSED>
+// (branch factors computed from the rows in hand, copies, |u|, per-block max |q|); the rest: the workspace head.
+template <int D, int KIND>
+__global__ __launch_bounds__(256) void k_eval_prologue_prep(int n_prep, int U, int n_local, const float *__restrict__ users_tab,
+                                                            const int32_t *__restrict__ user_ids, const float *__restrict__ items,
+                                                            const float *__restrict__ w_item, const float *__restrict__ w_user,
+                                                            float *__restrict__ sig_i, float *__restrict__ sig_u,
+                                                            float c_val, const float *__restrict__ c_dev,
+                                                            uint4 *__restrict__ users_c, uint4 *__restrict__ items_c,
+                                                            float *__restrict__ unorm, float *__restrict__ qpart,
+                                                            uint32_t *__restrict__ base, size_t n_zero, size_t n_tau,
+                                                            uint32_t tau_bits, int set_tau, size_t n_max) {
+    if ((int)blockIdx.x >= n_prep) {
+        const size_t blk = blockIdx.x - n_prep, nblk = gridDim.x - n_prep;
+        const size_t total = n_zero + n_tau + n_max;
+        for (size_t w = blk * (size_t)blockDim.x + threadIdx.x; w < total; w += nblk * blockDim.x) {
+            if (w < n_zero) base[w] = 0u;
+            else if (w < n_zero + n_tau) { if (set_tau) base[w] = tau_bits; }
+            else base[w] = 0xffffffffu;
+        }
+        return;
+    }
+    bf16_prep_c_block<D, KIND, kPrepTripsAlone, true, true>(blockIdx.x, U, n_local, users_tab, user_ids, items, nullptr, nullptr,
+                                                            c_dev ? *c_dev : c_val, users_c, items_c, unorm, nullptr,
+                                                            w_item, w_user, sig_i, sig_u, qpart);
+}
+
 // ----------------------------------------------------------------------------
 // metrics
 // ----------------------------------------------------------------------------
@@ -4035,6 +4104,7 @@ struct TopkWs {
     float *tau, *maxima; int32_t *counts; int32_t *overflow, *user_ovf, *ub_map, *blk_flag; uint32_t *shared_thr, *mask_bits; uint64_t *lists;
     uint4 *users_bf, *items_bf; float *unorm;        // bf16 filter: operand copies, |u| per query user (max |q|: overflow[8], zeroed per call)
     uint4 *users_c, *items_c;
+    float *qpart;
     int cap; size_t header_bytes, maxima_bytes, mask_bytes, lists_bytes, bytes;
 };
 static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g, int d = 0) {
@@ -4065,6 +4135,7 @@ static TopkWs carve_topk_ws(void *base, int U, int n_local, const StreamGeo &g, 
     w.unorm = static_cast<float *>(take((size_t)U * 4));
     w.users_c = static_cast<uint4 *>(take((size_t)U * d * 4));           // k_score_stream_c's copies (the epilogue in the operands)
     w.items_c = static_cast<uint4 *>(take(d ? items_c_bytes(n_local, d) : 0));
+    w.qpart = static_cast<float *>(take(d ? (size_t)bf16_prep_c_blocks(U, n_local, d, kPrepTripsAlone) * 4 : 0));   // k_eval_prologue_prep's per-block item norms
     w.bytes = off;
     return w;
 }
@@ -4208,7 +4279,11 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
     MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "score_topk: score_kind=%d", score_kind);
     // MACR_EVAL_WS_READY: macr_score_topk_prologue has initialised the workspace head for exactly this call
     const bool ws_ready = (filter & MACR_EVAL_WS_READY) != 0;
-    filter &= ~MACR_EVAL_WS_READY;
+    // MACR_EVAL_PREP_READY: macr_score_topk_prologue_prep has also written the fp16 filter's operand copies for this call
+    const bool prep_ready = (filter & MACR_EVAL_PREP_READY) != 0;
+    filter &= ~(MACR_EVAL_WS_READY | MACR_EVAL_PREP_READY);
+    MACR_REQUIRE(!prep_ready || (ws_ready && eval_filter_resolved(filter) == MACR_EVAL_FILTER_F16), MACR_E_INVALID,
+                 "score_topk: MACR_EVAL_PREP_READY goes with MACR_EVAL_WS_READY and the fp16 filter");
     MACR_REQUIRE(filter >= MACR_EVAL_FILTER_ENV && filter <= MACR_EVAL_FILTER_F16, MACR_E_INVALID, "score_topk: filter=%d", filter);
     MACR_REQUIRE(!ws_ready || mode != 2, MACR_E_INVALID, "score_topk: MACR_EVAL_WS_READY on a repair round");
     MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk: U=%d n_local=%d", U, n_local);
@@ -4314,6 +4389,7 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
         // users_c: the scaled query copies exist for DIRECT_MINUS_BOTH only; the other kinds' are the plain ones
         // (the fp16 copies have a layout of their own: always in users_c)
         uint4 *users_c = (half || KIND == MACR_SCORE_DIRECT_MINUS_BOTH) ? ws.users_c : ws.users_bf;
+        const int n_part = (int)bf16_prep_c_blocks(U, n_local, D, kPrepTripsAlone);         // k_eval_prologue_prep's per-block item norms
         const uint32_t *zero_word = reinterpret_cast<const uint32_t *>(ws.overflow + 3);
         // k_score_sample_c merges its classes in pairs where that still leaves several times K of them (k_tau ranks half as many)
         const int merge_pairs = geo.slots0 * 16 >= 4 * K ? 1 : 0, per_c = merge_pairs ? 16 : 32;
@@ -4325,11 +4401,20 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
             // the listing pass's operand copies (the epilogue in the operands), |u| per query, max |q| -- and, in the same
             // launch, the seeded thresholds
             const unsigned n_prep = bf16_prep_c_blocks(U, n_local, D, kPrepTrips);
+            if (prep_ready) {
+                // (the copies exist: the seeded thresholds alone, plus the block that reduces the prologue's item norms to max |q|)
+                k_tau_seed<D, KIND><<<(U + 7) / 8 + 1, 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
+                                                                       mask_bits, item_offset, K, seed_idx, ws.tau, ws.qpart, n_part, qmax_bits);
+                MACR_CHECK_LAUNCH("tau_seed", st);
+            } else {
             auto prep_seed = half ? k_prep_tau_seed<D, KIND, true> : k_prep_tau_seed<D, KIND, false>;
             prep_seed<<<n_prep + (U + 7) / 8, 256, 0, st>>>((int)n_prep, U, n_local, users_tab, user_ids, items, users_c,
                                                             ws.items_c, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev, mask_bits,
                                                             item_offset, K, seed_idx, ws.tau);
             MACR_CHECK_LAUNCH("bf16_prep+tau_seed", st);
+            }
+        } else if (filter_bf16 && prep_ready) {
+            // (the copies exist; the sampling pass below reduces the item norms)
         } else if (filter_bf16) {
             auto prep = half ? k_bf16_prep_c<D, KIND, true> : k_bf16_prep_c<D, KIND, false>;
             prep<<<bf16_prep_c_blocks(U, n_local, D, kPrepTripsAlone), 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
@@ -4342,7 +4427,8 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
             MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass0c), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
             pass0c<<<geo.grid0, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
-                                                  geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, nullptr, nullptr);
+                                                  geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, nullptr, nullptr,
+                                                  prep_ready ? ws.qpart : nullptr, n_part, qmax_bits);
             MACR_CHECK_LAUNCH("score_sample_b", st);
             launch_k_tau<false>((geo.slots0 * per_c + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev, D,
                                 merge_pairs ? 4 : 5, half ? 1 : 0, (half && KIND == MACR_SCORE_RUBI_BOTH) ? sig_u : nullptr);
@@ -4370,7 +4456,7 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
             MACR_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void *>(pass0c), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
             pass0c<<<geo.grid0, 512, smem_c, st>>>(U, n_local, ws.users_c, ws.items_c, sig_u, mask_bits, zero_word,
-                                                  geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, nullptr, nullptr);
+                                                  geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, nullptr, nullptr, nullptr, 0, nullptr);
             MACR_CHECK_LAUNCH("score_sample_b", st);
             launch_k_tau<false>((geo.slots0 * per_c + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws.maxima, nullptr, ws.tau, ws.unorm, qmax_bits, c, c_dev, D,
                                 merge_pairs ? 4 : 5, 1, KIND == MACR_SCORE_RUBI_BOTH ? sig_u : nullptr);
@@ -4443,7 +4529,8 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
                 MACR_REQUIRE(eb == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
                 if (seeded) {
                     pass0rb<<<geo.grid0, 512, smem_c0, st>>>(U, n_local, users_c, ws.items_c, sig_u, mask_bits, zero_word,
-                                                            geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, ws.ub_map, ws.overflow + 1);
+                                                            geo.ublocks, ws.maxima, sample_log2(n_local), merge_pairs, ws.ub_map, ws.overflow + 1,
+                                                            nullptr, 0, nullptr);
                     MACR_CHECK_LAUNCH("score_sample2", st);
                     launch_k_tau<true>((geo.slots0 * per_c + 63) / 64, sel_blocks, st, U, geo.slots0, K, ws.maxima, ws.blk_flag, ws.tau, ws.unorm, qmax_bits, c, c_dev, D,
                                        merge_pairs ? 4 : 5, half ? 1 : 0, (half && KIND == MACR_SCORE_RUBI_BOTH) ? sig_u : nullptr);
@@ -4568,6 +4655,40 @@ extern "C" int macr_score_topk_prologue(int filter, int U, int n_local, int d, i
                                                                    hp.set_tau, hp.n_max);
     });
     MACR_CHECK_LAUNCH("eval_prologue", st);
+    return MACR_OK;
+}
+
+// The same plus the fp16 filter's operand copies (abi 15): one launch reads every row once.  The ranking call that follows takes
+// MACR_EVAL_WS_READY | MACR_EVAL_PREP_READY with MACR_EVAL_FILTER_F16 and the same score_kind, c, tables.
+extern "C" int macr_score_topk_prologue_prep(int score_kind, int U, int n_local, int d, int K, int seeded_first_round,
+                                             const float *items, const float *w_item, float *sig_i,
+                                             const float *users_tab, const int32_t *user_ids, const float *w_user, float *sig_u,
+                                             float c, const float *c_dev, void *workspace, size_t workspace_bytes, void *stream) {
+    hipStream_t st = as_stream(stream);
+    MACR_REQUIRE(score_kind_valid(score_kind), MACR_E_INVALID, "score_topk_prologue_prep: score_kind=%d", score_kind);
+    MACR_REQUIRE(U > 0 && n_local > 0, MACR_E_INVALID, "score_topk_prologue_prep: U=%d n_local=%d", U, n_local);
+    MACR_REQUIRE(dim_supported(d), MACR_E_UNSUPPORTED, "score_topk_prologue_prep: d=%d not in {32,64,128,256}", d);
+    MACR_REQUIRE(K >= 1 && K <= MACR_MAX_TOPK_FUSED, MACR_E_UNSUPPORTED, "score_topk_prologue_prep: K=%d outside [1,%d] (the fused ranking)", K,
+                 MACR_MAX_TOPK_FUSED);
+    MACR_REQUIRE(items && w_item && sig_i && users_tab, MACR_E_INVALID, "score_topk_prologue_prep: null pointer (items, w_item, sig_i, users_tab)");
+    MACR_REQUIRE((sig_u == nullptr) == (w_user == nullptr), MACR_E_INVALID, "score_topk_prologue_prep: sig_u and w_user come together");
+    MACR_REQUIRE(!score_uses_sig_u(score_kind) || sig_u, MACR_E_INVALID, "score_topk_prologue_prep: score_kind %d needs sig_u / w_user", score_kind);
+    MACR_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, MACR_E_INVALID,
+                 "score_topk_prologue_prep: workspace is null or not 256-byte aligned");
+    const StreamGeo geo = stream_geo(U, n_local, d);
+    TopkWs ws = carve_topk_ws(workspace, U, n_local, geo, d);
+    MACR_REQUIRE(workspace_bytes >= ws.bytes, MACR_E_WORKSPACE, "score_topk_prologue_prep: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    const bool list_all = n_local <= kSelRegs * 64 && geo.range1 * kTileItems <= ws.cap;
+    MACR_REQUIRE(!list_all, MACR_E_UNSUPPORTED, "score_topk_prologue_prep: a catalogue this small lists everything -- no filter, no copies (use macr_score_topk_prologue)");
+    const WsHeadPlan hp = ws_head_plan(ws, geo, U, n_local, K, MACR_EVAL_FILTER_F16, seeded_first_round != 0);
+    MACR_DISPATCH_DK(d, score_kind, {
+        const unsigned n_prep = bf16_prep_c_blocks(U, n_local, D, kPrepTripsAlone);
+        k_eval_prologue_prep<D, KIND><<<n_prep + hp.grid, 256, 0, st>>>((int)n_prep, U, n_local, users_tab, user_ids, items, w_item, w_user, sig_i, sig_u,
+                                                                       c, c_dev, ws.users_c, ws.items_c, ws.unorm, ws.qpart,
+                                                                       static_cast<uint32_t *>(workspace), hp.n_zero, hp.n_tau, 0xff800000u,
+                                                                       hp.set_tau, hp.n_max);
+    });
+    MACR_CHECK_LAUNCH("eval_prologue_prep", st);
     return MACR_OK;
 }
 

@@ -55,6 +55,7 @@ class Evaluator(object):
         # replaces -- no gain under graph replay (profiles/r05_eval_fold_ab.txt), so off unless asked for.  "1": both, "0": none.
         fold = os.environ.get("MACR_EVAL_FOLD", "p").strip().lower()
         self.fold_prologue, self.fold_metrics = fold in ("1", "p"), fold in ("1", "m")
+        self.fold_prep = os.environ.get("MACR_EVAL_FOLD_PREP", "1") != "0"       # (A/B switch of macr_score_topk_prologue_prep)
         self._topk_mode = None                    # None: the complete call; "first" / "repair": its two halves
         self._repair_bufs = None
         self._last_entry = None
@@ -158,14 +159,21 @@ class Evaluator(object):
             # the ranking leaves its best SEED_WIDTH candidates per query in `seed` (in place): the next ranking's seeds
             mask = self._mask_local if self._local_own is not None else self.mask
             mode = self._topk_mode
-            if fold:
+            # under the fp16 filter the prologue also writes the listing pass's operand copies: every row read once (the tables are
+            # cold after a log interval of training) -- not for a catalogue small enough to list everything, which runs no filter
+            fold_prep = (fold and self.fold_prep and self.filter_now == "f16" and K <= _lib_consts.MAX_TOPK_FUSED
+                         and self._shape_uses_seeds(hi - lo, items_tab.shape[1]))
+            if fold_prep:
+                sig_i, sig_u = ops.score_topk_prologue_prep(kind, users_tab, user_ids, items_local, K, w, wu if both else None, c,
+                                                            seeded_first_round=seeded and mode == "first")
+            elif fold:
                 sig_i, sig_u = ops.score_topk_prologue(users_tab, user_ids, items_local, K, w, wu if both else None,
                                                        seeded_first_round=seeded and mode == "first", filter=self.filter_now)
             vals, idx = ops.score_topk(kind, users_tab, user_ids, items_local, K, sig_u, sig_i, c, mask, lo,
                                        seed=seed if seeded else None, seed_out=seed,
                                        stats=self._stats_first if mode else self._stats, first_round=mode == "first",
                                        repair_of=self._repair_bufs if mode == "repair" else None, filter=self.filter_now,
-                                       ws_ready=fold)
+                                       ws_ready=fold, prep_ready=fold_prep)
         else:
             # the ranking workspace (candidate lists, mask bitmap) grows with the number of queries: rank them in
             # chunks; every query is independent of the chunking

@@ -293,6 +293,7 @@ def _c_args(c):
 
 
 EVAL_WS_READY = 0x100
+EVAL_PREP_READY = 0x200
 
 
 def score_topk_prologue(users_tab, user_ids, items, K, w_item, w_user=None, seeded_first_round=False, filter=None):
@@ -314,9 +315,27 @@ def score_topk_prologue(users_tab, user_ids, items, K, w_item, w_user=None, seed
     return sig_i, sig_u
 
 
+def score_topk_prologue_prep(kind, users_tab, user_ids, items, K, w_item, w_user=None, c=0.0, seeded_first_round=False):
+    """score_topk_prologue AND the fp16 filter's operand copies in one launch (macr_score_topk_prologue_prep): every row is
+    read once.  For the score_topk call that follows with filter="f16", ws_ready=True, prep_ready=True and the same kind, c,
+    tables, K.  c: a float or a 1-element device tensor."""
+    U = users_tab.shape[0] if user_ids is None else user_ids.numel()
+    n_local, d = items.shape
+    sig_i = torch.empty(n_local, dtype=_f32, device=items.device)
+    sig_u = torch.empty(U, dtype=_f32, device=items.device) if w_user is not None else None
+    ws = _topk_workspace(U, n_local, d, items.device)
+    cv, cp = _c_args(c)
+    check(_lib.lib().macr_score_topk_prologue_prep(kind, U, n_local, d, K, int(bool(seeded_first_round)),
+                                                   _ptr(items, _f32), _ptr(w_item.reshape(-1), _f32), _ptr(sig_i),
+                                                   _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
+                                                   _ptr(w_user.reshape(-1), _f32) if w_user is not None else None, _ptr(sig_u, _f32, True),
+                                                   cv, cp, _ptr(ws), ws.numel(), _stream()))
+    return sig_i, sig_u
+
+
 def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.0, mask=None,
                item_offset=0, n_splits=0, seed=None, seed_out=None, stats=None, first_round=False, repair_of=None,
-               filter=None, ws_ready=False):
+               filter=None, ws_ready=False, prep_ready=False):
     """Fused U.I^T + epilogue + mask + top-K.  Returns (vals, idx) of shape (n_splits, U, K).
     c: python float, or a 1-element fp32 device tensor (read at run time: graph replays follow its value).
     seed: optional (U, SEED_WIDTH) int32 device tensor of global item ids per query -- what seed_out received last time:
@@ -330,7 +349,8 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     repair_of=(vals, idx, ws) -- macr_score_topk_repair_round on the same arguments, the first-round call's outputs AND the
     workspace it ran on (thresholds, overflow counters and candidate lists are where the first round left them; the
     per-device cache may have been regrown by another caller since) -- or run the complete call.
-    ws_ready: score_topk_prologue ran for this call (same stream, nothing of the ranking workspace touched in between)."""
+    ws_ready: score_topk_prologue ran for this call (same stream, nothing of the ranking workspace touched in between);
+    prep_ready: it was score_topk_prologue_prep (filter "f16": the operand copies are in the workspace too)."""
     U = users_tab.shape[0] if user_ids is None else user_ids.numel()
     n_local, d = items.shape
     if n_splits <= 0:
@@ -353,7 +373,9 @@ def score_topk(kind, users_tab, user_ids, items, K, sig_u=None, sig_i=None, c=0.
     if repair_of is not None:
         fn = _lib.lib().macr_score_topk_repair_round
     assert not (ws_ready and repair_of is not None)
-    check(fn(kind, _filter_arg(filter) | (EVAL_WS_READY if ws_ready else 0), U, n_local, d, _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
+    assert not prep_ready or ws_ready
+    check(fn(kind, _filter_arg(filter) | (EVAL_WS_READY if ws_ready else 0) | (EVAL_PREP_READY if prep_ready else 0), U, n_local, d,
+             _ptr(users_tab, _f32), _ptr(user_ids, _i32, True),
              _ptr(items, _f32), _ptr(sig_u, _f32, True), _ptr(sig_i, _f32, True),
              cv, cp, mp, mi, mb, item_offset, K, n_splits, _ptr(seed, _i32, True), _ptr(seed_out, _i32, True), _ptr(vals), _ptr(idx),
              _ptr_visible(stats, _i32, True), _ptr(ws), ws.numel(), _stream()))

@@ -1071,25 +1071,31 @@ def test_prologue_is_the_branch_sigmoids_and_the_workspace_initialisation(ops, e
     want_v, want_i = want_v.clone(), want_i.clone()
     stats = torch.full((2,), 77, dtype=torch.int32).pin_memory()
     use_seeds = K <= 32 and ops._lib.lib().macr_score_topk_uses_seeds(U, N, d)
-    for name, seed, first in (("complete", None, False), ("sampled first round", None, True), ("seeded first round", seeds.clone(), True)):
+    for name0, seed, first in (("complete", None, False), ("sampled first round", None, True), ("seeded first round", seeds.clone(), True)):
         if seed is not None and not use_seeds:
             continue
-        ops._topk_ws_cache[Qd.device].fill_(0xA5)                 # whatever was there before
-        gi, gu = ops.score_topk_prologue(Pd, uid, Qd, K, wd, wud, seeded_first_round=first and seed is not None, filter=eval_filter)
-        assert torch.equal(gi, sig_i) and torch.equal(gu, sig_u), name
-        stats.fill_(77)
-        v, ix = ops.score_topk(ops.SCORE_RUBI_BOTH, Pd, uid, Qd, K, gu, gi, 30.0, mcsr, seed=seed, seed_out=torch.empty_like(seeds),
-                               stats=stats, first_round=first, filter=eval_filter, ws_ready=True)
-        torch.cuda.synchronize()
-        if eval_filter == "f16" and stats.tolist()[0] != 0:
-            # (y - 30) sig_i sig_u on untrained rows packs the top of every query closer than the fp16 filter's margin at d = 128:
-            # lists overflow and query blocks are listed again -- the Evaluator then steps down to bf16.  Same ranking either way.
-            assert stats.tolist()[1] == 0, (name, stats.tolist())
-            if first:
-                continue                                        # (the first round says so itself: its rows are not the ranking)
-        else:
-            assert stats.tolist() == [0, 0], (name, stats.tolist())
-        assert torch.equal(ix, want_i) and torch.equal(v.view(torch.int32), want_v.view(torch.int32)), name
+        # (fused: macr_score_topk_prologue_prep -- the fp16 filter's operand copies written by the same launch, abi 15)
+        for fused in ((False, True) if (eval_filter == "f16" and use_seeds) else (False,)):
+            name = name0 + (" + prep" if fused else "")
+            ops._topk_ws_cache[Qd.device].fill_(0xA5)                 # whatever was there before
+            if fused:
+                gi, gu = ops.score_topk_prologue_prep(ops.SCORE_RUBI_BOTH, Pd, uid, Qd, K, wd, wud, 30.0, seeded_first_round=first and seed is not None)
+            else:
+                gi, gu = ops.score_topk_prologue(Pd, uid, Qd, K, wd, wud, seeded_first_round=first and seed is not None, filter=eval_filter)
+            assert torch.equal(gi, sig_i) and torch.equal(gu, sig_u), name
+            stats.fill_(77)
+            v, ix = ops.score_topk(ops.SCORE_RUBI_BOTH, Pd, uid, Qd, K, gu, gi, 30.0, mcsr, seed=seed, seed_out=torch.empty_like(seeds),
+                                   stats=stats, first_round=first, filter=eval_filter, ws_ready=True, prep_ready=fused)
+            torch.cuda.synchronize()
+            if eval_filter == "f16" and stats.tolist()[0] != 0:
+                # (y - 30) sig_i sig_u on untrained rows packs the top of every query closer than the fp16 filter's margin at d = 128:
+                # lists overflow and query blocks are listed again -- the Evaluator then steps down to bf16.  Same ranking either way.
+                assert stats.tolist()[1] == 0, (name, stats.tolist())
+                if first:
+                    continue                                        # (the first round says so itself: its rows are not the ranking)
+            else:
+                assert stats.tolist() == [0, 0], (name, stats.tolist())
+            assert torch.equal(ix, want_i) and torch.equal(v.view(torch.int32), want_v.view(torch.int32)), name
     # one-branch scores: no query factors
     gi, gu = ops.score_topk_prologue(Pd, uid, Qd, K, wd, None, filter=eval_filter)
     assert gu is None and torch.equal(gi, sig_i)
