@@ -2725,13 +2725,22 @@ __device__ __forceinline__ void tau_seed_block(int blk, int U, int n_local, cons
                                                const float *__restrict__ sig_u, const float *__restrict__ sig_i,
                                                float c_val, const float *__restrict__ c_dev,
                                                const uint32_t *__restrict__ mask_bits, int item_offset, int K,
-                                               const int32_t *__restrict__ seed, float *__restrict__ tau) {
+                                               const int32_t *__restrict__ seed, float *__restrict__ tau,
+                                               const int32_t *__restrict__ mask_ptr = nullptr, const int32_t *__restrict__ mask_idx = nullptr) {
     const float c = c_dev ? *c_dev : c_val;
     const int q = blk * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     if (q >= U) return;                                   // whole 32-lane halves leave together
     const int it = seed[(size_t)q * kSeedWidth + l] - item_offset;
     bool ok = it >= 0 && it < n_local;
-    if (ok && mask_bits) ok = ((mask_bits[(size_t)(it >> 5) * U + q] >> (it & 31)) & 1u) == 0u;    // a masked item is no candidate
+    if (ok && mask_ptr) {
+        // a masked item is no candidate.  Looked up in the query's ascending train list (a few lines the 32 lanes of the half
+        // share) rather than in the (tile, query) bitmap: one word per seed of a 79 MB array at the Gowalla shape -- 32 cold
+        // lines per query after a log interval of training, where the list is one to four
+        const int gid = it + item_offset;
+        int lo = mask_ptr[q], hi = mask_ptr[q + 1];
+        while (lo < hi) { const int mid = (lo + hi) >> 1; const int v = mask_idx[mid]; if (v < gid) lo = mid + 1; else hi = mid; }
+        ok = !(lo < mask_ptr[q + 1] && mask_idx[lo] == gid);
+    } else if (ok && mask_bits) ok = ((mask_bits[(size_t)(it >> 5) * U + q] >> (it & 31)) & 1u) == 0u;
     float v = -INFINITY;
     if (ok) {
         const float *ur = users_tab + (size_t)(user_ids ? user_ids[q] : q) * D, *ir = items + (size_t)it * D;
@@ -2781,10 +2790,12 @@ __global__ __launch_bounds__(256) void k_tau_seed(int U, int n_local, const floa
                                                   float c_val, const float *__restrict__ c_dev,
                                                   const uint32_t *__restrict__ mask_bits, int item_offset, int K,
                                                   const int32_t *__restrict__ seed, float *__restrict__ tau,
-                                                  const float *__restrict__ qpart = nullptr, int n_part = 0, uint32_t *__restrict__ qmax_bits = nullptr) {
+                                                  const float *__restrict__ qpart = nullptr, int n_part = 0, uint32_t *__restrict__ qmax_bits = nullptr,
+                                                  const int32_t *__restrict__ mask_ptr = nullptr, const int32_t *__restrict__ mask_idx = nullptr) {
     // (after k_eval_prologue_prep: one extra block turns its per-block item norms into max |q| for the listing pass)
     if (qpart && blockIdx.x == gridDim.x - 1) { qmax_from_parts(qpart, n_part, qmax_bits); return; }
-    tau_seed_block<D, KIND>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_val, c_dev, mask_bits, item_offset, K, seed, tau);
+    tau_seed_block<D, KIND>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_val, c_dev, mask_bits, item_offset, K, seed, tau,
+                            mask_ptr, mask_idx);
 }
 
 // Seeded ranking under the bf16 filter: the operand copies and the seeded thresholds do not depend on each other -- two
@@ -2797,13 +2808,14 @@ __global__ __launch_bounds__(256) void k_prep_tau_seed(int n_prep, int U, int n_
                                                        const float *__restrict__ sig_u, const float *__restrict__ sig_i,
                                                        float c_val, const float *__restrict__ c_dev,
                                                        const uint32_t *__restrict__ mask_bits, int item_offset, int K,
-                                                       const int32_t *__restrict__ seed, float *__restrict__ tau) {
+                                                       const int32_t *__restrict__ seed, float *__restrict__ tau,
+                                                       const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_idx) {
     if ((int)blockIdx.x < n_prep)
         bf16_prep_c_block<D, KIND, kPrepTrips, HALF>(blockIdx.x, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_dev ? *c_dev : c_val, users_bf,
                                                      items_bf, unorm, qmax_bits);
     else
         tau_seed_block<D, KIND>(blockIdx.x - n_prep, U, n_local, users_tab, user_ids, items, sig_u, sig_i, c_val, c_dev, mask_bits,
-                                item_offset, K, seed, tau);
+                                item_offset, K, seed, tau, mask_ptr, mask_idx);
 }
 
 // ----------------------------------------------------------------------------
@@ -4404,13 +4416,14 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
             if (prep_ready) {
                 // (the copies exist: the seeded thresholds alone, plus the block that reduces the prologue's item norms to max |q|)
                 k_tau_seed<D, KIND><<<(U + 7) / 8 + 1, 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
-                                                                       mask_bits, item_offset, K, seed_idx, ws.tau, ws.qpart, n_part, qmax_bits);
+                                                                       mask_bits, item_offset, K, seed_idx, ws.tau, ws.qpart, n_part, qmax_bits,
+                                                                       mask_ptr, mask_idx);
                 MACR_CHECK_LAUNCH("tau_seed", st);
             } else {
             auto prep_seed = half ? k_prep_tau_seed<D, KIND, true> : k_prep_tau_seed<D, KIND, false>;
             prep_seed<<<n_prep + (U + 7) / 8, 256, 0, st>>>((int)n_prep, U, n_local, users_tab, user_ids, items, users_c,
                                                             ws.items_c, ws.unorm, qmax_bits, sig_u, sig_i, c, c_dev, mask_bits,
-                                                            item_offset, K, seed_idx, ws.tau);
+                                                            item_offset, K, seed_idx, ws.tau, mask_ptr, mask_idx);
             MACR_CHECK_LAUNCH("bf16_prep+tau_seed", st);
             }
         } else if (filter_bf16 && prep_ready) {
@@ -4438,7 +4451,7 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
         } else if (seeded) {
             // thresholds from the exact scores of the caller's seed items (its previous top K): no sampling pass, no k_tau
             k_tau_seed<D, KIND><<<(U + 7) / 8, 256, 0, st>>>(U, n_local, users_tab, user_ids, items, sig_u, sig_i, c, c_dev,
-                                                               mask_bits, item_offset, K, seed_idx, ws.tau);
+                                                               mask_bits, item_offset, K, seed_idx, ws.tau, nullptr, 0, nullptr, mask_ptr, mask_idx);
             MACR_CHECK_LAUNCH("tau_seed", st);
         } else if (!list_all && f32_sample_bf16) {
             // fp32 listing, thresholds from the reduced-precision sampling pass (round 6).  k_tau's threshold under that pass is already
