@@ -1752,16 +1752,23 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_c(
         const uint32_t tailm = valid < kTileItems ? ~0u << (valid > 0 ? valid : 0) : 0u;
         const uint32_t tmh = (tm_cur | tailm) >> (4 * h);      // bit (r & 3) + 8 (r >> 2): this lane's row of slot r is masked / past the end
         const int id0 = t * kTileItems + id_lane;
+        // (a row quad is tested together first -- v_max3 + v_max, one compare + branch -- and looked at score by score only where
+        // some lane passes: k_score_stream_h's epilogue, measured there; 2/3 of the quads under sampled thresholds, 1/6 under seeded)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool above = acc[r] >= thr;
-            if (__builtin_amdgcn_ballot_w64(above)) {          // wave-uniform: some lane's score r passes
-                const int rbit = (r & 3) + 8 * (r >> 2);
-                uint32_t m = tmh;
-                asm volatile("" : "+v"(m));                    // (the mask test belongs in here, not in front of the branch)
-                if (above && !((m >> rbit) & 1u)) {
-                    const uint32_t pos = atomicAdd(my_cnt, 1u);        // (keeps counting past cap: the segment's end flags it)
-                    if (pos < (uint32_t)cap) my_list[pos] = make_key(acc[r] * fu, id0 + rbit);
+        for (int r4 = 0; r4 < 16; r4 += 4) {
+            const float quad = fmaxf(fmaxf(fmaxf(acc[r4], acc[r4 + 1]), acc[r4 + 2]), acc[r4 + 3]);
+            if (!__builtin_amdgcn_ballot_w64(quad >= thr)) continue;
+#pragma unroll
+            for (int r = r4; r < r4 + 4; ++r) {
+                const bool above = acc[r] >= thr;
+                if (__builtin_amdgcn_ballot_w64(above)) {      // wave-uniform: some lane's score r passes
+                    const int rbit = (r & 3) + 8 * (r >> 2);
+                    uint32_t m = tmh;
+                    asm volatile("" : "+v"(m));                // (the mask test belongs in here, not in front of the branch)
+                    if (above && !((m >> rbit) & 1u)) {
+                        const uint32_t pos = atomicAdd(my_cnt, 1u);    // (keeps counting past cap: the segment's end flags it)
+                        if (pos < (uint32_t)cap) my_list[pos] = make_key(acc[r] * fu, id0 + rbit);
+                    }
                 }
             }
         }
