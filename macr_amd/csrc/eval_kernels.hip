@@ -2061,7 +2061,10 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
 // sampled thresholds, 145-148 under seeded ones (k_score_stream_c: 247 / 228); by ablation (-DMACR_ABL_H_*): without the
 // epilogue 97 us, without epilogue and MFMAs 82 us, without the barrier no change -- the skeleton of a step (two tiles from
 // global memory through registers into LDS, five fragment reads per wave, the visit arithmetic) is most of the pass, the 10
-// MFMAs of a wave's step hide under it, and the epilogue is the rest.  The matrix cores alone would need 46 us.
+// MFMAs of a wave's step hide under it, and the epilogue is the rest.  The matrix cores alone would need 46 us.  The skeleton is
+// a latency chain per step (load -> wait -> ds_write -> barrier -> fragment reads -> wait), two blocks per CU to overlap it:
+// with epilogue, MFMAs and mask loads compiled out it takes 76-81 us, 77 with every tile load forced to hit the cache
+// (-DMACR_ABL_H_SAMETILE: not a memory bound), 70-74 without the barrier as well.
 // ----------------------------------------------------------------------------
 template <int D, int KIND, bool REPAIR = false>
 __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
@@ -2166,9 +2169,13 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
             stg[k] = items_h[(size_t)(second ? tbu : tau_) * TU + (second ? e - TU : e)];
         }
         const int mine = tslot ? tbu : tau_;
+#ifndef MACR_ABL_H_NOMASK
         const uint32_t *mrow = (mask_bits ? mask_bits : zero_word) + (size_t)mine * mask_stride;
         tm_next[0] = mrow[my_q[0]];
         tm_next[1] = mrow[my_q[1]];
+#else
+        tm_next[0] = zero_word[mine & 0]; tm_next[1] = tm_next[0];
+#endif
     };
     auto store_step = [&](auto BUF) {
         constexpr int buf = decltype(BUF)::value;
