@@ -1409,13 +1409,23 @@ struct StreamCfgH1 {                                           // one tile per v
     static constexpr int LDU = (TU + 511) / 512, REM = TU - 512 * (LDU - 1);
     static constexpr size_t smem = (size_t)2 * TU * 16 + kUsersPerBlock * 4 + 16;
 };
+// Tiles per step of k_score_stream_h (= 4-wave groups of its block).  1 (default): a block is FOUR waves, 256 queries x one tile
+// per step, four blocks per CU; 2: eight waves, the two halves on two tiles of one step, two blocks per CU.  A step is a latency
+// chain (load -> wait -> ds_write -> barrier -> fragment reads -> wait) and four independent chains per CU hide it better than two:
+// listing pass 167 -> 134 us sampled, 145 -> 123 seeded on the Gowalla shape (-DMACR_H_TPS=2 for the A/B; profiles/r06_eval_f16_filter.txt).
+// The price: twice the blocks, shorter tile ranges, 18 result slots per query instead of 10 (k_select_b +2-4 us).
+#ifndef MACR_H_TPS
+#define MACR_H_TPS 1
+#endif
+constexpr int kHTiles = MACR_H_TPS;
 template <int D>
-struct StreamCfgH {                                            // two tiles per step (k_score_stream_h)
+struct StreamCfgH {                                            // kHTiles tiles per step (k_score_stream_h)
     static constexpr int RU = D / 8 + 1;
     static constexpr int TU = kTileItems * RU;
     static constexpr int NS = D / 16;
-    static constexpr int SU = 2 * TU;                          // units staged per step
-    static constexpr int LDU = (SU + 511) / 512, REM = SU - 512 * (LDU - 1);
+    static constexpr int THREADS = 256 * kHTiles;
+    static constexpr int SU = kHTiles * TU;                    // units staged per step
+    static constexpr int LDU = (SU + THREADS - 1) / THREADS;
     static constexpr size_t smem = (size_t)2 * SU * 16 + kUsersPerBlock * 4 + 16;
 };
 // eight fp16 numbers per operand register group, carried in the bf16 vector type of the surrounding code
@@ -2053,12 +2063,13 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
 // and repair layout as k_score_stream_c (a block = one 256-query block x a scattered range of item tiles), but with one
 // MFMA per 16 k the matrix cores are no longer what a visit costs -- the LDS reads of the item fragments and the barrier
 // are -- so a wave keeps TWO 32-query groups in registers (64 queries; B operands 2 x D/2 bytes per lane) and every item
-// fragment it reads serves two MFMAs; the block's eight waves then cover the 256 queries twice, and the two halves take
-// two DIFFERENT tiles of one step (waves 0-3 the first, 4-7 the second): two tiles staged per barrier, each tile's
-// fragments read by four waves instead of eight.  LDS reads per 32 x 32 products: a quarter of k_score_stream_c's in
-// count, an eighth in bytes.  The two waves that share a query append to her list through the same LDS counter.
-// Measured on the Gowalla shape (15 424 queries x 40 981 items, d = 64; profiles/r06_eval_f16_filter.txt): 165-172 us under
-// sampled thresholds, 145-148 under seeded ones (k_score_stream_c: 247 / 228); by ablation (-DMACR_ABL_H_*): without the
+// fragment it reads serves two MFMAs: four waves cover the 256 queries of a block, each tile's fragments are read by four
+// waves instead of eight -- LDS reads per 32 x 32 products: a quarter of k_score_stream_c's in count, an eighth in bytes.
+// A block is those four waves and one tile per step (kHTiles = 1, four blocks per CU); with kHTiles = 2 it is eight waves
+// whose halves take two DIFFERENT tiles of one step (two tiles staged per barrier; the two waves that share a query append
+// to her list through the same LDS counter) -- the first form built, 20 % slower: see kHTiles.
+// Measured on the Gowalla shape (15 424 queries x 40 981 items, d = 64; profiles/r06_eval_f16_filter.txt): 134 us under
+// sampled thresholds, 123 under seeded ones (k_score_stream_c: 247 / 228).  With kHTiles = 2 (165-172 / 145-148), by ablation (-DMACR_ABL_H_*): without the
 // epilogue 97 us, without epilogue and MFMAs 82 us, without the barrier no change -- the skeleton of a step (two tiles from
 // global memory through registers into LDS, five fragment reads per wave, the visit arithmetic) is most of the pass, the 10
 // MFMAs of a wave's step hide under it, and the epilogue is the rest.  The matrix cores alone would need 46 us.  The skeleton is
@@ -2067,7 +2078,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_sample_c(
 // (-DMACR_ABL_H_SAMETILE: not a memory bound), 70-74 without the barrier as well.
 // ----------------------------------------------------------------------------
 template <int D, int KIND, bool REPAIR = false>
-__global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
+__global__ __launch_bounds__(StreamCfgH<D>::THREADS, D <= 64 ? 4 : 2) void k_score_stream_h(
     int U, int n_local, const uint4 *__restrict__ users_h, const uint4 *__restrict__ items_h,
     const float *__restrict__ unorm, const uint32_t *__restrict__ qmax_bits,
     const float *__restrict__ sig_u, float c_val, const float *__restrict__ c_dev,
@@ -2075,7 +2086,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
     const float *__restrict__ tau, uint64_t *__restrict__ lists, int32_t *__restrict__ counts, int cap, int32_t *overflow,
     int ovf_per_user, int32_t *blk_flag, const int32_t *__restrict__ ub_map, const int32_t *__restrict__ n_ub_dev, int slots_full) {
     using C = StreamCfgH<D>;
-    constexpr int THREADS = 512, NS = C::NS, RU = C::RU, TU = C::TU, SU = C::SU, LDU = C::LDU;
+    constexpr int THREADS = C::THREADS, NS = C::NS, RU = C::RU, TU = C::TU, SU = C::SU, LDU = C::LDU;
     constexpr int kCheckTiles = 8;
     const float c = c_dev ? *c_dev : c_val;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2084,7 +2095,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
     int *s_stop = reinterpret_cast<int *>(s_cnt + kUsersPerBlock);                     // [1]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int tslot = __builtin_amdgcn_readfirstlane(wid >> 2), uw = wid & 3;          // this wave's tile of a step; its 64 queries
+    const int tslot = kHTiles == 2 ? __builtin_amdgcn_readfirstlane(wid >> 2) : 0, uw = wid & 3;      // this wave's tile of a step; its 64 queries
     const int T = (n_local + kTileItems - 1) / kTileItems;
     int n_ub = ublocks;
     long long G = gridDim.x;
@@ -2165,7 +2176,7 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
         for (int k = 0; k < LDU; ++k) {
             int e = tid + THREADS * k;
             if (k + 1 == LDU && e >= SU) e -= SU;              // (the wrapped loads of the last round: any valid unit)
-            const bool second = e >= TU;
+            const bool second = kHTiles == 2 && e >= TU;
             stg[k] = items_h[(size_t)(second ? tbu : tau_) * TU + (second ? e - TU : e)];
         }
         const int mine = tslot ? tbu : tau_;
@@ -2294,38 +2305,40 @@ __global__ __launch_bounds__(512, D <= 64 ? 4 : 2) void k_score_stream_h(
 
     // steps of two tiles: (ta, tb) = (visit(vi), visit(vi + 1)); an odd range ends with a step whose second tile is none
     int vi = i0;
-    int ta = visit(i0), tb = vi + 1 < i1 ? visit_after(ta) : -1;
+    auto second_of = [&](int first_tile, int v) { return (kHTiles == 2 && v + 1 < i1) ? visit_after(first_tile) : -1; };
+    auto first_after = [&](int a_, int b_, int v) { return v + kHTiles < i1 ? visit_after(b_ < 0 ? a_ : b_) : a_; };
+    int ta = visit(i0), tb = second_of(ta, vi);
     if (vi < i1) { load_step(ta, tb < 0 ? ta : tb); store_step(std::integral_constant<int, 0>()); }
     uint32_t tm0 = tm_next[0], tm1 = tm_next[1];
     __syncthreads();
     while (vi < i1) {
         {
-            const int na = vi + 2 < i1 ? visit_after(tb) : ta, nb = vi + 3 < i1 ? visit_after(na) : -1;
+            const int na = first_after(ta, tb, vi), nb = second_of(na, vi + kHTiles);
             load_step(na, nb < 0 ? na : nb);
             __builtin_amdgcn_sched_barrier(0);
             one_step(std::integral_constant<int, 0>(), tslot ? tb : ta, tm0, tm1);
-            const int done = min(vi + 2, i1) - i0;
+            const int done = min(vi + kHTiles, i1) - i0;
             const bool looked = stale_mark(vi - i0, done);
             store_step(std::integral_constant<int, 1>());
 #ifndef MACR_ABL_H_NOBARRIER
             __syncthreads();
 #endif
-            tm0 = tm_next[0]; tm1 = tm_next[1]; ta = na; tb = nb; vi += 2;
+            tm0 = tm_next[0]; tm1 = tm_next[1]; ta = na; tb = nb; vi += kHTiles;
             if (stale_read(looked)) break;
         }
         if (vi >= i1) break;
         {
-            const int na = vi + 2 < i1 ? visit_after(tb) : ta, nb = vi + 3 < i1 ? visit_after(na) : -1;
+            const int na = first_after(ta, tb, vi), nb = second_of(na, vi + kHTiles);
             load_step(na, nb < 0 ? na : nb);
             __builtin_amdgcn_sched_barrier(0);
             one_step(std::integral_constant<int, 1>(), tslot ? tb : ta, tm0, tm1);
-            const int done = min(vi + 2, i1) - i0;
+            const int done = min(vi + kHTiles, i1) - i0;
             const bool looked = stale_mark(vi - i0, done);
             store_step(std::integral_constant<int, 0>());
 #ifndef MACR_ABL_H_NOBARRIER
             __syncthreads();
 #endif
-            tm0 = tm_next[0]; tm1 = tm_next[1]; ta = na; tb = nb; vi += 2;
+            tm0 = tm_next[0]; tm1 = tm_next[1]; ta = na; tb = nb; vi += kHTiles;
             if (stale_read(looked)) break;
         }
     }
@@ -4101,7 +4114,7 @@ extern "C" void macr_dbg_counters(unsigned long long *out) {
 namespace macr {
 // Launch geometry of the two streaming passes (see k_score_stream): grid sizes and the number of result slots a
 // user block can have (= blocks overlapping its tile range).
-struct StreamGeo { int ublocks, grid0, slots0, grid1, slots1, range1; };   // range1: longest tile range of pass 1
+struct StreamGeo { int ublocks, grid0, slots0, grid1, slots1, range1, grid_h; };   // range1: longest tile range of pass 1; grid_h: k_score_stream_h's blocks
 static StreamGeo stream_geo(int U, int n_local, int d) {
     StreamGeo g;
     g.ublocks = (U + kUsersPerBlock - 1) / kUsersPerBlock;
@@ -4120,6 +4133,17 @@ static StreamGeo stream_geo(int U, int n_local, int d) {
     plan(T0, g.grid0, g.slots0);
     plan(T1, g.grid1, g.slots1);
     g.range1 = (int)(((long long)g.ublocks * T1 + g.grid1 - 1) / g.grid1);
+    g.grid_h = g.grid1;
+    if (kHTiles == 1) {                                       // 4-wave blocks: twice as many of them resident, shorter ranges, more result slots
+        const long long W = (long long)g.ublocks * T1;
+        long long G = 2LL * resident;
+        if (G > W / 8) G = W / 8;
+        if (G > (long long)g.ublocks * 60) G = (long long)g.ublocks * 60;
+        if (G < 1) G = 1;
+        const long long chunk = W / G;
+        g.grid_h = (int)G;
+        g.slots1 = std::max(g.slots1, (int)((T1 + chunk - 1) / chunk + 1));
+    }
     return g;
 }
 
@@ -4506,7 +4530,7 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
             MACR_REQUIRE(hipFuncSetAttribute(pass1c, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)smem_c) == hipSuccess, MACR_E_LAUNCH, "score_topk: cannot reserve %zu B of LDS", smem_c);
             if (half)
-                k_score_stream_h<D, KIND><<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
+                k_score_stream_h<D, KIND><<<geo.grid_h, StreamCfgH<D>::THREADS, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
                                                                        mask_bits, zero_word, item_offset, geo.ublocks,
                                                                        ws.tau, ws.lists, ws.counts, ws.cap,
                                                                        repair ? ws.user_ovf : ws.overflow, repair ? 1 : 0,
@@ -4564,7 +4588,7 @@ static int score_topk_impl(int mode, int filter, int score_kind, int U, int n_lo
                     MACR_CHECK_LAUNCH("tau2", st);
                 }
                 if (half)
-                    k_score_stream_h<D, KIND, true><<<geo.grid1, 512, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
+                    k_score_stream_h<D, KIND, true><<<geo.grid_h, StreamCfgH<D>::THREADS, smem_c, st>>>(U, n_local, users_c, ws.items_c, ws.unorm, qmax_bits, sig_u, c, c_dev,
                                                                                 mask_bits, zero_word, item_offset, geo.ublocks, ws.tau,
                                                                                 ws.lists, ws.counts, ws.cap, ws.overflow, 0, nullptr,
                                                                                 ws.ub_map, ws.overflow + 1, geo.slots1);
