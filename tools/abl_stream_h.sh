@@ -5,11 +5,11 @@
 # (profiles/r06_eval_f16_filter.txt holds the round-6 numbers)
 C=/root/repo/macr_amd/csrc; L=$C/_abl; mkdir -p $L
 for v in "$@"; do
-  defs=""; [ "$v" != "NONE" ] && for a in ${v//+/ }; do defs="$defs -DMACR_ABL_H_$a"; done
+  defs=""; [ "$v" != "NONE" ] && for a in ${v//+/ }; do if [ "$a" = "TPS2" ]; then defs="$defs -DMACR_H_TPS=2"; else defs="$defs -DMACR_ABL_H_$a"; fi; done
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-function -DMACR_DEV_FAST $defs -c $C/eval_kernels.hip -o $L/eval_h_$v.o &&
     hipcc --offload-arch=gfx950 -shared -fPIC -o $L/libmacr_hip_h_$v.so $C/_obj/capi_common.o $C/_obj/train_kernels.o $C/_obj/spmm_kernels.o $C/_obj/sample_kernels.o $L/eval_h_$v.o ) &
 done; wait
 args=()
 for v in "$@"; do args+=("MACR_EVAL_FILTER=f16 MACR_HIP_LIB=$L/libmacr_hip_h_$v.so"); done
 bash tools/ab_eval.sh gpurun_out/ab_eval_h_abl.txt "${args[@]}" > /dev/null 2>&1
-grep -o "libmacr_hip_h_[A-Za-z+]*.so\|FAILED.*\|seeded (listing [0-9.]*\|score_stream_b [0-9.]*" gpurun_out/ab_eval_h_abl.txt | paste - - -
+grep -o "libmacr_hip_h_[A-Za-z0-9+]*.so *[0-9.]* M users/s\|FAILED.*\|seeded (listing [0-9.]*\|score_stream_b [0-9.]*" gpurun_out/ab_eval_h_abl.txt | paste - - -
