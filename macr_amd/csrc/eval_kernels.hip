@@ -3060,20 +3060,25 @@ __global__ __launch_bounds__(64 * kSelWaves) void k_select(int U, int n_splits, 
 template <int NREG>
 __device__ __forceinline__ uint64_t gather_top64(int q, int lane, int U, int n_splits, int cap, int n, int incl,
                                                  const uint64_t *__restrict__ lists, uint64_t *s_top, bool sorted = true) {
-    size_t rel[NREG];
+    // candidate i of the query sits in the list of split s_i = #{s >= 1 : incl[s - 1] <= i} at position i - incl[s_i - 1]: the
+    // splits are counted (one compare per split and register -- with 18 result slots per query the 64-bit address
+    // selects this loop used to carry were a tenth of the kernel) and the offset fetched once, by lane
+    int sj[NREG];
 #pragma unroll
-    for (int j = 0; j < NREG; ++j) rel[j] = (size_t)q * cap + (j * 64 + lane);
+    for (int j = 0; j < NREG; ++j) sj[j] = 0;
     for (int s = 1; s < n_splits; ++s) {
         const int off = __builtin_amdgcn_readlane(incl, s - 1);
         if (off >= n) break;
-        const size_t base = ((size_t)s * U + q) * cap - off;
 #pragma unroll
-        for (int j = 0; j < NREG; ++j)
-            if (j * 64 + lane >= off) rel[j] = base + (j * 64 + lane);
+        for (int j = 0; j < NREG; ++j) sj[j] += (j * 64 + lane >= off) ? 1 : 0;
     }
     uint64_t key[NREG];
 #pragma unroll
-    for (int j = 0; j < NREG; ++j) key[j] = j * 64 + lane < n ? lists[rel[j]] : 0ull;
+    for (int j = 0; j < NREG; ++j) {
+        const int before = __shfl(incl, sj[j] > 0 ? sj[j] - 1 : 0, kWave);       // (every lane takes part in the exchange)
+        const size_t rel = ((size_t)sj[j] * U + q) * cap + (size_t)(j * 64 + lane - (sj[j] > 0 ? before : 0));
+        key[j] = j * 64 + lane < n ? lists[rel] : 0ull;
+    }
     uint64_t kth = 0ull;
     if (n > 64) {                                                   // the 64th largest of the n keys (distinct: ids differ)
         uint64_t cand[NREG];
