@@ -98,3 +98,22 @@ def test_reference_evaluator_abi_is_exported_with_its_own_names():
     # argument validation is checkable without a GPU: a failed call reports through the status channel
     L.c_top_k_array_index(None, 5, 2, 3, 1, None)
     assert L.macr_eval_compat_status() == _lib.E_INVALID and b"bad argument" in L.macr_eval_compat_error()
+
+
+def test_filter_constants_agree_across_header_bindings_evaluator_and_bench():
+    """MACR_EVAL_FILTER_* (include/macr_hip.h) = macr_amd/ops.py's table; the Evaluator's default filter is the one bench.py times
+    as `eval_users_per_s`; the readiness flags are the header's."""
+    import importlib.util
+    from macr_amd import ops
+    src = open(os.path.join(REPO, "include", "macr_hip.h")).read()
+    consts = dict(re.findall(r"#define (MACR_EVAL_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)", src))
+    assert int(consts["MACR_EVAL_FILTER_F32"], 0) == ops.EVAL_FILTER_F32 and int(consts["MACR_EVAL_FILTER_BF16"], 0) == ops.EVAL_FILTER_BF16
+    assert int(consts["MACR_EVAL_FILTER_F16"], 0) == ops.EVAL_FILTER_F16 == ops.eval_filter_code("f16")
+    assert int(consts["MACR_EVAL_WS_READY"], 0) == ops.EVAL_WS_READY and int(consts["MACR_EVAL_PREP_READY"], 0) == ops.EVAL_PREP_READY
+    with pytest.raises(Exception):
+        ops.eval_filter_code("fp16")                  # a typo is refused by name
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    ev_src = open(os.path.join(REPO, "macr_amd", "evaluator.py")).read()
+    default = re.search(r'os\.environ\.get\("MACR_EVAL_FILTER", "([a-z0-9]+)"\)', ev_src).group(1)
+    bench_src = open(spec.origin).read()
+    assert re.search(r'DEFAULT_EVAL_FILTER = "%s"' % default, bench_src), default
